@@ -1,0 +1,106 @@
+"""Deterministic synthetic read sets.
+
+Counter-based (splitmix64) so that the numpy version here, the C version in
+``oracle/mcom_oracle.c`` (``mcomo_synth_reads``) and the HIP kernel ``mcom_synth_reads``
+(minicom_amd/csrc/synth.hip) produce byte-identical reads for the same
+(seed, n_reads, read_len, coverage) without sharing state:
+
+  genome length G = max(n*L/coverage, L+1); base g        = key(0, g) & 3
+  read r:  start = key(1, r) % (G - L + 1);  strand       = key(2, r) & 1
+           base i substituted when (key(3, r*L+i) & 0xFFFFFF) < sub_rate*2^24,
+           new base = (old + 1 + ((key >> 24) % 3)) & 3
+           strand 1 -> reverse complement
+  "plumbing" extras (only when plumbing=True), c = key(4, r) % 10000:
+           c < 100  -> 1..3 bases replaced by 'N';  100 <= c < 105 -> poly-A with <=3 other bases
+           105 <= c < 110 -> poly-T likewise;  c == 110 -> all 'N';  c == 111 -> all 'A'; c == 112 -> all 'T'
+           113 <= c < 118 -> more than 0.4*L bases replaced by 'N'
+  key(s, i) = sm64(sm64(seed + s) + i)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def sm64(z: np.ndarray) -> np.ndarray:
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def key(seed: int, stream: int, idx) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        base = sm64(np.uint64((seed + stream) & 0xFFFFFFFFFFFFFFFF))
+        return sm64(base + np.asarray(idx, dtype=np.uint64))
+
+
+def genome_len(n_reads: int, read_len: int, coverage: int = 30) -> int:
+    return max(n_reads * read_len // coverage, read_len + 1)
+
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def synth_reads(seed: int, n_reads: int, read_len: int, coverage: int = 30,
+                sub_rate: float = 0.005, plumbing: bool = False,
+                first: int = 0, count: int | None = None) -> np.ndarray:
+    """Return reads [count, read_len] as uint8 ASCII (rows ``first .. first+count`` of the set)."""
+    L = read_len
+    if count is None:
+        count = n_reads - first
+    G = genome_len(n_reads, L, coverage)
+    r = np.arange(first, first + count, dtype=np.uint64)
+    start = key(seed, 1, r) % np.uint64(G - L + 1)
+    strand = (key(seed, 2, r) & np.uint64(1)).astype(bool)
+    pos = start[:, None] + np.arange(L, dtype=np.uint64)[None, :]
+    base = (key(seed, 0, pos) & np.uint64(3)).astype(np.uint8)
+    u = key(seed, 3, r[:, None] * np.uint64(L) + np.arange(L, dtype=np.uint64)[None, :])
+    thr = np.uint64(int(sub_rate * (1 << 24)))
+    sub = (u & np.uint64(0xFFFFFF)) < thr
+    nb = (base + np.uint8(1) + ((u >> np.uint64(24)) % np.uint64(3)).astype(np.uint8)) & np.uint8(3)
+    base = np.where(sub, nb, base)
+    rc = (np.uint8(3) - base)[:, ::-1]
+    base = np.where(strand[:, None], rc, base)
+    out = ACGT[base]
+    if plumbing:
+        c = (key(seed, 4, r) % np.uint64(10000)).astype(np.int64)
+        for j in np.nonzero(c < 118)[0]:
+            cj = int(c[j])
+            rr = int(r[j])
+            h = [int(x) for x in key(seed, 5, np.arange(rr * 8, rr * 8 + 8, dtype=np.uint64))]
+            if cj < 100:
+                for t in range(1 + h[0] % 3):
+                    out[j, h[1 + t] % L] = ord("N")
+            elif cj < 110:
+                ch = ord("A") if cj < 105 else ord("T")
+                keep = [(h[1 + t] % L, out[j, h[1 + t] % L]) for t in range(h[0] % 4)]
+                out[j, :] = ch
+                for p, b in keep:
+                    out[j, p] = b
+            elif cj == 110:
+                out[j, :] = ord("N")
+            elif cj == 111:
+                out[j, :] = ord("A")
+            elif cj == 112:
+                out[j, :] = ord("T")
+            else:
+                nN = int(0.4 * L) + 1 + h[0] % 5
+                idx = key(seed, 6, np.arange(rr * 512, rr * 512 + nN, dtype=np.uint64)) % np.uint64(L)
+                out[j, idx.astype(np.int64)] = ord("N")
+    return np.ascontiguousarray(out)
+
+
+def write_fastq(path: str, reads: np.ndarray) -> None:
+    n, L = reads.shape
+    qual = b"I" * L
+    with open(path, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n" % i)
+            f.write(reads[i].tobytes())
+            f.write(b"\n+\n")
+            f.write(qual)
+            f.write(b"\n")

@@ -1,0 +1,60 @@
+#!/bin/bash
+# Builds the reference minicom (read-only sources under /root/reference/src) into oracle/_ref/.
+# TEST INFRASTRUCTURE ONLY.  Nothing is copied from the reference: sources are compiled where they lie.
+# The reference's own CLI writes src/config.h on every run (reference minicom:56-91); this recipe
+# writes the same macro set into oracle/_ref/cfg_<variant>/config.h and compiles with g++ directly
+# (the reference Makefile is not run).  Outputs only under oracle/_ref/ (git-ignored, travels via gpurun).
+set -e
+REF=${MCOM_REFERENCE:-/root/reference}/src
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+[ -d "$REF" ] || { echo "reference sources not present at $REF: skipping oracle/_ref build"; exit 0; }
+mkdir -p "$OUT"
+CXX=${CXX:-g++}
+CXXFLAGS="-O3 -Wno-unused-function -std=c++11 -w -march=x86-64-v2 -fopenmp"
+LIB_SRCS="bseq misc preprocess sketch bbhashdict kthread_reads kthread_bucket kthread_idx kthread_cb kthread_hash_realign kthread_dump "
+
+build_variant() {   # name readlen extra_defines...
+  local name=$1 L=$2; shift 2
+  local d=$OUT/$name
+  mkdir -p "$d/output_ref"
+  {
+    echo "#pragma once"
+    for x in "$@"; do
+      echo "#define $x"
+      case "$x" in ORDER|_PE) echo "int cmpcluster3(const void *a_, const void *b_);";; esac
+    done
+    echo "#define readlen $L"
+    echo "#define num_thr 1"
+    echo "#define uniqid \"uref\""
+    echo "#define output \"output_ref/\""
+    for m in inik inithr inimaxthr inistep ininumdict iniw inim inicbthr inimaxrounds; do echo "#define $m 0"; done
+  } > "$d/config.h"
+  local defs=""
+  for x in "$@"; do defs="$defs -D$x"; done
+  local srcs="$LIB_SRCS"
+  # the reference links through an archive, so only one of the two dump objects is ever pulled in
+  case " $* " in *" _PE "*) srcs="${srcs/kthread_dump /} kthread_dump_pe";; esac
+  local objs=""
+  for s in $srcs; do
+    if [ ! -f "$d/$s.o" ] || [ "$REF/$s.c" -nt "$d/$s.o" ]; then
+      $CXX -c $CXXFLAGS $defs -I"$d" -I"$REF" "$REF/$s.c" -o "$d/$s.o" &
+    fi
+    objs="$objs $d/$s.o"
+  done
+  wait
+  # the reference's main(), renamed so the same object supplies the globals to the dumper
+  $CXX -c $CXXFLAGS $defs -I"$d" -I"$REF" "$REF/minicommain.c" -o "$d/minicommain.o"
+  $CXX -c $CXXFLAGS $defs -Dmain=ref_main -I"$d" -I"$REF" "$REF/minicommain.c" -o "$d/minicommain_nomain.o"
+  $CXX $CXXFLAGS "$d/minicommain.o" $objs -o "$d/minicom_bin" -lm -lz -lpthread
+  $CXX -c $CXXFLAGS $defs -I"$d" -I"$REF" "$REF/decompress.c" -o "$d/decompress.o"
+  $CXX $CXXFLAGS "$d/decompress.o" -o "$d/decompress" -lm -lz -lpthread
+  # golden-vector dumper (our code, oracle/refdump.cpp) linked against the reference objects
+  $CXX $CXXFLAGS $defs -I"$d" -I"$REF" "$HERE/refdump.cpp" "$d/minicommain_nomain.o" $objs -o "$d/refdump" -lm -lz -lpthread
+  echo "built $d"
+}
+
+build_variant L100 100
+build_variant L150 150
+build_variant L100_order 100 ORDER
+build_variant L100_pe 100 _PE
