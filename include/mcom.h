@@ -1,0 +1,82 @@
+/* include/mcom.h -- C ABI of the MI355X-native minicom hot path (libmcom_hip.so).
+ *
+ * Drop-in boundary: these entry points are what the reference's L2 stage workers (kthread_*.c)
+ * would call in place of their per-item L1 functions; each one cites the reference interface it
+ * replaces (file:line into yuansliu/minicom src/).  The reference-side stubs are in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types.  All d_* pointers are DEVICE (HBM) pointers owned by the caller.
+ *   - every call is asynchronous on the context's HIP stream unless it returns host values;
+ *     mcom_sync() waits.  One context per host thread / per GPU.
+ *   - return 0 on success, a negative mcom_status otherwise; mcom_last_error() gives the text.
+ *     (the reference asserts / exit(1)s instead: sketch.c:122,248, bseq.c:54-57)
+ *   - records are the reference's mm128_t: { x = hash, y = id<<32 | pos<<1 | strand } (minicom.h:17-19)
+ *
+ * Packed read format ("packed rows"): W = ceil(2L/64) little-endian 64-bit words per read, base i in
+ * bits [2i, 2i+1], A=0 C=1 G=2 T=3 (sketch.c:8-25), unused high bits zero.  This is also the byte
+ * layout of the reference's single.seq / ref.bin streams (breads.h:232-239).  The reference's Stage-2
+ * bitset (bbhashdict.c:69-74) has the two bits of every base swapped (C=2, G=1); XOR-popcounts and
+ * key equality are invariant under that swap, see DESIGN.md.
+ */
+#ifndef MCOM_H
+#define MCOM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t x, y; } mcom_mm128;
+typedef struct mcom_ctx mcom_ctx;
+
+enum mcom_status {
+	MCOM_OK = 0,
+	MCOM_E_ARG = -1,      /* bad argument (k out of 1..31, L out of 1..256, null pointer ...) */
+	MCOM_E_HIP = -2,      /* HIP runtime error, text in mcom_last_error */
+	MCOM_E_NOMEM = -3,
+	MCOM_E_OVERFLOW = -4  /* a caller-provided output capacity was too small; nothing partial is valid */
+};
+
+/* read classes of process_reads (kthread_reads.c:84-225) */
+enum mcom_read_class {
+	MCOM_CLS_SKETCH = 0,  /* kept: N substituted, sketched, goes to a bucket   :182-218 */
+	MCOM_CLS_ALLA = 1, MCOM_CLS_ALLT = 2, MCOM_CLS_ALLN = 3,                  /* :84-111  */
+	MCOM_CLS_NEARA = 4, MCOM_CLS_NEART = 5, MCOM_CLS_NEARN = 6,                /* :113-126 */
+	MCOM_CLS_NHEAVY = 7                                                        /* :219-224 */
+};
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* stream: a hipStream_t (may be NULL for the default stream).  The context never owns the stream. */
+int  mcom_create(mcom_ctx **out, int device, void *hip_stream);
+void mcom_destroy(mcom_ctx *ctx);
+int  mcom_set_stream(mcom_ctx *ctx, void *hip_stream);
+int  mcom_sync(mcom_ctx *ctx);
+const char *mcom_last_error(const mcom_ctx *ctx);
+const char *mcom_version(void);
+
+/* ---- a4 + a2: reads --------------------------------------------------------------------------- */
+/* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:
+ * classify, substitute N by the majority base (tie order A,T,G,C), 2-bit pack, and sketch the kept
+ * reads with mm_sketch_two (sketch.c:238).  d_ascii is [n][pitch] bytes, upper-case ACGTN.
+ * Outputs (all [n]): d_packed [n][W] (N packs as the substituted base for class 0, as A otherwise),
+ * d_cls, d_ncnt (number of N), d_rec (x=y=UINT64_MAX unless class 0; rid = rid0+i).
+ * d_nmask (optional, may be NULL): [n][ceil(L/64)] bit i set when base i was 'N'.              */
+int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
+                       uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
+                       uint64_t *d_nmask, mcom_mm128 *d_rec);
+
+/* Batched mm_sketch_two (sketch.c:238-289) on packed rows.  d_rids (optional): sketch rows
+ * d_rids[i] of d_packed and stamp that rid (the re-sketch of rejected reads with k-1, k-2, ...,
+ * kthread_bucket.c:205, :489); NULL: rows rid0+i... i.e. row i with rid rid0+i.                 */
+int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L,
+                      int k, uint32_t rid0, mcom_mm128 *d_rec);
+
+/* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
+int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
+                     uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

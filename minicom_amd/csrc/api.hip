@@ -1,0 +1,70 @@
+// minicom_amd/csrc/api.hip -- context, error text and workspace of libmcom_hip.so
+#include "mcom_dev.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+
+int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (ctx) ctx->err = buf;
+	return code;
+}
+
+int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
+{
+	if (bytes <= ctx->ws_bytes) return MCOM_OK;
+	if (ctx->ws) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); MCOM_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+	size_t want = bytes + bytes / 8 + (1 << 20);
+	hipError_t e = hipMalloc(&ctx->ws, want);
+	if (e != hipSuccess) { ctx->ws = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "workspace of %zu bytes: %s", want, hipGetErrorString(e)); }
+	ctx->ws_bytes = want;
+	return MCOM_OK;
+}
+
+extern "C" const char *mcom_version(void) { return "mcom-hip 0.1 (gfx950)"; }
+
+extern "C" int mcom_create(mcom_ctx **out, int device, void *hip_stream)
+{
+	if (!out) return MCOM_E_ARG;
+	*out = nullptr;
+	mcom_ctx *ctx = new mcom_ctx();
+	ctx->device = device; ctx->stream = (hipStream_t)hip_stream; ctx->ws = nullptr; ctx->ws_bytes = 0; ctx->n_cu = 256;
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) {
+		// no usable GPU: the product path must fail loudly, there is no CPU fallback
+		fprintf(stderr, "mcom_create: hipSetDevice(%d) failed: %s\n", device, hipGetErrorString(e));
+		delete ctx;
+		return MCOM_E_HIP;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+	*out = ctx;
+	return MCOM_OK;
+}
+
+extern "C" void mcom_destroy(mcom_ctx *ctx)
+{
+	if (!ctx) return;
+	if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
+	delete ctx;
+}
+
+extern "C" int mcom_set_stream(mcom_ctx *ctx, void *hip_stream)
+{
+	if (!ctx) return MCOM_E_ARG;
+	ctx->stream = (hipStream_t)hip_stream;
+	return MCOM_OK;
+}
+
+extern "C" int mcom_sync(mcom_ctx *ctx)
+{
+	if (!ctx) return MCOM_E_ARG;
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MCOM_OK;
+}
+
+extern "C" const char *mcom_last_error(const mcom_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }

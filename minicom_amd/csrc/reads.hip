@@ -1,0 +1,299 @@
+// minicom_amd/csrc/reads.hip -- read ingest kernels for gfx950 (MI355X).
+//
+//   k_classify_pack : ASCII reads -> class, N count, N mask, 2-bit packed rows (N substituted)
+//                     restates process_reads up to the sketch call (reference kthread_reads.c:55-205)
+//   k_sketch_reads  : one minimizer per read from packed rows = mm_sketch_two (reference sketch.c:238-289)
+//   k_synth_reads   : counter-based synthetic reads (minicom_amd/synth.py)
+//
+// Both hot kernels are integer/byte work: no MFMA.  k_classify_pack is HBM-bound (L + 8W + 4 bytes per
+// read), k_sketch_reads is VALU-bound (one 2k-bit invertible hash per base), see DESIGN.md.
+#include "mcom_dev.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// k_classify_pack: G lanes cooperate on one read, 8 bases per lane (G = 16 for L <= 128, else 32), so a
+// 64-wide wave holds 64/G reads and every global access of a wave is one contiguous span.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p)
+{
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+
+// 4 ASCII bases in a dword -> 4 x 2-bit codes in the low byte (A0 C1 G2 T3; N and anything else -> junk)
+__device__ __forceinline__ uint32_t ascii4_to_codes(uint32_t d)
+{
+	uint32_t t = ((d >> 1) ^ (d >> 2)) & 0x03030303u;
+	return (t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xFFu;
+}
+// bit j set when byte j of d is 'N'/'n' (bit 3 of the byte distinguishes N from A,C,G,T)
+__device__ __forceinline__ uint32_t ascii4_nbits(uint32_t d)
+{
+	uint32_t t = (d >> 3) & 0x01010101u;
+	return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_classify_pack(const uint8_t *__restrict__ ascii, size_t pitch, size_t n,
+                                                       int L, int e, uint64_t *__restrict__ packed, int W,
+                                                       uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt,
+                                                       uint64_t *__restrict__ nmask, int NW)
+{
+	constexpr int RPW = 64 / G;                       // reads per wave
+	const int lane = threadIdx.x & 63;
+	const int sub = lane / G, j = lane % G;
+	const size_t wave0 = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+	const size_t total_bytes = n ? (n - 1) * pitch + (size_t)L : 0;
+
+	for (size_t base = wave0 * RPW; base < n; base += nwaves * RPW) {
+		const size_t r = base + sub;
+		const bool live = r < n;
+		const int c0 = 8 * j;                         // first base of this lane
+		int nv = L - c0; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+		if (!live) nv = 0;
+		uint32_t d0 = 0, d1 = 0;
+		if (nv > 0) {
+			const size_t off = r * pitch + (size_t)c0;
+			if (off + 8 <= total_bytes) { d0 = load_u32_any(ascii + off); d1 = load_u32_any(ascii + off + 4); }
+			else {
+				for (int q = 0; q < nv; ++q) {
+					uint32_t b = ascii[off + q];
+					if (q < 4) d0 |= b << (8 * q); else d1 |= b << (8 * (q - 4));
+				}
+			}
+		}
+		const uint32_t vmask = nv >= 8 ? 0xFFu : ((1u << nv) - 1u);          // valid bases of this lane
+		uint32_t codes = (ascii4_to_codes(d0) | (ascii4_to_codes(d1) << 8)); // 8 x 2 bits
+		uint32_t nb = (ascii4_nbits(d0) | (ascii4_nbits(d1) << 4)) & vmask;  // 8 N flags
+		// per-lane base counts among valid non-N bases: 2-bit fields -> one-hot tests
+		uint32_t lo = codes & 0x5555u, hi = (codes >> 1) & 0x5555u;          // low/high bit of each code, at even bits
+		uint32_t ok = 0;                                                     // valid & not N, spread to even bits
+		{
+			uint32_t m = vmask & ~nb;                                        // 8 bits
+			m = (m | (m << 4)) & 0x0F0Fu; m = (m | (m << 2)) & 0x3333u; m = (m | (m << 1)) & 0x5555u;
+			ok = m;
+		}
+		uint32_t cA = __popc(~lo & ~hi & ok), cC = __popc(lo & ~hi & ok), cG = __popc(~lo & hi & ok), cT = __popc(lo & hi & ok);
+		uint32_t acc0 = cA | (cT << 16), acc1 = cG | (cC << 16), accN = __popc(nb);
+#pragma unroll
+		for (int s = 1; s < G; s <<= 1) {
+			acc0 += __shfl_xor(acc0, s, 64); acc1 += __shfl_xor(acc1, s, 64); accN += __shfl_xor(accN, s, 64);
+		}
+		const int nA = acc0 & 0xFFFF, nT = acc0 >> 16, nG = acc1 & 0xFFFF, nC = acc1 >> 16, nN = (int)accN;
+		int c;                                                               // kthread_reads.c:84-224
+		if (nA == L) c = MCOM_CLS_ALLA;
+		else if (nT == L) c = MCOM_CLS_ALLT;
+		else if (nN == L) c = MCOM_CLS_ALLN;
+		else if (nT + nG + nC + nN <= e) c = MCOM_CLS_NEARA;
+		else if (nA + nG + nC + nN <= e) c = MCOM_CLS_NEART;
+		else if (nA + nT + nG + nC <= e) c = MCOM_CLS_NEARN;
+		else if (!((double)nN <= 0.4 * (double)L)) c = MCOM_CLS_NHEAVY;
+		else c = MCOM_CLS_SKETCH;
+		uint32_t rep = 0;                                                    // majority base, ties A,T,G,C (:185-201)
+		if (c == MCOM_CLS_SKETCH && nN > 0) {
+			int mx = nA; if (nT > mx) mx = nT; if (nG > mx) mx = nG; if (nC > mx) mx = nC;
+			rep = (mx == nA) ? 0u : (mx == nT) ? 3u : (mx == nG) ? 2u : 1u;
+		}
+		// substitute: N positions take rep, invalid positions take 0
+		uint32_t nsp = nb; nsp = (nsp | (nsp << 4)) & 0x0F0Fu; nsp = (nsp | (nsp << 2)) & 0x3333u; nsp = (nsp | (nsp << 1)) & 0x5555u;
+		uint32_t keep = ok | (ok << 1);
+		uint32_t fill = (rep & 1 ? nsp : 0u) | (rep & 2 ? (nsp << 1) : 0u);
+		uint32_t out16 = (codes & keep) | fill;
+		// four lanes make one 64-bit word
+		uint64_t word = (uint64_t)out16 << (16 * (j & 3));
+		word |= __shfl_xor(word, 1, 64);
+		word |= __shfl_xor(word, 2, 64);
+		if (live && (j & 3) == 0 && (j >> 2) < W) packed[r * (size_t)W + (j >> 2)] = word;
+		if (nmask) {
+			uint64_t nw = (uint64_t)nb << (8 * (j & 7));
+			nw |= __shfl_xor(nw, 1, 64); nw |= __shfl_xor(nw, 2, 64); nw |= __shfl_xor(nw, 4, 64);
+			if (live && (j & 7) == 0 && (j >> 3) < NW) nmask[r * (size_t)NW + (j >> 3)] = nw;
+		}
+		if (live && j == 0) { cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN; }
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sketch_reads: one thread per read, rolling forward / reverse-complement k-mers out of the packed
+// row held in registers; 64 reads of a wave run the same control flow (the only divergent branch is the
+// rare k-mer that equals its own reverse complement).
+//   WIDE = true : 17 <= k <= 31, k-mers in a 64-bit register pair, mask low word is all ones
+//   WIDE = false: k <= 16, everything in 32-bit registers
+// ------------------------------------------------------------------------------------------------
+template <int W, bool WIDE>
+__global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ rids,
+                                                      size_t n, int L, int k, uint32_t rid0, mcom_mm128 *__restrict__ rec)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const uint32_t rid = rids ? rids[t] : rid0 + (uint32_t)t;
+	const size_t row = rids ? (size_t)rid : t;
+	uint64_t w[W];
+#pragma unroll
+	for (int q = 0; q < W; ++q) w[q] = packed[row * W + q];
+
+	uint64_t best_x = U64MAX; uint32_t best_i = 0, best_z = 0;
+	int run = 0;
+	if (WIDE) {
+		const uint32_t mhi = (uint32_t)((1ull << (2 * k - 32)) - 1);
+		const uint64_t mask = ((uint64_t)mhi << 32) | 0xFFFFFFFFull;
+		const int sh_hi = 2 * (k - 1) - 32;                 // top base of the reverse k-mer, inside the high word
+		uint64_t fwd = 0, rev = 0;
+		int i = 0;
+#pragma unroll
+		for (int q = 0; q < W; ++q) {
+			uint64_t cur = w[q];
+			const int lim = (L - 32 * q) < 32 ? (L - 32 * q) : 32;
+			for (int b = 0; b < lim; ++b, ++i) {
+				const uint32_t c = (uint32_t)cur & 3u; cur >>= 2;
+				fwd = ((fwd << 2) | c) & mask;
+				rev = (rev >> 2) | ((uint64_t)((3u ^ c) << sh_hi) << 32);
+				if (fwd != rev) {
+					++run;
+					if (run >= k) {
+						const uint32_t z = fwd < rev ? 0u : 1u;
+						const uint64_t h = mcom_hash64(z ? rev : fwd, mask);
+						if (h < best_x) { best_x = h; best_i = (uint32_t)i; best_z = z; }
+					}
+				}
+			}
+		}
+	} else {
+		const uint32_t mask = (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+		const int sh = 2 * (k - 1);
+		uint32_t fwd = 0, rev = 0;
+		int i = 0;
+#pragma unroll
+		for (int q = 0; q < W; ++q) {
+			uint64_t cur = w[q];
+			const int lim = (L - 32 * q) < 32 ? (L - 32 * q) : 32;
+			for (int b = 0; b < lim; ++b, ++i) {
+				const uint32_t c = (uint32_t)cur & 3u; cur >>= 2;
+				fwd = ((fwd << 2) | c) & mask;
+				rev = (rev >> 2) | ((3u ^ c) << sh);
+				if (fwd != rev) {
+					++run;
+					if (run >= k) {
+						const uint32_t z = fwd < rev ? 0u : 1u;
+						const uint64_t h = mcom_hash64_lo(z ? rev : fwd, mask);
+						if (h < best_x) { best_x = h; best_i = (uint32_t)i; best_z = z; }
+					}
+				}
+			}
+		}
+	}
+	mcom_mm128 o;
+	o.x = best_x;
+	o.y = best_x == U64MAX ? U64MAX : ((uint64_t)rid << 32 | (uint64_t)(best_i << 1) | best_z);
+	rec[t] = o;
+}
+
+// only class-0 reads carry a record; the others get {MAX, MAX}
+__global__ void k_mask_records(const uint8_t *__restrict__ cls, size_t n, mcom_mm128 *__restrict__ rec)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < n && cls[t] != MCOM_CLS_SKETCH) { mcom_mm128 o; o.x = U64MAX; o.y = U64MAX; rec[t] = o; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic reads (minicom_amd/synth.py, plumbing=False); one thread per base
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sm64(uint64_t z)
+{
+	z += 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+__global__ void k_synth_reads(uint64_t seed, uint64_t G, int L, uint64_t thr, uint64_t first, uint64_t count,
+                              uint8_t *__restrict__ out, size_t pitch)
+{
+	const uint64_t b0 = sm64(seed + 0), b1 = sm64(seed + 1), b2 = sm64(seed + 2), b3 = sm64(seed + 3);
+	const uint64_t total = count * (uint64_t)L;
+	for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t q = t / (uint64_t)L; const int o = (int)(t - q * (uint64_t)L);   // output column
+		const uint64_t r = first + q;
+		const uint64_t start = sm64(b1 + r) % (G - (uint64_t)L + 1);
+		const int strand = (int)(sm64(b2 + r) & 1);
+		const int i = strand ? L - 1 - o : o;                                              // forward coordinate
+		unsigned b = (unsigned)(sm64(b0 + start + (uint64_t)i) & 3);
+		const uint64_t u = sm64(b3 + r * (uint64_t)L + (uint64_t)i);
+		if ((u & 0xFFFFFF) < thr) b = (b + 1 + (unsigned)((u >> 24) % 3)) & 3;
+		out[q * pitch + o] = "ACGT"[strand ? 3 - b : b];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------
+template <bool WIDE>
+static int launch_sketch(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L, int k,
+                         uint32_t rid0, mcom_mm128 *d_rec)
+{
+	const int W = mcom_words_per_read(L);
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_sketch_reads<WW, WIDE>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
+	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+	default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported (1..256)", L); }
+#undef MCOM_CASE
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L,
+                                 int k, uint32_t rid0, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range 1..256", L);
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
+	if (n == 0) return MCOM_OK;
+	if (!d_packed || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	return k >= 17 ? launch_sketch<true>(ctx, d_packed, d_rids, n, L, k, rid0, d_rec)
+	               : launch_sketch<false>(ctx, d_packed, d_rids, n, L, k, rid0, d_rec);
+}
+
+extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
+                                  uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
+                                  uint64_t *d_nmask, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range 1..256", L);
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
+	if (pitch < (size_t)L) return mcom_fail(ctx, MCOM_E_ARG, "pitch %zu < read length %d", pitch, L);
+	if (n == 0) return MCOM_OK;
+	if (!d_ascii || !d_packed || !d_cls || !d_ncnt || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const int W = mcom_words_per_read(L), NW = (L + 63) / 64;
+	const int G = L <= 128 ? 16 : 32;
+	const size_t waves = (n + (64 / G) - 1) / (64 / G);
+	size_t blocks = (waves + 3) / 4;
+	const size_t cap = (size_t)ctx->n_cu * 16;
+	if (blocks > cap) blocks = cap;
+	if (G == 16) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
+	else         hipLaunchKernelGGL((k_classify_pack<32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
+	MCOM_LAUNCH_CHECK(ctx);
+	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_mask_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_rec);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
+                                uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (L < 1 || L > 256 || coverage < 1 || pitch < (size_t)L) return mcom_fail(ctx, MCOM_E_ARG, "bad synth arguments");
+	if (count == 0) return MCOM_OK;
+	if (!d_ascii) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	uint64_t G = n_reads * (uint64_t)L / (uint64_t)coverage;
+	if (G < (uint64_t)L + 1) G = (uint64_t)L + 1;
+	const uint64_t thr = (uint64_t)(sub_rate * (double)(1 << 24));
+	uint64_t blocks = (count * (uint64_t)L + 255) / 256;
+	const uint64_t cap = (uint64_t)ctx->n_cu * 32;
+	if (blocks > cap) blocks = cap;
+	hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, G, L, thr, first, count, d_ascii, pitch);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

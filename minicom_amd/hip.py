@@ -1,0 +1,162 @@
+"""ctypes binding of libmcom_hip.so (include/mcom.h) over torch CUDA(=HIP) tensors."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MM_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8")])
+
+
+class McomError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "lib", "libmcom_hip.so")
+
+
+def header_path() -> str:
+    return os.path.join(os.path.dirname(HERE), "include", "mcom.h")
+
+
+def _declared_symbols() -> list[str]:
+    txt = open(header_path()).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcom_[a-z0-9_]+)\s*\(", txt)))
+
+
+ABI_SYMBOLS = _declared_symbols()
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise McomError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback for the product path)")
+    L = C.CDLL(p)
+    vp, sz, i32, u32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64
+    L.mcom_create.restype = i32; L.mcom_create.argtypes = [C.POINTER(vp), i32, vp]
+    L.mcom_destroy.restype = None; L.mcom_destroy.argtypes = [vp]
+    L.mcom_set_stream.restype = i32; L.mcom_set_stream.argtypes = [vp, vp]
+    L.mcom_sync.restype = i32; L.mcom_sync.argtypes = [vp]
+    L.mcom_last_error.restype = C.c_char_p; L.mcom_last_error.argtypes = [vp]
+    L.mcom_version.restype = C.c_char_p; L.mcom_version.argtypes = []
+    L.mcom_process_reads.restype = i32
+    L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
+    L.mcom_sketch_reads.restype = i32
+    L.mcom_sketch_reads.argtypes = [vp, vp, vp, sz, i32, i32, u32, vp]
+    L.mcom_synth_reads.restype = i32
+    L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
+    _lib = L
+    return L
+
+
+def words_per_read(L: int) -> int:
+    return (2 * L + 63) // 64
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Context:
+    """One context per process / GPU (mcom_ctx).  All tensors must live on this context's device."""
+
+    def __init__(self, device: int = 0, stream=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise McomError("no GPU visible: the minicom_amd product path has no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.mcom_create(C.byref(h), device, C.c_void_p(self._stream.cuda_stream))
+        if rc:
+            raise McomError(f"mcom_create failed ({rc})")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mcom_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _check(self, rc: int):
+        if rc:
+            raise McomError(f"mcom error {rc}: {self.lib.mcom_last_error(self._h).decode()}")
+
+    def _p(self, t, dtype=None):
+        if t is None:
+            return C.c_void_p(0)
+        assert t.is_cuda and t.is_contiguous(), "device, contiguous tensors only"
+        if dtype is not None:
+            assert t.dtype == dtype, (t.dtype, dtype)
+        return C.c_void_p(t.data_ptr())
+
+    def sync(self):
+        self._check(self.lib.mcom_sync(self._h))
+
+    def empty_records(self, n: int):
+        torch = _torch()
+        return torch.empty((n, 2), dtype=torch.int64, device=self.device)  # mm128_t = 2 x u64, viewed as int64
+
+    # -- include/mcom.h entry points
+    def process_reads(self, ascii_, L: int, k: int, e: int = 4, rid0: int = 0, want_nmask: bool = False):
+        """mcom_process_reads.  ascii_: uint8 [n, pitch] on the device.  Returns dict of device tensors."""
+        torch = _torch()
+        n, pitch = ascii_.shape
+        W = words_per_read(L)
+        packed = torch.empty((n, W), dtype=torch.int64, device=self.device)
+        cls = torch.empty(n, dtype=torch.uint8, device=self.device)
+        ncnt = torch.empty(n, dtype=torch.int16, device=self.device)
+        nmask = torch.empty((n, (L + 63) // 64), dtype=torch.int64, device=self.device) if want_nmask else None
+        rec = self.empty_records(n)
+        self._check(self.lib.mcom_process_reads(self._h, self._p(ascii_, torch.uint8), pitch, n, L, k, e, rid0,
+                                                self._p(packed), self._p(cls), self._p(ncnt), self._p(nmask), self._p(rec)))
+        return {"packed": packed, "cls": cls, "ncnt": ncnt, "nmask": nmask, "rec": rec}
+
+    def sketch_reads(self, packed, L: int, k: int, rids=None, rid0: int = 0, out=None):
+        """mcom_sketch_reads.  packed: int64 [N, W]; rids: optional int32 [n] row selector."""
+        torch = _torch()
+        n = int(rids.shape[0]) if rids is not None else int(packed.shape[0])
+        rec = out if out is not None else self.empty_records(n)
+        self._check(self.lib.mcom_sketch_reads(self._h, self._p(packed, torch.int64),
+                                               self._p(rids, torch.int32) if rids is not None else C.c_void_p(0),
+                                               n, L, k, rid0, self._p(rec)))
+        return rec
+
+    def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,
+                    first: int = 0, count: int | None = None, pitch: int | None = None):
+        torch = _torch()
+        if count is None:
+            count = n_reads - first
+        pitch = pitch or L
+        out = torch.empty((count, pitch), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mcom_synth_reads(self._h, seed, n_reads, L, coverage, sub_rate, first, count, self._p(out), pitch))
+        return out
+
+
+def records_to_numpy(rec) -> np.ndarray:
+    """Device [n,2] int64 record tensor -> numpy structured (x, y) uint64."""
+    a = rec.detach().cpu().numpy().view(np.uint64)
+    out = np.empty(a.shape[0], dtype=MM_DTYPE)
+    out["x"] = a[:, 0]; out["y"] = a[:, 1]
+    return out

@@ -1,8 +1,7 @@
 """Deterministic synthetic read sets.
 
-Counter-based (splitmix64) so that the numpy version here, the C version in
-``oracle/mcom_oracle.c`` (``mcomo_synth_reads``) and the HIP kernel ``mcom_synth_reads``
-(minicom_amd/csrc/synth.hip) produce byte-identical reads for the same
+Counter-based (splitmix64) so that the numpy version here, the C version kept with the CPU
+baseline and the HIP kernel ``mcom_synth_reads`` (minicom_amd/csrc/reads.hip) produce byte-identical reads for the same
 (seed, n_reads, read_len, coverage) without sharing state:
 
   genome length G = max(n*L/coverage, L+1); base g        = key(0, g) & 3
