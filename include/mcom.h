@@ -72,6 +72,25 @@ int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size
 int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L,
                       int k, uint32_t rid0, mcom_mm128 *d_rec);
 
+/* ---- a5 + a6: sort and group ------------------------------------------------------------------- */
+/* radix_sort_128x (misc.c:22, ksort.h:153): sorts n records in place by x ascending.  Stable: equal keys
+ * keep their input order (the reference is stable only up to 64 elements, ksort.h:155).             */
+int mcom_radix_sort_128x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
+
+/* One Stage-1 round's front half for all 2^b buckets: the per-bucket radix_sort_128x, the run-length
+ * grouping of equal hashes and the cmpcluster ordering of process_bucket (kthread_bucket.c:391-446,
+ * :44-62).  d_rec: n records in ascending rid order, sketched with k = kmer (k_orig = the run's first k,
+ * which cmpcluster keeps using in later rounds); records with x = UINT64_MAX (no minimizer) are ignored.
+ * Outputs, in the order the reference visits them (bucket ascending, hash ascending):
+ *   d_sorted  [n]      all records, sorted (ignored records last)
+ *   d_singles [<=n]    rid of every group of one                     (:402-413, pushed to reads->sg)
+ *   d_members [<=n]    y of every member of a group >= 2, each group in cmpcluster order (:438-442)
+ *   d_group_off[<=n/2+1]  start of each such group in d_members, plus the end sentinel
+ *   h_counts[4] (HOST) = { n_valid, n_singles, n_groups, n_members }.  Synchronous.                  */
+int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int k_orig, int kmer, int b,
+                    mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
+                    uint64_t *h_counts);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

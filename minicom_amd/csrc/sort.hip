@@ -1,0 +1,342 @@
+// minicom_amd/csrc/sort.hip -- minimizer-record sort and grouping for gfx950 (MI355X).
+//
+// Replaces, for all 2^b buckets of a Stage-1 round at once, the per-bucket radix_sort_128x + run-length
+// grouping + cmpcluster ordering at the top of process_bucket (reference kthread_bucket.c:391-446, :44-62;
+// misc.c:22, ksort.h:108-157) and the bucket sort of the minimizer index (kthread_idx.c:126).
+//
+// One stable LSD radix sort (8-bit digits) over a composite key
+//      C = [ bucket = x & (2^b-1) | x >> b | (L + k - aligned_pos) ]      (most .. least significant)
+// on records that arrive in ascending rid order gives exactly the order the reference produces bucket by
+// bucket: buckets ascending, hashes ascending inside a bucket, and inside a group of equal hashes the
+// cmpcluster order (aligned position descending, rid ascending).  HBM-bound: every pass streams the
+// 16-byte records once for the histogram and once for the scatter, and writes them once.
+#include "mcom_dev.hpp"
+
+#define RS_THREADS 256
+#define RS_ITEMS 16
+#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 records = 64 KiB staged in LDS
+
+struct KeySpec {
+	int mode;       // 0: key = x (64 bits);  1: composite minimizer key
+	int b;          // bucket bits
+	int kbits;      // 2 * k of the sketch that produced x
+	int L, k_orig;  // for the aligned position of cmpcluster
+};
+
+// 128-bit composite key as (lo, hi); digit p = bits [8p, 8p+8)
+__device__ __forceinline__ void make_key(const KeySpec &ks, uint64_t x, uint64_t y, uint64_t &lo, uint32_t &hi)
+{
+	if (ks.mode == 0) { lo = x; hi = 0; return; }
+	if (x == U64MAX) { lo = U64MAX; hi = 0xFFFFFFFFu; return; }           // records without a minimizer sort last
+	const uint64_t bucket = x & ((1ull << ks.b) - 1);
+	const uint64_t K = (bucket << (ks.kbits - ks.b)) | (x >> ks.b);
+	int pos = (int)(((uint32_t)y) >> 1);
+	if (y & 1) pos = ks.L - pos + ks.k_orig - 2;                         // kthread_bucket.c:51-56
+	const uint32_t key2 = (uint32_t)(ks.L + ks.k_orig - pos) & 0x1FFu;    // descending aligned position
+	lo = (K << 9) | key2;
+	hi = (uint32_t)(K >> 55);
+}
+__device__ __forceinline__ uint32_t key_digit(uint64_t lo, uint32_t hi, int pass)
+{
+	return pass < 8 ? (uint32_t)(lo >> (8 * pass)) & 255u : (hi >> (8 * (pass - 8))) & 255u;
+}
+
+// ---- per-tile digit histogram: hist[digit * nblocks + block] ------------------------------------
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const mcom_mm128 *__restrict__ in, size_t n, KeySpec ks, int pass,
+                                                           uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+	for (int it = 0; it < RS_ITEMS; ++it) {
+		const size_t i = base + (size_t)it * RS_THREADS + threadIdx.x;
+		if (i < n) {
+			const mcom_mm128 r = in[i];
+			uint64_t lo; uint32_t hi; make_key(ks, r.x, r.y, lo, hi);
+			atomicAdd(&h[key_digit(lo, hi, pass)], 1u);
+		}
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- stable scatter of one tile --------------------------------------------------------------------
+// wave w of the block owns records [w*1024, w*1024+1024) of the tile, 16 chunks of 64 (one per lane).
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out, size_t n,
+                                                              KeySpec ks, int pass, const uint32_t *__restrict__ offs, uint32_t nblocks)
+{
+	__shared__ mcom_mm128 stage[RS_TILE];
+	__shared__ uint32_t wcnt[4][256];        // per-wave digit counts, then per-wave start inside the tile
+	__shared__ uint32_t tstart[256];         // first local slot of each digit in the staged tile
+	__shared__ uint32_t gofs[256];           // global slot of that first local slot
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int q = threadIdx.x; q < 4 * 256; q += RS_THREADS) (&wcnt[0][0])[q] = 0;
+	__syncthreads();
+
+	const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)wv * (RS_TILE / 4);
+	mcom_mm128 r[RS_ITEMS];
+	uint16_t rank[RS_ITEMS];
+	uint8_t dig[RS_ITEMS];
+	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+	for (int c = 0; c < RS_ITEMS; ++c) {
+		const size_t i = base + (size_t)c * 64 + lane;
+		const bool valid = i < n;
+		uint32_t d = 0;
+		if (valid) {
+			r[c] = in[i];
+			uint64_t lo; uint32_t hi; make_key(ks, r[c].x, r[c].y, lo, hi);
+			d = key_digit(lo, hi, pass);
+		}
+		uint64_t peers = __ballot(valid);
+#pragma unroll
+		for (int bit = 0; bit < 8; ++bit) {
+			const bool one = (d >> bit) & 1;
+			const uint64_t bl = __ballot(one);
+			peers &= one ? bl : ~bl;
+		}
+		uint32_t old = 0;
+		const int leader = __ffsll((unsigned long long)peers) - 1;
+		if (valid && lane == leader) { old = wcnt[wv][d]; wcnt[wv][d] = old + (uint32_t)__popcll(peers); }
+		old = __shfl(old, leader < 0 ? 0 : leader, 64);
+		rank[c] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
+		dig[c] = (uint8_t)d;
+	}
+	__syncthreads();
+	{   // digit totals -> exclusive prefix over digits (tstart), per-wave starts, global starts
+		const int d = threadIdx.x;
+		const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
+		const uint32_t tot = c0 + c1 + c2 + c3;
+		// block exclusive scan of tot over 256 threads
+		uint32_t v = tot;
+#pragma unroll
+		for (int s = 1; s < 64; s <<= 1) { uint32_t t = __shfl_up(v, s, 64); if (lane >= s) v += t; }
+		__shared__ uint32_t wsum[4];
+		if (lane == 63) wsum[wv] = v;
+		__syncthreads();
+		uint32_t add = 0;
+		for (int q = 0; q < wv; ++q) add += wsum[q];
+		const uint32_t excl = v + add - tot;
+		tstart[d] = excl;
+		wcnt[0][d] = excl; wcnt[1][d] = excl + c0; wcnt[2][d] = excl + c0 + c1; wcnt[3][d] = excl + c0 + c1 + c2;
+		gofs[d] = offs[(size_t)d * nblocks + blockIdx.x];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int c = 0; c < RS_ITEMS; ++c) {
+		const size_t i = base + (size_t)c * 64 + lane;
+		if (i < n) stage[wcnt[wv][dig[c]] + rank[c]] = r[c];
+	}
+	__syncthreads();
+	const size_t tile_base = (size_t)blockIdx.x * RS_TILE;
+	const uint32_t cnt = (uint32_t)((n - tile_base) < (size_t)RS_TILE ? (n - tile_base) : (size_t)RS_TILE);
+	for (uint32_t q = threadIdx.x; q < cnt; q += RS_THREADS) {
+		const mcom_mm128 v = stage[q];
+		uint64_t lo; uint32_t hi; make_key(ks, v.x, v.y, lo, hi);
+		const uint32_t d = key_digit(lo, hi, pass);
+		out[(size_t)gofs[d] + (q - tstart[d])] = v;
+	}
+}
+
+// ---- generic exclusive scan of uint32 (2048 elements per block, recursive on the block sums) -------
+#define SC_THREADS 256
+#define SC_PER 8
+#define SC_TILE (SC_THREADS * SC_PER)
+__global__ __launch_bounds__(SC_THREADS) void k_scan_tile(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+                                                          uint32_t *__restrict__ sums)
+{
+	__shared__ uint32_t wsum[SC_THREADS / 64];
+	const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_PER;
+	uint32_t v[SC_PER], tot = 0;
+#pragma unroll
+	for (int q = 0; q < SC_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0u; tot += v[q]; }
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint32_t inc = tot;
+#pragma unroll
+	for (int s = 1; s < 64; s <<= 1) { uint32_t t = __shfl_up(inc, s, 64); if (lane >= s) inc += t; }
+	if (lane == 63) wsum[wv] = inc;
+	__syncthreads();
+	uint32_t add = 0, all = 0;
+	for (int q = 0; q < SC_THREADS / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
+	uint32_t run = inc + add - tot;
+#pragma unroll
+	for (int q = 0; q < SC_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+	if (sums && threadIdx.x == 0) sums[blockIdx.x] = all;
+}
+__global__ void k_scan_add(uint32_t *__restrict__ out, size_t n, const uint32_t *__restrict__ sums)
+{
+	const size_t i = (size_t)blockIdx.x * SC_TILE + threadIdx.x;
+	const uint32_t a = sums[blockIdx.x];
+#pragma unroll
+	for (int q = 0; q < SC_PER; ++q) { const size_t j = i + (size_t)q * SC_THREADS; if (j < n) out[j] += a; }
+}
+
+// scratch: needs room for the block sums of every level; returns bytes needed for n elements
+static size_t scan_scratch_elems(size_t n)
+{
+	size_t tot = 0;
+	while (n > SC_TILE) { n = (n + SC_TILE - 1) / SC_TILE; tot += n; }
+	return tot + 1;
+}
+static int scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch)
+{
+	if (n == 0) return MCOM_OK;
+	const size_t nb = (n + SC_TILE - 1) / SC_TILE;
+	hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
+	MCOM_LAUNCH_CHECK(ctx);
+	if (nb > 1) {
+		int rc = scan_u32(ctx, scratch, scratch, nb, scratch + nb);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, out, n, scratch);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	return MCOM_OK;
+}
+
+// exported to the other translation units of the library
+int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch) { return scan_u32(ctx, in, out, n, scratch); }
+size_t mcom_scan_scratch_elems(size_t n) { return scan_scratch_elems(n); }
+
+// ---- the sort driver -------------------------------------------------------------------------------
+// a and tmp are ping-pong buffers of n records; on return *sorted points at the one holding the result
+static int radix_sort_records(mcom_ctx *ctx, mcom_mm128 *a, mcom_mm128 *tmp, size_t n, const KeySpec &ks, int passes,
+                              uint32_t *hist, uint32_t *scratch, mcom_mm128 **sorted)
+{
+	const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+	mcom_mm128 *src = a, *dst = tmp;
+	for (int p = 0; p < passes; ++p) {
+		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, ks, p, hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		int rc = scan_u32(ctx, hist, hist, (size_t)256 * nblocks, scratch);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, ks, p, hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		mcom_mm128 *t = src; src = dst; dst = t;
+	}
+	*sorted = src;
+	return MCOM_OK;
+}
+
+struct SortWs { mcom_mm128 *tmp; uint32_t *hist, *scratch; size_t bytes; };
+static size_t sort_ws_layout(size_t n, SortWs *w, char *base)
+{
+	const size_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+	size_t off = 0;
+	auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+	size_t o_tmp = take(n * sizeof(mcom_mm128));
+	size_t o_hist = take((size_t)256 * nblocks * 4);
+	size_t o_scr = take(scan_scratch_elems((size_t)256 * nblocks) * 4 + 1024);
+	if (w && base) { w->tmp = (mcom_mm128*)(base + o_tmp); w->hist = (uint32_t*)(base + o_hist); w->scratch = (uint32_t*)(base + o_scr); }
+	return off;
+}
+
+// a5: radix_sort_128x (misc.c:22).  Stable, so equal keys keep their input order; the reference is stable
+// only up to 64 elements (ksort.h:155) and leaves equal keys of larger arrays in an order that depends on
+// its in-place cycle walk.
+extern "C" int mcom_radix_sort_128x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_a) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-1 records");
+	const size_t need = sort_ws_layout(n, nullptr, nullptr);
+	int rc = mcom_ws_reserve(ctx, need);
+	if (rc) return rc;
+	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
+	KeySpec ks{0, 0, 64, 0, 0};
+	mcom_mm128 *res = nullptr;
+	rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 8, w.hist, w.scratch, &res);
+	if (rc) return rc;
+	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
+// ---- grouping ------------------------------------------------------------------------------------------
+// flags per sorted record: bit0 single (group of one), bit1 member of a group >= 2, bit2 first member of such a group
+__global__ void k_group_flags(const mcom_mm128 *__restrict__ s, size_t n, uint32_t *__restrict__ f_single,
+                              uint32_t *__restrict__ f_member, uint32_t *__restrict__ f_head)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t x = s[i].x;
+	const bool valid = x != U64MAX;
+	const bool eq_prev = i > 0 && s[i - 1].x == x, eq_next = i + 1 < n && s[i + 1].x == x;
+	const bool single = valid && !eq_prev && !eq_next, member = valid && (eq_prev || eq_next);
+	f_single[i] = single; f_member[i] = member; f_head[i] = member && !eq_prev;
+}
+__global__ void k_group_emit(const mcom_mm128 *__restrict__ s, size_t n, const uint32_t *__restrict__ p_single,
+                             const uint32_t *__restrict__ p_member, const uint32_t *__restrict__ p_head,
+                             uint32_t *__restrict__ singles, uint64_t *__restrict__ members, uint32_t *__restrict__ group_off,
+                             uint64_t *__restrict__ counts)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const mcom_mm128 r = s[i];
+	const bool valid = r.x != U64MAX;
+	const bool eq_prev = i > 0 && s[i - 1].x == r.x, eq_next = i + 1 < n && s[i + 1].x == r.x;
+	const bool single = valid && !eq_prev && !eq_next, member = valid && (eq_prev || eq_next);
+	if (single) singles[p_single[i]] = (uint32_t)(r.y >> 32);
+	if (member) { members[p_member[i]] = r.y; if (!eq_prev) group_off[p_head[i]] = p_member[i]; }
+	if (i == n - 1) {
+		const uint32_t ns = p_single[i] + (single ? 1u : 0u), nm = p_member[i] + (member ? 1u : 0u), ng = p_head[i] + ((member && !eq_prev) ? 1u : 0u);
+		group_off[ng] = nm;
+		counts[1] = ns; counts[2] = ng; counts[3] = nm;
+	}
+}
+__global__ void k_count_valid(const mcom_mm128 *__restrict__ s, size_t n, uint64_t *__restrict__ counts)
+{
+	// sorted: the records without a minimizer are a suffix; binary search its start
+	if (threadIdx.x || blockIdx.x) return;
+	size_t lo = 0, hi = n;
+	while (lo < hi) { size_t mid = (lo + hi) / 2; if (s[mid].x == U64MAX) hi = mid; else lo = mid + 1; }
+	counts[0] = lo;
+}
+
+extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int k_orig, int kmer, int b,
+                               mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
+                               uint64_t *h_counts)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!h_counts) return mcom_fail(ctx, MCOM_E_ARG, "h_counts is null");
+	h_counts[0] = h_counts[1] = h_counts[2] = h_counts[3] = 0;
+	if (n == 0) return MCOM_OK;
+	if (!d_rec || !d_sorted || !d_singles || !d_members || !d_group_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-1 records");
+	if (kmer < 1 || kmer > 31 || k_orig < 1 || k_orig > 31 || L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad k/L");
+	if (b < 1 || b > 2 * kmer || b > 24) return mcom_fail(ctx, MCOM_E_ARG, "bucket bits %d not in 1..min(24, 2k)", b);
+	// workspace: sort buffers + three flag/prefix arrays + counts
+	const size_t sort_bytes = sort_ws_layout(n, nullptr, nullptr);
+	const size_t flag_bytes = ((n * 4 + 255) & ~(size_t)255);
+	const size_t scr_bytes = ((scan_scratch_elems(n) * 4 + 1024 + 255) & ~(size_t)255);
+	const size_t need = sort_bytes + 3 * flag_bytes + scr_bytes + 256;
+	int rc = mcom_ws_reserve(ctx, need);
+	if (rc) return rc;
+	char *base = (char*)ctx->ws;
+	SortWs w; sort_ws_layout(n, &w, base);
+	uint32_t *f0 = (uint32_t*)(base + sort_bytes), *f1 = (uint32_t*)(base + sort_bytes + flag_bytes), *f2 = (uint32_t*)(base + sort_bytes + 2 * flag_bytes);
+	uint32_t *scr = (uint32_t*)(base + sort_bytes + 3 * flag_bytes);
+	uint64_t *d_counts = (uint64_t*)(base + sort_bytes + 3 * flag_bytes + scr_bytes);
+
+	MCOM_HIP(ctx, hipMemcpyAsync(d_sorted, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	KeySpec ks{1, b, 2 * kmer, L, k_orig};
+	const int bits = 2 * kmer + 9 + 1;                 // +1: the all-ones key of records without a minimizer
+	const int passes = (bits + 7) / 8;
+	mcom_mm128 *res = nullptr;
+	rc = radix_sort_records(ctx, d_sorted, w.tmp, n, ks, passes, w.hist, w.scratch, &res);
+	if (rc) return rc;
+	if (res != d_sorted) MCOM_HIP(ctx, hipMemcpyAsync(d_sorted, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+	hipLaunchKernelGGL(k_group_flags, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan_u32(ctx, f0, f0, n, scr))) return rc;
+	if ((rc = scan_u32(ctx, f1, f1, n, scr))) return rc;
+	if ((rc = scan_u32(ctx, f2, f2, n, scr))) return rc;
+	hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, d_sorted, n, d_counts);
+	hipLaunchKernelGGL(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_members, d_group_off, d_counts);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MCOM_OK;
+}

@@ -55,6 +55,9 @@ def load_library():
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32
     L.mcom_sketch_reads.argtypes = [vp, vp, vp, sz, i32, i32, u32, vp]
+    L.mcom_radix_sort_128x.restype = i32; L.mcom_radix_sort_128x.argtypes = [vp, vp, sz]
+    L.mcom_sort_group.restype = i32
+    L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
     _lib = L
@@ -142,6 +145,27 @@ class Context:
                                                self._p(rids, torch.int32) if rids is not None else C.c_void_p(0),
                                                n, L, k, rid0, self._p(rec)))
         return rec
+
+    def radix_sort_128x(self, rec):
+        """mcom_radix_sort_128x: in place, by x ascending, stable."""
+        torch = _torch()
+        self._check(self.lib.mcom_radix_sort_128x(self._h, self._p(rec, torch.int64), int(rec.shape[0])))
+        return rec
+
+    def sort_group(self, rec, L: int, k_orig: int, kmer: int, b: int = 14):
+        """mcom_sort_group.  Returns dict(sorted, singles, members, group_off) trimmed to their counts."""
+        torch = _torch()
+        n = int(rec.shape[0])
+        srt = self.empty_records(n)
+        singles = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        members = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        goff = torch.empty(n // 2 + 2, dtype=torch.int32, device=self.device)
+        cnt = (C.c_uint64 * 4)()
+        self._check(self.lib.mcom_sort_group(self._h, self._p(rec, torch.int64), n, L, k_orig, kmer, b, self._p(srt),
+                                             self._p(singles), self._p(members), self._p(goff), cnt))
+        nv, ns, ng, nm = (int(x) for x in cnt)
+        return {"sorted": srt, "n_valid": nv, "singles": singles[:ns], "members": members[:nm], "group_off": goff[:ng + 1] if n else goff[:0],
+                "n_groups": ng}
 
     def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,
                     first: int = 0, count: int | None = None, pitch: int | None = None):
