@@ -91,6 +91,47 @@ int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int
                     mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
                     uint64_t *h_counts);
 
+/* ---- a10..a15: Stage-2 realignment --------------------------------------------------------------- */
+/* setglobalarrays_realign (kthread_hash_realign.c:153-206): first/last base of every dictionary key.
+ * Host only.  Returns numdict_s (>= 1) or a negative status; start/end need room for 16 entries.    */
+int mcom_dict_layout(int L, int ininumdict, int *start, int *end);
+
+/* rows d_rids[i] of d_packed -> d_out[i] (the singleton pool of singleRead2bitset, bbhashdict.c:146) */
+int mcom_gather_rows(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L, uint64_t *d_out);
+
+/* Near-poly-A / poly-T filter of singleRead2bitset (bbhashdict.c:157-222).  d_flag[i] = 1 (A list),
+ * 2 (T list) or 0.  d_nmask (optional, with d_rids): N mask rows [n_reads][ceil(L/64)] indexed by rid.  */
+int mcom_poly_filter(mcom_ctx *ctx, const uint64_t *d_sgbits, const uint64_t *d_nmask, const uint32_t *d_rids,
+                     size_t n_sg, int L, int thr, uint8_t *d_flag);
+
+/* constructdictionary_realign + boomphf::mphf (kthread_hash_realign.c:3-140, BooPHF.h:891-1009): the
+ * numdict_s dictionaries over n_sg packed singletons, device resident.  A bin lists its singleton
+ * indices ascending (read_id[]); key -> bin is an exact hash table instead of an MPHF (every reference
+ * hit is re-verified against the bin key, :385-386, so results do not depend on the map).  Synchronous. */
+typedef struct mcom_dicts mcom_dicts;
+int  mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, mcom_dicts **out);
+void mcom_dicts_free(mcom_ctx *ctx, mcom_dicts *d);
+int  mcom_dicts_info(const mcom_dicts *d, int *nd, uint32_t *numkeys, uint32_t *maxbin);
+/* bphf->lookup + findpos (bbhashdict.c:33-43) for n keys of dictionary `dict`: bin start/size into the
+ * dictionary's id array (size 0 = key absent).  mcom_dicts_ids copies that id array (n_sg entries).   */
+int  mcom_dicts_lookup(mcom_ctx *ctx, const mcom_dicts *d, int dict, const uint64_t *d_keys, size_t n,
+                       uint32_t *d_start, uint32_t *d_count);
+int  mcom_dicts_ids(mcom_ctx *ctx, const mcom_dicts *d, int dict, uint32_t *d_ids_out);
+
+/* realign_hash_search over every window of every contig (kthread_hash_realign.c:316-508).
+ *   d_cbits : 2-bit packed contigs; contig c starts at word d_coff[c], holds ceil(2*len/64) words and is
+ *             followed by at least ONE padding word;  d_woff[c] = number of windows of contigs < c
+ *             (a contig of length len has max(0, len-L+1) windows);  n_windows = their total.
+ *   d_sgflag: [n_sg] nonzero = not claimable (flagged by mcom_poly_filter)
+ *   d_claim : [n_sg] out.  UINT64_MAX = unclaimed, else c<<33 | window<<5 | dir<<4 | dict: the FIRST
+ *             (contig, window, dir, dict) in the reference's visiting order whose test the read passes,
+ *             i.e. exactly where the sequential reference claims it.  Appending order inside one tuple
+ *             is descending singleton index (the bin is walked from its end, :388).
+ *   d_stats : optional [3] = { lookups, bin hits, candidates tested } (diagnostics, slows the kernel)   */
+int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, const uint8_t *d_sgflag,
+                      const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                      uint64_t n_windows, int thr, int maxsearch, uint64_t *d_claim, uint64_t *d_stats);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

@@ -18,6 +18,12 @@ struct mcom_ctx {
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
 
+// internal helpers shared between translation units (sort.hip)
+int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch);
+size_t mcom_scan_scratch_elems(size_t n);
+size_t mcom_sort_ws_bytes(size_t n);
+int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
+
 #define MCOM_HIP(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) \
 	return mcom_fail(ctx, MCOM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
 #define MCOM_LAUNCH_CHECK(ctx) MCOM_HIP(ctx, hipGetLastError())

@@ -1,0 +1,419 @@
+// minicom_amd/csrc/realign.hip -- Stage-2 realignment kernels for gfx950 (MI355X).
+//
+// Replaces realign_hash (reference kthread_hash_realign.c:569): singleRead2bitset (bbhashdict.c:127-227),
+// constructdictionary_realign (kthread_hash_realign.c:3-140, with BooPHF.h's MPHF) and the window scan
+// realign_hash_search (kthread_hash_realign.c:316-508).
+//
+//  * Dictionaries: for every dictionary j the 2*len_j-bit key of each singleton is sorted together with its
+//    singleton index (stable, so a bin lists its reads in ascending index like read_id[] does), the runs of
+//    equal keys become bins, and an open-addressing hash table in HBM maps key -> (bin start, bin size).
+//    The reference's MPHF is only a key -> bin id map whose every hit is re-verified against the bin's key
+//    (kthread_hash_realign.c:385-386), so any exact map gives the same results.
+//  * Window scan: one thread per contig window.  The reference claims a read at the first window (contig
+//    order, window order, forward before reverse, dictionary order) whose test it passes, then deletes it
+//    from every dictionary.  The tests themselves do not depend on that state, so the claim of a read is
+//    the MINIMUM over all passing (contig, window, dir, dict) tuples: one 64-bit atomicMin per passing
+//    candidate, no locks, same result as the sequential scan (exception: bins larger than maxsearch, see
+//    DESIGN.md).  Random-access HBM-bound.
+#include "mcom_dev.hpp"
+#include <cstring>
+
+#define MAXDICT 16
+
+struct mcom_dicts {
+	int L, W, nd;
+	int ds[MAXDICT], kl[MAXDICT];           // first base and length (bases) of every key
+	size_t n_sg;
+	uint64_t *slots[MAXDICT];               // hash tables: pairs {key, start | count << 32}, EMPTY key = ~0
+	uint32_t log2cap[MAXDICT];
+	uint32_t *ids[MAXDICT];                 // singleton indices, bin after bin, ascending inside a bin
+	uint32_t numkeys[MAXDICT], maxbin[MAXDICT];
+};
+
+struct DictDev {
+	int nd, W, L;
+	int ds[MAXDICT], kl[MAXDICT];
+	const uint64_t *slots[MAXDICT];
+	uint32_t log2cap[MAXDICT];
+	const uint32_t *ids[MAXDICT];
+};
+
+__host__ __device__ static inline int dict_layout(int L, int ininumdict, int *start, int *len)
+{
+	// setglobalarrays_realign (kthread_hash_realign.c:153-206)
+	const int len_t = L <= 80 ? 11 : 17;
+	int nd = L / len_t;
+	if (ininumdict > 1 && ininumdict < nd) nd = ininumdict;
+	if (nd > MAXDICT) nd = MAXDICT;
+	start[0] = (ininumdict > 0 && ininumdict < nd) ? L / 2 - (len_t * nd) / 2 : 0;
+	len[0] = len_t;
+	for (int i = 1; i < nd; ++i) { start[i] = start[i - 1] + len_t; len[i] = len_t; }
+	return nd;
+}
+
+extern "C" int mcom_dict_layout(int L, int ininumdict, int *start, int *end)
+{
+	if (L < 1 || L > 256 || !start || !end) return MCOM_E_ARG;
+	int len[MAXDICT], st[MAXDICT];
+	const int nd = dict_layout(L, ininumdict, st, len);
+	for (int i = 0; i < nd; ++i) { start[i] = st[i]; end[i] = st[i] + len[i] - 1; }
+	return nd;
+}
+
+// bits [2*start, 2*start + 2*len) of a packed row
+__device__ __forceinline__ uint64_t bits_key(const uint64_t *w, int start, int len)
+{
+	const int bo = 2 * start, wi = bo >> 6, sh = bo & 63;
+	uint64_t v = w[wi] >> sh;
+	if (sh && sh + 2 * len > 64) v |= w[wi + 1] << (64 - sh);
+	return v & ((1ull << (2 * len)) - 1);
+}
+__device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t log2cap)
+{
+	return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap));
+}
+
+// ---- gather packed rows of the singletons ------------------------------------------------------------
+__global__ void k_gather_rows(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ rids, size_t n, int W,
+                              uint64_t *__restrict__ out)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n * (size_t)W) return;
+	const size_t i = t / W; const int q = (int)(t - i * W);
+	out[t] = packed[(size_t)rids[i] * W + q];
+}
+
+extern "C" int mcom_gather_rows(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L, uint64_t *d_out)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_packed || !d_rids || !d_out || L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad gather arguments");
+	const int W = mcom_words_per_read(L);
+	const size_t tot = n * (size_t)W;
+	hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d_rids, n, W, d_out);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ---- near-poly-A / poly-T filter of singleRead2bitset (bbhashdict.c:157-222) -----------------------
+// flag 1: goes to the A list, 2: to the T list, 0: stays.  The 2-bit distance is the popcount against
+// all-A (zero) / all-T (ones); the text length is taken on the read with its N restored.
+__device__ __forceinline__ int ndigits_dev(int v) { return v >= 100 ? 3 : (v >= 10 ? 2 : 1); }
+
+__global__ void k_poly_filter(const uint64_t *__restrict__ bits, const uint64_t *__restrict__ nmask, const uint32_t *__restrict__ rids,
+                              size_t n, int L, int W, int NW, int thr, uint8_t *__restrict__ flag)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t *b = bits + i * (size_t)W;
+	int dA = 0, dT = 0;
+	for (int q = 0; q < W; ++q) {
+		const int nb = (2 * L - 64 * q) < 64 ? (2 * L - 64 * q) : 64;
+		const uint64_t m = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
+		dA += __popcll(b[q]); dT += __popcll((~b[q]) & m);
+	}
+	uint8_t f = 0;
+	const bool nearA = dA <= thr, nearT = !nearA && dT <= thr;
+	if (nearA || nearT) {
+		const uint32_t want = nearA ? 0u : 3u;
+		const uint64_t *nm = nmask ? nmask + (size_t)rids[i] * NW : nullptr;
+		int len = 0, eq = 0;
+		for (int t = 0; t < L; ++t) {
+			const uint32_t c = (uint32_t)(b[t >> 5] >> (2 * (t & 31))) & 3u;
+			const bool isn = nm && ((nm[t >> 6] >> (t & 63)) & 1);
+			if (isn || c != want) { if (eq > 0) { len += ndigits_dev(eq); eq = 0; } ++len; }
+			else ++eq;
+		}
+		if (len == 0) len = 1;
+		if ((double)len <= (double)L * 0.4) f = nearA ? 1 : 2;
+	}
+	flag[i] = f;
+}
+
+extern "C" int mcom_poly_filter(mcom_ctx *ctx, const uint64_t *d_sgbits, const uint64_t *d_nmask, const uint32_t *d_rids,
+                                size_t n_sg, int L, int thr, uint8_t *d_flag)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_sg == 0) return MCOM_OK;
+	if (!d_sgbits || !d_flag || L < 1 || L > 256 || (d_nmask && !d_rids)) return mcom_fail(ctx, MCOM_E_ARG, "bad poly filter arguments");
+	hipLaunchKernelGGL(k_poly_filter, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d_nmask, d_rids, n_sg, L,
+	                   mcom_words_per_read(L), (L + 63) / 64, thr, d_flag);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ---- dictionary build ------------------------------------------------------------------------------------
+__global__ void k_dict_keys(const uint64_t *__restrict__ bits, size_t n, int W, int start, int len, mcom_mm128 *__restrict__ rec)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	mcom_mm128 r; r.x = bits_key(bits + i * (size_t)W, start, len); r.y = i;
+	rec[i] = r;
+}
+__global__ void k_dict_heads(const mcom_mm128 *__restrict__ s, size_t n, uint32_t *__restrict__ head, uint32_t *__restrict__ ids)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	head[i] = (i == 0 || s[i].x != s[i - 1].x) ? 1u : 0u;
+	ids[i] = (uint32_t)s[i].y;
+}
+__global__ void k_dict_insert(const mcom_mm128 *__restrict__ s, size_t n, const uint32_t *__restrict__ hpre, uint64_t *__restrict__ slots,
+                              uint32_t log2cap, uint32_t *__restrict__ meta /* [0]=numkeys, [1]=maxbin */)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint64_t key = s[i].x;
+	if (i > 0 && s[i - 1].x == key) return;               // only run heads insert
+	size_t e = i + 1;                                       // run length by forward scan (bins are short; long runs are rare)
+	while (e < n && s[e].x == key) ++e;
+	const uint32_t cnt = (uint32_t)(e - i);
+	const uint32_t capm = (1u << log2cap) - 1u;
+	uint32_t sl = slot_of(key, log2cap);
+	for (;;) {
+		const unsigned long long prev = atomicCAS((unsigned long long*)&slots[2 * (size_t)sl], ~0ull, (unsigned long long)key);
+		if (prev == ~0ull) break;
+		sl = (sl + 1) & capm;
+	}
+	slots[2 * (size_t)sl + 1] = (uint64_t)i | ((uint64_t)cnt << 32);
+	atomicMax(&meta[1], cnt);
+	if (e == n) meta[0] = hpre[i] + 1;                      // exclusive prefix of heads at the last head + 1
+}
+
+extern "C" void mcom_dicts_free(mcom_ctx *ctx, mcom_dicts *d)
+{
+	if (!d) return;
+	if (ctx) (void)hipStreamSynchronize(ctx->stream);
+	for (int j = 0; j < MAXDICT; ++j) { if (d->slots[j]) (void)hipFree(d->slots[j]); if (d->ids[j]) (void)hipFree(d->ids[j]); }
+	delete d;
+}
+
+extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, mcom_dicts **out)
+{
+	if (!ctx || !out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range", L);
+	if (n_sg && !d_sgbits) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_sg >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons");
+	mcom_dicts *d = new mcom_dicts();
+	std::memset(d, 0, sizeof *d);
+	d->L = L; d->W = mcom_words_per_read(L); d->n_sg = n_sg;
+	d->nd = dict_layout(L, ininumdict, d->ds, d->kl);
+	const size_t n = n_sg;
+	// workspace: records + sort workspace + heads + scan scratch + meta
+	const size_t rec_b = ((n * sizeof(mcom_mm128)) + 255) & ~(size_t)255;
+	const size_t sort_b = mcom_sort_ws_bytes(n);
+	const size_t head_b = ((n * 4) + 255) & ~(size_t)255;
+	const size_t scr_b = ((mcom_scan_scratch_elems(n) * 4 + 1024) + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, rec_b + sort_b + head_b + scr_b + 256);
+	if (rc) { delete d; return rc; }
+	char *base = (char*)ctx->ws;
+	mcom_mm128 *rec = (mcom_mm128*)base;
+	void *sortws = base + rec_b;
+	uint32_t *head = (uint32_t*)(base + rec_b + sort_b);
+	uint32_t *scr = (uint32_t*)(base + rec_b + sort_b + head_b);
+	uint32_t *meta = (uint32_t*)(base + rec_b + sort_b + head_b + scr_b);
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+	for (int j = 0; j < d->nd; ++j) {
+		uint32_t lg = 4;
+		while ((1ull << lg) < 2 * n + 16) ++lg;
+		d->log2cap[j] = lg;
+		hipError_t e1 = hipMalloc(&d->slots[j], (size_t)16 << lg);
+		hipError_t e2 = hipMalloc(&d->ids[j], (n ? n : 1) * 4);
+		if (e1 != hipSuccess || e2 != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
+		hipError_t e = hipMemsetAsync(d->slots[j], 0xFF, (size_t)16 << lg, ctx->stream);
+		if (e != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "memset: %s", hipGetErrorString(e)); }
+		if (n == 0) continue;
+		hipLaunchKernelGGL(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
+		rc = mcom_sort_by_x(ctx, rec, n, 2 * d->kl[j], sortws);
+		if (rc) { mcom_dicts_free(ctx, d); return rc; }
+		hipLaunchKernelGGL(k_dict_heads, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, head, d->ids[j]);
+		rc = mcom_scan_u32(ctx, head, head, n, scr);
+		if (rc) { mcom_dicts_free(ctx, d); return rc; }
+		(void)hipMemsetAsync(meta, 0, 8, ctx->stream);
+		hipLaunchKernelGGL(k_dict_insert, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, head, d->slots[j], lg, meta);
+		uint32_t hm[2] = {0, 0};
+		hipError_t e3 = hipMemcpyAsync(hm, meta, 8, hipMemcpyDeviceToHost, ctx->stream);
+		if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+		if (e3 != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "dictionary %d: %s", j, hipGetErrorString(e3)); }
+		d->numkeys[j] = hm[0]; d->maxbin[j] = hm[1];
+	}
+	hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "dict build: %s", hipGetErrorString(e)); }
+	*out = d;
+	return MCOM_OK;
+}
+
+extern "C" int mcom_dicts_info(const mcom_dicts *d, int *nd, uint32_t *numkeys, uint32_t *maxbin)
+{
+	if (!d) return MCOM_E_ARG;
+	if (nd) *nd = d->nd;
+	for (int j = 0; j < d->nd; ++j) { if (numkeys) numkeys[j] = d->numkeys[j]; if (maxbin) maxbin[j] = d->maxbin[j]; }
+	return MCOM_OK;
+}
+
+// ---- batched lookup (bphf->lookup + findpos on an untouched dictionary, bbhashdict.c:33-43) ----------
+__device__ __forceinline__ bool dict_find(const uint64_t *slots, uint32_t log2cap, uint64_t key, uint32_t &start, uint32_t &count)
+{
+	const uint32_t capm = (1u << log2cap) - 1u;
+	uint32_t sl = slot_of(key, log2cap);
+	for (;;) {
+		const uint64_t k = slots[2 * (size_t)sl];
+		if (k == key) { const uint64_t v = slots[2 * (size_t)sl + 1]; start = (uint32_t)v; count = (uint32_t)(v >> 32); return true; }
+		if (k == ~0ull) return false;
+		sl = (sl + 1) & capm;
+	}
+}
+__global__ void k_dict_lookup(const uint64_t *__restrict__ slots, uint32_t log2cap, const uint64_t *__restrict__ keys, size_t n,
+                              uint32_t *__restrict__ start, uint32_t *__restrict__ count)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = 0, c = 0;
+	dict_find(slots, log2cap, keys[i], s, c);
+	start[i] = s; count[i] = c;
+}
+extern "C" int mcom_dicts_lookup(mcom_ctx *ctx, const mcom_dicts *d, int dict, const uint64_t *d_keys, size_t n,
+                                 uint32_t *d_start, uint32_t *d_count)
+{
+	if (!ctx || !d) return MCOM_E_ARG;
+	if (dict < 0 || dict >= d->nd) return mcom_fail(ctx, MCOM_E_ARG, "dictionary %d out of range", dict);
+	if (n == 0) return MCOM_OK;
+	hipLaunchKernelGGL(k_dict_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d->slots[dict], d->log2cap[dict], d_keys, n, d_start, d_count);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+extern "C" int mcom_dicts_ids(mcom_ctx *ctx, const mcom_dicts *d, int dict, uint32_t *d_ids_out)
+{
+	if (!ctx || !d) return MCOM_E_ARG;
+	if (dict < 0 || dict >= d->nd) return mcom_fail(ctx, MCOM_E_ARG, "dictionary %d out of range", dict);
+	if (d->n_sg) MCOM_HIP(ctx, hipMemcpyAsync(d_ids_out, d->ids[dict], d->n_sg * 4, hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
+// ---- window scan ---------------------------------------------------------------------------------------------
+// reverse the order of the 32 bases of a word (2-bit groups)
+__device__ __forceinline__ uint64_t rev_groups(uint64_t x)
+{
+	x = __brevll(x);                                                     // reverses bits: groups reversed, bits inside a group swapped
+	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+
+// encode_byte's length estimate from a per-base mismatch mask (kthread_hash_realign.c:283-314); rev: walk
+// the window from its last base to its first (the reference reverse-complements the read instead)
+template <int W>
+__device__ __forceinline__ bool encode_ok(const uint64_t (&mm)[W], int L, bool rev)
+{
+	int len = 0, eq = 0;
+	for (int t = 0; t < L; ++t) {
+		const int p = rev ? L - 1 - t : t;
+		const bool mis = (mm[p >> 5] >> (2 * (p & 31))) & 1;
+		if (mis) { if (eq > 1) { len += ndigits_dev(eq); eq = 0; } else len += eq; ++len; }
+		else ++eq;
+	}
+	if (len == 0) len = 1;
+	return (double)len <= (double)L * 0.4;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_realign_windows(DictDev dd, const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
+                                                         const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
+                                                         const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_windows,
+                                                         int thr, int maxsearch, unsigned long long *__restrict__ claim,
+                                                         unsigned long long *__restrict__ stats)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_windows) return;
+	// contig of this window: last c with woff[c] <= g
+	uint32_t lo = 0, hi = n_contigs;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (woff[mid] <= g) lo = mid; else hi = mid; }
+	const uint32_t c = lo;
+	const uint64_t jj = g - woff[c];
+	const int L = dd.L;
+	// window bits
+	uint64_t win[W], rwin[W];
+	{
+		const uint64_t *src = cbits + coff[c] + ((2 * jj) >> 6);
+		const int sh = (int)((2 * jj) & 63);
+		uint64_t cur = src[0];
+#pragma unroll
+		for (int q = 0; q < W; ++q) {
+			// the last source word may lie beyond the window's own bits but is inside the contig's padded storage
+			const uint64_t nxt = src[q + 1];
+			win[q] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
+			cur = nxt;
+		}
+		const int tail = 2 * L - 64 * (W - 1);
+		if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+		// reverse complement: reverse all 32*W groups, complement, then drop the 32*W - L leading pad groups
+		uint64_t t[W];
+#pragma unroll
+		for (int q = 0; q < W; ++q) t[q] = ~rev_groups(win[W - 1 - q]);
+		const int drop = 64 * W - 2 * L;                                 // < 64
+#pragma unroll
+		for (int q = 0; q < W; ++q) {
+			const uint64_t a = t[q], b = q + 1 < W ? t[q + 1] : 0ull;
+			rwin[q] = drop ? (a >> drop) | (b << (64 - drop)) : a;
+		}
+		if (tail < 64) rwin[W - 1] &= (1ull << tail) - 1;
+	}
+	unsigned long long n_look = 0, n_hit = 0, n_cand = 0;
+	for (int dir = 0; dir < 2; ++dir) {
+		const uint64_t *q = dir ? rwin : win;
+		for (int l = 0; l < dd.nd; ++l) {
+			if (dir && dd.ds[l] <= 0) continue;                          // kthread_hash_realign.c:440
+			++n_look;
+			const uint64_t key = bits_key(q, dd.ds[l], dd.kl[l]);
+			uint32_t start, count;
+			if (!dict_find(dd.slots[l], dd.log2cap[l], key, start, count)) continue;
+			++n_hit;
+			const uint32_t nscan = count < (uint32_t)maxsearch ? count : (uint32_t)maxsearch;
+			const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+			for (uint32_t u = 0; u < nscan; ++u) {
+				const uint32_t sg = dd.ids[l][start + count - 1 - u];     // from the bin's end, descending (:388)
+				if (sgflag[sg]) continue;
+				++n_cand;
+				const uint64_t *rb = sgbits + (size_t)sg * W;
+				uint64_t mm[W]; int dist = 0;
+#pragma unroll
+				for (int w = 0; w < W; ++w) { const uint64_t x = q[w] ^ rb[w]; dist += __popcll(x); mm[w] = (x | (x >> 1)) & 0x5555555555555555ull; }
+				if (dist > thr) continue;
+				if (!dir) { if (!encode_ok<W>(mm, L, false)) continue; }                         // :393
+				else if (thr > 24 && !encode_ok<W>(mm, L, true)) continue;                      // :461
+				atomicMin(&claim[sg], ck);
+			}
+		}
+	}
+	if (stats) {
+		// wave-level reduction would be cheaper; these are diagnostics only
+		atomicAdd(&stats[0], n_look); if (n_hit) atomicAdd(&stats[1], n_hit); if (n_cand) atomicAdd(&stats[2], n_cand);
+	}
+}
+
+__global__ void k_window_counts(const uint32_t *__restrict__ clen, uint32_t n, int L, uint32_t *__restrict__ cnt)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cnt[i] = clen[i] >= (uint32_t)L ? clen[i] - (uint32_t)L + 1 : 0u;
+}
+
+extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, const uint8_t *d_sgflag,
+                                 const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                 uint64_t n_windows, int thr, int maxsearch, uint64_t *d_claim, uint64_t *d_stats)
+{
+	if (!ctx || !d) return MCOM_E_ARG;
+	if (d->n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, d->n_sg * 8, ctx->stream));
+	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+	if (n_windows == 0 || n_contigs == 0 || d->n_sg == 0) return MCOM_OK;
+	if (!d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_contigs >= (1u << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the claim key");
+	DictDev dd; std::memset(&dd, 0, sizeof dd);
+	dd.nd = d->nd; dd.W = d->W; dd.L = d->L;
+	for (int j = 0; j < d->nd; ++j) { dd.ds[j] = d->ds[j]; dd.kl[j] = d->kl[j]; dd.slots[j] = d->slots[j]; dd.log2cap[j] = d->log2cap[j]; dd.ids[j] = d->ids[j]; }
+	const uint64_t blocks = (n_windows + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many windows for one launch");
+#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_windows<WW>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dd, d_sgbits, d_sgflag, d_cbits, d_coff, d_woff, n_contigs, n_windows, thr, maxsearch, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
+	switch (d->W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_CASE
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

@@ -232,6 +232,20 @@ static size_t sort_ws_layout(size_t n, SortWs *w, char *base)
 	return off;
 }
 
+// internal: stable sort of records by the low `bits` bits of x; ws must hold mcom_sort_ws_bytes(n) bytes.
+size_t mcom_sort_ws_bytes(size_t n) { return sort_ws_layout(n, nullptr, nullptr); }
+int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws)
+{
+	if (n == 0) return MCOM_OK;
+	SortWs w; sort_ws_layout(n, &w, (char*)ws);
+	KeySpec ks{0, 0, 64, 0, 0};
+	mcom_mm128 *res = nullptr;
+	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
+	if (rc) return rc;
+	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
 // a5: radix_sort_128x (misc.c:22).  Stable, so equal keys keep their input order; the reference is stable
 // only up to 64 elements (ksort.h:155) and leaves equal keys of larger arrays in an order that depends on
 // its in-place cycle walk.

@@ -58,6 +58,16 @@ def load_library():
     L.mcom_radix_sort_128x.restype = i32; L.mcom_radix_sort_128x.argtypes = [vp, vp, sz]
     L.mcom_sort_group.restype = i32
     L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.mcom_dict_layout.restype = i32; L.mcom_dict_layout.argtypes = [i32, i32, vp, vp]
+    L.mcom_gather_rows.restype = i32; L.mcom_gather_rows.argtypes = [vp, vp, vp, sz, i32, vp]
+    L.mcom_poly_filter.restype = i32; L.mcom_poly_filter.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp]
+    L.mcom_dicts_build.restype = i32; L.mcom_dicts_build.argtypes = [vp, vp, sz, i32, i32, C.POINTER(vp)]
+    L.mcom_dicts_free.restype = None; L.mcom_dicts_free.argtypes = [vp, vp]
+    L.mcom_dicts_info.restype = i32; L.mcom_dicts_info.argtypes = [vp, C.POINTER(i32), vp, vp]
+    L.mcom_dicts_lookup.restype = i32; L.mcom_dicts_lookup.argtypes = [vp, vp, i32, vp, sz, vp, vp]
+    L.mcom_dicts_ids.restype = i32; L.mcom_dicts_ids.argtypes = [vp, vp, i32, vp]
+    L.mcom_realign_pass.restype = i32
+    L.mcom_realign_pass.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u64, i32, i32, vp, vp]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
     _lib = L
@@ -167,6 +177,35 @@ class Context:
         return {"sorted": srt, "n_valid": nv, "singles": singles[:ns], "members": members[:nm], "group_off": goff[:ng + 1] if n else goff[:0],
                 "n_groups": ng}
 
+    # -- Stage 2
+    def gather_rows(self, packed, rids, L: int):
+        torch = _torch()
+        n = int(rids.shape[0])
+        out = torch.empty((n, words_per_read(L)), dtype=torch.int64, device=self.device)
+        self._check(self.lib.mcom_gather_rows(self._h, self._p(packed, torch.int64), self._p(rids, torch.int32), n, L, self._p(out)))
+        return out
+
+    def poly_filter(self, sgbits, L: int, thr: int, nmask=None, rids=None):
+        torch = _torch()
+        n = int(sgbits.shape[0])
+        flag = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mcom_poly_filter(self._h, self._p(sgbits, torch.int64), self._p(nmask), self._p(rids), n, L, thr, self._p(flag)))
+        return flag
+
+    def dicts_build(self, sgbits, L: int, ininumdict: int = 0):
+        return Dicts(self, sgbits, L, ininumdict)
+
+    def realign_pass(self, dicts, sgbits, sgflag, cbits, coff, woff, n_windows: int, thr: int, maxsearch: int, stats: bool = False):
+        """mcom_realign_pass.  Returns (claim int64 [n_sg], stats tensor or None)."""
+        torch = _torch()
+        n_sg = int(sgbits.shape[0])
+        claim = torch.empty(max(n_sg, 1), dtype=torch.int64, device=self.device)
+        st = torch.zeros(3, dtype=torch.int64, device=self.device) if stats else None
+        self._check(self.lib.mcom_realign_pass(self._h, dicts._h, self._p(sgbits, torch.int64), self._p(sgflag, torch.uint8),
+                                               self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
+                                               int(coff.shape[0]), int(n_windows), thr, maxsearch, self._p(claim), self._p(st)))
+        return claim[:n_sg], st
+
     def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,
                     first: int = 0, count: int | None = None, pitch: int | None = None):
         torch = _torch()
@@ -176,6 +215,89 @@ class Context:
         out = torch.empty((count, pitch), dtype=torch.uint8, device=self.device)
         self._check(self.lib.mcom_synth_reads(self._h, seed, n_reads, L, coverage, sub_rate, first, count, self._p(out), pitch))
         return out
+
+
+class Dicts:
+    """Device-resident Stage-2 dictionaries (mcom_dicts)."""
+
+    def __init__(self, ctx: Context, sgbits, L: int, ininumdict: int = 0):
+        torch = _torch()
+        self.ctx = ctx
+        self.n_sg = int(sgbits.shape[0])
+        h = C.c_void_p()
+        ctx._check(ctx.lib.mcom_dicts_build(ctx._h, ctx._p(sgbits, torch.int64), self.n_sg, L, ininumdict, C.byref(h)))
+        self._h = h
+        nd = C.c_int()
+        nk = (C.c_uint32 * 16)(); mb = (C.c_uint32 * 16)()
+        ctx._check(ctx.lib.mcom_dicts_info(self._h, C.byref(nd), nk, mb))
+        self.nd = nd.value
+        self.numkeys = [int(nk[i]) for i in range(self.nd)]
+        self.maxbin = [int(mb[i]) for i in range(self.nd)]
+
+    def lookup(self, dict_idx: int, keys):
+        torch = _torch()
+        n = int(keys.shape[0])
+        start = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        count = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        self.ctx._check(self.ctx.lib.mcom_dicts_lookup(self.ctx._h, self._h, dict_idx, self.ctx._p(keys, torch.int64), n,
+                                                       self.ctx._p(start), self.ctx._p(count)))
+        return start, count
+
+    def ids(self, dict_idx: int):
+        torch = _torch()
+        out = torch.empty(max(self.n_sg, 1), dtype=torch.int32, device=self.ctx.device)
+        self.ctx._check(self.ctx.lib.mcom_dicts_ids(self.ctx._h, self._h, dict_idx, self.ctx._p(out)))
+        return out[: self.n_sg]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.mcom_dicts_free(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dict_layout(L: int, ininumdict: int = 0):
+    """mcom_dict_layout (host only): (start[], end[]) of the dictionary keys."""
+    lib = load_library()
+    st = (C.c_int * 16)(); en = (C.c_int * 16)()
+    nd = lib.mcom_dict_layout(L, ininumdict, st, en)
+    if nd < 0:
+        raise McomError("mcom_dict_layout failed")
+    return [st[i] for i in range(nd)], [en[i] for i in range(nd)]
+
+
+def pack_nt4(reads: np.ndarray) -> np.ndarray:
+    """Host statement of the packed-row format of include/mcom.h for ACGT-only rows (tests, host driver)."""
+    n, L = reads.shape
+    W = words_per_read(L)
+    code = ((reads >> 1) ^ (reads >> 2)) & 3
+    out = np.zeros((n, W), dtype=np.uint64)
+    for i in range(L):
+        out[:, i // 32] |= code[:, i].astype(np.uint64) << np.uint64(2 * (i % 32))
+    return out
+
+
+def pack_contigs(refs) -> tuple:
+    """Packs contig strings (bytes, ACGT) as mcom_realign_pass wants them: returns (cbits u64, coff u64, clen u32)."""
+    coff = np.zeros(len(refs), dtype=np.uint64)
+    clen = np.array([len(r) for r in refs], dtype=np.uint32)
+    words = [(2 * int(l) + 63) // 64 + 1 for l in clen]          # one padding word after every contig
+    total = int(sum(words)) + 1
+    cbits = np.zeros(total, dtype=np.uint64)
+    o = 0
+    for i, r in enumerate(refs):
+        coff[i] = o
+        a = np.frombuffer(r, dtype=np.uint8)
+        code = (((a >> 1) ^ (a >> 2)) & 3).astype(np.uint64)
+        sh = (2 * (np.arange(len(a)) % 32)).astype(np.uint64)
+        np.bitwise_or.at(cbits, o + np.arange(len(a)) // 32, code << sh)
+        o += words[i]
+    return cbits, coff, clen
 
 
 def records_to_numpy(rec) -> np.ndarray:

@@ -66,6 +66,7 @@ def lib():
     L.mcomo_contig_n.restype = sz; L.mcomo_contig_n.argtypes = [vp, sz]
     L.mcomo_contig_members.restype = vp; L.mcomo_contig_members.argtypes = [vp, sz]
     L.mcomo_counter.restype = sz; L.mcomo_counter.argtypes = [vp, cp]
+    L.mcomo_list.restype = vp; L.mcomo_list.argtypes = [vp, cp, C.POINTER(sz)]
     L.mcomo_synth_reads.restype = None
     L.mcomo_synth_reads.argtypes = [u64, u64, i32, i32, C.c_double, u64, u64, vp]
     _lib = L
@@ -204,6 +205,11 @@ class Pipeline:
     def sg(self): return self._arr(lib().mcomo_sg(self._h), np.uint32, lib().mcomo_n_sg(self._h))
     @property
     def sg_flag(self): return self._arr(lib().mcomo_sg_flag(self._h), np.uint8, lib().mcomo_n_sg(self._h))
+
+    def id_list(self, name: str) -> np.ndarray:
+        n = C.c_size_t()
+        p = lib().mcomo_list(self._h, name.encode(), C.byref(n))
+        return self._arr(p, np.uint32, n.value)
 
     def contigs(self):
         out = []

@@ -1063,3 +1063,15 @@ void mcomo_synth_reads(uint64_t seed, uint64_t n_reads, int L, int coverage, dou
 		}
 	}
 }
+
+/* named id lists: allA allT allN fpA fpT fpN Nfile sg */
+const uint32_t *mcomo_list(const mcomo_ctx *c, const char *name, size_t *n)
+{
+	const v32 *v = 0;
+	if (!strcmp(name, "allA")) v = &c->allA; else if (!strcmp(name, "allT")) v = &c->allT; else if (!strcmp(name, "allN")) v = &c->allN;
+	else if (!strcmp(name, "fpA")) v = &c->fpA; else if (!strcmp(name, "fpT")) v = &c->fpT; else if (!strcmp(name, "fpN")) v = &c->fpN;
+	else if (!strcmp(name, "Nfile")) v = &c->Nfile; else if (!strcmp(name, "sg")) v = &c->sg;
+	if (!v) { *n = 0; return 0; }
+	*n = v->n;
+	return v->a;
+}

@@ -93,6 +93,7 @@ const char *mcomo_contig_ref(const mcomo_ctx *c, size_t i);
 size_t mcomo_contig_n(const mcomo_ctx *c, size_t i);
 const uint64_t *mcomo_contig_members(const mcomo_ctx *c, size_t i);
 size_t mcomo_counter(const mcomo_ctx *c, const char *name);
+const uint32_t *mcomo_list(const mcomo_ctx *c, const char *name, size_t *n);
 
 /* ---- synthetic reads (same generator as minicom_amd/synth.py, plumbing=False) ------------------ */
 void mcomo_synth_reads(uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,

@@ -1,0 +1,178 @@
+"""GPU parity: Stage-2 dictionaries + window scan (mcom_dicts_*, mcom_poly_filter, mcom_realign_pass)
+against the oracle's sequential realign pass, which is pinned to the reference dumps."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MAXU = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import minicom_amd
+    c = minicom_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _golden_reads(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, tag + ".reads.gz"), "rb") as f:
+        rows = f.read().split(b"\n")[:-1]
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+
+
+def _stage1(reads, **kw):
+    import oracle
+    p = oracle.Pipeline(reads, **kw)
+    p.stage_reads(); p.stage_bucket(); p.stage_combine()
+    return p
+
+
+def _gpu_pass(ctx, p, reads_orig, thr, check_dicts=False):
+    """One Stage-2 pass on the GPU from the oracle's pre-pass state; returns (flags, appended members per contig)."""
+    import torch
+    from minicom_amd.hip import pack_nt4, pack_contigs
+    L = p.L
+    p.update_single()
+    sg = p.sg
+    seq = p.seq                                             # N substituted for kept reads
+    keep = p.cls == 0
+    packed = np.zeros((p.n, (2 * L + 63) // 64), dtype=np.uint64)
+    packed[keep] = pack_nt4(seq[keep])
+    d_packed = torch.from_numpy(packed.view(np.int64)).cuda()
+    nmask = np.zeros((p.n, (L + 63) // 64), dtype=np.uint64)
+    isn = reads_orig == ord("N")
+    for w in range(nmask.shape[1]):
+        seg = isn[:, 64 * w: 64 * (w + 1)]
+        nmask[:, w] = (seg.astype(np.uint64) << np.arange(seg.shape[1], dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+    d_nmask = torch.from_numpy(nmask.view(np.int64)).cuda()
+    d_sg = torch.from_numpy(sg.astype(np.int32)).cuda()
+    sgbits = ctx.gather_rows(d_packed, d_sg, L)
+    flag = ctx.poly_filter(sgbits, L, thr, nmask=d_nmask, rids=d_sg)
+    dicts = ctx.dicts_build(sgbits, L)
+    contigs = p.contigs()
+    refs = [r for r, _ in contigs]
+    cbits, coff, clen = pack_contigs(refs)
+    nwin = np.maximum(clen.astype(np.int64) - L + 1, 0)
+    woff = np.concatenate([[0], np.cumsum(nwin)[:-1]]).astype(np.uint64) if len(nwin) else np.zeros(0, np.uint64)
+    maxsearch = p.counter("maxsearch")
+    claim, st = ctx.realign_pass(dicts, sgbits, flag, torch.from_numpy(cbits.view(np.int64)).cuda(),
+                                 torch.from_numpy(coff.view(np.int64)).cuda(), torch.from_numpy(woff.view(np.int64)).cuda(),
+                                 int(nwin.sum()), thr, maxsearch, stats=True)
+    ctx.sync()
+    if check_dicts:
+        _check_dicts(ctx, dicts, sgbits.cpu().numpy().view(np.uint64), L)
+    claim = claim.cpu().numpy().view(np.uint64)
+    flag = flag.cpu().numpy()
+    assert max(dicts.maxbin) <= maxsearch, "fixture has a bin above maxsearch: the parallel claim rule is not exact there"
+    claimed = claim != MAXU
+    # appended members per contig, reference order: claim key ascending, singleton index descending
+    order = np.lexsort((-np.arange(len(sg)), claim))
+    order = order[claimed[order]]
+    app = {}
+    for i in order:
+        ck = int(claim[i])
+        c, jj, d = ck >> 33, (ck >> 5) & ((1 << 28) - 1), (ck >> 4) & 1
+        app.setdefault(c, []).append((int(sg[i]) << 32) | (jj << 1) | d)
+    dicts.close()
+    return flag, claimed, app, [len(m) for _, m in contigs], st.cpu().numpy()
+
+
+def _check_dicts(ctx, dicts, sgbits, L):
+    """mcom_dicts_lookup / ids against a numpy statement of constructdictionary_realign's CSR layout."""
+    import torch
+    from minicom_amd.hip import dict_layout
+    st, en = dict_layout(L)
+    assert dicts.nd == len(st)
+    for j in range(dicts.nd):
+        bo, kl = 2 * st[j], en[j] - st[j] + 1
+        wi, sh = bo >> 6, bo & 63
+        key = sgbits[:, wi] >> np.uint64(sh)
+        if sh and sh + 2 * kl > 64:
+            key = key | (sgbits[:, wi + 1] << np.uint64(64 - sh))
+        key = key & np.uint64((1 << (2 * kl)) - 1)
+        order = np.argsort(key, kind="stable")
+        assert np.array_equal(dicts.ids(j).cpu().numpy().view(np.uint32), order.astype(np.uint32))
+        uk, first, cnt = np.unique(key, return_index=True, return_counts=True)
+        assert dicts.numkeys[j] == len(uk) and dicts.maxbin[j] == cnt.max()
+        sk = key[order]
+        starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+        probe = np.concatenate([uk, uk ^ np.uint64(1), np.array([0, (1 << (2 * kl)) - 1], dtype=np.uint64)])
+        s, c = dicts.lookup(j, torch.from_numpy(probe.view(np.int64)).cuda())
+        s, c = s.cpu().numpy(), c.cpu().numpy()
+        have = dict(zip(uk.tolist(), zip(starts.tolist(), cnt.tolist())))
+        for q, kq in enumerate(probe.tolist()):
+            if kq in have:
+                assert (int(s[q]), int(c[q])) == have[kq]
+            else:
+                assert int(c[q]) == 0
+
+
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_every_realign_pass_matches_sequential_reference_semantics(ctx, golden_dir, tag):
+    """All passes of Stage 2 on the reference fixture reads: flags and the members appended to every contig,
+    in order, equal the sequential scan (itself byte-identical to the reference dump)."""
+    reads = _golden_reads(golden_dir, tag)
+    L = reads.shape[1]
+    p = _stage1(reads)
+    thr, step, pre, npass = 4, 4, 0, 0
+    while thr <= L // 2:
+        flag, claimed, app, nbefore, st = _gpu_pass(ctx, p, reads, thr, check_dicts=(npass == 0))
+        fa0, ft0 = len(p.id_list("fpA")), len(p.id_list("fpT"))
+        cr = p.realign_pass(thr)                                  # oracle, sequential
+        want_flag = p.sg_flag
+        assert np.array_equal((flag != 0) | claimed, want_flag != 0)
+        sg = p.sg
+        assert np.array_equal(sg[flag == 1], p.id_list("fpA")[fa0:])
+        assert np.array_equal(sg[flag == 2], p.id_list("fpT")[ft0:])
+        after = p.contigs()
+        n_app = 0
+        for c, (_, mem) in enumerate(after):
+            got = app.get(c, [])
+            assert [int(v) for v in mem[nbefore[c]:]] == got, (tag, thr, c)
+            n_app += len(got)
+        assert n_app == int(claimed.sum())
+        assert st[0] > 0 and st[1] > 0 and st[2] >= n_app
+        npass += 1
+        if cr - pre < 1000:
+            break
+        pre = cr; thr += step
+    assert npass >= 2
+
+
+def test_realign_high_threshold_uses_cost_filter_on_reverse_strand(ctx):
+    """thr > 24 switches encode_byte on for reverse-strand candidates (kthread_hash_realign.c:461)."""
+    from minicom_amd import synth
+    reads = synth.synth_reads(31337, 4000, 100, sub_rate=0.03)
+    p = _stage1(reads)
+    for thr in (4, 28, 40):
+        flag, claimed, app, nbefore, _ = _gpu_pass(ctx, p, reads, thr)
+        p.realign_pass(thr)
+        assert np.array_equal((flag != 0) | claimed, p.sg_flag != 0)
+        for c, (_, mem) in enumerate(p.contigs()):
+            assert [int(v) for v in mem[nbefore[c]:]] == app.get(c, []), (thr, c)
+    assert claimed.sum() > 0
+
+
+def test_realign_empty_inputs(ctx):
+    import torch
+    z64 = torch.zeros((0, 5), dtype=torch.int64, device="cuda")
+    d = ctx.dicts_build(z64, 150)
+    assert d.nd == 8 and d.numkeys == [0] * 8
+    claim, _ = ctx.realign_pass(d, z64, torch.zeros(0, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"),
+                                torch.zeros(0, dtype=torch.int64, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 0, 4, 500)
+    assert claim.numel() == 0
+    d.close()
+
+
+def test_dict_layout_matches_oracle():
+    import oracle
+    from minicom_amd.hip import dict_layout
+    for L in (37, 64, 80, 81, 100, 101, 150, 151, 256):
+        for nd in (0, 1, 2, 3, 5):
+            st, en = dict_layout(L, nd)
+            os_, oe = oracle.dict_layout(L, nd)
+            assert st == os_.tolist() and en == oe.tolist()
