@@ -91,6 +91,51 @@ int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int
                     mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
                     uint64_t *h_counts);
 
+/* ---- a3, a7..a9: contigs ------------------------------------------------------------------------- */
+/* Batched mm_sketch_lh_ori (sketch.c:116-165): the (w,k)-minimizers of n contigs.  Contig c is the ASCII
+ * string d_seq[d_off[c] .. d_off[c+1]) (ACGT, anything else is an ambiguous base that resets the run);
+ * its record id is d_ids[c] (NULL: c<<8, the reference's (index<<8)+tid at tid 0, kthread_bucket.c:458).
+ * max_per_contig > 0 keeps only the first that many (callers index the first m, kthread_bucket.c:463).
+ * Out: d_moff[n+1] = start of each contig's minimizers in d_out (position order), *h_total = their
+ * number.  MCOM_E_OVERFLOW (with *h_total set) when cap is too small.  1 <= w <= 128.  Synchronous.   */
+int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
+                        int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                        uint64_t *h_total);
+
+/* ASCII contigs -> the packed layout of mcom_realign_pass / mcom_match_pro: contig c occupies words
+ * [d_coff[c], d_coff[c] + ceil(2*len/64)] of d_cbits, the last one being the mandatory padding word
+ * (so d_coff[c+1] - d_coff[c] = ceil(2*len/64) + 1; total_words = their sum).  Non-ACGT packs as A.   */
+int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                      uint64_t total_words, uint64_t *d_cbits);
+
+/* mm_idx_init + mm_idx_generation (kthread_idx.c:77, :116-170): index over n minimizer records sketched
+ * with k.  Equal minimizers keep the order they were given in (the reference's bucket sort does too for
+ * buckets of <= 64 entries; above that its in-place radix sort permutes equal keys, ksort.h:132-144).
+ * mcom_idx_get = mm_idx_get (:84-101) for n minimizers: start/count into the index's sorted record array
+ * (count 0 = absent), which mcom_idx_records copies out.                                              */
+typedef struct mcom_idx mcom_idx;
+int  mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, mcom_idx **out);
+void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi);
+int  mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d_x, size_t n, uint32_t *d_start, uint32_t *d_count);
+int  mcom_idx_records(mcom_ctx *ctx, const mcom_idx *mi, mcom_mm128 *d_out, size_t *n);
+
+/* Batched match_pro (kthread_cb.c:36-52): mismatches over the whole overlap of contigs a[i], b[i] when
+ * base pos_a[i] of a is laid on base pos_b[i] of b.                                                   */
+int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen,
+                   const uint32_t *d_a, const uint32_t *d_pos_a, const uint32_t *d_b, const uint32_t *d_pos_b, size_t n,
+                   uint32_t *d_mismatch);
+
+/* Lookup part of find_next (kthread_cb.c:267-291) for all contigs at once.  d_query: every minimizer of
+ * every contig (mcom_sketch_contigs with max_per_contig 0), contig after contig.  For each query, in
+ * order, and each index hit, in index order, the pair passes when the hit belongs to another contig,
+ * has the same strand bit and match_pro <= cbthr.  d_out receives the passing pairs in that order as
+ * { x = query y (contig<<8 in the id, pos_ori, dir), y = hit y (other contig, pos, dir) }.  The merge
+ * flags (:286, :339) change while merging and stay with the caller.  h_counts = { pairs, passing }.
+ * MCOM_E_OVERFLOW when cap is too small.  Synchronous.                                                */
+int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
+                              const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
+                              mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
+
 /* ---- a10..a15: Stage-2 realignment --------------------------------------------------------------- */
 /* setglobalarrays_realign (kthread_hash_realign.c:153-206): first/last base of every dictionary key.
  * Host only.  Returns numdict_s (>= 1) or a negative status; start/end need room for 16 entries.    */

@@ -1,0 +1,390 @@
+// minicom_amd/csrc/contigs.hip -- contig-side kernels of Stage 1 for gfx950 (MI355X).
+//
+//   mcom_sketch_contigs     : mm_sketch_lh_ori, the minimap-style (w,k)-minimizers of a contig
+//                             (reference sketch.c:116-165), one thread per contig
+//   mcom_pack_contigs       : ASCII contigs -> 2-bit packed words (the layout mcom_realign_pass reads)
+//   mcom_idx_build / _get   : mm_idx_generation / mm_idx_get (kthread_idx.c:116-170, :84-101)
+//   mcom_match_pro          : match_pro (kthread_cb.c:36-52) on packed contigs, batched
+//   mcom_find_next_candidates: the lookup part of find_next (kthread_cb.c:267-291) for every contig
+#include "mcom_dev.hpp"
+#include <cstring>
+
+#define MAXW 128
+
+// A0 C1 G2 T3, anything else 4 (sketch.c:8-25 for the letters that occur)
+__device__ __forceinline__ int nt4_of(uint8_t ch)
+{
+	const uint8_t u = ch & 0xDF;                       // fold case
+	return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mm_sketch_lh_ori.  EMIT = false counts, EMIT = true writes; at most `limit` minimizers per contig.
+// The ring keeps (hash, pos<<1|strand) per slot; y = id<<32 | that.
+// ------------------------------------------------------------------------------------------------
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ ids, size_t n, int w, int k, uint32_t limit,
+                                                       uint32_t *__restrict__ cnt, const uint32_t *__restrict__ out_off,
+                                                       mcom_mm128 *__restrict__ out)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	const uint8_t *s = seq + off[t];
+	const int len = (int)(off[t + 1] - off[t]);
+	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
+	const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ull << (2 * k)) - 1;
+	uint64_t rx[MAXW]; uint32_t rp[MAXW];
+	for (int j = 0; j < w; ++j) { rx[j] = U64MAX; rp[j] = 0xFFFFFFFFu; }
+	uint64_t fwd = 0, rev = 0, bx = U64MAX; uint32_t bp = 0xFFFFFFFFu;
+	int run = 0, slot = 0, bslot = 0;
+	uint32_t ne = 0;
+	mcom_mm128 *o = EMIT ? out + out_off[t] : nullptr;
+#define PUT(X, P) do { if (ne < limit) { if (EMIT) { mcom_mm128 v_; v_.x = (X); v_.y = (X) == U64MAX && (P) == 0xFFFFFFFFu ? U64MAX : (idhi | (P)); o[ne] = v_; } } ++ne; } while (0)
+	for (int i = 0; i < len && ne < limit; ++i) {
+		const int c = nt4_of(s[i]);
+		uint64_t cx = U64MAX; uint32_t cp = 0xFFFFFFFFu;
+		if (c < 4) {
+			fwd = ((fwd << 2) | (uint64_t)c) & mask;
+			rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1);
+			if (fwd == rev) continue;
+			const uint32_t z = fwd < rev ? 0u : 1u;
+			if (++run >= k) { cx = mcom_hash64(z ? rev : fwd, mask); cp = ((uint32_t)i << 1) | z; }
+		} else run = 0;
+		rx[slot] = cx; rp[slot] = cp;
+		if (run == w + k - 1) {
+			for (int j = slot + 1; j < w; ++j) if (bx == rx[j] && rp[j] != bp) PUT(rx[j], rp[j]);
+			for (int j = 0; j < slot; ++j)     if (bx == rx[j] && rp[j] != bp) PUT(rx[j], rp[j]);
+		}
+		if (cx <= bx) {
+			if (run >= w + k) PUT(bx, bp);
+			bx = cx; bp = cp; bslot = slot;
+		} else if (slot == bslot) {
+			if (run >= w + k - 1) PUT(bx, bp);
+			bx = U64MAX;
+			for (int j = slot + 1; j < w; ++j) if (bx >= rx[j]) { bx = rx[j]; bp = rp[j]; bslot = j; }
+			for (int j = 0; j <= slot; ++j)    if (bx >= rx[j]) { bx = rx[j]; bp = rp[j]; bslot = j; }
+			if (run >= w + k - 1) {
+				for (int j = slot + 1; j < w; ++j) if (bx == rx[j] && bp != rp[j]) PUT(rx[j], rp[j]);
+				for (int j = 0; j <= slot; ++j)    if (bx == rx[j] && bp != rp[j]) PUT(rx[j], rp[j]);
+			}
+		}
+		if (++slot == w) slot = 0;
+	}
+	if (ne < limit && bx != U64MAX) PUT(bx, bp);
+#undef PUT
+	if (!EMIT) cnt[t] = ne < limit ? ne : limit;
+}
+
+extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
+                                   int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                                   uint64_t *h_total)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (h_total) *h_total = 0;
+	if (k < 1 || k > 31 || w < 1 || w > MAXW) return mcom_fail(ctx, MCOM_E_ARG, "w=%d (1..%d) or k=%d (1..31) out of range", w, MAXW, k);
+	if (n >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs");
+	if (!d_moff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 4, ctx->stream)); return MCOM_OK; }
+	if (!d_seq || !d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const uint32_t limit = max_per_contig ? max_per_contig : 0xFFFFFFFFu;
+	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, scr_b);
+	if (rc) return rc;
+	const unsigned blocks = (unsigned)((n + 63) / 64);
+	// counts go to d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
+	hipLaunchKernelGGL((k_sketch_contigs<false>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, d_moff, nullptr, nullptr);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
+	rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, (uint32_t*)ctx->ws);
+	if (rc) return rc;
+	uint32_t total = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h_total) *h_total = total;
+	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
+	if (total == 0) return MCOM_OK;
+	if (!d_out) return mcom_fail(ctx, MCOM_E_ARG, "null output pointer");
+	hipLaunchKernelGGL((k_sketch_contigs<true>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, nullptr, d_moff, d_out);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: one thread per output word; contig c owns words [coff[c], coff[c+1]) of which the last is padding
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ coff,
+                               uint32_t n, uint64_t total_words, uint64_t *__restrict__ cbits)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= total_words) return;
+	uint32_t lo = 0, hi = n;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= g) lo = mid; else hi = mid; }
+	const uint64_t wi = g - coff[lo];
+	const uint64_t len = off[lo + 1] - off[lo];
+	const uint8_t *s = seq + off[lo];
+	uint64_t v = 0;
+	const uint64_t b0 = wi * 32;
+	for (int q = 0; q < 32; ++q) {
+		const uint64_t i = b0 + q;
+		if (i >= len) break;
+		const int c = nt4_of(s[i]);
+		v |= (uint64_t)(c & 3) << (2 * q);          // non-ACGT packs as A
+	}
+	cbits[g] = v;
+}
+
+extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                                 uint64_t total_words, uint64_t *d_cbits)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0 || total_words == 0) return MCOM_OK;
+	if (!d_seq || !d_off || !d_coff || !d_cbits) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const uint64_t blocks = (total_words + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
+	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// minimizer index: records sorted by x (stable: equal minimizers keep their push order, which is the order
+// the reference's bucket sort keeps for buckets of <= 64 entries, ksort.h:155) + exact hash table
+// ------------------------------------------------------------------------------------------------
+struct mcom_idx {
+	size_t n;
+	mcom_mm128 *rec;     // sorted records
+	McomTable tab;
+};
+
+extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
+{
+	if (!mi) return;
+	if (ctx) (void)hipStreamSynchronize(ctx->stream);
+	if (mi->rec) (void)hipFree(mi->rec);
+	mcom_table_free(&mi->tab);
+	delete mi;
+}
+
+extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, mcom_idx **out)
+{
+	if (!ctx || !out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range", k);
+	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many records");
+	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	mcom_idx *mi = new mcom_idx();
+	mi->n = n; mi->rec = nullptr; mi->tab.slots = nullptr;
+	hipError_t e = hipMalloc(&mi->rec, (n ? n : 1) * sizeof(mcom_mm128));
+	if (e != hipSuccess) { mi->rec = nullptr; mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_NOMEM, "index records: %s", hipGetErrorString(e)); }
+	const size_t sort_b = mcom_sort_ws_bytes(n);
+	const size_t head_b = ((n * 4) + 255) & ~(size_t)255;
+	const size_t scr_b = ((mcom_scan_scratch_elems(n) * 4 + 1024) + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, sort_b + head_b + scr_b + 256);
+	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+	char *base = (char*)ctx->ws;
+	if (n) {
+		hipError_t e1 = hipMemcpyAsync(mi->rec, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream);
+		if (e1 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e1)); }
+		rc = mcom_sort_by_x(ctx, mi->rec, n, 2 * k, base);
+		if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+	}
+	rc = mcom_table_build(ctx, mi->rec, n, (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
+	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+	*out = mi;
+	return MCOM_OK;
+}
+
+__global__ void k_idx_get(const uint64_t *__restrict__ slots, uint32_t log2cap, const uint64_t *__restrict__ x, size_t n,
+                          uint32_t *__restrict__ start, uint32_t *__restrict__ count)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = 0, c = 0;
+	if (x[i] != U64MAX) mcom_table_find(slots, log2cap, x[i], s, c);
+	start[i] = s; count[i] = c;
+}
+
+extern "C" int mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d_x, size_t n, uint32_t *d_start, uint32_t *d_count)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_x || !d_start || !d_count) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_x, n, d_start, d_count);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_idx_records(mcom_ctx *ctx, const mcom_idx *mi, mcom_mm128 *d_out, size_t *n)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	if (n) *n = mi->n;
+	if (d_out && mi->n) MCOM_HIP(ctx, hipMemcpyAsync(d_out, mi->rec, mi->n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// match_pro on packed contigs: mismatches over the whole overlap of A and B anchored at A[i] ~ B[j]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t bits_at(const uint64_t *w, uint64_t bitoff)
+{
+	const uint64_t wi = bitoff >> 6; const int sh = (int)(bitoff & 63);
+	return sh ? (w[wi] >> sh) | (w[wi + 1] << (64 - sh)) : w[wi];      // relies on the padding word after every contig
+}
+__device__ __forceinline__ uint32_t match_pro_packed(const uint64_t *A, uint32_t lenA, const uint64_t *B, uint32_t lenB, int i_, int j_,
+                                                     uint32_t stop_above)
+{
+	const long d = (long)i_ - (long)j_;                                    // A[p] is compared with B[p - d]
+	const long lo = d > 0 ? d : 0;
+	long hi = (long)lenB + d; if (hi > (long)lenA) hi = (long)lenA;
+	uint32_t mis = 0;
+	for (long p = lo; p < hi; p += 32) {
+		const long nb = hi - p < 32 ? hi - p : 32;
+		uint64_t x = bits_at(A, 2 * (uint64_t)p) ^ bits_at(B, 2 * (uint64_t)(p - d));
+		x = (x | (x >> 1)) & 0x5555555555555555ull;
+		if (nb < 32) x &= (1ull << (2 * nb)) - 1;
+		mis += (uint32_t)__popcll(x);
+		if (mis > stop_above) break;
+	}
+	return mis;
+}
+
+__global__ void k_match_pro(const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
+                            const uint32_t *__restrict__ a, const uint32_t *__restrict__ pa, const uint32_t *__restrict__ b,
+                            const uint32_t *__restrict__ pb, size_t n, uint32_t *__restrict__ out)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n) return;
+	out[t] = match_pro_packed(cbits + coff[a[t]], clen[a[t]], cbits + coff[b[t]], clen[b[t]], (int)pa[t], (int)pb[t], 0xFFFFFFFFu);
+}
+
+extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen,
+                              const uint32_t *d_a, const uint32_t *d_pos_a, const uint32_t *d_b, const uint32_t *d_pos_b, size_t n,
+                              uint32_t *d_mismatch)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_cbits || !d_coff || !d_clen || !d_a || !d_pos_a || !d_b || !d_pos_b || !d_mismatch) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_match_pro, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits, d_coff, d_clen, d_a, d_pos_a, d_b, d_pos_b, n, d_mismatch);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// find_next, lookup part: for query minimizer q of contig i (all minimizers, in order) and every index hit
+// in index order: other contig != i, same strand bit, match_pro <= cbthr  -> one passing candidate.
+// The flags the reference also tests (:286) change while it merges, so they are left to the caller, who
+// walks each contig's candidates in this order and takes the first whose partner is still free.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ q, size_t nq,
+                            uint32_t *__restrict__ hits)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq) return;
+	uint32_t s = 0, c = 0;
+	if (q[i].x != U64MAX) mcom_table_find(slots, log2cap, q[i].x, s, c);
+	hits[i] = c;
+}
+// one thread per query: walks its hits, tests, writes a pass flag per (query, hit) pair at pair_off[q] + k
+__global__ void k_fn_eval(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ irec,
+                          const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
+                          const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
+                          int cbthr, uint32_t *__restrict__ pass)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq) return;
+	const mcom_mm128 m = q[i];
+	uint32_t s = 0, c = 0;
+	if (m.x == U64MAX || !mcom_table_find(slots, log2cap, m.x, s, c)) return;
+	const uint32_t rid_ori = (uint32_t)(m.y >> 32), pos_ori = (uint32_t)m.y >> 1, dir_ori = (uint32_t)(m.y & 1);
+	const uint32_t ci = rid_ori >> 8;
+	for (uint32_t u = 0; u < c; ++u) {
+		const uint64_t y = irec[s + u].y;
+		const uint32_t rid = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1, dir = (uint32_t)(y & 1);
+		uint32_t ok = 0;
+		if (rid != rid_ori && dir == dir_ori) {
+			const uint32_t cj = rid >> 8;
+			const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
+			ok = mis <= (uint32_t)cbthr;
+		}
+		pass[pair_off[i] + u] = ok;
+	}
+}
+__global__ void k_fn_emit(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ irec,
+                          const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
+                          const uint32_t *__restrict__ pass_pre, uint32_t n_pairs, uint32_t last_flag,
+                          mcom_mm128 *__restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq) return;
+	const mcom_mm128 m = q[i];
+	uint32_t s = 0, c = 0;
+	if (m.x == U64MAX || !mcom_table_find(slots, log2cap, m.x, s, c)) return;
+	for (uint32_t u = 0; u < c; ++u) {
+		const uint32_t p = pair_off[i] + u;
+		const uint32_t here = pass_pre[p], nxt = (p + 1 < n_pairs) ? pass_pre[p + 1] : pass_pre[p] + last_flag;
+		if (nxt != here) { mcom_mm128 v; v.x = m.y; v.y = irec[s + u].y; out[here] = v; }   // x = query y (contig i, pos_ori, dir), y = hit y
+	}
+}
+
+extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
+                                         const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
+                                         mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	if (h_counts) { h_counts[0] = h_counts[1] = 0; }
+	if (n_query == 0) return MCOM_OK;
+	if (!d_query || !d_cbits || !d_coff || !d_clen) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_query >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many query minimizers");
+	// pass 1: hits per query -> pair offsets
+	const size_t nq1 = n_query + 1;
+	const size_t hit_b = (nq1 * 4 + 255) & ~(size_t)255;
+	const size_t scr1_b = (mcom_scan_scratch_elems(nq1) * 4 + 1024 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, hit_b + scr1_b);
+	if (rc) return rc;
+	uint32_t *hits = (uint32_t*)ctx->ws;
+	const unsigned qb = (unsigned)((n_query + 255) / 256);
+	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_query, n_query, hits);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
+	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
+	if (rc) return rc;
+	uint32_t n_pairs = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&n_pairs, hits + n_query, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h_counts) h_counts[0] = n_pairs;
+	if (n_pairs == 0) return MCOM_OK;
+	// pass 2: evaluate pairs; the workspace may move, so the offsets are kept in a fresh allocation
+	uint32_t *pair_off = nullptr, *pass = nullptr;
+	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
+	hipError_t e = hipMalloc(&pair_off, nq1 * 4);
+	if (e == hipSuccess) e = hipMalloc(&pass, (size_t)n_pairs * 4);
+	if (e != hipSuccess) { if (pair_off) (void)hipFree(pair_off); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
+	auto cleanup = [&]() { (void)hipFree(pair_off); (void)hipFree(pass); };
+	hipError_t e1 = hipMemcpyAsync(pair_off, hits, nq1 * 4, hipMemcpyDeviceToDevice, ctx->stream);
+	if (e1 == hipSuccess) e1 = hipMemsetAsync(pass, 0, (size_t)n_pairs * 4, ctx->stream);
+	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate buffers: %s", hipGetErrorString(e1)); }
+	rc = mcom_ws_reserve(ctx, scr2_b);
+	if (rc) { cleanup(); return rc; }
+	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass);
+	uint32_t last_flag = 0, n_pass = 0;
+	e1 = hipMemcpyAsync(&last_flag, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate evaluation: %s", hipGetErrorString(e1)); }
+	rc = mcom_scan_u32(ctx, pass, pass, n_pairs, (uint32_t*)ctx->ws);
+	if (rc) { cleanup(); return rc; }
+	e1 = hipMemcpyAsync(&n_pass, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate scan: %s", hipGetErrorString(e1)); }
+	n_pass += last_flag;
+	if (h_counts) h_counts[1] = n_pass;
+	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
+	if (n_pass) {
+		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
+		hipLaunchKernelGGL(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
+		e1 = hipStreamSynchronize(ctx->stream);
+		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
+	}
+	cleanup();
+	return MCOM_OK;
+}

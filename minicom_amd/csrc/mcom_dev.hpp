@@ -59,3 +59,30 @@ __device__ __forceinline__ uint32_t mcom_hash64_lo(uint32_t key, uint32_t mask)
 }
 
 static inline int mcom_words_per_read(int L) { return (2 * L + 63) / 64; }
+
+// ---- exact key -> (run start, run length) map over a sorted record array (table.hip) ---------------------
+// Open addressing, linear probing, 16-byte slots {key, start | count << 32}, EMPTY key = ~0, load <= 0.5.
+struct McomTable {
+	uint64_t *slots; uint32_t log2cap;
+	uint32_t numkeys, maxrun;
+};
+// sorted: n records sorted by x (runs of equal x are the bins); head/scr: scratch of n and
+// mcom_scan_scratch_elems(n)+256 uint32; meta: 2 uint32 on the device.  Synchronous.
+int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t);
+void mcom_table_free(McomTable *t);
+
+__device__ __forceinline__ uint32_t mcom_slot_of(uint64_t key, uint32_t log2cap)
+{
+	return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap));
+}
+__device__ __forceinline__ bool mcom_table_find(const uint64_t *slots, uint32_t log2cap, uint64_t key, uint32_t &start, uint32_t &count)
+{
+	const uint32_t capm = (1u << log2cap) - 1u;
+	uint32_t sl = mcom_slot_of(key, log2cap);
+	for (;;) {
+		const uint64_t k = slots[2 * (size_t)sl];
+		if (k == key) { const uint64_t v = slots[2 * (size_t)sl + 1]; start = (uint32_t)v; count = (uint32_t)(v >> 32); return true; }
+		if (k == ~0ull) return false;
+		sl = (sl + 1) & capm;
+	}
+}

@@ -68,10 +68,6 @@ __device__ __forceinline__ uint64_t bits_key(const uint64_t *w, int start, int l
 	if (sh && sh + 2 * len > 64) v |= w[wi + 1] << (64 - sh);
 	return v & ((1ull << (2 * len)) - 1);
 }
-__device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t log2cap)
-{
-	return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap));
-}
 
 // ---- gather packed rows of the singletons ------------------------------------------------------------
 __global__ void k_gather_rows(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ rids, size_t n, int W,
@@ -150,33 +146,10 @@ __global__ void k_dict_keys(const uint64_t *__restrict__ bits, size_t n, int W, 
 	mcom_mm128 r; r.x = bits_key(bits + i * (size_t)W, start, len); r.y = i;
 	rec[i] = r;
 }
-__global__ void k_dict_heads(const mcom_mm128 *__restrict__ s, size_t n, uint32_t *__restrict__ head, uint32_t *__restrict__ ids)
+__global__ void k_dict_ids(const mcom_mm128 *__restrict__ s, size_t n, uint32_t *__restrict__ ids)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	head[i] = (i == 0 || s[i].x != s[i - 1].x) ? 1u : 0u;
-	ids[i] = (uint32_t)s[i].y;
-}
-__global__ void k_dict_insert(const mcom_mm128 *__restrict__ s, size_t n, const uint32_t *__restrict__ hpre, uint64_t *__restrict__ slots,
-                              uint32_t log2cap, uint32_t *__restrict__ meta /* [0]=numkeys, [1]=maxbin */)
-{
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint64_t key = s[i].x;
-	if (i > 0 && s[i - 1].x == key) return;               // only run heads insert
-	size_t e = i + 1;                                       // run length by forward scan (bins are short; long runs are rare)
-	while (e < n && s[e].x == key) ++e;
-	const uint32_t cnt = (uint32_t)(e - i);
-	const uint32_t capm = (1u << log2cap) - 1u;
-	uint32_t sl = slot_of(key, log2cap);
-	for (;;) {
-		const unsigned long long prev = atomicCAS((unsigned long long*)&slots[2 * (size_t)sl], ~0ull, (unsigned long long)key);
-		if (prev == ~0ull) break;
-		sl = (sl + 1) & capm;
-	}
-	slots[2 * (size_t)sl + 1] = (uint64_t)i | ((uint64_t)cnt << 32);
-	atomicMax(&meta[1], cnt);
-	if (e == n) meta[0] = hpre[i] + 1;                      // exclusive prefix of heads at the last head + 1
+	if (i < n) ids[i] = (uint32_t)s[i].y;
 }
 
 extern "C" void mcom_dicts_free(mcom_ctx *ctx, mcom_dicts *d)
@@ -214,28 +187,18 @@ extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t 
 	uint32_t *meta = (uint32_t*)(base + rec_b + sort_b + head_b + scr_b);
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 	for (int j = 0; j < d->nd; ++j) {
-		uint32_t lg = 4;
-		while ((1ull << lg) < 2 * n + 16) ++lg;
-		d->log2cap[j] = lg;
-		hipError_t e1 = hipMalloc(&d->slots[j], (size_t)16 << lg);
 		hipError_t e2 = hipMalloc(&d->ids[j], (n ? n : 1) * 4);
-		if (e1 != hipSuccess || e2 != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
-		hipError_t e = hipMemsetAsync(d->slots[j], 0xFF, (size_t)16 << lg, ctx->stream);
-		if (e != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "memset: %s", hipGetErrorString(e)); }
-		if (n == 0) continue;
-		hipLaunchKernelGGL(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
-		rc = mcom_sort_by_x(ctx, rec, n, 2 * d->kl[j], sortws);
+		if (e2 != hipSuccess) { d->ids[j] = nullptr; mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
+		if (n) {
+			hipLaunchKernelGGL(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
+			rc = mcom_sort_by_x(ctx, rec, n, 2 * d->kl[j], sortws);
+			if (rc) { mcom_dicts_free(ctx, d); return rc; }
+			hipLaunchKernelGGL(k_dict_ids, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, d->ids[j]);
+		}
+		McomTable t;
+		rc = mcom_table_build(ctx, rec, n, head, scr, meta, &t);
+		d->slots[j] = t.slots; d->log2cap[j] = t.log2cap; d->numkeys[j] = t.numkeys; d->maxbin[j] = t.maxrun;
 		if (rc) { mcom_dicts_free(ctx, d); return rc; }
-		hipLaunchKernelGGL(k_dict_heads, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, head, d->ids[j]);
-		rc = mcom_scan_u32(ctx, head, head, n, scr);
-		if (rc) { mcom_dicts_free(ctx, d); return rc; }
-		(void)hipMemsetAsync(meta, 0, 8, ctx->stream);
-		hipLaunchKernelGGL(k_dict_insert, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, head, d->slots[j], lg, meta);
-		uint32_t hm[2] = {0, 0};
-		hipError_t e3 = hipMemcpyAsync(hm, meta, 8, hipMemcpyDeviceToHost, ctx->stream);
-		if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
-		if (e3 != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "dictionary %d: %s", j, hipGetErrorString(e3)); }
-		d->numkeys[j] = hm[0]; d->maxbin[j] = hm[1];
 	}
 	hipError_t e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "dict build: %s", hipGetErrorString(e)); }
@@ -252,17 +215,7 @@ extern "C" int mcom_dicts_info(const mcom_dicts *d, int *nd, uint32_t *numkeys, 
 }
 
 // ---- batched lookup (bphf->lookup + findpos on an untouched dictionary, bbhashdict.c:33-43) ----------
-__device__ __forceinline__ bool dict_find(const uint64_t *slots, uint32_t log2cap, uint64_t key, uint32_t &start, uint32_t &count)
-{
-	const uint32_t capm = (1u << log2cap) - 1u;
-	uint32_t sl = slot_of(key, log2cap);
-	for (;;) {
-		const uint64_t k = slots[2 * (size_t)sl];
-		if (k == key) { const uint64_t v = slots[2 * (size_t)sl + 1]; start = (uint32_t)v; count = (uint32_t)(v >> 32); return true; }
-		if (k == ~0ull) return false;
-		sl = (sl + 1) & capm;
-	}
-}
+#define dict_find mcom_table_find
 __global__ void k_dict_lookup(const uint64_t *__restrict__ slots, uint32_t log2cap, const uint64_t *__restrict__ keys, size_t n,
                               uint32_t *__restrict__ start, uint32_t *__restrict__ count)
 {

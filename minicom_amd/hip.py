@@ -58,6 +58,16 @@ def load_library():
     L.mcom_radix_sort_128x.restype = i32; L.mcom_radix_sort_128x.argtypes = [vp, vp, sz]
     L.mcom_sort_group.restype = i32
     L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.mcom_sketch_contigs.restype = i32
+    L.mcom_sketch_contigs.argtypes = [vp, vp, vp, vp, sz, i32, i32, u32, vp, vp, sz, C.POINTER(u64)]
+    L.mcom_pack_contigs.restype = i32; L.mcom_pack_contigs.argtypes = [vp, vp, vp, vp, u32, u64, vp]
+    L.mcom_idx_build.restype = i32; L.mcom_idx_build.argtypes = [vp, vp, sz, i32, C.POINTER(vp)]
+    L.mcom_idx_destroy.restype = None; L.mcom_idx_destroy.argtypes = [vp, vp]
+    L.mcom_idx_get.restype = i32; L.mcom_idx_get.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.mcom_idx_records.restype = i32; L.mcom_idx_records.argtypes = [vp, vp, vp, C.POINTER(sz)]
+    L.mcom_match_pro.restype = i32; L.mcom_match_pro.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.mcom_find_next_candidates.restype = i32
+    L.mcom_find_next_candidates.argtypes = [vp, vp, vp, sz, vp, vp, vp, i32, vp, sz, vp]
     L.mcom_dict_layout.restype = i32; L.mcom_dict_layout.argtypes = [i32, i32, vp, vp]
     L.mcom_gather_rows.restype = i32; L.mcom_gather_rows.argtypes = [vp, vp, vp, sz, i32, vp]
     L.mcom_poly_filter.restype = i32; L.mcom_poly_filter.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp]
@@ -177,6 +187,64 @@ class Context:
         return {"sorted": srt, "n_valid": nv, "singles": singles[:ns], "members": members[:nm], "group_off": goff[:ng + 1] if n else goff[:0],
                 "n_groups": ng}
 
+    # -- contigs
+    def upload_contigs(self, refs):
+        """Host list of contig strings (bytes) -> device (seq uint8, off int64 [n+1], coff int64 [n], clen int32 [n], cbits)."""
+        torch = _torch()
+        lens = np.array([len(r) for r in refs], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        words = (2 * lens + 63) // 64 + 1
+        coff = np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.int64) if len(refs) else np.zeros(0, np.int64)
+        total = int(words.sum())
+        seq = torch.from_numpy(np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8).copy()).to(self.device)
+        d_off = torch.from_numpy(off).to(self.device)
+        d_coff = torch.from_numpy(coff).to(self.device)
+        d_clen = torch.from_numpy(lens.astype(np.int32)).to(self.device)
+        cbits = torch.zeros(total + 1, dtype=torch.int64, device=self.device)
+        self._check(self.lib.mcom_pack_contigs(self._h, self._p(seq), self._p(d_off), self._p(d_coff), len(refs), total, self._p(cbits)))
+        return {"seq": seq, "off": d_off, "coff": d_coff, "clen": d_clen, "cbits": cbits, "n": len(refs), "lens": lens}
+
+    def sketch_contigs(self, seq, off, n: int, w: int, k: int, max_per_contig: int = 0, ids=None):
+        """mcom_sketch_contigs.  Returns (moff int32 [n+1], records int64 [total,2])."""
+        torch = _torch()
+        moff = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+        total = C.c_uint64(0)
+        cap = max(1024, 2 * n * (max_per_contig if max_per_contig else 4))
+        while True:
+            out = self.empty_records(cap)
+            rc = self.lib.mcom_sketch_contigs(self._h, self._p(seq), self._p(off), self._p(ids), n, w, k, max_per_contig,
+                                              self._p(moff), self._p(out), cap, C.byref(total))
+            if rc == -4:
+                cap = int(total.value)
+                continue
+            self._check(rc)
+            return moff, out[: int(total.value)]
+
+    def idx_build(self, rec, k: int):
+        return Index(self, rec, k)
+
+    def match_pro(self, cg, a, pa, b, pb):
+        torch = _torch()
+        n = int(a.shape[0])
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._check(self.lib.mcom_match_pro(self._h, self._p(cg["cbits"]), self._p(cg["coff"]), self._p(cg["clen"]),
+                                            self._p(a, torch.int32), self._p(pa, torch.int32), self._p(b, torch.int32), self._p(pb, torch.int32), n, self._p(out)))
+        return out
+
+    def find_next_candidates(self, idx, query, cg, cbthr: int):
+        """mcom_find_next_candidates.  Returns (pairs int64 [n_pass,2], n_pairs_tested)."""
+        cnt = (C.c_uint64 * 2)()
+        cap = max(1024, int(query.shape[0]))
+        while True:
+            out = self.empty_records(cap)
+            rc = self.lib.mcom_find_next_candidates(self._h, idx._h, self._p(query), int(query.shape[0]), self._p(cg["cbits"]),
+                                                    self._p(cg["coff"]), self._p(cg["clen"]), cbthr, self._p(out), cap, cnt)
+            if rc == -4:
+                cap = int(cnt[1])
+                continue
+            self._check(rc)
+            return out[: int(cnt[1])], int(cnt[0])
+
     # -- Stage 2
     def gather_rows(self, packed, rids, L: int):
         torch = _torch()
@@ -215,6 +283,42 @@ class Context:
         out = torch.empty((count, pitch), dtype=torch.uint8, device=self.device)
         self._check(self.lib.mcom_synth_reads(self._h, seed, n_reads, L, coverage, sub_rate, first, count, self._p(out), pitch))
         return out
+
+
+class Index:
+    """Device-resident contig-minimizer index (mcom_idx)."""
+
+    def __init__(self, ctx: Context, rec, k: int):
+        self.ctx = ctx
+        self.n = int(rec.shape[0])
+        h = C.c_void_p()
+        ctx._check(ctx.lib.mcom_idx_build(ctx._h, ctx._p(rec), self.n, k, C.byref(h)))
+        self._h = h
+
+    def get(self, x):
+        torch = _torch()
+        n = int(x.shape[0])
+        start = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        count = torch.empty(n, dtype=torch.int32, device=self.ctx.device)
+        self.ctx._check(self.ctx.lib.mcom_idx_get(self.ctx._h, self._h, self.ctx._p(x, torch.int64), n, self.ctx._p(start), self.ctx._p(count)))
+        return start, count
+
+    def records(self):
+        out = self.ctx.empty_records(max(self.n, 1))
+        n = C.c_size_t()
+        self.ctx._check(self.ctx.lib.mcom_idx_records(self.ctx._h, self._h, self.ctx._p(out), C.byref(n)))
+        return out[: self.n]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.mcom_idx_destroy(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Dicts:

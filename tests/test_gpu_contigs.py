@@ -1,0 +1,162 @@
+"""GPU parity: contig kernels (mcom_sketch_contigs, mcom_pack_contigs, mcom_idx_*, mcom_match_pro,
+mcom_find_next_candidates) against the reference's golden vectors and the oracle."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MAXU = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import minicom_amd
+    c = minicom_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    with gzip.open(os.path.join(golden_dir, "kat.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def _golden_reads(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, tag + ".reads.gz"), "rb") as f:
+        rows = f.read().split(b"\n")[:-1]
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+
+
+def _recs(t):
+    from minicom_amd.hip import records_to_numpy
+    return records_to_numpy(t)
+
+
+def test_sketch_contigs_equals_reference_vectors(ctx, kat):
+    """mm_sketch_lh_ori golden outputs (including N runs, palindromes, w = 1)."""
+    import torch
+    by = {}
+    for t in kat["LH"]:
+        by.setdefault((t["w"], t["k"]), []).append(t)
+    assert len(by) >= 6
+    for (w, k), items in by.items():
+        refs = [t["seq"].encode() for t in items]
+        cg = ctx.upload_contigs(refs)
+        ids = torch.tensor([t["rid"] for t in items], dtype=torch.int32, device="cuda")
+        moff, out = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k, ids=ids)
+        ctx.sync()
+        moff = moff.cpu().numpy(); r = _recs(out)
+        for i, t in enumerate(items):
+            seg = r[moff[i]:moff[i + 1]]
+            flat = np.stack([seg["x"], seg["y"]], axis=1).reshape(-1).tolist()
+            assert flat == t["out"], (w, k, i)
+        # first-m prefix, as the index builders use it (kthread_bucket.c:463)
+        moff6, out6 = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k, max_per_contig=6, ids=ids)
+        ctx.sync()
+        moff6 = moff6.cpu().numpy(); r6 = _recs(out6)
+        for i, t in enumerate(items):
+            seg = r6[moff6[i]:moff6[i + 1]]
+            assert np.stack([seg["x"], seg["y"]], axis=1).reshape(-1).tolist() == t["out"][:12]
+
+
+def test_pack_contigs_layout(ctx):
+    from minicom_amd import synth
+    from minicom_amd.hip import pack_contigs
+    refs = [synth.synth_reads(70 + i, 1, ln)[0].tobytes() for i, ln in enumerate((150, 151, 31, 32, 33, 64, 1000, 97, 160))]
+    cg = ctx.upload_contigs(refs)
+    ctx.sync()
+    cbits, coff, clen = pack_contigs(refs)
+    assert np.array_equal(cg["coff"].cpu().numpy().view(np.uint64), coff)
+    assert np.array_equal(cg["cbits"].cpu().numpy().view(np.uint64)[: len(cbits)], cbits)
+
+
+def test_match_pro_equals_reference_vectors(ctx, kat):
+    import torch
+    refs, a, pa, b, pb, want = [], [], [], [], [], []
+    for t in kat["MP"]:
+        a.append(len(refs)); refs.append(t["s0"].encode())
+        b.append(len(refs)); refs.append(t["s1"].encode())
+        pa.append(t["i"]); pb.append(t["j"]); want.append(t["d"])
+    cg = ctx.upload_contigs(refs)
+    f = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+    got = ctx.match_pro(cg, f(a), f(pa), f(b), f(pb))
+    ctx.sync()
+    assert got.cpu().numpy().tolist() == want
+
+
+def test_idx_build_and_get(ctx):
+    import torch
+    rng = np.random.default_rng(3)
+    n = 20000
+    keys = rng.integers(0, 1 << 62, 6000, dtype=np.uint64)
+    rec = np.zeros(n, dtype=[("x", "<u8"), ("y", "<u8")])
+    rec["x"] = keys[rng.integers(0, len(keys), n)]
+    rec["y"] = np.arange(n, dtype=np.uint64) << np.uint64(32) | rng.integers(0, 400, n).astype(np.uint64)
+    t = torch.from_numpy(np.stack([rec["x"], rec["y"]], axis=1).view(np.int64)).cuda()
+    idx = ctx.idx_build(t, 31)
+    srt = _recs(idx.records())
+    order = np.argsort(rec["x"], kind="stable")
+    assert np.array_equal(srt["x"], rec["x"][order]) and np.array_equal(srt["y"], rec["y"][order])
+    probe = np.concatenate([keys, keys ^ np.uint64(1 << 40), np.array([MAXU], dtype=np.uint64)])
+    s, c = idx.get(torch.from_numpy(probe.view(np.int64)).cuda())
+    ctx.sync()
+    s, c = s.cpu().numpy(), c.cpu().numpy()
+    sx = srt["x"]
+    for q, kq in enumerate(probe):
+        lo, hi = np.searchsorted(sx, kq, "left"), np.searchsorted(sx, kq, "right")
+        if kq == MAXU:
+            assert c[q] == 0
+        else:
+            assert c[q] == hi - lo and (hi == lo or s[q] == lo)
+    idx.close()
+    e = ctx.idx_build(ctx.empty_records(0), 31)
+    s, c = e.get(torch.zeros(3, dtype=torch.int64, device="cuda"))
+    assert c.sum().item() == 0
+    e.close()
+
+
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_find_next_candidates_on_reference_fixture_contigs(ctx, golden_dir, tag):
+    """Contigs after the reference's kt_for_bucket stage: index of first-6 minimizers, all-minimizer queries,
+    passing candidates in find_next's visiting order."""
+    import torch
+    import oracle
+    reads = _golden_reads(golden_dir, tag)
+    L = reads.shape[1]
+    p = oracle.Pipeline(reads)
+    p.stage_reads(); p.stage_bucket()
+    contigs = p.contigs()
+    refs = [r for r, _ in contigs]
+    k, rw, cbthr, m = p.counter("k"), p.counter("rw"), 8, 6
+    cg = ctx.upload_contigs(refs)
+    moff6, first6 = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), rw, k, max_per_contig=m)
+    idx = ctx.idx_build(first6, k)
+    moff, allq = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), rw, k)
+    pairs, n_tested = ctx.find_next_candidates(idx, allq, cg, cbthr)
+    ctx.sync()
+    got = _recs(pairs)
+    # expectation with the oracle's functions
+    table = {}
+    for i, r in enumerate(refs):
+        mz = oracle.sketch_lh_ori(r, rw, k, i << 8)[:m]
+        for x, y in zip(mz["x"].tolist(), mz["y"].tolist()):
+            table.setdefault(x, []).append(y)
+    want = []
+    tested = 0
+    for i, r in enumerate(refs):
+        for x, y in zip(*[v.tolist() for v in (lambda a: (a["x"], a["y"]))(oracle.sketch_lh_ori(r, rw, k, i << 8))]):
+            for hy in table.get(x, []):
+                tested += 1
+                rid = hy >> 32
+                if rid == (i << 8) or (hy & 1) != (y & 1):
+                    continue
+                if oracle.match_pro(r, refs[rid >> 8], (y & 0xFFFFFFFF) >> 1, (hy & 0xFFFFFFFF) >> 1) <= cbthr:
+                    want.append((y, hy))
+    assert n_tested == tested
+    assert list(zip(got["x"].tolist(), got["y"].tolist())) == want
+    assert len(want) > 10
+    idx.close()
