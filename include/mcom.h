@@ -84,12 +84,14 @@ int mcom_radix_sort_128x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
  * Outputs, in the order the reference visits them (bucket ascending, hash ascending):
  *   d_sorted  [n]      all records, sorted (ignored records last)
  *   d_singles [<=n]    rid of every group of one                     (:402-413, pushed to reads->sg)
+ *   d_single_ord[<=n]  (optional) number of groups >= 2 visited before that single: lets the caller
+ *                      interleave singles and groups in the reference's visiting order
  *   d_members [<=n]    y of every member of a group >= 2, each group in cmpcluster order (:438-442)
  *   d_group_off[<=n/2+1]  start of each such group in d_members, plus the end sentinel
  *   h_counts[4] (HOST) = { n_valid, n_singles, n_groups, n_members }.  Synchronous.                  */
 int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int k_orig, int kmer, int b,
-                    mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
-                    uint64_t *h_counts);
+                    mcom_mm128 *d_sorted, uint32_t *d_singles, uint32_t *d_single_ord, uint64_t *d_members,
+                    uint32_t *d_group_off, uint64_t *h_counts);
 
 /* ---- a3, a7..a9: contigs ------------------------------------------------------------------------- */
 /* Batched mm_sketch_lh_ori (sketch.c:116-165): the (w,k)-minimizers of n contigs.  Contig c is the ASCII

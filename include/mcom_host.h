@@ -1,0 +1,66 @@
+/* include/mcom_host.h -- host side of the MI355X-native minicom hot path (libmcom_host.so).
+ *
+ * Mirrors the reference's pipeline driver for this path: the stage functions have the reference's names
+ * and meaning (pre_process preprocess.c:39, kt_for_reads kthread_reads.c:247, kt_for_bucket
+ * kthread_bucket.c:562, combine_cluster kthread_cb.c:570, realign_hash kthread_hash_realign.c:569,
+ * updateSingle preprocess.c:243) but run their hot loops as HIP kernels through include/mcom.h.
+ * Contig consensus (construct_ref kthread_bucket.c:69, construct_ref2 kthread_cb.c:105), pair claiming
+ * and claim resolution stay on the host, as in the reference.  No CPU fallback: every stage needs the GPU.
+ * Results equal the reference at one thread (-t 1, its only deterministic mode).
+ */
+#ifndef MCOM_HOST_H
+#define MCOM_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	int k;          /* -k  0 = 31 (17 when L < 80)      minicommain.c:92-114 */
+	int e;          /* -e  0 = 4                         minicommain.c:60     */
+	int m;          /* -m  0 = 6                         minicommain.c:63     */
+	int w;          /* -w  0 = L/2-k (3 when L < 70)     preprocess.c:89-107  */
+	int cbthr;      /* -g  0 = 2e                        minicommain.c:122    */
+	int max_rounds; /* -R  0 = 35                        minicommain.c:64     */
+	int step;       /* -S  0 = e (5 when e > 10)         minicommain.c:130    */
+	int maxthr;     /* -E  0 = L/2                       minicommain.c:140    */
+	int numdict;    /* -s  0 = L/17 (L/11 when L <= 80)  kthread_hash_realign.c:153 */
+	int host_threads; /* host worker threads for the consensus loops (0 = 1); results do not depend on it */
+} mcomh_params;
+
+typedef struct mcomh_pipeline mcomh_pipeline;
+
+/* reads: n rows of L upper-case ACGTN characters.  host_reads [n][L] lives in host memory and is uploaded;
+ * alternatively d_reads [n][pitch] is already resident in HBM (exactly one of the two is non-NULL).      */
+int  mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, const uint8_t *host_reads,
+                  const uint8_t *d_reads, size_t pitch, size_t n, int L, const mcomh_params *p);
+void mcomh_destroy(mcomh_pipeline *p);
+const char *mcomh_last_error(const mcomh_pipeline *p);
+
+int mcomh_kt_for_reads(mcomh_pipeline *p);
+int mcomh_kt_for_bucket(mcomh_pipeline *p);
+int mcomh_combine_cluster(mcomh_pipeline *p);
+int mcomh_update_single(mcomh_pipeline *p);
+/* updateSingle + realign_hash at threshold thr; *cluster_reads = reads held by contigs afterwards */
+int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_reads);
+/* the whole timed region of the reference: Stage 1 + Stage 2 with its loop control (preprocess.c:141-233) */
+int mcomh_pre_process(mcomh_pipeline *p);
+/* runs everything and writes the state after every stage in the text format of oracle/refdump.cpp */
+int mcomh_dump_stages(mcomh_pipeline *p, const char *path);
+
+/* results */
+size_t mcomh_n_contigs(const mcomh_pipeline *p);
+const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i);
+size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i);
+const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i);   /* rid<<32 | offset<<1 | dir */
+const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n); /* allA allT allN fpA fpT fpN Nfile sg */
+/* counters: rounds merge_rounds passes windows resketch n_sg0 big_bins; timers (ms): t_reads t_bucket
+ * t_combine t_realign t_gpu t_host */
+double mcomh_stat(const mcomh_pipeline *p, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

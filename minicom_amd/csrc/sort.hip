@@ -282,8 +282,8 @@ __global__ void k_group_flags(const mcom_mm128 *__restrict__ s, size_t n, uint32
 }
 __global__ void k_group_emit(const mcom_mm128 *__restrict__ s, size_t n, const uint32_t *__restrict__ p_single,
                              const uint32_t *__restrict__ p_member, const uint32_t *__restrict__ p_head,
-                             uint32_t *__restrict__ singles, uint64_t *__restrict__ members, uint32_t *__restrict__ group_off,
-                             uint64_t *__restrict__ counts)
+                             uint32_t *__restrict__ singles, uint32_t *__restrict__ single_ord, uint64_t *__restrict__ members,
+                             uint32_t *__restrict__ group_off, uint64_t *__restrict__ counts)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -291,7 +291,7 @@ __global__ void k_group_emit(const mcom_mm128 *__restrict__ s, size_t n, const u
 	const bool valid = r.x != U64MAX;
 	const bool eq_prev = i > 0 && s[i - 1].x == r.x, eq_next = i + 1 < n && s[i + 1].x == r.x;
 	const bool single = valid && !eq_prev && !eq_next, member = valid && (eq_prev || eq_next);
-	if (single) singles[p_single[i]] = (uint32_t)(r.y >> 32);
+	if (single) { singles[p_single[i]] = (uint32_t)(r.y >> 32); if (single_ord) single_ord[p_single[i]] = p_head[i]; }
 	if (member) { members[p_member[i]] = r.y; if (!eq_prev) group_off[p_head[i]] = p_member[i]; }
 	if (i == n - 1) {
 		const uint32_t ns = p_single[i] + (single ? 1u : 0u), nm = p_member[i] + (member ? 1u : 0u), ng = p_head[i] + ((member && !eq_prev) ? 1u : 0u);
@@ -309,8 +309,8 @@ __global__ void k_count_valid(const mcom_mm128 *__restrict__ s, size_t n, uint64
 }
 
 extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int k_orig, int kmer, int b,
-                               mcom_mm128 *d_sorted, uint32_t *d_singles, uint64_t *d_members, uint32_t *d_group_off,
-                               uint64_t *h_counts)
+                               mcom_mm128 *d_sorted, uint32_t *d_singles, uint32_t *d_single_ord, uint64_t *d_members,
+                               uint32_t *d_group_off, uint64_t *h_counts)
 {
 	if (!ctx) return MCOM_E_ARG;
 	if (!h_counts) return mcom_fail(ctx, MCOM_E_ARG, "h_counts is null");
@@ -348,7 +348,7 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	if ((rc = scan_u32(ctx, f1, f1, n, scr))) return rc;
 	if ((rc = scan_u32(ctx, f2, f2, n, scr))) return rc;
 	hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, d_sorted, n, d_counts);
-	hipLaunchKernelGGL(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_members, d_group_off, d_counts);
+	hipLaunchKernelGGL(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_single_ord, d_members, d_group_off, d_counts);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -57,7 +57,7 @@ def load_library():
     L.mcom_sketch_reads.argtypes = [vp, vp, vp, sz, i32, i32, u32, vp]
     L.mcom_radix_sort_128x.restype = i32; L.mcom_radix_sort_128x.argtypes = [vp, vp, sz]
     L.mcom_sort_group.restype = i32
-    L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mcom_sketch_contigs.restype = i32
     L.mcom_sketch_contigs.argtypes = [vp, vp, vp, vp, sz, i32, i32, u32, vp, vp, sz, C.POINTER(u64)]
     L.mcom_pack_contigs.restype = i32; L.mcom_pack_contigs.argtypes = [vp, vp, vp, vp, u32, u64, vp]
@@ -178,13 +178,14 @@ class Context:
         n = int(rec.shape[0])
         srt = self.empty_records(n)
         singles = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        sord = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         members = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         goff = torch.empty(n // 2 + 2, dtype=torch.int32, device=self.device)
         cnt = (C.c_uint64 * 4)()
         self._check(self.lib.mcom_sort_group(self._h, self._p(rec, torch.int64), n, L, k_orig, kmer, b, self._p(srt),
-                                             self._p(singles), self._p(members), self._p(goff), cnt))
+                                             self._p(singles), self._p(sord), self._p(members), self._p(goff), cnt))
         nv, ns, ng, nm = (int(x) for x in cnt)
-        return {"sorted": srt, "n_valid": nv, "singles": singles[:ns], "members": members[:nm], "group_off": goff[:ng + 1] if n else goff[:0],
+        return {"sorted": srt, "n_valid": nv, "singles": singles[:ns], "single_ord": sord[:ns], "members": members[:nm], "group_off": goff[:ng + 1] if n else goff[:0],
                 "n_groups": ng}
 
     # -- contigs

@@ -1,0 +1,126 @@
+"""ctypes binding of libmcom_host.so (include/mcom_host.h): the C++ host driver of the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .hip import McomError, load_library
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("k", "e", "m", "w", "cbthr", "max_rounds", "step", "maxthr", "numdict", "host_threads")]
+
+
+def host_lib_path() -> str:
+    return os.path.join(HERE, "lib", "libmcom_host.so")
+
+
+_lib = None
+
+
+def load_host_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    load_library()                      # libmcom_hip.so first: fails loudly when it has not been built
+    p = host_lib_path()
+    if not os.path.exists(p):
+        raise McomError(f"{p} is missing: run __graft_entry__.build()")
+    L = C.CDLL(p)
+    vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
+    L.mcomh_create.restype = i32
+    L.mcomh_create.argtypes = [C.POINTER(vp), i32, vp, vp, vp, sz, sz, i32, C.POINTER(Params)]
+    L.mcomh_destroy.restype = None; L.mcomh_destroy.argtypes = [vp]
+    L.mcomh_last_error.restype = cp; L.mcomh_last_error.argtypes = [vp]
+    for f in ("mcomh_kt_for_reads", "mcomh_kt_for_bucket", "mcomh_combine_cluster", "mcomh_update_single", "mcomh_pre_process"):
+        getattr(L, f).restype = i32; getattr(L, f).argtypes = [vp]
+    L.mcomh_realign_hash.restype = i32; L.mcomh_realign_hash.argtypes = [vp, i32, C.POINTER(C.c_long)]
+    L.mcomh_dump_stages.restype = i32; L.mcomh_dump_stages.argtypes = [vp, cp]
+    L.mcomh_n_contigs.restype = sz; L.mcomh_n_contigs.argtypes = [vp]
+    L.mcomh_contig_ref.restype = cp; L.mcomh_contig_ref.argtypes = [vp, sz]
+    L.mcomh_contig_n.restype = sz; L.mcomh_contig_n.argtypes = [vp, sz]
+    L.mcomh_contig_members.restype = vp; L.mcomh_contig_members.argtypes = [vp, sz]
+    L.mcomh_list.restype = vp; L.mcomh_list.argtypes = [vp, cp, C.POINTER(sz)]
+    L.mcomh_stat.restype = C.c_double; L.mcomh_stat.argtypes = [vp, cp]
+    _lib = L
+    return L
+
+
+HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
+                    "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
+                    "mcomh_dump_stages", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
+                    "mcomh_list", "mcomh_stat"]
+
+
+class Pipeline:
+    """Stage 1 + Stage 2 of minicom on one GPU.  reads: numpy uint8 [n, L] (host) or a torch uint8 CUDA tensor [n, pitch]."""
+
+    def __init__(self, reads, L: int | None = None, device: int = 0, stream=None, **params):
+        self.lib = load_host_library()
+        p = Params(**{k: int(v) for k, v in params.items()})
+        h = C.c_void_p()
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(0)
+        if isinstance(reads, np.ndarray):
+            reads = np.ascontiguousarray(reads, dtype=np.uint8)
+            n, L = reads.shape
+            self._keep = reads
+            rc = self.lib.mcomh_create(C.byref(h), device, s, reads.ctypes.data_as(C.c_void_p), None, L, n, L, C.byref(p))
+        else:
+            assert reads.is_cuda and reads.is_contiguous() and L is not None
+            n, pitch = reads.shape
+            self._keep = reads
+            rc = self.lib.mcomh_create(C.byref(h), device, s, None, C.c_void_p(reads.data_ptr()), pitch, n, L, C.byref(p))
+        if rc:
+            raise McomError(f"mcomh_create failed ({rc}): no usable GPU or bad arguments; there is no CPU fallback")
+        self._h = h
+        self.n, self.L = n, L
+
+    def _check(self, rc):
+        if rc:
+            raise McomError(f"mcom host error {rc}: {self.lib.mcomh_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mcomh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def kt_for_reads(self): self._check(self.lib.mcomh_kt_for_reads(self._h))
+    def kt_for_bucket(self): self._check(self.lib.mcomh_kt_for_bucket(self._h))
+    def combine_cluster(self): self._check(self.lib.mcomh_combine_cluster(self._h))
+    def update_single(self): self._check(self.lib.mcomh_update_single(self._h))
+    def pre_process(self): self._check(self.lib.mcomh_pre_process(self._h))
+
+    def realign_hash(self, thr: int) -> int:
+        cr = C.c_long()
+        self._check(self.lib.mcomh_realign_hash(self._h, thr, C.byref(cr)))
+        return cr.value
+
+    def dump_stages(self, path: str): self._check(self.lib.mcomh_dump_stages(self._h, path.encode()))
+
+    def stat(self, name: str) -> float:
+        return float(self.lib.mcomh_stat(self._h, name.encode()))
+
+    def id_list(self, name: str) -> np.ndarray:
+        n = C.c_size_t()
+        ptr = self.lib.mcomh_list(self._h, name.encode(), C.byref(n))
+        if not n.value:
+            return np.zeros(0, dtype=np.uint32)
+        return np.frombuffer((C.c_char * (4 * n.value)).from_address(ptr), dtype=np.uint32).copy()
+
+    def contigs(self):
+        out = []
+        for i in range(self.lib.mcomh_n_contigs(self._h)):
+            n = self.lib.mcomh_contig_n(self._h, i)
+            mem = np.frombuffer((C.c_char * (8 * n)).from_address(self.lib.mcomh_contig_members(self._h, i)), dtype=np.uint64).copy() if n else np.zeros(0, np.uint64)
+            out.append((self.lib.mcomh_contig_ref(self._h, i), mem))
+        return out

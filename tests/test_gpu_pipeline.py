@@ -1,0 +1,91 @@
+"""GPU parity of the whole hot path (host driver + HIP kernels) against the REFERENCE's own stage dumps:
+state after kt_for_reads, kt_for_bucket, combine_cluster and every realign pass, byte for byte."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_reads(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, tag + ".reads.gz"), "rb") as f:
+        rows = f.read().split(b"\n")[:-1]
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+
+
+def _first_diff(got, want):
+    gl, wl = got.split(b"\n"), want.split(b"\n")
+    for i, (a, b) in enumerate(zip(gl, wl)):
+        if a != b:
+            stage = [x for x in wl[:i] if x.startswith(b"STAGE")][-1:]
+            return f"first difference at line {i} after {stage}: got {a[:200]!r} want {b[:200]!r}"
+    return f"length differs: {len(gl)} vs {len(wl)} lines"
+
+
+@pytest.mark.parametrize("tag,k,threads", [("stages_L100", 0, 1), ("stages_L150", 0, 4), ("stages_L100_k24", 24, 2)])
+def test_pipeline_stage_dumps_equal_reference(golden_dir, tmp_path, tag, k, threads):
+    from minicom_amd.pipeline import Pipeline
+    reads = _golden_reads(golden_dir, tag)
+    with gzip.open(os.path.join(golden_dir, tag + ".dump.gz"), "rb") as f:
+        want = f.read()
+    p = Pipeline(reads, k=k, host_threads=threads)
+    out = str(tmp_path / "dump.txt")
+    p.dump_stages(out)
+    got = open(out, "rb").read()
+    assert got == want, _first_diff(got, want)
+    assert p.stat("rounds") >= 2 and p.stat("passes") >= 2 and p.stat("big_bins") == 0
+    p.close()
+
+
+def test_pipeline_equals_oracle_on_fresh_synthetic_reads():
+    """A read set no fixture covers: final contigs, members and leftover singletons equal the oracle's."""
+    import oracle
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = synth.synth_reads(777, 6000, 150, plumbing=True)
+    o = oracle.Pipeline(reads); o.run_all()
+    p = Pipeline(reads, host_threads=3); p.pre_process()
+    oc, pc = o.contigs(), p.contigs()
+    assert len(oc) == len(pc) and len(oc) > 20
+    for (r0, m0), (r1, m1) in zip(oc, pc):
+        assert r0 == r1 and np.array_equal(m0, m1)
+    for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        assert np.array_equal(o.id_list(name), p.id_list(name)), name
+    p.close(); o.close()
+
+
+def test_pipeline_device_resident_input_and_lossless_accounting():
+    """Reads generated in HBM (the bench path): every read ends in exactly one place."""
+    import torch
+    import minicom_amd
+    from minicom_amd.pipeline import Pipeline
+    n, L = 200000, 150
+    ctx = minicom_amd.Context(0)
+    a = ctx.synth_reads(1002, n, L)
+    ctx.sync()
+    p = Pipeline(a, L=L, host_threads=8)
+    p.pre_process()
+    seen = np.zeros(n, dtype=np.int32)
+    for _, mem in p.contigs():
+        np.add.at(seen, (mem >> np.uint64(32)).astype(np.int64), 1)
+    for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        np.add.at(seen, p.id_list(name).astype(np.int64), 1)
+    assert int(seen.min()) == 1 and int(seen.max()) == 1
+    # every member really lies on its contig within the thresholds the pipeline used
+    reads = a.cpu().numpy()
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    bad = 0
+    for ref, mem in p.contigs()[:300]:
+        r = np.frombuffer(ref, dtype=np.uint8)
+        for y in mem.tolist():
+            rid, off, d = y >> 32, (y & 0xFFFFFFFF) >> 1, y & 1
+            s = reads[rid]
+            if d:
+                s = comp[s][::-1]
+            if int((r[off:off + L] != s).sum()) > L // 2:
+                bad += 1
+    assert bad == 0
+    assert p.stat("t_gpu") > 0
+    p.close(); ctx.close()
