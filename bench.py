@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of minicom's sketch + index + overlap hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one full pass of the hot path (the reference's timed region, Stage 1 + Stage 2,
+preprocess.c:137-234) over one batch of synthetic reads that are already resident in HBM:
+BASELINE.json configs[1], 100 M x 150 bp, k = 31, default parameters, per GPU.
+N > 1: one process per GPU; every rank sketches its shard, the reads move to the owners of their minimizer
+buckets with one RCCL all-to-all (minicom_amd/distributed.py), then every rank runs the rest of the path on
+its partition ("weak" scaling: reads per GPU fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 1002            # seed = 1000 + config number
+
+
+def cpu_baseline(L, sample):
+    """The reference itself (oracle/_ref, built from /root/reference in the build container) on the host cores,
+    on a bounded sample of the same workload; falls back to the C restatement (oracle/) when the binary is absent."""
+    from minicom_amd import synth
+    reads = synth.synth_reads(SEED, sample, L)
+    tag = f"{sample} reads x {L} bp, same generator (seed {SEED}, 30x coverage, 0.5% substitutions)"
+    for variant, cores in (("L150_t16", 16), ("L150", 1)):
+        exe = os.path.join(ROOT, "oracle", "_ref", variant, "minicom_bin")
+        if L != 150 or not os.path.exists(exe):
+            continue
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "s.fastq")
+                synth.write_fastq(fq, reads)
+                out = os.path.join(td, "out"); os.makedirs(out)
+                cwd = os.path.join(td, "cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
+                p = subprocess.run([exe, fq, out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+                t = [float(x) for x in re.findall(r"\[Stage \d\] Real time: ([\d.]+)", p.stdout.decode())]
+                if p.returncode == 0 and len(t) == 2:
+                    return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": cores, "kind": "reference",
+                            "sample": tag + f"; reference's own Stage 1 + Stage 2 timers, -t {cores}", "seconds": round(sum(t), 3)}
+        except Exception:
+            pass
+    import oracle
+    p = oracle.Pipeline(reads)
+    t0 = time.perf_counter(); p.run_all(); dt = time.perf_counter() - t0
+    p.close()
+    return {"value": round(sample / dt / 1e6, 6), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": tag + "; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
+
+
+# algorithmic bytes per unit of every timed kernel class
+def algorithmic_bytes(name, st, L, nd):
+    W = (2 * L + 63) // 64
+    if name == "realign_windows":      # per (window, dir, dict): 8 key + 8 table word + 8 rank + 8 startpos + 4 id + 8W verify
+        return (36 + 8 * W) * (2 * nd - 1) * st["windows"]
+    if name == "sketch_reads":         # packed row in, one record out
+        return (8 * W + 16) * (st["n"] + st["resketch"])
+    if name == "classify_pack":        # ASCII in, packed row + class + N count out
+        return (L + 8 * W + 3) * st["n"]
+    if name == "sketch_contigs":       # every contig base (1 byte) once per launch: a count launch and an emit launch per call
+        return st.get("sketch_bases", 0) or None
+    return None                        # radix_pass / dict_build / find_next: launches of many sizes, no single byte model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import minicom_amd
+    from minicom_amd.pipeline import Pipeline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    L, n_local = a.read_len, a.reads
+    n_total = n_local * world
+    threads = a.host_threads or max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
+    ctx = minicom_amd.Context(local_rank)
+
+    # synthetic input, resident in HBM before any timed region: this rank's shard of one n_total-read set
+    reads = ctx.synth_reads(SEED, n_total, L, first=rank * n_local, count=n_local)
+    ctx.sync()
+
+    agg = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(timed):
+        if world == 1:
+            p = Pipeline(reads, L=L, device=local_rank, host_threads=threads)
+        else:
+            from minicom_amd.distributed import exchange_by_bucket
+            out = ctx.process_reads(reads, L, 31, rid0=0)
+            keep = (out["cls"] == 0).nonzero().squeeze(1)
+            x = out["rec"][:, 0][keep]
+            rids = keep + rank * n_local
+            _, rows = exchange_by_bucket(x, rids, out["packed"][keep])
+            del out
+            p = Pipeline(rows, L=L, device=local_rank, host_threads=threads, packed=True)
+        p.prof_enable(True)
+        p.pre_process()
+        if timed:
+            for k in ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu"):
+                agg[k] = agg.get(k, 0.0) + p.stat(k)
+            agg["n"] = agg.get("n", 0.0) + p.n
+            for name in ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows"):
+                ms, calls = p.prof_read(name)
+                agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
+                agg["calls_" + name] = agg.get("calls_" + name, 0) + calls
+        p.close()
+
+    for _ in range(a.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        nd = len(minicom_amd.hip.dict_layout(L)[0])
+        st = dict(agg)
+        # dominant kernel class by device time over the timed steps (HIP events on the launch stream)
+        names = ["classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows"]
+        roof = None
+        for cand in sorted(names, key=lambda q: -agg.get("ms_" + q, 0.0)):   # the dominant class that has a byte model
+            b = algorithmic_bytes(cand, st, L, nd)
+            if b and agg.get("ms_" + cand, 0.0) > 0:
+                ms, calls = agg["ms_" + cand], agg["calls_" + cand]
+                achieved = (b / calls) / (ms / calls * 1e-3) / 1e9
+                roof = {"kernel": cand, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": None, "launches": int(calls),
+                        "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
+                        "device_ms_per_step_by_kernel": {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in names}}
+                break
+        res = {
+            "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",
+            "value": round(n_total * a.steps / dt / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{n_local // 1_000_000}M x {L}bp synthetic reads per GPU, k=31 default params (BASELINE configs[1]); "
+                                   "full Stage 1 + Stage 2 per step", "reads_per_gpu": n_local, "read_len": L, "k": 31,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: reads sharded, minimizer-bucket all-to-all over RCCL",
+                       "host_threads": threads,
+                       "per_step": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("rounds", "merge_rounds", "passes", "windows", "resketch", "n_sg0", "big_bins")},
+                       "stage_ms_rank0": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu")}},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(L, a.cpu_sample)
+        elif not a.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

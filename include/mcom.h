@@ -55,6 +55,13 @@ int  mcom_sync(mcom_ctx *ctx);
 const char *mcom_last_error(const mcom_ctx *ctx);
 const char *mcom_version(void);
 
+/* Optional kernel timing: when enabled every hot kernel launch is bracketed by HIP events recorded on the
+ * context's stream.  Names: classify_pack sketch_reads radix_pass sketch_contigs find_next dict_build
+ * realign_windows.  mcom_prof_read synchronises and returns the accumulated device time and launch count. */
+int mcom_prof_enable(mcom_ctx *ctx, int on);
+int mcom_prof_reset(mcom_ctx *ctx);
+int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
+
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:
  * classify, substitute N by the majority base (tie order A,T,G,C), 2-bit pack, and sketch the kept

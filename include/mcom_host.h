@@ -36,6 +36,10 @@ typedef struct mcomh_pipeline mcomh_pipeline;
  * alternatively d_reads [n][pitch] is already resident in HBM (exactly one of the two is non-NULL).      */
 int  mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, const uint8_t *host_reads,
                   const uint8_t *d_reads, size_t pitch, size_t n, int L, const mcomh_params *p);
+/* Same, from 2-bit packed rows already in HBM (include/mcom.h format, ACGT only, every read kept): the
+ * entry used after the multi-GPU minimizer-bucket exchange, where a rank receives its partition packed.  */
+int  mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, const uint64_t *d_packed, size_t n, int L,
+                         const mcomh_params *p);
 void mcomh_destroy(mcomh_pipeline *p);
 const char *mcomh_last_error(const mcomh_pipeline *p);
 
@@ -59,6 +63,9 @@ const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 /* counters: rounds merge_rounds passes windows resketch n_sg0 big_bins; timers (ms): t_reads t_bucket
  * t_combine t_realign t_gpu t_host */
 double mcomh_stat(const mcomh_pipeline *p, const char *name);
+/* kernel timing of the pipeline's own mcom_ctx (mcom_prof_enable / mcom_prof_read of include/mcom.h) */
+int mcomh_prof_enable(mcomh_pipeline *p, int on);
+int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *total_ms, uint64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 #include "mcom_dev.hpp"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -68,3 +69,47 @@ extern "C" int mcom_sync(mcom_ctx *ctx)
 }
 
 extern "C" const char *mcom_last_error(const mcom_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ---- optional kernel timing with HIP events on the context's stream ------------------------------------
+static const char *PROF_NAMES[PROF_COUNT] = { "classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next",
+                                              "dict_build", "realign_windows" };
+
+static void prof_collect(mcom_ctx *ctx)
+{
+	if (ctx->prof_open.empty()) return;
+	(void)hipStreamSynchronize(ctx->stream);
+	for (McomProfSpan &s : ctx->prof_open) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { ctx->prof_ms[s.id] += ms; ctx->prof_calls[s.id] += 1; }
+		(void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+	}
+	ctx->prof_open.clear();
+}
+
+extern "C" int mcom_prof_enable(mcom_ctx *ctx, int on)
+{
+	if (!ctx) return MCOM_E_ARG;
+	prof_collect(ctx);
+	ctx->prof_on = on != 0;
+	return MCOM_OK;
+}
+
+extern "C" int mcom_prof_reset(mcom_ctx *ctx)
+{
+	if (!ctx) return MCOM_E_ARG;
+	prof_collect(ctx);
+	for (int i = 0; i < PROF_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_calls[i] = 0; }
+	return MCOM_OK;
+}
+
+extern "C" int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches)
+{
+	if (!ctx || !name) return MCOM_E_ARG;
+	prof_collect(ctx);
+	for (int i = 0; i < PROF_COUNT; ++i) if (!strcmp(name, PROF_NAMES[i])) {
+		if (total_ms) *total_ms = ctx->prof_ms[i];
+		if (launches) *launches = ctx->prof_calls[i];
+		return MCOM_OK;
+	}
+	return mcom_fail(ctx, MCOM_E_ARG, "unknown profiler name %s", name);
+}

@@ -93,7 +93,8 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	if (rc) return rc;
 	const unsigned blocks = (unsigned)((n + 63) / 64);
 	// counts go to d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
-	hipLaunchKernelGGL((k_sketch_contigs<false>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, d_moff, nullptr, nullptr);
+	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
+	hipLaunchKernelGGL((k_sketch_contigs<false>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, d_moff, nullptr, nullptr); }
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, (uint32_t*)ctx->ws);
@@ -105,7 +106,8 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
 	if (total == 0) return MCOM_OK;
 	if (!d_out) return mcom_fail(ctx, MCOM_E_ARG, "null output pointer");
-	hipLaunchKernelGGL((k_sketch_contigs<true>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, nullptr, d_moff, d_out);
+	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
+	hipLaunchKernelGGL((k_sketch_contigs<true>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, nullptr, d_moff, d_out); }
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -366,7 +368,8 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate buffers: %s", hipGetErrorString(e1)); }
 	rc = mcom_ws_reserve(ctx, scr2_b);
 	if (rc) { cleanup(); return rc; }
-	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass);
+	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
+	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
 	uint32_t last_flag = 0, n_pass = 0;
 	e1 = hipMemcpyAsync(&last_flag, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
 	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);

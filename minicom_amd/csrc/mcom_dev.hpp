@@ -4,7 +4,13 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <vector>
 #include "../../include/mcom.h"
+
+// kernel classes timed by the optional in-library profiler (mcom_prof_*): HIP events on the launch stream
+enum McomProfId { PROF_CLASSIFY_PACK = 0, PROF_SKETCH_READS, PROF_RADIX_PASS, PROF_SKETCH_CONTIGS, PROF_FIND_NEXT,
+                  PROF_DICT_BUILD, PROF_REALIGN_WINDOWS, PROF_COUNT };
+struct McomProfSpan { int id; hipEvent_t a, b; };
 
 struct mcom_ctx {
 	int device;
@@ -13,6 +19,25 @@ struct mcom_ctx {
 	// grow-only device workspace
 	void *ws; size_t ws_bytes;
 	int n_cu;
+	// profiler
+	bool prof_on = false;
+	std::vector<McomProfSpan> prof_open;
+	double prof_ms[PROF_COUNT] = {0};
+	uint64_t prof_calls[PROF_COUNT] = {0};
+};
+
+// brackets one kernel launch (or a short launch sequence) with events when the profiler is on
+struct McomProfScope {
+	mcom_ctx *ctx; int idx;
+	McomProfScope(mcom_ctx *c, int id) : ctx(c), idx(-1) {
+		if (!c->prof_on) return;
+		McomProfSpan s; s.id = id;
+		if (hipEventCreate(&s.a) != hipSuccess) return;
+		if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+		(void)hipEventRecord(s.a, c->stream);
+		c->prof_open.push_back(s); idx = (int)c->prof_open.size() - 1;
+	}
+	~McomProfScope() { if (idx >= 0) (void)hipEventRecord(ctx->prof_open[idx].b, ctx->stream); }
 };
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);

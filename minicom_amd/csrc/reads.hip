@@ -235,6 +235,7 @@ static int launch_sketch(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t
 	const int W = mcom_words_per_read(L);
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 #define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_sketch_reads<WW, WIDE>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
+	McomProfScope ps_(ctx, PROF_SKETCH_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported (1..256)", L); }
 #undef MCOM_CASE
@@ -270,8 +271,9 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 	size_t blocks = (waves + 3) / 4;
 	const size_t cap = (size_t)ctx->n_cu * 16;
 	if (blocks > cap) blocks = cap;
+	{ McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
 	if (G == 16) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
-	else         hipLaunchKernelGGL((k_classify_pack<32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
+	else         hipLaunchKernelGGL((k_classify_pack<32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
 	MCOM_LAUNCH_CHECK(ctx);
 	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
 	if (rc) return rc;

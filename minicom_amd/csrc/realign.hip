@@ -187,6 +187,7 @@ extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t 
 	uint32_t *meta = (uint32_t*)(base + rec_b + sort_b + head_b + scr_b);
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 	for (int j = 0; j < d->nd; ++j) {
+		McomProfScope ps_(ctx, PROF_DICT_BUILD);
 		hipError_t e2 = hipMalloc(&d->ids[j], (n ? n : 1) * 4);
 		if (e2 != hipSuccess) { d->ids[j] = nullptr; mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
 		if (n) {
@@ -364,6 +365,7 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 	const uint64_t blocks = (n_windows + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many windows for one launch");
 #define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_windows<WW>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dd, d_sgbits, d_sgflag, d_cbits, d_coff, d_woff, n_contigs, n_windows, thr, maxsearch, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
+	McomProfScope ps_(ctx, PROF_REALIGN_WINDOWS);
 	switch (d->W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE

@@ -207,6 +207,7 @@ static int radix_sort_records(mcom_ctx *ctx, mcom_mm128 *a, mcom_mm128 *tmp, siz
 	const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
 	mcom_mm128 *src = a, *dst = tmp;
 	for (int p = 0; p < passes; ++p) {
+		McomProfScope ps_(ctx, PROF_RADIX_PASS);
 		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, ks, p, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 		int rc = scan_u32(ctx, hist, hist, (size_t)256 * nblocks, scratch);

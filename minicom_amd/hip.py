@@ -43,6 +43,9 @@ def load_library():
     if not os.path.exists(p):
         raise McomError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback for the product path)")
+    # PyTorch ships its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the whole process,
+    # and torch.cuda stops working when it is not torch's.  So torch is always imported before our library.
+    import torch  # noqa: F401
     L = C.CDLL(p)
     vp, sz, i32, u32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64
     L.mcom_create.restype = i32; L.mcom_create.argtypes = [C.POINTER(vp), i32, vp]
@@ -51,6 +54,9 @@ def load_library():
     L.mcom_sync.restype = i32; L.mcom_sync.argtypes = [vp]
     L.mcom_last_error.restype = C.c_char_p; L.mcom_last_error.argtypes = [vp]
     L.mcom_version.restype = C.c_char_p; L.mcom_version.argtypes = []
+    L.mcom_prof_enable.restype = i32; L.mcom_prof_enable.argtypes = [vp, i32]
+    L.mcom_prof_reset.restype = i32; L.mcom_prof_reset.argtypes = [vp]
+    L.mcom_prof_read.restype = i32; L.mcom_prof_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
     L.mcom_process_reads.restype = i32
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32

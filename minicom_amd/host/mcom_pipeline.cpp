@@ -54,6 +54,7 @@ struct mcomh_pipeline {
 	int host_threads = 1;
 	// device
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
+	const uint64_t *ext_packed = nullptr;    // packed-row input (mcomh_create_packed): no classification stage
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
@@ -122,6 +123,21 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	return MCOM_OK;
 }
 
+extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, const uint64_t *d_packed, size_t n, int L,
+                                   const mcomh_params *pp)
+{
+	if (!out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (n && !d_packed) return MCOM_E_ARG;
+	static const uint8_t dummy = 0;
+	// reuse the parameter resolution of mcomh_create with a placeholder device pointer, then switch the input
+	int rc = mcomh_create(out, device, hip_stream, nullptr, n ? (const uint8_t*)d_packed : &dummy, (size_t)L, n, L, pp);
+	if (rc) return rc;
+	(*out)->d_ascii = nullptr;
+	(*out)->ext_packed = d_packed;
+	return MCOM_OK;
+}
+
 extern "C" void mcomh_destroy(mcomh_pipeline *p)
 {
 	if (!p) return;
@@ -142,7 +158,16 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 	const size_t n = p->n;
 	if (!p->d_packed.reserve(n * p->W + 1) || !p->d_nmask.reserve(n * p->NW + 1) || !p->d_cls.reserve(n + 1) ||
 	    !p->d_ncnt.reserve(n + 1) || !p->d_rec.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "read buffers");
-	int rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
+	int rc;
+	if (p->ext_packed) {
+		// packed rows handed over by the caller: every read is a kept read (class 0) without N
+		if (n && ((rc = p->hipc(hipMemcpyAsync(p->d_packed.p, p->ext_packed, n * (size_t)p->W * 8, hipMemcpyDeviceToDevice, p->stream), "copy packed rows")) ||
+		          (rc = p->hipc(hipMemsetAsync(p->d_cls.p, 0, n, p->stream), "clear")) ||
+		          (rc = p->hipc(hipMemsetAsync(p->d_nmask.p, 0, n * (size_t)p->NW * 8, p->stream), "clear")))) return rc;
+		rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, nullptr, n, p->L, p->k, 0, p->d_rec.p));
+	} else {
+		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
+	}
 	if (rc) return rc;
 	p->h_cls.resize(n); p->h_packed.resize(n * (size_t)p->W);
 	if (n) {
@@ -294,6 +319,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				return p->fail(MCOM_E_NOMEM, "round buffers");
 			uint64_t cnts[4];
 			const double tg = now_ms();
+			p->stat["sort_records"] += (double)n_cur * (double)((2 * kmer_in + 10 + 7) / 8);   // records x LSD passes
 			int rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts));
 			if (rc) return rc;
 			const size_t ns = cnts[1], ng = cnts[2], nm = cnts[3];
@@ -391,6 +417,7 @@ static int upload_contigs(P *p, const std::vector<Contig> &cs, DevContigs &d, bo
 static int sketch_contigs(P *p, const DevContigs &d, uint32_t max_per, DevBuf<uint32_t> &moff, DevBuf<mcom_mm128> &out, uint64_t &total)
 {
 	total = 0;
+	p->stat["sketch_bases"] += 2.0 * (double)d.h_off[d.n];          // one count launch + one emit launch
 	if (!moff.reserve(d.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
 	size_t cap = std::max<size_t>(1024, max_per ? d.n * max_per : d.h_off[d.n] / 8 + d.n);
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -444,7 +471,10 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
 		// first-come claiming in contig order (find_next :267-343 at one thread)
+		const double tc0 = now_ms();
 		std::vector<uint8_t> flag(n, 0);
+		struct Job { uint32_t ci, cj, pos_ori, pos; };
+		std::vector<Job> jobs;
 		for (size_t q = 0; q < n_pass;) {
 			const uint32_t ci = (uint32_t)(pairs[q].x >> 32) >> 8;
 			size_t qe = q;
@@ -453,25 +483,40 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				for (size_t u = q; u < qe; ++u) {
 					const uint32_t cj = (uint32_t)(pairs[u].y >> 32) >> 8;
 					if (flag[cj]) continue;
-					const uint32_t pos_ori = (uint32_t)pairs[u].x >> 1, pos = (uint32_t)pairs[u].y >> 1;
-					const Contig &a = src[ci], &b = src[cj];
-					Contig t;
-					t.a.reserve(a.a.size() + b.a.size());
-					if (pos_ori >= pos) {                                                   // :302-315
-						t.a.insert(t.a.end(), a.a.begin(), a.a.end());
-						for (uint64_t y : b.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(pos_ori - pos)) << 1) | (y & 1));
-					} else {                                                                // :316-325
-						t.a.insert(t.a.end(), b.a.begin(), b.a.end());
-						for (uint64_t y : a.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(pos - pos_ori)) << 1) | (y & 1));
-					}
-					construct_ref2(p, t, cnt);
-					flag[ci] = flag[cj] = 1;
-					dst.emplace_back(std::move(t));
+					jobs.push_back(Job{ci, cj, (uint32_t)pairs[u].x >> 1, (uint32_t)pairs[u].y >> 1});
+					flag[ci] = flag[cj] = 1;                                                // :339-343
 					break;
 				}
 			}
 			q = qe;
 		}
+		// the merged contigs themselves are independent of each other: build them on all host threads
+		const double tc1 = now_ms();
+		p->stat["t_claim"] += tc1 - tc0;
+		dst.resize(jobs.size());
+		{
+			const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, jobs.size() / 16)));
+			auto work = [&](int tid) {
+				std::vector<uint32_t> lcnt;
+				for (size_t j = (size_t)tid; j < jobs.size(); j += (size_t)nt) {
+					const Job &jb = jobs[j];
+					const Contig &a = src[jb.ci], &b = src[jb.cj];
+					Contig &t = dst[j];
+					t.a.reserve(a.a.size() + b.a.size());
+					if (jb.pos_ori >= jb.pos) {                                             // :302-315
+						t.a.insert(t.a.end(), a.a.begin(), a.a.end());
+						for (uint64_t y : b.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(jb.pos_ori - jb.pos)) << 1) | (y & 1));
+					} else {                                                                // :316-325
+						t.a.insert(t.a.end(), b.a.begin(), b.a.end());
+						for (uint64_t y : a.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(jb.pos - jb.pos_ori)) << 1) | (y & 1));
+					}
+					construct_ref2(p, t, lcnt);
+				}
+			};
+			if (nt == 1) work(0);
+			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
+		}
+		p->stat["t_merge_cons"] += now_ms() - tc1;
 		for (size_t i = 0; i < n; ++i) if (!flag[i]) dst.emplace_back(std::move(src[i]));   // cp_cluster (:397-434)
 		src.clear();
 		p->stat["merge_rounds"] += 1;
@@ -725,6 +770,11 @@ extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name,
 	if (!v) { if (n) *n = 0; return nullptr; }
 	if (n) *n = v->size();
 	return v->data();
+}
+extern "C" int mcomh_prof_enable(mcomh_pipeline *p, int on) { return p ? mcom_prof_enable(p->ctx, on) : MCOM_E_ARG; }
+extern "C" int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *total_ms, uint64_t *launches)
+{
+	return p ? p->gpu(mcom_prof_read(p->ctx, name, total_ms, launches)) : MCOM_E_ARG;
 }
 extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 {

@@ -34,6 +34,8 @@ def load_host_library():
     vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.mcomh_create.restype = i32
     L.mcomh_create.argtypes = [C.POINTER(vp), i32, vp, vp, vp, sz, sz, i32, C.POINTER(Params)]
+    L.mcomh_create_packed.restype = i32
+    L.mcomh_create_packed.argtypes = [C.POINTER(vp), i32, vp, vp, sz, i32, C.POINTER(Params)]
     L.mcomh_destroy.restype = None; L.mcomh_destroy.argtypes = [vp]
     L.mcomh_last_error.restype = cp; L.mcomh_last_error.argtypes = [vp]
     for f in ("mcomh_kt_for_reads", "mcomh_kt_for_bucket", "mcomh_combine_cluster", "mcomh_update_single", "mcomh_pre_process"):
@@ -46,25 +48,33 @@ def load_host_library():
     L.mcomh_contig_members.restype = vp; L.mcomh_contig_members.argtypes = [vp, sz]
     L.mcomh_list.restype = vp; L.mcomh_list.argtypes = [vp, cp, C.POINTER(sz)]
     L.mcomh_stat.restype = C.c_double; L.mcomh_stat.argtypes = [vp, cp]
+    L.mcomh_prof_enable.restype = i32; L.mcomh_prof_enable.argtypes = [vp, i32]
+    L.mcomh_prof_read.restype = i32; L.mcomh_prof_read.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
 
-HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
+HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
-                    "mcomh_list", "mcomh_stat"]
+                    "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read"]
 
 
 class Pipeline:
     """Stage 1 + Stage 2 of minicom on one GPU.  reads: numpy uint8 [n, L] (host) or a torch uint8 CUDA tensor [n, pitch]."""
 
-    def __init__(self, reads, L: int | None = None, device: int = 0, stream=None, **params):
+    def __init__(self, reads, L: int | None = None, device: int = 0, stream=None, packed: bool = False, **params):
         self.lib = load_host_library()
         p = Params(**{k: int(v) for k, v in params.items()})
         h = C.c_void_p()
         s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(0)
-        if isinstance(reads, np.ndarray):
+        if packed:
+            # int64 CUDA tensor [n, W] of packed rows (include/mcom.h format)
+            assert reads.is_cuda and reads.is_contiguous() and L is not None and reads.shape[1] == (2 * L + 63) // 64
+            n = int(reads.shape[0])
+            self._keep = reads
+            rc = self.lib.mcomh_create_packed(C.byref(h), device, s, C.c_void_p(reads.data_ptr()), n, L, C.byref(p))
+        elif isinstance(reads, np.ndarray):
             reads = np.ascontiguousarray(reads, dtype=np.uint8)
             n, L = reads.shape
             self._keep = reads
@@ -106,6 +116,14 @@ class Pipeline:
         return cr.value
 
     def dump_stages(self, path: str): self._check(self.lib.mcomh_dump_stages(self._h, path.encode()))
+
+    def prof_enable(self, on: bool = True): self._check(self.lib.mcomh_prof_enable(self._h, 1 if on else 0))
+
+    def prof_read(self, name: str):
+        """(device milliseconds, launches) of one kernel class, measured with HIP events on the launch stream."""
+        ms = C.c_double(); n = C.c_uint64()
+        self._check(self.lib.mcomh_prof_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def stat(self, name: str) -> float:
         return float(self.lib.mcomh_stat(self._h, name.encode()))

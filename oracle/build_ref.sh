@@ -25,7 +25,7 @@ build_variant() {   # name readlen extra_defines...
       case "$x" in ORDER|_PE) echo "int cmpcluster3(const void *a_, const void *b_);";; esac
     done
     echo "#define readlen $L"
-    echo "#define num_thr 1"
+    echo "#define num_thr ${NUM_THR:-1}"
     echo "#define uniqid \"uref\""
     echo "#define output \"output_ref/\""
     for m in inik inithr inimaxthr inistep ininumdict iniw inim inicbthr inimaxrounds; do echo "#define $m 0"; done
@@ -58,3 +58,5 @@ build_variant L100 100
 build_variant L150 150
 build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE
+# multi-threaded builds, used only as the CPU baseline of bench.py (their output is not reproducible run to run)
+NUM_THR=16 build_variant L150_t16 150

@@ -1,0 +1,30 @@
+"""Developer timing of the whole hot path (host driver + kernels) at several sizes."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import minicom_amd
+from minicom_amd.pipeline import Pipeline
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, nargs="+", default=[1_000_000])
+ap.add_argument("--L", type=int, default=150)
+ap.add_argument("--threads", type=int, default=16)
+a = ap.parse_args()
+ctx = minicom_amd.Context(0)
+for n in a.n:
+    reads = ctx.synth_reads(1002, n, a.L)
+    ctx.sync()
+    t0 = time.perf_counter()
+    p = Pipeline(reads, L=a.L, host_threads=a.threads)
+    p.pre_process()
+    dt = time.perf_counter() - t0
+    keys = ["t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "rounds", "merge_rounds", "passes", "windows", "resketch", "n_sg0", "big_bins", "cand_pairs", "t_claim", "t_merge_cons"]
+    print(f"n={n} L={a.L}: {dt:.3f} s  {n/dt/1e6:.3f} Mreads/s  contigs={len(p.contigs()) if n <= 2_000_000 else -1} sg={len(p.id_list('sg'))}", flush=True)
+    print("   " + " ".join(f"{k}={p.stat(k):.0f}" for k in keys), flush=True)
+    p.close()
+    del reads
+    torch.cuda.empty_cache()
