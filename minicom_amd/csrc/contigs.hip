@@ -22,34 +22,80 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 // mm_sketch_lh_ori.  EMIT = false counts, EMIT = true writes; at most `limit` minimizers per contig.
 // The ring keeps (hash, pos<<1|strand) per slot; y = id<<32 | that.
 // ------------------------------------------------------------------------------------------------
+//
+// One wave (one 64-thread workgroup) per contig, the contig taken in pieces of PIECE bases:
+//   phase 1, all 64 lanes: every lane rolls the forward / reverse k-mers of its PIECE/64 consecutive bases
+//            (warmed up over the k-1 valid bases before them) and leaves the hash, the strand, the
+//            "own reverse complement" flag and the ambiguous-base flag of every position in LDS;
+//   phase 2, lane 0: the reference's window scan, statement for statement, reading those values from LDS,
+//            with its ring of the last w entries also in LDS.
+// The hashing (the expensive part) is spread over the wave; the sequential part is a few LDS reads a base.
+#define PIECE 512
+#define PER_LANE (PIECE / 64)
+
 template <bool EMIT>
 __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                        const uint32_t *__restrict__ ids, size_t n, int w, int k, uint32_t limit,
                                                        uint32_t *__restrict__ cnt, const uint32_t *__restrict__ out_off,
                                                        mcom_mm128 *__restrict__ out)
 {
-	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ uint64_t PX[PIECE];          // hash of the canonical k-mer ending at each position of the piece
+	__shared__ uint8_t PF[PIECE];           // bit0 strand, bit1 k-mer equals its reverse complement, bit2 ambiguous base
+	__shared__ uint64_t rx[MAXW];           // ring of the last w entries: hash ...
+	__shared__ uint32_t rp[MAXW];           // ... and pos<<1|strand (0xFFFFFFFF for an empty entry)
+	__shared__ uint32_t done;
+	const size_t t = blockIdx.x;
 	if (t >= n) return;
+	const int lane = threadIdx.x;
 	const uint8_t *s = seq + off[t];
 	const int len = (int)(off[t + 1] - off[t]);
 	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
 	const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ull << (2 * k)) - 1;
-	uint64_t rx[MAXW]; uint32_t rp[MAXW];
-	for (int j = 0; j < w; ++j) { rx[j] = U64MAX; rp[j] = 0xFFFFFFFFu; }
-	uint64_t fwd = 0, rev = 0, bx = U64MAX; uint32_t bp = 0xFFFFFFFFu;
+	for (int j = lane; j < w; j += 64) { rx[j] = U64MAX; rp[j] = 0xFFFFFFFFu; }
+	if (lane == 0) done = 0;
+	uint64_t bx = U64MAX; uint32_t bp = 0xFFFFFFFFu;
 	int run = 0, slot = 0, bslot = 0;
 	uint32_t ne = 0;
 	mcom_mm128 *o = EMIT ? out + out_off[t] : nullptr;
 #define PUT(X, P) do { if (ne < limit) { if (EMIT) { mcom_mm128 v_; v_.x = (X); v_.y = (X) == U64MAX && (P) == 0xFFFFFFFFu ? U64MAX : (idhi | (P)); o[ne] = v_; } } ++ne; } while (0)
-	for (int i = 0; i < len && ne < limit; ++i) {
-		const int c = nt4_of(s[i]);
+	for (int ps = 0; ps < len; ps += PIECE) {
+		const int pe = ps + PIECE < len ? ps + PIECE : len;
+		__syncthreads();                                   // phase 2 of the previous piece has finished with PX / PF
+		if (done) break;
+		{   // ---- phase 1
+			const int a = ps + lane * PER_LANE;
+			if (a < pe) {
+				// k-mer registers as the reference has them before position a: the last k-1 VALID bases (ambiguous
+				// bases do not enter the registers, sketch.c:129-132), or everything from the contig start
+				int st = a, need = k - 1;
+				while (st > 0 && need > 0) { --st; if (nt4_of(s[st]) < 4) --need; }
+				uint64_t fwd = 0, rev = 0;
+				for (int i = st; i < a; ++i) {
+					const int c = nt4_of(s[i]);
+					if (c < 4) { fwd = ((fwd << 2) | (uint64_t)c) & mask; rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1); }
+				}
+				const int b = a + PER_LANE < pe ? a + PER_LANE : pe;
+				for (int i = a; i < b; ++i) {
+					const int c = nt4_of(s[i]);
+					uint8_t f = 0; uint64_t x = U64MAX;
+					if (c < 4) {
+						fwd = ((fwd << 2) | (uint64_t)c) & mask;
+						rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1);
+						if (fwd == rev) f = 2;
+						else { const uint32_t z = fwd < rev ? 0u : 1u; f = (uint8_t)z; x = mcom_hash64(z ? rev : fwd, mask); }
+					} else f = 4;
+					PX[i - ps] = x; PF[i - ps] = f;
+				}
+			}
+		}
+		__syncthreads();
+		if (lane == 0) {   // ---- phase 2: sketch.c:126-162
+	for (int i = ps; i < pe && ne < limit; ++i) {
+		const uint8_t f = PF[i - ps];
 		uint64_t cx = U64MAX; uint32_t cp = 0xFFFFFFFFu;
-		if (c < 4) {
-			fwd = ((fwd << 2) | (uint64_t)c) & mask;
-			rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1);
-			if (fwd == rev) continue;
-			const uint32_t z = fwd < rev ? 0u : 1u;
-			if (++run >= k) { cx = mcom_hash64(z ? rev : fwd, mask); cp = ((uint32_t)i << 1) | z; }
+		if (!(f & 4)) {
+			if (f & 2) continue;
+			if (++run >= k) { cx = PX[i - ps]; cp = ((uint32_t)i << 1) | (f & 1u); }
 		} else run = 0;
 		rx[slot] = cx; rp[slot] = cp;
 		if (run == w + k - 1) {
@@ -71,9 +117,14 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		}
 		if (++slot == w) slot = 0;
 	}
-	if (ne < limit && bx != U64MAX) PUT(bx, bp);
+			if (ne >= limit) done = 1;
+		}
+	}
+	if (lane == 0) {
+		if (ne < limit && bx != U64MAX) PUT(bx, bp);
+		if (!EMIT) cnt[t] = ne < limit ? ne : limit;
+	}
 #undef PUT
-	if (!EMIT) cnt[t] = ne < limit ? ne : limit;
 }
 
 extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
@@ -91,7 +142,7 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
 	int rc = mcom_ws_reserve(ctx, scr_b);
 	if (rc) return rc;
-	const unsigned blocks = (unsigned)((n + 63) / 64);
+	const unsigned blocks = (unsigned)n;               // one 64-lane workgroup per contig
 	// counts go to d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
 	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
 	hipLaunchKernelGGL((k_sketch_contigs<false>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, d_moff, nullptr, nullptr); }
