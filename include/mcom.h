@@ -145,6 +145,30 @@ int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm12
                               const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
                               mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
 
+/* ---- contig consensus on the device ------------------------------------- */
+/* construct_ref (kthread_bucket.c:69-377) for all n_groups groups of mcom_sort_group's output at once.
+ * In : d_members / d_group_off as mcom_sort_group returns them (sketch records y in cmpcluster order).
+ * Out: d_members[q] = rid<<32 | off<<1 | dir with off = column of the member in the FIRST consensus (:101);
+ *      d_keep[q] = 1 when the member has <= e mismatches against it (:189), else it is a reject (:194);
+ *      per group: d_nkept, d_sv (first covered column, :305-317; final offsets are off - sv, :349),
+ *      d_reflen and the second consensus (:319-341) as ASCII at d_refs + g*ref_stride (ref_stride >= 2L). */
+int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t *d_members, const uint32_t *d_group_off,
+                         uint32_t n_groups, int L, int k_orig, int e, uint8_t *d_keep, uint32_t *d_nkept,
+                         uint16_t *d_sv, uint16_t *d_reflen, uint8_t *d_refs, int ref_stride);
+
+/* construct_ref2 (kthread_cb.c:105-218) for a batch of merged contigs ("jobs").  Members of job j are
+ * d_members[d_job_off[j] .. d_job_off[j+1]), already sorted by cmpcluster2 (offset, then direction); its
+ * consensus, of length max(offset)+L = d_ref_off[j+1]-d_ref_off[j], is written as ASCII at d_refs+d_ref_off[j].
+ * The work list is (d_tile_job[t], d_tile_idx[t]): tile d_tile_idx[t] (512 columns) of job d_tile_job[t].  */
+int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off,
+                         const uint64_t *d_ref_off, const uint32_t *d_tile_job, const uint32_t *d_tile_idx,
+                         uint32_t n_tiles, int L, uint8_t *d_refs);
+
+/* First m minimizers of every contig out of a full mcom_sketch_contigs result (what the reference's contig
+ * builders push into the index, kthread_bucket.c:463, kthread_cb.c:370, :423).  h_total may be NULL.      */
+int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, size_t n, uint32_t m,
+                          uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total);
+
 /* ---- a10..a15: Stage-2 realignment --------------------------------------------------------------- */
 /* setglobalarrays_realign (kthread_hash_realign.c:153-206): first/last base of every dictionary key.
  * Host only.  Returns numdict_s (>= 1) or a negative status; start/end need room for 16 entries.    */

@@ -1,0 +1,233 @@
+// minicom_amd/csrc/consensus.hip -- contig consensus on the device.
+//
+//   mcom_group_consensus : construct_ref (reference kthread_bucket.c:69-377) for every minimizer group of a
+//                          Stage-1 round: column counts of the members laid out by their minimizer position,
+//                          majority base per column, rejection of members with more than e mismatches, second
+//                          consensus from the kept members.
+//   mcom_merge_consensus : construct_ref2 (kthread_cb.c:105-218): majority base per column of a merged contig.
+//   mcom_minimizer_prefix: the first m minimizers of every contig (what the builders push into the index,
+//                          kthread_bucket.c:463, kthread_cb.c:370, :423) taken from the full sketch.
+//
+// Byte/integer work, LDS count tables, HBM-bound on the gathered packed rows (2 x 8W bytes per member).
+#include "mcom_dev.hpp"
+
+// base i (0..L-1) of a read as it lies on the contig: reverse complement when dir = 1 (preprocess.c:22-37)
+__device__ __forceinline__ uint32_t obase(const uint64_t *row, int L, uint32_t dir, int i)
+{
+	const int j = dir ? L - 1 - i : i;
+	const uint32_t b = (uint32_t)(row[j >> 5] >> (2 * (j & 31))) & 3u;
+	return dir ? 3u - b : b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one 64-lane workgroup per group.  Columns: member q starts at off_q = pos0 - pos_q with pos the aligned
+// minimizer position (cmpcluster's, kthread_bucket.c:51-56); 0 <= off_q <= L - k, so 2L columns suffice.
+// ------------------------------------------------------------------------------------------------
+#define GC_MAXCOL 512
+
+__global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restrict__ packed, int W, uint64_t *__restrict__ members,
+                                                        const uint32_t *__restrict__ goff, uint32_t ng, int L, int k_orig, int e,
+                                                        uint8_t *__restrict__ keep, uint32_t *__restrict__ nkept,
+                                                        uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
+                                                        uint8_t *__restrict__ refs, int ref_stride)
+{
+	__shared__ uint32_t c1[4 * GC_MAXCOL];     // counts of all members
+	__shared__ uint32_t c2[4 * GC_MAXCOL];     // counts of the kept members
+	__shared__ uint8_t rc[GC_MAXCOL];          // first consensus, 0xFF beyond its end
+	const uint32_t g = blockIdx.x;
+	if (g >= ng) return;
+	const int lane = threadIdx.x;
+	const int TL = 2 * L;
+	const uint32_t m0 = goff[g], m1 = goff[g + 1];
+	for (int c = lane; c < 4 * TL; c += 64) { c1[c] = 0; c2[c] = 0; }
+	__syncthreads();
+	// pass 1: offsets, first counts
+	int pos0 = 0;
+	for (uint32_t q = m0; q < m1; ++q) {
+		const uint64_t y = members[q];
+		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
+		int pos = (int)((uint32_t)y >> 1);
+		if (dir) pos = L - pos + k_orig - 2;
+		if (q == m0) pos0 = pos;
+		const int off = pos0 - pos;
+		const uint64_t *row = packed + (size_t)rid * W;
+		for (int s = lane; s < L; s += 64) atomicAdd(&c1[obase(row, L, dir, s) * TL + off + s], 1u);
+	}
+	__syncthreads();
+	// first consensus: majority base per column, ties to the smaller code (strict '>'), ends at the first empty column
+	for (int c = lane; c < TL; c += 64) {
+		uint32_t mx = c1[c]; uint8_t b = 0;
+		for (int q = 1; q < 4; ++q) { const uint32_t v = c1[q * TL + c]; if (v > mx) { mx = v; b = (uint8_t)q; } }
+		rc[c] = mx ? b : (uint8_t)0xFF;
+	}
+	__syncthreads();
+	int ref_len = TL;
+	for (int c0 = 0; c0 < TL; c0 += 64) {
+		const int c = c0 + lane;
+		const uint64_t z = __ballot(c < TL && rc[c] == 0xFF);
+		if (z) { ref_len = c0 + __ffsll((unsigned long long)z) - 1; break; }
+	}
+	// pass 2: mismatches against the first consensus, kept members counted again
+	uint32_t nk = 0; int rend = 0;
+	for (uint32_t q = m0; q < m1; ++q) {
+		const uint64_t y = members[q];                                     // still the sketch record: rewritten below
+		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
+		int pos = (int)((uint32_t)y >> 1);
+		if (dir) pos = L - pos + k_orig - 2;
+		const int off = pos0 - pos;
+		const uint64_t *row = packed + (size_t)rid * W;
+		int dif = 0;
+		for (int s0 = 0; s0 < L; s0 += 64) {
+			const int s = s0 + lane;
+			const bool mis = s < L && ((off + s >= ref_len) || rc[off + s] != (uint8_t)obase(row, L, dir, s));
+			dif += __popcll(__ballot(mis));
+		}
+		const bool kp = dif <= e;                                          // kthread_bucket.c:189
+		if (kp) {
+			for (int s = lane; s < L; s += 64) atomicAdd(&c2[obase(row, L, dir, s) * TL + off + s], 1u);
+			++nk;
+			if (off + L > rend) rend = off + L;
+		}
+		if (lane == 0) { keep[q] = kp ? 1 : 0; members[q] = (y >> 32 << 32) | ((uint64_t)off << 1) | dir; }   // :101
+	}
+	__syncthreads();
+	// second consensus over [sv, rend): sv = first column (inside the first consensus) any kept member covers
+	int sv = 0;
+	if (nk) {
+		sv = ref_len;
+		for (int c0 = 0; c0 < ref_len; c0 += 64) {
+			const int c = c0 + lane;
+			const bool any = c < ref_len && (c2[c] | c2[TL + c] | c2[2 * TL + c] | c2[3 * TL + c]) != 0;
+			const uint64_t z = __ballot(any);
+			if (z) { sv = c0 + __ffsll((unsigned long long)z) - 1; break; }
+		}
+		uint8_t *out = refs + (size_t)g * ref_stride;
+		for (int c = sv + lane; c < rend; c += 64) {
+			uint32_t mx = c2[c]; int b = 0;
+			for (int q = 1; q < 4; ++q) { const uint32_t v = c2[q * TL + c]; if (v > mx) { mx = v; b = q; } }
+			out[c - sv] = (uint8_t)"ACGT"[b];
+		}
+	}
+	if (lane == 0) { nkept[g] = nk; svout[g] = (uint16_t)sv; reflen[g] = (uint16_t)(nk ? rend - sv : 0); }
+}
+
+extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t *d_members, const uint32_t *d_group_off,
+                                    uint32_t n_groups, int L, int k_orig, int e, uint8_t *d_keep, uint32_t *d_nkept,
+                                    uint16_t *d_sv, uint16_t *d_reflen, uint8_t *d_refs, int ref_stride)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_groups == 0) return MCOM_OK;
+	if (L < 1 || L > 256 || k_orig < 1 || k_orig > 31 || ref_stride < 2 * L) return mcom_fail(ctx, MCOM_E_ARG, "bad consensus arguments");
+	if (!d_packed || !d_members || !d_group_off || !d_keep || !d_nkept || !d_sv || !d_reflen || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	McomProfScope ps_(ctx, PROF_CONSENSUS);
+	hipLaunchKernelGGL(k_group_consensus, dim3(n_groups), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off,
+	                   n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// construct_ref2: members of job j are members[joff[j] .. joff[j+1]), sorted by offset (cmpcluster2); the
+// consensus of job j goes to refs[roff[j] .. roff[j+1]).  One 64-lane workgroup per (job, tile of MC_TILE columns).
+// ------------------------------------------------------------------------------------------------
+#define MC_TILE 512
+
+__global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restrict__ packed, int W, const uint64_t *__restrict__ members,
+                                                        const uint64_t *__restrict__ joff, const uint64_t *__restrict__ roff,
+                                                        const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
+                                                        uint32_t n_tiles, int L, uint8_t *__restrict__ refs)
+{
+	__shared__ uint32_t cc[4 * MC_TILE];
+	const uint32_t t = blockIdx.x;
+	if (t >= n_tiles) return;
+	const int lane = threadIdx.x;
+	const uint32_t j = tile_job[t];
+	const uint64_t m0 = joff[j], m1 = joff[j + 1];
+	const long len = (long)(roff[j + 1] - roff[j]);
+	const long lo = (long)tile_idx[t] * MC_TILE, hi = lo + MC_TILE < len ? lo + MC_TILE : len;
+	for (int c = lane; c < 4 * MC_TILE; c += 64) cc[c] = 0;
+	__syncthreads();
+	// first member whose read can reach column lo: offset > lo - L (members are sorted by offset)
+	uint64_t a = m0, b = m1;
+	while (a < b) { const uint64_t mid = (a + b) >> 1; if ((long)((uint32_t)members[mid] >> 1) + L <= lo) a = mid + 1; else b = mid; }
+	for (uint64_t q = a; q < m1; ++q) {
+		const uint64_t y = members[q];
+		const long off = (long)((uint32_t)y >> 1);
+		if (off >= hi) break;
+		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
+		const uint64_t *row = packed + (size_t)rid * W;
+		for (int s = lane; s < L; s += 64) {
+			const long c = off + s;
+			if (c >= lo && c < hi) atomicAdd(&cc[obase(row, L, dir, s) * MC_TILE + (int)(c - lo)], 1u);
+		}
+	}
+	__syncthreads();
+	uint8_t *out = refs + roff[j];
+	for (long c = lo + lane; c < hi; c += 64) {
+		const int i = (int)(c - lo);
+		uint32_t mx = cc[i]; int bb = 0;
+		for (int q = 1; q < 4; ++q) { const uint32_t v = cc[q * MC_TILE + i]; if (v > mx) { mx = v; bb = q; } }
+		out[c] = (uint8_t)"ACGT"[bb];
+	}
+}
+
+extern "C" int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off,
+                                    const uint64_t *d_ref_off, const uint32_t *d_tile_job, const uint32_t *d_tile_idx,
+                                    uint32_t n_tiles, int L, uint8_t *d_refs)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_tiles == 0) return MCOM_OK;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad read length");
+	if (!d_packed || !d_members || !d_job_off || !d_ref_off || !d_tile_job || !d_tile_idx || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	McomProfScope ps_(ctx, PROF_CONSENSUS);
+	hipLaunchKernelGGL(k_merge_consensus, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// first m minimizers of every contig out of the full sketch: out_moff[c] = c' start, fixed stride not needed
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prefix_counts(const uint32_t *__restrict__ moff, size_t n, uint32_t m, uint32_t *__restrict__ cnt)
+{
+	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < n) { const uint32_t k = moff[c + 1] - moff[c]; cnt[c] = k < m ? k : m; }
+	if (c == n) cnt[c] = 0;
+}
+__global__ void k_prefix_copy(const uint32_t *__restrict__ moff, const mcom_mm128 *__restrict__ rec, size_t n, uint32_t m,
+                              const uint32_t *__restrict__ ooff, mcom_mm128 *__restrict__ out)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t c = t / m; const uint32_t q = (uint32_t)(t - c * m);
+	if (c >= n) return;
+	if (q < ooff[c + 1] - ooff[c]) out[ooff[c] + q] = rec[moff[c] + q];
+}
+
+extern "C" int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, size_t n, uint32_t m,
+                                     uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (h_total) *h_total = 0;
+	if (m == 0) return mcom_fail(ctx, MCOM_E_ARG, "m must be positive");
+	if (!d_out_moff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_out_moff, 0, 4, ctx->stream)); return MCOM_OK; }
+	if (!d_moff || !d_rec || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, scr_b);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_prefix_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n, m, d_out_moff);
+	MCOM_LAUNCH_CHECK(ctx);
+	rc = mcom_scan_u32(ctx, d_out_moff, d_out_moff, n + 1, (uint32_t*)ctx->ws);
+	if (rc) return rc;
+	const size_t tot = n * (size_t)m;
+	hipLaunchKernelGGL(k_prefix_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_rec, n, m, d_out_moff, d_out);
+	MCOM_LAUNCH_CHECK(ctx);
+	if (h_total) {
+		uint32_t total = 0;
+		MCOM_HIP(ctx, hipMemcpyAsync(&total, d_out_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		*h_total = total;
+	}
+	return MCOM_OK;
+}

@@ -20,18 +20,26 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 
 // ------------------------------------------------------------------------------------------------
 // mm_sketch_lh_ori.  EMIT = false counts, EMIT = true writes; at most `limit` minimizers per contig.
-// The ring keeps (hash, pos<<1|strand) per slot; y = id<<32 | that.
-// ------------------------------------------------------------------------------------------------
 //
-// One wave (one 64-thread workgroup) per contig, the contig taken in pieces of PIECE bases:
-//   phase 1, all 64 lanes: every lane rolls the forward / reverse k-mers of its PIECE/64 consecutive bases
-//            (warmed up over the k-1 valid bases before them) and leaves the hash, the strand, the
-//            "own reverse complement" flag and the ambiguous-base flag of every position in LDS;
-//   phase 2, lane 0: the reference's window scan, statement for statement, reading those values from LDS,
-//            with its ring of the last w entries also in LDS.
-// The hashing (the expensive part) is spread over the wave; the sequential part is a few LDS reads a base.
-#define PIECE 512
+// One wave (one 64-thread workgroup) per contig, the contig taken in pieces of PIECE bases.  The reference
+// scan keeps, besides the run counter, a ring of the last w entries and "the minimum": by construction that
+// minimum is always the NEWEST smallest entry of the ring (sketch.c:145-153), i.e. a pure function of the last
+// w entries.  So the scan can be restarted anywhere from those entries, and every lane does so for its own
+// few entries:
+//   phase 1   all lanes: roll the forward / reverse k-mers of PIECE/64 consecutive bases each (warmed up over
+//             the k-1 valid bases before them), hash, leave hash + flags per POSITION in LDS;
+//   phase 1b  ballots over the flags give, per position, the run counter (valid, non-palindromic bases since
+//             the last ambiguous base) and the ENTRY index (palindromic k-mers store no entry, sketch.c:133);
+//             every position writes its entry (hash or "empty", pos<<1|strand, run) into an LDS ring by entry index;
+//   phase 2   lane l takes entries [l*Q, (l+1)*Q) of the piece: rebuilds the minimum from the w entries before
+//             its first one, then runs the reference's statements for each of its entries -- once to count what
+//             it would emit, and after a wave prefix sum once more to write at the right offsets.
+// ------------------------------------------------------------------------------------------------
+#define PIECE 384
 #define PER_LANE (PIECE / 64)
+#define ERING 512                          // >= PIECE + MAXW, power of two
+
+struct WinState { uint64_t bx; uint32_t bp; long bidx; };
 
 template <bool EMIT>
 __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
@@ -39,11 +47,12 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
                                                        uint32_t *__restrict__ cnt, const uint32_t *__restrict__ out_off,
                                                        mcom_mm128 *__restrict__ out)
 {
-	__shared__ uint64_t PX[PIECE];          // hash of the canonical k-mer ending at each position of the piece
+	__shared__ uint64_t PX[PIECE];          // per position of the piece: hash of the canonical k-mer ending there
 	__shared__ uint8_t PF[PIECE];           // bit0 strand, bit1 k-mer equals its reverse complement, bit2 ambiguous base
-	__shared__ uint64_t rx[MAXW];           // ring of the last w entries: hash ...
-	__shared__ uint32_t rp[MAXW];           // ... and pos<<1|strand (0xFFFFFFFF for an empty entry)
-	__shared__ uint32_t done;
+	__shared__ uint64_t EX[ERING];          // per entry (index mod ERING): hash or U64MAX when empty
+	__shared__ uint32_t EP[ERING];          // pos<<1|strand, 0xFFFFFFFF when empty
+	__shared__ uint16_t ER[ERING];          // run counter after the entry (saturating)
+	__shared__ uint8_t SB[PIECE + 64];      // the piece's characters and the 64 before it, staged with coalesced loads
 	const size_t t = blockIdx.x;
 	if (t >= n) return;
 	const int lane = threadIdx.x;
@@ -51,32 +60,66 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	const int len = (int)(off[t + 1] - off[t]);
 	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
 	const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ull << (2 * k)) - 1;
-	for (int j = lane; j < w; j += 64) { rx[j] = U64MAX; rp[j] = 0xFFFFFFFFu; }
-	if (lane == 0) done = 0;
-	uint64_t bx = U64MAX; uint32_t bp = 0xFFFFFFFFu;
-	int run = 0, slot = 0, bslot = 0;
-	uint32_t ne = 0;
 	mcom_mm128 *o = EMIT ? out + out_off[t] : nullptr;
-#define PUT(X, P) do { if (ne < limit) { if (EMIT) { mcom_mm128 v_; v_.x = (X); v_.y = (X) == U64MAX && (P) == 0xFFFFFFFFu ? U64MAX : (idhi | (P)); o[ne] = v_; } } ++ne; } while (0)
-	for (int ps = 0; ps < len; ps += PIECE) {
+	long ent_in = 0;                        // entries stored before the current piece   (wave uniform)
+	uint32_t run_in = 0;                    // run counter before the current piece       (wave uniform)
+	uint32_t ne_base = 0;                   // minimizers emitted before the current piece (wave uniform)
+
+	// entry e (may be negative = the ring's initial fill) as the scan sees it
+	auto EXat = [&](long e) -> uint64_t { return e < 0 ? U64MAX : EX[e & (ERING - 1)]; };
+	auto EPat = [&](long e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & (ERING - 1)]; };
+	// the minimum as the reference holds it just before entry t0 is stored (sketch.c:150-153 applied to the ring)
+	auto rebuild = [&](long t0) -> WinState {
+		WinState st; st.bx = U64MAX; st.bp = 0xFFFFFFFFu; st.bidx = -(long)w;
+		if (t0 == 0) return st;
+		for (long e = t0 - w; e < t0; ++e) { const uint64_t x = EXat(e); if (st.bx >= x) { st.bx = x; st.bp = EPat(e); st.bidx = e; } }
+		return st;
+	};
+	// one step of the scan (sketch.c:138-161) for entry te; emits through put(x, p)
+	auto step = [&](WinState &st, long te, auto &&put) {
+		const uint64_t cx = EX[te & (ERING - 1)]; const uint32_t cp = EP[te & (ERING - 1)];
+		const int run = ER[te & (ERING - 1)];
+		if (run == w + k - 1) {
+			for (long e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (st.bx == x && pp != st.bp) put(x, pp); }
+		}
+		if (cx <= st.bx) {
+			if (run >= w + k) put(st.bx, st.bp);
+			st.bx = cx; st.bp = cp; st.bidx = te;
+		} else if (st.bidx == te - w) {
+			if (run >= w + k - 1) put(st.bx, st.bp);
+			st.bx = U64MAX;
+			for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); if (st.bx >= x) { st.bx = x; st.bp = EPat(e); st.bidx = e; } }
+			if (run >= w + k - 1) {
+				for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (st.bx == x && st.bp != pp) put(x, pp); }
+			}
+		}
+	};
+	auto emit_at = [&](uint32_t idx, uint64_t x, uint32_t pp) {
+		if (EMIT && idx < limit) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); o[idx] = v; }
+	};
+
+	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE) {
 		const int pe = ps + PIECE < len ? ps + PIECE : len;
-		__syncthreads();                                   // phase 2 of the previous piece has finished with PX / PF
-		if (done) break;
+		__syncthreads();                                   // everybody is done with PX / PF / SB of the previous piece
+		const int sb0 = ps - 64;                           // contig position of SB[0]
+		for (int j = lane; j < 64 + (pe - ps); j += 64) SB[j] = sb0 + j >= 0 ? s[sb0 + j] : (uint8_t)0;
+		__syncthreads();
+		auto ch = [&](int i) -> uint8_t { return i >= sb0 ? SB[i - sb0] : s[i]; };   // global only for N-rich warm-ups
 		{   // ---- phase 1
 			const int a = ps + lane * PER_LANE;
 			if (a < pe) {
 				// k-mer registers as the reference has them before position a: the last k-1 VALID bases (ambiguous
 				// bases do not enter the registers, sketch.c:129-132), or everything from the contig start
 				int st = a, need = k - 1;
-				while (st > 0 && need > 0) { --st; if (nt4_of(s[st]) < 4) --need; }
+				while (st > 0 && need > 0) { --st; if (nt4_of(ch(st)) < 4) --need; }
 				uint64_t fwd = 0, rev = 0;
 				for (int i = st; i < a; ++i) {
-					const int c = nt4_of(s[i]);
+					const int c = nt4_of(ch(i));
 					if (c < 4) { fwd = ((fwd << 2) | (uint64_t)c) & mask; rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1); }
 				}
 				const int b = a + PER_LANE < pe ? a + PER_LANE : pe;
 				for (int i = a; i < b; ++i) {
-					const int c = nt4_of(s[i]);
+					const int c = nt4_of(SB[i - sb0]);
 					uint8_t f = 0; uint64_t x = U64MAX;
 					if (c < 4) {
 						fwd = ((fwd << 2) | (uint64_t)c) & mask;
@@ -89,42 +132,66 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			}
 		}
 		__syncthreads();
-		if (lane == 0) {   // ---- phase 2: sketch.c:126-162
-	for (int i = ps; i < pe && ne < limit; ++i) {
-		const uint8_t f = PF[i - ps];
-		uint64_t cx = U64MAX; uint32_t cp = 0xFFFFFFFFu;
-		if (!(f & 4)) {
-			if (f & 2) continue;
-			if (++run >= k) { cx = PX[i - ps]; cp = ((uint32_t)i << 1) | (f & 1u); }
-		} else run = 0;
-		rx[slot] = cx; rp[slot] = cp;
-		if (run == w + k - 1) {
-			for (int j = slot + 1; j < w; ++j) if (bx == rx[j] && rp[j] != bp) PUT(rx[j], rp[j]);
-			for (int j = 0; j < slot; ++j)     if (bx == rx[j] && rp[j] != bp) PUT(rx[j], rp[j]);
-		}
-		if (cx <= bx) {
-			if (run >= w + k) PUT(bx, bp);
-			bx = cx; bp = cp; bslot = slot;
-		} else if (slot == bslot) {
-			if (run >= w + k - 1) PUT(bx, bp);
-			bx = U64MAX;
-			for (int j = slot + 1; j < w; ++j) if (bx >= rx[j]) { bx = rx[j]; bp = rp[j]; bslot = j; }
-			for (int j = 0; j <= slot; ++j)    if (bx >= rx[j]) { bx = rx[j]; bp = rp[j]; bslot = j; }
-			if (run >= w + k - 1) {
-				for (int j = slot + 1; j < w; ++j) if (bx == rx[j] && bp != rp[j]) PUT(rx[j], rp[j]);
-				for (int j = 0; j <= slot; ++j)    if (bx == rx[j] && bp != rp[j]) PUT(rx[j], rp[j]);
+		// ---- phase 1b: run counter and entry index of every position from ballots, entries into the ring
+		long ent_run = ent_in; uint32_t run_run = run_in;
+#pragma unroll 1
+		for (int g = 0; g < PIECE / 64; ++g) {
+			const int p = ps + g * 64 + lane;
+			const uint8_t f = p < pe ? PF[p - ps] : (uint8_t)2;           // beyond the end: stores nothing, counts nothing
+			const bool isn = (f & 4) != 0, inc = (f & 6) == 0;
+			const uint64_t nM = __ballot(isn), incM = __ballot(inc), entM = nM | incM;
+			const uint64_t lowm = lane == 63 ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
+			const uint64_t nlow = nM & lowm;
+			uint32_t run;
+			if (nlow) { const int hb = 63 - __clzll((long long)nlow); const uint64_t above = hb == 63 ? 0ull : ~((2ull << hb) - 1); run = (uint32_t)__popcll(incM & lowm & above); }
+			else run = run_run + (uint32_t)__popcll(incM & lowm);
+			if (isn || inc) {
+				const long te = ent_run + (long)__popcll(entM & (lowm >> 1));
+				const bool real = inc && run >= (uint32_t)k;
+				EX[te & (ERING - 1)] = real ? PX[p - ps] : U64MAX;
+				EP[te & (ERING - 1)] = real ? (((uint32_t)p << 1) | (f & 1u)) : 0xFFFFFFFFu;
+				ER[te & (ERING - 1)] = (uint16_t)(run > 0xFFFFu ? 0xFFFFu : run);
 			}
+			// carry to the next group (uniform)
+			if (nM) { const int hb = 63 - __clzll((long long)nM); run_run = (uint32_t)__popcll(hb == 63 ? 0ull : (incM >> (hb + 1))); }
+			else run_run += (uint32_t)__popcll(incM);
+			ent_run += (long)__popcll(entM);
 		}
-		if (++slot == w) slot = 0;
-	}
-			if (ne >= limit) done = 1;
+		__syncthreads();
+		// ---- phase 2
+		const long E = ent_run - ent_in;
+		const long Q = (E + 63) / 64;
+		long t0 = ent_in + (long)lane * Q, t1 = t0 + Q;
+		if (t1 > ent_run) t1 = ent_run;
+		uint32_t mine = 0;
+		WinState st0; st0.bx = U64MAX; st0.bp = 0xFFFFFFFFu; st0.bidx = -(long)w;
+		if (t0 < t1) {
+			st0 = rebuild(t0);
+			WinState st = st0;
+			for (long te = t0; te < t1; ++te) step(st, te, [&](uint64_t, uint32_t) { ++mine; });
 		}
+		// wave exclusive prefix of the counts
+		uint32_t incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+		const uint32_t total = __shfl(incl, 63, 64);
+		if (EMIT && t0 < t1 && mine) {
+			uint32_t idx = ne_base + incl - mine;
+			WinState st = st0;
+			for (long te = t0; te < t1; ++te) step(st, te, [&](uint64_t x, uint32_t pp) { emit_at(idx, x, pp); ++idx; });
+		}
+		ne_base += total;
+		ent_in = ent_run; run_in = run_run;
 	}
+	__syncthreads();
 	if (lane == 0) {
-		if (ne < limit && bx != U64MAX) PUT(bx, bp);
-		if (!EMIT) cnt[t] = ne < limit ? ne : limit;
+		// the minimum still held after the last entry is written out (sketch.c:163-164)
+		if (ne_base < limit) {
+			const WinState st = rebuild(ent_in);
+			if (st.bx != U64MAX) { emit_at(ne_base, st.bx, st.bp); ++ne_base; }
+		}
+		if (!EMIT) cnt[t] = ne_base < limit ? ne_base : limit;
 	}
-#undef PUT
 }
 
 extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,

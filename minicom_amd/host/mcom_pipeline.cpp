@@ -62,6 +62,7 @@ struct mcomh_pipeline {
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
 	std::vector<Contig> C[2]; int idxv = 0;
+	std::vector<uint8_t> unsorted;           // Stage 2: contigs whose member list changed since it was last sorted
 	std::vector<mcom_mm128> mi0;             // first-m minimizers of the Stage-1 contigs, contig order
 	bool stage2_uploaded = false;
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
@@ -329,6 +330,8 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			(void)hipMemcpyAsync(h_goff.data(), d_goff.p, (ng + 1) * 4, hipMemcpyDeviceToHost, p->stream);
 			if ((rc = p->hipc(hipStreamSynchronize(p->stream), "round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
+			p->stat["t_bk_gpu"] += now_ms() - tg;
+			const double tb1 = now_ms();
 			// consensus of every group; groups are independent, only the appends below are ordered
 			std::vector<GroupOut> outs(ng);
 			const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, ng / 64)));
@@ -339,6 +342,8 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			};
 			if (nt == 1) work(0);
 			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
+			const double tb2 = now_ms();
+			p->stat["t_bk_cons"] += tb2 - tb1;
 			// replay in the reference's visiting order (process_bucket, :398-505)
 			size_t si = 0;
 			auto reject = [&](uint32_t rid) { if (last) p->sg.push_back(rid); else resk.push_back(rid); };
@@ -350,6 +355,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				if (o.c.a.size() > 1) C0.emplace_back(std::move(o.c));                        // :451-475
 				else if (o.c.a.size() == 1) reject((uint32_t)(o.c.a[0] >> 32));              // :477-498
 			}
+			p->stat["t_bk_replay"] += now_ms() - tb2;
 		}
 		p->stat["rounds"] += 1;
 		if (last_rounds) ++last_rounds;                                             // :594
@@ -446,14 +452,20 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		uint64_t n_pass = 0;
 		if (n) {
 			const double tg = now_ms();
+			double tl = tg;
+			auto lap = [&](const char *nm) { (void)hipStreamSynchronize(p->stream); const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
 			int rc = upload_contigs(p, src, dc, true);
 			if (rc) return rc;
+			lap("t_cb_upload");
 			uint64_t tm = 0, ta = 0;
-			if ((rc = sketch_contigs(p, dc, (uint32_t)p->m, moff_m, rec_m, tm))) return rc;       // what the builders pushed to mi[index] (:370-380, :423-432)
+			if ((rc = sketch_contigs(p, dc, (uint32_t)p->m, moff_m, rec_m, tm))) return rc;
+			lap("t_cb_sketch");       // what the builders pushed to mi[index] (:370-380, :423-432)
 			if (index == 0 && p->mi0.empty() && tm) { p->mi0.resize(tm); (void)hipMemcpy(p->mi0.data(), rec_m.p, tm * sizeof(mcom_mm128), hipMemcpyDeviceToHost); }
 			mcom_idx *mi = nullptr;
 			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, &mi)))) return rc;          // mm_idx_generation (:580)
+			lap("t_cb_idx");
 			if ((rc = sketch_contigs(p, dc, 0, moff_all, rec_all, ta))) { mcom_idx_destroy(p->ctx, mi); return rc; }   // find_next's own sketch (:234)
+			lap("t_cb_sketch");
 			uint64_t hc[2] = {0, 0};
 			size_t cap = std::max<size_t>(1024, ta);
 			for (int attempt = 0; attempt < 2; ++attempt) {
@@ -464,9 +476,11 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			}
 			mcom_idx_destroy(p->ctx, mi);
 			if (rc) return p->gpu(rc);
+			lap("t_cb_findnext");
 			n_pass = hc[1];
 			pairs.resize(n_pass);
 			if (n_pass && (rc = p->hipc(hipMemcpy(pairs.data(), d_pairs.p, n_pass * sizeof(mcom_mm128), hipMemcpyDeviceToHost), "copy candidates"))) return rc;
+			lap("t_cb_d2h");
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
@@ -516,9 +530,13 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if (nt == 1) work(0);
 			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
 		}
-		p->stat["t_merge_cons"] += now_ms() - tc1;
+		const double tc2 = now_ms();
+		p->stat["t_merge_cons"] += tc2 - tc1;
 		for (size_t i = 0; i < n; ++i) if (!flag[i]) dst.emplace_back(std::move(src[i]));   // cp_cluster (:397-434)
+		const double tc3 = now_ms();
+		p->stat["t_cb_copy"] += tc3 - tc2;
 		src.clear();
+		p->stat["t_cb_free"] += now_ms() - tc3;
 		p->stat["merge_rounds"] += 1;
 		index ^= 1;
 		const long tot = (long)p->C[index].size();
@@ -526,6 +544,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		pre = tot;
 	}
 	p->idxv = index;
+	p->unsorted.assign(p->C[index].size(), 1);
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -572,7 +591,18 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	p->stat["passes"] += 1;
 	p->stat["windows"] += (double)p->n_windows;
 	// every contig is re-sorted at the start of its scan (:318)
-	for (Contig &c : cs) std::stable_sort(c.a.begin(), c.a.end(), less_cluster2);
+	const double tr0 = now_ms();
+	{   // a stable sort of an already sorted list is the identity: only contigs that changed are sorted again
+		if (p->unsorted.size() != cs.size()) p->unsorted.assign(cs.size(), 1);
+		const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, cs.size() / 4096)));
+		auto work = [&](int tid) {
+			for (size_t c = (size_t)tid; c < cs.size(); c += (size_t)nt)
+				if (p->unsorted[c]) { std::stable_sort(cs[c].a.begin(), cs[c].a.end(), less_cluster2); p->unsorted[c] = 0; }
+		};
+		if (nt == 1) work(0);
+		else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
+	}
+	p->stat["t_ra_sort"] += now_ms() - tr0;
 	if (n_sg) {
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
@@ -601,6 +631,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		mcom_dicts_free(p->ctx, dicts);
 		if (rc) return rc;
 		p->stat["t_gpu"] += now_ms() - tg;
+		p->stat["t_ra_gpu"] += now_ms() - tg;
 		// append in the order of the sequential scan: claim key ascending, singleton index descending (:388)
 		std::vector<std::pair<uint64_t, uint32_t>> won;
 		for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) won.emplace_back(claim[i], (uint32_t)i);
@@ -610,6 +641,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			const uint64_t ck = w.first;
 			const size_t c = (size_t)(ck >> 33); const uint64_t jj = (ck >> 5) & ((1ull << 28) - 1), dir = (ck >> 4) & 1;
 			cs[c].a.push_back((uint64_t)p->sg[w.second] << 32 | (jj << 1) | dir);              // :408-409, :474-475
+			p->unsorted[c] = 1;
 			p->sg_flag[w.second] = 1;
 		}
 	}
