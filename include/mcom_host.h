@@ -56,7 +56,7 @@ int mcomh_dump_stages(mcomh_pipeline *p, const char *path);
 
 /* results */
 size_t mcomh_n_contigs(const mcomh_pipeline *p);
-const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i);
+const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len);   /* consensus, NOT NUL-terminated */
 size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i);
 const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i);   /* rid<<32 | offset<<1 | dir */
 const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n); /* allA allT allN fpA fpT fpN Nfile sg */

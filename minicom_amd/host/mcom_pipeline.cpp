@@ -1,9 +1,11 @@
 // minicom_amd/host/mcom_pipeline.cpp -- host driver of the MI355X-native minicom hot path.
 //
 // Restates the control flow of the reference's pre_process (preprocess.c:39-241) and of its stage drivers,
-// with every hot loop replaced by a call into libmcom_hip.so (include/mcom.h).  What stays on the host is
-// what the reference keeps sequential by design: contig consensus, first-come pair claiming and the
-// resolution of Stage-2 claims.  Citations are file:line into yuansliu/minicom src/.
+// with every hot loop replaced by a call into libmcom_hip.so (include/mcom.h), including the contig consensus
+// (mcom_group_consensus / mcom_merge_consensus).  What stays on the host is what the reference keeps
+// sequential by design: the order in which singletons and contigs are appended, first-come pair claiming, and
+// the order in which Stage-2 claims are appended.  Contigs live in flat arrays (members and consensus strings
+// back to back + offsets), so no stage allocates per contig.  Citations are file:line into yuansliu/minicom src/.
 #include "../../include/mcom.h"
 #include "../../include/mcom_host.h"
 #include <hip/hip_runtime_api.h>
@@ -24,9 +26,15 @@ namespace {
 constexpr int NB_BITS = 14;                 // MM_IDX_DEF_B, minicommain.c:175
 constexpr uint64_t U64MAX = ~0ull;
 
-struct Contig {
-	std::vector<uint64_t> a;                // rid<<32 | offset<<1 | dir   (breads.h:49-58)
-	std::string ref;
+// all contigs of one stage: members (rid<<32 | offset<<1 | dir, breads.h:49-58) and consensus strings, flat
+struct ContigSet {
+	std::vector<uint64_t> mem, moff{0};
+	std::vector<char> ref;
+	std::vector<uint64_t> roff{0};
+	size_t n() const { return moff.size() - 1; }
+	void clear() { mem.clear(); ref.clear(); moff.assign(1, 0); roff.assign(1, 0); }
+	size_t msize(size_t i) const { return (size_t)(moff[i + 1] - moff[i]); }
+	size_t rsize(size_t i) const { return (size_t)(roff[i + 1] - roff[i]); }
 };
 
 template <class T> struct DevBuf {
@@ -43,6 +51,29 @@ template <class T> struct DevBuf {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// static split of [0, n) over nt threads
+template <class F> void parallel_for(int nt, size_t n, F &&fn)
+{
+	if (nt > 1 && n < 4096) nt = 1;
+	if (nt <= 1) { fn(0, (size_t)0, n); return; }
+	std::vector<std::thread> th;
+	const size_t chunk = (n + (size_t)nt - 1) / (size_t)nt;
+	for (int t = 0; t < nt; ++t) {
+		const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
+		if (b >= e) break;
+		th.emplace_back([&fn, t, b, e]() { fn(t, b, e); });
+	}
+	for (auto &t : th) t.join();
+}
+
+// cmpcluster2: offset ascending, then direction (kthread_cb.c:54-69); the reference's qsort is glibc's merge sort
+bool less_cluster2(uint64_t a, uint64_t b)
+{
+	const int pa = (int)((uint32_t)a >> 1), pb = (int)((uint32_t)b >> 1);
+	if (pa != pb) return pa < pb;
+	return (int)(a & 1) < (int)(b & 1);
+}
+
 } // namespace
 
 struct mcomh_pipeline {
@@ -58,15 +89,16 @@ struct mcomh_pipeline {
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
-	std::vector<uint64_t> h_packed; std::vector<uint8_t> h_cls;
+	std::vector<uint8_t> h_cls;
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
-	std::vector<Contig> C[2]; int idxv = 0;
+	ContigSet C;
 	std::vector<uint8_t> unsorted;           // Stage 2: contigs whose member list changed since it was last sorted
-	std::vector<mcom_mm128> mi0;             // first-m minimizers of the Stage-1 contigs, contig order
-	bool stage2_uploaded = false;
+	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
-	uint64_t n_windows = 0;
+	std::vector<uint64_t> h_coff_words;
+	uint64_t total_words = 0, n_windows = 0;
+	bool stage2_uploaded = false;
 	std::map<std::string, double> stat;
 
 	int fail(int code, const char *fmt, ...) {
@@ -75,10 +107,13 @@ struct mcomh_pipeline {
 	}
 	int gpu(int rc) { if (rc) err = std::string("libmcom_hip: ") + mcom_last_error(ctx); return rc; }
 	int hipc(hipError_t e_, const char *what) { if (e_ != hipSuccess) return fail(MCOM_E_HIP, "%s: %s", what, hipGetErrorString(e_)); return 0; }
-
-	inline int base(uint32_t rid, int i) const { return (int)((h_packed[(size_t)rid * W + (i >> 5)] >> (2 * (i & 31))) & 3); }
-	// base i of the read as laid on the contig: reverse complement when dir = 1 (reverse_complement, preprocess.c:22)
-	inline int obase(uint32_t rid, int dir, int i) const { return dir ? 3 - base(rid, L - 1 - i) : base(rid, i); }
+	template <class T> int d2h(T *dst, const T *src, size_t cnt, const char *what) {
+		return cnt ? hipc(hipMemcpyAsync(dst, src, cnt * sizeof(T), hipMemcpyDeviceToHost, stream), what) : 0;
+	}
+	template <class T> int h2d(T *dst, const T *src, size_t cnt, const char *what) {
+		return cnt ? hipc(hipMemcpyAsync(dst, src, cnt * sizeof(T), hipMemcpyHostToDevice, stream), what) : 0;
+	}
+	int sync(const char *what) { return hipc(hipStreamSynchronize(stream), what); }
 };
 
 using P = mcomh_pipeline;
@@ -112,7 +147,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	if (pp->w > 0) p->rw = pp->w;
 	p->numdict = pp->numdict;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
-	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { delete p; return MCOM_E_ARG; }
+	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
 	if (host_reads) {
 		p->pitch = (size_t)L;
 		p->h_ascii.assign(host_reads, host_reads + n * (size_t)L);
@@ -170,14 +205,11 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
 	}
 	if (rc) return rc;
-	p->h_cls.resize(n); p->h_packed.resize(n * (size_t)p->W);
-	if (n) {
-		if ((rc = p->hipc(hipMemcpyAsync(p->h_cls.data(), p->d_cls.p, n, hipMemcpyDeviceToHost, p->stream), "copy classes"))) return rc;
-		if ((rc = p->hipc(hipMemcpyAsync(p->h_packed.data(), p->d_packed.p, n * (size_t)p->W * 8, hipMemcpyDeviceToHost, p->stream), "copy packed reads"))) return rc;
-	}
-	if ((rc = p->hipc(hipStreamSynchronize(p->stream), "kt_for_reads"))) return rc;
+	p->h_cls.resize(n);
+	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->sync("kt_for_reads"))) return rc;
 	for (size_t r = 0; r < n; ++r) {                                              // one thread: rid order
 		switch (p->h_cls[r]) {
+		case MCOM_CLS_SKETCH: break;
 		case MCOM_CLS_ALLA: p->allA.push_back((uint32_t)r); break;
 		case MCOM_CLS_ALLT: p->allT.push_back((uint32_t)r); break;
 		case MCOM_CLS_ALLN: p->allN.push_back((uint32_t)r); break;
@@ -193,120 +225,22 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// construct_ref: consensus of one minimizer group                           kthread_bucket.c:69-377
-//   members: y values in cmpcluster order.  Keeps the members within e mismatches of the first consensus,
-//   rebuilds the consensus from them, returns the rejected rids.
-// ----------------------------------------------------------------------------------------------------
-struct GroupOut { Contig c; std::vector<uint32_t> rejected; };
-
-static void construct_ref(const P *p, const uint64_t *y, size_t n, GroupOut &out, std::vector<uint32_t> &cnt)
-{
-	const int L = p->L;
-	const int tlen = L << 2;                        // "readlen<<1 + 1" parses as readlen << 2 (:72)
-	cnt.assign((size_t)4 * tlen, 0);
-	std::vector<uint64_t> &a = out.c.a;
-	a.assign(y, y + n);
-	int pos0 = L;
-	for (size_t q = 0; q < n; ++q) {
-		const uint64_t v = a[q];
-		const uint32_t rid = (uint32_t)(v >> 32); int pos = (int)((uint32_t)v >> 1); const int dir = (int)(v & 1);
-		if (dir) pos = L - pos + p->k - 2;                                          // :93 (the run's first k, always)
-		if (q == 0) pos0 = pos;
-		const int off = pos0 - pos;
-		for (int s = 0; s < L; ++s) ++cnt[(size_t)p->obase(rid, dir, s) * tlen + off + s];
-		a[q] = (v >> 32 << 32) | ((uint64_t)off << 1) | (uint64_t)dir;
-	}
-	std::string ref; ref.reserve(2 * L + 64);
-	for (int s = 0; s < tlen; ++s) {
-		uint32_t mx = cnt[s]; int b = 0;
-		for (int q = 1; q < 4; ++q) if (cnt[(size_t)q * tlen + s] > mx) { mx = cnt[(size_t)q * tlen + s]; b = q; }
-		if (mx == 0) break;
-		ref.push_back(ACGT[b]);
-	}
-	const int ref_len = (int)ref.size();
-	size_t kept = 0;
-	for (size_t q = 0; q < n; ++q) {
-		const uint64_t v = a[q];
-		const uint32_t rid = (uint32_t)(v >> 32); const int pos = (int)((uint32_t)v >> 1), dir = (int)(v & 1);
-		int dif = 0;
-		for (int s = 0; s < L; ++s) if (ref[pos + s] != ACGT[p->obase(rid, dir, s)]) ++dif;
-		if (dif <= p->e) a[kept++] = v; else out.rejected.push_back(rid);           // :189-213
-	}
-	a.resize(kept);
-	out.c.ref = ref;
-	if (kept > 0) {                                                                 // :244-352
-		std::fill(cnt.begin(), cnt.end(), 0u);
-		int rend = 0;
-		for (size_t q = 0; q < kept; ++q) {
-			const uint64_t v = a[q];
-			const uint32_t rid = (uint32_t)(v >> 32); const int pos = (int)((uint32_t)v >> 1), dir = (int)(v & 1);
-			for (int s = 0; s < L; ++s) ++cnt[(size_t)p->obase(rid, dir, s) * tlen + pos + s];
-			if (pos + L > rend) rend = pos + L;
-		}
-		int s = 0;
-		for (; s < ref_len; ++s) {
-			uint32_t mx = cnt[s];
-			for (int q = 1; q < 4; ++q) if (cnt[(size_t)q * tlen + s] > mx) mx = cnt[(size_t)q * tlen + s];
-			if (mx != 0) break;
-		}
-		const int sv = s;
-		std::string r2; r2.reserve((size_t)(rend - sv));
-		for (; s < rend; ++s) {
-			uint32_t mx = cnt[s]; int b = 0;
-			for (int q = 1; q < 4; ++q) if (cnt[(size_t)q * tlen + s] > mx) { mx = cnt[(size_t)q * tlen + s]; b = q; }
-			r2.push_back(ACGT[b]);
-		}
-		out.c.ref.swap(r2);
-		for (size_t q = 0; q < kept; ++q) {
-			const uint64_t v = a[q];
-			a[q] = (v >> 32 << 32) | ((uint64_t)((int)((uint32_t)v >> 1) - sv) << 1) | (v & 1);
-		}
-	}
-}
-
-// cmpcluster2: offset ascending, then direction (kthread_cb.c:54-69); the reference's qsort is glibc's merge sort
-static bool less_cluster2(uint64_t a, uint64_t b)
-{
-	const int pa = (int)((uint32_t)a >> 1), pb = (int)((uint32_t)b >> 1);
-	if (pa != pb) return pa < pb;
-	return (int)(a & 1) < (int)(b & 1);
-}
-
-// construct_ref2: consensus of a merged contig                                 kthread_cb.c:105-218
-static void construct_ref2(const P *p, Contig &c, std::vector<uint32_t> &cnt)
-{
-	const int L = p->L;
-	std::stable_sort(c.a.begin(), c.a.end(), less_cluster2);
-	const int tlen = (int)((uint32_t)c.a.back() >> 1) + (L << 1) + 1;
-	cnt.assign((size_t)4 * tlen, 0);
-	int rend = 0;
-	for (uint64_t v : c.a) {
-		const uint32_t rid = (uint32_t)(v >> 32); const int pos = (int)((uint32_t)v >> 1), dir = (int)(v & 1);
-		for (int s = 0; s < L; ++s) ++cnt[(size_t)p->obase(rid, dir, s) * tlen + pos + s];
-		if (pos + L > rend) rend = pos + L;
-	}
-	c.ref.assign((size_t)rend, 'A');
-	for (int s = 0; s < rend; ++s) {
-		uint32_t mx = cnt[s]; int b = 0;
-		for (int q = 1; q < 4; ++q) if (cnt[(size_t)q * tlen + s] > mx) { mx = cnt[(size_t)q * tlen + s]; b = q; }
-		c.ref[s] = ACGT[b];
-	}
-}
-
-// ----------------------------------------------------------------------------------------------------
 // kt_for_bucket: Stage-1 rounds                                               kthread_bucket.c:562-629
 // ----------------------------------------------------------------------------------------------------
 extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	const int L = p->L;
+	const int L = p->L, nt = p->host_threads;
+	const int RS = (2 * L + 15) & ~15;                       // stride of one group's consensus on the device
 	size_t n_cur = p->n;
-	DevBuf<mcom_mm128> d_cur, d_sorted; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids; DevBuf<uint64_t> d_members;
+	DevBuf<mcom_mm128> d_cur, d_sorted; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
+	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
-	std::vector<uint32_t> h_singles, h_sord, h_goff, resk;
-	std::vector<uint64_t> h_members;
-	std::vector<Contig> &C0 = p->C[0];
+	std::vector<uint32_t> h_singles, h_sord, h_goff, h_nkept, resk;
+	std::vector<uint64_t> h_members; std::vector<uint8_t> h_keep, h_refs; std::vector<uint16_t> h_sv, h_reflen;
+	ContigSet &C = p->C;
+	C.clear();
 	int last_rounds = 0; long pre = 0;
 	for (int r = 1;; ++r) {
 		if (p->k - r <= 9) ++last_rounds;                                           // :584-585
@@ -320,47 +254,65 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				return p->fail(MCOM_E_NOMEM, "round buffers");
 			uint64_t cnts[4];
 			const double tg = now_ms();
-			p->stat["sort_records"] += (double)n_cur * (double)((2 * kmer_in + 10 + 7) / 8);   // records x LSD passes
 			int rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts));
 			if (rc) return rc;
 			const size_t ns = cnts[1], ng = cnts[2], nm = cnts[3];
+			if (!d_keep.reserve(nm + 1) || !d_nkept.reserve(ng + 1) || !d_sv.reserve(ng + 1) || !d_reflen.reserve(ng + 1) || !d_refs.reserve(ng * (size_t)RS + 16))
+				return p->fail(MCOM_E_NOMEM, "consensus buffers");
+			// construct_ref of every group on the device (:446)
+			if ((rc = p->gpu(mcom_group_consensus(p->ctx, p->d_packed.p, d_members.p, d_goff.p, (uint32_t)ng, L, p->k, p->e, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS)))) return rc;
 			h_singles.resize(ns); h_sord.resize(ns); h_members.resize(nm); h_goff.resize(ng + 1);
-			if (ns) { (void)hipMemcpyAsync(h_singles.data(), d_singles.p, ns * 4, hipMemcpyDeviceToHost, p->stream); (void)hipMemcpyAsync(h_sord.data(), d_sord.p, ns * 4, hipMemcpyDeviceToHost, p->stream); }
-			if (nm) (void)hipMemcpyAsync(h_members.data(), d_members.p, nm * 8, hipMemcpyDeviceToHost, p->stream);
-			(void)hipMemcpyAsync(h_goff.data(), d_goff.p, (ng + 1) * 4, hipMemcpyDeviceToHost, p->stream);
-			if ((rc = p->hipc(hipStreamSynchronize(p->stream), "round copy"))) return rc;
+			h_keep.resize(nm); h_nkept.resize(ng); h_sv.resize(ng); h_reflen.resize(ng); h_refs.resize(ng * (size_t)RS);
+			if ((rc = p->d2h(h_singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(h_sord.data(), d_sord.p, ns, "copy")) ||
+			    (rc = p->d2h(h_members.data(), d_members.p, nm, "copy")) || (rc = p->d2h(h_goff.data(), d_goff.p, ng + 1, "copy")) ||
+			    (rc = p->d2h(h_keep.data(), d_keep.p, nm, "copy")) || (rc = p->d2h(h_nkept.data(), d_nkept.p, ng, "copy")) ||
+			    (rc = p->d2h(h_sv.data(), d_sv.p, ng, "copy")) || (rc = p->d2h(h_reflen.data(), d_reflen.p, ng, "copy")) ||
+			    (rc = p->d2h(h_refs.data(), d_refs.p, ng * (size_t)RS, "copy")) || (rc = p->sync("round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["t_bk_gpu"] += now_ms() - tg;
 			const double tb1 = now_ms();
-			// consensus of every group; groups are independent, only the appends below are ordered
-			std::vector<GroupOut> outs(ng);
-			const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, ng / 64)));
-			auto work = [&](int tid) {
-				std::vector<uint32_t> cnt;
-				for (size_t g = (size_t)tid; g < ng; g += (size_t)nt)
-					construct_ref(p, h_members.data() + h_goff[g], h_goff[g + 1] - h_goff[g], outs[g], cnt);
-			};
-			if (nt == 1) work(0);
-			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
+			// groups that stay contigs (more than one member kept, :451) get their slots by prefix sums ...
+			const size_t c0 = C.n();
+			std::vector<uint64_t> gslot(ng + 1, 0), gm(ng + 1, 0), gr(ng + 1, 0);
+			for (size_t g = 0; g < ng; ++g) {
+				const bool acc = h_nkept[g] > 1;
+				gslot[g + 1] = gslot[g] + (acc ? 1 : 0);
+				gm[g + 1] = gm[g] + (acc ? h_nkept[g] : 0);
+				gr[g + 1] = gr[g] + (acc ? h_reflen[g] : 0);
+			}
+			const size_t nc = gslot[ng], m_base = C.mem.size(), r_base = C.ref.size();
+			C.mem.resize(m_base + gm[ng]); C.ref.resize(r_base + gr[ng]);
+			C.moff.resize(c0 + nc + 1); C.roff.resize(c0 + nc + 1);
+			// ... and are filled in parallel; final offsets are relative to the first covered column (:349)
+			parallel_for(nt, ng, [&](int, size_t gb, size_t ge) {
+				for (size_t g = gb; g < ge; ++g) {
+					if (h_nkept[g] <= 1) continue;
+					uint64_t *dst = C.mem.data() + m_base + gm[g];
+					const uint64_t sv2 = (uint64_t)h_sv[g] << 1;
+					for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (h_keep[q]) *dst++ = h_members[q] - sv2;
+					memcpy(C.ref.data() + r_base + gr[g], h_refs.data() + g * (size_t)RS, h_reflen[g]);
+					C.moff[c0 + gslot[g] + 1] = m_base + gm[g + 1];
+					C.roff[c0 + gslot[g] + 1] = r_base + gr[g + 1];
+				}
+			});
 			const double tb2 = now_ms();
 			p->stat["t_bk_cons"] += tb2 - tb1;
-			// replay in the reference's visiting order (process_bucket, :398-505)
+			// singletons and rejects in the reference's visiting order (process_bucket, :398-505)
 			size_t si = 0;
 			auto reject = [&](uint32_t rid) { if (last) p->sg.push_back(rid); else resk.push_back(rid); };
 			for (size_t g = 0; g <= ng; ++g) {
 				while (si < ns && h_sord[si] == g) p->sg.push_back(h_singles[si++]);      // groups of one (:402-413)
 				if (g == ng) break;
-				GroupOut &o = outs[g];
-				for (uint32_t rid : o.rejected) reject(rid);                                  // :194-213
-				if (o.c.a.size() > 1) C0.emplace_back(std::move(o.c));                        // :451-475
-				else if (o.c.a.size() == 1) reject((uint32_t)(o.c.a[0] >> 32));              // :477-498
+				const uint32_t sz = h_goff[g + 1] - h_goff[g], nk = h_nkept[g];
+				if (nk == sz && nk > 1) continue;
+				for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (!h_keep[q]) reject((uint32_t)(h_members[q] >> 32));   // :194-213
+				if (nk == 1) for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (h_keep[q]) reject((uint32_t)(h_members[q] >> 32)); // :477-498
 			}
 			p->stat["t_bk_replay"] += now_ms() - tb2;
 		}
 		p->stat["rounds"] += 1;
 		if (last_rounds) ++last_rounds;                                             // :594
-		long cr = 0;
-		for (const Contig &c : C0) cr += (long)c.a.size();
+		const long cr = (long)C.mem.size();
 		if (cr - pre < 100) ++last_rounds;                                          // :614-618
 		pre = cr;
 		if (last_rounds > 1) break;
@@ -370,9 +322,10 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		p->stat["resketch"] += (double)n_cur;
 		if (n_cur) {
 			if (!d_rids.reserve(n_cur) || !d_cur.reserve(n_cur)) return p->fail(MCOM_E_NOMEM, "re-sketch buffers");
-			int rc = p->hipc(hipMemcpyAsync(d_rids.p, resk.data(), n_cur * 4, hipMemcpyHostToDevice, p->stream), "upload rids");
+			int rc = p->h2d(d_rids.p, resk.data(), n_cur, "upload rids");
 			if (rc) return rc;
 			if ((rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, d_rids.p, n_cur, L, kmer_next, 0, d_cur.p)))) return rc;
+			if ((rc = p->sync("re-sketch"))) return rc;
 			cur = d_cur.p;
 		}
 	}
@@ -383,52 +336,39 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// contigs on the device
+// contigs on the device: ASCII concat + char offsets, packed words + word offsets, lengths
 // ----------------------------------------------------------------------------------------------------
-struct DevContigs {
-	DevBuf<uint8_t> seq; DevBuf<uint64_t> off, coff, cbits; DevBuf<uint32_t> clen;
-	std::vector<uint64_t> h_off, h_coff; std::vector<uint32_t> h_len;
-	uint64_t total_words = 0; size_t n = 0;
-};
-
-static int upload_contigs(P *p, const std::vector<Contig> &cs, DevContigs &d, bool pack)
+static int upload_contigs(P *p, const ContigSet &C)
 {
-	const size_t n = cs.size();
-	d.n = n;
-	d.h_off.assign(n + 1, 0); d.h_coff.assign(n + 1, 0); d.h_len.assign(n, 0);
-	for (size_t i = 0; i < n; ++i) {
-		d.h_len[i] = (uint32_t)cs[i].ref.size();
-		d.h_off[i + 1] = d.h_off[i] + cs[i].ref.size();
-		d.h_coff[i + 1] = d.h_coff[i] + (2 * cs[i].ref.size() + 63) / 64 + 1;
-	}
-	d.total_words = d.h_coff[n];
-	std::string cat; cat.reserve(d.h_off[n] + 1);
-	for (const Contig &c : cs) cat += c.ref;
-	if (!d.seq.reserve(cat.size() + 16) || !d.off.reserve(n + 1) || !d.coff.reserve(n + 1) || !d.clen.reserve(n + 1) || (pack && !d.cbits.reserve(d.total_words + 2)))
-		return p->fail(MCOM_E_NOMEM, "contig buffers");
+	const size_t n = C.n();
+	p->h_coff_words.assign(n + 1, 0);
+	std::vector<uint32_t> len(n);
+	for (size_t i = 0; i < n; ++i) { len[i] = (uint32_t)C.rsize(i); p->h_coff_words[i + 1] = p->h_coff_words[i] + (2 * C.rsize(i) + 63) / 64 + 1; }
+	p->total_words = p->h_coff_words[n];
+	if (!p->d_cseq.reserve(C.ref.size() + 16) || !p->d_coff_chars.reserve(n + 1) || !p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1) ||
+	    !p->d_cbits.reserve(p->total_words + 2)) return p->fail(MCOM_E_NOMEM, "contig buffers");
 	int rc;
-	if (cat.size() && (rc = p->hipc(hipMemcpyAsync(d.seq.p, cat.data(), cat.size(), hipMemcpyHostToDevice, p->stream), "upload contigs"))) return rc;
-	if ((rc = p->hipc(hipMemcpyAsync(d.off.p, d.h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, p->stream), "upload offsets"))) return rc;
-	if ((rc = p->hipc(hipMemcpyAsync(d.coff.p, d.h_coff.data(), (n + 1) * 8, hipMemcpyHostToDevice, p->stream), "upload offsets"))) return rc;
-	if (n && (rc = p->hipc(hipMemcpyAsync(d.clen.p, d.h_len.data(), n * 4, hipMemcpyHostToDevice, p->stream), "upload lengths"))) return rc;
-	if (pack && n) {
-		if ((rc = p->hipc(hipMemsetAsync(d.cbits.p, 0, (d.total_words + 2) * 8, p->stream), "clear"))) return rc;
-		if ((rc = p->gpu(mcom_pack_contigs(p->ctx, d.seq.p, d.off.p, d.coff.p, (uint32_t)n, d.total_words, d.cbits.p)))) return rc;
+	if ((rc = p->h2d(p->d_cseq.p, (const uint8_t*)C.ref.data(), C.ref.size(), "upload contigs")) ||
+	    (rc = p->h2d(p->d_coff_chars.p, C.roff.data(), n + 1, "upload offsets")) ||
+	    (rc = p->h2d(p->d_coff_words.p, p->h_coff_words.data(), n + 1, "upload offsets")) ||
+	    (rc = p->h2d(p->d_clen.p, len.data(), n, "upload lengths"))) return rc;
+	if (n) {
+		if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (p->total_words + 2) * 8, p->stream), "clear"))) return rc;
+		if ((rc = p->gpu(mcom_pack_contigs(p->ctx, p->d_cseq.p, p->d_coff_chars.p, p->d_coff_words.p, (uint32_t)n, p->total_words, p->d_cbits.p)))) return rc;
 	}
-	// the host vectors must outlive the async copies
-	return p->hipc(hipStreamSynchronize(p->stream), "upload contigs");
+	return p->sync("upload contigs");            // `len` must outlive the async copy
 }
 
-// mm_sketch_lh_ori of every contig; max_per = 0 keeps all minimizers
-static int sketch_contigs(P *p, const DevContigs &d, uint32_t max_per, DevBuf<uint32_t> &moff, DevBuf<mcom_mm128> &out, uint64_t &total)
+// mm_sketch_lh_ori of every uploaded contig (all minimizers)
+static int sketch_contigs(P *p, size_t n, size_t total_chars, DevBuf<uint32_t> &moff, DevBuf<mcom_mm128> &out, uint64_t &total)
 {
 	total = 0;
-	p->stat["sketch_bases"] += 2.0 * (double)d.h_off[d.n];          // one count launch + one emit launch
-	if (!moff.reserve(d.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
-	size_t cap = std::max<size_t>(1024, max_per ? d.n * max_per : d.h_off[d.n] / 8 + d.n);
+	p->stat["sketch_bases"] += 2.0 * (double)total_chars;          // one count launch + one emit launch
+	if (!moff.reserve(n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	size_t cap = std::max<size_t>(1024, total_chars / 8 + n);
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (!out.reserve(cap)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-		int rc = mcom_sketch_contigs(p->ctx, d.seq.p, d.off.p, nullptr, d.n, p->rw, p->k, max_per, moff.p, out.p, out.cap, &total);
+		int rc = mcom_sketch_contigs(p->ctx, p->d_cseq.p, p->d_coff_chars.p, nullptr, n, p->rw, p->k, 0, moff.p, out.p, out.cap, &total);
 		if (rc == MCOM_E_OVERFLOW) { cap = total; continue; }
 		return p->gpu(rc);
 	}
@@ -442,35 +382,36 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	int index = 0; long pre = 0;
-	DevContigs dc; DevBuf<uint32_t> moff_m, moff_all; DevBuf<mcom_mm128> rec_m, rec_all, d_pairs;
-	std::vector<mcom_mm128> pairs; std::vector<uint32_t> cnt;
+	const int L = p->L, nt = p->host_threads;
+	long pre = 0;
+	DevBuf<uint32_t> moff_all, moff_m, d_tjob, d_tidx; DevBuf<mcom_mm128> rec_all, rec_m, d_pairs;
+	DevBuf<uint64_t> d_jm, d_jmoff, d_jroff; DevBuf<uint8_t> d_jref;
+	std::vector<mcom_mm128> pairs;
 	for (;;) {
-		std::vector<Contig> &src = p->C[index], &dst = p->C[index ^ 1];
-		dst.clear();
-		const size_t n = src.size();
+		ContigSet &S = p->C;
+		const size_t n = S.n();
 		uint64_t n_pass = 0;
+		double tl = now_ms();
+		auto lap = [&](const char *nm) { const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
 		if (n) {
 			const double tg = now_ms();
-			double tl = tg;
-			auto lap = [&](const char *nm) { (void)hipStreamSynchronize(p->stream); const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
-			int rc = upload_contigs(p, src, dc, true);
+			int rc = upload_contigs(p, S);
 			if (rc) return rc;
 			lap("t_cb_upload");
-			uint64_t tm = 0, ta = 0;
-			if ((rc = sketch_contigs(p, dc, (uint32_t)p->m, moff_m, rec_m, tm))) return rc;
-			lap("t_cb_sketch");       // what the builders pushed to mi[index] (:370-380, :423-432)
-			if (index == 0 && p->mi0.empty() && tm) { p->mi0.resize(tm); (void)hipMemcpy(p->mi0.data(), rec_m.p, tm * sizeof(mcom_mm128), hipMemcpyDeviceToHost); }
-			mcom_idx *mi = nullptr;
-			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, &mi)))) return rc;          // mm_idx_generation (:580)
-			lap("t_cb_idx");
-			if ((rc = sketch_contigs(p, dc, 0, moff_all, rec_all, ta))) { mcom_idx_destroy(p->ctx, mi); return rc; }   // find_next's own sketch (:234)
+			uint64_t ta = 0, tm = 0;
+			if ((rc = sketch_contigs(p, n, S.ref.size(), moff_all, rec_all, ta))) return rc;                 // find_next's own sketch (:234)
+			// the first m of them are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
+			if (!moff_m.reserve(n + 2) || !rec_m.reserve(n * (size_t)p->m + 16)) return p->fail(MCOM_E_NOMEM, "index records");
+			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, moff_all.p, rec_all.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
 			lap("t_cb_sketch");
+			mcom_idx *mi = nullptr;
+			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, &mi)))) return rc;                    // mm_idx_generation (:580)
+			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
 			size_t cap = std::max<size_t>(1024, ta);
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-				rc = mcom_find_next_candidates(p->ctx, mi, rec_all.p, ta, dc.cbits.p, dc.coff.p, dc.clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
+				rc = mcom_find_next_candidates(p->ctx, mi, rec_all.p, ta, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
 				if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 				break;
 			}
@@ -479,13 +420,12 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			lap("t_cb_findnext");
 			n_pass = hc[1];
 			pairs.resize(n_pass);
-			if (n_pass && (rc = p->hipc(hipMemcpy(pairs.data(), d_pairs.p, n_pass * sizeof(mcom_mm128), hipMemcpyDeviceToHost), "copy candidates"))) return rc;
+			if ((rc = p->d2h(pairs.data(), d_pairs.p, n_pass, "copy candidates")) || (rc = p->sync("candidates"))) return rc;
 			lap("t_cb_d2h");
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
 		// first-come claiming in contig order (find_next :267-343 at one thread)
-		const double tc0 = now_ms();
 		std::vector<uint8_t> flag(n, 0);
 		struct Job { uint32_t ci, cj, pos_ori, pos; };
 		std::vector<Job> jobs;
@@ -504,47 +444,76 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			}
 			q = qe;
 		}
-		// the merged contigs themselves are independent of each other: build them on all host threads
-		const double tc1 = now_ms();
-		p->stat["t_claim"] += tc1 - tc0;
-		dst.resize(jobs.size());
-		{
-			const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, jobs.size() / 16)));
-			auto work = [&](int tid) {
-				std::vector<uint32_t> lcnt;
-				for (size_t j = (size_t)tid; j < jobs.size(); j += (size_t)nt) {
-					const Job &jb = jobs[j];
-					const Contig &a = src[jb.ci], &b = src[jb.cj];
-					Contig &t = dst[j];
-					t.a.reserve(a.a.size() + b.a.size());
-					if (jb.pos_ori >= jb.pos) {                                             // :302-315
-						t.a.insert(t.a.end(), a.a.begin(), a.a.end());
-						for (uint64_t y : b.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(jb.pos_ori - jb.pos)) << 1) | (y & 1));
-					} else {                                                                // :316-325
-						t.a.insert(t.a.end(), b.a.begin(), b.a.end());
-						for (uint64_t y : a.a) t.a.push_back((y >> 32 << 32) | (((uint64_t)((uint32_t)y >> 1) + (uint64_t)(jb.pos - jb.pos_ori)) << 1) | (y & 1));
-					}
-					construct_ref2(p, t, lcnt);
+		lap("t_claim");
+		// merged member lists (:297-325), sorted by cmpcluster2 as construct_ref2 does first (:107)
+		const size_t nj = jobs.size();
+		std::vector<uint64_t> jmoff(nj + 1, 0), jroff(nj + 1, 0);
+		for (size_t j = 0; j < nj; ++j) jmoff[j + 1] = jmoff[j] + S.msize(jobs[j].ci) + S.msize(jobs[j].cj);
+		std::vector<uint64_t> jm(jmoff[nj]);
+		std::vector<uint64_t> jlen(nj, 0);
+		parallel_for(nt, nj, [&](int, size_t jb, size_t je) {
+			for (size_t j = jb; j < je; ++j) {
+				const Job &J = jobs[j];
+				uint64_t *dst = jm.data() + jmoff[j];
+				const uint64_t *a = S.mem.data() + S.moff[J.ci], *b = S.mem.data() + S.moff[J.cj];
+				const size_t na = S.msize(J.ci), nb = S.msize(J.cj);
+				if (J.pos_ori >= J.pos) {                                                   // :302-315
+					memcpy(dst, a, na * 8);
+					const uint64_t sh = (uint64_t)(J.pos_ori - J.pos) << 1;
+					for (size_t u = 0; u < nb; ++u) dst[na + u] = b[u] + sh;
+				} else {                                                                    // :316-325
+					memcpy(dst, b, nb * 8);
+					const uint64_t sh = (uint64_t)(J.pos - J.pos_ori) << 1;
+					for (size_t u = 0; u < na; ++u) dst[nb + u] = a[u] + sh;
 				}
-			};
-			if (nt == 1) work(0);
-			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
+				std::stable_sort(dst, dst + na + nb, less_cluster2);
+				jlen[j] = (uint64_t)((uint32_t)dst[na + nb - 1] >> 1) + (uint64_t)L;         // rend: the last member reaches furthest
+			}
+		});
+		for (size_t j = 0; j < nj; ++j) jroff[j + 1] = jroff[j] + jlen[j];
+		lap("t_merge_members");
+		// construct_ref2 of every merged contig on the device (:327)
+		std::vector<char> jref(jroff[nj]);
+		if (nj) {
+			std::vector<uint32_t> tjob, tidx;
+			for (size_t j = 0; j < nj; ++j) for (uint64_t t = 0; t * 512 < jlen[j]; ++t) { tjob.push_back((uint32_t)j); tidx.push_back((uint32_t)t); }
+			if (!d_jm.reserve(jm.size() + 1) || !d_jmoff.reserve(nj + 1) || !d_jroff.reserve(nj + 1) || !d_jref.reserve(jref.size() + 16) ||
+			    !d_tjob.reserve(tjob.size() + 1) || !d_tidx.reserve(tidx.size() + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+			int rc;
+			if ((rc = p->h2d(d_jm.p, jm.data(), jm.size(), "upload merged members")) || (rc = p->h2d(d_jmoff.p, jmoff.data(), nj + 1, "upload")) ||
+			    (rc = p->h2d(d_jroff.p, jroff.data(), nj + 1, "upload")) || (rc = p->h2d(d_tjob.p, tjob.data(), tjob.size(), "upload")) ||
+			    (rc = p->h2d(d_tidx.p, tidx.data(), tidx.size(), "upload"))) return rc;
+			if ((rc = p->gpu(mcom_merge_consensus(p->ctx, p->d_packed.p, d_jm.p, d_jmoff.p, d_jroff.p, d_tjob.p, d_tidx.p, (uint32_t)tjob.size(), L, d_jref.p)))) return rc;
+			if ((rc = p->d2h((uint8_t*)jref.data(), d_jref.p, jref.size(), "copy merged consensus")) || (rc = p->sync("merge consensus"))) return rc;
 		}
-		const double tc2 = now_ms();
-		p->stat["t_merge_cons"] += tc2 - tc1;
-		for (size_t i = 0; i < n; ++i) if (!flag[i]) dst.emplace_back(std::move(src[i]));   // cp_cluster (:397-434)
-		const double tc3 = now_ms();
-		p->stat["t_cb_copy"] += tc3 - tc2;
-		src.clear();
-		p->stat["t_cb_free"] += now_ms() - tc3;
+		lap("t_merge_cons");
+		// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
+		ContigSet N;
+		size_t nkeep = 0;
+		for (size_t i = 0; i < n; ++i) if (!flag[i]) ++nkeep;
+		const size_t nn = nj + nkeep;
+		N.moff.assign(nn + 1, 0); N.roff.assign(nn + 1, 0);
+		std::vector<uint32_t> keepidx; keepidx.reserve(nkeep);
+		for (size_t i = 0; i < n; ++i) if (!flag[i]) keepidx.push_back((uint32_t)i);
+		for (size_t j = 0; j < nj; ++j) { N.moff[j + 1] = jmoff[j + 1]; N.roff[j + 1] = jroff[j + 1]; }
+		for (size_t u = 0; u < nkeep; ++u) { N.moff[nj + u + 1] = N.moff[nj + u] + S.msize(keepidx[u]); N.roff[nj + u + 1] = N.roff[nj + u] + S.rsize(keepidx[u]); }
+		N.mem.resize(N.moff[nn]); N.ref.resize(N.roff[nn]);
+		if (nj) { memcpy(N.mem.data(), jm.data(), jm.size() * 8); memcpy(N.ref.data(), jref.data(), jref.size()); }
+		parallel_for(nt, nkeep, [&](int, size_t ub, size_t ue) {
+			for (size_t u = ub; u < ue; ++u) {
+				const size_t i = keepidx[u];
+				memcpy(N.mem.data() + N.moff[nj + u], S.mem.data() + S.moff[i], S.msize(i) * 8);
+				memcpy(N.ref.data() + N.roff[nj + u], S.ref.data() + S.roff[i], S.rsize(i));
+			}
+		});
+		p->C = std::move(N);
+		lap("t_cb_copy");
 		p->stat["merge_rounds"] += 1;
-		index ^= 1;
-		const long tot = (long)p->C[index].size();
+		const long tot = (long)p->C.n();
 		if (std::labs(pre - tot) < 100) break;                                              // :625
 		pre = tot;
 	}
-	p->idxv = index;
-	p->unsorted.assign(p->C[index].size(), 1);
+	p->unsorted.assign(p->C.n(), 1);
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -571,47 +540,40 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
+	const int nt = p->host_threads;
 	mcomh_update_single(p);                                                                 // preprocess.c:203
-	std::vector<Contig> &cs = p->C[p->idxv];
-	const size_t n_sg = p->sg.size();
+	ContigSet &C = p->C;
+	const size_t nc = C.n(), n_sg = p->sg.size();
 	int rc;
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
-		DevContigs dc;
-		// reuse the pipeline-owned buffers: move them in and out of the helper struct
-		if ((rc = upload_contigs(p, cs, dc, true))) return rc;
-		std::vector<uint64_t> woff(cs.size() + 1, 0);
-		for (size_t i = 0; i < cs.size(); ++i) woff[i + 1] = woff[i] + (dc.h_len[i] >= (uint32_t)p->L ? dc.h_len[i] - p->L + 1 : 0);
-		p->n_windows = woff[cs.size()];
-		if (!p->d_woff.reserve(cs.size() + 1)) return p->fail(MCOM_E_NOMEM, "window offsets");
-		if ((rc = p->hipc(hipMemcpy(p->d_woff.p, woff.data(), (cs.size() + 1) * 8, hipMemcpyHostToDevice), "upload window offsets"))) return rc;
-		std::swap(p->d_cbits.p, dc.cbits.p); std::swap(p->d_cbits.cap, dc.cbits.cap);
-		std::swap(p->d_coff_words.p, dc.coff.p); std::swap(p->d_coff_words.cap, dc.coff.cap);
+		if ((rc = upload_contigs(p, C))) return rc;
+		std::vector<uint64_t> woff(nc + 1, 0);
+		for (size_t i = 0; i < nc; ++i) woff[i + 1] = woff[i] + (C.rsize(i) >= (size_t)p->L ? C.rsize(i) - p->L + 1 : 0);
+		p->n_windows = woff[nc];
+		if (!p->d_woff.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "window offsets");
+		if ((rc = p->h2d(p->d_woff.p, woff.data(), nc + 1, "upload window offsets")) || (rc = p->sync("upload"))) return rc;
 		p->stage2_uploaded = true;
 	}
 	p->stat["passes"] += 1;
 	p->stat["windows"] += (double)p->n_windows;
-	// every contig is re-sorted at the start of its scan (:318)
 	const double tr0 = now_ms();
-	{   // a stable sort of an already sorted list is the identity: only contigs that changed are sorted again
-		if (p->unsorted.size() != cs.size()) p->unsorted.assign(cs.size(), 1);
-		const int nt = std::max(1, std::min<int>(p->host_threads, (int)std::max<size_t>(1, cs.size() / 4096)));
-		auto work = [&](int tid) {
-			for (size_t c = (size_t)tid; c < cs.size(); c += (size_t)nt)
-				if (p->unsorted[c]) { std::stable_sort(cs[c].a.begin(), cs[c].a.end(), less_cluster2); p->unsorted[c] = 0; }
-		};
-		if (nt == 1) work(0);
-		else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
-	}
+	// every contig is re-sorted at the start of its scan (:318); a stable sort of a sorted list is the identity,
+	// so only contigs that changed since their last sort are touched
+	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
+	parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
+		for (size_t c = cb; c < ce; ++c)
+			if (p->unsorted[c]) { std::stable_sort(C.mem.data() + C.moff[c], C.mem.data() + C.moff[c + 1], less_cluster2); p->unsorted[c] = 0; }
+	});
 	p->stat["t_ra_sort"] += now_ms() - tr0;
 	if (n_sg) {
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
 		if (!d_sg.reserve(n_sg) || !d_sgbits.reserve(n_sg * p->W) || !d_claim.reserve(n_sg) || !d_flag.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
-		if ((rc = p->hipc(hipMemcpyAsync(d_sg.p, p->sg.data(), n_sg * 4, hipMemcpyHostToDevice, p->stream), "upload singletons"))) return rc;
+		if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
 		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
 		std::vector<uint8_t> pf(n_sg);
-		if ((rc = p->hipc(hipMemcpyAsync(pf.data(), d_flag.p, n_sg, hipMemcpyDeviceToHost, p->stream), "copy flags"))) return rc;
+		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
 		mcom_dicts *dicts = nullptr;
 		if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;               // constructdictionary_realign
 		{
@@ -623,11 +585,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			if (pf[i] == 1) { p->sg_flag[i] = 1; p->fpA.push_back(p->sg[i]); }
 			else if (pf[i] == 2) { p->sg_flag[i] = 1; p->fpT.push_back(p->sg[i]); }
 		}
-		rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)cs.size(),
+		rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
 		                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
 		std::vector<uint64_t> claim(n_sg);
-		if (!rc) rc = p->hipc(hipMemcpyAsync(claim.data(), d_claim.p, n_sg * 8, hipMemcpyDeviceToHost, p->stream), "copy claims");
-		if (!rc) rc = p->hipc(hipStreamSynchronize(p->stream), "realign pass");
+		if (!rc) rc = p->d2h(claim.data(), d_claim.p, n_sg, "copy claims");
+		if (!rc) rc = p->sync("realign pass");
 		mcom_dicts_free(p->ctx, dicts);
 		if (rc) return rc;
 		p->stat["t_gpu"] += now_ms() - tg;
@@ -637,17 +599,29 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) won.emplace_back(claim[i], (uint32_t)i);
 		std::sort(won.begin(), won.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
 			return a.first != b.first ? a.first < b.first : a.second > b.second; });
-		for (const auto &w : won) {
-			const uint64_t ck = w.first;
-			const size_t c = (size_t)(ck >> 33); const uint64_t jj = (ck >> 5) & ((1ull << 28) - 1), dir = (ck >> 4) & 1;
-			cs[c].a.push_back((uint64_t)p->sg[w.second] << 32 | (jj << 1) | dir);              // :408-409, :474-475
-			p->unsorted[c] = 1;
-			p->sg_flag[w.second] = 1;
+		if (!won.empty()) {
+			std::vector<uint64_t> add(nc + 1, 0);
+			for (const auto &w : won) ++add[(size_t)(w.first >> 33) + 1];
+			for (size_t c = 0; c < nc; ++c) add[c + 1] += add[c];                             // appended members before contig c
+			std::vector<uint64_t> nmem(C.mem.size() + won.size()), nmoff(nc + 1);
+			for (size_t c = 0; c <= nc; ++c) nmoff[c] = C.moff[c] + add[c];
+			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
+				for (size_t c = cb; c < ce; ++c) {
+					memcpy(nmem.data() + nmoff[c], C.mem.data() + C.moff[c], C.msize(c) * 8);
+					uint64_t *dst = nmem.data() + nmoff[c] + C.msize(c);
+					for (uint64_t u = add[c]; u < add[c + 1]; ++u) {
+						const uint64_t ck = won[u].first;
+						const uint64_t jj = (ck >> 5) & ((1ull << 28) - 1), dir = (ck >> 4) & 1;
+						*dst++ = (uint64_t)p->sg[won[u].second] << 32 | (jj << 1) | dir;        // :408-409, :474-475
+					}
+					if (add[c + 1] > add[c]) p->unsorted[c] = 1;
+				}
+			});
+			for (const auto &w : won) p->sg_flag[w.second] = 1;
+			C.mem.swap(nmem); C.moff.swap(nmoff);
 		}
 	}
-	long cr = 0;
-	for (const Contig &c : cs) cr += (long)c.a.size();
-	if (cluster_reads) *cluster_reads = cr;
+	if (cluster_reads) *cluster_reads = (long)C.mem.size();
 	p->stat["t_realign"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -674,12 +648,12 @@ static void dump_list(FILE *f, const char *name, const std::vector<uint32_t> &v)
 	for (uint32_t x : v) fprintf(f, " %u", x);
 	fprintf(f, "\n");
 }
-static void dump_contigs(FILE *f, const char *stage, const std::vector<Contig> &cs)
+static void dump_contigs(FILE *f, const char *stage, const ContigSet &C)
 {
-	fprintf(f, "CLUSTERS %s %zu\n", stage, cs.size());
-	for (const Contig &c : cs) {
-		fprintf(f, "C %zu %s", c.a.size(), c.ref.c_str());
-		for (uint64_t y : c.a) fprintf(f, " %" PRIu64, y);
+	fprintf(f, "CLUSTERS %s %zu\n", stage, C.n());
+	for (size_t c = 0; c < C.n(); ++c) {
+		fprintf(f, "C %zu %.*s", C.msize(c), (int)C.rsize(c), C.ref.data() + C.roff[c]);
+		for (uint64_t q = C.moff[c]; q < C.moff[c + 1]; ++q) fprintf(f, " %" PRIu64, C.mem[q]);
 		fprintf(f, "\n");
 	}
 }
@@ -714,7 +688,7 @@ static int run_stage2(P *p, FILE *f)
 			for (uint8_t v : p->sg_flag) fprintf(f, " %d", v ? 1 : 0);
 			fprintf(f, "\n");
 			dump_list(f, "fpA", p->fpA); dump_list(f, "fpT", p->fpT);
-			dump_contigs(f, "realign", p->C[p->idxv]);
+			dump_contigs(f, "realign", p->C);
 		}
 		const long lim = (p->sg.size() > 1000000 && p->L >= 68) ? 10000 : 1000;
 		++pass;
@@ -732,14 +706,16 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 	if (!f) return p->fail(MCOM_E_ARG, "cannot write %s", path);
 	int rc = mcomh_kt_for_reads(p);
 	if (rc) { fclose(f); return rc; }
-	const int L = p->L;
+	const int L = p->L, W = p->W;
 	fprintf(f, "PARAMS L %d k %d b %d rw %d e %d cbthr %d m %d n %zu\n", L, p->k, NB_BITS, p->rw, p->e, p->cbthr, p->m, p->n);
 	fprintf(f, "STAGE reads\nREADS %zu\n", p->n);
+	std::vector<uint64_t> h_packed(p->n * (size_t)W);
+	if (p->n && (rc = p->hipc(hipMemcpy(h_packed.data(), p->d_packed.p, p->n * (size_t)W * 8, hipMemcpyDeviceToHost), "copy packed reads"))) { fclose(f); return rc; }
 	std::string line((size_t)L, 'A');
 	size_t nn = 0;
 	for (size_t r = 0; r < p->n; ++r) {
 		const uint8_t *src = p->h_ascii.data() + r * (size_t)L;
-		if (p->h_cls[r] == MCOM_CLS_SKETCH) for (int i = 0; i < L; ++i) line[i] = ACGT[p->base((uint32_t)r, i)];
+		if (p->h_cls[r] == MCOM_CLS_SKETCH) for (int i = 0; i < L; ++i) line[i] = ACGT[(h_packed[r * W + (i >> 5)] >> (2 * (i & 31))) & 3];
 		else line.assign((const char*)src, (size_t)L);
 		fprintf(f, "%s\n", line.c_str());
 		if (memchr(src, 'N', (size_t)L)) ++nn;
@@ -762,24 +738,24 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 	}
 	if ((rc = mcomh_kt_for_bucket(p))) { fclose(f); return rc; }
 	fprintf(f, "STAGE bucket\n");
-	dump_contigs(f, "bucket", p->C[0]);
+	dump_contigs(f, "bucket", p->C);
 	dump_list(f, "sg", p->sg);
-	const std::vector<Contig> stage1 = p->C[0];
-	(void)stage1;
 	// the first-m minimizers the reference pushed into mi[0] while building the contigs (:458-474)
 	{
-		DevContigs dc; DevBuf<uint32_t> mo; DevBuf<mcom_mm128> mr; uint64_t tm = 0;
 		std::vector<mcom_mm128> rec;
-		if (!p->C[0].empty()) {
-			if ((rc = upload_contigs(p, p->C[0], dc, false)) || (rc = sketch_contigs(p, dc, (uint32_t)p->m, mo, mr, tm))) { fclose(f); return rc; }
+		if (p->C.n()) {
+			DevBuf<uint32_t> mo, mo2; DevBuf<mcom_mm128> mr, mr2; uint64_t ta = 0, tm = 0;
+			if ((rc = upload_contigs(p, p->C)) || (rc = sketch_contigs(p, p->C.n(), p->C.ref.size(), mo, mr, ta))) { fclose(f); return rc; }
+			if (!mo2.reserve(p->C.n() + 2) || !mr2.reserve(p->C.n() * (size_t)p->m + 16)) { fclose(f); return p->fail(MCOM_E_NOMEM, "dump buffers"); }
+			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, mo.p, mr.p, p->C.n(), (uint32_t)p->m, mo2.p, mr2.p, &tm)))) { fclose(f); return rc; }
 			rec.resize(tm);
-			if (tm) (void)hipMemcpy(rec.data(), mr.p, tm * sizeof(mcom_mm128), hipMemcpyDeviceToHost);
+			if (tm) (void)hipMemcpy(rec.data(), mr2.p, tm * sizeof(mcom_mm128), hipMemcpyDeviceToHost);
 		}
 		dump_buckets(f, "MI0", rec);
 	}
 	if ((rc = mcomh_combine_cluster(p))) { fclose(f); return rc; }
 	fprintf(f, "STAGE combine\n");
-	dump_contigs(f, "combine", p->C[p->idxv]);
+	dump_contigs(f, "combine", p->C);
 	if ((rc = run_stage2(p, f))) { fclose(f); return rc; }
 	fprintf(f, "STAGE final\n");
 	dump_list(f, "sg", p->sg);
@@ -789,10 +765,14 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 }
 
 // ---- results -----------------------------------------------------------------------------------------------
-extern "C" size_t mcomh_n_contigs(const mcomh_pipeline *p) { return p ? p->C[p->idxv].size() : 0; }
-extern "C" const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i) { return p->C[p->idxv][i].ref.c_str(); }
-extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { return p->C[p->idxv][i].a.size(); }
-extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { return p->C[p->idxv][i].a.data(); }
+extern "C" size_t mcomh_n_contigs(const mcomh_pipeline *p) { return p ? p->C.n() : 0; }
+extern "C" const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len)
+{
+	if (len) *len = p->C.rsize(i);
+	return p->C.ref.data() + p->C.roff[i];                 // NOT NUL-terminated: use *len
+}
+extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { return p->C.msize(i); }
+extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { return p->C.mem.data() + p->C.moff[i]; }
 extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 {
 	const std::vector<uint32_t> *v = nullptr;

@@ -43,7 +43,7 @@ def load_host_library():
     L.mcomh_realign_hash.restype = i32; L.mcomh_realign_hash.argtypes = [vp, i32, C.POINTER(C.c_long)]
     L.mcomh_dump_stages.restype = i32; L.mcomh_dump_stages.argtypes = [vp, cp]
     L.mcomh_n_contigs.restype = sz; L.mcomh_n_contigs.argtypes = [vp]
-    L.mcomh_contig_ref.restype = cp; L.mcomh_contig_ref.argtypes = [vp, sz]
+    L.mcomh_contig_ref.restype = vp; L.mcomh_contig_ref.argtypes = [vp, sz, C.POINTER(sz)]
     L.mcomh_contig_n.restype = sz; L.mcomh_contig_n.argtypes = [vp, sz]
     L.mcomh_contig_members.restype = vp; L.mcomh_contig_members.argtypes = [vp, sz]
     L.mcomh_list.restype = vp; L.mcomh_list.argtypes = [vp, cp, C.POINTER(sz)]
@@ -140,5 +140,7 @@ class Pipeline:
         for i in range(self.lib.mcomh_n_contigs(self._h)):
             n = self.lib.mcomh_contig_n(self._h, i)
             mem = np.frombuffer((C.c_char * (8 * n)).from_address(self.lib.mcomh_contig_members(self._h, i)), dtype=np.uint64).copy() if n else np.zeros(0, np.uint64)
-            out.append((self.lib.mcomh_contig_ref(self._h, i), mem))
+            ln = C.c_size_t()
+            ptr = self.lib.mcomh_contig_ref(self._h, i, C.byref(ln))
+            out.append((C.string_at(ptr, ln.value), mem))
         return out
