@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,10 +27,60 @@ namespace {
 constexpr int NB_BITS = 14;                 // MM_IDX_DEF_B, minicommain.c:175
 constexpr uint64_t U64MAX = ~0ull;
 
+// Process-wide pool of page-locked host blocks.  Pinning memory (hipHostMalloc) and first-touching fresh pages are
+// both expensive, and every large host array here is a DMA source or target, so blocks are pinned once and reused
+// by later pipelines of the same process (the pool never returns memory to the system).
+class PinnedPool {
+	std::mutex mu;
+	std::multimap<size_t, void*> free_;
+public:
+	void *get(size_t bytes, size_t &cap) {
+		const size_t unit = (size_t)2 << 20;
+		cap = ((bytes + bytes / 8 + unit - 1) / unit) * unit;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			auto it = free_.lower_bound(cap);
+			if (it != free_.end() && it->first <= 2 * cap + unit) { void *p = it->second; cap = it->first; free_.erase(it); return p; }
+		}
+		void *p = nullptr;
+		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) p = nullptr;
+		return p;
+	}
+	void put(void *p, size_t cap) { if (!p) return; std::lock_guard<std::mutex> g(mu); free_.emplace(cap, p); }
+};
+PinnedPool &pinned_pool() { static PinnedPool *pool = new PinnedPool(); return *pool; }
+
+// minimal vector over pooled pinned memory: no value initialisation, contents kept on growth
+template <class T> class PinVec {
+	T *p_ = nullptr; size_t n_ = 0, cap_ = 0;      // cap_ in bytes
+public:
+	PinVec() {}
+	PinVec(const PinVec&) = delete; PinVec &operator=(const PinVec&) = delete;
+	PinVec(PinVec &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+	PinVec &operator=(PinVec &&o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+	~PinVec() { release(); }
+	void release() { pinned_pool().put(p_, cap_); p_ = nullptr; n_ = cap_ = 0; }
+	bool resize(size_t n) {
+		if (n * sizeof(T) > cap_) {
+			size_t nc = 0; T *q = (T*)pinned_pool().get(std::max<size_t>(n * sizeof(T), 64), nc);
+			if (!q) return false;
+			if (n_) memcpy(q, p_, n_ * sizeof(T));
+			pinned_pool().put(p_, cap_);
+			p_ = q; cap_ = nc;
+		}
+		n_ = n; return true;
+	}
+	void clear() { n_ = 0; }
+	size_t size() const { return n_; }
+	T *data() { return p_; } const T *data() const { return p_; }
+	T &operator[](size_t i) { return p_[i]; } const T &operator[](size_t i) const { return p_[i]; }
+	void swap(PinVec &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
+};
+
 // all contigs of one stage: members (rid<<32 | offset<<1 | dir, breads.h:49-58) and consensus strings, flat
 struct ContigSet {
-	std::vector<uint64_t> mem, moff{0};
-	std::vector<char> ref;
+	PinVec<uint64_t> mem; std::vector<uint64_t> moff{0};
+	PinVec<char> ref;
 	std::vector<uint64_t> roff{0};
 	size_t n() const { return moff.size() - 1; }
 	void clear() { mem.clear(); ref.clear(); moff.assign(1, 0); roff.assign(1, 0); }
@@ -37,15 +88,46 @@ struct ContigSet {
 	size_t rsize(size_t i) const { return (size_t)(roff[i + 1] - roff[i]); }
 };
 
+// Process-wide pool of device blocks, per device: hipMalloc / hipFree of multi-GB buffers cost milliseconds each and
+// a pipeline needs dozens of them; later pipelines of the same process reuse the blocks.
+class DevicePool {
+	std::mutex mu;
+	std::multimap<std::pair<int, size_t>, void*> free_;
+public:
+	void *get(size_t bytes, size_t &cap) {
+		int dev = 0; (void)hipGetDevice(&dev);
+		const size_t unit = (size_t)2 << 20;
+		cap = ((bytes + bytes / 8 + unit - 1) / unit) * unit;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			auto it = free_.lower_bound(std::make_pair(dev, cap));
+			if (it != free_.end() && it->first.first == dev && it->first.second <= 2 * cap + unit) { void *p = it->second; cap = it->first.second; free_.erase(it); return p; }
+		}
+		void *p = nullptr;
+		if (hipMalloc(&p, cap) != hipSuccess) {
+			// out of memory: give the pooled blocks of this device back and try once more
+			std::vector<void*> drop;
+			{ std::lock_guard<std::mutex> g(mu); for (auto it = free_.begin(); it != free_.end();) { if (it->first.first == dev) { drop.push_back(it->second); it = free_.erase(it); } else ++it; } }
+			for (void *q : drop) (void)hipFree(q);
+			if (hipMalloc(&p, cap) != hipSuccess) p = nullptr;
+		}
+		return p;
+	}
+	void put(void *p, size_t cap) { if (!p) return; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(mu); free_.emplace(std::make_pair(dev, cap), p); }
+};
+DevicePool &device_pool() { static DevicePool *pool = new DevicePool(); return *pool; }
+
 template <class T> struct DevBuf {
-	T *p = nullptr; size_t cap = 0;
-	~DevBuf() { if (p) (void)hipFree(p); }
+	T *p = nullptr; size_t cap = 0;            // cap in elements
+	size_t bytes_ = 0;
+	~DevBuf() { device_pool().put(p, bytes_); }
 	bool reserve(size_t n) {
 		if (n <= cap) return true;
-		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-		size_t want = n + n / 8 + 64;
-		if (hipMalloc(&p, want * sizeof(T)) != hipSuccess) { p = nullptr; return false; }
-		cap = want; return true;
+		device_pool().put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0;
+		size_t got = 0;
+		p = (T*)device_pool().get(std::max<size_t>(n * sizeof(T), 256), got);
+		if (!p) return false;
+		bytes_ = got; cap = got / sizeof(T); return true;
 	}
 };
 
@@ -92,7 +174,7 @@ struct mcomh_pipeline {
 	std::vector<uint8_t> h_cls;
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
-	ContigSet C;
+	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
 	std::vector<uint8_t> unsorted;           // Stage 2: contigs whose member list changed since it was last sorted
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
@@ -237,8 +319,9 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	DevBuf<mcom_mm128> d_cur, d_sorted; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
 	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
-	std::vector<uint32_t> h_singles, h_sord, h_goff, h_nkept, resk;
-	std::vector<uint64_t> h_members; std::vector<uint8_t> h_keep, h_refs; std::vector<uint16_t> h_sv, h_reflen;
+	std::vector<uint32_t> resk;
+	PinVec<uint32_t> h_singles, h_sord, h_goff, h_nkept;
+	PinVec<uint64_t> h_members; PinVec<uint8_t> h_keep, h_refs; PinVec<uint16_t> h_sv, h_reflen;
 	ContigSet &C = p->C;
 	C.clear();
 	int last_rounds = 0; long pre = 0;
@@ -257,6 +340,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			int rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts));
 			if (rc) return rc;
 			const size_t ns = cnts[1], ng = cnts[2], nm = cnts[3];
+			p->stat["t_bk_sort"] += now_ms() - tg;
 			if (!d_keep.reserve(nm + 1) || !d_nkept.reserve(ng + 1) || !d_sv.reserve(ng + 1) || !d_reflen.reserve(ng + 1) || !d_refs.reserve(ng * (size_t)RS + 16))
 				return p->fail(MCOM_E_NOMEM, "consensus buffers");
 			// construct_ref of every group on the device (:446)
@@ -386,7 +470,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	long pre = 0;
 	DevBuf<uint32_t> moff_all, moff_m, d_tjob, d_tidx; DevBuf<mcom_mm128> rec_all, rec_m, d_pairs;
 	DevBuf<uint64_t> d_jm, d_jmoff, d_jroff; DevBuf<uint8_t> d_jref;
-	std::vector<mcom_mm128> pairs;
+	PinVec<mcom_mm128> pairs;
 	for (;;) {
 		ContigSet &S = p->C;
 		const size_t n = S.n();
@@ -449,7 +533,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		const size_t nj = jobs.size();
 		std::vector<uint64_t> jmoff(nj + 1, 0), jroff(nj + 1, 0);
 		for (size_t j = 0; j < nj; ++j) jmoff[j + 1] = jmoff[j] + S.msize(jobs[j].ci) + S.msize(jobs[j].cj);
-		std::vector<uint64_t> jm(jmoff[nj]);
+		PinVec<uint64_t> jm; jm.resize(jmoff[nj]);
 		std::vector<uint64_t> jlen(nj, 0);
 		parallel_for(nt, nj, [&](int, size_t jb, size_t je) {
 			for (size_t j = jb; j < je; ++j) {
@@ -473,7 +557,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		for (size_t j = 0; j < nj; ++j) jroff[j + 1] = jroff[j] + jlen[j];
 		lap("t_merge_members");
 		// construct_ref2 of every merged contig on the device (:327)
-		std::vector<char> jref(jroff[nj]);
+		PinVec<char> jref; jref.resize(jroff[nj]);
 		if (nj) {
 			std::vector<uint32_t> tjob, tidx;
 			for (size_t j = 0; j < nj; ++j) for (uint64_t t = 0; t * 512 < jlen[j]; ++t) { tjob.push_back((uint32_t)j); tidx.push_back((uint32_t)t); }
@@ -488,7 +572,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		}
 		lap("t_merge_cons");
 		// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
-		ContigSet N;
+		ContigSet &N = p->Cnext;
 		size_t nkeep = 0;
 		for (size_t i = 0; i < n; ++i) if (!flag[i]) ++nkeep;
 		const size_t nn = nj + nkeep;
@@ -506,7 +590,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				memcpy(N.ref.data() + N.roff[nj + u], S.ref.data() + S.roff[i], S.rsize(i));
 			}
 		});
-		p->C = std::move(N);
+		std::swap(p->C, p->Cnext);
 		lap("t_cb_copy");
 		p->stat["merge_rounds"] += 1;
 		const long tot = (long)p->C.n();
@@ -554,6 +638,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->h2d(p->d_woff.p, woff.data(), nc + 1, "upload window offsets")) || (rc = p->sync("upload"))) return rc;
 		p->stage2_uploaded = true;
 	}
+	p->stat["t_ra_setup"] += now_ms() - t0;
 	p->stat["passes"] += 1;
 	p->stat["windows"] += (double)p->n_windows;
 	const double tr0 = now_ms();
@@ -572,7 +657,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
 		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
-		std::vector<uint8_t> pf(n_sg);
+		PinVec<uint8_t> pf; pf.resize(n_sg);
 		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
 		mcom_dicts *dicts = nullptr;
 		if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;               // constructdictionary_realign
@@ -587,7 +672,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		}
 		rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
 		                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
-		std::vector<uint64_t> claim(n_sg);
+		PinVec<uint64_t> claim; claim.resize(n_sg);
 		if (!rc) rc = p->d2h(claim.data(), d_claim.p, n_sg, "copy claims");
 		if (!rc) rc = p->sync("realign pass");
 		mcom_dicts_free(p->ctx, dicts);
@@ -595,31 +680,39 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		p->stat["t_gpu"] += now_ms() - tg;
 		p->stat["t_ra_gpu"] += now_ms() - tg;
 		// append in the order of the sequential scan: claim key ascending, singleton index descending (:388)
-		std::vector<std::pair<uint64_t, uint32_t>> won;
-		for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) won.emplace_back(claim[i], (uint32_t)i);
-		std::sort(won.begin(), won.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
-			return a.first != b.first ? a.first < b.first : a.second > b.second; });
-		if (!won.empty()) {
-			std::vector<uint64_t> add(nc + 1, 0);
-			for (const auto &w : won) ++add[(size_t)(w.first >> 33) + 1];
+		const double tw0 = now_ms();
+		// counting sort of the claims by contig (the high bits of the key), then each contig orders its own few
+		std::vector<uint64_t> add(nc + 1, 0);
+		size_t nwon = 0;
+		for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) { ++add[(size_t)(claim[i] >> 33) + 1]; ++nwon; }
+		if (nwon) {
 			for (size_t c = 0; c < nc; ++c) add[c + 1] += add[c];                             // appended members before contig c
-			std::vector<uint64_t> nmem(C.mem.size() + won.size()), nmoff(nc + 1);
+			std::vector<std::pair<uint64_t, uint32_t>> won(nwon);
+			{
+				std::vector<uint64_t> fill(add.begin(), add.end() - 1);
+				for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) { won[fill[(size_t)(claim[i] >> 33)]++] = std::make_pair(claim[i], (uint32_t)i); p->sg_flag[i] = 1; }
+			}
+			PinVec<uint64_t> &nmem = p->Cnext.mem; std::vector<uint64_t> &nmoff = p->Cnext.moff;   // reuse the spare buffers of the merge stage
+			nmem.resize(C.mem.size() + nwon); nmoff.resize(nc + 1);
 			for (size_t c = 0; c <= nc; ++c) nmoff[c] = C.moff[c] + add[c];
 			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
 				for (size_t c = cb; c < ce; ++c) {
 					memcpy(nmem.data() + nmoff[c], C.mem.data() + C.moff[c], C.msize(c) * 8);
+					if (add[c + 1] == add[c]) continue;
+					std::sort(won.begin() + (long)add[c], won.begin() + (long)add[c + 1], [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
+						return a.first != b.first ? a.first < b.first : a.second > b.second; });
 					uint64_t *dst = nmem.data() + nmoff[c] + C.msize(c);
 					for (uint64_t u = add[c]; u < add[c + 1]; ++u) {
 						const uint64_t ck = won[u].first;
 						const uint64_t jj = (ck >> 5) & ((1ull << 28) - 1), dir = (ck >> 4) & 1;
 						*dst++ = (uint64_t)p->sg[won[u].second] << 32 | (jj << 1) | dir;        // :408-409, :474-475
 					}
-					if (add[c + 1] > add[c]) p->unsorted[c] = 1;
+					p->unsorted[c] = 1;
 				}
 			});
-			for (const auto &w : won) p->sg_flag[w.second] = 1;
 			C.mem.swap(nmem); C.moff.swap(nmoff);
 		}
+		p->stat["t_ra_append"] += now_ms() - tw0;
 	}
 	if (cluster_reads) *cluster_reads = (long)C.mem.size();
 	p->stat["t_realign"] += now_ms() - t0;
