@@ -35,9 +35,9 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 //             its first one, then runs the reference's statements for each of its entries -- once to count what
 //             it would emit, and after a wave prefix sum once more to write at the right offsets.
 // ------------------------------------------------------------------------------------------------
-#define PIECE 384
+#define PIECE 128
 #define PER_LANE (PIECE / 64)
-#define ERING 512                          // >= PIECE + MAXW, power of two
+#define ERING 256                          // >= PIECE + MAXW, power of two
 
 struct WinState { uint64_t bx; uint32_t bp; long bidx; };
 
