@@ -24,22 +24,23 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 // One wave (one 64-thread workgroup) per contig, the contig taken in pieces of PIECE bases.  The reference
 // scan keeps, besides the run counter, a ring of the last w entries and "the minimum": by construction that
 // minimum is always the NEWEST smallest entry of the ring (sketch.c:145-153), i.e. a pure function of the last
-// w entries.  So the scan can be restarted anywhere from those entries, and every lane does so for its own
-// few entries:
+// w entries.  What the scan emits when it stores entry t therefore depends only on entry t, on the newest
+// smallest entry of the windows ending at t-1 and at t, and (rarely) on equal hashes inside the window: every
+// entry can be handled by its own lane.
 //   phase 1   all lanes: roll the forward / reverse k-mers of PIECE/64 consecutive bases each (warmed up over
 //             the k-1 valid bases before them), hash, leave hash + flags per POSITION in LDS;
 //   phase 1b  ballots over the flags give, per position, the run counter (valid, non-palindromic bases since
 //             the last ambiguous base) and the ENTRY index (palindromic k-mers store no entry, sketch.c:133);
 //             every position writes its entry (hash or "empty", pos<<1|strand, run) into an LDS ring by entry index;
-//   phase 2   lane l takes entries [l*Q, (l+1)*Q) of the piece: rebuilds the minimum from the w entries before
-//             its first one, then runs the reference's statements for each of its entries -- once to count what
-//             it would emit, and after a wave prefix sum once more to write at the right offsets.
+//   phase 1c  a sparse table over the entries (log2 w levels) gives the newest smallest entry of any window,
+//             plus a flag "another entry of the window has the same hash";
+//   phase 2   one lane per entry: the reference's statements (sketch.c:138-161) with the window minimum looked
+//             up instead of scanned; counts, wave prefix sum, then the same once more to write.
 // ------------------------------------------------------------------------------------------------
 #define PIECE 128
 #define PER_LANE (PIECE / 64)
 #define ERING 256                          // >= PIECE + MAXW, power of two
-
-struct WinState { uint64_t bx; uint32_t bp; long bidx; };
+#define EMASK (ERING - 1)
 
 template <bool EMIT>
 __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	__shared__ uint32_t EP[ERING];          // pos<<1|strand, 0xFFFFFFFF when empty
 	__shared__ uint16_t ER[ERING];          // run counter after the entry (saturating)
 	__shared__ uint8_t SB[PIECE + 64];      // the piece's characters and the 64 before it, staged with coalesced loads
+	__shared__ uint8_t ST[8][ERING];        // sparse table, level j >= 1, entry e: bits 0-6 offset of the newest smallest
+	                                        // entry of [e, e+2^j), bit 7: another entry of that range has the same hash
 	const size_t t = blockIdx.x;
 	if (t >= n) return;
 	const int lane = threadIdx.x;
@@ -64,38 +67,51 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	long ent_in = 0;                        // entries stored before the current piece   (wave uniform)
 	uint32_t run_in = 0;                    // run counter before the current piece       (wave uniform)
 	uint32_t ne_base = 0;                   // minimizers emitted before the current piece (wave uniform)
+	int LG = 0; while ((2 << LG) <= w) ++LG;                            // floor(log2 w)
 
 	// entry e (may be negative = the ring's initial fill) as the scan sees it
-	auto EXat = [&](long e) -> uint64_t { return e < 0 ? U64MAX : EX[e & (ERING - 1)]; };
-	auto EPat = [&](long e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & (ERING - 1)]; };
-	// the minimum as the reference holds it just before entry t0 is stored (sketch.c:150-153 applied to the ring)
-	auto rebuild = [&](long t0) -> WinState {
-		WinState st; st.bx = U64MAX; st.bp = 0xFFFFFFFFu; st.bidx = -(long)w;
-		if (t0 == 0) return st;
-		for (long e = t0 - w; e < t0; ++e) { const uint64_t x = EXat(e); if (st.bx >= x) { st.bx = x; st.bp = EPat(e); st.bidx = e; } }
-		return st;
+	auto EXat = [&](long e) -> uint64_t { return e < 0 ? U64MAX : EX[e & EMASK]; };
+	auto EPat = [&](long e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & EMASK]; };
+	// newest smallest entry of [e, e+2^j) and its duplicate flag, from level j of the table
+	auto lvl = [&](int j, long e, bool &dup) -> long {
+		if (j == 0) { dup = false; return e; }
+		const uint8_t v = ST[j][e & EMASK]; dup = (v & 128) != 0; return e + (v & 127);
 	};
-	// one step of the scan (sketch.c:138-161) for entry te; emits through put(x, p)
-	auto step = [&](WinState &st, long te, auto &&put) {
-		const uint64_t cx = EX[te & (ERING - 1)]; const uint32_t cp = EP[te & (ERING - 1)];
-		const int run = ER[te & (ERING - 1)];
-		if (run == w + k - 1) {
-			for (long e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (st.bx == x && pp != st.bp) put(x, pp); }
-		}
-		if (cx <= st.bx) {
-			if (run >= w + k) put(st.bx, st.bp);
-			st.bx = cx; st.bp = cp; st.bidx = te;
-		} else if (st.bidx == te - w) {
-			if (run >= w + k - 1) put(st.bx, st.bp);
-			st.bx = U64MAX;
-			for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); if (st.bx >= x) { st.bx = x; st.bp = EPat(e); st.bidx = e; } }
-			if (run >= w + k - 1) {
-				for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (st.bx == x && st.bp != pp) put(x, pp); }
-			}
-		}
+	// newest smallest entry of the window of w entries ending at te (the reference's "min" after storing te)
+	auto wquery = [&](long te, bool &dup) -> long {
+		const long lo = te - w + 1, lo2 = te - (1L << LG) + 1;
+		bool da, db;
+		const long a = lvl(LG, lo, da), b = lvl(LG, lo2, db);
+		if (a == b) { dup = da || db; return a; }
+		const uint64_t xa = EXat(a), xb = EXat(b);
+		if (xa < xb) { dup = da; return a; }
+		dup = xa == xb ? true : db;
+		return b;                                                    // equal hashes: the newer one (b > a)
 	};
 	auto emit_at = [&](uint32_t idx, uint64_t x, uint32_t pp) {
 		if (EMIT && idx < limit) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); o[idx] = v; }
+	};
+	// what storing entry te makes the scan emit (sketch.c:138-161); put(x, p) in emission order
+	auto entry_emits = [&](long te, auto &&put) {
+		const uint64_t cx = EX[te & EMASK];
+		const int run = ER[te & EMASK];
+		long bidx = -(long)w; bool bdup = false;
+		if (te > 0) bidx = wquery(te - 1, bdup);
+		const uint64_t bx = EXat(bidx); const uint32_t bp = EPat(bidx);
+		if (run == w + k - 1 && bdup && bx != U64MAX) {               // first full window: older copies of the minimum
+			for (long e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (bx == x && pp != bp) put(x, pp); }
+		}
+		if (cx <= bx) {
+			if (run >= w + k) put(bx, bp);
+		} else if (bidx == te - w) {                                  // the minimum has just left the window
+			if (run >= w + k - 1) {
+				put(bx, bp);
+				bool ndup; const long nidx = wquery(te, ndup);
+				const uint64_t nx = EXat(nidx); const uint32_t np = EPat(nidx);
+				if (ndup && nx != U64MAX)
+					for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (nx == x && np != pp) put(x, pp); }
+			}
+		}
 	};
 
 	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE) {
@@ -148,9 +164,9 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			if (isn || inc) {
 				const long te = ent_run + (long)__popcll(entM & (lowm >> 1));
 				const bool real = inc && run >= (uint32_t)k;
-				EX[te & (ERING - 1)] = real ? PX[p - ps] : U64MAX;
-				EP[te & (ERING - 1)] = real ? (((uint32_t)p << 1) | (f & 1u)) : 0xFFFFFFFFu;
-				ER[te & (ERING - 1)] = (uint16_t)(run > 0xFFFFu ? 0xFFFFu : run);
+				EX[te & EMASK] = real ? PX[p - ps] : U64MAX;
+				EP[te & EMASK] = real ? (((uint32_t)p << 1) | (f & 1u)) : 0xFFFFFFFFu;
+				ER[te & EMASK] = (uint16_t)(run > 0xFFFFu ? 0xFFFFu : run);
 			}
 			// carry to the next group (uniform)
 			if (nM) { const int hb = 63 - __clzll((long long)nM); run_run = (uint32_t)__popcll(hb == 63 ? 0ull : (incM >> (hb + 1))); }
@@ -158,37 +174,47 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			ent_run += (long)__popcll(entM);
 		}
 		__syncthreads();
-		// ---- phase 2
-		const long E = ent_run - ent_in;
-		const long Q = (E + 63) / 64;
-		long t0 = ent_in + (long)lane * Q, t1 = t0 + Q;
-		if (t1 > ent_run) t1 = ent_run;
-		uint32_t mine = 0;
-		WinState st0; st0.bx = U64MAX; st0.bp = 0xFFFFFFFFu; st0.bidx = -(long)w;
-		if (t0 < t1) {
-			st0 = rebuild(t0);
-			WinState st = st0;
-			for (long te = t0; te < t1; ++te) step(st, te, [&](uint64_t, uint32_t) { ++mine; });
+		// ---- phase 1c: sparse table over entries [ent_in - w, ent_run)
+		{
+			const long lo = ent_in - w, hi = ent_run;
+			for (int j = 1; j <= LG; ++j) {
+				const long h = 1L << (j - 1);
+				for (long e = lo + lane; e + 2 * h <= hi; e += 64) {
+					bool da, db;
+					const long a = lvl(j - 1, e, da), b = lvl(j - 1, e + h, db);
+					const uint64_t xa = EXat(a), xb = EXat(b);
+					const long win = xa < xb ? a : b;                       // equal: b, the newer
+					const bool dup = xa == xb ? true : (xa < xb ? da : db);
+					ST[j][e & EMASK] = (uint8_t)((win - e) | (dup ? 128 : 0));
+				}
+				__syncthreads();
+			}
 		}
-		// wave exclusive prefix of the counts
-		uint32_t incl = mine;
+		// ---- phase 2: one lane per entry, 64 entries at a time, emission order = entry order
+		for (long t0 = ent_in; t0 < ent_run && ne_base < limit; t0 += 64) {
+			const long te = t0 + lane;
+			uint32_t mine = 0;
+			if (te < ent_run) entry_emits(te, [&](uint64_t, uint32_t) { ++mine; });
+			uint32_t incl = mine;
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-		const uint32_t total = __shfl(incl, 63, 64);
-		if (EMIT && t0 < t1 && mine) {
-			uint32_t idx = ne_base + incl - mine;
-			WinState st = st0;
-			for (long te = t0; te < t1; ++te) step(st, te, [&](uint64_t x, uint32_t pp) { emit_at(idx, x, pp); ++idx; });
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+			const uint32_t total = __shfl(incl, 63, 64);
+			if (EMIT && mine) {
+				uint32_t idx = ne_base + incl - mine;
+				entry_emits(te, [&](uint64_t x, uint32_t pp) { emit_at(idx, x, pp); ++idx; });
+			}
+			ne_base += total;
 		}
-		ne_base += total;
 		ent_in = ent_run; run_in = run_run;
 	}
 	__syncthreads();
 	if (lane == 0) {
 		// the minimum still held after the last entry is written out (sketch.c:163-164)
-		if (ne_base < limit) {
-			const WinState st = rebuild(ent_in);
-			if (st.bx != U64MAX) { emit_at(ne_base, st.bx, st.bp); ++ne_base; }
+		if (ne_base < limit && ent_in > 0) {
+			// the table of the last piece covers the window ending at the last entry
+			bool d; const long b = wquery(ent_in - 1, d);
+			const uint64_t bx = EXat(b);
+			if (bx != U64MAX) { emit_at(ne_base, bx, EPat(b)); ++ne_base; }
 		}
 		if (!EMIT) cnt[t] = ne_base < limit ? ne_base : limit;
 	}
