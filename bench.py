@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--force-exchange", action="store_true", help="run the N>1 bucket exchange path even with one rank (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -96,7 +97,10 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    exchange = world > 1 or a.force_exchange
+    if exchange:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     L, n_local = a.read_len, a.reads
@@ -116,7 +120,7 @@ def main():
         torch.cuda.synchronize()
 
     def step(timed):
-        if world == 1:
+        if not exchange:
             p = Pipeline(reads, L=L, device=local_rank, host_threads=threads)
         else:
             from minicom_amd.distributed import exchange_by_bucket
@@ -186,7 +190,7 @@ def main():
         elif not a.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -54,6 +54,14 @@ int mcomh_pre_process(mcomh_pipeline *p);
 /* runs everything and writes the state after every stage in the text format of oracle/refdump.cpp */
 int mcomh_dump_stages(mcomh_pipeline *p, const char *path);
 
+/* the pre-bsc stream files of cluster_dump at one thread (kthread_dump.c:364-678),
+ * single-end, not order-preserving: ref.bin.0 beg_pos.bin.0 dir.bin.0 dif_char.txt.0 info.txt single.seq
+ * single_N.seq AA.txt TT.txt NN.txt, written into the existing directory `folder`.  Call after mcomh_pre_process. */
+int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder);
+/* Inverse of those files (the reference's decompress for that mode, decompress.c:495-760): one read per line into
+ * out_path, order = all-A/T/N, near-constant reads, N reads, unclustered reads, contig reads.  No GPU needed. */
+int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads);
+
 /* results */
 size_t mcomh_n_contigs(const mcomh_pipeline *p);
 const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len);   /* consensus, NOT NUL-terminated */

@@ -1,0 +1,137 @@
+// minicom_amd/host/mcom_decompress.cpp -- inverse of the stream files written by mcomh_cluster_dump
+// (= the reference's cluster_dump at one thread, single-end, not order-preserving).
+//
+// Restates the reference decoder for that mode (decompress.c: decomp_AATTNN_nonorder :646, decomp_single_nonorder
+// :612, decompress_nonorder :495, helpers :40-100) so that losslessness (parity level P2) can be
+// proven on a machine where the reference does not exist.  Plain host code, no GPU.
+#include "../../include/mcom_host.h"
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+bool slurp(const std::string &path, std::vector<uint8_t> &out)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return false;
+	fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+	out.resize((size_t)n);
+	size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+	fclose(f);
+	return got == (size_t)n;
+}
+
+struct DnaReader {                      // getDNAcode (decompress.c:56-74): 4 bases per byte, low bits first
+	const std::vector<uint8_t> &b; size_t pos = 0; int k = 4; unsigned cur = 0;
+	explicit DnaReader(const std::vector<uint8_t> &b_) : b(b_) {}
+	int next() { if (k >= 4) { if (pos >= b.size()) return -1; cur = b[pos++]; k = 0; } int c = (int)(cur & 3); cur >>= 2; ++k; return c; }
+};
+struct BitReader {                      // getDir (decompress.c:40-54): 8 flags per byte, low bit first
+	const std::vector<uint8_t> &b; size_t pos = 0; int k = 8; unsigned cur = 0;
+	explicit BitReader(const std::vector<uint8_t> &b_) : b(b_) {}
+	int next() { if (k >= 8) { cur = pos < b.size() ? b[pos++] : 0; k = 0; } int c = (int)(cur & 1); cur >>= 1; ++k; return c; }
+};
+
+// text of a read against a reference string: letters are literal bases, digits a run of matching bases
+// (decompress.c:573-590); the missing tail matches
+void decode_line(const char *txt, size_t n, const char *ref, int L, std::string &seq)
+{
+	seq.clear();
+	int eq = 0;
+	for (size_t i = 0; i < n; ++i) {
+		const char ch = txt[i];
+		if (ch >= 'A' && ch <= 'Z') {
+			for (int j = 0; j < eq; ++j) seq.push_back(ref[seq.size()]);
+			eq = 0;
+			seq.push_back(ch);
+		} else eq = eq * 10 + (ch - '0');
+	}
+	while ((int)seq.size() < L) seq.push_back(ref[seq.size()]);
+}
+
+void revcomp(std::string &s)
+{
+	const size_t n = s.size();
+	for (size_t i = 0, j = n ? n - 1 : 0; i < j; ++i, --j) std::swap(s[i], s[j]);
+	for (char &c : s) c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
+}
+
+} // namespace
+
+extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads)
+{
+	if (!folder || !out_path) return -1;
+	const std::string dir(folder);
+	FILE *fi = fopen((dir + "/info.txt").c_str(), "r");
+	if (!fi) return -1;
+	int L = 0, nth = 0; long na = 0, nt = 0, nn = 0;
+	if (fscanf(fi, "%d %d %ld %ld %ld", &L, &nth, &na, &nt, &nn) != 5) { fclose(fi); return -1; }
+	fclose(fi);
+	if (L < 1 || L > 256 || nth < 1) return -1;
+	FILE *out = fopen(out_path, "w");
+	if (!out) return -1;
+	uint64_t total = 0;
+	auto line = [&](const std::string &s) { fwrite(s.data(), 1, s.size(), out); fputc('\n', out); ++total; };
+	// all-A / all-T / all-N reads are only counted (decompress.c:660-688)
+	for (long i = 0; i < na; ++i) line(std::string((size_t)L, 'A'));
+	for (long i = 0; i < nt; ++i) line(std::string((size_t)L, 'T'));
+	for (long i = 0; i < nn; ++i) line(std::string((size_t)L, 'N'));
+	// near-constant reads: text against a constant base (:690-760)
+	std::vector<uint8_t> buf;
+	std::string seq;
+	const char bases[3] = {'A', 'T', 'N'}; const char *names[3] = {"AA.txt", "TT.txt", "NN.txt"};
+	for (int q = 0; q < 3; ++q) {
+		if (!slurp(dir + "/" + names[q], buf)) { fclose(out); return -1; }
+		const std::string cref((size_t)L, bases[q]);
+		size_t s = 0;
+		for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); line(seq); s = i + 1; }
+	}
+	// reads kept as text because they contain N
+	if (!slurp(dir + "/single_N.seq", buf)) { fclose(out); return -1; }
+	{ size_t s = 0; for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { line(std::string((const char*)buf.data() + s, i - s)); s = i + 1; } }
+	// unclustered reads, 2 bits per base (:612-644); a trailing partial byte carries no complete read
+	if (!slurp(dir + "/single.seq", buf)) { fclose(out); return -1; }
+	{
+		DnaReader r(buf);
+		for (;;) {
+			seq.clear();
+			int c = 0;
+			for (int i = 0; i < L; ++i) { c = r.next(); if (c < 0) break; seq.push_back("ACGT"[c]); }
+			if (c < 0 || (int)seq.size() < L) break;
+			line(seq);
+		}
+	}
+	// contigs and their reads, one stream set per writer thread (:495-610)
+	for (int th = 0; th < nth; ++th) {
+		std::vector<uint8_t> bref, bpos, bdir, bdif;
+		const std::string sfx = "." + std::to_string(th);
+		if (!slurp(dir + "/ref.bin" + sfx, bref) || !slurp(dir + "/beg_pos.bin" + sfx, bpos) || !slurp(dir + "/dir.bin" + sfx, bdir) ||
+		    !slurp(dir + "/dif_char.txt" + sfx, bdif)) { fclose(out); return -1; }
+		DnaReader rr(bref); BitReader dr(bdir);
+		size_t pp = 0, dp = 0;
+		std::string ref;
+		while (pp + 4 <= bpos.size()) {
+			uint32_t num; memcpy(&num, bpos.data() + pp, 4); pp += 4;
+			ref.clear();
+			int pre = 0;
+			for (uint32_t q = 0; q < num; ++q) {
+				if (pp + 2 > bpos.size()) { fclose(out); return -1; }
+				uint16_t d; memcpy(&d, bpos.data() + pp, 2); pp += 2;
+				const int pos = pre + d; pre = pos;
+				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) { fclose(out); return -1; } ref.push_back("ACGT"[c]); }   // getRef (:92-100)
+				const int rev = dr.next();
+				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
+				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				dp = e + 1;
+				if (rev) revcomp(seq);
+				line(seq);
+			}
+		}
+	}
+	fclose(out);
+	if (n_reads) *n_reads = total;
+	return 0;
+}

@@ -890,3 +890,115 @@ extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 	auto it = p->stat.find(name);
 	return it == p->stat.end() ? 0.0 : it->second;
 }
+
+// ----------------------------------------------------------------------------------------------------
+// cluster_dump at one thread: the pre-bsc stream files      kthread_dump.c:364-678
+//   ref.bin.0 beg_pos.bin.0 dir.bin.0 dif_char.txt.0 (print_encode, :142-236) info.txt single.seq single_N.seq
+//   AA.txt TT.txt NN.txt.  Single-end, not order-preserving.  Host serialisation, outside the timed region.
+// ----------------------------------------------------------------------------------------------------
+namespace {
+struct BitWriter {                          // DNA_push / bit_push (breads.h:232-248)
+	FILE *f; unsigned acc = 0; int n = 0; int per;
+	BitWriter(FILE *f_, int bits) : f(f_), per(bits) {}
+	void push(unsigned x) { acc += x << (per * n); if (++n == 8 / per) { fputc((int)acc, f); acc = 0; n = 0; } }
+	void flush() { if (n > 0) fputc((int)acc, f); acc = 0; n = 0; }
+};
+// run-length text against a constant base (:579-596)
+std::string const_base_text(const char *s, int L, char base)
+{
+	std::string out; int eq = 0;
+	for (int t = 0; t < L; ++t) {
+		if (s[t] != base) { if (eq > 0) { out += std::to_string(eq); eq = 0; } out.push_back(s[t]); }
+		else ++eq;
+	}
+	if (out.empty()) out = "0";
+	return out;
+}
+}
+
+extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
+{
+	if (!p || !folder) return MCOM_E_ARG;
+	const int L = p->L, W = p->W, NW = p->NW;
+	const size_t n = p->n;
+	int rc;
+	std::vector<uint64_t> packed(n * (size_t)W), nmask(n * (size_t)NW);
+	if (n && ((rc = p->hipc(hipMemcpy(packed.data(), p->d_packed.p, n * (size_t)W * 8, hipMemcpyDeviceToHost), "copy packed reads")) ||
+	          (rc = p->hipc(hipMemcpy(nmask.data(), p->d_nmask.p, n * (size_t)NW * 8, hipMemcpyDeviceToHost), "copy N masks")))) return rc;
+	auto has_n = [&](uint32_t rid) { for (int q = 0; q < NW; ++q) if (nmask[(size_t)rid * NW + q]) return true; return false; };
+	// the read as stored by the reference with its N put back (:178-186)
+	auto read_str = [&](uint32_t rid, char *out) {
+		for (int i = 0; i < L; ++i) {
+			const bool isn = (nmask[(size_t)rid * NW + (i >> 6)] >> (i & 63)) & 1;
+			out[i] = isn ? 'N' : ACGT[(packed[(size_t)rid * W + (i >> 5)] >> (2 * (i & 31))) & 3];
+		}
+		out[L] = 0;
+	};
+	auto open = [&](const char *name, const char *mode) { std::string path = std::string(folder) + "/" + name; return fopen(path.c_str(), mode); };
+	FILE *fref = open("ref.bin.0", "wb"), *fpos = open("beg_pos.bin.0", "wb"), *fdir = open("dir.bin.0", "wb"), *fdif = open("dif_char.txt.0", "w");
+	if (!fref || !fpos || !fdir || !fdif) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	BitWriter refbin(fref, 2), dirbin(fdir, 1);
+	ContigSet &C = p->C;
+	std::vector<char> t((size_t)L + 1), en;
+	static const char RCT[256] = {0};
+	for (size_t c = 0; c < C.n(); ++c) {
+		std::stable_sort(C.mem.data() + C.moff[c], C.mem.data() + C.moff[c + 1], less_cluster2);     // :143
+		const char *ref = C.ref.data() + C.roff[c];
+		for (size_t i = 0; i < C.rsize(c); ++i) refbin.push(ref[i] == 'A' ? 0u : ref[i] == 'C' ? 1u : ref[i] == 'G' ? 2u : 3u);   // :158-160
+		const uint32_t num = (uint32_t)C.msize(c);
+		fwrite(&num, 4, 1, fpos);
+		int pre_pos = 0;
+		for (uint64_t q = C.moff[c]; q < C.moff[c + 1]; ++q) {
+			const uint64_t y = C.mem[q];
+			const uint32_t rid = (uint32_t)(y >> 32); const int pos = (int)((uint32_t)y >> 1), dir = (int)(y & 1);
+			read_str(rid, t.data());
+			if (dir) {                                                         // reverse_complement, N stays N (preprocess.c:22-37)
+				for (int i = 0, j = L - 1; i < j; ++i, --j) std::swap(t[i], t[j]);
+				for (int i = 0; i < L; ++i) t[i] = t[i] == 'A' ? 'T' : t[i] == 'T' ? 'A' : t[i] == 'C' ? 'G' : t[i] == 'G' ? 'C' : 'N';
+			}
+			en.clear();
+			int eq = 0;
+			for (int tj = 0; tj < L; ++tj) {                                   // :200-216
+				if (ref[pos + tj] != t[tj]) {
+					if (eq > 1) { const std::string d = std::to_string(eq); en.insert(en.end(), d.begin(), d.end()); }
+					else for (int i = tj - eq; i < tj; ++i) en.push_back(t[i]);
+					eq = 0;
+					en.push_back(t[tj]);
+				} else ++eq;
+			}
+			if (en.empty()) en.push_back('0');
+			fwrite(en.data(), 1, en.size(), fdif); fputc('\n', fdif);
+			const uint16_t posbin = (uint16_t)(pos - pre_pos);
+			fwrite(&posbin, 2, 1, fpos);
+			dirbin.push((unsigned)dir);
+			pre_pos = pos;
+		}
+	}
+	(void)RCT;
+	dirbin.flush(); refbin.flush();                                               // :303-309
+	fclose(fref); fclose(fpos); fclose(fdir); fclose(fdif);
+	FILE *finfo = open("info.txt", "w");
+	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
+	fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	fclose(finfo);
+	// singletons: those with N join the N file, the others are packed 4 per byte (:390-417, :545-548)
+	FILE *fsingle = open("single.seq", "wb");
+	if (!fsingle) return p->fail(MCOM_E_ARG, "cannot write single.seq");
+	BitWriter sb(fsingle, 2);
+	std::vector<uint32_t> nfile = p->Nfile;
+	for (size_t i = 0; i < p->sg.size(); ++i) {
+		if (p->sg_flag[i]) continue;
+		const uint32_t rid = p->sg[i];
+		if (has_n(rid)) nfile.push_back(rid);
+		else for (int j = 0; j < L; ++j) sb.push((unsigned)((packed[(size_t)rid * W + (j >> 5)] >> (2 * (j & 31))) & 3));
+	}
+	sb.flush(); fclose(fsingle);
+	FILE *fa = open("AA.txt", "w"), *ft = open("TT.txt", "w"), *fn = open("NN.txt", "w"), *fnf = open("single_N.seq", "w");
+	if (!fa || !ft || !fn || !fnf) return p->fail(MCOM_E_ARG, "cannot write text streams");
+	for (uint32_t rid : p->fpA) { read_str(rid, t.data()); fprintf(fa, "%s\n", const_base_text(t.data(), L, 'A').c_str()); }   // :566-597
+	for (uint32_t rid : p->fpT) { read_str(rid, t.data()); fprintf(ft, "%s\n", const_base_text(t.data(), L, 'T').c_str()); }   // :599-627
+	for (uint32_t rid : p->fpN) { read_str(rid, t.data()); fprintf(fn, "%s\n", const_base_text(t.data(), L, 'N').c_str()); }   // :629-657
+	for (uint32_t rid : nfile) { read_str(rid, t.data()); fprintf(fnf, "%s\n", t.data()); }                                     // :659-671
+	fclose(fa); fclose(ft); fclose(fn); fclose(fnf);
+	return MCOM_OK;
+}

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Stream-file fixtures (parity level P1): runs the compiled reference itself (oracle/_ref/*/minicom_bin,
+one thread) on the fixture reads and stores the pre-bsc stream files it writes as tests/golden/streams_<tag>.tar.gz.
+
+Build-container only (needs oracle/_ref).    python tests/golden/make_streams.py
+"""
+import gzip
+import io
+import os
+import subprocess
+import sys
+import tarfile
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from minicom_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def make(tag, variant):
+    with gzip.open(os.path.join(HERE, tag + ".reads.gz"), "rb") as f:
+        rows = f.read().split(b"\n")[:-1]
+    reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0]))
+    with tempfile.TemporaryDirectory() as td:
+        fq = os.path.join(td, "in.fastq")
+        synth.write_fastq(fq, reads)
+        out = os.path.join(td, "out"); os.makedirs(out)
+        cwd = os.path.join(td, "cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
+        subprocess.run([os.path.join(REF, variant, "minicom_bin"), fq, out], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+        buf = io.BytesIO()
+        with tarfile.open(fileobj=buf, mode="w") as tf:
+            for name in sorted(os.listdir(out)):
+                ti = tarfile.TarInfo(name); data = open(os.path.join(out, name), "rb").read()
+                ti.size = len(data); ti.mtime = 0
+                tf.addfile(ti, io.BytesIO(data))
+        with gzip.GzipFile(os.path.join(HERE, "streams_" + tag + ".tar.gz"), "wb", mtime=0) as g:
+            g.write(buf.getvalue())
+        print(tag, {n: os.path.getsize(os.path.join(out, n)) for n in sorted(os.listdir(out))})
+
+
+if __name__ == "__main__":
+    make("stages_L100", "L100")
+    make("stages_L150", "L150")

@@ -1,0 +1,76 @@
+"""Stream files: P1 = the files our driver writes are byte-identical to the ones the
+compiled reference wrote at one thread (tests/golden/streams_*.tar.gz); P2 = decoding them gives the input reads back."""
+import gzip
+import io
+import os
+import tarfile
+
+import numpy as np
+import pytest
+
+
+def _golden_reads(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, tag + ".reads.gz"), "rb") as f:
+        return f.read().split(b"\n")[:-1]
+
+
+def _golden_streams(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, "streams_" + tag + ".tar.gz"), "rb") as g:
+        tf = tarfile.open(fileobj=io.BytesIO(g.read()))
+        return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
+
+
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_our_decoder_inverts_the_reference_streams(golden_dir, tmp_path, tag):
+    """CPU: the decoder (minicom_amd/host/mcom_decompress.cpp) applied to streams written by the reference itself."""
+    from minicom_amd.pipeline import decompress
+    d = tmp_path / "streams"; d.mkdir()
+    for name, data in _golden_streams(golden_dir, tag).items():
+        (d / name).write_bytes(data)
+    out = tmp_path / "reads.txt"
+    n = decompress(str(d), str(out))
+    want = _golden_reads(golden_dir, tag)
+    got = out.read_bytes().split(b"\n")[:-1]
+    assert n == len(want) == len(got)
+    assert sorted(got) == sorted(want)                      # default mode keeps the multiset, not the order (README.md:33-37)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_stream_files_byte_identical_to_reference_and_lossless(golden_dir, tmp_path, tag):
+    from minicom_amd.pipeline import Pipeline, decompress
+    rows = _golden_reads(golden_dir, tag)
+    reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+    p = Pipeline(reads, host_threads=4)
+    p.pre_process()
+    d = tmp_path / "streams"; d.mkdir()
+    p.cluster_dump(str(d))
+    p.close()
+    want = _golden_streams(golden_dir, tag)
+    assert sorted(os.listdir(d)) == sorted(want)
+    for name, data in want.items():
+        assert (d / name).read_bytes() == data, name                       # P1
+    out = tmp_path / "reads.txt"
+    assert decompress(str(d), str(out)) == len(rows)
+    assert sorted(out.read_bytes().split(b"\n")[:-1]) == sorted(rows)      # P2
+
+
+@pytest.mark.gpu
+def test_round_trip_at_a_size_no_fixture_covers():
+    """P2 on 300 k device-generated reads with the plumbing extras mixed in on the host."""
+    import tempfile
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress
+    reads = synth.synth_reads(2024, 300000, 100)
+    extra = synth.synth_reads(2025, 20000, 100, plumbing=True)
+    reads = np.concatenate([reads, extra])
+    p = Pipeline(reads, host_threads=16)
+    p.pre_process()
+    with tempfile.TemporaryDirectory() as td:
+        p.cluster_dump(td)
+        out = os.path.join(td, "reads.txt")
+        assert decompress(td, out) == reads.shape[0]
+        got = np.frombuffer(open(out, "rb").read(), dtype=np.uint8).reshape(reads.shape[0], 101)[:, :100]
+        a = np.sort(got.view("S100").ravel()); b = np.sort(np.ascontiguousarray(reads).view("S100").ravel())
+        assert np.array_equal(a, b)
+    p.close()
