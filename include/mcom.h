@@ -118,12 +118,18 @@ int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
                       uint64_t total_words, uint64_t *d_cbits);
 
 /* mm_idx_init + mm_idx_generation (kthread_idx.c:77, :116-170): index over n minimizer records sketched
- * with k.  Equal minimizers keep the order they were given in (the reference's bucket sort does too for
- * buckets of <= 64 entries; above that its in-place radix sort permutes equal keys, ksort.h:132-144).
+ * with k, given in the order the reference pushes them (contig order, minimizer order).
+ *   b > 0: the reference's layout and ORDER: 2^b buckets by x & (2^b-1), each sorted by radix_sort_128x with
+ *          its exact element order (stable up to 64 entries per bucket, a cycle-leader permutation of equal
+ *          keys above, ksort.h:132-144) -- what find_next iterates over (kthread_idx.c:154-155).
+ *   b = 0: one stable sort by x (equal minimizers keep the order they were given in).
  * mcom_idx_get = mm_idx_get (:84-101) for n minimizers: start/count into the index's sorted record array
  * (count 0 = absent), which mcom_idx_records copies out.                                              */
 typedef struct mcom_idx mcom_idx;
-int  mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, mcom_idx **out);
+int  mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out);
+/* radix_sort_128x with the reference's exact element order (sequential emulation, see mcom_radix_sort_128x
+ * for the fast stable sort).                                                                          */
+int  mcom_radix_sort_128x_ref_order(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
 void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi);
 int  mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d_x, size_t n, uint32_t *d_start, uint32_t *d_count);
 int  mcom_idx_records(mcom_ctx *ctx, const mcom_idx *mi, mcom_mm128 *d_out, size_t *n);

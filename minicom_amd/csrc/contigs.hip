@@ -8,6 +8,8 @@
 //   mcom_find_next_candidates: the lookup part of find_next (kthread_cb.c:267-291) for every contig
 #include "mcom_dev.hpp"
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 #define MAXW 128
 
@@ -312,11 +314,15 @@ extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 	delete mi;
 }
 
-extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, mcom_idx **out)
+int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bstart, uint32_t nr, uint32_t max_range, uint32_t *d_overflow);
+int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bits, uint32_t *d_bstart);
+
+extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out)
 {
 	if (!ctx || !out) return MCOM_E_ARG;
 	*out = nullptr;
 	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range", k);
+	if (b < 0 || b > 20 || b > 2 * k) return mcom_fail(ctx, MCOM_E_ARG, "bucket bits %d out of range", b);
 	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many records");
 	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	mcom_idx *mi = new mcom_idx();
@@ -326,14 +332,38 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 	const size_t sort_b = mcom_sort_ws_bytes(n);
 	const size_t head_b = ((n * 4) + 255) & ~(size_t)255;
 	const size_t scr_b = ((mcom_scan_scratch_elems(n) * 4 + 1024) + 255) & ~(size_t)255;
-	int rc = mcom_ws_reserve(ctx, sort_b + head_b + scr_b + 256);
+	const size_t bst_b = ((((size_t)1 << b) + 2) * 4 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, sort_b + head_b + scr_b + 256 + bst_b);
 	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 	char *base = (char*)ctx->ws;
 	if (n) {
 		hipError_t e1 = hipMemcpyAsync(mi->rec, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream);
 		if (e1 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e1)); }
-		rc = mcom_sort_by_x(ctx, mi->rec, n, 2 * k, base);
-		if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+		if (b == 0) {
+			rc = mcom_sort_by_x(ctx, mi->rec, n, 2 * k, base);                 // stable: equal minimizers keep their input order
+			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+		} else {
+			// the reference's order: records go to bucket x & (2^b-1) in input order (kthread_bucket.c:468-473), every bucket
+			// is then sorted by radix_sort_128x (kthread_idx.c:126), whose order of equal keys is reproduced exactly
+			uint32_t *bst = (uint32_t*)(base + sort_b + head_b + scr_b + 256);
+			const uint32_t nb = 1u << b;
+			rc = mcom_sort_by_low_bits(ctx, mi->rec, n, b, base);
+			if (!rc) rc = mcom_bucket_starts(ctx, mi->rec, n, b, bst);
+			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+			std::vector<uint32_t> hb(nb + 1);
+			hipError_t e2 = hipMemcpyAsync(hb.data(), bst, (nb + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
+			if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+			if (e2 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "bucket bounds: %s", hipGetErrorString(e2)); }
+			uint32_t mx = 0;
+			for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
+			uint32_t *ovf = (uint32_t*)(base + sort_b + head_b + scr_b);           // the 256-byte meta area, reused below
+			(void)hipMemsetAsync(ovf, 0, 4, ctx->stream);
+			rc = mcom_flag_sort_ranges(ctx, mi->rec, bst, nb, mx, ovf);
+			uint32_t ov = 0;
+			if (!rc) { e2 = hipMemcpyAsync(&ov, ovf, 4, hipMemcpyDeviceToHost, ctx->stream); if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "index sort: %s", hipGetErrorString(e2)); }
+			if (!rc && ov) rc = mcom_fail(ctx, MCOM_E_OVERFLOW, "index bucket sort ran out of range stack");
+			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
+		}
 	}
 	rc = mcom_table_build(ctx, mi->rec, n, (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
 	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }

@@ -1,0 +1,140 @@
+// minicom_amd/csrc/flagsort.hip -- the reference's radix_sort_128x with its exact, UNSTABLE element order.
+//
+// radix_sort_128x (reference ksort.h:108-157, misc.c:22) is an in-place American-flag MSD radix sort on .x, 8 bits
+// a level, that finishes ranges of <= 64 elements by insertion sort.  Above 64 elements the cycle-leader
+// permutation reorders equal keys, and mm_idx (kthread_idx.c:126, :154-155) hands equal minimizers to find_next in
+// exactly that order.  To reproduce the order the algorithm is run as written, by ONE lane per range: the ranges
+// are the 2^b index buckets (thousands of them run side by side, one wave each), small enough to be sorted inside
+// LDS; a range that does not fit is sorted in HBM by the same code.
+#include "mcom_dev.hpp"
+
+#define FS_STACK 1024
+
+struct FsRange { uint32_t b, e, shift; };
+
+// the algorithm on an array `a` (LDS or global); bb/be: 256-entry scratch, stk: pending big ranges
+template <class PTR>
+__device__ void flag_sort_range(PTR a, uint32_t n, uint32_t *bb, uint32_t *be, FsRange *stk, uint32_t *overflow)
+{
+	auto insertion = [&](uint32_t beg, uint32_t end) {                       // rs_insertsort (ksort.h:112-122)
+		for (uint32_t i = beg + 1; i < end; ++i) {
+			if (a[i].x < a[i - 1].x) {
+				const mcom_mm128 t = a[i]; uint32_t j = i;
+				while (j > beg && t.x < a[j - 1].x) { a[j] = a[j - 1]; --j; }
+				a[j] = t;
+			}
+		}
+	};
+	if (n <= 64) { insertion(0, n); return; }                                // radix_sort (ksort.h:153-157)
+	uint32_t sp = 0;
+	stk[sp++] = FsRange{0, n, 56};
+	while (sp) {
+		const FsRange r = stk[--sp];
+		const uint32_t beg = r.b, end = r.e, s = r.shift;
+		// rs_sort (ksort.h:123-152)
+		for (int q = 0; q < 256; ++q) { bb[q] = beg; be[q] = beg; }
+		for (uint32_t i = beg; i != end; ++i) ++be[(a[i].x >> s) & 255];
+		for (int q = 1; q < 256; ++q) { be[q] += be[q - 1] - beg; bb[q] = be[q - 1]; }
+		for (int q = 0; q < 256;) {
+			if (bb[q] != be[q]) {
+				int l = (int)((a[bb[q]].x >> s) & 255);
+				if (l != q) {
+					mcom_mm128 hold = a[bb[q]], moved;
+					do {
+						moved = hold; hold = a[bb[l]]; a[bb[l]++] = moved;
+						l = (int)((hold.x >> s) & 255);
+					} while (l != q);
+					a[bb[q]++] = hold;
+				} else ++bb[q];
+			} else ++q;
+		}
+		bb[0] = beg;
+		for (int q = 1; q < 256; ++q) bb[q] = be[q - 1];
+		if (s) {
+			const uint32_t nxt = s > 8 ? s - 8 : 0;
+			for (int q = 0; q < 256; ++q) {
+				const uint32_t cnt = be[q] - bb[q];
+				if (cnt > 64) { if (sp < FS_STACK) stk[sp++] = FsRange{bb[q], be[q], nxt}; else *overflow = 1; }
+				else if (cnt > 1) insertion(bb[q], be[q]);
+			}
+		}
+	}
+}
+
+// one 64-lane workgroup per range [bstart[r], bstart[r+1]); lanes stage the range into LDS and back, lane 0 sorts
+__global__ __launch_bounds__(64) void k_flag_sort(mcom_mm128 *__restrict__ rec, const uint32_t *__restrict__ bstart, uint32_t nr,
+                                                  uint32_t lds_cap, uint32_t *__restrict__ overflow)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	uint32_t *bb = (uint32_t*)smem, *be = bb + 256;
+	FsRange *stk = (FsRange*)(be + 256);
+	mcom_mm128 *buf = (mcom_mm128*)(stk + FS_STACK);
+	const uint32_t r = blockIdx.x;
+	if (r >= nr) return;
+	const uint32_t beg = bstart[r], end = bstart[r + 1], n = end - beg;
+	if (n < 2) return;
+	if (n <= lds_cap) {
+		for (uint32_t i = threadIdx.x; i < n; i += 64) buf[i] = rec[beg + i];
+		__syncthreads();
+		if (threadIdx.x == 0) flag_sort_range(buf, n, bb, be, stk, overflow);
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < n; i += 64) rec[beg + i] = buf[i];
+	} else if (threadIdx.x == 0) {
+		flag_sort_range(rec + beg, n, bb, be, stk, overflow);
+	}
+}
+
+// starts of the runs of equal (x & mask) in an array sorted by that value: bstart[v] = first index with value >= v
+__global__ void k_bucket_starts(const mcom_mm128 *__restrict__ rec, size_t n, uint64_t mask, uint32_t nb, uint32_t *__restrict__ bstart)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	const uint64_t cur = i < n ? (rec[i].x & mask) : (uint64_t)nb;
+	const uint64_t prev = i > 0 ? (rec[i - 1].x & mask) + 1 : 0;
+	for (uint64_t v = prev; v <= cur && v <= nb; ++v) bstart[v] = (uint32_t)i;   // also fills the empty values in between
+}
+
+// sorts every range of d_rec given by d_bstart[0..nr] into the reference's order
+int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bstart, uint32_t nr, uint32_t max_range, uint32_t *d_overflow)
+{
+	if (nr == 0) return MCOM_OK;
+	const size_t fixed = 2 * 256 * 4 + FS_STACK * sizeof(FsRange);
+	size_t cap = max_range;
+	const size_t lds_max = 150 * 1024;
+	if (fixed + cap * sizeof(mcom_mm128) > lds_max) cap = (lds_max - fixed) / sizeof(mcom_mm128);
+	const size_t lds = fixed + cap * sizeof(mcom_mm128);
+	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(k_flag_sort, dim3(nr), dim3(64), lds, ctx->stream, d_rec, d_bstart, nr, (uint32_t)cap, d_overflow);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bits, uint32_t *d_bstart)
+{
+	const uint32_t nb = 1u << bits;
+	hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n, (uint64_t)nb - 1, nb, d_bstart);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// a5, exact: radix_sort_128x with the reference's element order (one range = the whole array).  Sequential by
+// nature: meant for index buckets and tests, not for bulk sorting (mcom_radix_sort_128x is the fast, stable one).
+extern "C" int mcom_radix_sort_128x_ref_order(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n < 2) return MCOM_OK;
+	if (!d_a) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many records");
+	int rc = mcom_ws_reserve(ctx, 64);
+	if (rc) return rc;
+	uint32_t *d = (uint32_t*)ctx->ws;
+	const uint32_t h[3] = {0, (uint32_t)n, 0};
+	MCOM_HIP(ctx, hipMemcpyAsync(d, h, 12, hipMemcpyHostToDevice, ctx->stream));
+	rc = mcom_flag_sort_ranges(ctx, d_a, d, 1, (uint32_t)n, d + 2);
+	if (rc) return rc;
+	uint32_t ov = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&ov, d + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ov) return mcom_fail(ctx, MCOM_E_OVERFLOW, "radix sort emulation ran out of range stack");
+	return MCOM_OK;
+}

@@ -48,6 +48,7 @@ int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, ui
 size_t mcom_scan_scratch_elems(size_t n);
 size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
+int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 
 #define MCOM_HIP(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) \
 	return mcom_fail(ctx, MCOM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)

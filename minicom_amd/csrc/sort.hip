@@ -27,6 +27,7 @@ struct KeySpec {
 __device__ __forceinline__ void make_key(const KeySpec &ks, uint64_t x, uint64_t y, uint64_t &lo, uint32_t &hi)
 {
 	if (ks.mode == 0) { lo = x; hi = 0; return; }
+	if (ks.mode == 2) { lo = x & ((1ull << ks.kbits) - 1); hi = 0; return; }   // only the low kbits of x (bucket id)
 	if (x == U64MAX) { lo = U64MAX; hi = 0xFFFFFFFFu; return; }           // records without a minimizer sort last
 	const uint64_t bucket = x & ((1ull << ks.b) - 1);
 	const uint64_t K = (bucket << (ks.kbits - ks.b)) | (x >> ks.b);
@@ -240,6 +241,19 @@ int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws)
 	if (n == 0) return MCOM_OK;
 	SortWs w; sort_ws_layout(n, &w, (char*)ws);
 	KeySpec ks{0, 0, 64, 0, 0};
+	mcom_mm128 *res = nullptr;
+	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
+	if (rc) return rc;
+	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
+// internal: stable sort by x & (2^bits - 1) only (records of one bucket keep their input order)
+int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws)
+{
+	if (n == 0) return MCOM_OK;
+	SortWs w; sort_ws_layout(n, &w, (char*)ws);
+	KeySpec ks{2, 0, bits, 0, 0};
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;

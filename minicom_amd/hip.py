@@ -67,7 +67,8 @@ def load_library():
     L.mcom_sketch_contigs.restype = i32
     L.mcom_sketch_contigs.argtypes = [vp, vp, vp, vp, sz, i32, i32, u32, vp, vp, sz, C.POINTER(u64)]
     L.mcom_pack_contigs.restype = i32; L.mcom_pack_contigs.argtypes = [vp, vp, vp, vp, u32, u64, vp]
-    L.mcom_idx_build.restype = i32; L.mcom_idx_build.argtypes = [vp, vp, sz, i32, C.POINTER(vp)]
+    L.mcom_idx_build.restype = i32; L.mcom_idx_build.argtypes = [vp, vp, sz, i32, i32, C.POINTER(vp)]
+    L.mcom_radix_sort_128x_ref_order.restype = i32; L.mcom_radix_sort_128x_ref_order.argtypes = [vp, vp, sz]
     L.mcom_idx_destroy.restype = None; L.mcom_idx_destroy.argtypes = [vp, vp]
     L.mcom_idx_get.restype = i32; L.mcom_idx_get.argtypes = [vp, vp, vp, sz, vp, vp]
     L.mcom_idx_records.restype = i32; L.mcom_idx_records.argtypes = [vp, vp, vp, C.POINTER(sz)]
@@ -227,8 +228,15 @@ class Context:
             self._check(rc)
             return moff, out[: int(total.value)]
 
-    def idx_build(self, rec, k: int):
-        return Index(self, rec, k)
+    def idx_build(self, rec, k: int, b: int = 14):
+        """mcom_idx_build: b > 0 reproduces the reference's bucket order, b = 0 is one stable sort by x."""
+        return Index(self, rec, k, b)
+
+    def radix_sort_128x_ref_order(self, rec):
+        """mcom_radix_sort_128x_ref_order: in place, the reference's exact (unstable) element order."""
+        torch = _torch()
+        self._check(self.lib.mcom_radix_sort_128x_ref_order(self._h, self._p(rec, torch.int64), int(rec.shape[0])))
+        return rec
 
     def match_pro(self, cg, a, pa, b, pb):
         torch = _torch()
@@ -295,11 +303,11 @@ class Context:
 class Index:
     """Device-resident contig-minimizer index (mcom_idx)."""
 
-    def __init__(self, ctx: Context, rec, k: int):
+    def __init__(self, ctx: Context, rec, k: int, b: int = 14):
         self.ctx = ctx
         self.n = int(rec.shape[0])
         h = C.c_void_p()
-        ctx._check(ctx.lib.mcom_idx_build(ctx._h, ctx._p(rec), self.n, k, C.byref(h)))
+        ctx._check(ctx.lib.mcom_idx_build(ctx._h, ctx._p(rec), self.n, k, b, C.byref(h)))
         self._h = h
 
     def get(self, x):

@@ -489,7 +489,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, moff_all.p, rec_all.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
 			lap("t_cb_sketch");
 			mcom_idx *mi = nullptr;
-			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, &mi)))) return rc;                    // mm_idx_generation (:580)
+			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;           // mm_idx_generation (:580)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
 			size_t cap = std::max<size_t>(1024, ta);

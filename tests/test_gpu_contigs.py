@@ -97,7 +97,7 @@ def test_idx_build_and_get(ctx):
     rec["x"] = keys[rng.integers(0, len(keys), n)]
     rec["y"] = np.arange(n, dtype=np.uint64) << np.uint64(32) | rng.integers(0, 400, n).astype(np.uint64)
     t = torch.from_numpy(np.stack([rec["x"], rec["y"]], axis=1).view(np.int64)).cuda()
-    idx = ctx.idx_build(t, 31)
+    idx = ctx.idx_build(t, 31, b=0)
     srt = _recs(idx.records())
     order = np.argsort(rec["x"], kind="stable")
     assert np.array_equal(srt["x"], rec["x"][order]) and np.array_equal(srt["y"], rec["y"][order])
@@ -113,7 +113,7 @@ def test_idx_build_and_get(ctx):
         else:
             assert c[q] == hi - lo and (hi == lo or s[q] == lo)
     idx.close()
-    e = ctx.idx_build(ctx.empty_records(0), 31)
+    e = ctx.idx_build(ctx.empty_records(0), 31, b=14)
     s, c = e.get(torch.zeros(3, dtype=torch.int64, device="cuda"))
     assert c.sum().item() == 0
     e.close()
@@ -159,4 +159,43 @@ def test_find_next_candidates_on_reference_fixture_contigs(ctx, golden_dir, tag)
     assert n_tested == tested
     assert list(zip(got["x"].tolist(), got["y"].tolist())) == want
     assert len(want) > 10
+    idx.close()
+
+
+def test_radix_sort_ref_order_reproduces_the_reference_permutation(ctx, kat):
+    """Every golden radix_sort_128x vector, including the sizes where the reference sort is unstable."""
+    import torch
+    for t in kat["RS"]:
+        a = np.array([tuple(p) for p in t["in"]], dtype=[("x", "<u8"), ("y", "<u8")])
+        d = torch.from_numpy(np.stack([a["x"], a["y"]], axis=1).view(np.int64)).cuda()
+        got = _recs(ctx.radix_sort_128x_ref_order(d))
+        assert [[int(p["x"]), int(p["y"])] for p in got] == t["out"]
+
+
+@pytest.mark.parametrize("n,nkeys,nbuckets", [(40000, 300, 7), (200000, 5000, 64), (30000, 30000, 16384)])
+def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, nbuckets):
+    """Index buckets far above 64 entries with many equal minimizers: mm_idx's order (kthread_idx.c:126,154) exactly."""
+    import torch
+    import oracle
+    rng = np.random.default_rng(n)
+    bucket_ids = rng.choice(16384, nbuckets, replace=False).astype(np.uint64)
+    keys = (rng.integers(0, 1 << 48, nkeys, dtype=np.uint64) << np.uint64(14)) | bucket_ids[rng.integers(0, nbuckets, nkeys)]
+    rec = np.zeros(n, dtype=[("x", "<u8"), ("y", "<u8")])
+    rec["x"] = keys[rng.integers(0, nkeys, n)]
+    rec["y"] = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 600, n).astype(np.uint64)
+    d = torch.from_numpy(np.stack([rec["x"], rec["y"]], axis=1).view(np.int64)).cuda()
+    idx = ctx.idx_build(d, 31, b=14)
+    got = _recs(idx.records())
+    b = (rec["x"] & np.uint64(0x3FFF)).astype(np.int64)
+    order = np.argsort(b, kind="stable")
+    srt, sb = rec[order], b[order]
+    starts = np.flatnonzero(np.r_[True, sb[1:] != sb[:-1]]); ends = np.r_[starts[1:], n]
+    want = np.concatenate([oracle.radix_sort_128x(srt[s:e]) for s, e in zip(starts, ends)])
+    assert max(ends - starts) > 64 or nbuckets == 16384
+    assert np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"])
+    s, c = idx.get(torch.from_numpy(keys[:50].view(np.int64).copy()).cuda())
+    ctx.sync()
+    for q in range(50):
+        lo = int(s[q]); cnt = int(c[q])
+        assert cnt == int((rec["x"] == keys[q]).sum()) and np.all(got["x"][lo:lo + cnt] == keys[q])
     idx.close()
