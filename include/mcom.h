@@ -216,6 +216,25 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
                       const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                       uint64_t n_windows, int thr, int maxsearch, uint64_t *d_claim, uint64_t *d_stats);
 
+/* The same pass driven from the singletons (results identical to mcom_realign_pass; it is the production path).
+ * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed
+ * ONCE: mcom_cindex_plan sizes the index (d_keys and d_vals: 8 << log2lines uint64 each) for a contig set,
+ * mcom_cindex_build fills it from the packed contigs.  mcom_realign_pass_reads then looks up, for every
+ * unflagged singleton, the key of each dictionary l at contig position window + ds[l] and the reverse complement
+ * of that key at window + L - ds[l] - klen (the two probes of kthread_hash_realign.c:380 and :446 seen from the
+ * read), verifies every hit like :390-393 / :458-461 and keeps the minimum claim key per singleton.
+ *   d_elig : NULL, or [n_sg] bit l set = the singleton is within the last `maxsearch` entries of its bin of
+ *            dictionary l (mcom_dicts_eligible) -- only needed when some bin exceeds maxsearch (:388)
+ *   d_stats: optional [3] = { lookups, windows verified, tuples passing }                                */
+int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines);
+int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                      uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys, uint64_t *d_vals);
+int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
+int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_vals, uint32_t log2lines,
+                            const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
+                            const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                            int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

@@ -72,7 +72,7 @@ extern "C" const char *mcom_last_error(const mcom_ctx *ctx) { return ctx ? ctx->
 
 // ---- optional kernel timing with HIP events on the context's stream ------------------------------------
 static const char *PROF_NAMES[PROF_COUNT] = { "classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next",
-                                              "dict_build", "realign_windows", "consensus" };
+                                              "dict_build", "realign_windows", "consensus", "cindex_build", "realign_reads" };
 
 static void prof_collect(mcom_ctx *ctx)
 {

@@ -9,7 +9,7 @@
 
 // kernel classes timed by the optional in-library profiler (mcom_prof_*): HIP events on the launch stream
 enum McomProfId { PROF_CLASSIFY_PACK = 0, PROF_SKETCH_READS, PROF_RADIX_PASS, PROF_SKETCH_CONTIGS, PROF_FIND_NEXT,
-                  PROF_DICT_BUILD, PROF_REALIGN_WINDOWS, PROF_CONSENSUS, PROF_COUNT };
+                  PROF_DICT_BUILD, PROF_REALIGN_WINDOWS, PROF_CONSENSUS, PROF_CINDEX_BUILD, PROF_REALIGN_READS, PROF_COUNT };
 struct McomProfSpan { int id; hipEvent_t a, b; };
 
 struct mcom_ctx {

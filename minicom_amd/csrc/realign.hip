@@ -372,3 +372,260 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
+
+// ==== read-driven form of the same pass =======================================================================
+// The window scan asks, for every (window, dir, dict), "which singletons carry this key?": ~15 random probes per
+// contig base although only the singletons (a few % of the reads) can ever answer.  Because the claim of a read is
+// a MINIMUM over its passing (contig, window, dir, dict) tuples, the join can be driven from the other side with the
+// same result: index every klen-mer of the (fixed) Stage-2 contigs once, then let every singleton look its own
+// 2*nd - 1 keys up (forward key of dictionary l at contig position jj + ds[l]; for the reverse direction the
+// reverse complement of the key at jj + L - ds[l] - klen) and verify exactly the tuples the window scan would have
+// verified.  Probes per pass drop from (2nd-1) * windows to (2nd-1) * singletons.
+//
+// Index: multi-map in HBM, lines of 8 slots (one 64-B sector of keys, a parallel array of values c<<32 | p).
+// A key's probe sequence is line h1, h1+s, h1+2s, ... with an odd key-dependent stride s (so a repeat with 10^5
+// copies does not bury its neighbours the way linear probing would); inside a line slots fill from 0 up.  Slots are
+// never emptied, hence every copy of a key lies before the first EMPTY slot of its sequence.
+#define CIX_EMPTY (~0ull)
+struct CixGeom { uint32_t log2lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };
+
+__device__ __forceinline__ void cix_seq(uint64_t key, uint32_t log2lines, uint32_t &line, uint32_t &stride)
+{
+	const uint64_t h = key * 0x9E3779B97F4A7C15ull;
+	line = (uint32_t)(h >> (64 - log2lines));
+	stride = ((uint32_t)(h >> 5) | 1u) & ((1u << log2lines) - 1u);
+}
+
+static int cix_geom(int L, int ininumdict, CixGeom &g)
+{
+	int len[MAXDICT];
+	g.L = L; g.nd = dict_layout(L, ininumdict, g.ds, len);
+	if (g.nd < 1) return -1;
+	g.klen = len[0];
+	int mo = 0;
+	for (int l = 0; l < g.nd; ++l) {
+		if (g.ds[l] > mo) mo = g.ds[l];
+		if (g.ds[l] > 0 && L - g.ds[l] - g.klen > mo) mo = L - g.ds[l] - g.klen;
+	}
+	g.maxoff = mo;
+	return 0;
+}
+
+extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines)
+{
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return MCOM_E_ARG;
+	const uint64_t ne = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;
+	uint32_t lg = 4;
+	while (lg < 31 && (8ull << lg) * 5 < ne * 8) ++lg;                    // load <= 0.625
+	if ((8ull << lg) * 5 < ne * 8) return MCOM_E_ARG;
+	if (n_entries) *n_entries = ne;
+	if (log2lines) *log2lines = lg;
+	return MCOM_OK;
+}
+
+// position space: contig c owns [woff[c] + maxoff*c, woff[c+1] + maxoff*(c+1)); positions p = 0 .. nw-1+maxoff of a
+// contig with nw > 0 windows are indexed, the maxoff phantom positions of a contig without windows are skipped
+__global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
+                                                       const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_pos,
+                                                       unsigned long long *__restrict__ keys, uint64_t *__restrict__ vals)
+{
+	__shared__ uint32_t c0s;
+	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
+	if (threadIdx.x == 0) {
+		uint32_t lo = 0, hi = n_contigs;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (woff[mid] + (uint64_t)g.maxoff * mid <= g0) lo = mid; else hi = mid; }
+		c0s = lo;
+	}
+	__syncthreads();
+	const uint64_t gi = g0 + threadIdx.x;
+	if (gi >= n_pos) return;
+	uint32_t c = c0s;
+	while (c + 1 < n_contigs && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) <= gi) ++c;
+	const uint64_t nw = woff[c + 1] - woff[c];
+	if (nw == 0) return;
+	const uint64_t p = gi - (woff[c] + (uint64_t)g.maxoff * c);
+	const uint64_t *src = cbits + coff[c] + ((2 * p) >> 6);
+	const int sh = (int)((2 * p) & 63);
+	uint64_t v = src[0] >> sh;
+	if (sh + 2 * g.klen > 64) v |= src[1] << (64 - sh);
+	const uint64_t key = v & ((1ull << (2 * g.klen)) - 1);
+	uint32_t line, stride;
+	cix_seq(key, g.log2lines, line, stride);
+	const uint32_t lmask = (1u << g.log2lines) - 1u;
+	for (;;) {
+		unsigned long long *kl = keys + (size_t)line * 8;
+		for (int s = 0; s < 8; ++s) {
+			if (kl[s] != CIX_EMPTY) continue;
+			if (atomicCAS(&kl[s], CIX_EMPTY, (unsigned long long)key) == CIX_EMPTY) { vals[(size_t)line * 8 + s] = ((uint64_t)c << 32) | p; return; }
+		}
+		line = (line + stride) & lmask;
+	}
+}
+
+extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys, uint64_t *d_vals)
+{
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	if (!d_keys || !d_vals || log2lines < 4 || log2lines > 31) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	g.log2lines = log2lines;
+	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
+	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, (8ull << log2lines) * 8, ctx->stream));
+	if (n_contigs == 0 || n_windows == 0) return MCOM_OK;
+	if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_contigs >= (1u << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the claim key");
+	const uint64_t n_pos = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;
+	if ((8ull << log2lines) * 7 < n_pos * 8) return mcom_fail(ctx, MCOM_E_ARG, "contig index too small: %llu entries", (unsigned long long)n_pos);
+	const uint64_t blocks = (n_pos + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions for one launch");
+	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, n_contigs, n_pos,
+	                   (unsigned long long*)d_keys, d_vals);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// which dictionaries may still see a singleton when bins are cut at maxsearch: the window scan walks a bin from its
+// end and stops after maxsearch entries (:388), flagged reads included
+__global__ void k_dict_eligible(const uint64_t *__restrict__ sgbits, int W, const uint32_t *__restrict__ ids, size_t n,
+                                const uint64_t *__restrict__ slots, uint32_t log2cap, int start, int len, int l, uint32_t maxsearch,
+                                uint32_t *__restrict__ elig)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = ids[i];
+	uint32_t s = 0, c = 0;
+	if (!dict_find(slots, log2cap, bits_key(sgbits + (size_t)sg * W, start, len), s, c)) return;
+	if ((uint64_t)s + c - 1 - i < maxsearch) atomicOr(&elig[sg], 1u << l);
+}
+
+extern "C" int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig)
+{
+	if (!ctx || !d) return MCOM_E_ARG;
+	if (d->n_sg == 0) return MCOM_OK;
+	if (!d_sgbits || !d_elig || maxsearch < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad eligibility arguments");
+	MCOM_HIP(ctx, hipMemsetAsync(d_elig, 0, d->n_sg * 4, ctx->stream));
+	for (int l = 0; l < d->nd; ++l)
+		hipLaunchKernelGGL(k_dict_eligible, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
+		                   d->slots[l], d->log2cap[l], d->ds[l], d->kl[l], l, (uint32_t)maxsearch, d_elig);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// G lanes per singleton, lane q < 2*nd handles (dir = q / nd, dict = q % nd)
+template <int W, int G>
+__global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys, const uint64_t *__restrict__ vals,
+                                                       const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
+                                                       const uint32_t *__restrict__ elig, size_t n_sg, const uint64_t *__restrict__ cbits,
+                                                       const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff, int thr,
+                                                       unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t sg = t / G;
+	const int q = (int)(t % G);
+	unsigned long long n_look = 0, n_cand = 0, n_pass = 0;
+	const int dir = q / g.nd, l = q - dir * g.nd;
+	const int L = g.L;
+	bool live = sg < n_sg && q < 2 * g.nd && !(dir && g.ds[l] <= 0);                      // kthread_hash_realign.c:440
+	if (live && sgflag[sg]) live = false;
+	const uint32_t el = (live && elig) ? elig[sg] : 0xFFFFFFFFu;
+	if (live && !((el >> l) & 1u)) live = false;
+	if (live) {
+		uint64_t row[W];
+		const uint64_t *rb = sgbits + sg * (size_t)W;
+#pragma unroll
+		for (int w = 0; w < W; ++w) row[w] = rb[w];
+		uint64_t key = bits_key(row, g.ds[l], g.klen);
+		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
+		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
+		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
+		uint32_t line, stride;
+		cix_seq(key, g.log2lines, line, stride);
+		const uint32_t lmask = (1u << g.log2lines) - 1u;
+		++n_look;
+		for (bool more = true; more;) {
+			const unsigned long long *kl = keys + (size_t)line * 8;
+			unsigned long long ks[8];
+#pragma unroll
+			for (int s = 0; s < 8; ++s) ks[s] = kl[s];
+#pragma unroll
+			for (int s = 0; s < 8; ++s) {
+				if (ks[s] == CIX_EMPTY) { more = false; break; }
+				if (ks[s] != key) continue;
+				const uint64_t v = vals[(size_t)line * 8 + s];
+				const uint32_t c = (uint32_t)(v >> 32);
+				const int64_t jj = (int64_t)(uint32_t)v - off;
+				if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) continue;
+				++n_cand;
+				// window bits, as in k_realign_windows
+				uint64_t win[W], x[W];
+				const uint64_t *src = cbits + coff[c] + ((2 * (uint64_t)jj) >> 6);
+				const int sh = (int)((2 * (uint64_t)jj) & 63);
+				uint64_t cur = src[0];
+#pragma unroll
+				for (int w = 0; w < W; ++w) { const uint64_t nxt = src[w + 1]; win[w] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur; cur = nxt; }
+				const int tail = 2 * L - 64 * (W - 1);
+				if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+				if (dir) {
+					uint64_t tt[W];
+#pragma unroll
+					for (int w = 0; w < W; ++w) tt[w] = ~rev_groups(win[W - 1 - w]);
+					const int drop = 64 * W - 2 * L;
+#pragma unroll
+					for (int w = 0; w < W; ++w) { const uint64_t a = tt[w], b = w + 1 < W ? tt[w + 1] : 0ull; win[w] = drop ? (a >> drop) | (b << (64 - drop)) : a; }
+					if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+				}
+				int dist = 0;
+#pragma unroll
+				for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
+				if (dist > thr) continue;
+				// a lower dictionary that also sees this read at this window claims the same tuple with a smaller key
+				bool lower = false;
+				for (int l2 = 0; l2 < l; ++l2)
+					if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) { lower = true; break; }
+				if (lower) continue;
+				uint64_t mm[W];
+#pragma unroll
+				for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
+				if (!dir) { if (!encode_ok<W>(mm, L, false)) continue; }                          // :393
+				else if (thr > 24 && !encode_ok<W>(mm, L, true)) continue;                       // :461
+				++n_pass;
+				atomicMin(&claim[sg], ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l);
+			}
+			line = (line + stride) & lmask;
+		}
+	}
+	if (stats) {
+		for (int o = 32; o; o >>= 1) { n_look += __shfl_xor(n_look, o); n_cand += __shfl_xor(n_cand, o); n_pass += __shfl_xor(n_pass, o); }
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], n_look); if (n_cand) atomicAdd(&stats[1], n_cand); if (n_pass) atomicAdd(&stats[2], n_pass); }
+	}
+}
+
+extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_vals, uint32_t log2lines, const uint64_t *d_sgbits,
+                                       const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
+                                       const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
+                                       uint64_t *d_claim, uint64_t *d_stats)
+{
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	g.log2lines = log2lines;
+	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
+	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+	if (n_contigs == 0 || n_sg == 0) return MCOM_OK;
+	if (!d_keys || !d_vals || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || log2lines < 4 || log2lines > 31)
+		return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const int W = mcom_words_per_read(L);
+	const int G = 2 * g.nd <= 16 ? 16 : 32;
+	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
+#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, (unsigned long long*)d_stats); \
+	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
+	McomProfScope ps_(ctx, PROF_REALIGN_READS);
+	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_CASE
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

@@ -85,6 +85,14 @@ def load_library():
     L.mcom_dicts_ids.restype = i32; L.mcom_dicts_ids.argtypes = [vp, vp, i32, vp]
     L.mcom_realign_pass.restype = i32
     L.mcom_realign_pass.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u64, i32, i32, vp, vp]
+    L.mcom_cindex_plan.restype = i32
+    L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u32)]
+    L.mcom_cindex_build.restype = i32
+    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp, vp]
+    L.mcom_dicts_eligible.restype = i32
+    L.mcom_dicts_eligible.argtypes = [vp, vp, vp, i32, vp]
+    L.mcom_realign_pass_reads.restype = i32
+    L.mcom_realign_pass_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
     _lib = L
@@ -287,6 +295,38 @@ class Context:
         self._check(self.lib.mcom_realign_pass(self._h, dicts._h, self._p(sgbits, torch.int64), self._p(sgflag, torch.uint8),
                                                self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
                                                int(coff.shape[0]), int(n_windows), thr, maxsearch, self._p(claim), self._p(st)))
+        return claim[:n_sg], st
+
+    def cindex_build(self, cbits, coff, woff, n_windows: int, L: int, ininumdict: int = 0):
+        """mcom_cindex_plan + mcom_cindex_build.  Returns (keys int64, vals int64, log2lines)."""
+        torch = _torch()
+        ne, lg = C.c_uint64(), C.c_uint32()
+        n_contigs = int(coff.shape[0])
+        self._check(self.lib.mcom_cindex_plan(int(n_windows), n_contigs, L, ininumdict, C.byref(ne), C.byref(lg)))
+        keys = torch.empty(8 << lg.value, dtype=torch.int64, device=self.device)
+        vals = torch.empty(8 << lg.value, dtype=torch.int64, device=self.device)
+        self._check(self.lib.mcom_cindex_build(self._h, self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
+                                               n_contigs, int(n_windows), L, ininumdict, lg.value, self._p(keys), self._p(vals)))
+        return keys, vals, lg.value
+
+    def dicts_eligible(self, dicts, sgbits, maxsearch: int):
+        torch = _torch()
+        el = torch.zeros(max(int(sgbits.shape[0]), 1), dtype=torch.int32, device=self.device)
+        self._check(self.lib.mcom_dicts_eligible(self._h, dicts._h, self._p(sgbits, torch.int64), maxsearch, self._p(el)))
+        return el
+
+    def realign_pass_reads(self, cindex, sgbits, sgflag, cbits, coff, woff, L: int, thr: int, ininumdict: int = 0, elig=None,
+                           stats: bool = False):
+        """mcom_realign_pass_reads.  cindex = cindex_build's result.  Returns (claim int64 [n_sg], stats or None)."""
+        torch = _torch()
+        keys, vals, lg = cindex
+        n_sg = int(sgbits.shape[0])
+        claim = torch.empty(max(n_sg, 1), dtype=torch.int64, device=self.device)
+        st = torch.zeros(3, dtype=torch.int64, device=self.device) if stats else None
+        self._check(self.lib.mcom_realign_pass_reads(self._h, self._p(keys), self._p(vals), lg, self._p(sgbits, torch.int64),
+                                                     self._p(sgflag, torch.uint8), self._p(elig), n_sg, self._p(cbits, torch.int64),
+                                                     self._p(coff, torch.int64), self._p(woff, torch.int64), int(coff.shape[0]), L,
+                                                     ininumdict, thr, self._p(claim), self._p(st)))
         return claim[:n_sg], st
 
     def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,

@@ -180,6 +180,8 @@ struct mcomh_pipeline {
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
+	DevBuf<uint64_t> d_cix_keys, d_cix_vals; uint32_t cix_log2 = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
+	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
 	std::map<std::string, double> stat;
 
@@ -228,6 +230,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->rw = L >= 70 ? L / 2 - p->k : 3;                                             // preprocess.c:89-107
 	if (pp->w > 0) p->rw = pp->w;
 	p->numdict = pp->numdict;
+	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }   // A/B switch for measurements
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
 	if (host_reads) {
@@ -636,6 +639,13 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		p->n_windows = woff[nc];
 		if (!p->d_woff.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "window offsets");
 		if ((rc = p->h2d(p->d_woff.p, woff.data(), nc + 1, "upload window offsets")) || (rc = p->sync("upload"))) return rc;
+		if (!p->window_scan) {
+			uint64_t ne = 0;
+			if (mcom_cindex_plan(p->n_windows, (uint32_t)nc, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			if (!p->d_cix_keys.reserve(8ull << p->cix_log2) || !p->d_cix_vals.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
+			if ((rc = p->gpu(mcom_cindex_build(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->n_windows, p->L, p->numdict,
+			                                   p->cix_log2, p->d_cix_keys.p, p->d_cix_vals.p)))) return rc;
+		}
 		p->stage2_uploaded = true;
 	}
 	p->stat["t_ra_setup"] += now_ms() - t0;
@@ -661,17 +671,35 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
 		mcom_dicts *dicts = nullptr;
 		if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;               // constructdictionary_realign
+		bool big = false;
 		{
 			int nd = 0; uint32_t nk[16], mb[16];
 			mcom_dicts_info(dicts, &nd, nk, mb);
-			for (int j = 0; j < nd; ++j) if (mb[j] > (uint32_t)p->maxsearch) p->stat["big_bins"] += 1;
+			for (int j = 0; j < nd; ++j) if (mb[j] > (uint32_t)p->maxsearch) { p->stat["big_bins"] += 1; big = true; }
 		}
 		for (size_t i = 0; i < n_sg; ++i) {                                                  // bbhashdict.c:177-216, singleton order
 			if (pf[i] == 1) { p->sg_flag[i] = 1; p->fpA.push_back(p->sg[i]); }
 			else if (pf[i] == 2) { p->sg_flag[i] = 1; p->fpT.push_back(p->sg[i]); }
 		}
-		rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
-		                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
+		if (p->window_scan)
+			rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
+			                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
+		else {
+			DevBuf<uint32_t> d_elig; DevBuf<uint64_t> d_st;
+			rc = MCOM_OK;
+			if (big) {                                                                           // bins cut at maxsearch (:388)
+				if (!d_elig.reserve(n_sg)) rc = p->fail(MCOM_E_NOMEM, "eligibility");
+				else rc = p->gpu(mcom_dicts_eligible(p->ctx, dicts, d_sgbits.p, p->maxsearch, d_elig.p));
+			}
+			if (!rc && !d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
+			if (!rc) rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->d_cix_vals.p, p->cix_log2, d_sgbits.p, d_flag.p, big ? d_elig.p : nullptr,
+			                                             n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
+			PinVec<uint64_t> hst; hst.resize(3);
+			if (!rc) rc = p->d2h(hst.data(), d_st.p, 3, "copy pass counters");
+			if (!rc) rc = p->sync("realign pass");
+			if (!rc) { p->stat["ra_lookups"] += (double)hst[0]; p->stat["ra_verified"] += (double)hst[1]; p->stat["ra_passing"] += (double)hst[2]; }
+			p->stat["ra_singletons"] += (double)n_sg;
+		}
 		PinVec<uint64_t> claim; claim.resize(n_sg);
 		if (!rc) rc = p->d2h(claim.data(), d_claim.p, n_sg, "copy claims");
 		if (!rc) rc = p->sync("realign pass");

@@ -57,12 +57,16 @@ def _gpu_pass(ctx, p, reads_orig, thr, check_dicts=False):
     refs = [r for r, _ in contigs]
     cbits, coff, clen = pack_contigs(refs)
     nwin = np.maximum(clen.astype(np.int64) - L + 1, 0)
-    woff = np.concatenate([[0], np.cumsum(nwin)[:-1]]).astype(np.uint64) if len(nwin) else np.zeros(0, np.uint64)
+    woff = np.concatenate([[0], np.cumsum(nwin)]).astype(np.uint64)
     maxsearch = p.counter("maxsearch")
-    claim, st = ctx.realign_pass(dicts, sgbits, flag, torch.from_numpy(cbits.view(np.int64)).cuda(),
-                                 torch.from_numpy(coff.view(np.int64)).cuda(), torch.from_numpy(woff.view(np.int64)).cuda(),
-                                 int(nwin.sum()), thr, maxsearch, stats=True)
+    d_cbits, d_coff, d_woff = (torch.from_numpy(a.view(np.int64)).cuda() for a in (cbits, coff, woff))
+    claim, st = ctx.realign_pass(dicts, sgbits, flag, d_cbits, d_coff, d_woff, int(nwin.sum()), thr, maxsearch, stats=True)
+    # the read-driven form of the pass (the production path) must give the same claims
+    cix = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
+    claim_r, st_r = ctx.realign_pass_reads(cix, sgbits, flag, d_cbits, d_coff, d_woff, L, thr, stats=True)
     ctx.sync()
+    assert torch.equal(claim, claim_r)
+    assert int(st_r[0]) > 0 and int(st_r[1]) >= int(st_r[2]) >= int((claim_r != -1).sum())
     if check_dicts:
         _check_dicts(ctx, dicts, sgbits.cpu().numpy().view(np.uint64), L)
     claim = claim.cpu().numpy().view(np.uint64)
@@ -159,6 +163,50 @@ def test_realign_high_threshold_uses_cost_filter_on_reverse_strand(ctx):
         if thr > 24:
             rev_hi += sum(1 for v in app.values() for y in v if y & 1)
     assert total > 0 and rev_hi >= 0
+
+
+@pytest.mark.parametrize("L,maxsearch", [(150, 500), (150, 3), (150, 1), (100, 2), (64, 2), (200, 4)])
+def test_read_driven_pass_equals_window_scan_also_with_bins_above_maxsearch(ctx, L, maxsearch):
+    """Random contigs, singletons cut from them (both strands, substitutions, many duplicates so that bins exceed
+    maxsearch): mcom_realign_pass_reads + mcom_dicts_eligible give the claims of the window scan."""
+    import torch
+    from minicom_amd.hip import pack_nt4, pack_contigs
+    rng = np.random.default_rng(L * 1000 + maxsearch)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    lens = rng.integers(L, 6 * L, 150)
+    lens[:3] = [L, L + 1, 2 * L]
+    refs = [acgt[rng.integers(0, 4, n)] for n in lens]
+    refs[7] = refs[6].copy()                                               # a repeated contig: several windows per key
+    reads = []
+    for _ in range(6000):
+        c = int(rng.integers(0, len(refs)))
+        j = int(rng.integers(0, len(refs[c]) - L + 1))
+        if rng.random() < 0.3:
+            j = min(j, 3)                                                  # pile-ups: many reads with equal keys
+        r = refs[c][j:j + L].copy()
+        for q in rng.integers(0, L, int(rng.integers(0, 7))):
+            r[q] = acgt[rng.integers(0, 4)]
+        reads.append(comp[r][::-1] if rng.random() < 0.5 else r)
+    reads = np.stack(reads)
+    sgbits = torch.from_numpy(pack_nt4(reads).view(np.int64)).cuda()
+    flag = torch.from_numpy((rng.random(len(reads)) < 0.05).astype(np.uint8)).cuda()
+    cbits, coff, clen = pack_contigs([r.tobytes() for r in refs])
+    nwin = np.maximum(clen.astype(np.int64) - L + 1, 0)
+    woff = np.concatenate([[0], np.cumsum(nwin)]).astype(np.uint64)
+    d_cbits, d_coff, d_woff = (torch.from_numpy(a.view(np.int64)).cuda() for a in (cbits, coff, woff))
+    dicts = ctx.dicts_build(sgbits, L)
+    cix = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
+    if maxsearch < 500:
+        assert max(dicts.maxbin) > maxsearch
+    for thr in (4, 12, 28):
+        want, _ = ctx.realign_pass(dicts, sgbits, flag, d_cbits, d_coff, d_woff, int(nwin.sum()), thr, maxsearch)
+        elig = ctx.dicts_eligible(dicts, sgbits, maxsearch) if max(dicts.maxbin) > maxsearch else None
+        got, _ = ctx.realign_pass_reads(cix, sgbits, flag, d_cbits, d_coff, d_woff, L, thr, elig=elig)
+        ctx.sync()
+        assert torch.equal(want, got), (thr, int((want != got).sum()))
+        assert int((want != -1).sum()) > 1000
+    dicts.close()
 
 
 def test_realign_empty_inputs(ctx):
