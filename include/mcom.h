@@ -235,6 +235,15 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
 
+/* The members one pass appends, in the order the sequential scan appends them (claim key ascending, singleton
+ * index descending: the bin is walked from its end, kthread_hash_realign.c:388, :408-409, :474-475).
+ *   d_claim [n_sg] from mcom_realign_pass(_reads);  d_rids [n_sg] read id of every singleton
+ *   d_flag  [n_sg] in/out: the entry of every claimed singleton is set to 3
+ *   d_app_contig / d_app_member [<= n_sg] out: contig index and member word rid<<32 | window<<1 | dir of the
+ *   *h_nwon appended members.  Synchronous.                                                                 */
+int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const uint32_t *d_rids, size_t n_sg, uint32_t n_contigs,
+                        uint8_t *d_flag, uint32_t *d_app_contig, uint64_t *d_app_member, uint64_t *h_nwon);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

@@ -93,6 +93,8 @@ def load_library():
     L.mcom_dicts_eligible.argtypes = [vp, vp, vp, i32, vp]
     L.mcom_realign_pass_reads.restype = i32
     L.mcom_realign_pass_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
+    L.mcom_claims_resolve.restype = i32
+    L.mcom_claims_resolve.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp, C.POINTER(u64)]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
     _lib = L
@@ -328,6 +330,17 @@ class Context:
                                                      self._p(coff, torch.int64), self._p(woff, torch.int64), int(coff.shape[0]), L,
                                                      ininumdict, thr, self._p(claim), self._p(st)))
         return claim[:n_sg], st
+
+    def claims_resolve(self, claim, rids, n_contigs: int, flag):
+        """mcom_claims_resolve.  flag is updated in place; returns (contig int32 [nwon], member int64 [nwon])."""
+        torch = _torch()
+        n = int(claim.shape[0])
+        ac = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        am = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        nw = C.c_uint64()
+        self._check(self.lib.mcom_claims_resolve(self._h, self._p(claim, torch.int64), self._p(rids, torch.int32), n, n_contigs,
+                                                 self._p(flag, torch.uint8), self._p(ac), self._p(am), C.byref(nw)))
+        return ac[:nw.value], am[:nw.value]
 
     def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,
                     first: int = 0, count: int | None = None, pitch: int | None = None):

@@ -176,6 +176,12 @@ struct mcomh_pipeline {
 	std::vector<uint8_t> sg_flag;
 	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
 	std::vector<uint8_t> unsorted;           // Stage 2: contigs whose member list changed since it was last sorted
+	// Stage 2 never reads the member lists, so the appends of the passes are kept aside (contig, member; in the
+	// reference's appending order) and folded into C by materialize() when somebody looks at the members.
+	struct Appended { PinVec<uint32_t> contig; PinVec<uint64_t> member; };
+	std::vector<Appended> pend;
+	size_t n_pending = 0;
+	std::thread presort;                     // the sort at the start of a pass (:318), running beside the GPU work
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
@@ -201,6 +207,8 @@ struct mcomh_pipeline {
 };
 
 using P = mcomh_pipeline;
+static void join_presort(P *p);
+static int materialize(P *p);
 static const char ACGT[] = "ACGT";
 
 // ----------------------------------------------------------------------------------------------------
@@ -262,6 +270,7 @@ extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_s
 extern "C" void mcomh_destroy(mcomh_pipeline *p)
 {
 	if (!p) return;
+	join_presort(p);
 	(void)hipStreamSynchronize(p->stream);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
@@ -620,6 +629,62 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	return MCOM_OK;
 }
 
+static void join_presort(P *p) { if (p->presort.joinable()) p->presort.join(); }
+
+// Folds the pending appends of passes 1..m into the member lists.  The reference sorts a contig at the start of every
+// scan and appends behind it, so after m passes contig c holds
+//     stable_sort(C(c) + P_1(c) + ... + P_{m-1}(c)) + P_m(c)
+// (a stable sort of [sorted part + tail] = stable sort of the tail merged behind equal elements).
+static int materialize(P *p)
+{
+	join_presort(p);
+	const size_t m = p->pend.size();
+	if (!m) return MCOM_OK;
+	const double t0 = now_ms();
+	ContigSet &C = p->C;
+	const size_t nc = C.n();
+	const int nt = p->host_threads;
+	std::vector<std::vector<uint64_t>> off(m);
+	{
+		std::vector<std::thread> th;
+		for (size_t i = 0; i < m; ++i)
+			th.emplace_back([&, i]() {
+				std::vector<uint64_t> &o = off[i];
+				o.assign(nc + 1, 0);
+				const P::Appended &a = p->pend[i];
+				for (size_t u = 0; u < a.contig.size(); ++u) ++o[(size_t)a.contig[u] + 1];
+				for (size_t c = 0; c < nc; ++c) o[c + 1] += o[c];
+			});
+		for (std::thread &t : th) t.join();
+	}
+	PinVec<uint64_t> &nmem = p->Cnext.mem; std::vector<uint64_t> &nmoff = p->Cnext.moff;       // spare buffers of the merge stage
+	if (!nmem.resize(C.mem.size() + p->n_pending)) return p->fail(MCOM_E_NOMEM, "member lists");
+	nmoff.resize(nc + 1);
+	parallel_for(nt, nc + 1, [&](int, size_t cb, size_t ce) {
+		for (size_t c = cb; c < ce; ++c) { uint64_t s = C.moff[c]; for (size_t i = 0; i < m; ++i) s += off[i][c]; nmoff[c] = s; }
+	});
+	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
+	parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
+		for (size_t c = cb; c < ce; ++c) {
+			uint64_t *dst = nmem.data() + nmoff[c];
+			const size_t n0 = C.msize(c);
+			memcpy(dst, C.mem.data() + C.moff[c], n0 * 8);
+			if (nmoff[c + 1] - nmoff[c] == n0) continue;
+			size_t n1 = n0;
+			for (size_t i = 0; i + 1 < m; ++i) { const size_t k = off[i][c + 1] - off[i][c]; if (k) { memcpy(dst + n1, p->pend[i].member.data() + off[i][c], k * 8); n1 += k; } }
+			if (p->unsorted[c]) std::stable_sort(dst, dst + n1, less_cluster2);            // only when no pass sorted it yet
+			else if (n1 > n0) { std::stable_sort(dst + n0, dst + n1, less_cluster2); std::inplace_merge(dst, dst + n0, dst + n1, less_cluster2); }
+			const size_t k = off[m - 1][c + 1] - off[m - 1][c];
+			if (k) memcpy(dst + n1, p->pend[m - 1].member.data() + off[m - 1][c], k * 8);
+			p->unsorted[c] = k ? 1 : 0;
+		}
+	});
+	C.mem.swap(nmem); C.moff.swap(nmoff);
+	p->pend.clear(); p->n_pending = 0;
+	p->stat["t_ra_materialize"] += now_ms() - t0;
+	return MCOM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // realign_hash: one Stage-2 pass                                    kthread_hash_realign.c:569-594
 // ----------------------------------------------------------------------------------------------------
@@ -653,12 +718,18 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	p->stat["windows"] += (double)p->n_windows;
 	const double tr0 = now_ms();
 	// every contig is re-sorted at the start of its scan (:318); a stable sort of a sorted list is the identity,
-	// so only contigs that changed since their last sort are touched
+	// so only contigs that changed since their last sort are touched.  The scan itself never looks at the members:
+	// the sort runs beside the GPU work, and while appends are pending it is folded into materialize().
+	join_presort(p);
 	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
-	parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
-		for (size_t c = cb; c < ce; ++c)
-			if (p->unsorted[c]) { std::stable_sort(C.mem.data() + C.moff[c], C.mem.data() + C.moff[c + 1], less_cluster2); p->unsorted[c] = 0; }
-	});
+	if (p->pend.empty())
+		p->presort = std::thread([p, nt, nc]() {
+			ContigSet &S = p->C;
+			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
+				for (size_t c = cb; c < ce; ++c)
+					if (p->unsorted[c]) { std::stable_sort(S.mem.data() + S.moff[c], S.mem.data() + S.moff[c + 1], less_cluster2); p->unsorted[c] = 0; }
+			});
+		});
 	p->stat["t_ra_sort"] += now_ms() - tr0;
 	if (n_sg) {
 		const double tg = now_ms();
@@ -667,8 +738,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
 		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
-		PinVec<uint8_t> pf; pf.resize(n_sg);
-		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
+		PinVec<uint8_t> pf;
+		if (!pf.resize(n_sg)) return p->fail(MCOM_E_NOMEM, "flags");
 		mcom_dicts *dicts = nullptr;
 		if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;               // constructdictionary_realign
 		bool big = false;
@@ -676,10 +747,6 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			int nd = 0; uint32_t nk[16], mb[16];
 			mcom_dicts_info(dicts, &nd, nk, mb);
 			for (int j = 0; j < nd; ++j) if (mb[j] > (uint32_t)p->maxsearch) { p->stat["big_bins"] += 1; big = true; }
-		}
-		for (size_t i = 0; i < n_sg; ++i) {                                                  // bbhashdict.c:177-216, singleton order
-			if (pf[i] == 1) { p->sg_flag[i] = 1; p->fpA.push_back(p->sg[i]); }
-			else if (pf[i] == 2) { p->sg_flag[i] = 1; p->fpT.push_back(p->sg[i]); }
 		}
 		if (p->window_scan)
 			rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
@@ -700,49 +767,32 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			if (!rc) { p->stat["ra_lookups"] += (double)hst[0]; p->stat["ra_verified"] += (double)hst[1]; p->stat["ra_passing"] += (double)hst[2]; }
 			p->stat["ra_singletons"] += (double)n_sg;
 		}
-		PinVec<uint64_t> claim; claim.resize(n_sg);
-		if (!rc) rc = p->d2h(claim.data(), d_claim.p, n_sg, "copy claims");
-		if (!rc) rc = p->sync("realign pass");
 		mcom_dicts_free(p->ctx, dicts);
 		if (rc) return rc;
+		// the appends in the order of the sequential scan (claim key ascending, singleton index descending, :388),
+		// resolved on the device; they stay pending until somebody needs the member lists
+		DevBuf<uint32_t> d_ac; DevBuf<uint64_t> d_am;
+		if (!d_ac.reserve(n_sg) || !d_am.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+		uint64_t nwon = 0;
+		if ((rc = p->gpu(mcom_claims_resolve(p->ctx, d_claim.p, d_sg.p, n_sg, (uint32_t)nc, d_flag.p, d_ac.p, d_am.p, &nwon)))) return rc;
+		P::Appended app;
+		if (!app.contig.resize(nwon) || !app.member.resize(nwon)) return p->fail(MCOM_E_NOMEM, "appended members");
+		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
+		if (nwon && ((rc = p->d2h(app.contig.data(), d_ac.p, nwon, "copy appended members")) || (rc = p->d2h(app.member.data(), d_am.p, nwon, "copy appended members")))) return rc;
+		if ((rc = p->sync("realign pass"))) return rc;
 		p->stat["t_gpu"] += now_ms() - tg;
 		p->stat["t_ra_gpu"] += now_ms() - tg;
-		// append in the order of the sequential scan: claim key ascending, singleton index descending (:388)
 		const double tw0 = now_ms();
-		// counting sort of the claims by contig (the high bits of the key), then each contig orders its own few
-		std::vector<uint64_t> add(nc + 1, 0);
-		size_t nwon = 0;
-		for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) { ++add[(size_t)(claim[i] >> 33) + 1]; ++nwon; }
-		if (nwon) {
-			for (size_t c = 0; c < nc; ++c) add[c + 1] += add[c];                             // appended members before contig c
-			std::vector<std::pair<uint64_t, uint32_t>> won(nwon);
-			{
-				std::vector<uint64_t> fill(add.begin(), add.end() - 1);
-				for (size_t i = 0; i < n_sg; ++i) if (claim[i] != U64MAX) { won[fill[(size_t)(claim[i] >> 33)]++] = std::make_pair(claim[i], (uint32_t)i); p->sg_flag[i] = 1; }
-			}
-			PinVec<uint64_t> &nmem = p->Cnext.mem; std::vector<uint64_t> &nmoff = p->Cnext.moff;   // reuse the spare buffers of the merge stage
-			nmem.resize(C.mem.size() + nwon); nmoff.resize(nc + 1);
-			for (size_t c = 0; c <= nc; ++c) nmoff[c] = C.moff[c] + add[c];
-			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
-				for (size_t c = cb; c < ce; ++c) {
-					memcpy(nmem.data() + nmoff[c], C.mem.data() + C.moff[c], C.msize(c) * 8);
-					if (add[c + 1] == add[c]) continue;
-					std::sort(won.begin() + (long)add[c], won.begin() + (long)add[c + 1], [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) {
-						return a.first != b.first ? a.first < b.first : a.second > b.second; });
-					uint64_t *dst = nmem.data() + nmoff[c] + C.msize(c);
-					for (uint64_t u = add[c]; u < add[c + 1]; ++u) {
-						const uint64_t ck = won[u].first;
-						const uint64_t jj = (ck >> 5) & ((1ull << 28) - 1), dir = (ck >> 4) & 1;
-						*dst++ = (uint64_t)p->sg[won[u].second] << 32 | (jj << 1) | dir;        // :408-409, :474-475
-					}
-					p->unsorted[c] = 1;
-				}
-			});
-			C.mem.swap(nmem); C.moff.swap(nmoff);
+		for (size_t i = 0; i < n_sg; ++i) {                                                  // bbhashdict.c:177-216, singleton order
+			const uint8_t f = pf[i];
+			if (!f) continue;
+			p->sg_flag[i] = 1;
+			if (f == 1) p->fpA.push_back(p->sg[i]); else if (f == 2) p->fpT.push_back(p->sg[i]);
 		}
+		if (nwon) { p->n_pending += nwon; p->pend.push_back(std::move(app)); }
 		p->stat["t_ra_append"] += now_ms() - tw0;
 	}
-	if (cluster_reads) *cluster_reads = (long)C.mem.size();
+	if (cluster_reads) *cluster_reads = (long)(C.mem.size() + p->n_pending);
 	p->stat["t_realign"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -809,6 +859,7 @@ static int run_stage2(P *p, FILE *f)
 			for (uint8_t v : p->sg_flag) fprintf(f, " %d", v ? 1 : 0);
 			fprintf(f, "\n");
 			dump_list(f, "fpA", p->fpA); dump_list(f, "fpT", p->fpT);
+			if ((rc = materialize(p))) return rc;
 			dump_contigs(f, "realign", p->C);
 		}
 		const long lim = (p->sg.size() > 1000000 && p->L >= 68) ? 10000 : 1000;
@@ -816,7 +867,8 @@ static int run_stage2(P *p, FILE *f)
 		if (cr - pre < lim) break;
 		pre = cr;
 	}
-	return mcomh_update_single(p);
+	const int rc = materialize(p);
+	return rc ? rc : mcomh_update_single(p);
 }
 
 extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
@@ -892,8 +944,8 @@ extern "C" const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_
 	if (len) *len = p->C.rsize(i);
 	return p->C.ref.data() + p->C.roff[i];                 // NOT NUL-terminated: use *len
 }
-extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { return p->C.msize(i); }
-extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { return p->C.mem.data() + p->C.moff[i]; }
+extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { (void)materialize(const_cast<mcomh_pipeline*>(p)); return p->C.msize(i); }
+extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { (void)materialize(const_cast<mcomh_pipeline*>(p)); return p->C.mem.data() + p->C.moff[i]; }
 extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 {
 	const std::vector<uint32_t> *v = nullptr;
@@ -947,6 +999,7 @@ std::string const_base_text(const char *s, int L, char base)
 extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
 {
 	if (!p || !folder) return MCOM_E_ARG;
+	{ const int rcm = materialize(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
 	const size_t n = p->n;
 	int rc;

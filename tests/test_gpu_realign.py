@@ -66,6 +66,15 @@ def _gpu_pass(ctx, p, reads_orig, thr, check_dicts=False):
     claim_r, st_r = ctx.realign_pass_reads(cix, sgbits, flag, d_cbits, d_coff, d_woff, L, thr, stats=True)
     ctx.sync()
     assert torch.equal(claim, claim_r)
+    # device-side claim resolution = the lexsort below
+    f2 = flag.clone()
+    ac, am = ctx.claims_resolve(claim_r, d_sg, len(refs), f2)
+    o = np.lexsort((-np.arange(len(sg)), claim_r.cpu().numpy().view(np.uint64)))
+    o = o[(claim_r.cpu().numpy() != -1)[o]]
+    ck = claim_r.cpu().numpy().view(np.uint64)[o]
+    assert np.array_equal(ac.cpu().numpy(), (ck >> np.uint64(33)).astype(np.int32))
+    assert np.array_equal(am.cpu().numpy().view(np.uint64), (sg[o].astype(np.uint64) << np.uint64(32)) | (((ck >> np.uint64(5)) & np.uint64((1 << 28) - 1)) << np.uint64(1)) | ((ck >> np.uint64(4)) & np.uint64(1)))
+    assert np.array_equal(f2.cpu().numpy(), np.where(claim_r.cpu().numpy() != -1, 3, flag.cpu().numpy()))
     assert int(st_r[0]) > 0 and int(st_r[1]) >= int(st_r[2]) >= int((claim_r != -1).sum())
     if check_dicts:
         _check_dicts(ctx, dicts, sgbits.cpu().numpy().view(np.uint64), L)
