@@ -244,6 +244,41 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_
 int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const uint32_t *d_rids, size_t n_sg, uint32_t n_contigs,
                         uint8_t *d_flag, uint32_t *d_app_contig, uint64_t *d_app_member, uint64_t *h_nwon);
 
+/* ---- the contig set of combine_cluster, resident in HBM between merge rounds (kthread_cb.c:570-630) ---- */
+/* A contig set on the device: ASCII consensus strings d_seq with offsets d_soff[n+1], member words d_mem
+ * (rid<<32 | offset<<1 | dir, breads.h:49-58) with offsets d_moff[n+1], all minimizers d_rec with offsets
+ * d_roff[n+1] (uint32).  The claiming of find_next (:267-343) stays with the caller; these entry points do the
+ * rest of a round without the data leaving the device.  All of them are synchronous.                       */
+
+/* exclusive 64-bit prefix sums, in place allowed */
+int mcom_scan_u64(mcom_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t n);
+/* packed layout of a set for mcom_pack_contigs: d_coff_words[n+1], d_clen[n], *h_total_words                 */
+int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, uint64_t *d_coff_words, uint32_t *d_clen,
+                       uint64_t *h_total_words);
+/* Member lists of the nj claimed pairs (find_next :297-325): d_jobs = nj x {ci, cj, pos_ori, pos} (uint32);
+ * the list of the contig whose anchor lies further right first, the other one shifted behind it, then in
+ * cmpcluster2 order (stable, as construct_ref2's sort :107 with glibc's merge sort).  key_bits: every
+ * offset<<1|dir of the merged lists is below 2^key_bits (<= 29).  Out: d_jm with offsets d_jmoff[nj+1],
+ * d_jroff[nj+1] = offsets of the merged consensus strings (length = last offset + L, :112-113),
+ * h_totals[3] = { members, consensus chars, longest merged contig }.                                         */
+int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
+                       int key_bits, uint64_t *d_jm, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals);
+/* mcom_merge_consensus with the tile list made on the device from d_jroff                                    */
+int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_jm, const uint64_t *d_jmoff,
+                              const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs);
+/* cp_cluster (:397-434): the new set holds the nj merged contigs first (their data and offset entries [0..nj]
+ * already in d_seq2/d_soff2/d_mem2/d_moff2), then the nkeep contigs of the old set with d_flag[i] == 0, in
+ * their order.  Out: the rest of the new arrays, d_keepidx[nkeep] = old index of every carried contig,
+ * h_totals[2] = { chars, members } of the new set.                                                           */
+int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_soff, const uint64_t *d_mem, const uint64_t *d_moff,
+                       size_t n, const uint8_t *d_flag, size_t nj, size_t nkeep, uint8_t *d_seq2, uint64_t *d_soff2,
+                       uint64_t *d_mem2, uint64_t *d_moff2, uint32_t *d_keepidx, uint64_t *h_totals);
+/* The minimizers of a carried contig do not change, only its index does: records of old contig d_keepidx[u]
+ * are appended at d_rec2[base ...] with id (first_id+u)<<8, d_roff2[first_id .. first_id+nkeep] are written;
+ * *h_total = records in d_rec2 afterwards.  MCOM_E_OVERFLOW when cap2 is too small.                           */
+int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_keepidx, size_t nkeep,
+                       uint32_t first_id, uint32_t base, mcom_mm128 *d_rec2, size_t cap2, uint32_t *d_roff2, uint64_t *h_total);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

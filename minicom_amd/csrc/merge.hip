@@ -1,0 +1,400 @@
+// minicom_amd/csrc/merge.hip -- the contig set of combine_cluster kept on the device between merge rounds (gfx950).
+//
+// A merge round of the reference (kthread_cb.c:570-630) = find_next (candidates, first-come claiming, member merge,
+// construct_ref2) followed by cp_cluster (merged contigs first, untouched ones behind them).  Only the claiming is
+// order dependent; everything else is data movement over the members (8 B each) and the consensus strings, which is
+// done here so that neither leaves HBM between rounds:
+//   mcom_contig_layout      packed-word offsets and lengths of a contig set
+//   mcom_merge_members      member lists of the claimed pairs, shifted and in cmpcluster2 order       (:297-325, :107)
+//   mcom_merge_consensus_jobs  construct_ref2 of every merged list, tiles made on the device          (:327)
+//   mcom_contigs_carry      the untouched contigs copied behind the merged ones                        (:397-434)
+//   mcom_records_carry      their minimizers re-labelled for the next round instead of sketched again
+#include "mcom_dev.hpp"
+
+// ---- 64-bit exclusive scan -------------------------------------------------------------------------------------
+#define S64_THREADS 256
+#define S64_PER 4
+#define S64_TILE (S64_THREADS * S64_PER)
+
+__global__ __launch_bounds__(S64_THREADS) void k_scan64_tile(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, size_t n,
+                                                            uint64_t *__restrict__ sums)
+{
+	__shared__ uint64_t wsum[S64_THREADS / 64];
+	const size_t base = (size_t)blockIdx.x * S64_TILE + (size_t)threadIdx.x * S64_PER;
+	uint64_t v[S64_PER], tot = 0;
+#pragma unroll
+	for (int q = 0; q < S64_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0ull; tot += v[q]; }
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	uint64_t inc = tot;
+#pragma unroll
+	for (int s = 1; s < 64; s <<= 1) { const uint64_t t = __shfl_up(inc, s, 64); if (lane >= s) inc += t; }
+	if (lane == 63) wsum[wv] = inc;
+	__syncthreads();
+	uint64_t add = 0, all = 0;
+	for (int q = 0; q < S64_THREADS / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
+	uint64_t run = inc + add - tot;
+#pragma unroll
+	for (int q = 0; q < S64_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+	if (sums && threadIdx.x == 0) sums[blockIdx.x] = all;
+}
+__global__ __launch_bounds__(S64_THREADS) void k_scan64_add(uint64_t *__restrict__ out, size_t n, const uint64_t *__restrict__ sums)
+{
+	const size_t i = (size_t)blockIdx.x * S64_TILE + threadIdx.x;
+	const uint64_t a = sums[blockIdx.x];
+#pragma unroll
+	for (int q = 0; q < S64_PER; ++q) { const size_t j = i + (size_t)q * S64_THREADS; if (j < n) out[j] += a; }
+}
+static size_t scan64_scratch_elems(size_t n)
+{
+	size_t tot = 0;
+	while (n > S64_TILE) { n = (n + S64_TILE - 1) / S64_TILE; tot += n; }
+	return tot + 1;
+}
+static int scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch)
+{
+	if (n == 0) return MCOM_OK;
+	const size_t nb = (n + S64_TILE - 1) / S64_TILE;
+	hipLaunchKernelGGL(k_scan64_tile, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
+	MCOM_LAUNCH_CHECK(ctx);
+	if (nb > 1) {
+		int rc = scan64(ctx, scratch, scratch, nb, scratch + nb);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_scan64_add, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, out, n, scratch);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	return MCOM_OK;
+}
+
+// bump allocator over the context workspace
+struct WsCut {
+	char *base; size_t off;
+	template <class T> T *take(size_t n) { T *p = (T*)(base + off); off += (n * sizeof(T) + 255) & ~(size_t)255; return p; }
+};
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" int mcom_scan_u64(mcom_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t n)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_in || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(n) * 8) + 256);
+	if (rc) return rc;
+	return scan64(ctx, d_in, d_out, n, (uint64_t*)ctx->ws);
+}
+
+// ---- layout ----------------------------------------------------------------------------------------------------------
+__global__ void k_layout(const uint64_t *__restrict__ soff, size_t n, uint64_t *__restrict__ words, uint32_t *__restrict__ clen)
+{
+	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > n) return;
+	if (c == n) { words[c] = 0; return; }
+	const uint64_t len = soff[c + 1] - soff[c];
+	clen[c] = (uint32_t)len;
+	words[c] = (2 * len + 63) / 64 + 1;                                    // one padding word behind every contig
+}
+
+extern "C" int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, uint64_t *d_coff_words, uint32_t *d_clen, uint64_t *h_total_words)
+{
+	if (!ctx || !h_total_words) return MCOM_E_ARG;
+	*h_total_words = 0;
+	if (!d_coff_words) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_coff_words, 0, 8, ctx->stream)); return MCOM_OK; }
+	if (!d_soff || !d_clen) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(n + 1) * 8) + 256);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_layout, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, d_coff_words, d_clen);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan64(ctx, d_coff_words, d_coff_words, n + 1, (uint64_t*)ctx->ws))) return rc;
+	MCOM_HIP(ctx, hipMemcpyAsync(h_total_words, d_coff_words + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MCOM_OK;
+}
+
+// ---- member merge ------------------------------------------------------------------------------------------------
+struct Job { uint32_t ci, cj, pos_ori, pos; };
+
+__global__ void k_job_counts(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ moff, uint64_t *__restrict__ cnt)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nj) return;
+	if (j == nj) { cnt[j] = 0; return; }
+	const Job J = jobs[j];
+	cnt[j] = (moff[J.ci + 1] - moff[J.ci]) + (moff[J.cj + 1] - moff[J.cj]);
+}
+
+// one wave per job: the list of the contig whose anchor lies further right first, the other one shifted behind it
+// (:302-325); the sort key is the job and the low word of the member (offset<<1 | dir = cmpcluster2's order)
+__global__ __launch_bounds__(256) void k_job_fill(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ mem,
+                                                  const uint64_t *__restrict__ moff, const uint64_t *__restrict__ jmoff, int kb,
+                                                  mcom_mm128 *__restrict__ rec, unsigned int *__restrict__ err)
+{
+	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (j >= nj) return;
+	const int lane = threadIdx.x & 63;
+	const Job J = jobs[j];
+	const bool afirst = J.pos_ori >= J.pos;
+	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
+	const uint64_t sh = (uint64_t)(afirst ? J.pos_ori - J.pos : J.pos - J.pos_ori) << 1;
+	const uint64_t f0 = moff[f], nf = moff[f + 1] - f0, s0 = moff[s], ns = moff[s + 1] - s0;
+	mcom_mm128 *dst = rec + jmoff[j];
+	const uint64_t jk = (uint64_t)j << kb, kmask = (1ull << kb) - 1;
+	bool bad = false;
+	for (uint64_t t = lane; t < nf; t += 64) {
+		const uint64_t y = mem[f0 + t];
+		const uint64_t key = (uint32_t)y;
+		bad |= key > kmask;
+		mcom_mm128 r; r.x = jk | (key & kmask); r.y = y; dst[t] = r;
+	}
+	for (uint64_t t = lane; t < ns; t += 64) {
+		const uint64_t y = mem[s0 + t] + sh;
+		const uint64_t key = (uint32_t)y;
+		bad |= key > kmask;
+		mcom_mm128 r; r.x = jk | (key & kmask); r.y = y; dst[nf + t] = r;
+	}
+	if (bad) atomicOr(err, 1u);
+}
+__global__ void k_job_emit(const mcom_mm128 *__restrict__ rec, size_t n, uint64_t *__restrict__ jm)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) jm[i] = rec[i].y;
+}
+// rend = the last member's offset + L: members are sorted and all reads have one length (construct_ref2 :112-113)
+__global__ void k_job_len(const mcom_mm128 *__restrict__ rec, const uint64_t *__restrict__ jmoff, size_t nj, int L, uint64_t *__restrict__ len,
+                          unsigned long long *__restrict__ maxlen)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nj) return;
+	if (j == nj) { len[j] = 0; return; }
+	const uint64_t v = (uint64_t)((uint32_t)rec[jmoff[j + 1] - 1].y >> 1) + (uint64_t)L;
+	len[j] = v;
+	atomicMax(maxlen, (unsigned long long)v);
+}
+
+extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
+                                  int key_bits, uint64_t *d_jm, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals)
+{
+	if (!ctx || !h_totals) return MCOM_E_ARG;
+	h_totals[0] = h_totals[1] = h_totals[2] = 0;
+	if (nj == 0) {
+		if (d_jmoff) MCOM_HIP(ctx, hipMemsetAsync(d_jmoff, 0, 8, ctx->stream));
+		if (d_jroff) MCOM_HIP(ctx, hipMemsetAsync(d_jroff, 0, 8, ctx->stream));
+		return MCOM_OK;
+	}
+	if (!d_mem || !d_moff || !d_jobs || !d_jm || !d_jmoff || !d_jroff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (L < 1 || L > 256 || key_bits < 2 || key_bits > 29) return mcom_fail(ctx, MCOM_E_ARG, "bad merge arguments");
+	int jb = 1; while ((1ull << jb) < nj) ++jb;
+	if (nj >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many merges");
+	const Job *jobs = (const Job*)d_jobs;
+	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(nj + 1) * 8) + 512);
+	if (rc) return rc;
+	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
+	hipLaunchKernelGGL(k_job_counts, dim3(jblocks), dim3(256), 0, ctx->stream, jobs, nj, d_moff, d_jmoff);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan64(ctx, d_jmoff, d_jmoff, nj + 1, (uint64_t*)ctx->ws))) return rc;
+	uint64_t total = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_jmoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (total >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many members in one merge round");
+	const size_t rec_b = al256(total * sizeof(mcom_mm128));
+	if ((rc = mcom_ws_reserve(ctx, rec_b + mcom_sort_ws_bytes(total) + al256(scan64_scratch_elems(nj + 1) * 8) + 1024))) return rc;
+	WsCut w{(char*)ctx->ws, 0};
+	mcom_mm128 *rec = w.take<mcom_mm128>(total);
+	void *sortws = w.take<char>(mcom_sort_ws_bytes(total));
+	uint64_t *scr = w.take<uint64_t>(scan64_scratch_elems(nj + 1));
+	unsigned long long *meta = w.take<unsigned long long>(4);               // [0] maxlen, [1] error flag
+	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 32, ctx->stream));
+	hipLaunchKernelGGL(k_job_fill, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
+	                   (unsigned int*)(meta + 1));
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_sort_by_x(ctx, rec, total, key_bits + jb, sortws))) return rc;
+	hipLaunchKernelGGL(k_job_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rec, (size_t)total, d_jm);
+	hipLaunchKernelGGL(k_job_len, dim3(jblocks), dim3(256), 0, ctx->stream, rec, d_jmoff, nj, L, d_jroff, meta);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan64(ctx, d_jroff, d_jroff, nj + 1, scr))) return rc;
+	unsigned long long hm[2] = {0, 0}; uint64_t chars = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(hm, meta, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_jroff + nj, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (hm[1]) return mcom_fail(ctx, MCOM_E_ARG, "member offset beyond %d key bits", key_bits);
+	h_totals[0] = total; h_totals[1] = chars; h_totals[2] = hm[0];
+	return MCOM_OK;
+}
+
+// ---- consensus tiles made on the device -----------------------------------------------------------------------------
+#define MC_TILE 512
+__global__ void k_tile_counts(const uint64_t *__restrict__ jroff, size_t nj, uint32_t *__restrict__ cnt)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nj) return;
+	cnt[j] = j == nj ? 0u : (uint32_t)((jroff[j + 1] - jroff[j] + MC_TILE - 1) / MC_TILE);
+}
+__global__ void k_tile_fill(const uint32_t *__restrict__ toff, size_t nj, uint32_t *__restrict__ tjob, uint32_t *__restrict__ tidx)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nj) return;
+	const uint32_t a = toff[j], b = toff[j + 1];
+	for (uint32_t t = a; t < b; ++t) { tjob[t] = (uint32_t)j; tidx[t] = t - a; }
+}
+
+extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_jm, const uint64_t *d_jmoff,
+                                         const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (nj == 0) return MCOM_OK;
+	if (!d_packed || !d_jm || !d_jmoff || !d_jroff || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const size_t max_tiles = (size_t)(total_chars / MC_TILE) + nj + 1;
+	if (max_tiles >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many consensus tiles");
+	int rc = mcom_ws_reserve(ctx, al256((nj + 1) * 4) + al256(mcom_scan_scratch_elems(nj + 1) * 4 + 1024) + 2 * al256(max_tiles * 4) + 256);
+	if (rc) return rc;
+	WsCut w{(char*)ctx->ws, 0};
+	uint32_t *toff = w.take<uint32_t>(nj + 1);
+	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(nj + 1) + 256);
+	uint32_t *tjob = w.take<uint32_t>(max_tiles), *tidx = w.take<uint32_t>(max_tiles);
+	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
+	hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_scan_u32(ctx, toff, toff, nj + 1, scr))) return rc;
+	uint32_t nt = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&nt, toff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (nt > max_tiles) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
+	if (nt == 0) return MCOM_OK;
+	hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
+	MCOM_LAUNCH_CHECK(ctx);
+	return mcom_merge_consensus(ctx, d_packed, d_jm, d_jmoff, d_jroff, tjob, tidx, nt, L, d_refs);
+}
+
+// ---- untouched contigs ------------------------------------------------------------------------------------------------
+__global__ void k_keep_flags(const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ kf)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n) kf[i] = (i < n && !flag[i]) ? 1u : 0u;
+}
+__global__ void k_keep_index(const uint8_t *__restrict__ flag, const uint32_t *__restrict__ kpos, size_t n, uint32_t *__restrict__ keepidx)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && !flag[i]) keepidx[kpos[i]] = (uint32_t)i;
+}
+__global__ void k_keep_sizes(const uint32_t *__restrict__ keepidx, size_t nkeep, const uint64_t *__restrict__ soff, const uint64_t *__restrict__ moff,
+                             uint64_t *__restrict__ ss, uint64_t *__restrict__ ms)
+{
+	const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (u > nkeep) return;
+	if (u == nkeep) { ss[u] = 0; ms[u] = 0; return; }
+	const uint32_t i = keepidx[u];
+	ss[u] = soff[i + 1] - soff[i]; ms[u] = moff[i + 1] - moff[i];
+}
+// entries nj+1 .. nj+nkeep of the new offset arrays (entry nj, the end of the merged part, is already there)
+__global__ void k_keep_offsets(const uint64_t *__restrict__ ss, const uint64_t *__restrict__ ms, size_t nkeep, size_t nj,
+                               uint64_t *__restrict__ soff2, uint64_t *__restrict__ moff2)
+{
+	const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+	if (u > nkeep) return;
+	soff2[nj + u] = soff2[nj] + ss[u]; moff2[nj + u] = moff2[nj] + ms[u];
+}
+__global__ __launch_bounds__(256) void k_keep_copy(const uint32_t *__restrict__ keepidx, size_t nkeep, size_t nj, const uint8_t *__restrict__ seq,
+                                                   const uint64_t *__restrict__ soff, const uint64_t *__restrict__ mem, const uint64_t *__restrict__ moff,
+                                                   uint8_t *__restrict__ seq2, const uint64_t *__restrict__ soff2, uint64_t *__restrict__ mem2,
+                                                   const uint64_t *__restrict__ moff2)
+{
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (u >= nkeep) return;
+	const int lane = threadIdx.x & 63;
+	const uint32_t i = keepidx[u];
+	const uint64_t s0 = soff[i], sl = soff[i + 1] - s0, d0 = soff2[nj + u];
+	for (uint64_t t = lane; t < sl; t += 64) seq2[d0 + t] = seq[s0 + t];
+	const uint64_t m0 = moff[i], ml = moff[i + 1] - m0, e0 = moff2[nj + u];
+	for (uint64_t t = lane; t < ml; t += 64) mem2[e0 + t] = mem[m0 + t];
+}
+
+extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_soff, const uint64_t *d_mem, const uint64_t *d_moff, size_t n,
+                                  const uint8_t *d_flag, size_t nj, size_t nkeep, uint8_t *d_seq2, uint64_t *d_soff2, uint64_t *d_mem2,
+                                  uint64_t *d_moff2, uint32_t *d_keepidx, uint64_t *h_totals)
+{
+	if (!ctx || !h_totals) return MCOM_E_ARG;
+	h_totals[0] = h_totals[1] = 0;
+	if (!d_soff2 || !d_moff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (nkeep) {
+		if (!d_seq || !d_soff || !d_mem || !d_moff || !d_flag || !d_seq2 || !d_mem2 || !d_keepidx || nkeep > n) return mcom_fail(ctx, MCOM_E_ARG, "bad carry arguments");
+		int rc = mcom_ws_reserve(ctx, 2 * al256((n + 1) * 4) + al256(mcom_scan_scratch_elems(n + 1) * 4 + 1024) + 2 * al256((nkeep + 1) * 8) +
+		                                  al256(scan64_scratch_elems(nkeep + 1) * 8) + 256);
+		if (rc) return rc;
+		WsCut w{(char*)ctx->ws, 0};
+		uint32_t *kf = w.take<uint32_t>(n + 1);
+		uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(n + 1) + 256);
+		uint64_t *ss = w.take<uint64_t>(nkeep + 1), *ms = w.take<uint64_t>(nkeep + 1);
+		uint64_t *scr64 = w.take<uint64_t>(scan64_scratch_elems(nkeep + 1));
+		const unsigned nb = (unsigned)((n + 1 + 255) / 256), kb = (unsigned)((nkeep + 1 + 255) / 256);
+		hipLaunchKernelGGL(k_keep_flags, dim3(nb), dim3(256), 0, ctx->stream, d_flag, n, kf);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = mcom_scan_u32(ctx, kf, kf, n + 1, scr))) return rc;
+		uint32_t have = 0;
+		MCOM_HIP(ctx, hipMemcpyAsync(&have, kf + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (have != nkeep) return mcom_fail(ctx, MCOM_E_ARG, "%u contigs unflagged but %zu announced", have, nkeep);
+		hipLaunchKernelGGL(k_keep_index, dim3(nb), dim3(256), 0, ctx->stream, d_flag, kf, n, d_keepidx);
+		hipLaunchKernelGGL(k_keep_sizes, dim3(kb), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_soff, d_moff, ss, ms);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = scan64(ctx, ss, ss, nkeep + 1, scr64)) || (rc = scan64(ctx, ms, ms, nkeep + 1, scr64))) return rc;
+		hipLaunchKernelGGL(k_keep_offsets, dim3(kb), dim3(256), 0, ctx->stream, ss, ms, nkeep, nj, d_soff2, d_moff2);
+		hipLaunchKernelGGL(k_keep_copy, dim3((unsigned)((nkeep * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, nj, d_seq, d_soff, d_mem, d_moff,
+		                   d_seq2, d_soff2, d_mem2, d_moff2);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	MCOM_HIP(ctx, hipMemcpyAsync(&h_totals[0], d_soff2 + nj + nkeep, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&h_totals[1], d_moff2 + nj + nkeep, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MCOM_OK;
+}
+
+// ---- minimizers of untouched contigs: same records, new contig id ---------------------------------------------------
+__global__ void k_carry_counts(const uint32_t *__restrict__ keepidx, size_t nkeep, const uint32_t *__restrict__ roff, uint32_t *__restrict__ cnt)
+{
+	const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (u > nkeep) return;
+	if (u == nkeep) { cnt[u] = 0; return; }
+	const uint32_t i = keepidx[u];
+	cnt[u] = roff[i + 1] - roff[i];
+}
+__global__ __launch_bounds__(256) void k_carry_copy(const uint32_t *__restrict__ keepidx, size_t nkeep, const mcom_mm128 *__restrict__ rec,
+                                                    const uint32_t *__restrict__ roff, const uint32_t *__restrict__ sc, uint32_t first_id, uint32_t base,
+                                                    mcom_mm128 *__restrict__ rec2, uint32_t *__restrict__ roff2)
+{
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (u > nkeep) return;
+	const int lane = threadIdx.x & 63;
+	if (lane == 0) roff2[first_id + u] = base + sc[u];
+	if (u == nkeep) return;
+	const uint32_t i = keepidx[u];
+	const uint32_t r0 = roff[i], cnt = roff[i + 1] - r0, d0 = base + sc[u];
+	const uint64_t id = (uint64_t)((first_id + (uint32_t)u) << 8) << 32;     // (index<<8)+tid at tid 0, kthread_bucket.c:458
+	for (uint32_t t = lane; t < cnt; t += 64) { mcom_mm128 r = rec[r0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); rec2[d0 + t] = r; }
+}
+
+extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_keepidx, size_t nkeep,
+                                  uint32_t first_id, uint32_t base, mcom_mm128 *d_rec2, size_t cap2, uint32_t *d_roff2, uint64_t *h_total)
+{
+	if (!ctx || !h_total) return MCOM_E_ARG;
+	*h_total = base;
+	if (!d_roff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if ((uint64_t)first_id + nkeep >= (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: record ids overflow");
+	if (nkeep == 0) { MCOM_HIP(ctx, hipMemcpyAsync(d_roff2 + first_id, &base, 4, hipMemcpyHostToDevice, ctx->stream)); MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MCOM_OK; }
+	if (!d_rec || !d_roff || !d_keepidx || !d_rec2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	int rc = mcom_ws_reserve(ctx, al256((nkeep + 1) * 4) + al256(mcom_scan_scratch_elems(nkeep + 1) * 4 + 1024) + 256);
+	if (rc) return rc;
+	WsCut w{(char*)ctx->ws, 0};
+	uint32_t *sc = w.take<uint32_t>(nkeep + 1);
+	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(nkeep + 1) + 256);
+	hipLaunchKernelGGL(k_carry_counts, dim3((unsigned)((nkeep + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_roff, sc);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_scan_u32(ctx, sc, sc, nkeep + 1, scr))) return rc;
+	uint32_t kept = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&kept, sc + nkeep, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*h_total = (uint64_t)base + kept;
+	if ((uint64_t)base + kept > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", (unsigned long long)base + kept, cap2);
+	hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,
+	                   d_rec2, d_roff2);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

@@ -121,6 +121,7 @@ template <class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;            // cap in elements
 	size_t bytes_ = 0;
 	~DevBuf() { device_pool().put(p, bytes_); }
+	void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes_, o.bytes_); }
 	bool reserve(size_t n) {
 		if (n <= cap) return true;
 		device_pool().put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0;
@@ -471,43 +472,91 @@ static int sketch_contigs(P *p, size_t n, size_t total_chars, DevBuf<uint32_t> &
 	return p->fail(MCOM_E_OVERFLOW, "minimizer buffer");
 }
 
+// a contig set on the device (include/mcom.h, "the contig set of combine_cluster")
+struct DevSet {
+	DevBuf<uint8_t> seq; DevBuf<uint64_t> soff, mem, moff; DevBuf<mcom_mm128> rec; DevBuf<uint32_t> roff;
+	size_t n = 0; uint64_t chars = 0, members = 0, nrec = 0;
+	void swap(DevSet &o) {
+		seq.swap(o.seq); soff.swap(o.soff); mem.swap(o.mem); moff.swap(o.moff); rec.swap(o.rec); roff.swap(o.roff);
+		std::swap(n, o.n); std::swap(chars, o.chars); std::swap(members, o.members); std::swap(nrec, o.nrec);
+	}
+};
+
+// mm_sketch_lh_ori of contigs [0, n_first) of S into S.rec[0 ..) / S.roff[0 .. n_first]; room records stay free behind them
+static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, size_t room, uint64_t &total)
+{
+	total = 0;
+	p->stat["sketch_bases"] += 2.0 * (double)chars_first;          // one count launch + one emit launch
+	if (!S.roff.reserve(S.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	size_t cap = std::max<size_t>(1024, chars_first / 8 + n_first);
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (!S.rec.reserve(cap + room)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+		int rc = mcom_sketch_contigs(p->ctx, S.seq.p, S.soff.p, nullptr, n_first, p->rw, p->k, 0, S.roff.p, S.rec.p, S.rec.cap - room, &total);
+		if (rc == MCOM_E_OVERFLOW) { cap = total; continue; }
+		return p->gpu(rc);
+	}
+	return p->fail(MCOM_E_OVERFLOW, "minimizer buffer");
+}
+
 // ----------------------------------------------------------------------------------------------------
 // combine_cluster: merge rounds                                                kthread_cb.c:570-630
+// The contig set (consensus strings, members, minimizers) lives on the device for the whole stage; per round only the
+// passing candidate pairs come to the host, for the first-come claiming, and the claimed pairs go back.
 // ----------------------------------------------------------------------------------------------------
 extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	const int L = p->L, nt = p->host_threads;
+	const int L = p->L;
 	long pre = 0;
-	DevBuf<uint32_t> moff_all, moff_m, d_tjob, d_tidx; DevBuf<mcom_mm128> rec_all, rec_m, d_pairs;
-	DevBuf<uint64_t> d_jm, d_jmoff, d_jroff; DevBuf<uint8_t> d_jref;
-	PinVec<mcom_mm128> pairs;
+	int rc;
+	ContigSet &C = p->C;
+	DevSet A, B;
+	DevBuf<uint32_t> moff_m, d_jobs, d_keepidx; DevBuf<mcom_mm128> rec_m, d_pairs; DevBuf<uint8_t> d_flag;
+	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
+	struct Job { uint32_t ci, cj, pos_ori, pos; };
+	PinVec<Job> jobs;
+	double tl = now_ms();
+	auto lap = [&](const char *nm) { const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
+	// the set of the bucket stage goes to the device once
+	A.n = C.n(); A.chars = C.ref.size(); A.members = C.mem.size();
+	uint64_t maxlen = (uint64_t)L;
+	for (size_t i = 0; i < A.n; ++i) maxlen = std::max<uint64_t>(maxlen, C.rsize(i));
+	if (A.n) {
+		const double tg = now_ms();
+		if (!A.seq.reserve(A.chars + 16) || !A.soff.reserve(A.n + 1) || !A.mem.reserve(A.members + 1) || !A.moff.reserve(A.n + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
+		if ((rc = p->h2d(A.seq.p, (const uint8_t*)C.ref.data(), A.chars, "upload contigs")) || (rc = p->h2d(A.soff.p, C.roff.data(), A.n + 1, "upload offsets")) ||
+		    (rc = p->h2d(A.mem.p, C.mem.data(), A.members, "upload members")) || (rc = p->h2d(A.moff.p, C.moff.data(), A.n + 1, "upload offsets")) ||
+		    (rc = p->sync("upload contig set"))) return rc;
+		lap("t_cb_upload");
+		if ((rc = sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;                                  // find_next's own sketch (:234)
+		lap("t_cb_sketch");
+		p->stat["t_gpu"] += now_ms() - tg;
+	}
 	for (;;) {
-		ContigSet &S = p->C;
-		const size_t n = S.n();
+		const size_t n = A.n;
 		uint64_t n_pass = 0;
-		double tl = now_ms();
-		auto lap = [&](const char *nm) { const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
 		if (n) {
 			const double tg = now_ms();
-			int rc = upload_contigs(p, S);
-			if (rc) return rc;
-			lap("t_cb_upload");
-			uint64_t ta = 0, tm = 0;
-			if ((rc = sketch_contigs(p, n, S.ref.size(), moff_all, rec_all, ta))) return rc;                 // find_next's own sketch (:234)
-			// the first m of them are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
+			uint64_t tw = 0, tm = 0;
+			if (!p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+			if ((rc = p->gpu(mcom_contig_layout(p->ctx, A.soff.p, n, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+			p->total_words = tw;
+			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+			if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
+			if ((rc = p->gpu(mcom_pack_contigs(p->ctx, A.seq.p, A.soff.p, p->d_coff_words.p, (uint32_t)n, tw, p->d_cbits.p)))) return rc;
+			// the first m minimizers are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
 			if (!moff_m.reserve(n + 2) || !rec_m.reserve(n * (size_t)p->m + 16)) return p->fail(MCOM_E_NOMEM, "index records");
-			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, moff_all.p, rec_all.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
-			lap("t_cb_sketch");
+			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, A.roff.p, A.rec.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
+			lap("t_cb_pack");
 			mcom_idx *mi = nullptr;
 			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;           // mm_idx_generation (:580)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
-			size_t cap = std::max<size_t>(1024, ta);
+			size_t cap = std::max<size_t>(1024, A.nrec);
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-				rc = mcom_find_next_candidates(p->ctx, mi, rec_all.p, ta, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
+				rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
 				if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 				break;
 			}
@@ -515,16 +564,16 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if (rc) return p->gpu(rc);
 			lap("t_cb_findnext");
 			n_pass = hc[1];
-			pairs.resize(n_pass);
+			if (!pairs.resize(n_pass)) return p->fail(MCOM_E_NOMEM, "candidate pairs");
 			if ((rc = p->d2h(pairs.data(), d_pairs.p, n_pass, "copy candidates")) || (rc = p->sync("candidates"))) return rc;
 			lap("t_cb_d2h");
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
 		// first-come claiming in contig order (find_next :267-343 at one thread)
-		std::vector<uint8_t> flag(n, 0);
-		struct Job { uint32_t ci, cj, pos_ori, pos; };
-		std::vector<Job> jobs;
+		if (!flag.resize(n) || !jobs.resize(n / 2 + 1)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+		if (n) memset(flag.data(), 0, n);
+		size_t nj = 0;
 		for (size_t q = 0; q < n_pass;) {
 			const uint32_t ci = (uint32_t)(pairs[q].x >> 32) >> 8;
 			size_t qe = q;
@@ -533,7 +582,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				for (size_t u = q; u < qe; ++u) {
 					const uint32_t cj = (uint32_t)(pairs[u].y >> 32) >> 8;
 					if (flag[cj]) continue;
-					jobs.push_back(Job{ci, cj, (uint32_t)pairs[u].x >> 1, (uint32_t)pairs[u].y >> 1});
+					jobs[nj++] = Job{ci, cj, (uint32_t)pairs[u].x >> 1, (uint32_t)pairs[u].y >> 1};
 					flag[ci] = flag[cj] = 1;                                                // :339-343
 					break;
 				}
@@ -541,73 +590,50 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			q = qe;
 		}
 		lap("t_claim");
-		// merged member lists (:297-325), sorted by cmpcluster2 as construct_ref2 does first (:107)
-		const size_t nj = jobs.size();
-		std::vector<uint64_t> jmoff(nj + 1, 0), jroff(nj + 1, 0);
-		for (size_t j = 0; j < nj; ++j) jmoff[j + 1] = jmoff[j] + S.msize(jobs[j].ci) + S.msize(jobs[j].cj);
-		PinVec<uint64_t> jm; jm.resize(jmoff[nj]);
-		std::vector<uint64_t> jlen(nj, 0);
-		parallel_for(nt, nj, [&](int, size_t jb, size_t je) {
-			for (size_t j = jb; j < je; ++j) {
-				const Job &J = jobs[j];
-				uint64_t *dst = jm.data() + jmoff[j];
-				const uint64_t *a = S.mem.data() + S.moff[J.ci], *b = S.mem.data() + S.moff[J.cj];
-				const size_t na = S.msize(J.ci), nb = S.msize(J.cj);
-				if (J.pos_ori >= J.pos) {                                                   // :302-315
-					memcpy(dst, a, na * 8);
-					const uint64_t sh = (uint64_t)(J.pos_ori - J.pos) << 1;
-					for (size_t u = 0; u < nb; ++u) dst[na + u] = b[u] + sh;
-				} else {                                                                    // :316-325
-					memcpy(dst, b, nb * 8);
-					const uint64_t sh = (uint64_t)(J.pos - J.pos_ori) << 1;
-					for (size_t u = 0; u < na; ++u) dst[nb + u] = a[u] + sh;
-				}
-				std::stable_sort(dst, dst + na + nb, less_cluster2);
-				jlen[j] = (uint64_t)((uint32_t)dst[na + nb - 1] >> 1) + (uint64_t)L;         // rend: the last member reaches furthest
-			}
-		});
-		for (size_t j = 0; j < nj; ++j) jroff[j + 1] = jroff[j] + jlen[j];
-		lap("t_merge_members");
-		// construct_ref2 of every merged contig on the device (:327)
-		PinVec<char> jref; jref.resize(jroff[nj]);
 		if (nj) {
-			std::vector<uint32_t> tjob, tidx;
-			for (size_t j = 0; j < nj; ++j) for (uint64_t t = 0; t * 512 < jlen[j]; ++t) { tjob.push_back((uint32_t)j); tidx.push_back((uint32_t)t); }
-			if (!d_jm.reserve(jm.size() + 1) || !d_jmoff.reserve(nj + 1) || !d_jroff.reserve(nj + 1) || !d_jref.reserve(jref.size() + 16) ||
-			    !d_tjob.reserve(tjob.size() + 1) || !d_tidx.reserve(tidx.size() + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
-			int rc;
-			if ((rc = p->h2d(d_jm.p, jm.data(), jm.size(), "upload merged members")) || (rc = p->h2d(d_jmoff.p, jmoff.data(), nj + 1, "upload")) ||
-			    (rc = p->h2d(d_jroff.p, jroff.data(), nj + 1, "upload")) || (rc = p->h2d(d_tjob.p, tjob.data(), tjob.size(), "upload")) ||
-			    (rc = p->h2d(d_tidx.p, tidx.data(), tidx.size(), "upload"))) return rc;
-			if ((rc = p->gpu(mcom_merge_consensus(p->ctx, p->d_packed.p, d_jm.p, d_jmoff.p, d_jroff.p, d_tjob.p, d_tidx.p, (uint32_t)tjob.size(), L, d_jref.p)))) return rc;
-			if ((rc = p->d2h((uint8_t*)jref.data(), d_jref.p, jref.size(), "copy merged consensus")) || (rc = p->sync("merge consensus"))) return rc;
+			const double tg = now_ms();
+			const size_t nkeep = n - 2 * nj, nn = nj + nkeep;
+			if (!d_jobs.reserve(4 * nj) || !d_flag.reserve(n) || !d_keepidx.reserve(nkeep + 1) || !B.mem.reserve(A.members + 1) || !B.moff.reserve(nn + 1) ||
+			    !B.seq.reserve(A.chars + 16) || !B.soff.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+			if ((rc = p->h2d(d_jobs.p, (const uint32_t*)jobs.data(), 4 * nj, "upload claimed pairs")) || (rc = p->h2d(d_flag.p, flag.data(), n, "upload flags"))) return rc;
+			// merged member lists (:297-325) in cmpcluster2 order as construct_ref2 sorts them first (:107)
+			int kb = 2; while ((1ull << kb) < 4 * maxlen + 4) ++kb;
+			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);
+			uint64_t tot[3] = {0, 0, 0}, t2[2] = {0, 0};
+			if ((rc = p->gpu(mcom_merge_members(p->ctx, A.mem.p, A.moff.p, d_jobs.p, nj, L, kb, B.mem.p, B.moff.p, B.soff.p, tot)))) return rc;
+			maxlen = std::max(maxlen, tot[2]);
+			lap("t_merge_members");
+			// construct_ref2 of every merged contig (:327)
+			if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, B.mem.p, B.moff.p, B.soff.p, nj, tot[1], L, B.seq.p)))) return rc;
+			lap("t_merge_cons");
+			// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
+			if ((rc = p->gpu(mcom_contigs_carry(p->ctx, A.seq.p, A.soff.p, A.mem.p, A.moff.p, n, d_flag.p, nj, nkeep, B.seq.p, B.soff.p, B.mem.p, B.moff.p,
+			                                    d_keepidx.p, t2)))) return rc;
+			B.n = nn; B.chars = t2[0]; B.members = t2[1];
+			if (B.members != A.members) return p->fail(MCOM_E_ARG, "merge round lost members: %llu of %llu", (unsigned long long)B.members, (unsigned long long)A.members);
+			lap("t_cb_copy");
+			// minimizers: merged contigs are sketched, the untouched ones keep theirs under their new index
+			uint64_t tn = 0;
+			if ((rc = sketch_first(p, B, nj, tot[1], (size_t)A.nrec, tn))) return rc;
+			if ((rc = p->gpu(mcom_records_carry(p->ctx, A.rec.p, A.roff.p, d_keepidx.p, nkeep, (uint32_t)nj, (uint32_t)tn, B.rec.p, B.rec.cap, B.roff.p, &B.nrec)))) return rc;
+			lap("t_cb_sketch");
+			A.swap(B);
+			p->stat["t_gpu"] += now_ms() - tg;
 		}
-		lap("t_merge_cons");
-		// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
-		ContigSet &N = p->Cnext;
-		size_t nkeep = 0;
-		for (size_t i = 0; i < n; ++i) if (!flag[i]) ++nkeep;
-		const size_t nn = nj + nkeep;
-		N.moff.assign(nn + 1, 0); N.roff.assign(nn + 1, 0);
-		std::vector<uint32_t> keepidx; keepidx.reserve(nkeep);
-		for (size_t i = 0; i < n; ++i) if (!flag[i]) keepidx.push_back((uint32_t)i);
-		for (size_t j = 0; j < nj; ++j) { N.moff[j + 1] = jmoff[j + 1]; N.roff[j + 1] = jroff[j + 1]; }
-		for (size_t u = 0; u < nkeep; ++u) { N.moff[nj + u + 1] = N.moff[nj + u] + S.msize(keepidx[u]); N.roff[nj + u + 1] = N.roff[nj + u] + S.rsize(keepidx[u]); }
-		N.mem.resize(N.moff[nn]); N.ref.resize(N.roff[nn]);
-		if (nj) { memcpy(N.mem.data(), jm.data(), jm.size() * 8); memcpy(N.ref.data(), jref.data(), jref.size()); }
-		parallel_for(nt, nkeep, [&](int, size_t ub, size_t ue) {
-			for (size_t u = ub; u < ue; ++u) {
-				const size_t i = keepidx[u];
-				memcpy(N.mem.data() + N.moff[nj + u], S.mem.data() + S.moff[i], S.msize(i) * 8);
-				memcpy(N.ref.data() + N.roff[nj + u], S.ref.data() + S.roff[i], S.rsize(i));
-			}
-		});
-		std::swap(p->C, p->Cnext);
-		lap("t_cb_copy");
 		p->stat["merge_rounds"] += 1;
-		const long tot = (long)p->C.n();
+		const long tot = (long)A.n;
 		if (std::labs(pre - tot) < 100) break;                                              // :625
 		pre = tot;
+	}
+	// the final set comes back for Stage 2's member bookkeeping and the output stage
+	{
+		const size_t n = A.n;
+		C.moff.assign(n + 1, 0); C.roff.assign(n + 1, 0);
+		if (!C.mem.resize(A.members) || !C.ref.resize(A.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
+		if (n && ((rc = p->d2h((uint8_t*)C.ref.data(), A.seq.p, A.chars, "copy contigs")) || (rc = p->d2h(C.roff.data(), A.soff.p, n + 1, "copy offsets")) ||
+		          (rc = p->d2h(C.mem.data(), A.mem.p, A.members, "copy members")) || (rc = p->d2h(C.moff.data(), A.moff.p, n + 1, "copy offsets")) ||
+		          (rc = p->sync("copy contig set")))) return rc;
+		lap("t_cb_download");
 	}
 	p->unsorted.assign(p->C.n(), 1);
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
