@@ -58,6 +58,10 @@ def cpu_baseline(L, sample):
             "sample": tag + "; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
 
 
+KERNELS = ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows", "consensus",
+           "cindex_build", "realign_reads")
+
+
 # algorithmic bytes per unit of every timed kernel class
 def algorithmic_bytes(name, st, L, nd):
     W = (2 * L + 63) // 64
@@ -67,6 +71,10 @@ def algorithmic_bytes(name, st, L, nd):
         return (8 * W + 16) * (st["n"] + st["resketch"])
     if name == "classify_pack":        # ASCII in, packed row + class + N count out
         return (L + 8 * W + 3) * st["n"]
+    if name == "realign_reads":        # per lookup one 64-B line of keys; per verified window value + offsets + packed window; per singleton row, flag, claim
+        return 64 * st["ra_lookups"] + (8 + 24 + 8 * (W + 1)) * st["ra_verified"] + (8 * W + 9) * st["ra_singletons"]
+    if name == "cindex_build":         # table cleared (8 B per slot), per indexed position a 64-B key line read + 8 B key + 8 B value written + 2 words of packed contig
+        return 8 * st["cix_slots"] + (64 + 16 + 16) * st["cix_entries"]
     if name == "sketch_contigs":       # every contig base (1 byte) once per launch: a count launch and an emit launch per call
         return st.get("sketch_bases", 0) or None
     return None                        # radix_pass / dict_build / find_next: launches of many sizes, no single byte model
@@ -134,10 +142,11 @@ def main():
         p.prof_enable(True)
         p.pre_process()
         if timed:
-            for k in ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu"):
+            for k in ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu",
+                      "ra_lookups", "ra_verified", "ra_singletons", "cix_slots", "cix_entries"):
                 agg[k] = agg.get(k, 0.0) + p.stat(k)
             agg["n"] = agg.get("n", 0.0) + p.n
-            for name in ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows"):
+            for name in KERNELS:
                 ms, calls = p.prof_read(name)
                 agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
                 agg["calls_" + name] = agg.get("calls_" + name, 0) + calls
@@ -160,7 +169,7 @@ def main():
         nd = len(minicom_amd.hip.dict_layout(L)[0])
         st = dict(agg)
         # dominant kernel class by device time over the timed steps (HIP events on the launch stream)
-        names = ["classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows"]
+        names = list(KERNELS)
         roof = None
         for cand in sorted(names, key=lambda q: -agg.get("ms_" + q, 0.0)):   # the dominant class that has a byte model
             b = algorithmic_bytes(cand, st, L, nd)

@@ -734,6 +734,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			uint64_t ne = 0;
 			if (mcom_cindex_plan(p->n_windows, (uint32_t)nc, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
 			if (!p->d_cix_keys.reserve(8ull << p->cix_log2) || !p->d_cix_vals.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
+			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)(8ull << p->cix_log2);
 			if ((rc = p->gpu(mcom_cindex_build(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->n_windows, p->L, p->numdict,
 			                                   p->cix_log2, p->d_cix_keys.p, p->d_cix_vals.p)))) return rc;
 		}
