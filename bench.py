@@ -75,7 +75,7 @@ def algorithmic_bytes(name, st, L, nd):
         return 64 * st["ra_lookups"] + (8 + 24 + 8 * (W + 1)) * st["ra_verified"] + (8 * W + 9) * st["ra_singletons"]
     if name == "cindex_build":         # table cleared (8 B per slot), per indexed position a 64-B key line read + 8 B key + 8 B value written + 2 words of packed contig
         return 8 * st["cix_slots"] + (64 + 16 + 16) * st["cix_entries"]
-    if name == "sketch_contigs":       # every contig base (1 byte) once per launch: a count launch and an emit launch per call
+    if name == "sketch_contigs":       # every contig base (1 byte) in, 16 B per minimizer out, one launch per call
         return st.get("sketch_bases", 0) or None
     return None                        # radix_pass / dict_build / find_next: launches of many sizes, no single byte model
 

@@ -106,7 +106,8 @@ int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int
  * its record id is d_ids[c] (NULL: c<<8, the reference's (index<<8)+tid at tid 0, kthread_bucket.c:458).
  * max_per_contig > 0 keeps only the first that many (callers index the first m, kthread_bucket.c:463).
  * Out: d_moff[n+1] = start of each contig's minimizers in d_out (position order), *h_total = their
- * number.  MCOM_E_OVERFLOW (with *h_total set) when cap is too small.  1 <= w <= 128.  Synchronous.   */
+ * number.  MCOM_E_OVERFLOW (with *h_total = a capacity that is enough) when cap is too small.
+ * 1 <= w <= 128.  Synchronous.                                                                       */
 int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
                         int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
                         uint64_t *h_total);

@@ -21,7 +21,7 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 }
 
 // ------------------------------------------------------------------------------------------------
-// mm_sketch_lh_ori.  EMIT = false counts, EMIT = true writes; at most `limit` minimizers per contig.
+// mm_sketch_lh_ori, one pass.  At most `limit` minimizers per contig.
 //
 // One wave (one 64-thread workgroup) per contig, the contig taken in pieces of PIECE bases.  The reference
 // scan keeps, besides the run counter, a ring of the last w entries and "the minimum": by construction that
@@ -29,33 +29,57 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 // w entries.  What the scan emits when it stores entry t therefore depends only on entry t, on the newest
 // smallest entry of the windows ending at t-1 and at t, and (rarely) on equal hashes inside the window: every
 // entry can be handled by its own lane.
-//   phase 1   all lanes: roll the forward / reverse k-mers of PIECE/64 consecutive bases each (warmed up over
-//             the k-1 valid bases before them), hash, leave hash + flags per POSITION in LDS;
+//   phase 1   the k-mer registers of the reference hold the last k UNAMBIGUOUS bases (an ambiguous base resets the
+//             run counter but does not enter the registers, sketch.c:129-132; at the contig start they are partly
+//             zero).  The wave keeps those bases 2-bit packed in an LDS ring (bit planes from two ballots, spread
+//             with scalar bit tricks), and every lane cuts the k-mer ending at its own base out of the ring:
+//             reverse register = ~window, forward register = the window with its base order reversed.  No lane
+//             rolls a register over bases that belong to another lane;
 //   phase 1b  ballots over the flags give, per position, the run counter (valid, non-palindromic bases since
 //             the last ambiguous base) and the ENTRY index (palindromic k-mers store no entry, sketch.c:133);
 //             every position writes its entry (hash or "empty", pos<<1|strand, run) into an LDS ring by entry index;
 //   phase 1c  a sparse table over the entries (log2 w levels) gives the newest smallest entry of any window,
 //             plus a flag "another entry of the window has the same hash";
 //   phase 2   one lane per entry: the reference's statements (sketch.c:138-161) with the window minimum looked
-//             up instead of scanned; counts, wave prefix sum, then the same once more to write.
+//             up instead of scanned; counts, wave prefix sums, one atomicAdd per piece reserves room in a
+//             temporary record array, then the same once more to write.
+// A second, cheap kernel strings the pieces of every contig together in contig order (k_sketch_gather).
 // ------------------------------------------------------------------------------------------------
 #define PIECE 128
-#define PER_LANE (PIECE / 64)
+#define NGRP (PIECE / 64)
 #define ERING 256                          // >= PIECE + MAXW, power of two
 #define EMASK (ERING - 1)
 
-template <bool EMIT>
+// reverse the order of the 32 bases of a word (2-bit groups)
+__device__ __forceinline__ uint64_t rev_groups64(uint64_t x)
+{
+	x = __brevll(x);
+	return ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+}
+// bit i of the low 32 bits -> bit 2i
+__device__ __forceinline__ uint64_t spread32(uint64_t x)
+{
+	x &= 0xFFFFFFFFull;
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x << 2)) & 0x3333333333333333ull;
+	x = (x | (x << 1)) & 0x5555555555555555ull;
+	return x;
+}
+
+struct SkChunk { uint32_t start, count; };
+
 __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                        const uint32_t *__restrict__ ids, size_t n, int w, int k, uint32_t limit,
-                                                       uint32_t *__restrict__ cnt, const uint32_t *__restrict__ out_off,
-                                                       mcom_mm128 *__restrict__ out)
+                                                       const uint32_t *__restrict__ piece_off, SkChunk *__restrict__ chunks,
+                                                       mcom_mm128 *__restrict__ tmp, uint64_t arena_cap, uint32_t arena_mask,
+                                                       unsigned long long *__restrict__ cursors, uint32_t *__restrict__ cnt)
 {
-	__shared__ uint64_t PX[PIECE];          // per position of the piece: hash of the canonical k-mer ending there
-	__shared__ uint8_t PF[PIECE];           // bit0 strand, bit1 k-mer equals its reverse complement, bit2 ambiguous base
+	__shared__ uint64_t CW[8];              // the last <= 256 unambiguous bases, 2-bit packed, base q at bits 2(q%32) of word (q/32)%8
 	__shared__ uint64_t EX[ERING];          // per entry (index mod ERING): hash or U64MAX when empty
 	__shared__ uint32_t EP[ERING];          // pos<<1|strand, 0xFFFFFFFF when empty
 	__shared__ uint16_t ER[ERING];          // run counter after the entry (saturating)
-	__shared__ uint8_t SB[PIECE + 64];      // the piece's characters and the 64 before it, staged with coalesced loads
 	__shared__ uint8_t ST[8][ERING];        // sparse table, level j >= 1, entry e: bits 0-6 offset of the newest smallest
 	                                        // entry of [e, e+2^j), bit 7: another entry of that range has the same hash
 	const size_t t = blockIdx.x;
@@ -64,12 +88,18 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	const uint8_t *s = seq + off[t];
 	const int len = (int)(off[t + 1] - off[t]);
 	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
-	const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ull << (2 * k)) - 1;
-	mcom_mm128 *o = EMIT ? out + out_off[t] : nullptr;
+	const uint64_t mask = (1ull << (2 * k)) - 1;
+	SkChunk *my_chunks = chunks + piece_off[t];
+	// room in the temporary array comes from one of arena_mask+1 arenas, each with its own cursor: a single cursor would
+	// serialise tens of millions of atomics on one L2 channel
+	unsigned long long *cursor = cursors + (t & arena_mask);
+	const uint64_t arena0 = (uint64_t)(t & arena_mask) * arena_cap;
 	long ent_in = 0;                        // entries stored before the current piece   (wave uniform)
 	uint32_t run_in = 0;                    // run counter before the current piece       (wave uniform)
 	uint32_t ne_base = 0;                   // minimizers emitted before the current piece (wave uniform)
+	uint64_t qbase = 0;                     // unambiguous bases before the current group (wave uniform)
 	int LG = 0; while ((2 << LG) <= w) ++LG;                            // floor(log2 w)
+	const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));   // bits 0..lane-1
 
 	// entry e (may be negative = the ring's initial fill) as the scan sees it
 	auto EXat = [&](long e) -> uint64_t { return e < 0 ? U64MAX : EX[e & EMASK]; };
@@ -90,8 +120,8 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		dup = xa == xb ? true : db;
 		return b;                                                    // equal hashes: the newer one (b > a)
 	};
-	auto emit_at = [&](uint32_t idx, uint64_t x, uint32_t pp) {
-		if (EMIT && idx < limit) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); o[idx] = v; }
+	auto make_rec = [&](uint64_t x, uint32_t pp) -> mcom_mm128 {
+		mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); return v;
 	};
 	// what storing entry te makes the scan emit (sketch.c:138-161); put(x, p) in emission order
 	auto entry_emits = [&](long te, auto &&put) {
@@ -116,46 +146,66 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		}
 	};
 
-	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE) {
+	int piece = 0;
+	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE, ++piece) {
 		const int pe = ps + PIECE < len ? ps + PIECE : len;
-		__syncthreads();                                   // everybody is done with PX / PF / SB of the previous piece
-		const int sb0 = ps - 64;                           // contig position of SB[0]
-		for (int j = lane; j < 64 + (pe - ps); j += 64) SB[j] = sb0 + j >= 0 ? s[sb0 + j] : (uint8_t)0;
-		__syncthreads();
-		auto ch = [&](int i) -> uint8_t { return i >= sb0 ? SB[i - sb0] : s[i]; };   // global only for N-rich warm-ups
-		{   // ---- phase 1
-			const int a = ps + lane * PER_LANE;
-			if (a < pe) {
-				// k-mer registers as the reference has them before position a: the last k-1 VALID bases (ambiguous
-				// bases do not enter the registers, sketch.c:129-132), or everything from the contig start
-				int st = a, need = k - 1;
-				while (st > 0 && need > 0) { --st; if (nt4_of(ch(st)) < 4) --need; }
-				uint64_t fwd = 0, rev = 0;
-				for (int i = st; i < a; ++i) {
-					const int c = nt4_of(ch(i));
-					if (c < 4) { fwd = ((fwd << 2) | (uint64_t)c) & mask; rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1); }
-				}
-				const int b = a + PER_LANE < pe ? a + PER_LANE : pe;
-				for (int i = a; i < b; ++i) {
-					const int c = nt4_of(SB[i - sb0]);
-					uint8_t f = 0; uint64_t x = U64MAX;
-					if (c < 4) {
-						fwd = ((fwd << 2) | (uint64_t)c) & mask;
-						rev = (rev >> 2) | ((3ull ^ (uint64_t)c) << shift1);
-						if (fwd == rev) f = 2;
-						else { const uint32_t z = fwd < rev ? 0u : 1u; f = (uint8_t)z; x = mcom_hash64(z ? rev : fwd, mask); }
-					} else f = 4;
-					PX[i - ps] = x; PF[i - ps] = f;
+		__syncthreads();                                   // everybody is done with the rings of the previous piece
+		// ---- phase 1a: this piece's unambiguous bases into the packed ring
+		int cc[NGRP]; uint64_t QQ[NGRP];
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
+			const int p = ps + g * 64 + lane;
+			const int c = p < pe ? nt4_of(s[p]) : 5;                      // 4 = ambiguous, 5 = beyond the end
+			const bool valid = c < 4;
+			const uint64_t vM = __ballot(valid);
+			const int nv = __popcll(vM);
+			cc[g] = c; QQ[g] = qbase + (uint64_t)__popcll(vM & below);
+			if (nv) {
+				const int sft = 2 * (int)(qbase & 31); const uint64_t w0 = qbase >> 5;
+				if (vM == (nv == 64 ? ~0ull : ((1ull << nv) - 1))) {       // a run of bases from lane 0 on: bit planes -> 2-bit words
+					const uint64_t b0 = __ballot(valid && (c & 1)), b1 = __ballot(valid && (c & 2));
+					const uint64_t lo = spread32(b0) | (spread32(b1) << 1), hi = spread32(b0 >> 32) | (spread32(b1 >> 32) << 1);
+					if (lane == 0) {
+						if (sft == 0) { CW[w0 & 7] = lo; CW[(w0 + 1) & 7] = hi; }
+						else {
+							CW[w0 & 7] = (CW[w0 & 7] & ((1ull << sft) - 1)) | (lo << sft);
+							CW[(w0 + 1) & 7] = (lo >> (64 - sft)) | (hi << sft);
+							CW[(w0 + 2) & 7] = hi >> (64 - sft);
+						}
+					}
+				} else {                                                   // ambiguous bases inside the group (rare): one OR per base
+					if (lane == 0) {
+						if (sft) CW[w0 & 7] &= (1ull << sft) - 1;
+						for (uint64_t wi = (qbase + 31) >> 5; wi <= (qbase + (uint64_t)nv - 1) >> 5; ++wi) CW[wi & 7] = 0;
+					}
+					__syncthreads();
+					if (valid) atomicOr((unsigned long long*)&CW[(QQ[g] >> 5) & 7], (unsigned long long)c << (2 * (QQ[g] & 31)));
+					__syncthreads();
 				}
 			}
+			qbase += (uint64_t)nv;
 		}
 		__syncthreads();
-		// ---- phase 1b: run counter and entry index of every position from ballots, entries into the ring
+		// ---- phase 1 + 1b: k-mer, hash, run counter and entry index of every position; entries into the ring
 		long ent_run = ent_in; uint32_t run_run = run_in;
-#pragma unroll 1
-		for (int g = 0; g < PIECE / 64; ++g) {
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
 			const int p = ps + g * 64 + lane;
-			const uint8_t f = p < pe ? PF[p - ps] : (uint8_t)2;           // beyond the end: stores nothing, counts nothing
+			const int c = cc[g];
+			uint8_t f = 2; uint64_t x = U64MAX;                           // beyond the end: stores nothing, counts nothing
+			if (c < 4) {
+				const uint64_t Q = QQ[g];
+				const int m = Q + 1 < (uint64_t)k ? (int)(Q + 1) : k;       // bases in the registers
+				const uint64_t first = Q + 1 - (uint64_t)m;
+				const int sft = 2 * (int)(first & 31);
+				uint64_t V = CW[(first >> 5) & 7] >> sft;
+				if (sft) V |= CW[((first >> 5) + 1) & 7] << (64 - sft);
+				const uint64_t mm = (1ull << (2 * m)) - 1;
+				V &= mm;
+				const uint64_t rev = ((~V) & mm) << (2 * (k - m));
+				const uint64_t fwd = rev_groups64(V) >> (64 - 2 * m);
+				if (fwd != rev) { const uint32_t z = fwd < rev ? 0u : 1u; f = (uint8_t)z; x = mcom_hash64(z ? rev : fwd, mask); }
+			} else if (c == 4) f = 4;
 			const bool isn = (f & 4) != 0, inc = (f & 6) == 0;
 			const uint64_t nM = __ballot(isn), incM = __ballot(inc), entM = nM | incM;
 			const uint64_t lowm = lane == 63 ? ~0ull : ((2ull << lane) - 1);   // bits 0..lane
@@ -166,7 +216,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			if (isn || inc) {
 				const long te = ent_run + (long)__popcll(entM & (lowm >> 1));
 				const bool real = inc && run >= (uint32_t)k;
-				EX[te & EMASK] = real ? PX[p - ps] : U64MAX;
+				EX[te & EMASK] = real ? x : U64MAX;
 				EP[te & EMASK] = real ? (((uint32_t)p << 1) | (f & 1u)) : 0xFFFFFFFFu;
 				ER[te & EMASK] = (uint16_t)(run > 0xFFFFu ? 0xFFFFu : run);
 			}
@@ -192,33 +242,79 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 				__syncthreads();
 			}
 		}
-		// ---- phase 2: one lane per entry, 64 entries at a time, emission order = entry order
-		for (long t0 = ent_in; t0 < ent_run && ne_base < limit; t0 += 64) {
-			const long te = t0 + lane;
-			uint32_t mine = 0;
-			if (te < ent_run) entry_emits(te, [&](uint64_t, uint32_t) { ++mine; });
-			uint32_t incl = mine;
+		// ---- phase 2: one lane per entry (at most PIECE entries per piece), emission order = entry order
+		uint32_t mine[NGRP], excl[NGRP], gbase[NGRP], piece_total = 0;
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
+			const long te = ent_in + 64 * g + lane;
+			uint32_t m = 0;
+			if (te < ent_run) entry_emits(te, [&](uint64_t, uint32_t) { ++m; });
+			uint32_t incl = m;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-			const uint32_t total = __shfl(incl, 63, 64);
-			if (EMIT && mine) {
-				uint32_t idx = ne_base + incl - mine;
-				entry_emits(te, [&](uint64_t x, uint32_t pp) { emit_at(idx, x, pp); ++idx; });
-			}
-			ne_base += total;
+			mine[g] = m; excl[g] = incl - m; gbase[g] = piece_total;
+			piece_total += __shfl(incl, 63, 64);
 		}
+		const uint32_t room = limit - ne_base;
+		const uint32_t take = piece_total < room ? piece_total : room;
+		unsigned long long start = 0;
+		if (take) {
+			if (lane == 0) start = atomicAdd(cursor, (unsigned long long)take);
+			start = __shfl(start, 0, 64);
+		}
+		const bool fits = start + take <= arena_cap;
+		if (lane == 0) { SkChunk ck; ck.start = (uint32_t)(arena0 + start); ck.count = take; my_chunks[piece] = ck; }
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
+			if (!mine[g]) continue;
+			uint32_t rel = gbase[g] + excl[g];
+			entry_emits(ent_in + 64 * g + lane, [&](uint64_t x, uint32_t pp) {
+				if (rel < take && fits) tmp[arena0 + start + rel] = make_rec(x, pp);
+				++rel;
+			});
+		}
+		ne_base = ne_base + piece_total < ne_base ? 0xFFFFFFFFu : ne_base + piece_total;
 		ent_in = ent_run; run_in = run_run;
 	}
 	__syncthreads();
 	if (lane == 0) {
 		// the minimum still held after the last entry is written out (sketch.c:163-164)
+		const int tail = (len + PIECE - 1) / PIECE;                       // chunk slot behind the pieces
 		if (ne_base < limit && ent_in > 0) {
 			// the table of the last piece covers the window ending at the last entry
 			bool d; const long b = wquery(ent_in - 1, d);
 			const uint64_t bx = EXat(b);
-			if (bx != U64MAX) { emit_at(ne_base, bx, EPat(b)); ++ne_base; }
+			if (bx != U64MAX) {
+				const unsigned long long at = atomicAdd(cursor, 1ull);
+				SkChunk ck; ck.start = (uint32_t)(arena0 + at); ck.count = 1; my_chunks[tail] = ck;
+				if (at < arena_cap) tmp[arena0 + at] = make_rec(bx, EPat(b));
+				++ne_base;
+			}
 		}
-		if (!EMIT) cnt[t] = ne_base < limit ? ne_base : limit;
+		cnt[t] = ne_base < limit ? ne_base : limit;
+	}
+}
+
+__global__ void k_sketch_slots(const uint64_t *__restrict__ off, size_t n, uint32_t *__restrict__ slots)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > n) return;
+	slots[t] = t == n ? 0u : (uint32_t)((off[t + 1] - off[t] + PIECE - 1) / PIECE) + 1u;
+}
+// the chunks of contig t, in piece order, to out[moff[t] ...)
+__global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restrict__ piece_off, const SkChunk *__restrict__ chunks,
+                                                       const mcom_mm128 *__restrict__ tmp, size_t n, const uint32_t *__restrict__ moff,
+                                                       mcom_mm128 *__restrict__ out)
+{
+	const size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (t >= n) return;
+	const int lane = threadIdx.x & 63;
+	uint32_t dst = moff[t];
+	const uint32_t end = moff[t + 1];
+	for (uint32_t c = piece_off[t]; c < piece_off[t + 1] && dst < end; ++c) {
+		const SkChunk ck = chunks[c];
+		for (uint32_t i = lane; i < ck.count; i += 64) out[dst + i] = tmp[ck.start + i];
+		dst += ck.count;
 	}
 }
 
@@ -233,27 +329,50 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	if (!d_moff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 4, ctx->stream)); return MCOM_OK; }
 	if (!d_seq || !d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (cap && !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null output pointer");
 	const uint32_t limit = max_per_contig ? max_per_contig : 0xFFFFFFFFu;
-	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
-	int rc = mcom_ws_reserve(ctx, scr_b);
-	if (rc) return rc;
-	const unsigned blocks = (unsigned)n;               // one 64-lane workgroup per contig
-	// counts go to d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
-	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL((k_sketch_contigs<false>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, d_moff, nullptr, nullptr); }
-	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
-	rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, (uint32_t*)ctx->ws);
-	if (rc) return rc;
-	uint32_t total = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+	uint64_t chars = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (h_total) *h_total = total;
-	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
-	if (total == 0) return MCOM_OK;
-	if (!d_out) return mcom_fail(ctx, MCOM_E_ARG, "null output pointer");
+	const uint64_t max_slots = chars / PIECE + 2 * (uint64_t)n + 1;
+	if (max_slots >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig pieces");
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	uint32_t arenas = 1; while (arenas < 1024 && (size_t)arenas * 8192 <= n) arenas <<= 1;
+	const uint64_t arena_cap = cap / arenas;
+	const size_t slot_b = al((n + 1) * 4), scr_b = al(mcom_scan_scratch_elems(n + 1) * 4 + 1024), chunk_b = al(max_slots * sizeof(SkChunk)), cur_b = al(arenas * 8),
+	             tmp_b = al(cap * sizeof(mcom_mm128));
+	int rc = mcom_ws_reserve(ctx, slot_b + scr_b + chunk_b + cur_b + tmp_b);
+	if (rc) return rc;
+	char *base = (char*)ctx->ws;
+	uint32_t *piece_off = (uint32_t*)base;
+	uint32_t *scr = (uint32_t*)(base + slot_b);
+	SkChunk *chunks = (SkChunk*)(base + slot_b + scr_b);
+	unsigned long long *cursor = (unsigned long long*)(base + slot_b + scr_b + chunk_b);
+	mcom_mm128 *tmp = (mcom_mm128*)(base + slot_b + scr_b + chunk_b + cur_b);
+	hipLaunchKernelGGL(k_sketch_slots, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, n, piece_off);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_scan_u32(ctx, piece_off, piece_off, n + 1, scr))) return rc;
+	MCOM_HIP(ctx, hipMemsetAsync(chunks, 0, chunk_b + cur_b, ctx->stream));             // chunk table and the cursors behind it
 	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL((k_sketch_contigs<true>), dim3(blocks), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, nullptr, d_moff, d_out); }
+	hipLaunchKernelGGL(k_sketch_contigs, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, piece_off, chunks, tmp,
+	                   arena_cap, arenas - 1, cursor, d_moff); }
+	MCOM_LAUNCH_CHECK(ctx);
+	// counts are in d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
+	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
+	if ((rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, scr))) return rc;
+	std::vector<unsigned long long> fill(arenas);
+	MCOM_HIP(ctx, hipMemcpyAsync(fill.data(), cursor, arenas * 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	unsigned long long total = 0, most = 0;
+	for (unsigned long long f : fill) { total += f; most = std::max(most, f); }
+	if (h_total) *h_total = total;
+	if (total >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many minimizers");
+	if (most > arena_cap) {                           // room that is enough for every arena: the fullest one times their number
+		if (h_total) *h_total = (most + 1) * arenas;
+		return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", total, cap);
+	}
+	if (total == 0) return MCOM_OK;
+	hipLaunchKernelGGL(k_sketch_gather, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, ctx->stream, piece_off, chunks, tmp, n, d_moff, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

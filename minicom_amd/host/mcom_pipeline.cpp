@@ -460,7 +460,7 @@ static int upload_contigs(P *p, const ContigSet &C)
 static int sketch_contigs(P *p, size_t n, size_t total_chars, DevBuf<uint32_t> &moff, DevBuf<mcom_mm128> &out, uint64_t &total)
 {
 	total = 0;
-	p->stat["sketch_bases"] += 2.0 * (double)total_chars;          // one count launch + one emit launch
+	p->stat["sketch_bases"] += (double)total_chars;                // one launch per call
 	if (!moff.reserve(n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
 	size_t cap = std::max<size_t>(1024, total_chars / 8 + n);
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -486,7 +486,7 @@ struct DevSet {
 static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, size_t room, uint64_t &total)
 {
 	total = 0;
-	p->stat["sketch_bases"] += 2.0 * (double)chars_first;          // one count launch + one emit launch
+	p->stat["sketch_bases"] += (double)chars_first;                // one launch per call
 	if (!S.roff.reserve(S.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
 	size_t cap = std::max<size_t>(1024, chars_first / 8 + n_first);
 	for (int attempt = 0; attempt < 2; ++attempt) {
