@@ -15,10 +15,25 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 	return code;
 }
 
+// One spare workspace per device outlives its context: a job creates a context per run and the workspace reaches
+// gigabytes, whose hipMalloc / hipFree cost tens of milliseconds each time.
+#include <mutex>
+static std::mutex g_ws_mu;
+static struct { void *p; size_t bytes; } g_ws_spare[16] = {};
+
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
 {
 	if (bytes <= ctx->ws_bytes) return MCOM_OK;
 	if (ctx->ws) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); MCOM_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+	if (ctx->device >= 0 && ctx->device < 16) {
+		std::lock_guard<std::mutex> g(g_ws_mu);
+		if (g_ws_spare[ctx->device].p) {
+			void *sp = g_ws_spare[ctx->device].p; const size_t sb = g_ws_spare[ctx->device].bytes;
+			g_ws_spare[ctx->device].p = nullptr; g_ws_spare[ctx->device].bytes = 0;
+			if (sb >= bytes) { ctx->ws = sp; ctx->ws_bytes = sb; return MCOM_OK; }
+			(void)hipFree(sp);
+		}
+	}
 	size_t want = bytes + bytes / 8 + (1 << 20);
 	hipError_t e = hipMalloc(&ctx->ws, want);
 	if (e != hipSuccess) { ctx->ws = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "workspace of %zu bytes: %s", want, hipGetErrorString(e)); }
@@ -50,7 +65,15 @@ extern "C" int mcom_create(mcom_ctx **out, int device, void *hip_stream)
 extern "C" void mcom_destroy(mcom_ctx *ctx)
 {
 	if (!ctx) return;
-	if (ctx->ws) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->ws); }
+	if (ctx->ws) {
+		(void)hipStreamSynchronize(ctx->stream);
+		void *drop = ctx->ws;
+		if (ctx->device >= 0 && ctx->device < 16) {
+			std::lock_guard<std::mutex> g(g_ws_mu);
+			if (ctx->ws_bytes > g_ws_spare[ctx->device].bytes) { drop = g_ws_spare[ctx->device].p; g_ws_spare[ctx->device].p = ctx->ws; g_ws_spare[ctx->device].bytes = ctx->ws_bytes; }
+		}
+		if (drop) (void)hipFree(drop);
+	}
 	delete ctx;
 }
 

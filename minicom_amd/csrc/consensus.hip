@@ -19,6 +19,16 @@ __device__ __forceinline__ uint32_t obase(const uint64_t *row, int L, uint32_t d
 	return dir ? 3u - b : b;
 }
 
+// the same with the packed row spread over the wave (lane q holds word q): one global load per member instead of
+// one per base
+__device__ __forceinline__ uint32_t obase_w(uint64_t roww, int L, uint32_t dir, int i)
+{
+	const int j = dir ? L - 1 - i : i;
+	const uint64_t wv = __shfl(roww, j >> 5, 64);
+	const uint32_t b = (uint32_t)(wv >> (2 * (j & 31))) & 3u;
+	return dir ? 3u - b : b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // one 64-lane workgroup per group.  Columns: member q starts at off_q = pos0 - pos_q with pos the aligned
 // minimizer position (cmpcluster's, kthread_bucket.c:51-56); 0 <= off_q <= L - k, so 2L columns suffice.
@@ -31,13 +41,14 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
                                                         uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
                                                         uint8_t *__restrict__ refs, int ref_stride)
 {
-	__shared__ uint32_t c1[4 * GC_MAXCOL];     // counts of all members
-	__shared__ uint32_t c2[4 * GC_MAXCOL];     // counts of the kept members
-	__shared__ uint8_t rc[GC_MAXCOL];          // first consensus, 0xFF beyond its end
+	extern __shared__ uint32_t gc_lds[];
+	const int TL = 2 * L;
+	uint32_t *c1 = gc_lds;                      // counts of all members            [4][TL]
+	uint32_t *c2 = gc_lds + 4 * TL;             // counts of the kept members       [4][TL]
+	uint8_t *rc = (uint8_t*)(gc_lds + 8 * TL);  // first consensus, 0xFF beyond its end
 	const uint32_t g = blockIdx.x;
 	if (g >= ng) return;
 	const int lane = threadIdx.x;
-	const int TL = 2 * L;
 	const uint32_t m0 = goff[g], m1 = goff[g + 1];
 	for (int c = lane; c < 4 * TL; c += 64) { c1[c] = 0; c2[c] = 0; }
 	__syncthreads();
@@ -50,8 +61,12 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		if (dir) pos = L - pos + k_orig - 2;
 		if (q == m0) pos0 = pos;
 		const int off = pos0 - pos;
-		const uint64_t *row = packed + (size_t)rid * W;
-		for (int s = lane; s < L; s += 64) atomicAdd(&c1[obase(row, L, dir, s) * TL + off + s], 1u);
+		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
+		for (int s0 = 0; s0 < L; s0 += 64) {                                // whole wave in the shuffle, also past the read's end
+			const int s = s0 + lane;
+			const uint32_t b = obase_w(roww, L, dir, s < L ? s : 0);
+			if (s < L) atomicAdd(&c1[b * TL + off + s], 1u);
+		}
 	}
 	__syncthreads();
 	// first consensus: majority base per column, ties to the smaller code (strict '>'), ends at the first empty column
@@ -75,16 +90,23 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		int pos = (int)((uint32_t)y >> 1);
 		if (dir) pos = L - pos + k_orig - 2;
 		const int off = pos0 - pos;
-		const uint64_t *row = packed + (size_t)rid * W;
+		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
 		int dif = 0;
-		for (int s0 = 0; s0 < L; s0 += 64) {
-			const int s = s0 + lane;
-			const bool mis = s < L && ((off + s >= ref_len) || rc[off + s] != (uint8_t)obase(row, L, dir, s));
-			dif += __popcll(__ballot(mis));
+		uint32_t bs[4];                                                     // this lane's bases of the member (L <= 256)
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int s = u * 64 + lane;
+			bs[u] = 0;
+			if (u * 64 < L) {
+				bs[u] = obase_w(roww, L, dir, s < L ? s : 0);
+				const bool mis = s < L && ((off + s >= ref_len) || rc[off + s] != (uint8_t)bs[u]);
+				dif += __popcll(__ballot(mis));
+			}
 		}
 		const bool kp = dif <= e;                                          // kthread_bucket.c:189
 		if (kp) {
-			for (int s = lane; s < L; s += 64) atomicAdd(&c2[obase(row, L, dir, s) * TL + off + s], 1u);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int s = u * 64 + lane; if (s < L) atomicAdd(&c2[bs[u] * TL + off + s], 1u); }
 			++nk;
 			if (off + L > rend) rend = off + L;
 		}
@@ -120,7 +142,7 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	if (L < 1 || L > 256 || k_orig < 1 || k_orig > 31 || ref_stride < 2 * L) return mcom_fail(ctx, MCOM_E_ARG, "bad consensus arguments");
 	if (!d_packed || !d_members || !d_group_off || !d_keep || !d_nkept || !d_sv || !d_reflen || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL(k_group_consensus, dim3(n_groups), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off,
+	hipLaunchKernelGGL(k_group_consensus, dim3(n_groups), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off,
 	                   n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -155,10 +177,12 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 		const long off = (long)((uint32_t)y >> 1);
 		if (off >= hi) break;
 		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
-		const uint64_t *row = packed + (size_t)rid * W;
-		for (int s = lane; s < L; s += 64) {
+		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
+		for (int s0 = 0; s0 < L; s0 += 64) {
+			const int s = s0 + lane;
 			const long c = off + s;
-			if (c >= lo && c < hi) atomicAdd(&cc[obase(row, L, dir, s) * MC_TILE + (int)(c - lo)], 1u);
+			const uint32_t b = obase_w(roww, L, dir, s < L ? s : 0);
+			if (s < L && c >= lo && c < hi) atomicAdd(&cc[b * MC_TILE + (int)(c - lo)], 1u);
 		}
 	}
 	__syncthreads();

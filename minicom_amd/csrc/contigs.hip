@@ -435,6 +435,8 @@ extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 
 int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bstart, uint32_t nr, uint32_t max_range, uint32_t *d_overflow);
 int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bits, uint32_t *d_bstart);
+int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, const uint32_t *d_bstart, uint32_t nr, int low_bits,
+                           uint32_t max_range, uint32_t *d_overflow);
 
 extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out)
 {
@@ -477,7 +479,11 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 			for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
 			uint32_t *ovf = (uint32_t*)(base + sort_b + head_b + scr_b);           // the 256-byte meta area, reused below
 			(void)hipMemsetAsync(ovf, 0, 4, ctx->stream);
-			rc = mcom_flag_sort_ranges(ctx, mi->rec, bst, nb, mx, ovf);
+			if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
+				mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
+				rc = mcom_flag_sort_buckets(ctx, mi->rec, tmp, bst, nb, b, mx, ovf);
+				if (!rc) { e2 = hipMemcpyAsync(mi->rec, tmp, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e2)); }
+			} else rc = mcom_flag_sort_ranges(ctx, mi->rec, bst, nb, mx, ovf);
 			uint32_t ov = 0;
 			if (!rc) { e2 = hipMemcpyAsync(&ov, ovf, 4, hipMemcpyDeviceToHost, ctx->stream); if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "index sort: %s", hipGetErrorString(e2)); }
 			if (!rc && ov) rc = mcom_fail(ctx, MCOM_E_OVERFLOW, "index bucket sort ran out of range stack");

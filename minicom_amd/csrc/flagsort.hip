@@ -14,7 +14,7 @@ struct FsRange { uint32_t b, e, shift; };
 
 // the algorithm on an array `a` (LDS or global); bb/be: 256-entry scratch, stk: pending big ranges
 template <class PTR>
-__device__ void flag_sort_range(PTR a, uint32_t n, uint32_t *bb, uint32_t *be, FsRange *stk, uint32_t *overflow)
+__device__ void flag_sort_range(PTR a, uint32_t n, uint32_t *bb, uint32_t *be, FsRange *stk, uint32_t stk_cap, uint32_t *overflow)
 {
 	auto insertion = [&](uint32_t beg, uint32_t end) {                       // rs_insertsort (ksort.h:112-122)
 		for (uint32_t i = beg + 1; i < end; ++i) {
@@ -54,7 +54,7 @@ __device__ void flag_sort_range(PTR a, uint32_t n, uint32_t *bb, uint32_t *be, F
 			const uint32_t nxt = s > 8 ? s - 8 : 0;
 			for (int q = 0; q < 256; ++q) {
 				const uint32_t cnt = be[q] - bb[q];
-				if (cnt > 64) { if (sp < FS_STACK) stk[sp++] = FsRange{bb[q], be[q], nxt}; else *overflow = 1; }
+				if (cnt > 64) { if (sp < stk_cap) stk[sp++] = FsRange{bb[q], be[q], nxt}; else *overflow = 1; }
 				else if (cnt > 1) insertion(bb[q], be[q]);
 			}
 		}
@@ -76,12 +76,134 @@ __global__ __launch_bounds__(64) void k_flag_sort(mcom_mm128 *__restrict__ rec, 
 	if (n <= lds_cap) {
 		for (uint32_t i = threadIdx.x; i < n; i += 64) buf[i] = rec[beg + i];
 		__syncthreads();
-		if (threadIdx.x == 0) flag_sort_range(buf, n, bb, be, stk, overflow);
+		if (threadIdx.x == 0) flag_sort_range(buf, n, bb, be, stk, FS_STACK, overflow);
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < n; i += 64) rec[beg + i] = buf[i];
 	} else if (threadIdx.x == 0) {
-		flag_sort_range(rec + beg, n, bb, be, stk, overflow);
+		flag_sort_range(rec + beg, n, bb, be, stk, FS_STACK, overflow);
 	}
+}
+
+// ---- index buckets: the same algorithm on 8-byte elements, several buckets per CU ------------------------------------
+// All records of an index bucket share their low `low_bits` bits, so inside a bucket the order by x is the order by
+// x >> low_bits, which fits 48 bits; with the record's position in the bucket (16 bits) an element is one uint64 and a
+// bucket of thousands of records takes half the LDS, i.e. twice the buckets in flight for the latency-bound
+// cycle-leader permutation, which stays with one lane.  Histogram, prefix sums and the insertion sorts of the
+// sub-ranges (the bulk of the instructions) use all 64 lanes.  The records are moved once, at the end.
+#define FSB_STACK 192
+
+__global__ __launch_bounds__(64) void k_flag_sort_bucket(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out,
+                                                         const uint32_t *__restrict__ bstart, uint32_t nr, int low_bits, uint32_t lds_cap,
+                                                         uint32_t *__restrict__ overflow)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	uint32_t *bb = (uint32_t*)smem, *be = bb + 256;
+	FsRange *stk = (FsRange*)(be + 256);
+	uint64_t *E = (uint64_t*)(stk + FSB_STACK);
+	const uint32_t r = blockIdx.x;
+	if (r >= nr) return;
+	const int lane = threadIdx.x;
+	const uint32_t beg = bstart[r], end = bstart[r + 1], n = end - beg;
+	if (n == 0) return;
+	if (n > lds_cap || n > 65536u) {                                           // does not fit: the record form, in HBM
+		for (uint32_t i = lane; i < n; i += 64) out[beg + i] = in[beg + i];
+		__threadfence(); __syncthreads();
+		if (lane == 0) flag_sort_range(out + beg, n, bb, be, stk, FSB_STACK, overflow);
+		return;
+	}
+	for (uint32_t i = lane; i < n; i += 64) E[i] = ((in[beg + i].x >> low_bits) << 16) | (uint64_t)i;
+	__syncthreads();
+	auto digit = [&](uint64_t e, uint32_t s) -> uint32_t { return (uint32_t)(((((e >> 16) << low_bits) | (uint64_t)r) >> s) & 255); };
+	auto insertion = [&](uint32_t b0, uint32_t e0) {                           // rs_insertsort (ksort.h:112-122)
+		for (uint32_t i = b0 + 1; i < e0; ++i) {
+			if ((E[i] >> 16) < (E[i - 1] >> 16)) {
+				const uint64_t t = E[i]; uint32_t j = i;
+				while (j > b0 && (t >> 16) < (E[j - 1] >> 16)) { E[j] = E[j - 1]; --j; }
+				E[j] = t;
+			}
+		}
+	};
+	if (n <= 64) { if (lane == 0) insertion(0, n); }                           // radix_sort (ksort.h:153-157)
+	else {
+		uint32_t sp = 1;                                                       // uniform: every lane keeps the same count
+		if (lane == 0) stk[0] = FsRange{0, n, 56};
+		__syncthreads();
+		while (sp) {
+			const FsRange rg = stk[--sp];
+			const uint32_t rb = rg.b, re = rg.e, s = rg.shift;
+			__syncthreads();                                                   // everybody has read the entry before a push reuses it
+			// rs_sort (ksort.h:123-152): histogram and bucket bounds by all lanes
+			for (int q = lane; q < 256; q += 64) be[q] = 0;
+			__syncthreads();
+			for (uint32_t i = rb + lane; i < re; i += 64) atomicAdd(&be[digit(E[i], s)], 1u);
+			__syncthreads();
+			{
+				const uint32_t c0 = be[4 * lane], c1 = be[4 * lane + 1], c2 = be[4 * lane + 2], c3 = be[4 * lane + 3];
+				const uint32_t tot = c0 + c1 + c2 + c3;
+				uint32_t incl = tot;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+				uint32_t a = rb + incl - tot;
+				bb[4 * lane] = a; a += c0; be[4 * lane] = a;
+				bb[4 * lane + 1] = a; a += c1; be[4 * lane + 1] = a;
+				bb[4 * lane + 2] = a; a += c2; be[4 * lane + 2] = a;
+				bb[4 * lane + 3] = a; a += c3; be[4 * lane + 3] = a;
+			}
+			__syncthreads();
+			if (lane == 0) {                                                   // the cycle-leader permutation, as written
+				for (int q = 0; q < 256;) {
+					if (bb[q] != be[q]) {
+						int l = (int)digit(E[bb[q]], s);
+						if (l != q) {
+							uint64_t hold = E[bb[q]], moved;
+							do {
+								moved = hold; hold = E[bb[l]]; E[bb[l]++] = moved;
+								l = (int)digit(hold, s);
+							} while (l != q);
+							E[bb[q]++] = hold;
+						} else ++bb[q];
+					} else ++q;
+				}
+			}
+			__syncthreads();
+			if (s) {
+				const uint32_t nxt = s > 8 ? s - 8 : 0;
+				for (int q0 = 0; q0 < 256; q0 += 64) {
+					const int q = q0 + lane;
+					const uint32_t b0 = q ? be[q - 1] : rb, e0 = be[q], cnt = e0 - b0;
+					const bool big = cnt > 64;
+					const uint64_t bm = __ballot(big);
+					if (big) {
+						const uint32_t at = sp + (uint32_t)__popcll(bm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+						if (at < FSB_STACK) stk[at] = FsRange{b0, e0, nxt}; else *overflow = 1;
+					} else if (cnt > 1) insertion(b0, e0);
+					sp += (uint32_t)__popcll(bm);
+				}
+				if (sp > FSB_STACK) sp = FSB_STACK;
+			}
+			__syncthreads();
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = lane; i < n; i += 64) out[beg + i] = in[beg + (uint32_t)(E[i] & 0xFFFFull)];
+}
+
+// every bucket [d_bstart[r], d_bstart[r+1]) of d_in (all of whose x share their low low_bits bits = r) in the
+// reference's order, to d_out
+int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, const uint32_t *d_bstart, uint32_t nr, int low_bits,
+                           uint32_t max_range, uint32_t *d_overflow)
+{
+	if (nr == 0) return MCOM_OK;
+	const size_t fixed = 2 * 256 * 4 + FSB_STACK * sizeof(FsRange);
+	size_t cap = max_range < 64 ? 64 : max_range;
+	const size_t lds_max = 150 * 1024;
+	if (cap > 65536) cap = 65536;
+	if (fixed + cap * 8 > lds_max) cap = (lds_max - fixed) / 8;
+	const size_t lds = fixed + cap * 8;
+	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(k_flag_sort_bucket, dim3(nr), dim3(64), lds, ctx->stream, d_in, d_out, d_bstart, nr, low_bits, (uint32_t)cap, d_overflow);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
 }
 
 // starts of the runs of equal (x & mask) in an array sorted by that value: bstart[v] = first index with value >= v

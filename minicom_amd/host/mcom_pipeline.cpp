@@ -491,7 +491,7 @@ static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, s
 	size_t cap = std::max<size_t>(1024, chars_first / 8 + n_first);
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (!S.rec.reserve(cap + room)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-		int rc = mcom_sketch_contigs(p->ctx, S.seq.p, S.soff.p, nullptr, n_first, p->rw, p->k, 0, S.roff.p, S.rec.p, S.rec.cap - room, &total);
+		int rc = mcom_sketch_contigs(p->ctx, S.seq.p, S.soff.p, nullptr, n_first, p->rw, p->k, 0, S.roff.p, S.rec.p, cap, &total);
 		if (rc == MCOM_E_OVERFLOW) { cap = total; continue; }
 		return p->gpu(rc);
 	}
