@@ -167,7 +167,7 @@ __global__ void k_job_len(const mcom_mm128 *__restrict__ rec, const uint64_t *__
 	if (j == nj) { len[j] = 0; return; }
 	const uint64_t v = (uint64_t)((uint32_t)rec[jmoff[j + 1] - 1].y >> 1) + (uint64_t)L;
 	len[j] = v;
-	atomicMax(maxlen, (unsigned long long)v);
+	if (v > *maxlen) atomicMax(maxlen, (unsigned long long)v);          // filtered: a single address
 }
 
 extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,

@@ -513,7 +513,33 @@ extern "C" int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uin
 	return MCOM_OK;
 }
 
-// G lanes per singleton, lane q < 2*nd handles (dir = q / nd, dict = q % nd)
+// encode_ok with the work proportional to the mismatches: between two mismatches the scan only counts matches
+// (kthread_hash_realign.c:283-314), so it is enough to visit the set bits of the mismatch mask in scan order
+template <int W>
+__device__ __forceinline__ bool encode_ok_sparse(const uint64_t (&mm)[W], int L, bool rev)
+{
+	int len = 0, eq = 0, prev = -1;
+#pragma unroll
+	for (int u = 0; u < W; ++u) {
+		uint64_t m = mm[rev ? W - 1 - u : u];
+		const int wbase = 32 * (rev ? W - 1 - u : u);
+		while (m) {
+			int p;
+			if (rev) { const int b = 63 - __clzll((long long)m); m &= ~(1ull << b); p = L - 1 - (wbase + (b >> 1)); }
+			else { const int b = __ffsll((unsigned long long)m) - 1; m &= m - 1; p = wbase + (b >> 1); }
+			eq += p - prev - 1; prev = p;
+			if (eq > 1) { len += ndigits_dev(eq); eq = 0; } else len += eq;
+			++len;
+		}
+	}
+	if (len == 0) len = 1;
+	return (double)len <= (double)L * 0.4;
+}
+
+// G lanes per singleton, lane q < 2*nd handles (dir = q / nd, dict = q % nd).  A lane first collects the contig
+// positions that carry its key (a few at most), then all lanes verify their i-th candidate together: the expensive
+// part runs converged instead of once per slot of the probe loop.
+#define RR_CAND 4
 template <int W, int G>
 __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys, const uint64_t *__restrict__ vals,
                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
@@ -531,15 +557,58 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	if (live && sgflag[sg]) live = false;
 	const uint32_t el = (live && elig) ? elig[sg] : 0xFFFFFFFFu;
 	if (live && !((el >> l) & 1u)) live = false;
+	uint64_t row[W];
+#pragma unroll
+	for (int w = 0; w < W; ++w) row[w] = 0;
+	const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
+
+	// what one candidate (contig, position of the key) amounts to
+	auto verify = [&](uint64_t v) {
+		const uint32_t c = (uint32_t)(v >> 32);
+		const int64_t jj = (int64_t)(uint32_t)v - off;
+		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
+		++n_cand;
+		uint64_t win[W], x[W];
+		const uint64_t *src = cbits + coff[c] + ((2 * (uint64_t)jj) >> 6);
+		const int sh = (int)((2 * (uint64_t)jj) & 63);
+		uint64_t cur = src[0];
+#pragma unroll
+		for (int w = 0; w < W; ++w) { const uint64_t nxt = src[w + 1]; win[w] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur; cur = nxt; }
+		const int tail = 2 * L - 64 * (W - 1);
+		if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+		if (dir) {
+			uint64_t tt[W];
+#pragma unroll
+			for (int w = 0; w < W; ++w) tt[w] = ~rev_groups(win[W - 1 - w]);
+			const int drop = 64 * W - 2 * L;
+#pragma unroll
+			for (int w = 0; w < W; ++w) { const uint64_t a = tt[w], b = w + 1 < W ? tt[w + 1] : 0ull; win[w] = drop ? (a >> drop) | (b << (64 - drop)) : a; }
+			if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+		}
+		int dist = 0;
+#pragma unroll
+		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
+		if (dist > thr) return;
+		// a lower dictionary that also sees this read at this window claims the same tuple with a smaller key
+		for (int l2 = 0; l2 < l; ++l2)
+			if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;
+		uint64_t mm[W];
+#pragma unroll
+		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
+		if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) return; }                          // :393
+		else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) return;                       // :461
+		++n_pass;
+		atomicMin(&claim[sg], ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l);
+	};
+
+	uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int nc = 0;
 	if (live) {
-		uint64_t row[W];
 		const uint64_t *rb = sgbits + sg * (size_t)W;
 #pragma unroll
 		for (int w = 0; w < W; ++w) row[w] = rb[w];
 		uint64_t key = bits_key(row, g.ds[l], g.klen);
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
 		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
-		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
 		uint32_t line, stride;
 		cix_seq(key, g.log2lines, line, stride);
 		const uint32_t lmask = (1u << g.log2lines) - 1u;
@@ -554,52 +623,32 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 				if (ks[s] == CIX_EMPTY) { more = false; break; }
 				if (ks[s] != key) continue;
 				const uint64_t v = vals[(size_t)line * 8 + s];
-				const uint32_t c = (uint32_t)(v >> 32);
-				const int64_t jj = (int64_t)(uint32_t)v - off;
-				if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) continue;
-				++n_cand;
-				// window bits, as in k_realign_windows
-				uint64_t win[W], x[W];
-				const uint64_t *src = cbits + coff[c] + ((2 * (uint64_t)jj) >> 6);
-				const int sh = (int)((2 * (uint64_t)jj) & 63);
-				uint64_t cur = src[0];
-#pragma unroll
-				for (int w = 0; w < W; ++w) { const uint64_t nxt = src[w + 1]; win[w] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur; cur = nxt; }
-				const int tail = 2 * L - 64 * (W - 1);
-				if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
-				if (dir) {
-					uint64_t tt[W];
-#pragma unroll
-					for (int w = 0; w < W; ++w) tt[w] = ~rev_groups(win[W - 1 - w]);
-					const int drop = 64 * W - 2 * L;
-#pragma unroll
-					for (int w = 0; w < W; ++w) { const uint64_t a = tt[w], b = w + 1 < W ? tt[w + 1] : 0ull; win[w] = drop ? (a >> drop) | (b << (64 - drop)) : a; }
-					if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
-				}
-				int dist = 0;
-#pragma unroll
-				for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
-				if (dist > thr) continue;
-				// a lower dictionary that also sees this read at this window claims the same tuple with a smaller key
-				bool lower = false;
-				for (int l2 = 0; l2 < l; ++l2)
-					if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) { lower = true; break; }
-				if (lower) continue;
-				uint64_t mm[W];
-#pragma unroll
-				for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
-				if (!dir) { if (!encode_ok<W>(mm, L, false)) continue; }                          // :393
-				else if (thr > 24 && !encode_ok<W>(mm, L, true)) continue;                       // :461
-				++n_pass;
-				atomicMin(&claim[sg], ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l);
+				if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
+				else verify(v);                                                                // a repeat: more copies than registers
+				++nc;
 			}
 			line = (line + stride) & lmask;
 		}
 	}
+#pragma unroll 1
+	for (int i = 0; i < RR_CAND; ++i) {
+		if (!__any(nc > i)) break;
+		if (nc > i) verify(i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3);
+	}
 	if (stats) {
 		for (int o = 32; o; o >>= 1) { n_look += __shfl_xor(n_look, o); n_cand += __shfl_xor(n_cand, o); n_pass += __shfl_xor(n_pass, o); }
-		if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], n_look); if (n_cand) atomicAdd(&stats[1], n_cand); if (n_pass) atomicAdd(&stats[2], n_pass); }
+		// 1024 sets of counters: millions of atomics on three addresses would serialise on one L2 channel
+		unsigned long long *st = stats + 4 * (blockIdx.x & 1023);
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&st[0], n_look); if (n_cand) atomicAdd(&st[1], n_cand); if (n_pass) atomicAdd(&st[2], n_pass); }
 	}
+}
+
+__global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsigned long long *__restrict__ out)
+{
+	const int c = threadIdx.x;                                                       // 3 threads
+	unsigned long long s = 0;
+	for (int i = 0; i < 1024; ++i) s += sets[4 * i + c];
+	out[c] = s;
 }
 
 extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_vals, uint32_t log2lines, const uint64_t *d_sgbits,
@@ -614,19 +663,27 @@ extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, co
 	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
 	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
 	if (n_contigs == 0 || n_sg == 0) return MCOM_OK;
+	unsigned long long *sets = nullptr;
+	if (d_stats) {
+		int rcw = mcom_ws_reserve(ctx, 1024 * 4 * 8);
+		if (rcw) return rcw;
+		sets = (unsigned long long*)ctx->ws;
+		MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 1024 * 4 * 8, ctx->stream));
+	}
 	if (!d_keys || !d_vals || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || log2lines < 4 || log2lines > 31)
 		return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const int W = mcom_words_per_read(L);
 	const int G = 2 * g.nd <= 16 ? 16 : 32;
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
-#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, (unsigned long long*)d_stats); \
-	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
+#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); \
+	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
 	MCOM_LAUNCH_CHECK(ctx);
+	if (d_stats) hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
 	return MCOM_OK;
 }
 

@@ -27,7 +27,7 @@ __global__ void k_table_insert(const mcom_mm128 *__restrict__ s, size_t n, const
 		sl = (sl + 1) & capm;
 	}
 	slots[2 * (size_t)sl + 1] = (uint64_t)i | ((uint64_t)cnt << 32);
-	atomicMax(&meta[1], cnt);
+	if (cnt > meta[1]) atomicMax(&meta[1], cnt);             // filtered: one address for every key would serialise on its L2 channel
 	if (e == n) meta[0] = hpre[i] + 1;
 }
 
