@@ -251,6 +251,20 @@ int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const uint32_t *
  * d_roff[n+1] (uint32).  The claiming of find_next (:267-343) stays with the caller; these entry points do the
  * rest of a round without the data leaving the device.  All of them are synchronous.                       */
 
+/* What process_bucket does with the outcome of construct_ref (kthread_bucket.c:446-505), for the ng groups of a
+ * round after mcom_group_consensus: a group that keeps more than one member (:451) is appended to the contig set
+ * (which already holds n_have contigs, chars_have chars, members_have members; capacities seq_cap / mem_cap /
+ * off_cap entries), its members re-based to the first covered column (:349).  Every other member of a group is
+ * a reject: d_rej_rid / d_rej_group [<= rej_cap] list them in the reference's order (group ascending; inside a
+ * group the members construct_ref dropped, :194-213, then the single kept one of a dissolved group, :477-498)
+ * with the index of their group.  h_counts[4] = { new contigs, new chars, new members, rejects }.
+ * MCOM_E_OVERFLOW (counts set, nothing written) when a capacity is too small.  Synchronous.                   */
+int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, const uint32_t *d_goff, size_t ng, const uint8_t *d_keep,
+                           const uint32_t *d_nkept, const uint16_t *d_sv, const uint16_t *d_reflen, const uint8_t *d_refs,
+                           int ref_stride, uint64_t n_have, uint64_t chars_have, uint64_t members_have, uint8_t *d_seq,
+                           uint64_t seq_cap, uint64_t *d_soff, uint64_t *d_mem, uint64_t mem_cap, uint64_t *d_moff,
+                           uint64_t off_cap, uint32_t *d_rej_rid, uint32_t *d_rej_group, uint64_t rej_cap, uint64_t *h_counts);
+
 /* exclusive 64-bit prefix sums, in place allowed */
 int mcom_scan_u64(mcom_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t n);
 /* packed layout of a set for mcom_pack_contigs: d_coff_words[n+1], d_clen[n], *h_total_words                 */

@@ -65,6 +65,10 @@ static int scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, ui
 	return MCOM_OK;
 }
 
+// exported to the other translation units of the library
+size_t mcom_scan64_scratch_elems(size_t n) { return scan64_scratch_elems(n); }
+int mcom_scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch) { return scan64(ctx, in, out, n, scratch); }
+
 // bump allocator over the context workspace
 struct WsCut {
 	char *base; size_t off;

@@ -122,6 +122,15 @@ template <class T> struct DevBuf {
 	size_t bytes_ = 0;
 	~DevBuf() { device_pool().put(p, bytes_); }
 	void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes_, o.bytes_); }
+	// reserve that keeps the first `keep` elements
+	bool grow(size_t n, size_t keep, hipStream_t st) {
+		if (n <= cap) return true;
+		DevBuf nb;
+		if (!nb.reserve(n + n / 4)) return false;
+		if (keep && p) { if (hipMemcpyAsync(nb.p, p, keep * sizeof(T), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false; }
+		swap(nb);
+		return true;
+	}
 	bool reserve(size_t n) {
 		if (n <= cap) return true;
 		device_pool().put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0;
@@ -129,6 +138,16 @@ template <class T> struct DevBuf {
 		p = (T*)device_pool().get(std::max<size_t>(n * sizeof(T), 256), got);
 		if (!p) return false;
 		bytes_ = got; cap = got / sizeof(T); return true;
+	}
+};
+
+// a contig set on the device (include/mcom.h, "the contig set of combine_cluster")
+struct DevSet {
+	DevBuf<uint8_t> seq; DevBuf<uint64_t> soff, mem, moff; DevBuf<mcom_mm128> rec; DevBuf<uint32_t> roff;
+	size_t n = 0; uint64_t chars = 0, members = 0, nrec = 0;
+	void swap(DevSet &o) {
+		seq.swap(o.seq); soff.swap(o.soff); mem.swap(o.mem); moff.swap(o.moff); rec.swap(o.rec); roff.swap(o.roff);
+		std::swap(n, o.n); std::swap(chars, o.chars); std::swap(members, o.members); std::swap(nrec, o.nrec);
 	}
 };
 
@@ -182,6 +201,8 @@ struct mcomh_pipeline {
 	struct Appended { PinVec<uint32_t> contig; PinVec<uint64_t> member; };
 	std::vector<Appended> pend;
 	size_t n_pending = 0;
+	DevSet dC;                               // the contig set while it lives on the device (bucket stage -> combine_cluster)
+	bool dC_valid = false, hostC_valid = true;
 	std::thread presort;                     // the sort at the start of a pass (:318), running beside the GPU work
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
@@ -210,6 +231,7 @@ struct mcomh_pipeline {
 using P = mcomh_pipeline;
 static void join_presort(P *p);
 static int materialize(P *p);
+static int ensure_host_contigs(P *p);
 static const char ACGT[] = "ACGT";
 
 // ----------------------------------------------------------------------------------------------------
@@ -326,17 +348,19 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	const int L = p->L, nt = p->host_threads;
+	const int L = p->L;
 	const int RS = (2 * L + 15) & ~15;                       // stride of one group's consensus on the device
 	size_t n_cur = p->n;
 	DevBuf<mcom_mm128> d_cur, d_sorted; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
 	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
 	std::vector<uint32_t> resk;
-	PinVec<uint32_t> h_singles, h_sord, h_goff, h_nkept;
-	PinVec<uint64_t> h_members; PinVec<uint8_t> h_keep, h_refs; PinVec<uint16_t> h_sv, h_reflen;
-	ContigSet &C = p->C;
-	C.clear();
+	PinVec<uint32_t> h_singles, h_sord, h_rej, h_rejg;
+	DevBuf<uint32_t> d_rej, d_rejg;
+	// the contigs are built on the device (p->dC) and stay there for combine_cluster; the host copy is made on demand
+	p->C.clear();
+	p->dC.n = 0; p->dC.chars = 0; p->dC.members = 0; p->dC.nrec = 0;
+	p->dC_valid = true; p->hostC_valid = false;
 	int last_rounds = 0; long pre = 0;
 	for (int r = 1;; ++r) {
 		if (p->k - r <= 9) ++last_rounds;                                           // :584-585
@@ -358,58 +382,46 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				return p->fail(MCOM_E_NOMEM, "consensus buffers");
 			// construct_ref of every group on the device (:446)
 			if ((rc = p->gpu(mcom_group_consensus(p->ctx, p->d_packed.p, d_members.p, d_goff.p, (uint32_t)ng, L, p->k, p->e, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS)))) return rc;
-			h_singles.resize(ns); h_sord.resize(ns); h_members.resize(nm); h_goff.resize(ng + 1);
-			h_keep.resize(nm); h_nkept.resize(ng); h_sv.resize(ng); h_reflen.resize(ng); h_refs.resize(ng * (size_t)RS);
+			// groups that stay contigs (more than one member kept, :451) join the device-resident contig set; the others'
+			// members come back as rejects, in visiting order
+			DevSet &D = p->dC;
+			if (!d_rej.reserve(nm + 1) || !d_rejg.reserve(nm + 1)) return p->fail(MCOM_E_NOMEM, "reject buffers");
+			uint64_t gc[4] = {0, 0, 0, 0};
+			for (int attempt = 0; attempt < 2; ++attempt) {
+				rc = mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, D.n, D.chars, D.members,
+				                            D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc);
+				if (rc != MCOM_E_OVERFLOW) break;
+				if (!D.seq.grow(D.chars + gc[1] + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + 1, D.members, p->stream) ||
+				    !D.soff.grow(D.n + gc[0] + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+			}
+			if (rc) return p->gpu(rc);
+			D.n += gc[0]; D.chars += gc[1]; D.members += gc[2];
+			const size_t nrej = gc[3];
+			h_singles.resize(ns); h_sord.resize(ns); h_rej.resize(nrej); h_rejg.resize(nrej);
 			if ((rc = p->d2h(h_singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(h_sord.data(), d_sord.p, ns, "copy")) ||
-			    (rc = p->d2h(h_members.data(), d_members.p, nm, "copy")) || (rc = p->d2h(h_goff.data(), d_goff.p, ng + 1, "copy")) ||
-			    (rc = p->d2h(h_keep.data(), d_keep.p, nm, "copy")) || (rc = p->d2h(h_nkept.data(), d_nkept.p, ng, "copy")) ||
-			    (rc = p->d2h(h_sv.data(), d_sv.p, ng, "copy")) || (rc = p->d2h(h_reflen.data(), d_reflen.p, ng, "copy")) ||
-			    (rc = p->d2h(h_refs.data(), d_refs.p, ng * (size_t)RS, "copy")) || (rc = p->sync("round copy"))) return rc;
+			    (rc = p->d2h(h_rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(h_rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["t_bk_gpu"] += now_ms() - tg;
-			const double tb1 = now_ms();
-			// groups that stay contigs (more than one member kept, :451) get their slots by prefix sums ...
-			const size_t c0 = C.n();
-			std::vector<uint64_t> gslot(ng + 1, 0), gm(ng + 1, 0), gr(ng + 1, 0);
-			for (size_t g = 0; g < ng; ++g) {
-				const bool acc = h_nkept[g] > 1;
-				gslot[g + 1] = gslot[g] + (acc ? 1 : 0);
-				gm[g + 1] = gm[g] + (acc ? h_nkept[g] : 0);
-				gr[g + 1] = gr[g] + (acc ? h_reflen[g] : 0);
-			}
-			const size_t nc = gslot[ng], m_base = C.mem.size(), r_base = C.ref.size();
-			C.mem.resize(m_base + gm[ng]); C.ref.resize(r_base + gr[ng]);
-			C.moff.resize(c0 + nc + 1); C.roff.resize(c0 + nc + 1);
-			// ... and are filled in parallel; final offsets are relative to the first covered column (:349)
-			parallel_for(nt, ng, [&](int, size_t gb, size_t ge) {
-				for (size_t g = gb; g < ge; ++g) {
-					if (h_nkept[g] <= 1) continue;
-					uint64_t *dst = C.mem.data() + m_base + gm[g];
-					const uint64_t sv2 = (uint64_t)h_sv[g] << 1;
-					for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (h_keep[q]) *dst++ = h_members[q] - sv2;
-					memcpy(C.ref.data() + r_base + gr[g], h_refs.data() + g * (size_t)RS, h_reflen[g]);
-					C.moff[c0 + gslot[g] + 1] = m_base + gm[g + 1];
-					C.roff[c0 + gslot[g] + 1] = r_base + gr[g + 1];
-				}
-			});
 			const double tb2 = now_ms();
-			p->stat["t_bk_cons"] += tb2 - tb1;
-			// singletons and rejects in the reference's visiting order (process_bucket, :398-505)
+			// singletons and rejects in the reference's visiting order (process_bucket, :398-505): a single whose ordinal
+			// is g was visited before group g
 			size_t si = 0;
-			auto reject = [&](uint32_t rid) { if (last) p->sg.push_back(rid); else resk.push_back(rid); };
-			for (size_t g = 0; g <= ng; ++g) {
-				while (si < ns && h_sord[si] == g) p->sg.push_back(h_singles[si++]);      // groups of one (:402-413)
-				if (g == ng) break;
-				const uint32_t sz = h_goff[g + 1] - h_goff[g], nk = h_nkept[g];
-				if (nk == sz && nk > 1) continue;
-				for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (!h_keep[q]) reject((uint32_t)(h_members[q] >> 32));   // :194-213
-				if (nk == 1) for (uint32_t q = h_goff[g]; q < h_goff[g + 1]; ++q) if (h_keep[q]) reject((uint32_t)(h_members[q] >> 32)); // :477-498
+			auto singles_upto = [&](uint32_t g) {                                       // groups of one (:402-413)
+				size_t sj = si;
+				while (sj < ns && h_sord[sj] <= g) ++sj;
+				p->sg.insert(p->sg.end(), h_singles.data() + si, h_singles.data() + sj);
+				si = sj;
+			};
+			for (size_t u = 0; u < nrej; ++u) {
+				singles_upto(h_rejg[u]);
+				if (last) p->sg.push_back(h_rej[u]); else resk.push_back(h_rej[u]);
 			}
+			p->sg.insert(p->sg.end(), h_singles.data() + si, h_singles.data() + ns);
 			p->stat["t_bk_replay"] += now_ms() - tb2;
 		}
 		p->stat["rounds"] += 1;
 		if (last_rounds) ++last_rounds;                                             // :594
-		const long cr = (long)C.mem.size();
+		const long cr = (long)p->dC.members;
 		if (cr - pre < 100) ++last_rounds;                                          // :614-618
 		pre = cr;
 		if (last_rounds > 1) break;
@@ -472,15 +484,6 @@ static int sketch_contigs(P *p, size_t n, size_t total_chars, DevBuf<uint32_t> &
 	return p->fail(MCOM_E_OVERFLOW, "minimizer buffer");
 }
 
-// a contig set on the device (include/mcom.h, "the contig set of combine_cluster")
-struct DevSet {
-	DevBuf<uint8_t> seq; DevBuf<uint64_t> soff, mem, moff; DevBuf<mcom_mm128> rec; DevBuf<uint32_t> roff;
-	size_t n = 0; uint64_t chars = 0, members = 0, nrec = 0;
-	void swap(DevSet &o) {
-		seq.swap(o.seq); soff.swap(o.soff); mem.swap(o.mem); moff.swap(o.moff); rec.swap(o.rec); roff.swap(o.roff);
-		std::swap(n, o.n); std::swap(chars, o.chars); std::swap(members, o.members); std::swap(nrec, o.nrec);
-	}
-};
 
 // mm_sketch_lh_ori of contigs [0, n_first) of S into S.rec[0 ..) / S.roff[0 .. n_first]; room records stay free behind them
 static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, size_t room, uint64_t &total)
@@ -518,16 +521,21 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	PinVec<Job> jobs;
 	double tl = now_ms();
 	auto lap = [&](const char *nm) { const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
-	// the set of the bucket stage goes to the device once
-	A.n = C.n(); A.chars = C.ref.size(); A.members = C.mem.size();
-	uint64_t maxlen = (uint64_t)L;
-	for (size_t i = 0; i < A.n; ++i) maxlen = std::max<uint64_t>(maxlen, C.rsize(i));
+	// the set of the bucket stage is on the device already (kt_for_bucket); a set that only exists on the host is uploaded
+	uint64_t maxlen = 2 * (uint64_t)L;                                        // a group's consensus spans at most 2L columns
+	if (p->dC_valid) { A.swap(p->dC); p->dC_valid = false; }
+	else {
+		A.n = C.n(); A.chars = C.ref.size(); A.members = C.mem.size();
+		for (size_t i = 0; i < A.n; ++i) maxlen = std::max<uint64_t>(maxlen, C.rsize(i));
+		if (A.n) {
+			if (!A.seq.reserve(A.chars + 16) || !A.soff.reserve(A.n + 1) || !A.mem.reserve(A.members + 1) || !A.moff.reserve(A.n + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
+			if ((rc = p->h2d(A.seq.p, (const uint8_t*)C.ref.data(), A.chars, "upload contigs")) || (rc = p->h2d(A.soff.p, C.roff.data(), A.n + 1, "upload offsets")) ||
+			    (rc = p->h2d(A.mem.p, C.mem.data(), A.members, "upload members")) || (rc = p->h2d(A.moff.p, C.moff.data(), A.n + 1, "upload offsets")) ||
+			    (rc = p->sync("upload contig set"))) return rc;
+		}
+	}
 	if (A.n) {
 		const double tg = now_ms();
-		if (!A.seq.reserve(A.chars + 16) || !A.soff.reserve(A.n + 1) || !A.mem.reserve(A.members + 1) || !A.moff.reserve(A.n + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
-		if ((rc = p->h2d(A.seq.p, (const uint8_t*)C.ref.data(), A.chars, "upload contigs")) || (rc = p->h2d(A.soff.p, C.roff.data(), A.n + 1, "upload offsets")) ||
-		    (rc = p->h2d(A.mem.p, C.mem.data(), A.members, "upload members")) || (rc = p->h2d(A.moff.p, C.moff.data(), A.n + 1, "upload offsets")) ||
-		    (rc = p->sync("upload contig set"))) return rc;
 		lap("t_cb_upload");
 		if ((rc = sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;                                  // find_next's own sketch (:234)
 		lap("t_cb_sketch");
@@ -634,6 +642,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		          (rc = p->d2h(C.mem.data(), A.mem.p, A.members, "copy members")) || (rc = p->d2h(C.moff.data(), A.moff.p, n + 1, "copy offsets")) ||
 		          (rc = p->sync("copy contig set")))) return rc;
 		lap("t_cb_download");
+		p->hostC_valid = true;
 	}
 	p->unsorted.assign(p->C.n(), 1);
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
@@ -657,6 +666,23 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 
 static void join_presort(P *p) { if (p->presort.joinable()) p->presort.join(); }
 
+// the contig set of the bucket stage is built on the device; whoever wants it on the host (stage dumps, accessors,
+// a Stage 2 without combine_cluster) gets a copy here
+static int ensure_host_contigs(P *p)
+{
+	if (p->hostC_valid) return MCOM_OK;
+	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set");
+	DevSet &D = p->dC; ContigSet &C = p->C;
+	C.moff.assign(D.n + 1, 0); C.roff.assign(D.n + 1, 0);
+	if (!C.mem.resize(D.members) || !C.ref.resize(D.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
+	int rc;
+	if (D.n && ((rc = p->d2h((uint8_t*)C.ref.data(), D.seq.p, D.chars, "copy contigs")) || (rc = p->d2h(C.roff.data(), D.soff.p, D.n + 1, "copy offsets")) ||
+	            (rc = p->d2h(C.mem.data(), D.mem.p, D.members, "copy members")) || (rc = p->d2h(C.moff.data(), D.moff.p, D.n + 1, "copy offsets")) ||
+	            (rc = p->sync("copy contig set")))) return rc;
+	p->hostC_valid = true;
+	return MCOM_OK;
+}
+
 // Folds the pending appends of passes 1..m into the member lists.  The reference sorts a contig at the start of every
 // scan and appends behind it, so after m passes contig c holds
 //     stable_sort(C(c) + P_1(c) + ... + P_{m-1}(c)) + P_m(c)
@@ -664,6 +690,7 @@ static void join_presort(P *p) { if (p->presort.joinable()) p->presort.join(); }
 static int materialize(P *p)
 {
 	join_presort(p);
+	{ const int rch = ensure_host_contigs(p); if (rch) return rch; }
 	const size_t m = p->pend.size();
 	if (!m) return MCOM_OK;
 	const double t0 = now_ms();
@@ -719,6 +746,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
 	const int nt = p->host_threads;
+	{ const int rch = ensure_host_contigs(p); if (rch) return rch; }
 	mcomh_update_single(p);                                                                 // preprocess.c:203
 	ContigSet &C = p->C;
 	const size_t nc = C.n(), n_sg = p->sg.size();
@@ -936,7 +964,7 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 		if (p->n && (rc = p->hipc(hipMemcpy(rec.data(), p->d_rec.p, p->n * sizeof(mcom_mm128), hipMemcpyDeviceToHost), "copy records"))) { fclose(f); return rc; }
 		dump_buckets(f, "B0", rec);
 	}
-	if ((rc = mcomh_kt_for_bucket(p))) { fclose(f); return rc; }
+	if ((rc = mcomh_kt_for_bucket(p)) || (rc = ensure_host_contigs(p))) { fclose(f); return rc; }
 	fprintf(f, "STAGE bucket\n");
 	dump_contigs(f, "bucket", p->C);
 	dump_list(f, "sg", p->sg);
@@ -965,9 +993,10 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 }
 
 // ---- results -----------------------------------------------------------------------------------------------
-extern "C" size_t mcomh_n_contigs(const mcomh_pipeline *p) { return p ? p->C.n() : 0; }
+extern "C" size_t mcomh_n_contigs(const mcomh_pipeline *p) { if (!p) return 0; (void)ensure_host_contigs(const_cast<mcomh_pipeline*>(p)); return p->C.n(); }
 extern "C" const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len)
 {
+	(void)ensure_host_contigs(const_cast<mcomh_pipeline*>(p));
 	if (len) *len = p->C.rsize(i);
 	return p->C.ref.data() + p->C.roff[i];                 // NOT NUL-terminated: use *len
 }
