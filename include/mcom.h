@@ -265,6 +265,15 @@ int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, const uint3
                            uint64_t seq_cap, uint64_t *d_soff, uint64_t *d_mem, uint64_t mem_cap, uint64_t *d_moff,
                            uint64_t off_cap, uint32_t *d_rej_rid, uint32_t *d_rej_group, uint64_t rej_cap, uint64_t *h_counts);
 
+/* The first-come claiming of find_next (:267-343, :339-343) for a whole round: d_pairs = the passing candidate
+ * pairs in the reference's visiting order (as mcom_find_next_candidates emits them).  The reference takes a pair
+ * iff neither contig has been taken by an earlier pair, which is the greedy matching over the list; it is settled
+ * in rounds (a pair that is the earliest live pair at both of its contigs is taken).  Out: d_jobs = *h_nj x
+ * { ci, cj, pos_ori, pos } in claiming order, d_flag[n_contigs] = 1 for every claimed contig.
+ * MCOM_E_OVERFLOW when the list has not settled after max_rounds (the caller then claims sequentially).      */
+int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t n_pairs, size_t n_contigs, int max_rounds, uint32_t *d_jobs,
+                     uint8_t *d_flag, uint64_t *h_nj, int *h_rounds);
+
 /* exclusive 64-bit prefix sums, in place allowed */
 int mcom_scan_u64(mcom_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t n);
 /* packed layout of a set for mcom_pack_contigs: d_coff_words[n+1], d_clen[n], *h_total_words                 */

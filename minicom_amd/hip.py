@@ -95,6 +95,8 @@ def load_library():
     L.mcom_realign_pass_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
     L.mcom_claims_resolve.restype = i32
     L.mcom_claims_resolve.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp, C.POINTER(u64)]
+    L.mcom_claim_pairs.restype = i32
+    L.mcom_claim_pairs.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(u64), C.POINTER(i32)]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
     _lib = L
@@ -330,6 +332,16 @@ class Context:
                                                      self._p(coff, torch.int64), self._p(woff, torch.int64), int(coff.shape[0]), L,
                                                      ininumdict, thr, self._p(claim), self._p(st)))
         return claim[:n_sg], st
+
+    def claim_pairs(self, pairs, n_contigs: int, max_rounds: int = 4096):
+        """mcom_claim_pairs.  pairs: int64 [n, 2] records in visiting order.  Returns (jobs int32 [nj, 4], flag uint8 [n_contigs], rounds)."""
+        torch = _torch()
+        n = int(pairs.shape[0])
+        jobs = torch.empty((max(n_contigs // 2 + 1, 1), 4), dtype=torch.int32, device=self.device)
+        flag = torch.empty(max(n_contigs, 1), dtype=torch.uint8, device=self.device)
+        nj, rounds = C.c_uint64(), C.c_int()
+        self._check(self.lib.mcom_claim_pairs(self._h, self._p(pairs), n, n_contigs, max_rounds, self._p(jobs), self._p(flag), C.byref(nj), C.byref(rounds)))
+        return jobs[: nj.value], flag[:n_contigs], rounds.value
 
     def claims_resolve(self, claim, rids, n_contigs: int, flag):
         """mcom_claims_resolve.  flag is updated in place; returns (contig int32 [nwon], member int64 [nwon])."""

@@ -572,16 +572,25 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if (rc) return p->gpu(rc);
 			lap("t_cb_findnext");
 			n_pass = hc[1];
-			if (!pairs.resize(n_pass)) return p->fail(MCOM_E_NOMEM, "candidate pairs");
-			if ((rc = p->d2h(pairs.data(), d_pairs.p, n_pass, "copy candidates")) || (rc = p->sync("candidates"))) return rc;
-			lap("t_cb_d2h");
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
-		// first-come claiming in contig order (find_next :267-343 at one thread)
+		// first-come claiming in contig order (find_next :267-343 at one thread) = the greedy matching over the pair list,
+		// settled in rounds on the device; a list that does not settle goes through the sequential loop on the host
+		size_t nj = 0;
+		bool on_device = false;
+		if (n) {
+			if (!d_jobs.reserve(4 * (n / 2 + 1)) || !d_flag.reserve(n)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+			uint64_t njv = 0; int rounds = 0;
+			rc = mcom_claim_pairs(p->ctx, d_pairs.p, n_pass, n, 4096, d_jobs.p, d_flag.p, &njv, &rounds);
+			if (rc == MCOM_OK) { on_device = true; nj = (size_t)njv; p->stat["claim_rounds"] += rounds; }
+			else if (rc != MCOM_E_OVERFLOW) return p->gpu(rc);
+		}
+		if (!on_device) {
+		if (!pairs.resize(n_pass)) return p->fail(MCOM_E_NOMEM, "candidate pairs");
+		if ((rc = p->d2h(pairs.data(), d_pairs.p, n_pass, "copy candidates")) || (rc = p->sync("candidates"))) return rc;
 		if (!flag.resize(n) || !jobs.resize(n / 2 + 1)) return p->fail(MCOM_E_NOMEM, "claim buffers");
 		if (n) memset(flag.data(), 0, n);
-		size_t nj = 0;
 		for (size_t q = 0; q < n_pass;) {
 			const uint32_t ci = (uint32_t)(pairs[q].x >> 32) >> 8;
 			size_t qe = q;
@@ -597,13 +606,15 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			}
 			q = qe;
 		}
+		if (nj && ((rc = p->h2d(d_jobs.p, (const uint32_t*)jobs.data(), 4 * nj, "upload claimed pairs")) || (rc = p->h2d(d_flag.p, flag.data(), n, "upload flags")) ||
+		           (rc = p->sync("upload claims")))) return rc;
+		}
 		lap("t_claim");
 		if (nj) {
 			const double tg = now_ms();
 			const size_t nkeep = n - 2 * nj, nn = nj + nkeep;
-			if (!d_jobs.reserve(4 * nj) || !d_flag.reserve(n) || !d_keepidx.reserve(nkeep + 1) || !B.mem.reserve(A.members + 1) || !B.moff.reserve(nn + 1) ||
+			if (!d_keepidx.reserve(nkeep + 1) || !B.mem.reserve(A.members + 1) || !B.moff.reserve(nn + 1) ||
 			    !B.seq.reserve(A.chars + 16) || !B.soff.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
-			if ((rc = p->h2d(d_jobs.p, (const uint32_t*)jobs.data(), 4 * nj, "upload claimed pairs")) || (rc = p->h2d(d_flag.p, flag.data(), n, "upload flags"))) return rc;
 			// merged member lists (:297-325) in cmpcluster2 order as construct_ref2 sorts them first (:107)
 			int kb = 2; while ((1ull << kb) < 4 * maxlen + 4) ++kb;
 			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);

@@ -1,0 +1,77 @@
+"""GPU parity: mcom_claim_pairs (rounds of locally-earliest pairs) against the sequential first-come loop of
+find_next (kthread_cb.c:267-343) on synthetic candidate lists."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import minicom_amd
+    c = minicom_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _sequential(pairs, n):
+    """The reference's loop: contigs in index order, an unclaimed contig takes its first unclaimed candidate."""
+    flag = np.zeros(n, dtype=np.uint8)
+    jobs = []
+    for ci, cj, po, pp in pairs:
+        if flag[ci] or flag[cj]:
+            continue
+        jobs.append((ci, cj, po, pp)); flag[ci] = flag[cj] = 1
+    return jobs, flag
+
+
+def _records(pairs):
+    a = np.array(pairs, dtype=np.uint64).reshape(-1, 4)
+    x = ((a[:, 0] << np.uint64(8)) << np.uint64(32)) | (a[:, 2] << np.uint64(1))
+    y = ((a[:, 1] << np.uint64(8)) << np.uint64(32)) | (a[:, 3] << np.uint64(1)) | np.uint64(1)
+    return np.stack([x, y], axis=1)
+
+
+def _lists(rng, n, deg, near=0):
+    """Candidate lists in visiting order: contig ascending, a few candidates each (never itself)."""
+    out = []
+    for ci in range(n):
+        for _ in range(int(rng.integers(0, deg + 1))):
+            cj = int(rng.integers(0, n)) if not near else int(np.clip(ci + rng.integers(-near, near + 1), 0, n - 1))
+            if cj != ci:
+                out.append((ci, cj, int(rng.integers(0, 5000)), int(rng.integers(0, 5000))))
+    return out
+
+
+@pytest.mark.parametrize("n,deg,near", [(50, 3, 0), (5000, 4, 0), (200000, 3, 0), (3000, 2, 1), (20000, 5, 3)])
+def test_claim_rounds_equal_the_sequential_loop(ctx, n, deg, near):
+    import torch
+    rng = np.random.default_rng(n + deg + near)
+    pairs = _lists(rng, n, deg, near)
+    want_jobs, want_flag = _sequential(pairs, n)
+    rec = torch.from_numpy(_records(pairs).view(np.int64)).cuda()
+    jobs, flag, rounds = ctx.claim_pairs(rec, n)
+    ctx.sync()
+    assert jobs.cpu().numpy().tolist() == [list(j) for j in want_jobs]
+    assert np.array_equal(flag.cpu().numpy(), want_flag)
+    assert rounds >= 1 and len(want_jobs) > 5
+
+
+def test_claim_chain_needs_many_rounds_and_reports_when_it_does_not_settle(ctx):
+    """A path 0-1-2-...: every taken pair frees the next one, one round each (near = 1 lists make such chains)."""
+    import torch
+    from minicom_amd.hip import McomError
+    n = 400
+    pairs = [(i, i + 1, 7, 9) for i in range(n - 1)]
+    want_jobs, want_flag = _sequential(pairs, n)
+    rec = torch.from_numpy(_records(pairs).view(np.int64)).cuda()
+    jobs, flag, rounds = ctx.claim_pairs(rec, n)
+    assert jobs.cpu().numpy().tolist() == [list(j) for j in want_jobs] and rounds >= n // 2 - 1
+    with pytest.raises(McomError):
+        ctx.claim_pairs(rec, n, max_rounds=10)
+
+
+def test_claim_empty(ctx):
+    import torch
+    jobs, flag, rounds = ctx.claim_pairs(torch.zeros((0, 2), dtype=torch.int64, device="cuda"), 7)
+    assert jobs.shape[0] == 0 and int(flag.sum()) == 0
