@@ -219,19 +219,25 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
 
 /* The same pass driven from the singletons (results identical to mcom_realign_pass; it is the production path).
  * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed
- * ONCE: mcom_cindex_plan sizes the index (d_keys and d_vals: 8 << log2lines uint64 each) for a contig set,
- * mcom_cindex_build fills it from the packed contigs.  mcom_realign_pass_reads then looks up, for every
+ * ONCE: mcom_cindex_plan sizes the index (d_keys: 8 << log2lines uint64; a slot is a 12-bit tag of the key, the
+ * contig (24 bits) and the position (28 bits)) for a contig set, mcom_cindex_build fills it from the packed
+ * contigs (d_woff must hold n_contigs + 1 entries).  mcom_realign_pass_reads then looks up, for every
  * unflagged singleton, the key of each dictionary l at contig position window + ds[l] and the reverse complement
  * of that key at window + L - ds[l] - klen (the two probes of kthread_hash_realign.c:380 and :446 seen from the
- * read), verifies every hit like :390-393 / :458-461 and keeps the minimum claim key per singleton.
+ * read), verifies every hit like :390-393 / :458-461 -- including the exact key comparison of :385-386, which
+ * the tags leave open -- and keeps the minimum claim key per singleton.
  *   d_elig : NULL, or [n_sg] bit l set = the singleton is within the last `maxsearch` entries of its bin of
  *            dictionary l (mcom_dicts_eligible) -- only needed when some bin exceeds maxsearch (:388)
  *   d_stats: optional [3] = { lookups, windows verified, tuples passing }                                */
 int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines);
 int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                      uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys, uint64_t *d_vals);
+                      uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys);
 int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
-int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_vals, uint32_t log2lines,
+/* Screen before mcom_dicts_build: *h_may_exceed = 0 proves that no bin of any dictionary over these singletons
+ * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
+ * neither the dictionaries nor d_elig; 1 = build them and look.  Synchronous.                                */
+int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed);
+int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines,
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);

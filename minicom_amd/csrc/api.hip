@@ -21,6 +21,52 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 static std::mutex g_ws_mu;
 static struct { void *p; size_t bytes; } g_ws_spare[16] = {};
 
+// Device blocks of the library's own objects (index, dictionaries, tables, scratch) are recycled: a job builds and
+// drops dozens of multi-gigabyte objects per run, each a different size, and the driver's page-table work for a fresh
+// allocation is tens of milliseconds per gigabyte.  Blocks are rounded up so that the next round's slightly different
+// request still fits, and are only given back to the driver when an allocation fails.
+#include <map>
+static std::mutex g_blk_mu;
+static std::multimap<std::pair<int, size_t>, void*> g_blk_free;       // (device, bytes) -> block
+static std::map<void*, std::pair<int, size_t>> g_blk_live;
+
+hipError_t mcom_dmalloc(void **out, size_t bytes)
+{
+	int dev = 0; (void)hipGetDevice(&dev);
+	const size_t unit = (size_t)8 << 20;
+	size_t cap = ((bytes + bytes / 4 + unit - 1) / unit) * unit;
+	{
+		std::lock_guard<std::mutex> g(g_blk_mu);
+		auto it = g_blk_free.lower_bound(std::make_pair(dev, bytes));
+		if (it != g_blk_free.end() && it->first.first == dev && it->first.second <= 2 * cap) {
+			*out = it->second; g_blk_live[*out] = it->first; g_blk_free.erase(it); return hipSuccess;
+		}
+	}
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, cap);
+	if (e != hipSuccess) {
+		std::vector<void*> drop;
+		{ std::lock_guard<std::mutex> g(g_blk_mu); for (auto it = g_blk_free.begin(); it != g_blk_free.end();) { if (it->first.first == dev) { drop.push_back(it->second); it = g_blk_free.erase(it); } else ++it; } }
+		for (void *q : drop) (void)hipFree(q);
+		(void)hipGetLastError();
+		e = hipMalloc(&p, cap);
+		if (e != hipSuccess) { *out = nullptr; return e; }
+	}
+	std::lock_guard<std::mutex> g(g_blk_mu);
+	g_blk_live[p] = std::make_pair(dev, cap);
+	*out = p;
+	return hipSuccess;
+}
+void mcom_dfree(void *p)
+{
+	if (!p) return;
+	std::lock_guard<std::mutex> g(g_blk_mu);
+	auto it = g_blk_live.find(p);
+	if (it == g_blk_live.end()) { (void)hipFree(p); return; }
+	g_blk_free.emplace(it->second, p);
+	g_blk_live.erase(it);
+}
+
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
 {
 	if (bytes <= ctx->ws_bytes) return MCOM_OK;

@@ -428,7 +428,7 @@ extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 {
 	if (!mi) return;
 	if (ctx) (void)hipStreamSynchronize(ctx->stream);
-	if (mi->rec) (void)hipFree(mi->rec);
+	if (mi->rec) mcom_dfree(mi->rec);
 	mcom_table_free(&mi->tab);
 	delete mi;
 }
@@ -448,7 +448,7 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	mcom_idx *mi = new mcom_idx();
 	mi->n = n; mi->rec = nullptr; mi->tab.slots = nullptr;
-	hipError_t e = hipMalloc(&mi->rec, (n ? n : 1) * sizeof(mcom_mm128));
+	hipError_t e = mcom_dmalloc(&mi->rec, (n ? n : 1) * sizeof(mcom_mm128));
 	if (e != hipSuccess) { mi->rec = nullptr; mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_NOMEM, "index records: %s", hipGetErrorString(e)); }
 	const size_t sort_b = mcom_sort_ws_bytes(n);
 	const size_t head_b = ((n * 4) + 255) & ~(size_t)255;
@@ -658,10 +658,10 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	// pass 2: evaluate pairs; the workspace may move, so the offsets are kept in a fresh allocation
 	uint32_t *pair_off = nullptr, *pass = nullptr;
 	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
-	hipError_t e = hipMalloc(&pair_off, nq1 * 4);
-	if (e == hipSuccess) e = hipMalloc(&pass, (size_t)n_pairs * 4);
-	if (e != hipSuccess) { if (pair_off) (void)hipFree(pair_off); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
-	auto cleanup = [&]() { (void)hipFree(pair_off); (void)hipFree(pass); };
+	hipError_t e = mcom_dmalloc(&pair_off, nq1 * 4);
+	if (e == hipSuccess) e = mcom_dmalloc(&pass, (size_t)n_pairs * 4);
+	if (e != hipSuccess) { if (pair_off) mcom_dfree(pair_off); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
+	auto cleanup = [&]() { mcom_dfree(pair_off); mcom_dfree(pass); };
 	hipError_t e1 = hipMemcpyAsync(pair_off, hits, nq1 * 4, hipMemcpyDeviceToDevice, ctx->stream);
 	if (e1 == hipSuccess) e1 = hipMemsetAsync(pass, 0, (size_t)n_pairs * 4, ctx->stream);
 	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate buffers: %s", hipGetErrorString(e1)); }

@@ -42,6 +42,10 @@ struct McomProfScope {
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
+// recycled device blocks for the library's own objects (api.hip)
+hipError_t mcom_dmalloc(void **out, size_t bytes);
+void mcom_dfree(void *p);
+template <class T> static inline hipError_t mcom_dmalloc(T **out, size_t bytes) { return mcom_dmalloc((void**)out, bytes); }
 
 // internal helpers shared between translation units (sort.hip)
 int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch);

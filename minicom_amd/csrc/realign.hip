@@ -156,7 +156,7 @@ extern "C" void mcom_dicts_free(mcom_ctx *ctx, mcom_dicts *d)
 {
 	if (!d) return;
 	if (ctx) (void)hipStreamSynchronize(ctx->stream);
-	for (int j = 0; j < MAXDICT; ++j) { if (d->slots[j]) (void)hipFree(d->slots[j]); if (d->ids[j]) (void)hipFree(d->ids[j]); }
+	for (int j = 0; j < MAXDICT; ++j) { if (d->slots[j]) mcom_dfree(d->slots[j]); if (d->ids[j]) mcom_dfree(d->ids[j]); }
 	delete d;
 }
 
@@ -188,7 +188,7 @@ extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t 
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 	for (int j = 0; j < d->nd; ++j) {
 		McomProfScope ps_(ctx, PROF_DICT_BUILD);
-		hipError_t e2 = hipMalloc(&d->ids[j], (n ? n : 1) * 4);
+		hipError_t e2 = mcom_dmalloc(&d->ids[j], (n ? n : 1) * 4);
 		if (e2 != hipSuccess) { d->ids[j] = nullptr; mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
 		if (n) {
 			hipLaunchKernelGGL(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
@@ -382,11 +382,15 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 // reverse complement of the key at jj + L - ds[l] - klen) and verify exactly the tuples the window scan would have
 // verified.  Probes per pass drop from (2nd-1) * windows to (2nd-1) * singletons.
 //
-// Index: multi-map in HBM, lines of 8 slots (one 64-B sector of keys, a parallel array of values c<<32 | p).
+// Index: multi-map in HBM, lines of 8 slots = one 64-B sector; a slot is tag<<52 | contig<<28 | position with a
+// 12-bit tag of the key: a hit is only a candidate, the verification re-checks the key bits exactly (the XOR of read
+// and window is zero over the key's bases), so a tag collision costs one wasted verification and nothing else.
 // A key's probe sequence is line h1, h1+s, h1+2s, ... with an odd key-dependent stride s (so a repeat with 10^5
 // copies does not bury its neighbours the way linear probing would); inside a line slots fill from 0 up.  Slots are
 // never emptied, hence every copy of a key lies before the first EMPTY slot of its sequence.
 #define CIX_EMPTY (~0ull)
+#define CIX_CBITS 24
+#define CIX_PBITS 28
 struct CixGeom { uint32_t log2lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };
 
 __device__ __forceinline__ void cix_seq(uint64_t key, uint32_t log2lines, uint32_t &line, uint32_t &stride)
@@ -395,6 +399,7 @@ __device__ __forceinline__ void cix_seq(uint64_t key, uint32_t log2lines, uint32
 	line = (uint32_t)(h >> (64 - log2lines));
 	stride = ((uint32_t)(h >> 5) | 1u) & ((1u << log2lines) - 1u);
 }
+__device__ __forceinline__ uint64_t cix_tag(uint64_t key) { return (key * 0xD6E8FEB86659FD93ull) >> 52; }
 
 static int cix_geom(int L, int ininumdict, CixGeom &g)
 {
@@ -428,7 +433,7 @@ extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, i
 // contig with nw > 0 windows are indexed, the maxoff phantom positions of a contig without windows are skipped
 __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
                                                        const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_pos,
-                                                       unsigned long long *__restrict__ keys, uint64_t *__restrict__ vals)
+                                                       unsigned long long *__restrict__ keys)
 {
 	__shared__ uint32_t c0s;
 	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
@@ -453,35 +458,36 @@ __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t
 	uint32_t line, stride;
 	cix_seq(key, g.log2lines, line, stride);
 	const uint32_t lmask = (1u << g.log2lines) - 1u;
+	const unsigned long long slot = (cix_tag(key) << 52) | ((unsigned long long)c << CIX_PBITS) | p;
 	for (;;) {
 		unsigned long long *kl = keys + (size_t)line * 8;
 		for (int s = 0; s < 8; ++s) {
 			if (kl[s] != CIX_EMPTY) continue;
-			if (atomicCAS(&kl[s], CIX_EMPTY, (unsigned long long)key) == CIX_EMPTY) { vals[(size_t)line * 8 + s] = ((uint64_t)c << 32) | p; return; }
+			if (atomicCAS(&kl[s], CIX_EMPTY, slot) == CIX_EMPTY) return;
 		}
 		line = (line + stride) & lmask;
 	}
 }
 
 extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys, uint64_t *d_vals)
+                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
 {
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
-	if (!d_keys || !d_vals || log2lines < 4 || log2lines > 31) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	if (!d_keys || log2lines < 4 || log2lines > 31) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
 	g.log2lines = log2lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
 	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, (8ull << log2lines) * 8, ctx->stream));
 	if (n_contigs == 0 || n_windows == 0) return MCOM_OK;
 	if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	if (n_contigs >= (1u << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the claim key");
+	if (n_contigs >= (1u << CIX_CBITS) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the index slots");
 	const uint64_t n_pos = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;
 	if ((8ull << log2lines) * 7 < n_pos * 8) return mcom_fail(ctx, MCOM_E_ARG, "contig index too small: %llu entries", (unsigned long long)n_pos);
 	const uint64_t blocks = (n_pos + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions for one launch");
 	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, n_contigs, n_pos,
-	                   (unsigned long long*)d_keys, d_vals);
+	                   (unsigned long long*)d_keys);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -541,7 +547,7 @@ __device__ __forceinline__ bool encode_ok_sparse(const uint64_t (&mm)[W], int L,
 // part runs converged instead of once per slot of the probe loop.
 #define RR_CAND 4
 template <int W, int G>
-__global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys, const uint64_t *__restrict__ vals,
+__global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys,
                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
                                                        const uint32_t *__restrict__ elig, size_t n_sg, const uint64_t *__restrict__ cbits,
                                                        const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff, int thr,
@@ -564,8 +570,8 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 
 	// what one candidate (contig, position of the key) amounts to
 	auto verify = [&](uint64_t v) {
-		const uint32_t c = (uint32_t)(v >> 32);
-		const int64_t jj = (int64_t)(uint32_t)v - off;
+		const uint32_t c = (uint32_t)(v >> CIX_PBITS) & ((1u << CIX_CBITS) - 1u);
+		const int64_t jj = (int64_t)(v & ((1ull << CIX_PBITS) - 1)) - off;
 		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
 		++n_cand;
 		uint64_t win[W], x[W];
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		int dist = 0;
 #pragma unroll
 		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
-		if (dist > thr) return;
+		if (dist > thr || bits_key(x, g.ds[l], g.klen) != 0) return;                         // a tag is not the key: exact check here
 		// a lower dictionary that also sees this read at this window claims the same tuple with a smaller key
 		for (int l2 = 0; l2 < l; ++l2)
 			if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		uint32_t line, stride;
 		cix_seq(key, g.log2lines, line, stride);
 		const uint32_t lmask = (1u << g.log2lines) - 1u;
+		const unsigned long long tag = cix_tag(key);
 		++n_look;
 		for (bool more = true; more;) {
 			const unsigned long long *kl = keys + (size_t)line * 8;
@@ -621,8 +628,8 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 #pragma unroll
 			for (int s = 0; s < 8; ++s) {
 				if (ks[s] == CIX_EMPTY) { more = false; break; }
-				if (ks[s] != key) continue;
-				const uint64_t v = vals[(size_t)line * 8 + s];
+				if ((ks[s] >> 52) != tag) continue;
+				const uint64_t v = ks[s];
 				if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
 				else verify(v);                                                                // a repeat: more copies than registers
 				++nc;
@@ -651,7 +658,7 @@ __global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsign
 	out[c] = s;
 }
 
-extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_vals, uint32_t log2lines, const uint64_t *d_sgbits,
+extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
                                        const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
                                        const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                        uint64_t *d_claim, uint64_t *d_stats)
@@ -670,14 +677,14 @@ extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, co
 		sets = (unsigned long long*)ctx->ws;
 		MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 1024 * 4 * 8, ctx->stream));
 	}
-	if (!d_keys || !d_vals || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || log2lines < 4 || log2lines > 31)
+	if (!d_keys || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || log2lines < 4 || log2lines > 31)
 		return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const int W = mcom_words_per_read(L);
 	const int G = 2 * g.nd <= 16 ? 16 : 32;
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
-#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); \
-	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_vals, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); break;
+#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); \
+	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
@@ -741,5 +748,47 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	MCOM_HIP(ctx, hipMemcpyAsync(&hn, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*h_nwon = hn;
+	return MCOM_OK;
+}
+
+// ---- can any bin exceed maxsearch?  (cheap screen before building the dictionaries) ---------------------------------
+// The read-driven pass needs the dictionaries only to cut bins at maxsearch (:388), which almost never happens.  One
+// counter per hashed (dictionary, key) in a table of about one counter per key: a counter is an UPPER bound of its bin
+// (collisions only add), so "no counter above maxsearch" proves that no bin is.
+__global__ void k_bin_screen(const uint64_t *__restrict__ sgbits, size_t n_sg, int W, int nd, CixGeom g, uint32_t log2t, uint32_t maxsearch,
+                             unsigned int *__restrict__ table, unsigned int *__restrict__ exceeded)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t sg = t / (size_t)nd; const int l = (int)(t - sg * (size_t)nd);
+	if (sg >= n_sg) return;
+	const uint64_t key = bits_key(sgbits + sg * (size_t)W, g.ds[l], g.klen);
+	const uint64_t h = (key * 8 + (uint64_t)l + 1) * 0x9E3779B97F4A7C15ull;
+	const unsigned int old = atomicAdd(&table[h >> (64 - log2t)], 1u);
+	if (old + 1 > maxsearch) *exceeded = 1;
+}
+
+extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)
+{
+	if (!ctx || !h_may_exceed) return MCOM_E_ARG;
+	*h_may_exceed = 0;
+	if (n_sg == 0) return MCOM_OK;
+	CixGeom g;
+	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
+	const uint64_t nkeys = (uint64_t)n_sg * (uint64_t)g.nd;
+	uint32_t lg = 10; while (lg < 30 && (1ull << lg) < nkeys) ++lg;
+	int rc = mcom_ws_reserve(ctx, ((size_t)4 << lg) + 256);
+	if (rc) return rc;
+	unsigned int *table = (unsigned int*)ctx->ws;
+	unsigned int *flag = (unsigned int*)((char*)ctx->ws + ((size_t)4 << lg));
+	MCOM_HIP(ctx, hipMemsetAsync(table, 0, ((size_t)4 << lg) + 4, ctx->stream));
+	const uint64_t blocks = (nkeys + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
+	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
+	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag); }
+	MCOM_LAUNCH_CHECK(ctx);
+	unsigned int hf = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&hf, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*h_may_exceed = hf ? 1 : 0;
 	return MCOM_OK;
 }

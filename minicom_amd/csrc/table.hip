@@ -33,7 +33,7 @@ __global__ void k_table_insert(const mcom_mm128 *__restrict__ s, size_t n, const
 
 void mcom_table_free(McomTable *t)
 {
-	if (t && t->slots) { (void)hipFree(t->slots); t->slots = nullptr; }
+	if (t && t->slots) { mcom_dfree(t->slots); t->slots = nullptr; }
 }
 
 int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t)
@@ -42,7 +42,7 @@ int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t
 	uint32_t lg = 4;
 	while ((1ull << lg) < 2 * n + 16) ++lg;
 	t->log2cap = lg;
-	hipError_t e = hipMalloc(&t->slots, (size_t)16 << lg);
+	hipError_t e = mcom_dmalloc(&t->slots, (size_t)16 << lg);
 	if (e != hipSuccess) { t->slots = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "hash table of %zu bytes: %s", (size_t)16 << lg, hipGetErrorString(e)); }
 	MCOM_HIP(ctx, hipMemsetAsync(t->slots, 0xFF, (size_t)16 << lg, ctx->stream));
 	if (n == 0) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MCOM_OK; }

@@ -88,11 +88,13 @@ def load_library():
     L.mcom_cindex_plan.restype = i32
     L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u32)]
     L.mcom_cindex_build.restype = i32
-    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp, vp]
+    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp]
     L.mcom_dicts_eligible.restype = i32
     L.mcom_dicts_eligible.argtypes = [vp, vp, vp, i32, vp]
     L.mcom_realign_pass_reads.restype = i32
-    L.mcom_realign_pass_reads.argtypes = [vp, vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
+    L.mcom_realign_pass_reads.argtypes = [vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
+    L.mcom_dicts_screen.restype = i32
+    L.mcom_dicts_screen.argtypes = [vp, vp, sz, i32, i32, i32, C.POINTER(i32)]
     L.mcom_claims_resolve.restype = i32
     L.mcom_claims_resolve.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp, C.POINTER(u64)]
     L.mcom_claim_pairs.restype = i32
@@ -302,16 +304,15 @@ class Context:
         return claim[:n_sg], st
 
     def cindex_build(self, cbits, coff, woff, n_windows: int, L: int, ininumdict: int = 0):
-        """mcom_cindex_plan + mcom_cindex_build.  Returns (keys int64, vals int64, log2lines)."""
+        """mcom_cindex_plan + mcom_cindex_build.  Returns (slots int64, log2lines)."""
         torch = _torch()
         ne, lg = C.c_uint64(), C.c_uint32()
         n_contigs = int(coff.shape[0])
         self._check(self.lib.mcom_cindex_plan(int(n_windows), n_contigs, L, ininumdict, C.byref(ne), C.byref(lg)))
         keys = torch.empty(8 << lg.value, dtype=torch.int64, device=self.device)
-        vals = torch.empty(8 << lg.value, dtype=torch.int64, device=self.device)
         self._check(self.lib.mcom_cindex_build(self._h, self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
-                                               n_contigs, int(n_windows), L, ininumdict, lg.value, self._p(keys), self._p(vals)))
-        return keys, vals, lg.value
+                                               n_contigs, int(n_windows), L, ininumdict, lg.value, self._p(keys)))
+        return keys, lg.value
 
     def dicts_eligible(self, dicts, sgbits, maxsearch: int):
         torch = _torch()
@@ -319,15 +320,22 @@ class Context:
         self._check(self.lib.mcom_dicts_eligible(self._h, dicts._h, self._p(sgbits, torch.int64), maxsearch, self._p(el)))
         return el
 
+    def dicts_screen(self, sgbits, L: int, maxsearch: int, ininumdict: int = 0) -> bool:
+        """mcom_dicts_screen: False proves that no dictionary bin exceeds maxsearch."""
+        torch = _torch()
+        out = C.c_int(0)
+        self._check(self.lib.mcom_dicts_screen(self._h, self._p(sgbits, torch.int64), int(sgbits.shape[0]), L, ininumdict, maxsearch, C.byref(out)))
+        return bool(out.value)
+
     def realign_pass_reads(self, cindex, sgbits, sgflag, cbits, coff, woff, L: int, thr: int, ininumdict: int = 0, elig=None,
                            stats: bool = False):
         """mcom_realign_pass_reads.  cindex = cindex_build's result.  Returns (claim int64 [n_sg], stats or None)."""
         torch = _torch()
-        keys, vals, lg = cindex
+        keys, lg = cindex
         n_sg = int(sgbits.shape[0])
         claim = torch.empty(max(n_sg, 1), dtype=torch.int64, device=self.device)
         st = torch.zeros(3, dtype=torch.int64, device=self.device) if stats else None
-        self._check(self.lib.mcom_realign_pass_reads(self._h, self._p(keys), self._p(vals), lg, self._p(sgbits, torch.int64),
+        self._check(self.lib.mcom_realign_pass_reads(self._h, self._p(keys), lg, self._p(sgbits, torch.int64),
                                                      self._p(sgflag, torch.uint8), self._p(elig), n_sg, self._p(cbits, torch.int64),
                                                      self._p(coff, torch.int64), self._p(woff, torch.int64), int(coff.shape[0]), L,
                                                      ininumdict, thr, self._p(claim), self._p(st)))

@@ -208,7 +208,7 @@ struct mcomh_pipeline {
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
-	DevBuf<uint64_t> d_cix_keys, d_cix_vals; uint32_t cix_log2 = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
+	DevBuf<uint64_t> d_cix_keys; uint32_t cix_log2 = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
 	std::map<std::string, double> stat;
@@ -772,10 +772,10 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if (!p->window_scan) {
 			uint64_t ne = 0;
 			if (mcom_cindex_plan(p->n_windows, (uint32_t)nc, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
-			if (!p->d_cix_keys.reserve(8ull << p->cix_log2) || !p->d_cix_vals.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
+			if (!p->d_cix_keys.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
 			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)(8ull << p->cix_log2);
 			if ((rc = p->gpu(mcom_cindex_build(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->n_windows, p->L, p->numdict,
-			                                   p->cix_log2, p->d_cix_keys.p, p->d_cix_vals.p)))) return rc;
+			                                   p->cix_log2, p->d_cix_keys.p)))) return rc;
 		}
 		p->stage2_uploaded = true;
 	}
@@ -806,13 +806,18 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
 		PinVec<uint8_t> pf;
 		if (!pf.resize(n_sg)) return p->fail(MCOM_E_NOMEM, "flags");
+		// constructdictionary_realign: the read-driven pass needs the dictionaries only where a bin is cut at maxsearch;
+		// a screen with hashed counters proves (nearly always) that none is
 		mcom_dicts *dicts = nullptr;
-		if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;               // constructdictionary_realign
 		bool big = false;
-		{
+		int may_exceed = 1;
+		if (!p->window_scan && (rc = p->gpu(mcom_dicts_screen(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, &may_exceed)))) return rc;
+		if (may_exceed) {
+			if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;
 			int nd = 0; uint32_t nk[16], mb[16];
 			mcom_dicts_info(dicts, &nd, nk, mb);
 			for (int j = 0; j < nd; ++j) if (mb[j] > (uint32_t)p->maxsearch) { p->stat["big_bins"] += 1; big = true; }
+			p->stat["dict_builds"] += 1;
 		}
 		if (p->window_scan)
 			rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
@@ -825,7 +830,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				else rc = p->gpu(mcom_dicts_eligible(p->ctx, dicts, d_sgbits.p, p->maxsearch, d_elig.p));
 			}
 			if (!rc && !d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
-			if (!rc) rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->d_cix_vals.p, p->cix_log2, d_sgbits.p, d_flag.p, big ? d_elig.p : nullptr,
+			if (!rc) rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits.p, d_flag.p, big ? d_elig.p : nullptr,
 			                                             n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
 			PinVec<uint64_t> hst; hst.resize(3);
 			if (!rc) rc = p->d2h(hst.data(), d_st.p, 3, "copy pass counters");

@@ -208,6 +208,9 @@ def test_read_driven_pass_equals_window_scan_also_with_bins_above_maxsearch(ctx,
     cix = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
     if maxsearch < 500:
         assert max(dicts.maxbin) > maxsearch
+    # the screen may only say "no bin exceeds" when that is true, and must say so for a generous limit
+    assert ctx.dicts_screen(sgbits, L, maxsearch) or max(dicts.maxbin) <= maxsearch
+    assert not ctx.dicts_screen(sgbits, L, 100000)
     for thr in (4, 12, 28):
         want, _ = ctx.realign_pass(dicts, sgbits, flag, d_cbits, d_coff, d_woff, int(nwin.sum()), thr, maxsearch)
         elig = ctx.dicts_eligible(dicts, sgbits, maxsearch) if max(dicts.maxbin) > maxsearch else None
