@@ -203,6 +203,9 @@ struct mcomh_pipeline {
 	size_t n_pending = 0;
 	DevSet dC;                               // the contig set while it lives on the device (bucket stage -> combine_cluster)
 	bool dC_valid = false, hostC_valid = true;
+	hipStream_t copy_stream = nullptr;       // the final set of combine_cluster comes to the host beside Stage 2's GPU work
+	hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+	bool copy_pending = false;
 	std::thread presort;                     // the sort at the start of a pass (:318), running beside the GPU work
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
@@ -231,7 +234,7 @@ struct mcomh_pipeline {
 using P = mcomh_pipeline;
 static void join_presort(P *p);
 static int materialize(P *p);
-static int ensure_host_contigs(P *p);
+static int ensure_host_contigs(P *p, bool wait_data = true);
 static const char ACGT[] = "ACGT";
 
 // ----------------------------------------------------------------------------------------------------
@@ -249,6 +252,8 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	P *p = new P();
 	p->stream = (hipStream_t)hip_stream;
 	int rc = mcom_create(&p->ctx, device, hip_stream);
+	if (!rc && (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) != hipSuccess ||
+	            hipEventCreateWithFlags(&p->ev_copied, hipEventDisableTiming) != hipSuccess)) rc = MCOM_E_HIP;
 	if (rc) { delete p; return rc; }
 	p->n = n; p->L = L; p->W = (2 * L + 63) / 64; p->NW = (L + 63) / 64;
 	p->k = pp->k > 0 ? pp->k : (L < 80 ? 17 : 31);                                  // minicommain.c:92-114
@@ -295,6 +300,9 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (!p) return;
 	join_presort(p);
 	(void)hipStreamSynchronize(p->stream);
+	if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+	if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+	if (p->ev_copied) (void)hipEventDestroy(p->ev_copied);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
 }
@@ -644,16 +652,23 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		if (std::labs(pre - tot) < 100) break;                                              // :625
 		pre = tot;
 	}
-	// the final set comes back for Stage 2's member bookkeeping and the output stage
+	// the final set stays on the device for Stage 2; its copy for the member bookkeeping and the output stage travels on
+	// a second stream beside Stage 2's kernels (offsets first, they are needed at once)
 	{
 		const size_t n = A.n;
 		C.moff.assign(n + 1, 0); C.roff.assign(n + 1, 0);
 		if (!C.mem.resize(A.members) || !C.ref.resize(A.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
-		if (n && ((rc = p->d2h((uint8_t*)C.ref.data(), A.seq.p, A.chars, "copy contigs")) || (rc = p->d2h(C.roff.data(), A.soff.p, n + 1, "copy offsets")) ||
-		          (rc = p->d2h(C.mem.data(), A.mem.p, A.members, "copy members")) || (rc = p->d2h(C.moff.data(), A.moff.p, n + 1, "copy offsets")) ||
-		          (rc = p->sync("copy contig set")))) return rc;
+		if (n) {
+			if ((rc = p->d2h(C.roff.data(), A.soff.p, n + 1, "copy offsets")) || (rc = p->d2h(C.moff.data(), A.moff.p, n + 1, "copy offsets")) || (rc = p->sync("copy offsets"))) return rc;
+			if ((rc = p->hipc(hipEventRecord(p->ev_ready, p->stream), "event")) || (rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_ready, 0), "event")) ||
+			    (rc = p->hipc(hipMemcpyAsync(C.mem.data(), A.mem.p, A.members * 8, hipMemcpyDeviceToHost, p->copy_stream), "copy members")) ||
+			    (rc = p->hipc(hipMemcpyAsync(C.ref.data(), A.seq.p, A.chars, hipMemcpyDeviceToHost, p->copy_stream), "copy contigs")) ||
+			    (rc = p->hipc(hipEventRecord(p->ev_copied, p->copy_stream), "event"))) return rc;
+			p->copy_pending = true;
+		}
+		p->dC.swap(A); p->dC_valid = true;
+		p->hostC_valid = true;                                                              // once the pending copy has landed
 		lap("t_cb_download");
-		p->hostC_valid = true;
 	}
 	p->unsorted.assign(p->C.n(), 1);
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
@@ -679,8 +694,12 @@ static void join_presort(P *p) { if (p->presort.joinable()) p->presort.join(); }
 
 // the contig set of the bucket stage is built on the device; whoever wants it on the host (stage dumps, accessors,
 // a Stage 2 without combine_cluster) gets a copy here
-static int ensure_host_contigs(P *p)
+static int ensure_host_contigs(P *p, bool wait_data)
 {
+	if (wait_data && p->copy_pending) {                     // offsets are there already, members and strings still travel
+		p->copy_pending = false;
+		if (hipEventSynchronize(p->ev_copied) != hipSuccess) return p->fail(MCOM_E_HIP, "copy of the contig set failed");
+	}
 	if (p->hostC_valid) return MCOM_OK;
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set");
 	DevSet &D = p->dC; ContigSet &C = p->C;
@@ -757,13 +776,23 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
 	const int nt = p->host_threads;
-	{ const int rch = ensure_host_contigs(p); if (rch) return rch; }
+	{ const int rch = ensure_host_contigs(p, false); if (rch) return rch; }
 	mcomh_update_single(p);                                                                 // preprocess.c:203
 	ContigSet &C = p->C;
 	const size_t nc = C.n(), n_sg = p->sg.size();
 	int rc;
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
-		if ((rc = upload_contigs(p, C))) return rc;
+		if (p->dC_valid && p->dC.n == nc) {                   // the set is still on the device from combine_cluster: pack it there
+			uint64_t tw = 0;
+			if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+			if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+			p->total_words = tw;
+			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+			if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
+			           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
+		} else {
+			if ((rc = ensure_host_contigs(p)) || (rc = upload_contigs(p, C))) return rc;
+		}
 		std::vector<uint64_t> woff(nc + 1, 0);
 		for (size_t i = 0; i < nc; ++i) woff[i + 1] = woff[i] + (C.rsize(i) >= (size_t)p->L ? C.rsize(i) - p->L + 1 : 0);
 		p->n_windows = woff[nc];
@@ -790,6 +819,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
 	if (p->pend.empty())
 		p->presort = std::thread([p, nt, nc]() {
+			if (p->copy_pending) (void)hipEventSynchronize(p->ev_copied);     // the members are still on their way from the device
 			ContigSet &S = p->C;
 			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
 				for (size_t c = cb; c < ce; ++c)
@@ -997,7 +1027,7 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 		}
 		dump_buckets(f, "MI0", rec);
 	}
-	if ((rc = mcomh_combine_cluster(p))) { fclose(f); return rc; }
+	if ((rc = mcomh_combine_cluster(p)) || (rc = ensure_host_contigs(p))) { fclose(f); return rc; }
 	fprintf(f, "STAGE combine\n");
 	dump_contigs(f, "combine", p->C);
 	if ((rc = run_stage2(p, f))) { fclose(f); return rc; }
