@@ -21,10 +21,10 @@ __device__ __forceinline__ uint32_t obase(const uint64_t *row, int L, uint32_t d
 
 // the same with the packed row spread over the wave (lane q holds word q): one global load per member instead of
 // one per base
-__device__ __forceinline__ uint32_t obase_w(uint64_t roww, int L, uint32_t dir, int i)
+__device__ __forceinline__ uint32_t obase_w(uint64_t roww, int L, uint32_t dir, int i, int lane0 = 0)
 {
 	const int j = dir ? L - 1 - i : i;
-	const uint64_t wv = __shfl(roww, j >> 5, 64);
+	const uint64_t wv = __shfl(roww, lane0 + (j >> 5), 64);
 	const uint32_t b = (uint32_t)(wv >> (2 * (j & 31))) & 3u;
 	return dir ? 3u - b : b;
 }
@@ -53,19 +53,27 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 	for (int c = lane; c < 4 * TL; c += 64) { c1[c] = 0; c2[c] = 0; }
 	__syncthreads();
 	// pass 1: offsets, first counts
+	// Members are taken eight at a time: lane 8i+w loads word w of member i's packed row, so the two dependent global
+	// loads (member word, then its row) are paid once per eight members instead of once per member.
 	int pos0 = 0;
-	for (uint32_t q = m0; q < m1; ++q) {
-		const uint64_t y = members[q];
-		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
-		int pos = (int)((uint32_t)y >> 1);
-		if (dir) pos = L - pos + k_orig - 2;
-		if (q == m0) pos0 = pos;
-		const int off = pos0 - pos;
-		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
-		for (int s0 = 0; s0 < L; s0 += 64) {                                // whole wave in the shuffle, also past the read's end
-			const int s = s0 + lane;
-			const uint32_t b = obase_w(roww, L, dir, s < L ? s : 0);
-			if (s < L) atomicAdd(&c1[b * TL + off + s], 1u);
+	const int il = lane >> 3, wl = lane & 7;
+	for (uint32_t q0 = m0; q0 < m1; q0 += 8) {
+		const uint32_t ql = q0 + (uint32_t)il;
+		const uint64_t yl = ql < m1 ? members[ql] : 0ull;
+		const uint64_t rowl = (ql < m1 && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+		const int nm = (int)(m1 - q0 < 8u ? m1 - q0 : 8u);
+		for (int i = 0; i < nm; ++i) {
+			const uint64_t y = __shfl(yl, 8 * i, 64);
+			const uint32_t dir = (uint32_t)(y & 1);
+			int pos = (int)((uint32_t)y >> 1);
+			if (dir) pos = L - pos + k_orig - 2;
+			if (q0 == m0 && i == 0) pos0 = pos;
+			const int off = pos0 - pos;
+			for (int s0 = 0; s0 < L; s0 += 64) {                            // whole wave in the shuffle, also past the read's end
+				const int s = s0 + lane;
+				const uint32_t b = obase_w(rowl, L, dir, s < L ? s : 0, 8 * i);
+				if (s < L) atomicAdd(&c1[b * TL + off + s], 1u);
+			}
 		}
 	}
 	__syncthreads();
@@ -84,13 +92,18 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 	}
 	// pass 2: mismatches against the first consensus, kept members counted again
 	uint32_t nk = 0; int rend = 0;
-	for (uint32_t q = m0; q < m1; ++q) {
-		const uint64_t y = members[q];                                     // still the sketch record: rewritten below
-		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
+	for (uint32_t q0 = m0; q0 < m1; q0 += 8) {
+		const uint32_t ql = q0 + (uint32_t)il;
+		const uint64_t yl = ql < m1 ? members[ql] : 0ull;                  // still the sketch records: rewritten below
+		const uint64_t rowl = (ql < m1 && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+		const int nm = (int)(m1 - q0 < 8u ? m1 - q0 : 8u);
+		for (int i = 0; i < nm; ++i) {
+		const uint32_t q = q0 + (uint32_t)i;
+		const uint64_t y = __shfl(yl, 8 * i, 64);
+		const uint32_t dir = (uint32_t)(y & 1);
 		int pos = (int)((uint32_t)y >> 1);
 		if (dir) pos = L - pos + k_orig - 2;
 		const int off = pos0 - pos;
-		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
 		int dif = 0;
 		uint32_t bs[4];                                                     // this lane's bases of the member (L <= 256)
 #pragma unroll
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 			const int s = u * 64 + lane;
 			bs[u] = 0;
 			if (u * 64 < L) {
-				bs[u] = obase_w(roww, L, dir, s < L ? s : 0);
+				bs[u] = obase_w(rowl, L, dir, s < L ? s : 0, 8 * i);
 				const bool mis = s < L && ((off + s >= ref_len) || rc[off + s] != (uint8_t)bs[u]);
 				dif += __popcll(__ballot(mis));
 			}
@@ -111,6 +124,7 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 			if (off + L > rend) rend = off + L;
 		}
 		if (lane == 0) { keep[q] = kp ? 1 : 0; members[q] = (y >> 32 << 32) | ((uint64_t)off << 1) | dir; }   // :101
+		}
 	}
 	__syncthreads();
 	// second consensus over [sv, rend): sv = first column (inside the first consensus) any kept member covers
@@ -172,17 +186,25 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 	// first member whose read can reach column lo: offset > lo - L (members are sorted by offset)
 	uint64_t a = m0, b = m1;
 	while (a < b) { const uint64_t mid = (a + b) >> 1; if ((long)((uint32_t)members[mid] >> 1) + L <= lo) a = mid + 1; else b = mid; }
-	for (uint64_t q = a; q < m1; ++q) {
-		const uint64_t y = members[q];
-		const long off = (long)((uint32_t)y >> 1);
-		if (off >= hi) break;
-		const uint32_t rid = (uint32_t)(y >> 32), dir = (uint32_t)(y & 1);
-		const uint64_t roww = lane < W ? packed[(size_t)rid * W + lane] : 0ull;
-		for (int s0 = 0; s0 < L; s0 += 64) {
-			const int s = s0 + lane;
-			const long c = off + s;
-			const uint32_t b = obase_w(roww, L, dir, s < L ? s : 0);
-			if (s < L && c >= lo && c < hi) atomicAdd(&cc[b * MC_TILE + (int)(c - lo)], 1u);
+	const int il = lane >> 3, wl = lane & 7;                                 // eight members per round of global loads
+	bool past = false;
+	for (uint64_t q0 = a; q0 < m1 && !past; q0 += 8) {
+		const uint64_t ql = q0 + (uint64_t)il;
+		const uint64_t yl = ql < m1 ? members[ql] : 0ull;
+		const bool use = ql < m1 && (long)((uint32_t)yl >> 1) < hi;
+		const uint64_t rowl = (use && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+		const int nm = (int)(m1 - q0 < 8ull ? m1 - q0 : 8ull);
+		for (int i = 0; i < nm; ++i) {
+			const uint64_t y = __shfl(yl, 8 * i, 64);
+			const long off = (long)((uint32_t)y >> 1);
+			if (off >= hi) { past = true; break; }
+			const uint32_t dir = (uint32_t)(y & 1);
+			for (int s0 = 0; s0 < L; s0 += 64) {
+				const int s = s0 + lane;
+				const long c = off + s;
+				const uint32_t b = obase_w(rowl, L, dir, s < L ? s : 0, 8 * i);
+				if (s < L && c >= lo && c < hi) atomicAdd(&cc[b * MC_TILE + (int)(c - lo)], 1u);
+			}
 		}
 	}
 	__syncthreads();

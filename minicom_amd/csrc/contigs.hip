@@ -244,11 +244,13 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		}
 		// ---- phase 2: one lane per entry (at most PIECE entries per piece), emission order = entry order
 		uint32_t mine[NGRP], excl[NGRP], gbase[NGRP], piece_total = 0;
+		uint64_t fx[NGRP]; uint32_t fp[NGRP];                              // an entry's first record: nearly always its only one
 #pragma unroll
 		for (int g = 0; g < NGRP; ++g) {
 			const long te = ent_in + 64 * g + lane;
 			uint32_t m = 0;
-			if (te < ent_run) entry_emits(te, [&](uint64_t, uint32_t) { ++m; });
+			fx[g] = 0; fp[g] = 0;
+			if (te < ent_run) entry_emits(te, [&](uint64_t x, uint32_t pp) { if (m == 0) { fx[g] = x; fp[g] = pp; } ++m; });
 			uint32_t incl = m;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		for (int g = 0; g < NGRP; ++g) {
 			if (!mine[g]) continue;
 			uint32_t rel = gbase[g] + excl[g];
+			if (mine[g] == 1) { if (rel < take && fits) tmp[arena0 + start + rel] = make_rec(fx[g], fp[g]); continue; }
 			entry_emits(ent_in + 64 * g + lane, [&](uint64_t x, uint32_t pp) {
 				if (rel < take && fits) tmp[arena0 + start + rel] = make_rec(x, pp);
 				++rel;
