@@ -383,23 +383,75 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 // ------------------------------------------------------------------------------------------------
 // pack: one thread per output word; contig c owns words [coff[c], coff[c+1]) of which the last is padding
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pack_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ coff,
-                               uint32_t n, uint64_t total_words, uint64_t *__restrict__ cbits)
+// A block of 256 threads makes 256 consecutive words.  The contig offsets the block needs (at most 130 contigs: a
+// contig owns at least two words) and the characters behind its words (one contiguous range of the concatenation, at
+// most 8 KB) are staged in LDS with coalesced loads; a thread then finds its contig by a search in LDS and packs 32
+// characters with word-wide bit tricks instead of 22 dependent global loads and a byte loop.
+#define PK_T 256
+__global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                       const uint64_t *__restrict__ coff, uint32_t n, uint64_t total_words,
+                                                       uint64_t *__restrict__ cbits)
 {
-	const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= total_words) return;
-	uint32_t lo = 0, hi = n;
-	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= g) lo = mid; else hi = mid; }
-	const uint64_t wi = g - coff[lo];
-	const uint64_t len = off[lo + 1] - off[lo];
-	const uint8_t *s = seq + off[lo];
+	__shared__ uint64_t CO[PK_T / 2 + 4], OF[PK_T / 2 + 4];
+	__shared__ uint32_t SB[PK_T * 8 + 16];
+	__shared__ uint32_t c0s;
+	__shared__ uint64_t lo_s, hi_s;
+	const uint64_t g0 = (uint64_t)blockIdx.x * PK_T;
+	const uint64_t g = g0 + threadIdx.x;
+	if (threadIdx.x == 0) {
+		uint32_t lo = 0, hi = n;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= g0) lo = mid; else hi = mid; }
+		c0s = lo; lo_s = 0; hi_s = 0;
+	}
+	__syncthreads();
+	const uint32_t c0 = c0s;
+	const int NC = PK_T / 2 + 2;
+	for (int t = threadIdx.x; t < NC; t += PK_T) {
+		const uint64_t c = (uint64_t)c0 + t;
+		CO[t] = c < n ? coff[c] : (c == n ? total_words : ~0ull);         // coff may hold n entries only
+		OF[t] = c <= n ? off[c] : off[n];
+	}
+	__syncthreads();
+	// my contig: last t with CO[t] <= g
+	uint64_t mybyte = 0, myend = 0; bool live = g < total_words;
+	int nb = 0;
+	if (live) {
+		int lo = 0, hi = NC;
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (CO[mid] <= g) lo = mid; else hi = mid; }
+		const uint64_t wi = g - CO[lo], len = OF[lo + 1] - OF[lo];
+		const uint64_t b0 = wi * 32;
+		nb = b0 < len ? (int)(len - b0 < 32 ? len - b0 : 32) : 0;
+		mybyte = OF[lo] + (b0 < len ? b0 : len); myend = mybyte + (uint64_t)nb;
+	}
+	const uint64_t last_live = total_words - g0 < PK_T ? total_words - g0 - 1 : PK_T - 1;
+	if (threadIdx.x == 0) lo_s = mybyte;
+	if (threadIdx.x == last_live) hi_s = myend;
+	__syncthreads();
+	const uint64_t start4 = lo_s & ~3ull;
+	const uint64_t ndw = hi_s > start4 ? (hi_s - start4 + 3) / 4 + 1 : 0;            // one more word for the funnel shift
+	const uint64_t seq_dw = (off[n] + 3) / 4;                                          // do not read past the concatenation
+	const uint32_t *seq32 = (const uint32_t*)(seq + start4);                           // the base pointer is 4-byte aligned
+	for (uint64_t i = threadIdx.x; i < ndw; i += PK_T) SB[i] = (start4 / 4 + i) < seq_dw ? seq32[i] : 0u;
+	__syncthreads();
+	if (!live) return;
 	uint64_t v = 0;
-	const uint64_t b0 = wi * 32;
-	for (int q = 0; q < 32; ++q) {
-		const uint64_t i = b0 + q;
-		if (i >= len) break;
-		const int c = nt4_of(s[i]);
-		v |= (uint64_t)(c & 3) << (2 * q);          // non-ACGT packs as A
+	if (nb) {
+		const uint32_t boff = (uint32_t)(mybyte - start4), d = boff >> 2, sh = (boff & 3) * 8;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const uint32_t a = SB[d + q], b = SB[d + q + 1];
+			const uint32_t w4 = sh ? (a >> sh) | (b << (32 - sh)) : a;                  // four characters
+			const uint32_t u = w4 & 0xDFDFDFDFu;                                       // fold case
+			// per byte: 0x80 where the character is A, C, G or T
+			auto eq = [](uint32_t x, uint32_t pat) { const uint32_t z = x ^ pat; return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu); };
+			const uint32_t ok = eq(u, 0x41414141u) | eq(u, 0x43434343u) | eq(u, 0x47474747u) | eq(u, 0x54545454u);
+			uint32_t c = ((w4 >> 1) ^ (w4 >> 2)) & 0x03030303u;                        // A0 C1 G2 T3
+			c &= (ok >> 7) * 3u;                                                       // anything else packs as A
+			c = (c | (c >> 6)) & 0x000F000Fu;
+			c = (c | (c >> 12)) & 0xFFu;
+			v |= (uint64_t)c << (8 * q);
+		}
+		if (nb < 32) v &= (1ull << (2 * nb)) - 1;
 	}
 	cbits[g] = v;
 }
@@ -412,7 +464,8 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 	if (!d_seq || !d_off || !d_coff || !d_cbits) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const uint64_t blocks = (total_words + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
-	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits);
+	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
+	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
