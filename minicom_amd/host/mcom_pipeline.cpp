@@ -191,7 +191,7 @@ struct mcomh_pipeline {
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
-	std::vector<uint8_t> h_cls;
+	PinVec<uint8_t> h_cls;
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
 	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
@@ -330,9 +330,14 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
 	}
 	if (rc) return rc;
-	p->h_cls.resize(n);
+	if (!p->h_cls.resize(n + 8)) return p->fail(MCOM_E_NOMEM, "classes");
 	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->sync("kt_for_reads"))) return rc;
+	memset(p->h_cls.data() + n, 0, 8);
 	for (size_t r = 0; r < n; ++r) {                                              // one thread: rid order
+		if ((r & 7) == 0) {                                                       // nearly every read is class 0: skip eight at a time
+			uint64_t w8; memcpy(&w8, p->h_cls.data() + r, 8);
+			if (w8 == 0) { r += 7; continue; }
+		}
 		switch (p->h_cls[r]) {
 		case MCOM_CLS_SKETCH: break;
 		case MCOM_CLS_ALLA: p->allA.push_back((uint32_t)r); break;
