@@ -4,8 +4,9 @@
  * and meaning (pre_process preprocess.c:39, kt_for_reads kthread_reads.c:247, kt_for_bucket
  * kthread_bucket.c:562, combine_cluster kthread_cb.c:570, realign_hash kthread_hash_realign.c:569,
  * updateSingle preprocess.c:243) but run their hot loops as HIP kernels through include/mcom.h.
- * Contig consensus (construct_ref kthread_bucket.c:69, construct_ref2 kthread_cb.c:105), pair claiming
- * and claim resolution stay on the host, as in the reference.  No CPU fallback: every stage needs the GPU.
+ * The contig set lives on the device from kt_for_bucket to the end of Stage 2; the host orders singletons and
+ * rejects, keeps the loop control of the stages and folds Stage 2's appends into the member lists.
+ * No CPU fallback: every stage needs the GPU.
  * Results equal the reference at one thread (-t 1, its only deterministic mode).
  */
 #ifndef MCOM_HOST_H
@@ -61,6 +62,17 @@ int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder);
 /* Inverse of those files (the reference's decompress for that mode, decompress.c:495-760): one read per line into
  * out_path, order = all-A/T/N, near-constant reads, N reads, unclustered reads, contig reads.  No GPU needed. */
 int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads);
+
+/* FASTQ / FASTA ingest (bseq_open + bseq_read, bseq.c:19-66; kseq.h), plain or gzip.
+ * Every read must have the same length (bseq.c:54-57 exits otherwise; here MCOM_E_ARG).  *L == 0: taken from
+ * the first read.
+ *   mcomh_fastq_read      : host only, the reads into out[cap_reads][L] (MCOM_E_OVERFLOW when there are more)
+ *   mcomh_fastq_to_device : the reads into HBM as [n][L] characters, parsed into two pinned chunks of chunk_reads
+ *                           rows (0 = 2^20) that alternate between the parser and the copy engine; *d_reads is
+ *                           what mcomh_create takes as d_reads (pitch = L); release it with mcomh_device_free.   */
+int mcomh_fastq_read(const char *path, int *L, uint8_t *out, size_t cap_reads, size_t *n);
+int mcomh_fastq_to_device(const char *path, int device, int *L, size_t chunk_reads, uint8_t **d_reads, size_t *n, char *err, size_t err_cap);
+void mcomh_device_free(void *d_ptr);
 
 /* results */
 size_t mcomh_n_contigs(const mcomh_pipeline *p);

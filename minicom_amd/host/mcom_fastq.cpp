@@ -1,0 +1,167 @@
+// minicom_amd/host/mcom_fastq.cpp -- FASTQ/FASTA ingest for the MI355X-native minicom hot path.
+//
+// Replaces bseq_open / bseq_read (reference bseq.c:19-66, kseq.h): the reference strdup()s every read into its own
+// heap block and copies them again into reads->seq; here the sequence lines are parsed straight into one of two pinned
+// host chunks, and while the parser fills one chunk the other one travels to HBM (hipMemcpyAsync on a copy stream), so
+// that the reads are resident on the device as an [n][L] character matrix when the file has been read -- the input
+// mcomh_create takes.  Plain or gzip-compressed files (zlib), FASTA or FASTQ, sequences over several lines.
+// As in the reference every read must have the same length (bseq.c:54-57): anything else is an error, not exit(1).
+#include "../../include/mcom.h"
+#include "../../include/mcom_host.h"
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// kseq-like record reader over a gz stream: yields one sequence at a time, appended to `out`
+class SeqReader {
+	gzFile f_;
+	std::vector<unsigned char> buf_;
+	size_t pos_ = 0, end_ = 0;
+	bool eof_ = false;
+	int last_ = 0;                         // the '>' or '@' that starts the next record, once seen
+	bool fill() {
+		if (eof_) return false;
+		const int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
+		if (n <= 0) { eof_ = true; pos_ = end_ = 0; return false; }
+		pos_ = 0; end_ = (size_t)n; return true;
+	}
+	int getc() { if (pos_ >= end_ && !fill()) return -1; return buf_[pos_++]; }
+	// appends the rest of the current line (without the newline) to out (if non-null); returns false at end of file
+	bool line(std::string *out) {
+		bool any = false;
+		for (;;) {
+			if (pos_ >= end_ && !fill()) return any;
+			any = true;
+			const unsigned char *b = buf_.data() + pos_;
+			const unsigned char *nl = (const unsigned char*)memchr(b, '\n', end_ - pos_);
+			const size_t len = nl ? (size_t)(nl - b) : end_ - pos_;
+			if (out) out->append((const char*)b, len);
+			pos_ += len;
+			if (nl) { ++pos_; if (out && !out->empty() && out->back() == '\r') out->pop_back(); return true; }
+		}
+	}
+public:
+	explicit SeqReader(gzFile f) : f_(f), buf_((size_t)4 << 20) {}
+	// 1 = a record was read into seq, 0 = end of file, -1 = malformed (quality string shorter than the sequence)
+	int next(std::string &seq) {
+		seq.clear();
+		int c = last_;
+		if (!c) { while ((c = getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return 0; }
+		last_ = 0;
+		line(nullptr);                                                     // name and comment
+		while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') {   // sequence lines
+			if (c == '\n') continue;
+			seq.push_back((char)c);
+			line(&seq);
+		}
+		if (c == '>' || c == '@') last_ = c;
+		if (c != '+') return 1;                                            // FASTA record, or the last one
+		line(nullptr);                                                     // the '+' line
+		size_t q = 0;
+		std::string ql;
+		while (q < seq.size()) { ql.clear(); if (!line(&ql)) return -1; q += ql.size(); }
+		return q == seq.size() ? 1 : -1;
+	}
+};
+
+struct Chunk { unsigned char *p = nullptr; hipEvent_t done = nullptr; bool busy = false; };
+
+}  // namespace
+
+// Host-only form (tests, tools): the reads of a file into a caller buffer of cap_reads rows of L characters.
+// *L == 0 on entry: taken from the first read.  Returns 0, MCOM_E_ARG for a malformed file or a read of another
+// length, MCOM_E_OVERFLOW when the file holds more than cap_reads reads (*n = that many were stored).
+extern "C" int mcomh_fastq_read(const char *path, int *L, uint8_t *out, size_t cap_reads, size_t *n)
+{
+	if (!path || !L || !n) return MCOM_E_ARG;
+	*n = 0;
+	gzFile f = gzopen(path, "rb");
+	if (!f) return MCOM_E_ARG;
+	gzbuffer(f, 1 << 20);
+	SeqReader rd(f);
+	std::string seq;
+	int rc = MCOM_OK, st;
+	while ((st = rd.next(seq)) == 1) {
+		if (*L == 0) *L = (int)seq.size();
+		if ((int)seq.size() != *L || *L < 1 || *L > 256) { rc = MCOM_E_ARG; break; }  // bseq.c:54-57 exits here
+		if (*n >= cap_reads) { rc = MCOM_E_OVERFLOW; break; }
+		if (out) memcpy(out + *n * (size_t)*L, seq.data(), (size_t)*L);
+		++*n;
+	}
+	if (st < 0) rc = MCOM_E_ARG;
+	gzclose(f);
+	return rc;
+}
+
+// The reads of a file to HBM: *d_reads = [n][L] characters (hipMalloc'ed, the caller hipFree()s it), ready for
+// mcomh_create(..., d_reads, pitch = L, ...).  Two pinned chunks of chunk_reads rows alternate between the parser
+// and the copy engine.
+extern "C" int mcomh_fastq_to_device(const char *path, int device, int *L, size_t chunk_reads, uint8_t **d_reads, size_t *n, char *err, size_t err_cap)
+{
+	auto fail = [&](int code, const char *msg) { if (err && err_cap) snprintf(err, err_cap, "%s", msg); return code; };
+	if (!path || !L || !d_reads || !n) return MCOM_E_ARG;
+	*d_reads = nullptr; *n = 0;
+	if (hipSetDevice(device) != hipSuccess) return fail(MCOM_E_HIP, "no usable GPU");
+	gzFile f = gzopen(path, "rb");
+	if (!f) return fail(MCOM_E_ARG, "cannot open the input file");
+	gzbuffer(f, 1 << 20);
+	SeqReader rd(f);
+	std::string seq;
+	if (chunk_reads == 0) chunk_reads = (size_t)1 << 20;
+	hipStream_t cs = nullptr;
+	Chunk ch[2];
+	uint8_t *dev = nullptr; size_t dev_cap = 0;                               // rows
+	int rc = MCOM_OK, st = 0, cur = 0;
+	size_t in_chunk = 0, total = 0;
+	auto cleanup = [&]() {
+		if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+		for (Chunk &c : ch) { if (c.p) (void)hipHostFree(c.p); if (c.done) (void)hipEventDestroy(c.done); }
+		gzclose(f);
+	};
+	auto flush = [&](bool last) -> int {                                     // chunk `cur` -> device, asynchronously
+		if (!in_chunk) return MCOM_OK;
+		if (total + in_chunk > dev_cap) {                                     // grow, keeping what has arrived
+			size_t want = dev_cap ? dev_cap * 2 : (last ? in_chunk : chunk_reads * 8);
+			while (want < total + in_chunk) want *= 2;
+			uint8_t *nd = nullptr;
+			if (hipMalloc(&nd, want * (size_t)*L + 16) != hipSuccess) return MCOM_E_NOMEM;
+			if (hipStreamSynchronize(cs) != hipSuccess) return MCOM_E_HIP;
+			if (dev && total && hipMemcpy(nd, dev, total * (size_t)*L, hipMemcpyDeviceToDevice) != hipSuccess) return MCOM_E_HIP;
+			if (dev) (void)hipFree(dev);
+			dev = nd; dev_cap = want;
+		}
+		if (hipMemcpyAsync(dev + total * (size_t)*L, ch[cur].p, in_chunk * (size_t)*L, hipMemcpyHostToDevice, cs) != hipSuccess) return MCOM_E_HIP;
+		if (hipEventRecord(ch[cur].done, cs) != hipSuccess) return MCOM_E_HIP;
+		ch[cur].busy = true;
+		total += in_chunk; in_chunk = 0; cur ^= 1;
+		if (ch[cur].busy) { if (hipEventSynchronize(ch[cur].done) != hipSuccess) return MCOM_E_HIP; ch[cur].busy = false; }   // the other chunk must have left
+		return MCOM_OK;
+	};
+	while ((st = rd.next(seq)) == 1) {
+		if (*L == 0) *L = (int)seq.size();
+		if ((int)seq.size() != *L || *L < 1 || *L > 256) { rc = fail(MCOM_E_ARG, "Length of reads are different. The program can not compress it."); break; }   // bseq.c:54-57
+		if (!cs) {
+			if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { rc = fail(MCOM_E_HIP, "stream"); break; }
+			for (Chunk &c : ch)
+				if (hipHostMalloc((void**)&c.p, chunk_reads * (size_t)*L, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) { rc = fail(MCOM_E_NOMEM, "pinned chunks"); break; }
+			if (rc) break;
+		}
+		memcpy(ch[cur].p + in_chunk * (size_t)*L, seq.data(), (size_t)*L);
+		if (++in_chunk == chunk_reads && (rc = flush(false))) { fail(rc, "upload failed"); break; }
+	}
+	if (!rc && st < 0) rc = fail(MCOM_E_ARG, "malformed record (quality string shorter than the sequence)");
+	if (!rc && (rc = flush(true))) fail(rc, "upload failed");
+	if (!rc && cs && hipStreamSynchronize(cs) != hipSuccess) rc = fail(MCOM_E_HIP, "upload failed");
+	cleanup();
+	if (rc) { if (dev) (void)hipFree(dev); return rc; }
+	*d_reads = dev; *n = total;
+	return MCOM_OK;
+}
+
+extern "C" void mcomh_device_free(void *d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }

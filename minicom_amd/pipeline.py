@@ -52,6 +52,10 @@ def load_host_library():
     L.mcomh_stat.restype = C.c_double; L.mcomh_stat.argtypes = [vp, cp]
     L.mcomh_prof_enable.restype = i32; L.mcomh_prof_enable.argtypes = [vp, i32]
     L.mcomh_prof_read.restype = i32; L.mcomh_prof_read.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.mcomh_fastq_read.restype = i32; L.mcomh_fastq_read.argtypes = [cp, C.POINTER(i32), vp, sz, C.POINTER(sz)]
+    L.mcomh_fastq_to_device.restype = i32
+    L.mcomh_fastq_to_device.argtypes = [cp, i32, C.POINTER(i32), sz, C.POINTER(vp), C.POINTER(sz), C.c_char_p, sz]
+    L.mcomh_device_free.restype = None; L.mcomh_device_free.argtypes = [vp]
     _lib = L
     return L
 
@@ -59,7 +63,8 @@ def load_host_library():
 HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
-                    "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read"]
+                    "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
+                    "mcomh_device_free"]
 
 
 def decompress(folder: str, out_path: str) -> int:
@@ -69,6 +74,20 @@ def decompress(folder: str, out_path: str) -> int:
     if rc:
         raise McomError(f"cannot decode the stream files in {folder}")
     return int(n.value)
+
+
+def read_fastq(path: str, L: int = 0) -> np.ndarray:
+    """mcomh_fastq_read: the reads of a FASTQ/FASTA file (plain or .gz) as a numpy uint8 [n, L] array.  Host only."""
+    lib = load_host_library()
+    Lc, n = C.c_int(L), C.c_size_t()
+    rc = lib.mcomh_fastq_read(path.encode(), C.byref(Lc), None, C.c_size_t(-1).value, C.byref(n))      # count + check
+    if rc:
+        raise McomError(f"{path}: not a FASTQ/FASTA file of equal-length reads ({rc})")
+    out = np.empty((n.value, Lc.value), dtype=np.uint8)
+    rc = lib.mcomh_fastq_read(path.encode(), C.byref(Lc), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    if rc:
+        raise McomError(f"{path}: read failed ({rc})")
+    return out
 
 
 class Pipeline:
@@ -100,6 +119,27 @@ class Pipeline:
         self._h = h
         self.n, self.L = n, L
 
+    @classmethod
+    def from_fastq(cls, path: str, L: int = 0, device: int = 0, chunk_reads: int = 0, **params):
+        """FASTQ/FASTA (plain or .gz) -> HBM through two pinned chunks (mcomh_fastq_to_device) -> pipeline."""
+        lib = load_host_library()
+        Lc, n, d = C.c_int(L), C.c_size_t(), C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = lib.mcomh_fastq_to_device(path.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
+        if rc:
+            raise McomError(f"{path}: {err.value.decode() or rc}")
+        self = cls.__new__(cls)
+        self.lib = lib
+        p = Params(**{k: int(v) for k, v in params.items()})
+        h = C.c_void_p()
+        rc = lib.mcomh_create(C.byref(h), device, C.c_void_p(0), None, d, Lc.value, n.value, Lc.value, C.byref(p))
+        if rc:
+            lib.mcomh_device_free(d)
+            raise McomError(f"mcomh_create failed ({rc})")
+        self._h, self._dev_reads, self._keep = h, d, None
+        self.n, self.L = n.value, Lc.value
+        return self
+
     def _check(self, rc):
         if rc:
             raise McomError(f"mcom host error {rc}: {self.lib.mcomh_last_error(self._h).decode()}")
@@ -108,6 +148,9 @@ class Pipeline:
         if getattr(self, "_h", None):
             self.lib.mcomh_destroy(self._h)
             self._h = None
+        if getattr(self, "_dev_reads", None):
+            self.lib.mcomh_device_free(self._dev_reads)
+            self._dev_reads = None
 
     def __del__(self):
         try:
