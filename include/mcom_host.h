@@ -62,6 +62,12 @@ int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder);
 /* Inverse of those files (the reference's decompress for that mode, decompress.c:495-760): one read per line into
  * out_path, order = all-A/T/N, near-constant reads, N reads, unclustered reads, contig reads.  No GPU needed. */
 int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads);
+/* SURVEY section 8f rank 4, single-end part: the order-preserving mode (minicom -p = the reference compiled with
+ * ORDER): members ordered by cmpcluster3 (kthread_cb.c:72), ids.bin.0 (kthread_dump.c:116-127), every list sorted by
+ * read id with a delta-coded *.ids.bin beside it and the read count in info.txt (:377-379, :420-543); and its inverse
+ * (decompress.c:109-493), which writes the reads in their original order.                                        */
+int mcomh_cluster_dump_order(mcomh_pipeline *p, const char *folder);
+int mcomh_decompress_order(const char *folder, const char *out_path, uint64_t *n_reads);
 
 /* FASTQ / FASTA ingest (bseq_open + bseq_read, bseq.c:19-66; kseq.h), plain or gzip.
  * Every read must have the same length (bseq.c:54-57 exits otherwise; here MCOM_E_ARG).  *L == 0: taken from

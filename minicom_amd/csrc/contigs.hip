@@ -329,6 +329,7 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	if (h_total) *h_total = 0;
 	if (k < 1 || k > 31 || w < 1 || w > MAXW) return mcom_fail(ctx, MCOM_E_ARG, "w=%d (1..%d) or k=%d (1..31) out of range", w, MAXW, k);
 	if (n >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs");
+	if (!d_ids && n > (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: the default record id (index<<8, kthread_bucket.c:458) overflows");
 	if (!d_moff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 4, ctx->stream)); return MCOM_OK; }
 	if (!d_seq || !d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");

@@ -135,3 +135,114 @@ extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64
 	if (n_reads) *n_reads = total;
 	return 0;
 }
+
+// ---- order-preserving mode (-p): every stream has a companion stream of read ids ------------------------------------
+// Restates decomp_AATTNN_order (decompress.c:299-493), decomp_single_order (:238-297) and decompress_order (:109-236):
+// the reads are rebuilt into a table indexed by their original position and written out in that order.  Id streams
+// are uint32, delta coded inside a list (lists are sorted by id); in ids.bin.T a member carries its id when it is the
+// first of its contig or starts at a new position, else the difference to the previous member's id (:164-167).
+extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, uint64_t *n_reads)
+{
+	if (!folder || !out_path) return -1;
+	const std::string dir(folder);
+	FILE *fi = fopen((dir + "/info.txt").c_str(), "r");
+	if (!fi) return -1;
+	int L = 0, nth = 0; long na = 0, nt = 0, nn = 0; unsigned long n_seq = 0;
+	if (fscanf(fi, "%d %d %ld %ld %ld %lu", &L, &nth, &na, &nt, &nn, &n_seq) != 6) { fclose(fi); return -1; }
+	fclose(fi);
+	if (L < 1 || L > 256 || nth < 1) return -1;
+	std::vector<char> table((size_t)n_seq * (size_t)L, 0);
+	std::vector<uint8_t> seen((size_t)n_seq, 0);
+	bool bad = false;
+	auto put = [&](uint64_t idx, const std::string &s) {
+		if (idx >= n_seq || (int)s.size() != L || seen[idx]) { bad = true; return; }
+		memcpy(table.data() + idx * (size_t)L, s.data(), (size_t)L); seen[idx] = 1;
+	};
+	struct Ids {                                                        // one delta-coded id list
+		std::vector<uint8_t> b; size_t p = 0; uint64_t pre = 0;
+		bool next(uint64_t &idx) { if (p + 4 > b.size()) return false; uint32_t v; memcpy(&v, b.data() + p, 4); p += 4; pre += v; idx = pre; return true; }
+	};
+	std::vector<uint8_t> buf;
+	std::string seq;
+	uint64_t idx = 0;
+	// all-A / all-T / all-N (:320-372)
+	{
+		const char bases[3] = {'A', 'T', 'N'}; const char *names[3] = {"allA.ids.bin", "allT.ids.bin", "allN.ids.bin"}; const long cnt[3] = {na, nt, nn};
+		for (int q = 0; q < 3; ++q) {
+			Ids ids; if (!slurp(dir + "/" + names[q], ids.b)) return -1;
+			for (long i = 0; i < cnt[q]; ++i) { if (!ids.next(idx)) return -1; put(idx, std::string((size_t)L, bases[q])); }
+		}
+	}
+	// near-constant reads (:374-493)
+	{
+		const char bases[3] = {'A', 'T', 'N'}; const char *names[3] = {"AA", "TT", "NN"};
+		for (int q = 0; q < 3; ++q) {
+			Ids ids;
+			if (!slurp(dir + "/" + names[q] + ".txt", buf) || !slurp(dir + "/" + names[q] + ".ids.bin", ids.b)) return -1;
+			const std::string cref((size_t)L, bases[q]);
+			size_t s = 0;
+			for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') {
+				decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); s = i + 1;
+				if (!ids.next(idx)) return -1;
+				put(idx, seq);
+			}
+		}
+	}
+	// unclustered reads (:238-280) and reads kept as text (:282-296)
+	{
+		Ids ids;
+		if (!slurp(dir + "/single.seq", buf) || !slurp(dir + "/singleFile.ids.bin", ids.b)) return -1;
+		DnaReader r(buf);
+		for (;;) {
+			seq.clear();
+			int c = 0;
+			for (int i = 0; i < L; ++i) { c = r.next(); if (c < 0) break; seq.push_back("ACGT"[c]); }
+			if (c < 0 || (int)seq.size() < L) break;
+			if (!ids.next(idx)) break;                                   // padding of the last byte can look like one more read of A
+			put(idx, seq);
+		}
+		Ids nids;
+		if (!slurp(dir + "/single_N.seq", buf) || !slurp(dir + "/Nfile.ids.bin", nids.b)) return -1;
+		size_t s = 0;
+		for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { seq.assign((const char*)buf.data() + s, i - s); s = i + 1; if (!nids.next(idx)) return -1; put(idx, seq); }
+	}
+	// contigs (:109-236)
+	for (int th = 0; th < nth; ++th) {
+		std::vector<uint8_t> bref, bpos, bdir, bdif, bids;
+		const std::string sfx = "." + std::to_string(th);
+		if (!slurp(dir + "/ref.bin" + sfx, bref) || !slurp(dir + "/beg_pos.bin" + sfx, bpos) || !slurp(dir + "/dir.bin" + sfx, bdir) ||
+		    !slurp(dir + "/dif_char.txt" + sfx, bdif) || !slurp(dir + "/ids.bin" + sfx, bids)) return -1;
+		DnaReader rr(bref); BitReader dr(bdir);
+		size_t pp = 0, dp = 0, ip = 0;
+		std::string ref;
+		while (pp + 4 <= bpos.size()) {
+			uint32_t num; memcpy(&num, bpos.data() + pp, 4); pp += 4;
+			ref.clear();
+			int pre = 0; uint64_t pre_idx = 0;
+			for (uint32_t q = 0; q < num; ++q) {
+				if (pp + 2 > bpos.size() || ip + 4 > bids.size()) return -1;
+				uint16_t d; memcpy(&d, bpos.data() + pp, 2); pp += 2;
+				uint32_t v; memcpy(&v, bids.data() + ip, 4); ip += 4;
+				uint64_t id = v;
+				if (d == 0) id += pre_idx;                                 // same begin position: a difference (:178-181)
+				pre_idx = id;
+				const int pos = pre + d; pre = pos;
+				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) return -1; ref.push_back("ACGT"[c]); }
+				const int rev = dr.next();
+				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
+				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				dp = e + 1;
+				if (rev) revcomp(seq);
+				put(id & 0xFFFFFFFFull, seq);
+			}
+		}
+	}
+	if (bad) return -1;
+	for (uint8_t s : seen) if (!s) return -1;                              // every position filled exactly once
+	FILE *out = fopen(out_path, "w");
+	if (!out) return -1;
+	for (size_t i = 0; i < n_seq; ++i) { fwrite(table.data() + i * (size_t)L, 1, (size_t)L, out); fputc('\n', out); }
+	fclose(out);
+	if (n_reads) *n_reads = n_seq;
+	return 0;
+}

@@ -1103,7 +1103,24 @@ std::string const_base_text(const char *s, int L, char base)
 }
 }
 
-extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
+// cmpcluster3 (kthread_cb.c:72-84): offset, then read id -- the member order of the order-preserving mode
+static bool less_cluster3(uint64_t a, uint64_t b)
+{
+	const int pa = (int)((uint32_t)a >> 1), pb = (int)((uint32_t)b >> 1);
+	if (pa != pb) return pa < pb;
+	return (int)(a >> 32) < (int)(b >> 32);
+}
+// one sorted id list as the reference writes it: the first id, then differences (kthread_dump.c:438-520)
+static bool write_ids(const std::string &path, const std::vector<uint32_t> &ids)
+{
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f) return false;
+	for (size_t i = 0; i < ids.size(); ++i) { const uint32_t v = i ? ids[i] - ids[i - 1] : ids[i]; fwrite(&v, 4, 1, f); }
+	fclose(f);
+	return true;
+}
+
+static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 {
 	if (!p || !folder) return MCOM_E_ARG;
 	{ const int rcm = materialize(p); if (rcm) return rcm; }
@@ -1124,20 +1141,28 @@ extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
 	};
 	auto open = [&](const char *name, const char *mode) { std::string path = std::string(folder) + "/" + name; return fopen(path.c_str(), mode); };
 	FILE *fref = open("ref.bin.0", "wb"), *fpos = open("beg_pos.bin.0", "wb"), *fdir = open("dir.bin.0", "wb"), *fdif = open("dif_char.txt.0", "w");
-	if (!fref || !fpos || !fdir || !fdif) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	FILE *fids = order ? open("ids.bin.0", "wb") : nullptr;                       // kthread_dump.c:266-269
+	if (!fref || !fpos || !fdir || !fdif || (order && !fids)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
 	BitWriter refbin(fref, 2), dirbin(fdir, 1);
 	ContigSet &C = p->C;
 	std::vector<char> t((size_t)L + 1), en;
+	std::vector<uint64_t> omem;
 	static const char RCT[256] = {0};
 	for (size_t c = 0; c < C.n(); ++c) {
-		std::stable_sort(C.mem.data() + C.moff[c], C.mem.data() + C.moff[c + 1], less_cluster2);     // :143
+		const uint64_t *mm = C.mem.data() + C.moff[c];
+		if (order) {                                                           // a copy: the pipeline keeps the order of the default mode
+			omem.assign(mm, mm + C.msize(c));
+			std::stable_sort(omem.begin(), omem.end(), less_cluster3);           // :34
+			mm = omem.data();
+		} else std::stable_sort(C.mem.data() + C.moff[c], C.mem.data() + C.moff[c + 1], less_cluster2);         // :143
+		uint32_t pre_rid = 0;
 		const char *ref = C.ref.data() + C.roff[c];
 		for (size_t i = 0; i < C.rsize(c); ++i) refbin.push(ref[i] == 'A' ? 0u : ref[i] == 'C' ? 1u : ref[i] == 'G' ? 2u : 3u);   // :158-160
 		const uint32_t num = (uint32_t)C.msize(c);
 		fwrite(&num, 4, 1, fpos);
 		int pre_pos = 0;
-		for (uint64_t q = C.moff[c]; q < C.moff[c + 1]; ++q) {
-			const uint64_t y = C.mem[q];
+		for (uint64_t q = 0; q < C.msize(c); ++q) {
+			const uint64_t y = mm[q];
 			const uint32_t rid = (uint32_t)(y >> 32); const int pos = (int)((uint32_t)y >> 1), dir = (int)(y & 1);
 			read_str(rid, t.data());
 			if (dir) {                                                         // reverse_complement, N stays N (preprocess.c:22-37)
@@ -1158,6 +1183,11 @@ extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
 			fwrite(en.data(), 1, en.size(), fdif); fputc('\n', fdif);
 			const uint16_t posbin = (uint16_t)(pos - pre_pos);
 			fwrite(&posbin, 2, 1, fpos);
+			if (order) {                                                       // :116-127: the id, or its difference at an equal position
+				const uint32_t v = (q == 0 || posbin > 0) ? rid : rid - pre_rid;
+				fwrite(&v, 4, 1, fids);
+				pre_rid = rid;
+			}
 			dirbin.push((unsigned)dir);
 			pre_pos = pos;
 		}
@@ -1165,28 +1195,47 @@ extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder)
 	(void)RCT;
 	dirbin.flush(); refbin.flush();                                               // :303-309
 	fclose(fref); fclose(fpos); fclose(fdir); fclose(fdif);
+	if (fids) fclose(fids);
 	FILE *finfo = open("info.txt", "w");
 	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
 	fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	if (order) fprintf(finfo, "%u\n", (unsigned)p->n);                                               // :377-379
 	fclose(finfo);
 	// singletons: those with N join the N file, the others are packed 4 per byte (:390-417, :545-548)
 	FILE *fsingle = open("single.seq", "wb");
 	if (!fsingle) return p->fail(MCOM_E_ARG, "cannot write single.seq");
 	BitWriter sb(fsingle, 2);
-	std::vector<uint32_t> nfile = p->Nfile;
+	std::vector<uint32_t> nfile = p->Nfile, single_ids;
+	auto push_single = [&](uint32_t rid) { for (int j = 0; j < L; ++j) sb.push((unsigned)((packed[(size_t)rid * W + (j >> 5)] >> (2 * (j & 31))) & 3)); };
 	for (size_t i = 0; i < p->sg.size(); ++i) {
 		if (p->sg_flag[i]) continue;
 		const uint32_t rid = p->sg[i];
 		if (has_n(rid)) nfile.push_back(rid);
-		else for (int j = 0; j < L; ++j) sb.push((unsigned)((packed[(size_t)rid * W + (j >> 5)] >> (2 * (j & 31))) & 3));
+		else if (order) single_ids.push_back(rid);                                // :409-411
+		else push_single(rid);
+	}
+	std::vector<uint32_t> fpA = p->fpA, fpT = p->fpT, fpN = p->fpN;
+	if (order) {
+		// every list sorted by read id, its ids delta coded beside it (:420-543); the singles follow their sorted ids
+		std::vector<uint32_t> allA = p->allA, allT = p->allT, allN = p->allN;
+		for (std::vector<uint32_t> *v : {&fpA, &fpT, &fpN, &nfile, &single_ids, &allA, &allT, &allN}) std::sort(v->begin(), v->end());
+		const std::string d(folder);
+		if (!write_ids(d + "/allA.ids.bin", allA) || !write_ids(d + "/allT.ids.bin", allT) || !write_ids(d + "/allN.ids.bin", allN) ||
+		    !write_ids(d + "/AA.ids.bin", fpA) || !write_ids(d + "/TT.ids.bin", fpT) || !write_ids(d + "/NN.ids.bin", fpN) ||
+		    !write_ids(d + "/Nfile.ids.bin", nfile) || !write_ids(d + "/singleFile.ids.bin", single_ids)) return p->fail(MCOM_E_ARG, "cannot write id streams");
+		for (uint32_t rid : single_ids) push_single(rid);
 	}
 	sb.flush(); fclose(fsingle);
 	FILE *fa = open("AA.txt", "w"), *ft = open("TT.txt", "w"), *fn = open("NN.txt", "w"), *fnf = open("single_N.seq", "w");
 	if (!fa || !ft || !fn || !fnf) return p->fail(MCOM_E_ARG, "cannot write text streams");
-	for (uint32_t rid : p->fpA) { read_str(rid, t.data()); fprintf(fa, "%s\n", const_base_text(t.data(), L, 'A').c_str()); }   // :566-597
-	for (uint32_t rid : p->fpT) { read_str(rid, t.data()); fprintf(ft, "%s\n", const_base_text(t.data(), L, 'T').c_str()); }   // :599-627
-	for (uint32_t rid : p->fpN) { read_str(rid, t.data()); fprintf(fn, "%s\n", const_base_text(t.data(), L, 'N').c_str()); }   // :629-657
+	for (uint32_t rid : fpA) { read_str(rid, t.data()); fprintf(fa, "%s\n", const_base_text(t.data(), L, 'A').c_str()); }   // :566-597
+	for (uint32_t rid : fpT) { read_str(rid, t.data()); fprintf(ft, "%s\n", const_base_text(t.data(), L, 'T').c_str()); }   // :599-627
+	for (uint32_t rid : fpN) { read_str(rid, t.data()); fprintf(fn, "%s\n", const_base_text(t.data(), L, 'N').c_str()); }   // :629-657
 	for (uint32_t rid : nfile) { read_str(rid, t.data()); fprintf(fnf, "%s\n", t.data()); }                                     // :659-671
 	fclose(fa); fclose(ft); fclose(fn); fclose(fnf);
 	return MCOM_OK;
 }
+
+extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, false); }
+// the order-preserving mode (minicom -p = the reference compiled with ORDER): id streams beside every stream
+extern "C" int mcomh_cluster_dump_order(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, true); }

@@ -44,6 +44,8 @@ def load_host_library():
     L.mcomh_dump_stages.restype = i32; L.mcomh_dump_stages.argtypes = [vp, cp]
     L.mcomh_cluster_dump.restype = i32; L.mcomh_cluster_dump.argtypes = [vp, cp]
     L.mcomh_decompress.restype = i32; L.mcomh_decompress.argtypes = [cp, cp, C.POINTER(C.c_uint64)]
+    L.mcomh_cluster_dump_order.restype = i32; L.mcomh_cluster_dump_order.argtypes = [vp, cp]
+    L.mcomh_decompress_order.restype = i32; L.mcomh_decompress_order.argtypes = [cp, cp, C.POINTER(C.c_uint64)]
     L.mcomh_n_contigs.restype = sz; L.mcomh_n_contigs.argtypes = [vp]
     L.mcomh_contig_ref.restype = vp; L.mcomh_contig_ref.argtypes = [vp, sz, C.POINTER(sz)]
     L.mcomh_contig_n.restype = sz; L.mcomh_contig_n.argtypes = [vp, sz]
@@ -64,13 +66,15 @@ HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_destroy", "mco
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
-                    "mcomh_device_free"]
+                    "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order"]
 
 
-def decompress(folder: str, out_path: str) -> int:
-    """mcomh_decompress: stream files -> one read per line.  Returns the number of reads.  Host only."""
+def decompress(folder: str, out_path: str, order: bool = False) -> int:
+    """mcomh_decompress(_order): stream files -> one read per line (order=True: the -p file set, original order).
+    Returns the number of reads.  Host only."""
     n = C.c_uint64()
-    rc = load_host_library().mcomh_decompress(folder.encode(), out_path.encode(), C.byref(n))
+    lib = load_host_library()
+    rc = (lib.mcomh_decompress_order if order else lib.mcomh_decompress)(folder.encode(), out_path.encode(), C.byref(n))
     if rc:
         raise McomError(f"cannot decode the stream files in {folder}")
     return int(n.value)
@@ -171,9 +175,10 @@ class Pipeline:
 
     def dump_stages(self, path: str): self._check(self.lib.mcomh_dump_stages(self._h, path.encode()))
 
-    def cluster_dump(self, folder: str):
-        """Writes the reference's pre-bsc stream files (cluster_dump at one thread) into an existing directory."""
-        self._check(self.lib.mcomh_cluster_dump(self._h, folder.encode()))
+    def cluster_dump(self, folder: str, order: bool = False):
+        """Writes the reference's pre-bsc stream files (cluster_dump at one thread) into an existing directory;
+        order=True: the order-preserving file set of minicom -p."""
+        self._check((self.lib.mcomh_cluster_dump_order if order else self.lib.mcomh_cluster_dump)(self._h, folder.encode()))
 
     def prof_enable(self, on: bool = True): self._check(self.lib.mcomh_prof_enable(self._h, 1 if on else 0))
 

@@ -22,7 +22,7 @@ from minicom_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def make(tag, variant):
+def make(tag, variant, prefix="streams_"):
     with gzip.open(os.path.join(HERE, tag + ".reads.gz"), "rb") as f:
         rows = f.read().split(b"\n")[:-1]
     reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0]))
@@ -38,7 +38,7 @@ def make(tag, variant):
                 ti = tarfile.TarInfo(name); data = open(os.path.join(out, name), "rb").read()
                 ti.size = len(data); ti.mtime = 0
                 tf.addfile(ti, io.BytesIO(data))
-        with gzip.GzipFile(os.path.join(HERE, "streams_" + tag + ".tar.gz"), "wb", mtime=0) as g:
+        with gzip.GzipFile(os.path.join(HERE, prefix + tag + ".tar.gz"), "wb", mtime=0) as g:
             g.write(buf.getvalue())
         print(tag, {n: os.path.getsize(os.path.join(out, n)) for n in sorted(os.listdir(out))})
 
@@ -46,3 +46,4 @@ def make(tag, variant):
 if __name__ == "__main__":
     make("stages_L100", "L100")
     make("stages_L150", "L150")
+    make("stages_L100", "L100_order", prefix="streams_order_")       # -p: the order-preserving file set (ids streams)

@@ -74,3 +74,65 @@ def test_round_trip_at_a_size_no_fixture_covers():
         a = np.sort(got.view("S100").ravel()); b = np.sort(np.ascontiguousarray(reads).view("S100").ravel())
         assert np.array_equal(a, b)
     p.close()
+
+
+# ---- order-preserving mode (minicom -p, the reference compiled with ORDER): SURVEY section 8f rank 4, single-end part
+def _golden_order_streams(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, "streams_order_" + tag + ".tar.gz"), "rb") as g:
+        tf = tarfile.open(fileobj=io.BytesIO(g.read()))
+        return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
+
+
+def test_our_decoder_restores_the_original_order_from_the_reference_order_streams(golden_dir, tmp_path):
+    """CPU: mcomh_decompress_order applied to the -p file set written by the reference itself."""
+    from minicom_amd.pipeline import decompress
+    tag = "stages_L100"
+    d = tmp_path / "streams"; d.mkdir()
+    for name, data in _golden_order_streams(golden_dir, tag).items():
+        (d / name).write_bytes(data)
+    out = tmp_path / "reads.txt"
+    n = decompress(str(d), str(out), order=True)
+    want = _golden_reads(golden_dir, tag)
+    assert n == len(want)
+    assert out.read_bytes().split(b"\n")[:-1] == want            # the same reads in the same order
+
+
+@pytest.mark.gpu
+def test_order_stream_files_byte_identical_to_reference_and_exact(golden_dir, tmp_path):
+    from minicom_amd.pipeline import Pipeline, decompress
+    tag = "stages_L100"
+    rows = _golden_reads(golden_dir, tag)
+    reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+    p = Pipeline(reads, host_threads=4)
+    p.pre_process()
+    d = tmp_path / "ordered"; d.mkdir()
+    p.cluster_dump(str(d), order=True)
+    want = _golden_order_streams(golden_dir, tag)
+    assert sorted(os.listdir(d)) == sorted(want)
+    for name, data in want.items():
+        assert (d / name).read_bytes() == data, name                       # P1, order mode
+    out = tmp_path / "reads.txt"
+    assert decompress(str(d), str(out), order=True) == len(rows)
+    assert out.read_bytes().split(b"\n")[:-1] == rows                      # P2, exact order
+    # the default file set written afterwards from the same pipeline is unaffected by the order-mode dump
+    d2 = tmp_path / "default"; d2.mkdir()
+    p.cluster_dump(str(d2))
+    p.close()
+    for name, data in _golden_streams(golden_dir, tag).items():
+        assert (d2 / name).read_bytes() == data, name
+
+
+@pytest.mark.gpu
+def test_order_round_trip_at_a_size_no_fixture_covers(tmp_path):
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress
+    reads = np.concatenate([synth.synth_reads(31, 200000, 150), synth.synth_reads(32, 15000, 150, plumbing=True)])
+    p = Pipeline(reads, host_threads=16)
+    p.pre_process()
+    d = tmp_path / "s"; d.mkdir()
+    p.cluster_dump(str(d), order=True)
+    p.close()
+    out = tmp_path / "reads.txt"
+    assert decompress(str(d), str(out), order=True) == reads.shape[0]
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(reads.shape[0], 151)[:, :150]
+    assert np.array_equal(got, reads)
