@@ -8,6 +8,7 @@
 //   mcom_find_next_candidates: the lookup part of find_next (kthread_cb.c:267-291) for every contig
 #include "mcom_dev.hpp"
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 
@@ -321,6 +322,9 @@ __global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restric
 	}
 }
 
+int mcom_sketch_contigs_flat(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n, uint64_t n_chars,
+                             int w, int k, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap, uint64_t *h_total, int *used);
+
 extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
                                    int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
                                    uint64_t *h_total)
@@ -338,6 +342,11 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	uint64_t chars = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (!max_per_contig && getenv("MCOM_SKETCH_FLAT")) {                   // experiment: one thread per position (sketchflat.hip); measured slower (two passes)
+		int used = 0;
+		const int rcf = mcom_sketch_contigs_flat(ctx, d_seq, d_off, d_ids, n, chars, w, k, d_moff, d_out, cap, h_total, &used);
+		if (rcf || used) return rcf;
+	}
 	const uint64_t max_slots = chars / PIECE + 2 * (uint64_t)n + 1;
 	if (max_slots >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig pieces");
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -395,17 +404,13 @@ __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict
 {
 	__shared__ uint64_t CO[PK_T / 2 + 4], OF[PK_T / 2 + 4];
 	__shared__ uint32_t SB[PK_T * 8 + 16];
-	__shared__ uint32_t c0s;
+	__shared__ uint32_t srch[16];
 	__shared__ uint64_t lo_s, hi_s;
 	const uint64_t g0 = (uint64_t)blockIdx.x * PK_T;
 	const uint64_t g = g0 + threadIdx.x;
-	if (threadIdx.x == 0) {
-		uint32_t lo = 0, hi = n;
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= g0) lo = mid; else hi = mid; }
-		c0s = lo; lo_s = 0; hi_s = 0;
-	}
+	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return coff[c] <= g0; }, srch);
+	if (threadIdx.x == 0) { lo_s = 0; hi_s = 0; }
 	__syncthreads();
-	const uint32_t c0 = c0s;
 	const int NC = PK_T / 2 + 2;
 	for (int t = threadIdx.x; t < NC; t += PK_T) {
 		const uint64_t c = (uint64_t)c0 + t;

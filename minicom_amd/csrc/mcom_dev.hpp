@@ -93,6 +93,33 @@ __device__ __forceinline__ uint32_t mcom_hash64_lo(uint32_t key, uint32_t mask)
 
 static inline int mcom_words_per_read(int L) { return (2 * L + 63) / 64; }
 
+#ifdef __HIPCC__
+// Largest c in [0, n) with le(c) true, for a predicate that is true for a prefix of [0, n) and for c = 0.  Called by
+// ALL threads of a block (blockDim.x a multiple of 64, <= 1024): every round the threads probe blockDim.x evenly
+// spaced candidates at once, so a search over millions of contig offsets costs three dependent global loads instead
+// of the twenty-odd of a one-thread binary search -- which, paid once per block behind a barrier, was what limited
+// the position-space kernels.  scratch: 16 uint32 of LDS.
+template <class F> __device__ __forceinline__ uint32_t mcom_block_search(uint32_t n, F le, uint32_t *scratch)
+{
+	uint32_t lo = 0, hi = n;
+	const uint32_t T = blockDim.x, tid = threadIdx.x, nwv = T >> 6;
+	while (hi - lo > 1) {
+		const uint32_t step = (hi - lo + T - 1) / T;
+		const uint64_t idx = (uint64_t)lo + (uint64_t)(tid + 1) * step;
+		const bool pred = idx < hi && le((uint32_t)idx);
+		const uint64_t m = __ballot(pred);
+		if ((tid & 63) == 0) scratch[tid >> 6] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t cnt = 0;
+		for (uint32_t i = 0; i < nwv; ++i) cnt += scratch[i];
+		__syncthreads();
+		lo += cnt * step;
+		if (lo + step < hi) hi = lo + step;
+	}
+	return lo;
+}
+#endif
+
 // ---- exact key -> (run start, run length) map over a sorted record array (table.hip) ---------------------
 // Open addressing, linear probing, 16-byte slots {key, start | count << 32}, EMPTY key = ~0, load <= 0.5.
 struct McomTable {
