@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	// serialise tens of millions of atomics on one L2 channel
 	unsigned long long *cursor = cursors + (t & arena_mask);
 	const uint64_t arena0 = (uint64_t)(t & arena_mask) * arena_cap;
-	long ent_in = 0;                        // entries stored before the current piece   (wave uniform)
+	int ent_in = 0;                        // entries stored before the current piece   (wave uniform)
 	uint32_t run_in = 0;                    // run counter before the current piece       (wave uniform)
 	uint32_t ne_base = 0;                   // minimizers emitted before the current piece (wave uniform)
 	uint64_t qbase = 0;                     // unambiguous bases before the current group (wave uniform)
@@ -103,18 +103,18 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));   // bits 0..lane-1
 
 	// entry e (may be negative = the ring's initial fill) as the scan sees it
-	auto EXat = [&](long e) -> uint64_t { return e < 0 ? U64MAX : EX[e & EMASK]; };
-	auto EPat = [&](long e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & EMASK]; };
+	auto EXat = [&](int e) -> uint64_t { return e < 0 ? U64MAX : EX[e & EMASK]; };
+	auto EPat = [&](int e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & EMASK]; };
 	// newest smallest entry of [e, e+2^j) and its duplicate flag, from level j of the table
-	auto lvl = [&](int j, long e, bool &dup) -> long {
+	auto lvl = [&](int j, int e, bool &dup) -> int {
 		if (j == 0) { dup = false; return e; }
 		const uint8_t v = ST[j][e & EMASK]; dup = (v & 128) != 0; return e + (v & 127);
 	};
 	// newest smallest entry of the window of w entries ending at te (the reference's "min" after storing te)
-	auto wquery = [&](long te, bool &dup) -> long {
-		const long lo = te - w + 1, lo2 = te - (1L << LG) + 1;
+	auto wquery = [&](int te, bool &dup) -> int {
+		const int lo = te - w + 1, lo2 = te - (1 << LG) + 1;
 		bool da, db;
-		const long a = lvl(LG, lo, da), b = lvl(LG, lo2, db);
+		const int a = lvl(LG, lo, da), b = lvl(LG, lo2, db);
 		if (a == b) { dup = da || db; return a; }
 		const uint64_t xa = EXat(a), xb = EXat(b);
 		if (xa < xb) { dup = da; return a; }
@@ -125,24 +125,24 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); return v;
 	};
 	// what storing entry te makes the scan emit (sketch.c:138-161); put(x, p) in emission order
-	auto entry_emits = [&](long te, auto &&put) {
+	auto entry_emits = [&](int te, auto &&put) {
 		const uint64_t cx = EX[te & EMASK];
 		const int run = ER[te & EMASK];
-		long bidx = -(long)w; bool bdup = false;
+		int bidx = -w; bool bdup = false;
 		if (te > 0) bidx = wquery(te - 1, bdup);
 		const uint64_t bx = EXat(bidx); const uint32_t bp = EPat(bidx);
 		if (run == w + k - 1 && bdup && bx != U64MAX) {               // first full window: older copies of the minimum
-			for (long e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (bx == x && pp != bp) put(x, pp); }
+			for (int e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (bx == x && pp != bp) put(x, pp); }
 		}
 		if (cx <= bx) {
 			if (run >= w + k) put(bx, bp);
 		} else if (bidx == te - w) {                                  // the minimum has just left the window
 			if (run >= w + k - 1) {
 				put(bx, bp);
-				bool ndup; const long nidx = wquery(te, ndup);
+				bool ndup; const int nidx = wquery(te, ndup);
 				const uint64_t nx = EXat(nidx); const uint32_t np = EPat(nidx);
 				if (ndup && nx != U64MAX)
-					for (long e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (nx == x && np != pp) put(x, pp); }
+					for (int e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (nx == x && np != pp) put(x, pp); }
 			}
 		}
 	};
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		}
 		__syncthreads();
 		// ---- phase 1 + 1b: k-mer, hash, run counter and entry index of every position; entries into the ring
-		long ent_run = ent_in; uint32_t run_run = run_in;
+		int ent_run = ent_in; uint32_t run_run = run_in;
 #pragma unroll
 		for (int g = 0; g < NGRP; ++g) {
 			const int p = ps + g * 64 + lane;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			if (nlow) { const int hb = 63 - __clzll((long long)nlow); const uint64_t above = hb == 63 ? 0ull : ~((2ull << hb) - 1); run = (uint32_t)__popcll(incM & lowm & above); }
 			else run = run_run + (uint32_t)__popcll(incM & lowm);
 			if (isn || inc) {
-				const long te = ent_run + (long)__popcll(entM & (lowm >> 1));
+				const int te = ent_run + (int)__popcll(entM & (lowm >> 1));
 				const bool real = inc && run >= (uint32_t)k;
 				EX[te & EMASK] = real ? x : U64MAX;
 				EP[te & EMASK] = real ? (((uint32_t)p << 1) | (f & 1u)) : 0xFFFFFFFFu;
@@ -224,19 +224,19 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			// carry to the next group (uniform)
 			if (nM) { const int hb = 63 - __clzll((long long)nM); run_run = (uint32_t)__popcll(hb == 63 ? 0ull : (incM >> (hb + 1))); }
 			else run_run += (uint32_t)__popcll(incM);
-			ent_run += (long)__popcll(entM);
+			ent_run += (int)__popcll(entM);
 		}
 		__syncthreads();
 		// ---- phase 1c: sparse table over entries [ent_in - w, ent_run)
 		{
-			const long lo = ent_in - w, hi = ent_run;
+			const int lo = ent_in - w, hi = ent_run;
 			for (int j = 1; j <= LG; ++j) {
-				const long h = 1L << (j - 1);
-				for (long e = lo + lane; e + 2 * h <= hi; e += 64) {
+				const int h = 1 << (j - 1);
+				for (int e = lo + lane; e + 2 * h <= hi; e += 64) {
 					bool da, db;
-					const long a = lvl(j - 1, e, da), b = lvl(j - 1, e + h, db);
+					const int a = lvl(j - 1, e, da), b = lvl(j - 1, e + h, db);
 					const uint64_t xa = EXat(a), xb = EXat(b);
-					const long win = xa < xb ? a : b;                       // equal: b, the newer
+					const int win = xa < xb ? a : b;                       // equal: b, the newer
 					const bool dup = xa == xb ? true : (xa < xb ? da : db);
 					ST[j][e & EMASK] = (uint8_t)((win - e) | (dup ? 128 : 0));
 				}
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		uint64_t fx[NGRP]; uint32_t fp[NGRP];                              // an entry's first record: nearly always its only one
 #pragma unroll
 		for (int g = 0; g < NGRP; ++g) {
-			const long te = ent_in + 64 * g + lane;
+			const int te = ent_in + 64 * g + lane;
 			uint32_t m = 0;
 			fx[g] = 0; fp[g] = 0;
 			if (te < ent_run) entry_emits(te, [&](uint64_t x, uint32_t pp) { if (m == 0) { fx[g] = x; fp[g] = pp; } ++m; });
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		const int tail = (len + PIECE - 1) / PIECE;                       // chunk slot behind the pieces
 		if (ne_base < limit && ent_in > 0) {
 			// the table of the last piece covers the window ending at the last entry
-			bool d; const long b = wquery(ent_in - 1, d);
+			bool d; const int b = wquery(ent_in - 1, d);
 			const uint64_t bx = EXat(b);
 			if (bx != U64MAX) {
 				const unsigned long long at = atomicAdd(cursor, 1ull);

@@ -435,12 +435,17 @@ __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t
                                                        const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_pos,
                                                        unsigned long long *__restrict__ keys)
 {
-	__shared__ uint32_t srch[16];
+	__shared__ uint32_t c0s;
 	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
-	const uint32_t c0 = mcom_block_search(n_contigs, [&](uint32_t c) { return woff[c] + (uint64_t)g.maxoff * c <= g0; }, srch);
+	if (threadIdx.x == 0) {                                                // (the block-wide search measured 8 % slower here: more barriers)
+		uint32_t lo = 0, hi = n_contigs;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (woff[mid] + (uint64_t)g.maxoff * mid <= g0) lo = mid; else hi = mid; }
+		c0s = lo;
+	}
+	__syncthreads();
 	const uint64_t gi = g0 + threadIdx.x;
 	if (gi >= n_pos) return;
-	uint32_t c = c0;
+	uint32_t c = c0s;
 	while (c + 1 < n_contigs && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) <= gi) ++c;
 	const uint64_t nw = woff[c + 1] - woff[c];
 	if (nw == 0) return;
