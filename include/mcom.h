@@ -293,9 +293,13 @@ int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, uint64_t
  * h_totals[3] = { members, consensus chars, longest merged contig }.                                         */
 int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
                        int key_bits, uint64_t *d_jm, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals);
-/* mcom_merge_consensus with the tile list made on the device from d_jroff                                    */
+/* mcom_merge_consensus with the tile list made on the device from d_jroff.  With the claimed pairs (d_jobs, as
+ * given to mcom_merge_members) and the set they came from (d_seq, d_soff) only the columns where the two parents
+ * overlap are counted; elsewhere a column sees the members of one parent only and keeps that parent's character.
+ * All three NULL: every column is counted.                                                                   */
 int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_jm, const uint64_t *d_jmoff,
-                              const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs);
+                              const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs,
+                              const uint32_t *d_jobs, const uint8_t *d_seq, const uint64_t *d_soff);
 /* cp_cluster (:397-434): the new set holds the nj merged contigs first (their data and offset entries [0..nj]
  * already in d_seq2/d_soff2/d_mem2/d_moff2), then the nkeep contigs of the old set with d_flag[i] == 0, in
  * their order.  Out: the rest of the new arrays, d_keepidx[nkeep] = old index of every carried contig,

@@ -171,7 +171,8 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restrict__ packed, int W, const uint64_t *__restrict__ members,
                                                         const uint64_t *__restrict__ joff, const uint64_t *__restrict__ roff,
                                                         const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
-                                                        uint32_t n_tiles, int L, uint8_t *__restrict__ refs)
+                                                        uint32_t n_tiles, int L, uint8_t *__restrict__ refs,
+                                                        const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi)
 {
 	__shared__ uint32_t cc[4 * MC_TILE];
 	const uint32_t t = blockIdx.x;
@@ -179,8 +180,9 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 	const int lane = threadIdx.x;
 	const uint32_t j = tile_job[t];
 	const uint64_t m0 = joff[j], m1 = joff[j + 1];
-	const long len = (long)(roff[j + 1] - roff[j]);
-	const long lo = (long)tile_idx[t] * MC_TILE, hi = lo + MC_TILE < len ? lo + MC_TILE : len;
+	// the columns to count: the whole contig, or only the region given for the job (the overlap of the two parents)
+	const long len = reg_hi ? (long)reg_hi[j] : (long)(roff[j + 1] - roff[j]);
+	const long lo = (reg_lo ? (long)reg_lo[j] : 0) + (long)tile_idx[t] * MC_TILE, hi = lo + MC_TILE < len ? lo + MC_TILE : len;
 	for (int c = lane; c < 4 * MC_TILE; c += 64) cc[c] = 0;
 	__syncthreads();
 	// first member whose read can reach column lo: offset > lo - L (members are sorted by offset)
@@ -227,7 +229,20 @@ extern "C" int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, con
 	if (!d_packed || !d_members || !d_job_off || !d_ref_off || !d_tile_job || !d_tile_idx || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	McomProfScope ps_(ctx, PROF_CONSENSUS);
 	hipLaunchKernelGGL(k_merge_consensus, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs);
+	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// the same over one column range per job (merge.hip: only the overlap of the two parents is counted again)
+int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
+                                 const uint32_t *d_tile_job, const uint32_t *d_tile_idx, uint32_t n_tiles, int L, uint8_t *d_refs,
+                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi)
+{
+	if (n_tiles == 0) return MCOM_OK;
+	McomProfScope ps_(ctx, PROF_CONSENSUS);
+	hipLaunchKernelGGL(k_merge_consensus, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

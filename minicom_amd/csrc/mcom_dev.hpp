@@ -53,6 +53,10 @@ size_t mcom_scan_scratch_elems(size_t n);
 size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
+// consensus of one column range per job (consensus.hip)
+int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
+                                 const uint32_t *d_tile_job, const uint32_t *d_tile_idx, uint32_t n_tiles, int L, uint8_t *d_refs,
+                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi);
 // 64-bit exclusive scan (merge.hip): scratch of mcom_scan64_scratch_elems(n) uint64
 size_t mcom_scan64_scratch_elems(size_t n);
 int mcom_scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch);

@@ -240,32 +240,80 @@ __global__ void k_tile_fill(const uint32_t *__restrict__ toff, size_t nj, uint32
 	for (uint32_t t = a; t < b; ++t) { tjob[t] = (uint32_t)j; tidx[t] = t - a; }
 }
 
+// Outside the overlap of its two parents a merged contig's columns see exactly the members one parent had, so the
+// majority there is the parent's consensus character: only the overlap [shift, min(len_first, shift + len_second)) is
+// counted again (k_merge_consensus over that column range), the rest is copied from the parents' strings.
+__global__ void k_job_regions(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ soff, uint32_t *__restrict__ olo, uint32_t *__restrict__ ohi,
+                              uint32_t *__restrict__ tcnt)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j > nj) return;
+	if (j == nj) { tcnt[j] = 0; return; }
+	const Job J = jobs[j];
+	const bool afirst = J.pos_ori >= J.pos;
+	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
+	const uint64_t sh = afirst ? J.pos_ori - J.pos : J.pos - J.pos_ori;
+	const uint64_t lf = soff[f + 1] - soff[f], ls = soff[s + 1] - soff[s];
+	const uint64_t lo = sh < lf ? sh : lf, hi = lf < sh + ls ? lf : sh + ls;
+	olo[j] = (uint32_t)lo; ohi[j] = (uint32_t)(hi > lo ? hi : lo);
+	tcnt[j] = (uint32_t)((ohi[j] - olo[j] + MC_TILE - 1) / MC_TILE);
+}
+__global__ __launch_bounds__(256) void k_merge_copy(const Job *__restrict__ jobs, size_t nj, const uint8_t *__restrict__ seq, const uint64_t *__restrict__ soff,
+                                                    const uint64_t *__restrict__ jroff, const uint32_t *__restrict__ olo, const uint32_t *__restrict__ ohi,
+                                                    uint8_t *__restrict__ refs)
+{
+	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (j >= nj) return;
+	const int lane = threadIdx.x & 63;
+	const Job J = jobs[j];
+	const bool afirst = J.pos_ori >= J.pos;
+	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
+	const uint64_t sh = afirst ? J.pos_ori - J.pos : J.pos - J.pos_ori;
+	const uint64_t lf = soff[f + 1] - soff[f];
+	const uint8_t *sf = seq + soff[f], *ss = seq + soff[s];
+	const uint64_t len = jroff[j + 1] - jroff[j];
+	uint8_t *out = refs + jroff[j];
+	const uint64_t lo = olo[j], hi = ohi[j];
+	for (uint64_t c = lane; c < lo; c += 64) out[c] = sf[c];                 // before the overlap: the first parent alone
+	for (uint64_t c = hi + lane; c < len; c += 64) out[c] = c < lf ? sf[c] : ss[c - sh];   // behind it: whichever parent reaches there
+}
+
 extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_jm, const uint64_t *d_jmoff,
-                                         const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs)
+                                         const uint64_t *d_jroff, size_t nj, uint64_t total_chars, int L, uint8_t *d_refs,
+                                         const uint32_t *d_jobs, const uint8_t *d_seq, const uint64_t *d_soff)
 {
 	if (!ctx) return MCOM_E_ARG;
 	if (nj == 0) return MCOM_OK;
 	if (!d_packed || !d_jm || !d_jmoff || !d_jroff || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const bool regions = d_jobs && d_seq && d_soff;                          // parents known: count the overlaps only
 	const size_t max_tiles = (size_t)(total_chars / MC_TILE) + nj + 1;
 	if (max_tiles >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many consensus tiles");
-	int rc = mcom_ws_reserve(ctx, al256((nj + 1) * 4) + al256(mcom_scan_scratch_elems(nj + 1) * 4 + 1024) + 2 * al256(max_tiles * 4) + 256);
+	int rc = mcom_ws_reserve(ctx, 3 * al256((nj + 1) * 4) + al256(mcom_scan_scratch_elems(nj + 1) * 4 + 1024) + 2 * al256(max_tiles * 4) + 256);
 	if (rc) return rc;
 	WsCut w{(char*)ctx->ws, 0};
-	uint32_t *toff = w.take<uint32_t>(nj + 1);
+	uint32_t *toff = w.take<uint32_t>(nj + 1), *olo = w.take<uint32_t>(nj + 1), *ohi = w.take<uint32_t>(nj + 1);
 	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(nj + 1) + 256);
 	uint32_t *tjob = w.take<uint32_t>(max_tiles), *tidx = w.take<uint32_t>(max_tiles);
 	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
-	hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff);
+	if (regions) hipLaunchKernelGGL(k_job_regions, dim3(jblocks), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, olo, ohi, toff);
+	else hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, toff, toff, nj + 1, scr))) return rc;
 	uint32_t nt = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&nt, toff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (nt > max_tiles) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
-	if (nt == 0) return MCOM_OK;
-	hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
-	MCOM_LAUNCH_CHECK(ctx);
-	return mcom_merge_consensus(ctx, d_packed, d_jm, d_jmoff, d_jroff, tjob, tidx, nt, L, d_refs);
+	if (nt) {
+		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = mcom_merge_consensus_regions(ctx, d_packed, d_jm, d_jmoff, d_jroff, tjob, tidx, nt, L, d_refs, regions ? olo : nullptr, regions ? ohi : nullptr))) return rc;
+	}
+	if (regions) {
+		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // the workspace arrays are in use until here
+	return MCOM_OK;
 }
 
 // ---- untouched contigs ------------------------------------------------------------------------------------------------

@@ -212,6 +212,7 @@ struct mcomh_pipeline {
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint32_t cix_log2 = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
+	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
 	std::map<std::string, double> stat;
@@ -266,7 +267,8 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->rw = L >= 70 ? L / 2 - p->k : 3;                                             // preprocess.c:89-107
 	if (pp->w > 0) p->rw = pp->w;
 	p->numdict = pp->numdict;
-	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }   // A/B switch for measurements
+	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }
+	{ const char *fc = getenv("MCOMH_FULL_CONSENSUS"); p->full_consensus = fc && fc[0] == '1'; }   // A/B switch for measurements
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
 	if (host_reads) {
@@ -636,7 +638,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			maxlen = std::max(maxlen, tot[2]);
 			lap("t_merge_members");
 			// construct_ref2 of every merged contig (:327)
-			if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, B.mem.p, B.moff.p, B.soff.p, nj, tot[1], L, B.seq.p)))) return rc;
+			if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, B.mem.p, B.moff.p, B.soff.p, nj, tot[1], L, B.seq.p, p->full_consensus ? nullptr : d_jobs.p, A.seq.p, A.soff.p)))) return rc;
 			lap("t_merge_cons");
 			// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
 			if ((rc = p->gpu(mcom_contigs_carry(p->ctx, A.seq.p, A.soff.p, A.mem.p, A.moff.p, n, d_flag.p, nj, nkeep, B.seq.p, B.soff.p, B.mem.p, B.moff.p,
