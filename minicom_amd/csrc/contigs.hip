@@ -342,7 +342,7 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	uint64_t chars = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (!max_per_contig && getenv("MCOM_SKETCH_FLAT")) {                   // experiment: one thread per position (sketchflat.hip); measured slower (two passes)
+	if (!max_per_contig && getenv("MCOM_SKETCH_FLAT")) {                   // alternative: one thread per position (sketchflat.hip); measured equal, not faster
 		int used = 0;
 		const int rcf = mcom_sketch_contigs_flat(ctx, d_seq, d_off, d_ids, n, chars, w, k, d_moff, d_out, cap, h_total, &used);
 		if (rcf || used) return rcf;

@@ -14,12 +14,15 @@
 // "equal hash in the window" flag) and evaluates the reference's statements per position.  Window queries are clamped
 // to the contig's first position: entries before it are the ring's initial all-ones fill.  Counts per block, one scan,
 // the same kernel again writes the records at their final place (position order = contig order) and the per-contig
-// offsets.  Irregular input (even k, an ambiguous base, a per-contig limit) goes to the wave-per-contig kernel.
+// offsets (one pass: the records go to a temporary array first, block by block).  Irregular input (even k, an ambiguous base, a per-contig limit) goes to the wave-per-contig kernel.
 //
-// MEASURED (round 1, 100 M reads): bit-exact, but 144 ms per step against 85 ms for the wave-per-contig kernel -- 8 VALU
-// wave-instructions per position and pass (hash 3, sparse table 3, emission rules 2) times two passes.  Kept as an
-// opt-in experiment (MCOM_SKETCH_FLAT=1); it needs a single pass and a cheaper window minimum to pay off.
+// MEASURED (round 1, 100 M reads): bit-exact, and as fast as the wave-per-contig kernel but not faster (80 ms per step
+// either way: 8 VALU wave-instructions per position here -- hash 3, sparse table 3, emission rules 2 -- against 15 there,
+// but at a lower issue rate).  Kept as an opt-in alternative (MCOM_SKETCH_FLAT=1); a cheaper window minimum than the
+// log2(w)-level table is what would make it win.
 #include "mcom_dev.hpp"
+#include <vector>
+#include <algorithm>
 
 #define FTH 64                             // threads per block
 #define FPER 4                             // positions per thread
@@ -68,11 +71,12 @@ __global__ void k_flat_check(const uint8_t *__restrict__ seq, uint64_t n_chars, 
 // FTH threads handle FT = FTH * FPER consecutive positions (position g0 + i * FTH + tid for i < FPER): small blocks so
 // that many of them are in flight per CU -- a block is a chain of dependent global loads (contig search, characters,
 // offsets) whose latency only other blocks can hide.
-template <bool EMIT>
+struct FlatChunk { uint32_t start, count; };
+
 __global__ __launch_bounds__(FTH) void k_sketch_flat(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint32_t *__restrict__ ids,
-                                                     uint32_t n, uint64_t n_chars, int w, int k, uint32_t *__restrict__ block_cnt,
-                                                     uint32_t *__restrict__ block_c0, const uint32_t *__restrict__ block_base, uint32_t *__restrict__ moff,
-                                                     mcom_mm128 *__restrict__ out)
+                                                     uint32_t n, uint64_t n_chars, int w, int k, FlatChunk *__restrict__ chunks,
+                                                     uint32_t *__restrict__ mloc, mcom_mm128 *__restrict__ tmp, uint64_t arena_cap, uint32_t arena_mask,
+                                                     unsigned long long *__restrict__ cursors)
 {
 	__shared__ uint64_t PW[(FT + FH) / 32 + 2];     // 2-bit packed characters of [g0 - H, g0 + FT)
 	__shared__ uint64_t EX[FE];                     // entry e <-> position g0 - w + e: hash, U64MAX when not real
@@ -96,10 +100,7 @@ __global__ __launch_bounds__(FTH) void k_sketch_flat(const uint8_t *__restrict__
 			PW[2 * q + 1] = f_spread32(b0 >> 32) | (f_spread32(b1 >> 32) << 1);
 		}
 	}
-	// the contig that holds g0: searched in the counting pass, remembered for the writing pass
-	uint32_t c0;
-	if (EMIT) c0 = block_c0[blockIdx.x];
-	else { c0 = mcom_block_search(n, [&](uint32_t c) { return off[c] <= g0; }, srch); if (tid == 0) block_c0[blockIdx.x] = c0; }
+	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return off[c] <= g0; }, srch);   // the contig that holds g0
 	__syncthreads();
 	const uint64_t s0 = off[c0];
 	// ---- hashes of the entries: e in [0, FT + w) <-> position g0 - w + e
@@ -150,20 +151,19 @@ __global__ __launch_bounds__(FTH) void k_sketch_flat(const uint8_t *__restrict__
 		}
 		__syncthreads();
 	}
-	// ---- what storing an entry emits (sketch.c:138-161), FPER positions per thread
-	uint32_t run_base = 0;                                                    // records of the rows before the current one
-	uint32_t block_first = EMIT ? block_base[blockIdx.x] : 0;
-#pragma unroll 1
-	for (int row = 0; row < FPER; ++row) {
+	// ---- what storing an entry emits (sketch.c:138-161), FPER positions per thread.  First sweep: counts and every
+	// entry's first record (nearly always its only one); then one atomicAdd reserves the block's room in the temporary
+	// array (1024 arenas, as in contigs.hip); second sweep: write.
+	uint32_t mine_r[FPER], excl_r[FPER], fp_r[FPER], c_r[FPER]; uint64_t fx_r[FPER];
+	uint32_t run_base = 0;
+	auto row_eval = [&](int row, auto &&put_fn) {
 		const uint64_t g = g0 + (uint64_t)row * FTH + tid;
-		const bool live = g < n_chars;
-		uint32_t c = c0;
-		if (live) while (c + 1 < n && off[c + 1] <= g) ++c;
-		const uint64_t cs = live ? off[c] : 0, ce = live ? off[c + 1] : 0;
+		const uint32_t c = c_r[row];
+		const uint64_t cs = off[c], ce = off[c + 1];
 		const int te = w + row * FTH + tid;                                   // my entry
 		const int64_t csrel = (int64_t)cs - ((int64_t)g0 - w);                // entry of my contig's first position
-		const int first_e = (live && csrel > 0) ? (int)csrel : 0;            // before it: the ring's initial fill
-		const int64_t prel = live ? (int64_t)(g - cs) : 0;
+		const int first_e = csrel > 0 ? (int)csrel : 0;                       // before it: the ring's initial fill
+		const int64_t prel = (int64_t)(g - cs);
 		auto EXat = [&](int e) -> uint64_t { return e < first_e ? U64MAX : EX[e]; };
 		auto EPat = [&](int e) -> uint32_t { return e < first_e ? 0xFFFFFFFFu : EP[e]; };
 		// newest smallest entry of [lo, hi] (hi - lo + 1 <= w), entries before the contig start being all-ones
@@ -179,40 +179,44 @@ __global__ __launch_bounds__(FTH) void k_sketch_flat(const uint8_t *__restrict__
 			dup = xa == xb ? true : db;
 			return b;
 		};
-		auto entry_emits = [&](auto &&put) {
-			const uint64_t cx = EX[te];
-			const int64_t run = prel + 1;
-			int bidx = te - w; bool bdup = false;                              // prel == 0: the ring is all initial fill
-			if (prel > 0) bidx = wquery(te - w, te - 1, bdup);
-			const bool binit = prel == 0;
-			const uint64_t bx = binit ? U64MAX : EX[bidx]; const uint32_t bp = binit ? 0xFFFFFFFFu : EP[bidx];
-			if (run == w + k - 1 && bdup && bx != U64MAX) {
-				for (int e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (bx == x && pp != bp) put(x, pp); }
+		const uint64_t cx = EX[te];
+		const int64_t run = prel + 1;
+		int bidx = te - w; bool bdup = false;                                  // prel == 0: the ring is all initial fill
+		if (prel > 0) bidx = wquery(te - w, te - 1, bdup);
+		const bool binit = prel == 0;
+		const uint64_t bx = binit ? U64MAX : EX[bidx]; const uint32_t bp = binit ? 0xFFFFFFFFu : EP[bidx];
+		if (run == w + k - 1 && bdup && bx != U64MAX) {
+			for (int e = te - w + 1; e < te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (bx == x && pp != bp) put_fn(x, pp); }
+		}
+		if (cx <= bx) {
+			if (run >= w + k) put_fn(bx, bp);
+		} else if (bidx == te - w) {
+			if (run >= w + k - 1) {
+				put_fn(bx, bp);
+				bool ndup; const int nidx = wquery(te - w + 1, te, ndup);
+				const uint64_t nx = EX[nidx]; const uint32_t np = EP[nidx];
+				if (ndup && nx != U64MAX)
+					for (int e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (nx == x && np != pp) put_fn(x, pp); }
 			}
-			if (cx <= bx) {
-				if (run >= w + k) put(bx, bp);
-			} else if (bidx == te - w) {
-				if (run >= w + k - 1) {
-					put(bx, bp);
-					bool ndup; const int nidx = wquery(te - w + 1, te, ndup);
-					const uint64_t nx = EX[nidx]; const uint32_t np = EP[nidx];
-					if (ndup && nx != U64MAX)
-						for (int e = te - w + 1; e <= te; ++e) { const uint64_t x = EXat(e); const uint32_t pp = EPat(e); if (nx == x && np != pp) put(x, pp); }
-				}
-			}
-			if ((uint64_t)g + 1 == ce) {                                      // last position: the minimum still held (sketch.c:163-164)
-				bool d; const int b = wquery(te - w + 1, te, d);
-				if (EX[b] != U64MAX) put(EX[b], EP[b]);
-			}
-		};
-		uint32_t mine = 0;
-		uint64_t fx = 0; uint32_t fp = 0;
-		if (live) entry_emits([&](uint64_t x, uint32_t pp) { if (mine == 0) { fx = x; fp = pp; } ++mine; });
-		// prefix inside the row, rows in order
+		}
+		if ((uint64_t)g + 1 == ce) {                                          // last position: the minimum still held (sketch.c:163-164)
+			bool d; const int b = wquery(te - w + 1, te, d);
+			if (EX[b] != U64MAX) put_fn(EX[b], EP[b]);
+		}
+	};
+#pragma unroll
+	for (int row = 0; row < FPER; ++row) {
+		const uint64_t g = g0 + (uint64_t)row * FTH + tid;
+		const bool live = g < n_chars;
+		uint32_t c = c0;
+		if (live) while (c + 1 < n && off[c + 1] <= g) ++c;
+		c_r[row] = c;
+		uint32_t mine = 0; uint64_t fx = 0; uint32_t fp = 0;
+		if (live) row_eval(row, [&](uint64_t x, uint32_t pp) { if (mine == 0) { fx = x; fp = pp; } ++mine; });
 		uint32_t incl = mine;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-		uint32_t add = 0, all = incl;
+		uint32_t add = 0, all;
 		if (FTH > 64) {
 			__syncthreads();
 			if (lane == 63) wsum[wv] = incl;
@@ -220,22 +224,61 @@ __global__ __launch_bounds__(FTH) void k_sketch_flat(const uint8_t *__restrict__
 			all = 0;
 			for (int q = 0; q < FTH / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
 		} else all = __shfl(incl, 63, 64);
-		if (EMIT) {
-			const uint32_t at = block_first + run_base + add + incl - mine;
-			if (live && g == cs) {                                            // my contig starts here, and so do the empty ones before it
-				moff[c] = at;
-				for (uint32_t cc = c; cc > 0 && off[cc - 1] == cs; --cc) moff[cc - 1] = at;
-			}
-			if (mine) {
-				const uint64_t idhi = (uint64_t)(ids ? ids[c] : (uint32_t)(c << 8)) << 32;
-				auto rec = [&](uint64_t x, uint32_t pp) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); return v; };
-				if (mine == 1) out[at] = rec(fx, fp);
-				else { uint32_t o = at; entry_emits([&](uint64_t x, uint32_t pp) { out[o++] = rec(x, pp); }); }
-			}
+		mine_r[row] = mine; fx_r[row] = fx; fp_r[row] = fp; excl_r[row] = run_base + add + incl - mine;
+		if (live && g == off[c]) {                                            // my contig starts here, and so do the empty ones before it
+			mloc[c] = excl_r[row];
+			for (uint32_t cc = c; cc > 0 && off[cc - 1] == off[c]; --cc) mloc[cc - 1] = excl_r[row];
 		}
 		run_base += all;
 	}
-	if (!EMIT && tid == 0) block_cnt[blockIdx.x] = run_base;
+	// room for the block's records
+	__shared__ unsigned long long start_s;
+	const uint32_t arena = blockIdx.x & arena_mask;
+	if (tid == 0) {
+		unsigned long long st = 0;
+		if (run_base) st = atomicAdd(&cursors[arena], (unsigned long long)run_base);
+		start_s = st;
+		FlatChunk ck; ck.start = (uint32_t)((uint64_t)arena * arena_cap + st); ck.count = run_base; chunks[blockIdx.x] = ck;
+	}
+	__syncthreads();
+	const unsigned long long st = start_s;
+	if (st + run_base > arena_cap) return;                                    // the arena is full: counted, not written (the caller retries)
+	mcom_mm128 *dst = tmp + (uint64_t)arena * arena_cap + st;
+#pragma unroll
+	for (int row = 0; row < FPER; ++row) {
+		if (!mine_r[row]) continue;
+		const uint32_t c = c_r[row];
+		const uint64_t idhi = (uint64_t)(ids ? ids[c] : (uint32_t)(c << 8)) << 32;
+		auto rec = [&](uint64_t x, uint32_t pp) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); return v; };
+		if (mine_r[row] == 1) dst[excl_r[row]] = rec(fx_r[row], fp_r[row]);
+		else { uint32_t o = excl_r[row]; row_eval(row, [&](uint64_t x, uint32_t pp) { dst[o++] = rec(x, pp); }); }
+	}
+}
+
+// the records of block b, to their final place (block order = position order = contig order)
+__global__ __launch_bounds__(256) void k_flat_gather(const FlatChunk *__restrict__ chunks, const uint32_t *__restrict__ base, size_t nblocks,
+                                                     const mcom_mm128 *__restrict__ tmp, mcom_mm128 *__restrict__ out)
+{
+	const size_t b = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (b >= nblocks) return;
+	const int lane = threadIdx.x & 63;
+	const FlatChunk ck = chunks[b];
+	const uint32_t o = base[b];
+	for (uint32_t i = lane; i < ck.count; i += 64) out[o + i] = tmp[ck.start + i];
+}
+__global__ void k_flat_counts(const FlatChunk *__restrict__ chunks, size_t nblocks, uint32_t *__restrict__ cnt)
+{
+	const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b <= nblocks) cnt[b] = b < nblocks ? chunks[b].count : 0u;
+}
+// offsets of the contigs: the base of the block that holds the contig's first position + the prefix inside it
+__global__ void k_flat_moff(const uint64_t *__restrict__ off, uint32_t n, uint64_t n_chars, const uint32_t *__restrict__ base, const uint32_t *__restrict__ mloc,
+                            uint32_t total, uint32_t *__restrict__ moff)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > n) return;
+	if (c == n || off[c] >= n_chars) { moff[c] = total; return; }            // the end, and empty contigs behind the last character
+	moff[c] = base[off[c] / FT] + mloc[c];
 }
 
 // 0 = done through the flat path (*used = 1) or not applicable (*used = 0, nothing written); else an error
@@ -247,35 +290,49 @@ int mcom_sketch_contigs_flat(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	const uint64_t nblocks = (n_chars + FT - 1) / FT;
 	if (nblocks >= (1ull << 31)) return MCOM_OK;
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-	const size_t cnt_b = al((nblocks + 1) * 4), scr_b = al(mcom_scan_scratch_elems(nblocks + 1) * 4 + 1024);
-	int rc = mcom_ws_reserve(ctx, 3 * cnt_b + scr_b + 256);
+	uint32_t arenas = 1; while (arenas < 1024 && (size_t)arenas * 4096 <= nblocks) arenas <<= 1;
+	const uint64_t arena_cap = cap / arenas;
+	const size_t cnt_b = al((nblocks + 1) * 4), scr_b = al(mcom_scan_scratch_elems(nblocks + 1) * 4 + 1024), chunk_b = al(nblocks * sizeof(FlatChunk)),
+	             mloc_b = al((n + 1) * 4), cur_b = al(arenas * 8), tmp_b = al(cap * sizeof(mcom_mm128));
+	int rc = mcom_ws_reserve(ctx, 2 * cnt_b + scr_b + chunk_b + mloc_b + cur_b + 256 + tmp_b);
 	if (rc) return rc;
-	char *base = (char*)ctx->ws;
-	uint32_t *cnt = (uint32_t*)base, *bbase = (uint32_t*)(base + cnt_b), *bc0 = (uint32_t*)(base + 2 * cnt_b), *scr = (uint32_t*)(base + 3 * cnt_b);
-	unsigned int *bad = (unsigned int*)(base + 3 * cnt_b + scr_b);
-	MCOM_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+	char *base = (char*)ctx->ws; size_t o = 0;
+	auto take = [&](size_t b) { char *q = base + o; o += b; return q; };
+	uint32_t *cnt = (uint32_t*)take(cnt_b), *bbase = (uint32_t*)take(cnt_b), *scr = (uint32_t*)take(scr_b);
+	FlatChunk *chunks = (FlatChunk*)take(chunk_b);
+	uint32_t *mloc = (uint32_t*)take(mloc_b);
+	unsigned long long *cursors = (unsigned long long*)take(cur_b);
+	unsigned int *bad = (unsigned int*)take(256);
+	mcom_mm128 *tmp = (mcom_mm128*)take(tmp_b);
+	MCOM_HIP(ctx, hipMemsetAsync(cursors, 0, cur_b + 256, ctx->stream));
 	hipLaunchKernelGGL(k_flat_check, dim3((unsigned)((n_chars / 16 + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_seq, n_chars, bad);
 	unsigned int hb = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (hb) return MCOM_OK;                                                   // an ambiguous base somewhere: the general kernel
 	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL((k_sketch_flat<false>), dim3((unsigned)nblocks), dim3(FTH), 0, ctx->stream, d_seq, d_off, d_ids, (uint32_t)n, n_chars, w, k, cnt,
-	                   bc0, (const uint32_t*)nullptr, (uint32_t*)nullptr, (mcom_mm128*)nullptr); }
+	hipLaunchKernelGGL(k_sketch_flat, dim3((unsigned)nblocks), dim3(FTH), 0, ctx->stream, d_seq, d_off, d_ids, (uint32_t)n, n_chars, w, k, chunks, mloc, tmp,
+	                   arena_cap, arenas - 1, cursors); }
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemsetAsync(cnt + nblocks, 0, 4, ctx->stream));
+	hipLaunchKernelGGL(k_flat_counts, dim3((unsigned)((nblocks + 1 + 255) / 256)), dim3(256), 0, ctx->stream, chunks, (size_t)nblocks, cnt);
 	if ((rc = mcom_scan_u32(ctx, cnt, bbase, nblocks + 1, scr))) return rc;
+	std::vector<unsigned long long> fill(arenas);
 	uint32_t total = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(fill.data(), cursors, arenas * 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipMemcpyAsync(&total, bbase + nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	unsigned long long most = 0, sum = 0;
+	for (unsigned long long f : fill) { most = std::max(most, f); sum += f; }
 	*used = 1;
 	if (h_total) *h_total = total;
-	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
-	MCOM_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)d_moff, (int)total, n + 1, ctx->stream));   // the end, and trailing empty contigs
-	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL((k_sketch_flat<true>), dim3((unsigned)nblocks), dim3(FTH), 0, ctx->stream, d_seq, d_off, d_ids, (uint32_t)n, n_chars, w, k, (uint32_t*)nullptr,
-	                   bc0, bbase, d_moff, d_out); }
+	if (sum >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many minimizers");
+	if (most > arena_cap) {
+		if (h_total) *h_total = (most + 1) * arenas;
+		return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", sum, cap);
+	}
+	hipLaunchKernelGGL(k_flat_moff, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, (uint32_t)n, n_chars, bbase, mloc, total, d_moff);
+	if (total) hipLaunchKernelGGL(k_flat_gather, dim3((unsigned)((nblocks * 64 + 255) / 256)), dim3(256), 0, ctx->stream, chunks, bbase, (size_t)nblocks, tmp, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                          // `total` and the workspace arrays are in use until here
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                          // the workspace arrays are in use until here
 	return MCOM_OK;
 }
