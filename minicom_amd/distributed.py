@@ -27,28 +27,63 @@ def bucket_owner(x: torch.Tensor, world: int) -> torch.Tensor:
     return (x & ((1 << BUCKET_BITS) - 1)) % world
 
 
-def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tensor, group=None):
+# A single all_to_all_single message above about 1 GiB arrives HALF on this stack (RCCL of PyTorch 2.10 / ROCm 7.0,
+# measured on MI355X: 1024 MiB intact, 1536 MiB and more only the first half -- tools/dbg_a2a.py), without any error.
+# The exchange is therefore cut into slices whose per-peer messages stay far below that, and every slice is verified
+# with a checksum that travels beside it.
+MAX_MESSAGE_BYTES = 256 << 20
+
+
+def _checksums(rows_s: torch.Tensor, counts: list) -> torch.Tensor:
+    """Wrapping int64 sum of every per-peer segment of the send buffer."""
+    out, o = [], 0
+    for c in counts:
+        out.append(rows_s[o:o + c].sum() if c else rows_s.new_zeros(()))
+        o += c
+    return torch.stack(out)
+
+
+def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tensor, group=None, max_message_bytes: int = MAX_MESSAGE_BYTES):
     """All-to-all of the reads of this rank to the owners of their minimizer buckets.
 
     rec_x : int64 [n]     minimizer hash of every kept read of this rank
     rids  : int64 [n]     global read ids
     rows  : int64 [n, W]  packed rows
-    Returns (rids_recv int64 [m], rows_recv int64 [m, W]) ordered by source rank, then by the sender's order
-    (so ascending global rid when every rank holds a contiguous ascending rid range)."""
+    Returns (rids_recv int64 [m], rows_recv int64 [m, W]).  The reads travel in slices of the sender's order (so that no
+    message exceeds max_message_bytes); inside a slice they arrive ordered by source rank, then by the sender's order.
+    Raises RuntimeError when a slice does not arrive intact."""
     world = dist.get_world_size(group)
-    owner = bucket_owner(rec_x, world)
-    perm = torch.argsort(owner, stable=True)
-    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    sc, rc = send_counts.tolist(), recv_counts.tolist()
-    m = int(sum(rc))
-    W = rows.shape[1]
-    rids_s = rids[perm].contiguous()
-    rows_s = rows[perm].contiguous()
-    rids_r = torch.empty(m, dtype=rids.dtype, device=rids.device)
-    rows_r = torch.empty((m, W), dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(rids_r, rids_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
-    dist.all_to_all_single(rows_r.view(-1), rows_s.view(-1), output_split_sizes=[c * W for c in rc],
-                           input_split_sizes=[c * W for c in sc], group=group)
-    return rids_r, rows_r
+    n, W = int(rows.shape[0]), int(rows.shape[1])
+    owner_all = bucket_owner(rec_x, world)
+    # the largest slice any rank needs decides the number of rounds for everybody (collectives must match)
+    per_slice = max(1, max_message_bytes // (8 * W))
+    rounds = torch.tensor([(n + per_slice - 1) // per_slice], dtype=torch.int64, device=rows.device)
+    dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, int(rounds.item()))
+    out_rids, out_rows = [], []
+    for r in range(rounds):
+        lo, hi = min(n, r * per_slice), min(n, (r + 1) * per_slice)
+        owner = owner_all[lo:hi]
+        perm = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        m = int(sum(rc))
+        rids_s = rids[lo:hi][perm].contiguous()
+        rows_s = rows[lo:hi][perm].contiguous()
+        rids_r = torch.empty(m, dtype=rids.dtype, device=rids.device)
+        rows_r = torch.empty((m, W), dtype=rows.dtype, device=rows.device)
+        dist.all_to_all_single(rids_r, rids_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        dist.all_to_all_single(rows_r.view(-1), rows_s.view(-1), output_split_sizes=[c * W for c in rc],
+                               input_split_sizes=[c * W for c in sc], group=group)
+        # what left must be what arrived
+        sums_s = _checksums(rows_s, sc) + _checksums(rids_s, sc)
+        sums_r = torch.empty_like(sums_s)
+        dist.all_to_all_single(sums_r, sums_s, group=group)
+        if not torch.equal(sums_r, _checksums(rows_r, rc) + _checksums(rids_r, rc)):
+            raise RuntimeError(f"minimizer-bucket exchange: slice {r} did not arrive intact (collective library fault)")
+        out_rids.append(rids_r); out_rows.append(rows_r)
+    if len(out_rows) == 1:
+        return out_rids[0], out_rows[0]
+    return torch.cat(out_rids), torch.cat(out_rows)
