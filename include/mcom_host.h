@@ -68,6 +68,16 @@ int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads
  * (decompress.c:109-493), which writes the reads in their original order.                                        */
 int mcomh_cluster_dump_order(mcomh_pipeline *p, const char *folder);
 int mcomh_decompress_order(const char *folder, const char *out_path, uint64_t *n_reads);
+/* ... and the paired-end part (minicompe = the reference compiled with _PE, kthread_dump_pe.c:218-619): the pipeline
+ * holds the reads of the first file as rows [0, n/2) and their mates as rows [n/2, n) (mcomh_fastq_pair_to_device);
+ * besides the contig / list streams the file set carries one file bit per read and, for every read of the second
+ * file, the output line of its mate (peids.bin.*, file.bin.*).  The inverse (decompress.c:780-1212) writes the first
+ * file's reads to out_path1 and every mate to the same line of out_path2.                                          */
+int mcomh_cluster_dump_pe(mcomh_pipeline *p, const char *folder);
+int mcomh_decompress_pe(const char *folder, const char *out_path1, const char *out_path2, uint64_t *n_pairs);
+/* both files of a pair into one device matrix, second file behind the first; MCOM_E_ARG when the counts differ      */
+int mcomh_fastq_pair_to_device(const char *path1, const char *path2, int device, int *L, size_t chunk_reads, uint8_t **d_reads, size_t *n,
+                               char *err, size_t err_cap);
 
 /* FASTQ / FASTA ingest (bseq_open + bseq_read, bseq.c:19-66; kseq.h), plain or gzip.
  * Every read must have the same length (bseq.c:54-57 exits otherwise; here MCOM_E_ARG).  *L == 0: taken from

@@ -246,3 +246,101 @@ extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, 
 	if (n_reads) *n_reads = n_seq;
 	return 0;
 }
+
+// ---- paired end (_PE): decomp_AATTNN_pe (decompress.c:963-1212) + decompress_pe (:780-917) ----------------------------
+// Reads of the first file are written to out_path1 in stream order (the eight lists, then the contig members); a read
+// of the second file carries the line number of its mate (peids streams, one file bit per read says which kind a
+// read is) and goes to that line of out_path2: line i of the two outputs is a pair.
+extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, const char *out_path2, uint64_t *n_pairs)
+{
+	if (!folder || !out_path1 || !out_path2) return -1;
+	const std::string dir(folder);
+	FILE *fi = fopen((dir + "/info.txt").c_str(), "r");
+	if (!fi) return -1;
+	int L = 0, nth = 0; long half = 0, na = 0, nt = 0, nn = 0;
+	if (fscanf(fi, "%d %d %ld %ld %ld %ld", &L, &nth, &half, &na, &nt, &nn) != 6) { fclose(fi); return -1; }
+	fclose(fi);
+	if (L < 1 || L > 256 || nth < 1 || half < 0) return -1;
+	std::vector<char> table((size_t)half * (size_t)L, 0);
+	std::vector<uint8_t> seen((size_t)half, 0);
+	FILE *out = fopen(out_path1, "w");
+	if (!out) return -1;
+	uint64_t left = 0; bool bad = false;
+	struct Pairing {                                                      // file bits + mate numbers of one stream set
+		std::vector<uint8_t> fb, ids; size_t ip = 0; size_t bpos = 0; int k = 8; unsigned cur = 0;
+		int bit() { if (k >= 8) { cur = bpos < fb.size() ? fb[bpos++] : 0; k = 0; } const int c = (int)(cur & 1); cur >>= 1; ++k; return c; }
+		bool id(uint32_t &v) { if (ip + 4 > ids.size()) return false; memcpy(&v, ids.data() + ip, 4); ip += 4; return true; }
+	};
+	auto place = [&](Pairing &pr, const std::string &s) {
+		if ((int)s.size() != L) { bad = true; return; }
+		if (pr.bit()) {                                                    // a read of the second file: to its mate's line
+			uint32_t v; if (!pr.id(v) || v >= (uint64_t)half || seen[v]) { bad = true; return; }
+			memcpy(table.data() + (size_t)v * L, s.data(), (size_t)L); seen[v] = 1;
+		} else { fwrite(s.data(), 1, s.size(), out); fputc('\n', out); ++left; }
+	};
+	std::vector<uint8_t> buf;
+	std::string seq;
+	Pairing sp;
+	if (!slurp(dir + "/file.bin.sp", sp.fb) || !slurp(dir + "/peids.bin.sp", sp.ids)) { fclose(out); return -1; }
+	for (long i = 0; i < na; ++i) place(sp, std::string((size_t)L, 'A'));
+	for (long i = 0; i < nt; ++i) place(sp, std::string((size_t)L, 'T'));
+	for (long i = 0; i < nn; ++i) place(sp, std::string((size_t)L, 'N'));
+	{
+		const char bases[3] = {'A', 'T', 'N'}; const char *names[3] = {"AA.txt", "TT.txt", "NN.txt"};
+		for (int q = 0; q < 3; ++q) {
+			if (!slurp(dir + "/" + names[q], buf)) { fclose(out); return -1; }
+			const std::string cref((size_t)L, bases[q]);
+			size_t s = 0;
+			for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); s = i + 1; place(sp, seq); }
+		}
+	}
+	if (!slurp(dir + "/single_N.seq", buf)) { fclose(out); return -1; }
+	{ size_t s = 0; for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { seq.assign((const char*)buf.data() + s, i - s); s = i + 1; place(sp, seq); } }
+	if (!slurp(dir + "/single.seq", buf)) { fclose(out); return -1; }
+	{
+		// the last byte may be padded with up to three A: reads are taken while whole reads remain (4 bases per byte)
+		const size_t whole = buf.size() * 4 / (size_t)L;
+		DnaReader r(buf);
+		for (size_t i = 0; i < whole; ++i) {
+			seq.clear();
+			for (int j = 0; j < L; ++j) seq.push_back("ACGT"[r.next() & 3]);
+			place(sp, seq);
+		}
+	}
+	for (int th = 0; th < nth; ++th) {
+		std::vector<uint8_t> bref, bpos, bdir, bdif;
+		Pairing pr;
+		const std::string sfx = "." + std::to_string(th);
+		if (!slurp(dir + "/ref.bin" + sfx, bref) || !slurp(dir + "/beg_pos.bin" + sfx, bpos) || !slurp(dir + "/dir.bin" + sfx, bdir) ||
+		    !slurp(dir + "/dif_char.txt" + sfx, bdif) || !slurp(dir + "/file.bin" + sfx, pr.fb) || !slurp(dir + "/peids.bin" + sfx, pr.ids)) { fclose(out); return -1; }
+		DnaReader rr(bref); BitReader dr(bdir);
+		size_t pp = 0, dp = 0;
+		std::string ref;
+		while (pp + 4 <= bpos.size()) {
+			uint32_t num; memcpy(&num, bpos.data() + pp, 4); pp += 4;
+			ref.clear();
+			int pre = 0;
+			for (uint32_t q = 0; q < num; ++q) {
+				if (pp + 2 > bpos.size()) { fclose(out); return -1; }
+				uint16_t d; memcpy(&d, bpos.data() + pp, 2); pp += 2;
+				const int pos = pre + d; pre = pos;
+				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) { fclose(out); return -1; } ref.push_back("ACGT"[c]); }
+				const int rev = dr.next();
+				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
+				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				dp = e + 1;
+				if (rev) revcomp(seq);
+				place(pr, seq);
+			}
+		}
+	}
+	fclose(out);
+	if (bad || left != (uint64_t)half) return -1;
+	for (uint8_t s : seen) if (!s) return -1;
+	FILE *out2 = fopen(out_path2, "w");
+	if (!out2) return -1;
+	for (long i = 0; i < half; ++i) { fwrite(table.data() + (size_t)i * L, 1, (size_t)L, out2); fputc('\n', out2); }
+	fclose(out2);
+	if (n_pairs) *n_pairs = (uint64_t)half;
+	return 0;
+}

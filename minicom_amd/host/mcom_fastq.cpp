@@ -165,3 +165,26 @@ extern "C" int mcomh_fastq_to_device(const char *path, int device, int *L, size_
 }
 
 extern "C" void mcomh_device_free(void *d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }
+
+// paired end: bseq_read + bseq_read_second (preprocess.c:52-75) -- the mates of read i of the first file is read n/2 + i
+extern "C" int mcomh_fastq_pair_to_device(const char *path1, const char *path2, int device, int *L, size_t chunk_reads, uint8_t **d_reads, size_t *n,
+                                          char *err, size_t err_cap)
+{
+	if (!d_reads || !n || !L) return MCOM_E_ARG;
+	*d_reads = nullptr; *n = 0;
+	uint8_t *d1 = nullptr, *d2 = nullptr; size_t n1 = 0, n2 = 0;
+	int rc = mcomh_fastq_to_device(path1, device, L, chunk_reads, &d1, &n1, err, err_cap);
+	if (!rc) rc = mcomh_fastq_to_device(path2, device, L, chunk_reads, &d2, &n2, err, err_cap);
+	if (!rc && n1 != n2) { if (err && err_cap) snprintf(err, err_cap, "the two files hold %zu and %zu reads", n1, n2); rc = MCOM_E_ARG; }
+	uint8_t *d = nullptr;
+	if (!rc && n1) {
+		const size_t bytes = n1 * (size_t)*L;
+		if (hipMalloc(&d, 2 * bytes + 16) != hipSuccess) rc = MCOM_E_NOMEM;
+		else if (hipMemcpy(d, d1, bytes, hipMemcpyDeviceToDevice) != hipSuccess || hipMemcpy(d + bytes, d2, bytes, hipMemcpyDeviceToDevice) != hipSuccess) rc = MCOM_E_HIP;
+	}
+	if (d1) (void)hipFree(d1);
+	if (d2) (void)hipFree(d2);
+	if (rc) { if (d) (void)hipFree(d); return rc; }
+	*d_reads = d; *n = 2 * n1;
+	return MCOM_OK;
+}

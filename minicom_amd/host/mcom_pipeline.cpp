@@ -1122,9 +1122,13 @@ static bool write_ids(const std::string &path, const std::vector<uint32_t> &ids)
 	return true;
 }
 
-static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
+// mode 0: default; 1: order-preserving (-p, ORDER); 2: paired end (_PE: reads [0, n/2) are the first file, the rest their mates)
+static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 {
 	if (!p || !folder) return MCOM_E_ARG;
+	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
+	const uint32_t half = (uint32_t)(p->n / 2);
+	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
 	{ const int rcm = materialize(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
 	const size_t n = p->n;
@@ -1143,8 +1147,9 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 	};
 	auto open = [&](const char *name, const char *mode) { std::string path = std::string(folder) + "/" + name; return fopen(path.c_str(), mode); };
 	FILE *fref = open("ref.bin.0", "wb"), *fpos = open("beg_pos.bin.0", "wb"), *fdir = open("dir.bin.0", "wb"), *fdif = open("dif_char.txt.0", "w");
-	FILE *fids = order ? open("ids.bin.0", "wb") : nullptr;                       // kthread_dump.c:266-269
-	if (!fref || !fpos || !fdir || !fdif || (order && !fids)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	FILE *fids = order ? open("ids.bin.0", "wb") : pe ? open("ids.txt.0", "w") : nullptr;   // kthread_dump.c:266-269, kthread_dump_pe.c:150
+	if (!fref || !fpos || !fdir || !fdif || (sorted && !fids)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	std::vector<uint32_t> pe_members;                                             // paired end: the members in stream order
 	BitWriter refbin(fref, 2), dirbin(fdir, 1);
 	ContigSet &C = p->C;
 	std::vector<char> t((size_t)L + 1), en;
@@ -1152,7 +1157,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 	static const char RCT[256] = {0};
 	for (size_t c = 0; c < C.n(); ++c) {
 		const uint64_t *mm = C.mem.data() + C.moff[c];
-		if (order) {                                                           // a copy: the pipeline keeps the order of the default mode
+		if (sorted) {                                                          // a copy: the pipeline keeps the order of the default mode
 			omem.assign(mm, mm + C.msize(c));
 			std::stable_sort(omem.begin(), omem.end(), less_cluster3);           // :34
 			mm = omem.data();
@@ -1166,6 +1171,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 		for (uint64_t q = 0; q < C.msize(c); ++q) {
 			const uint64_t y = mm[q];
 			const uint32_t rid = (uint32_t)(y >> 32); const int pos = (int)((uint32_t)y >> 1), dir = (int)(y & 1);
+			if (pe) { fprintf(fids, "%d %u\n", rid < half ? 0 : 1, rid); pe_members.push_back(rid); }   // kthread_dump_pe.c:70-74
 			read_str(rid, t.data());
 			if (dir) {                                                         // reverse_complement, N stays N (preprocess.c:22-37)
 				for (int i = 0, j = L - 1; i < j; ++i, --j) std::swap(t[i], t[j]);
@@ -1200,7 +1206,8 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 	if (fids) fclose(fids);
 	FILE *finfo = open("info.txt", "w");
 	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
-	fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	if (pe) fprintf(finfo, "%d %d\n%u\n%zu %zu %zu\n", L, 1, half, p->allA.size(), p->allT.size(), p->allN.size());   // kthread_dump_pe.c:222-234
+	else fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
 	if (order) fprintf(finfo, "%u\n", (unsigned)p->n);                                               // :377-379
 	fclose(finfo);
 	// singletons: those with N join the N file, the others are packed 4 per byte (:390-417, :545-548)
@@ -1213,16 +1220,34 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 		if (p->sg_flag[i]) continue;
 		const uint32_t rid = p->sg[i];
 		if (has_n(rid)) nfile.push_back(rid);
-		else if (order) single_ids.push_back(rid);                                // :409-411
+		else if (sorted) single_ids.push_back(rid);                               // :409-411
 		else push_single(rid);
 	}
 	std::vector<uint32_t> fpA = p->fpA, fpT = p->fpT, fpN = p->fpN;
-	if (order) {
-		// every list sorted by read id, its ids delta coded beside it (:420-543); the singles follow their sorted ids
+	if (sorted) {
+		// every list sorted by read id (:420-427); the singles follow their sorted ids
 		std::vector<uint32_t> allA = p->allA, allT = p->allT, allN = p->allN;
 		for (std::vector<uint32_t> *v : {&fpA, &fpT, &fpN, &nfile, &single_ids, &allA, &allT, &allN}) std::sort(v->begin(), v->end());
 		const std::string d(folder);
-		if (!write_ids(d + "/allA.ids.bin", allA) || !write_ids(d + "/allT.ids.bin", allT) || !write_ids(d + "/allN.ids.bin", allN) ||
+		if (pe) {
+			// Pairing (kthread_dump_pe.c:270-470, :583-612): reads of the first file are numbered in the order the decoder
+			// will write them (the eight lists, then the contig members); a read of the second file carries the number of
+			// its mate, a file bit per read says which kind it is.
+			std::vector<uint32_t> mpv(half, 0); uint32_t mpvid = 0;
+			const std::vector<uint32_t> *lists[8] = {&allA, &allT, &allN, &fpA, &fpT, &fpN, &nfile, &single_ids};
+			for (const std::vector<uint32_t> *v : lists) for (uint32_t rid : *v) if (rid < half) mpv[rid] = mpvid++;
+			for (uint32_t rid : pe_members) if (rid < half) mpv[rid] = mpvid++;
+			auto write_pairing = [&](const char *ids_name, const char *file_name, auto &&each) -> bool {
+				FILE *fi = open(ids_name, "wb"), *ff = open(file_name, "wb");
+				if (!fi || !ff) return false;
+				BitWriter fb(ff, 1);
+				each([&](uint32_t rid) { if (rid < half) fb.push(0); else { fb.push(1); const uint32_t v = mpv[rid - half]; fwrite(&v, 4, 1, fi); } });
+				fb.flush(); fclose(fi); fclose(ff);
+				return true;
+			};
+			if (!write_pairing("peids.bin.sp", "file.bin.sp", [&](auto &&f) { for (const std::vector<uint32_t> *v : lists) for (uint32_t rid : *v) f(rid); }) ||
+			    !write_pairing("peids.bin.0", "file.bin.0", [&](auto &&f) { for (uint32_t rid : pe_members) f(rid); })) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+		} else if (!write_ids(d + "/allA.ids.bin", allA) || !write_ids(d + "/allT.ids.bin", allT) || !write_ids(d + "/allN.ids.bin", allN) ||
 		    !write_ids(d + "/AA.ids.bin", fpA) || !write_ids(d + "/TT.ids.bin", fpT) || !write_ids(d + "/NN.ids.bin", fpN) ||
 		    !write_ids(d + "/Nfile.ids.bin", nfile) || !write_ids(d + "/singleFile.ids.bin", single_ids)) return p->fail(MCOM_E_ARG, "cannot write id streams");
 		for (uint32_t rid : single_ids) push_single(rid);
@@ -1238,6 +1263,8 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, bool order)
 	return MCOM_OK;
 }
 
-extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, false); }
+extern "C" int mcomh_cluster_dump(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, 0); }
 // the order-preserving mode (minicom -p = the reference compiled with ORDER): id streams beside every stream
-extern "C" int mcomh_cluster_dump_order(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, true); }
+extern "C" int mcomh_cluster_dump_order(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, 1); }
+// paired end (minicompe = the reference compiled with _PE): reads [0, n/2) come from the first file, read n/2 + i is the mate of read i
+extern "C" int mcomh_cluster_dump_pe(mcomh_pipeline *p, const char *folder) { return cluster_dump_impl(p, folder, 2); }

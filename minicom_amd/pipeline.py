@@ -46,6 +46,10 @@ def load_host_library():
     L.mcomh_decompress.restype = i32; L.mcomh_decompress.argtypes = [cp, cp, C.POINTER(C.c_uint64)]
     L.mcomh_cluster_dump_order.restype = i32; L.mcomh_cluster_dump_order.argtypes = [vp, cp]
     L.mcomh_decompress_order.restype = i32; L.mcomh_decompress_order.argtypes = [cp, cp, C.POINTER(C.c_uint64)]
+    L.mcomh_cluster_dump_pe.restype = i32; L.mcomh_cluster_dump_pe.argtypes = [vp, cp]
+    L.mcomh_decompress_pe.restype = i32; L.mcomh_decompress_pe.argtypes = [cp, cp, cp, C.POINTER(C.c_uint64)]
+    L.mcomh_fastq_pair_to_device.restype = i32
+    L.mcomh_fastq_pair_to_device.argtypes = [cp, cp, i32, C.POINTER(i32), sz, C.POINTER(vp), C.POINTER(sz), C.c_char_p, sz]
     L.mcomh_n_contigs.restype = sz; L.mcomh_n_contigs.argtypes = [vp]
     L.mcomh_contig_ref.restype = vp; L.mcomh_contig_ref.argtypes = [vp, sz, C.POINTER(sz)]
     L.mcomh_contig_n.restype = sz; L.mcomh_contig_n.argtypes = [vp, sz]
@@ -66,7 +70,8 @@ HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_destroy", "mco
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
-                    "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order"]
+                    "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order",
+                    "mcomh_cluster_dump_pe", "mcomh_decompress_pe", "mcomh_fastq_pair_to_device"]
 
 
 def decompress(folder: str, out_path: str, order: bool = False) -> int:
@@ -77,6 +82,15 @@ def decompress(folder: str, out_path: str, order: bool = False) -> int:
     rc = (lib.mcomh_decompress_order if order else lib.mcomh_decompress)(folder.encode(), out_path.encode(), C.byref(n))
     if rc:
         raise McomError(f"cannot decode the stream files in {folder}")
+    return int(n.value)
+
+
+def decompress_pe(folder: str, out_path1: str, out_path2: str) -> int:
+    """mcomh_decompress_pe: the paired-end file set -> two files, line i of both is a pair.  Returns the number of pairs."""
+    n = C.c_uint64()
+    rc = load_host_library().mcomh_decompress_pe(folder.encode(), out_path1.encode(), out_path2.encode(), C.byref(n))
+    if rc:
+        raise McomError(f"cannot decode the paired-end stream files in {folder}")
     return int(n.value)
 
 
@@ -124,12 +138,16 @@ class Pipeline:
         self.n, self.L = n, L
 
     @classmethod
-    def from_fastq(cls, path: str, L: int = 0, device: int = 0, chunk_reads: int = 0, **params):
-        """FASTQ/FASTA (plain or .gz) -> HBM through two pinned chunks (mcomh_fastq_to_device) -> pipeline."""
+    def from_fastq(cls, path: str, L: int = 0, device: int = 0, chunk_reads: int = 0, path2: str | None = None, **params):
+        """FASTQ/FASTA (plain or .gz) -> HBM through two pinned chunks (mcomh_fastq_to_device) -> pipeline.
+        path2: the mates' file (paired end): its reads follow those of the first file."""
         lib = load_host_library()
         Lc, n, d = C.c_int(L), C.c_size_t(), C.c_void_p()
         err = C.create_string_buffer(256)
-        rc = lib.mcomh_fastq_to_device(path.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
+        if path2 is None:
+            rc = lib.mcomh_fastq_to_device(path.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
+        else:
+            rc = lib.mcomh_fastq_pair_to_device(path.encode(), path2.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
         if rc:
             raise McomError(f"{path}: {err.value.decode() or rc}")
         self = cls.__new__(cls)
@@ -175,10 +193,12 @@ class Pipeline:
 
     def dump_stages(self, path: str): self._check(self.lib.mcomh_dump_stages(self._h, path.encode()))
 
-    def cluster_dump(self, folder: str, order: bool = False):
+    def cluster_dump(self, folder: str, order: bool = False, paired: bool = False):
         """Writes the reference's pre-bsc stream files (cluster_dump at one thread) into an existing directory;
-        order=True: the order-preserving file set of minicom -p."""
-        self._check((self.lib.mcomh_cluster_dump_order if order else self.lib.mcomh_cluster_dump)(self._h, folder.encode()))
+        order=True: the order-preserving file set of minicom -p; paired=True: the paired-end file set (rows [0, n/2) are
+        the first file, rows [n/2, n) their mates)."""
+        fn = self.lib.mcomh_cluster_dump_pe if paired else self.lib.mcomh_cluster_dump_order if order else self.lib.mcomh_cluster_dump
+        self._check(fn(self._h, folder.encode()))
 
     def prof_enable(self, on: bool = True): self._check(self.lib.mcomh_prof_enable(self._h, 1 if on else 0))
 

@@ -22,16 +22,22 @@ from minicom_amd import synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def make(tag, variant, prefix="streams_"):
+def make(tag, variant, prefix="streams_", paired=False):
     with gzip.open(os.path.join(HERE, tag + ".reads.gz"), "rb") as f:
         rows = f.read().split(b"\n")[:-1]
     reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0]))
     with tempfile.TemporaryDirectory() as td:
         fq = os.path.join(td, "in.fastq")
-        synth.write_fastq(fq, reads)
         out = os.path.join(td, "out"); os.makedirs(out)
         cwd = os.path.join(td, "cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
-        subprocess.run([os.path.join(REF, variant, "minicom_bin"), fq, out], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+        if paired:                                  # the first half of the fixture reads as file 1, the second half as their mates
+            half = reads.shape[0] // 2
+            fq2 = os.path.join(td, "in2.fastq")
+            synth.write_fastq(fq, reads[:half]); synth.write_fastq(fq2, reads[half:2 * half])
+            subprocess.run([os.path.join(REF, variant, "minicom_bin"), fq, fq2, out], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+        else:
+            synth.write_fastq(fq, reads)
+            subprocess.run([os.path.join(REF, variant, "minicom_bin"), fq, out], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
         buf = io.BytesIO()
         with tarfile.open(fileobj=buf, mode="w") as tf:
             for name in sorted(os.listdir(out)):
@@ -47,3 +53,4 @@ if __name__ == "__main__":
     make("stages_L100", "L100")
     make("stages_L150", "L150")
     make("stages_L100", "L100_order", prefix="streams_order_")       # -p: the order-preserving file set (ids streams)
+    make("stages_L100", "L100_pe", prefix="streams_pe_", paired=True)  # paired end: pairing streams

@@ -136,3 +136,73 @@ def test_order_round_trip_at_a_size_no_fixture_covers(tmp_path):
     assert decompress(str(d), str(out), order=True) == reads.shape[0]
     got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(reads.shape[0], 151)[:, :150]
     assert np.array_equal(got, reads)
+
+
+# ---- paired end (minicompe, the reference compiled with _PE): SURVEY section 8f rank 4, second part --------------------
+def _golden_pe_streams(golden_dir, tag):
+    with gzip.open(os.path.join(golden_dir, "streams_pe_" + tag + ".tar.gz"), "rb") as g:
+        tf = tarfile.open(fileobj=io.BytesIO(g.read()))
+        return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
+
+
+def test_our_decoder_pairs_the_mates_from_the_reference_pe_streams(golden_dir, tmp_path):
+    """CPU: mcomh_decompress_pe applied to the paired-end file set written by the reference itself (file 1 = the first half
+    of the fixture reads, file 2 = the second half)."""
+    from minicom_amd.pipeline import decompress_pe
+    tag = "stages_L100"
+    d = tmp_path / "streams"; d.mkdir()
+    for name, data in _golden_pe_streams(golden_dir, tag).items():
+        (d / name).write_bytes(data)
+    o1, o2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    rows = _golden_reads(golden_dir, tag)
+    half = len(rows) // 2
+    assert decompress_pe(str(d), str(o1), str(o2)) == half
+    a, b = o1.read_bytes().split(b"\n")[:-1], o2.read_bytes().split(b"\n")[:-1]
+    assert sorted(zip(a, b)) == sorted(zip(rows[:half], rows[half:2 * half]))      # every pair, still paired
+
+
+@pytest.mark.gpu
+def test_pe_stream_files_byte_identical_to_reference_and_pairs_kept(golden_dir, tmp_path):
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress_pe
+    tag = "stages_L100"
+    rows = _golden_reads(golden_dir, tag)
+    half = len(rows) // 2
+    reads = np.frombuffer(b"".join(rows[:2 * half]), dtype=np.uint8).reshape(2 * half, len(rows[0])).copy()
+    f1, f2 = str(tmp_path / "a_1.fastq"), str(tmp_path / "a_2.fastq")
+    synth.write_fastq(f1, reads[:half]); synth.write_fastq(f2, reads[half:])
+    p = Pipeline.from_fastq(f1, path2=f2, host_threads=4)
+    assert p.n == 2 * half
+    p.pre_process()
+    d = tmp_path / "pe"; d.mkdir()
+    p.cluster_dump(str(d), paired=True)
+    p.close()
+    want = _golden_pe_streams(golden_dir, tag)
+    assert sorted(os.listdir(d)) == sorted(want)
+    for name, data in want.items():
+        assert (d / name).read_bytes() == data, name                       # P1, paired end
+    o1, o2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    assert decompress_pe(str(d), str(o1), str(o2)) == half
+    a, b = o1.read_bytes().split(b"\n")[:-1], o2.read_bytes().split(b"\n")[:-1]
+    assert sorted(zip(a, b)) == sorted(zip(rows[:half], rows[half:2 * half]))   # P2: mate pairs
+
+
+@pytest.mark.gpu
+def test_pe_round_trip_at_a_size_no_fixture_covers(tmp_path):
+    """Mates = the two ends of fragments: the second half of a synthetic set stands in for them."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress_pe
+    reads = np.concatenate([synth.synth_reads(41, 120000, 150), synth.synth_reads(42, 8000, 150, plumbing=True)])
+    half = reads.shape[0] // 2
+    p = Pipeline(reads, host_threads=16)
+    p.pre_process()
+    d = tmp_path / "s"; d.mkdir()
+    p.cluster_dump(str(d), paired=True)
+    p.close()
+    o1, o2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    assert decompress_pe(str(d), str(o1), str(o2)) == half
+    a = np.frombuffer(o1.read_bytes(), dtype=np.uint8).reshape(half, 151)[:, :150]
+    b = np.frombuffer(o2.read_bytes(), dtype=np.uint8).reshape(half, 151)[:, :150]
+    got = np.sort(np.concatenate([a, b], axis=1).view("S300").ravel())
+    want = np.sort(np.ascontiguousarray(np.concatenate([reads[:half], reads[half:]], axis=1)).view("S300").ravel())
+    assert np.array_equal(got, want)
