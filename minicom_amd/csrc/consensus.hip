@@ -35,22 +35,30 @@ __device__ __forceinline__ uint32_t obase_w(uint64_t roww, int L, uint32_t dir, 
 // ------------------------------------------------------------------------------------------------
 #define GC_MAXCOL 512
 
+// PK = true: two 16-bit counters per LDS word -- half the LDS, twice the groups in flight for a kernel that lives on
+// hiding the latency of its dependent loads; groups of 65535 members or more are left to the PK = false launch.
+#define GC_BIG 65535u
+template <bool PK>
 __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restrict__ packed, int W, uint64_t *__restrict__ members,
                                                         const uint32_t *__restrict__ goff, uint32_t ng, int L, int k_orig, int e,
                                                         uint8_t *__restrict__ keep, uint32_t *__restrict__ nkept,
                                                         uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
-                                                        uint8_t *__restrict__ refs, int ref_stride)
+                                                        uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen)
 {
 	extern __shared__ uint32_t gc_lds[];
 	const int TL = 2 * L;
+	const int TW = PK ? 2 * TL : 4 * TL;        // words of one table
 	uint32_t *c1 = gc_lds;                      // counts of all members            [4][TL]
-	uint32_t *c2 = gc_lds + 4 * TL;             // counts of the kept members       [4][TL]
-	uint8_t *rc = (uint8_t*)(gc_lds + 8 * TL);  // first consensus, 0xFF beyond its end
+	uint32_t *c2 = gc_lds + TW;                 // counts of the kept members       [4][TL]
+	uint8_t *rc = (uint8_t*)(gc_lds + 2 * TW);  // first consensus, 0xFF beyond its end
 	const uint32_t g = blockIdx.x;
 	if (g >= ng) return;
 	const int lane = threadIdx.x;
 	const uint32_t m0 = goff[g], m1 = goff[g + 1];
-	for (int c = lane; c < 4 * TL; c += 64) { c1[c] = 0; c2[c] = 0; }
+	if (PK ? (m1 - m0 >= GC_BIG) : (m1 - m0 < GC_BIG)) { if (PK && lane == 0) *big_seen = 1; return; }
+	auto cadd = [&](uint32_t *t, int idx) { if (PK) atomicAdd(&t[idx >> 1], 1u << (16 * (idx & 1))); else atomicAdd(&t[idx], 1u); };
+	auto cget = [&](const uint32_t *t, int idx) -> uint32_t { return PK ? (t[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu : t[idx]; };
+	for (int c = lane; c < TW; c += 64) { c1[c] = 0; c2[c] = 0; }
 	__syncthreads();
 	// pass 1: offsets, first counts
 	// Members are taken eight at a time: lane 8i+w loads word w of member i's packed row, so the two dependent global
@@ -72,15 +80,15 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 			for (int s0 = 0; s0 < L; s0 += 64) {                            // whole wave in the shuffle, also past the read's end
 				const int s = s0 + lane;
 				const uint32_t b = obase_w(rowl, L, dir, s < L ? s : 0, 8 * i);
-				if (s < L) atomicAdd(&c1[b * TL + off + s], 1u);
+				if (s < L) cadd(c1, b * TL + off + s);
 			}
 		}
 	}
 	__syncthreads();
 	// first consensus: majority base per column, ties to the smaller code (strict '>'), ends at the first empty column
 	for (int c = lane; c < TL; c += 64) {
-		uint32_t mx = c1[c]; uint8_t b = 0;
-		for (int q = 1; q < 4; ++q) { const uint32_t v = c1[q * TL + c]; if (v > mx) { mx = v; b = (uint8_t)q; } }
+		uint32_t mx = cget(c1, c); uint8_t b = 0;
+		for (int q = 1; q < 4; ++q) { const uint32_t v = cget(c1, q * TL + c); if (v > mx) { mx = v; b = (uint8_t)q; } }
 		rc[c] = mx ? b : (uint8_t)0xFF;
 	}
 	__syncthreads();
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		const bool kp = dif <= e;                                          // kthread_bucket.c:189
 		if (kp) {
 #pragma unroll
-			for (int u = 0; u < 4; ++u) { const int s = u * 64 + lane; if (s < L) atomicAdd(&c2[bs[u] * TL + off + s], 1u); }
+			for (int u = 0; u < 4; ++u) { const int s = u * 64 + lane; if (s < L) cadd(c2, bs[u] * TL + off + s); }
 			++nk;
 			if (off + L > rend) rend = off + L;
 		}
@@ -133,14 +141,14 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		sv = ref_len;
 		for (int c0 = 0; c0 < ref_len; c0 += 64) {
 			const int c = c0 + lane;
-			const bool any = c < ref_len && (c2[c] | c2[TL + c] | c2[2 * TL + c] | c2[3 * TL + c]) != 0;
+			const bool any = c < ref_len && (cget(c2, c) | cget(c2, TL + c) | cget(c2, 2 * TL + c) | cget(c2, 3 * TL + c)) != 0;
 			const uint64_t z = __ballot(any);
 			if (z) { sv = c0 + __ffsll((unsigned long long)z) - 1; break; }
 		}
 		uint8_t *out = refs + (size_t)g * ref_stride;
 		for (int c = sv + lane; c < rend; c += 64) {
-			uint32_t mx = c2[c]; int b = 0;
-			for (int q = 1; q < 4; ++q) { const uint32_t v = c2[q * TL + c]; if (v > mx) { mx = v; b = q; } }
+			uint32_t mx = cget(c2, c); int b = 0;
+			for (int q = 1; q < 4; ++q) { const uint32_t v = cget(c2, q * TL + c); if (v > mx) { mx = v; b = q; } }
 			out[c - sv] = (uint8_t)"ACGT"[b];
 		}
 	}
@@ -155,10 +163,23 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	if (n_groups == 0) return MCOM_OK;
 	if (L < 1 || L > 256 || k_orig < 1 || k_orig > 31 || ref_stride < 2 * L) return mcom_fail(ctx, MCOM_E_ARG, "bad consensus arguments");
 	if (!d_packed || !d_members || !d_group_off || !d_keep || !d_nkept || !d_sv || !d_reflen || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL(k_group_consensus, dim3(n_groups), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off,
-	                   n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride);
+	int rc = mcom_ws_reserve(ctx, 256);
+	if (rc) return rc;
+	unsigned int *big = (unsigned int*)ctx->ws;
+	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
+	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
+	hipLaunchKernelGGL((k_group_consensus<true>), dim3(n_groups), dim3(64), (size_t)(4 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
+	                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big); }
 	MCOM_LAUNCH_CHECK(ctx);
+	unsigned int hb = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (hb) {                                                                // groups of 65535 members or more: 32-bit counters
+		McomProfScope ps_(ctx, PROF_CONSENSUS);
+		hipLaunchKernelGGL((k_group_consensus<false>), dim3(n_groups), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
+		                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
 	return MCOM_OK;
 }
 
@@ -168,22 +189,27 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 // ------------------------------------------------------------------------------------------------
 #define MC_TILE 512
 
+template <bool PK>
 __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restrict__ packed, int W, const uint64_t *__restrict__ members,
                                                         const uint64_t *__restrict__ joff, const uint64_t *__restrict__ roff,
                                                         const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
                                                         uint32_t n_tiles, int L, uint8_t *__restrict__ refs,
-                                                        const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi)
+                                                        const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi,
+                                                        unsigned int *__restrict__ big_seen)
 {
-	__shared__ uint32_t cc[4 * MC_TILE];
+	__shared__ uint32_t cc[PK ? 2 * MC_TILE : 4 * MC_TILE];                  // PK: two 16-bit counters per word (see k_group_consensus)
 	const uint32_t t = blockIdx.x;
 	if (t >= n_tiles) return;
 	const int lane = threadIdx.x;
 	const uint32_t j = tile_job[t];
 	const uint64_t m0 = joff[j], m1 = joff[j + 1];
+	if (PK ? (m1 - m0 >= GC_BIG) : (m1 - m0 < GC_BIG)) { if (PK && lane == 0) *big_seen = 1; return; }
+	auto cadd = [&](int idx) { if (PK) atomicAdd(&cc[idx >> 1], 1u << (16 * (idx & 1))); else atomicAdd(&cc[idx], 1u); };
+	auto cget = [&](int idx) -> uint32_t { return PK ? (cc[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu : cc[idx]; };
 	// the columns to count: the whole contig, or only the region given for the job (the overlap of the two parents)
 	const long len = reg_hi ? (long)reg_hi[j] : (long)(roff[j + 1] - roff[j]);
 	const long lo = (reg_lo ? (long)reg_lo[j] : 0) + (long)tile_idx[t] * MC_TILE, hi = lo + MC_TILE < len ? lo + MC_TILE : len;
-	for (int c = lane; c < 4 * MC_TILE; c += 64) cc[c] = 0;
+	for (int c = lane; c < (PK ? 2 : 4) * MC_TILE; c += 64) cc[c] = 0;
 	__syncthreads();
 	// first member whose read can reach column lo: offset > lo - L (members are sorted by offset)
 	uint64_t a = m0, b = m1;
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 				const int s = s0 + lane;
 				const long c = off + s;
 				const uint32_t b = obase_w(rowl, L, dir, s < L ? s : 0, 8 * i);
-				if (s < L && c >= lo && c < hi) atomicAdd(&cc[b * MC_TILE + (int)(c - lo)], 1u);
+				if (s < L && c >= lo && c < hi) cadd((int)b * MC_TILE + (int)(c - lo));
 			}
 		}
 	}
@@ -213,8 +239,8 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 	uint8_t *out = refs + roff[j];
 	for (long c = lo + lane; c < hi; c += 64) {
 		const int i = (int)(c - lo);
-		uint32_t mx = cc[i]; int bb = 0;
-		for (int q = 1; q < 4; ++q) { const uint32_t v = cc[q * MC_TILE + i]; if (v > mx) { mx = v; bb = q; } }
+		uint32_t mx = cget(i); int bb = 0;
+		for (int q = 1; q < 4; ++q) { const uint32_t v = cget(q * MC_TILE + i); if (v > mx) { mx = v; bb = q; } }
 		out[c] = (uint8_t)"ACGT"[bb];
 	}
 }
@@ -227,11 +253,7 @@ extern "C" int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, con
 	if (n_tiles == 0) return MCOM_OK;
 	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad read length");
 	if (!d_packed || !d_members || !d_job_off || !d_ref_off || !d_tile_job || !d_tile_idx || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL(k_merge_consensus, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
-	MCOM_LAUNCH_CHECK(ctx);
-	return MCOM_OK;
+	return mcom_merge_consensus_regions(ctx, d_packed, d_members, d_job_off, d_ref_off, d_tile_job, d_tile_idx, n_tiles, L, d_refs, nullptr, nullptr);
 }
 
 // the same over one column range per job (merge.hip: only the overlap of the two parents is counted again)
@@ -240,9 +262,24 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
                                  const uint32_t *d_reg_lo, const uint32_t *d_reg_hi)
 {
 	if (n_tiles == 0) return MCOM_OK;
-	McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL(k_merge_consensus, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi);
+	// the flag lives behind everything the callers keep in the workspace (they reserve their own part first)
+	unsigned int *big = nullptr;
+	MCOM_HIP(ctx, mcom_dmalloc((void**)&big, 256));
+	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
+	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
+	hipLaunchKernelGGL((k_merge_consensus<true>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big); }
+	unsigned int hb = 0;
+	hipError_t e1 = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	if (e1 == hipSuccess && hb) {                                            // a job of 65535 members or more: 32-bit counters
+		McomProfScope ps_(ctx, PROF_CONSENSUS);
+		hipLaunchKernelGGL((k_merge_consensus<false>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big);
+		e1 = hipStreamSynchronize(ctx->stream);
+	}
+	mcom_dfree(big);
+	if (e1 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "merge consensus: %s", hipGetErrorString(e1));
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
