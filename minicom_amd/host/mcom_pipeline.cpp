@@ -726,11 +726,13 @@ static int ensure_host_contigs(P *p, bool wait_data)
 // (a stable sort of [sorted part + tail] = stable sort of the tail merged behind equal elements).
 static int materialize(P *p)
 {
+	const double tj = now_ms();
 	join_presort(p);
 	{ const int rch = ensure_host_contigs(p); if (rch) return rch; }
 	const size_t m = p->pend.size();
 	if (!m) return MCOM_OK;
 	const double t0 = now_ms();
+	p->stat["t_mat_join"] += t0 - tj;
 	ContigSet &C = p->C;
 	const size_t nc = C.n();
 	const int nt = p->host_threads;
@@ -747,6 +749,7 @@ static int materialize(P *p)
 			});
 		for (std::thread &t : th) t.join();
 	}
+	p->stat["t_mat_count"] += now_ms() - t0;
 	PinVec<uint64_t> &nmem = p->Cnext.mem; std::vector<uint64_t> &nmoff = p->Cnext.moff;       // spare buffers of the merge stage
 	if (!nmem.resize(C.mem.size() + p->n_pending)) return p->fail(MCOM_E_NOMEM, "member lists");
 	nmoff.resize(nc + 1);
@@ -891,11 +894,15 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		p->stat["t_gpu"] += now_ms() - tg;
 		p->stat["t_ra_gpu"] += now_ms() - tg;
 		const double tw0 = now_ms();
-		for (size_t i = 0; i < n_sg; ++i) {                                                  // bbhashdict.c:177-216, singleton order
-			const uint8_t f = pf[i];
-			if (!f) continue;
-			p->sg_flag[i] = 1;
-			if (f == 1) p->fpA.push_back(p->sg[i]); else if (f == 2) p->fpT.push_back(p->sg[i]);
+		{                                                                                    // bbhashdict.c:177-216, singleton order
+			uint8_t *sf = p->sg_flag.data(); const uint8_t *f = pf.data();
+			for (size_t i = 0; i < n_sg; ++i) sf[i] = f[i] ? 1 : 0;                           // flagged or claimed (vectorises)
+			// the near-poly-A / -T reads (flag 1 / 2) are rare: eight flags per test, a byte is 1 or 2 iff its two low bits differ
+			for (size_t i = 0; i < n_sg; i += 8) {
+				uint64_t w8 = 0; memcpy(&w8, f + i, n_sg - i < 8 ? n_sg - i : 8);
+				if (!(((w8) ^ (w8 >> 1)) & 0x0101010101010101ull)) continue;
+				for (size_t q = i; q < i + 8 && q < n_sg; ++q) { if (f[q] == 1) p->fpA.push_back(p->sg[q]); else if (f[q] == 2) p->fpT.push_back(p->sg[q]); }
+			}
 		}
 		if (nwon) { p->n_pending += nwon; p->pend.push_back(std::move(app)); }
 		p->stat["t_ra_append"] += now_ms() - tw0;
