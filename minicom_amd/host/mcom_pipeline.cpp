@@ -758,15 +758,27 @@ static int materialize(P *p)
 	});
 	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
 	parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
+		std::vector<uint64_t> tail;                                          // per thread: no allocation per contig
 		for (size_t c = cb; c < ce; ++c) {
 			uint64_t *dst = nmem.data() + nmoff[c];
 			const size_t n0 = C.msize(c);
-			memcpy(dst, C.mem.data() + C.moff[c], n0 * 8);
-			if (nmoff[c + 1] - nmoff[c] == n0) continue;
-			size_t n1 = n0;
-			for (size_t i = 0; i + 1 < m; ++i) { const size_t k = off[i][c + 1] - off[i][c]; if (k) { memcpy(dst + n1, p->pend[i].member.data() + off[i][c], k * 8); n1 += k; } }
-			if (p->unsorted[c]) std::stable_sort(dst, dst + n1, less_cluster2);            // only when no pass sorted it yet
-			else if (n1 > n0) { std::stable_sort(dst + n0, dst + n1, less_cluster2); std::inplace_merge(dst, dst + n0, dst + n1, less_cluster2); }
+			const uint64_t *old = C.mem.data() + C.moff[c];
+			if (nmoff[c + 1] - nmoff[c] == n0) { memcpy(dst, old, n0 * 8); continue; }
+			tail.clear();
+			for (size_t i = 0; i + 1 < m; ++i) { const uint64_t *a = p->pend[i].member.data() + off[i][c]; tail.insert(tail.end(), a, a + (off[i][c + 1] - off[i][c])); }
+			size_t n1 = n0 + tail.size();
+			if (p->unsorted[c]) {                                             // only when no pass sorted it yet
+				memcpy(dst, old, n0 * 8); memcpy(dst + n0, tail.data(), tail.size() * 8);
+				std::stable_sort(dst, dst + n1, less_cluster2);
+			} else if (tail.empty()) memcpy(dst, old, n0 * 8);
+			else {
+				// stable sort of [sorted list + tail] = the tail, sorted stably, merged in behind equal elements
+				for (size_t i = 1; i < tail.size(); ++i) { const uint64_t v = tail[i]; size_t j = i; while (j > 0 && less_cluster2(v, tail[j - 1])) { tail[j] = tail[j - 1]; --j; } tail[j] = v; }
+				size_t i = 0, j = 0, o = 0;
+				while (i < n0 && j < tail.size()) dst[o++] = less_cluster2(tail[j], old[i]) ? tail[j++] : old[i++];
+				if (i < n0) memcpy(dst + o, old + i, (n0 - i) * 8);
+				else if (j < tail.size()) memcpy(dst + o, tail.data() + j, (tail.size() - j) * 8);
+			}
 			const size_t k = off[m - 1][c + 1] - off[m - 1][c];
 			if (k) memcpy(dst + n1, p->pend[m - 1].member.data() + off[m - 1][c], k * 8);
 			p->unsorted[c] = k ? 1 : 0;
