@@ -511,6 +511,7 @@ static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, s
 		if (!S.rec.reserve(cap + room)) return p->fail(MCOM_E_NOMEM, "minimizer records");
 		int rc = mcom_sketch_contigs(p->ctx, S.seq.p, S.soff.p, nullptr, n_first, p->rw, p->k, 0, S.roff.p, S.rec.p, cap, &total);
 		if (rc == MCOM_E_OVERFLOW) { cap = total; continue; }
+		if (!rc) p->stat["sketch_records"] += (double)total;
 		return p->gpu(rc);
 	}
 	return p->fail(MCOM_E_OVERFLOW, "minimizer buffer");
@@ -690,8 +691,15 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 extern "C" int mcomh_update_single(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
-	size_t nn = 0;
-	for (size_t i = 0; i < p->sg.size(); ++i) if (!p->sg_flag[i]) p->sg[nn++] = p->sg[i];
+	const size_t n = p->sg.size();
+	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); return MCOM_OK; }
+	// nothing flagged (the state after combine_cluster): nothing to compact; eight flags per test
+	const uint8_t *f = p->sg_flag.data();
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t w8; memcpy(&w8, f + i, 8); if (w8) break; }
+	if (i + 8 > n) { while (i < n && !f[i]) ++i; if (i == n) return MCOM_OK; }
+	size_t nn = i;                                                       // the first flagged entry is at or behind i
+	for (; i < n; ++i) if (!f[i]) p->sg[nn++] = p->sg[i];
 	p->sg.resize(nn);
 	p->sg_flag.assign(nn, 0);
 	return MCOM_OK;
