@@ -97,6 +97,15 @@ def load_library():
     L.mcom_dicts_screen.argtypes = [vp, vp, sz, i32, i32, i32, C.POINTER(i32)]
     L.mcom_claims_resolve.restype = i32
     L.mcom_claims_resolve.argtypes = [vp, vp, vp, sz, u32, vp, vp, vp, C.POINTER(u64)]
+    L.mcom_scan_u64.restype = i32; L.mcom_scan_u64.argtypes = [vp, vp, vp, sz]
+    L.mcom_contig_layout.restype = i32; L.mcom_contig_layout.argtypes = [vp, vp, sz, vp, vp, C.POINTER(u64)]
+    L.mcom_group_consensus.restype = i32; L.mcom_group_consensus.argtypes = [vp, vp, vp, vp, u32, i32, i32, i32, vp, vp, vp, vp, vp, i32]
+    L.mcom_groups_to_contigs.restype = i32
+    L.mcom_groups_to_contigs.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, i32, u64, u64, u64, vp, u64, vp, vp, u64, vp, u64, vp, vp, u64, C.POINTER(u64)]
+    L.mcom_merge_members.restype = i32; L.mcom_merge_members.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp, vp, C.POINTER(u64)]
+    L.mcom_merge_consensus_jobs.restype = i32; L.mcom_merge_consensus_jobs.argtypes = [vp, vp, vp, vp, vp, sz, u64, i32, vp, vp, vp, vp]
+    L.mcom_contigs_carry.restype = i32; L.mcom_contigs_carry.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    L.mcom_records_carry.restype = i32; L.mcom_records_carry.argtypes = [vp, vp, vp, vp, sz, u32, u32, vp, sz, vp, C.POINTER(u64)]
     L.mcom_claim_pairs.restype = i32
     L.mcom_claim_pairs.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(u64), C.POINTER(i32)]
     L.mcom_synth_reads.restype = i32
@@ -340,6 +349,93 @@ class Context:
                                                      self._p(coff, torch.int64), self._p(woff, torch.int64), int(coff.shape[0]), L,
                                                      ininumdict, thr, self._p(claim), self._p(st)))
         return claim[:n_sg], st
+
+    # -- the device-resident contig set (include/mcom.h, "the contig set of combine_cluster")
+    def scan_u64(self, x):
+        torch = _torch()
+        out = torch.empty_like(x)
+        self._check(self.lib.mcom_scan_u64(self._h, self._p(x, torch.int64), self._p(out), int(x.shape[0])))
+        return out
+
+    def contig_layout(self, soff):
+        """mcom_contig_layout.  Returns (coff_words int64 [n+1], clen int32 [n], total_words)."""
+        torch = _torch()
+        n = int(soff.shape[0]) - 1
+        coff = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        clen = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        tw = C.c_uint64()
+        self._check(self.lib.mcom_contig_layout(self._h, self._p(soff, torch.int64), n, self._p(coff), self._p(clen), C.byref(tw)))
+        return coff, clen[:n], int(tw.value)
+
+    def group_consensus(self, packed, members, goff, L: int, k_orig: int, e: int):
+        """mcom_group_consensus.  members is rewritten in place.  Returns dict(keep, nkept, sv, reflen, refs, stride)."""
+        torch = _torch()
+        ng, nm = int(goff.shape[0]) - 1, int(members.shape[0])
+        stride = (2 * L + 15) & ~15
+        o = dict(keep=torch.empty(max(nm, 1), dtype=torch.uint8, device=self.device), nkept=torch.empty(max(ng, 1), dtype=torch.int32, device=self.device),
+                 sv=torch.empty(max(ng, 1), dtype=torch.int16, device=self.device), reflen=torch.empty(max(ng, 1), dtype=torch.int16, device=self.device),
+                 refs=torch.zeros(max(ng, 1) * stride + 16, dtype=torch.uint8, device=self.device), stride=stride)
+        self._check(self.lib.mcom_group_consensus(self._h, self._p(packed, torch.int64), self._p(members, torch.int64), self._p(goff, torch.int32), ng, L, k_orig, e,
+                                                  self._p(o["keep"]), self._p(o["nkept"]), self._p(o["sv"]), self._p(o["reflen"]), self._p(o["refs"]), stride))
+        return o
+
+    def groups_to_contigs(self, members, goff, gc, cap_chars: int, cap_members: int, cap_contigs: int):
+        """mcom_groups_to_contigs into a fresh set.  Returns dict(seq, soff, mem, moff, rej_rid, rej_group, counts)."""
+        torch = _torch()
+        ng = int(goff.shape[0]) - 1
+        seq = torch.zeros(cap_chars + 16, dtype=torch.uint8, device=self.device)
+        soff = torch.zeros(cap_contigs + 2, dtype=torch.int64, device=self.device)
+        mem = torch.zeros(cap_members + 1, dtype=torch.int64, device=self.device)
+        moff = torch.zeros(cap_contigs + 2, dtype=torch.int64, device=self.device)
+        rr = torch.zeros(int(members.shape[0]) + 1, dtype=torch.int32, device=self.device)
+        rg = torch.zeros(int(members.shape[0]) + 1, dtype=torch.int32, device=self.device)
+        cnt = (C.c_uint64 * 4)()
+        self._check(self.lib.mcom_groups_to_contigs(self._h, self._p(members, torch.int64), self._p(goff, torch.int32), ng, self._p(gc["keep"]), self._p(gc["nkept"]),
+                                                    self._p(gc["sv"]), self._p(gc["reflen"]), self._p(gc["refs"]), gc["stride"], 0, 0, 0, self._p(seq), cap_chars,
+                                                    self._p(soff), self._p(mem), cap_members, self._p(moff), cap_contigs + 1, self._p(rr), self._p(rg),
+                                                    int(members.shape[0]), cnt))
+        nc, nch, nmm, nrj = (int(v) for v in cnt)
+        return dict(seq=seq[:nch], soff=soff[:nc + 1], mem=mem[:nmm], moff=moff[:nc + 1], rej_rid=rr[:nrj], rej_group=rg[:nrj], counts=(nc, nch, nmm, nrj))
+
+    def merge_members(self, mem, moff, jobs, L: int, key_bits: int):
+        """mcom_merge_members.  jobs: int32 [nj, 4].  Returns (jm, jmoff, jroff, totals)."""
+        torch = _torch()
+        nj = int(jobs.shape[0])
+        jm = torch.empty(int(mem.shape[0]) + 1, dtype=torch.int64, device=self.device)
+        jmoff = torch.empty(nj + 1, dtype=torch.int64, device=self.device)
+        jroff = torch.empty(nj + 1, dtype=torch.int64, device=self.device)
+        tot = (C.c_uint64 * 3)()
+        self._check(self.lib.mcom_merge_members(self._h, self._p(mem, torch.int64), self._p(moff, torch.int64), self._p(jobs, torch.int32), nj, L, key_bits,
+                                                self._p(jm), self._p(jmoff), self._p(jroff), tot))
+        return jm[: int(tot[0])], jmoff, jroff, tuple(int(v) for v in tot)
+
+    def merge_consensus_jobs(self, packed, jm, jmoff, jroff, total_chars: int, L: int, jobs=None, seq=None, soff=None):
+        torch = _torch()
+        nj = int(jmoff.shape[0]) - 1
+        refs = torch.zeros(total_chars + 16, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mcom_merge_consensus_jobs(self._h, self._p(packed, torch.int64), self._p(jm, torch.int64), self._p(jmoff, torch.int64),
+                                                       self._p(jroff, torch.int64), nj, total_chars, L, self._p(refs), self._p(jobs), self._p(seq), self._p(soff)))
+        self.sync()
+        return refs[:total_chars]
+
+    def contigs_carry(self, seq, soff, mem, moff, flag, nj: int, seq2, soff2, mem2, moff2):
+        """mcom_contigs_carry: appends the unflagged contigs behind the nj merged ones already in the *2 arrays."""
+        torch = _torch()
+        n = int(soff.shape[0]) - 1
+        nkeep = int((flag == 0).sum())
+        keepidx = torch.empty(max(nkeep, 1), dtype=torch.int32, device=self.device)
+        tot = (C.c_uint64 * 2)()
+        self._check(self.lib.mcom_contigs_carry(self._h, self._p(seq), self._p(soff, torch.int64), self._p(mem, torch.int64), self._p(moff, torch.int64), n,
+                                                self._p(flag, torch.uint8), nj, nkeep, self._p(seq2), self._p(soff2, torch.int64), self._p(mem2, torch.int64),
+                                                self._p(moff2, torch.int64), self._p(keepidx), tot))
+        return keepidx[:nkeep], (int(tot[0]), int(tot[1]))
+
+    def records_carry(self, rec, roff, keepidx, first_id: int, base: int, rec2, roff2):
+        torch = _torch()
+        tot = C.c_uint64()
+        self._check(self.lib.mcom_records_carry(self._h, self._p(rec), self._p(roff, torch.int32), self._p(keepidx, torch.int32), int(keepidx.shape[0]), first_id, base,
+                                                self._p(rec2), int(rec2.shape[0]), self._p(roff2, torch.int32), C.byref(tot)))
+        return int(tot.value)
 
     def claim_pairs(self, pairs, n_contigs: int, max_rounds: int = 4096):
         """mcom_claim_pairs.  pairs: int64 [n, 2] records in visiting order.  Returns (jobs int32 [nj, 4], flag uint8 [n_contigs], rounds)."""

@@ -1,0 +1,256 @@
+"""GPU parity of the device-resident contig set (include/mcom.h: mcom_group_consensus, mcom_groups_to_contigs,
+mcom_merge_members, mcom_merge_consensus_jobs, mcom_contigs_carry, mcom_records_carry, mcom_scan_u64, mcom_contig_layout)
+against plain numpy restatements of the reference's statements (construct_ref kthread_bucket.c:69-377 and :446-505,
+find_next's member merge kthread_cb.c:297-325, construct_ref2 :105-218, cp_cluster :397-434)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, dtype=np.uint8); COMP[[65, 67, 71, 84]] = [84, 71, 67, 65]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import minicom_amd
+    c = minicom_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _oriented(read, d):
+    return COMP[read][::-1] if d else read
+
+
+def _majority(cols):
+    """counts [4][n] -> base per column, ties to the smaller code A < C < G < T (strict '>' scan, kthread_bucket.c:129-141)."""
+    best = np.zeros(cols.shape[1], dtype=np.int64); mx = cols[0].copy()
+    for q in (1, 2, 3):
+        m = cols[q] > mx
+        best[m] = q; mx[m] = cols[q][m]
+    return best, mx
+
+
+def test_scan_u64_and_contig_layout(ctx):
+    rng = np.random.default_rng(1)
+    for n in (1, 7, 1000, 300000):
+        x = rng.integers(0, 1 << 40, n, dtype=np.int64)
+        got = ctx.scan_u64(_dev(x)).cpu().numpy()
+        assert np.array_equal(got, np.concatenate([[0], np.cumsum(x)[:-1]]))
+    lens = rng.integers(0, 5000, 4000)
+    soff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    coff, clen, tw = ctx.contig_layout(_dev(soff))
+    words = (2 * lens + 63) // 64 + 1
+    assert np.array_equal(coff.cpu().numpy(), np.concatenate([[0], np.cumsum(words)])) and tw == int(words.sum())
+    assert np.array_equal(clen.cpu().numpy(), lens)
+
+
+def _make_groups(rng, n_groups, L, k, e):
+    """Minimizer groups as mcom_sort_group hands them over: members share a k-mer; records carry rid<<32 | pos<<1 | strand."""
+    from minicom_amd.hip import pack_nt4
+    reads, members, goff = [], [], [0]
+    for g in range(n_groups):
+        size = int(rng.choice([2, 2, 3, 5, 9, 30, 70]))
+        src = ACGT[rng.integers(0, 4, 3 * L)]
+        anchor = L + int(rng.integers(0, L))                                   # the shared k-mer ends here on the source
+        rows = []
+        for _ in range(size):
+            start = anchor - int(rng.integers(k - 1, L))                      # the k-mer lies inside the read
+            r = src[start:start + L].copy()
+            nerr = int(rng.choice([0, 0, 0, 1, 2, 3 * e]))
+            for q in rng.integers(0, L, nerr):
+                if not (anchor - start - k + 1 <= q <= anchor - start):
+                    r[q] = ACGT[rng.integers(0, 4)]
+            d = int(rng.integers(0, 2))
+            pos = anchor - start                                               # last base of the k-mer in the oriented read
+            stored = _oriented(r, d)                                           # what the read file holds
+            rec_pos = pos if d == 0 else L - pos + k - 2                       # cmpcluster's strand flip, inverted (kthread_bucket.c:51-56)
+            rows.append((rec_pos if d == 0 else L - 1 - (pos - k + 1), d, stored))
+        # cmpcluster order: aligned position descending, then rid ascending (:44-62)
+        al = [(p if d == 0 else L - p + k - 2) for p, d, _ in rows]
+        order = sorted(range(size), key=lambda i: (-al[i], i))
+        for i in order:
+            p, d, stored = rows[i]
+            members.append(((len(reads)) << 32) | (p << 1) | d); reads.append(stored)
+        goff.append(len(members))
+    reads = np.stack(reads)
+    return reads, pack_nt4(reads), np.array(members, dtype=np.uint64), np.array(goff, dtype=np.int32)
+
+
+def _construct_ref(reads, members, L, k, e):
+    """construct_ref for one group (kthread_bucket.c:69-377): returns (keep flags, new member words, sv, consensus bytes)."""
+    al, ds, rids = [], [], []
+    for y in members.tolist():
+        rid, pos, d = y >> 32, (y & 0xFFFFFFFF) >> 1, y & 1
+        al.append(L - pos + k - 2 if d else pos); ds.append(d); rids.append(rid)
+    offs = [al[0] - a for a in al]
+    TL = 2 * L
+    c1 = np.zeros((4, TL), dtype=np.int64)
+    ors = [(_oriented(reads[r], d) >> 1 ^ _oriented(reads[r], d) >> 2) & 3 for r, d in zip(rids, ds)]
+    for o, code in zip(offs, ors):
+        c1[code, o + np.arange(L)] += 1
+    first, mx = _majority(c1)
+    ref_len = int(np.argmax(mx == 0)) if (mx == 0).any() else TL
+    keep, c2, rend = [], np.zeros((4, TL), dtype=np.int64), 0
+    for o, code in zip(offs, ors):
+        cols = o + np.arange(L)
+        dif = int(((cols >= ref_len) | (first[np.minimum(cols, TL - 1)] != code)).sum())
+        kp = dif <= e                                                          # :189
+        keep.append(kp)
+        if kp:
+            c2[code, cols] += 1; rend = max(rend, o + L)
+    nk = sum(keep)
+    new = [(r << 32) | (o << 1) | d for r, o, d in zip(rids, offs, ds)]
+    if not nk:
+        return keep, new, 0, b""
+    cov = c2.sum(axis=0)[:ref_len] > 0
+    sv = int(np.argmax(cov)) if cov.any() else ref_len
+    second, _ = _majority(c2)
+    return keep, new, sv, ACGT[second[sv:rend]].tobytes()
+
+
+@pytest.mark.parametrize("L,k,e", [(100, 31, 4), (150, 31, 4), (64, 17, 2)])
+def test_group_consensus_and_groups_to_contigs(ctx, L, k, e):
+    rng = np.random.default_rng(L + e)
+    reads, packed, members, goff = _make_groups(rng, 400, L, k, e)
+    d_members = _dev(members.view(np.int64))
+    gc = ctx.group_consensus(_dev(packed.view(np.int64)), d_members, _dev(goff), L, k, e)
+    ctx.sync()
+    got_keep, got_mem = gc["keep"].cpu().numpy(), d_members.cpu().numpy().view(np.uint64)
+    nk_all, contigs, rejects = [], [], []
+    for g in range(len(goff) - 1):
+        a, b = goff[g], goff[g + 1]
+        keep, new, sv, ref = _construct_ref(reads, members[a:b], L, k, e)
+        assert got_keep[a:b].tolist() == [int(x) for x in keep], g
+        assert got_mem[a:b].tolist() == new, g
+        nk = sum(keep); nk_all.append(nk)
+        assert int(gc["nkept"][g]) == nk and (nk == 0 or (int(gc["sv"][g]) == sv and int(gc["reflen"][g]) == len(ref)))
+        if nk:
+            assert gc["refs"][g * gc["stride"]: g * gc["stride"] + len(ref)].cpu().numpy().tobytes() == ref
+        # process_bucket :446-505: more than one kept -> contig (members re-based to sv); everybody else is a reject
+        if nk > 1:
+            contigs.append((ref, [y - (sv << 1) for y, kp in zip(new, keep) if kp]))
+        if not (nk == b - a and nk > 1):
+            rejects += [(y >> 32, g) for y, kp in zip(new, keep) if not kp]
+            if nk == 1:
+                rejects += [(y >> 32, g) for y, kp in zip(new, keep) if kp]
+    assert sum(1 for n in nk_all if n > 1) > 100 and len(rejects) > 20
+    out = ctx.groups_to_contigs(d_members, _dev(goff), gc, cap_chars=2 * L * len(goff), cap_members=len(members), cap_contigs=len(goff))
+    nc, nch, nmm, nrj = out["counts"]
+    assert nc == len(contigs) and nrj == len(rejects)
+    soff, moff = out["soff"].cpu().numpy(), out["moff"].cpu().numpy()
+    seq, mem = out["seq"].cpu().numpy().tobytes(), out["mem"].cpu().numpy().view(np.uint64)
+    for c, (ref, mm) in enumerate(contigs):
+        assert seq[soff[c]:soff[c + 1]] == ref and mem[moff[c]:moff[c + 1]].tolist() == mm, c
+    assert list(zip(out["rej_rid"].cpu().numpy().tolist(), out["rej_group"].cpu().numpy().tolist())) == rejects
+
+
+def _random_set(rng, n, L):
+    """A contig set with members that lie on their contigs (reads cut from the consensus, a few substitutions)."""
+    from minicom_amd.hip import pack_nt4
+    refs, mems, reads = [], [], []
+    for c in range(n):
+        ln = int(rng.integers(L, 5 * L))
+        ref = ACGT[rng.integers(0, 4, ln)]
+        mm = []
+        for off in sorted(rng.integers(0, ln - L + 1, int(rng.integers(2, 12))).tolist() + [0, ln - L]):
+            r = ref[off:off + L].copy()
+            for q in rng.integers(0, L, int(rng.integers(0, 3))):
+                r[q] = ACGT[rng.integers(0, 4)]
+            d = int(rng.integers(0, 2))
+            mm.append((len(reads) << 32) | (off << 1) | d); reads.append(_oriented(r, d))
+        refs.append(ref); mems.append(sorted(mm, key=lambda y: y & 0xFFFFFFFF))
+    reads = np.stack(reads)
+    # consensus = majority of the members, so that "outside the overlap keeps the parent's character" holds as in the pipeline
+    for c in range(n):
+        cnt = np.zeros((4, len(refs[c])), dtype=np.int64)
+        for y in mems[c]:
+            rid, off, d = y >> 32, (y & 0xFFFFFFFF) >> 1, y & 1
+            o = _oriented(reads[rid], d); cnt[(o >> 1 ^ o >> 2) & 3, off + np.arange(L)] += 1
+        refs[c] = ACGT[_majority(cnt)[0]]
+    return refs, mems, reads, pack_nt4(reads)
+
+
+def test_merge_round_pieces_against_numpy(ctx):
+    """One merge round on a random set: member merge, consensus (every column, and overlap only), carry of the rest."""
+    import torch
+    L = 100
+    rng = np.random.default_rng(77)
+    n = 300
+    refs, mems, reads, packed = _random_set(rng, n, L)
+    soff = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
+    moff = np.concatenate([[0], np.cumsum([len(m) for m in mems])]).astype(np.int64)
+    seq = np.concatenate(refs); mem = np.array([y for m in mems for y in m], dtype=np.uint64)
+    # claimed pairs: (ci, cj, pos_ori, pos) with anchors inside both contigs
+    perm = rng.permutation(n)
+    jobs = []
+    for j in range(90):
+        ci, cj = int(perm[2 * j]), int(perm[2 * j + 1])
+        jobs.append((ci, cj, int(rng.integers(30, len(refs[ci]))), int(rng.integers(30, min(len(refs[cj]), 60)))))
+    flag = np.zeros(n, dtype=np.uint8)
+    for ci, cj, _, _ in jobs:
+        flag[ci] = flag[cj] = 1
+    d_seq, d_soff, d_mem, d_moff = _dev(seq), _dev(soff), _dev(mem.view(np.int64)), _dev(moff)
+    d_jobs = _dev(np.array(jobs, dtype=np.int32))
+    jm, jmoff, jroff, tot = ctx.merge_members(d_mem, d_moff, d_jobs, L, 14)
+    # kthread_cb.c:297-325 + the stable cmpcluster2 sort of construct_ref2 (:107)
+    want_m, want_len = [], []
+    for ci, cj, po, pp in jobs:
+        if po >= pp:
+            lst = mems[ci] + [y + ((po - pp) << 1) for y in mems[cj]]
+        else:
+            lst = mems[cj] + [y + ((pp - po) << 1) for y in mems[ci]]
+        lst = sorted(lst, key=lambda y: y & 0xFFFFFFFF)                          # python's sort is stable
+        want_m.append(lst); want_len.append(((lst[-1] & 0xFFFFFFFF) >> 1) + L)
+    assert jm.cpu().numpy().view(np.uint64).tolist() == [y for lst in want_m for y in lst]
+    assert np.array_equal(jmoff.cpu().numpy(), np.concatenate([[0], np.cumsum([len(x) for x in want_m])]))
+    assert np.array_equal(jroff.cpu().numpy(), np.concatenate([[0], np.cumsum(want_len)])) and tot == (sum(len(x) for x in want_m), sum(want_len), max(want_len))
+    # consensus of every merged list
+    want_refs = []
+    for lst, ln in zip(want_m, want_len):
+        cnt = np.zeros((4, ln), dtype=np.int64)
+        for y in lst:
+            rid, off, d = y >> 32, (y & 0xFFFFFFFF) >> 1, y & 1
+            o = _oriented(reads[rid], d); cnt[(o >> 1 ^ o >> 2) & 3, off + np.arange(L)] += 1
+        want_refs.append(ACGT[_majority(cnt)[0]].tobytes())
+    d_packed = _dev(packed.view(np.int64))
+    full = ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L)
+    part = ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L, jobs=d_jobs, seq=d_seq, soff=d_soff)
+    assert full.cpu().numpy().tobytes() == b"".join(want_refs)
+    assert torch.equal(full, part)                                               # counting only the overlap changes nothing
+    # cp_cluster: merged first, then the untouched ones in their order
+    nj = len(jobs); nkeep = int((flag == 0).sum()); nn = nj + nkeep
+    seq2 = torch.zeros(len(seq) + 16, dtype=torch.uint8, device="cuda"); seq2[: tot[1]] = full
+    mem2 = torch.zeros(len(mem) + 1, dtype=torch.int64, device="cuda"); mem2[: tot[0]] = jm
+    soff2 = torch.zeros(nn + 1, dtype=torch.int64, device="cuda"); soff2[: nj + 1] = jroff
+    moff2 = torch.zeros(nn + 1, dtype=torch.int64, device="cuda"); moff2[: nj + 1] = jmoff
+    keepidx, totals = ctx.contigs_carry(d_seq, d_soff, d_mem, d_moff, _dev(flag), nj, seq2, soff2, mem2, moff2)
+    kept = np.flatnonzero(flag == 0)
+    assert np.array_equal(keepidx.cpu().numpy(), kept)
+    all_refs = want_refs + [refs[i].tobytes() for i in kept]
+    all_mems = want_m + [mems[i] for i in kept]
+    assert totals == (sum(len(r) for r in all_refs), len(mem))
+    s2, m2, so2, mo2 = seq2.cpu().numpy().tobytes(), mem2.cpu().numpy().view(np.uint64), soff2.cpu().numpy(), moff2.cpu().numpy()
+    for c in range(nn):
+        assert s2[so2[c]:so2[c + 1]] == all_refs[c] and m2[mo2[c]:mo2[c + 1]].tolist() == all_mems[c], c
+    # minimizers of the untouched contigs keep their values and take the new contig index
+    moff_r, rec = ctx.sketch_contigs(d_seq, d_soff, n, 19, 31)
+    ctx.sync()
+    base = 1234
+    rec2 = ctx.empty_records(base + int(rec.shape[0]) + 8)
+    roff2 = torch.zeros(nn + 1, dtype=torch.int32, device="cuda")
+    total = ctx.records_carry(rec, moff_r, keepidx, nj, base, rec2, roff2)
+    ctx.sync()
+    r, ro, r2, ro2 = rec.cpu().numpy().view(np.uint64), moff_r.cpu().numpy(), rec2.cpu().numpy().view(np.uint64), roff2.cpu().numpy()
+    at = base
+    for u, i in enumerate(kept.tolist()):
+        seg = r[ro[i]:ro[i + 1]].copy()
+        seg[:, 1] = (np.uint64((nj + u) << 8) << np.uint64(32)) | (seg[:, 1] & np.uint64(0xFFFFFFFF))
+        assert ro2[nj + u] == at and np.array_equal(r2[at:at + len(seg)], seg), u
+        at += len(seg)
+    assert ro2[nn] == at == total
