@@ -227,7 +227,9 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
  * read), verifies every hit like :390-393 / :458-461 -- including the exact key comparison of :385-386, which
  * the tags leave open -- and keeps the minimum claim key per singleton.
  *   d_elig : NULL, or [n_sg] bit l set = the singleton is within the last `maxsearch` entries of its bin of
- *            dictionary l (mcom_dicts_eligible) -- only needed when some bin exceeds maxsearch (:388)
+ *            dictionary l as built (mcom_dicts_eligible).  This static cut equals mcom_realign_pass with its
+ *            maxsearch argument; both equal the reference only while no bin exceeds maxsearch -- for longer
+ *            bins use mcom_dicts_bigbins / mcom_realign_pass_tuples below
  *   d_stats: optional [3] = { lookups, windows verified, tuples passing }                                */
 int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines);
 int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
@@ -241,6 +243,27 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
+
+/* Bins longer than maxsearch, exactly.  The reference walks the LIVE part of a bin from its end for at most
+ * maxsearch entries (kthread_hash_realign.c:388, findpos at bbhashdict.c:33-49) and takes claimed reads out of every
+ * bin after the visit that claimed them (:420-435, remove at bbhashdict.c:51-67), so a read deep in a long bin turns
+ * visible once enough of the reads above it are gone.  Only the members of such bins depend on that order:
+ *   mcom_dicts_bigbins       d_binstart [nd][n_sg]: start of the singleton's bin in dictionary l when that bin
+ *                            holds more than maxsearch reads, else 0xFFFFFFFF;  d_mark [n_sg]: 1 = member of
+ *                            at least one such bin
+ *   mcom_realign_pass_tuples mcom_realign_pass_reads for the unmarked singletons; for a marked one d_claim stays
+ *                            all-ones and EVERY tuple it passes is appended to d_tuples as {claim key, singleton
+ *                            index} (2 x uint64 each, at most `cap`; *h_ntuples is the number found, larger
+ *                            than cap = run again with a larger buffer).  Synchronous.
+ *   mcom_claims_patch        d_claim[d_idx[i]] = d_val[i]: the result of replaying the marked singletons
+ * The replay itself (a few thousand reads, in visiting order) is host work: minicom_amd/host/mcom_pipeline.cpp.  */
+int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_binstart, uint8_t *d_mark);
+int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines,
+                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg,
+                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats,
+                             uint64_t *d_tuples, uint64_t cap, uint64_t *h_ntuples);
+int mcom_claims_patch(mcom_ctx *ctx, uint64_t *d_claim, const uint32_t *d_idx, const uint64_t *d_val, size_t n);
 
 /* The members one pass appends, in the order the sequential scan appends them (claim key ascending, singleton
  * index descending: the bin is walked from its end, kthread_hash_realign.c:388, :408-409, :474-475).

@@ -546,12 +546,16 @@ __device__ __forceinline__ bool encode_ok_sparse(const uint64_t (&mm)[W], int L,
 // positions that carry its key (a few at most), then all lanes verify their i-th candidate together: the expensive
 // part runs converged instead of once per slot of the probe loop.
 #define RR_CAND 4
-template <int W, int G>
+// TUP: singletons with mark[sg] set (members of a bin longer than maxsearch) do not take part in the minimum: every
+// tuple they pass is appended to `tuples` {claim key, singleton} for the replay of those bins on the host
+template <int W, int G, bool TUP>
 __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys,
                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
                                                        const uint32_t *__restrict__ elig, size_t n_sg, const uint64_t *__restrict__ cbits,
                                                        const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff, int thr,
-                                                       unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats)
+                                                       unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats,
+                                                       const uint8_t *__restrict__ mark, ulonglong2 *__restrict__ tuples,
+                                                       unsigned long long tup_cap, unsigned long long *__restrict__ tup_count)
 {
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const size_t sg = t / G;
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	if (live && sgflag[sg]) live = false;
 	const uint32_t el = (live && elig) ? elig[sg] : 0xFFFFFFFFu;
 	if (live && !((el >> l) & 1u)) live = false;
+	const bool marked = TUP && live && mark[sg];
 	uint64_t row[W];
 #pragma unroll
 	for (int w = 0; w < W; ++w) row[w] = 0;
@@ -596,15 +601,21 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
 		if (dist > thr || bits_key(x, g.ds[l], g.klen) != 0) return;                         // a tag is not the key: exact check here
 		// a lower dictionary that also sees this read at this window claims the same tuple with a smaller key
-		for (int l2 = 0; l2 < l; ++l2)
-			if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;
+		// (not for a marked singleton: whether the lower dictionary sees it there is decided by the replay)
+		if (!marked)
+			for (int l2 = 0; l2 < l; ++l2)
+				if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;
 		uint64_t mm[W];
 #pragma unroll
 		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
 		if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) return; }                          // :393
 		else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) return;                       // :461
 		++n_pass;
-		atomicMin(&claim[sg], ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l);
+		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+		if (marked) {
+			const unsigned long long at = atomicAdd(tup_count, 1ull);
+			if (at < tup_cap) tuples[at] = make_ulonglong2(ck, (unsigned long long)sg);
+		} else atomicMin(&claim[sg], ck);
 	};
 
 	uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int nc = 0;
@@ -658,10 +669,11 @@ __global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsign
 	out[c] = s;
 }
 
-extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
-                                       const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
-                                       const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
-                                       uint64_t *d_claim, uint64_t *d_stats)
+static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+                                const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
+                                const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
+                                uint64_t *d_claim, uint64_t *d_stats, const uint8_t *d_mark, ulonglong2 *d_tuples, uint64_t cap,
+                                unsigned long long *d_count)
 {
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
@@ -683,14 +695,104 @@ extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, ui
 	const int G = 2 * g.nd <= 16 ? 16 : 32;
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
-#define MCOM_CASE(WW) case WW: if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); \
-	else hipLaunchKernelGGL((k_realign_reads<WW, 32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets); break;
+#define MCOM_ARGS g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count
+#define MCOM_CASE(WW) case WW: \
+	if (d_mark) { if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	              else hipLaunchKernelGGL((k_realign_reads<WW, 32, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } \
+	else if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else hipLaunchKernelGGL((k_realign_reads<WW, 32, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
+#undef MCOM_ARGS
 	MCOM_LAUNCH_CHECK(ctx);
 	if (d_stats) hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+                                       const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
+                                       const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
+                                       uint64_t *d_claim, uint64_t *d_stats)
+{
+	return realign_reads_launch(ctx, d_keys, log2lines, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
+	                            d_claim, d_stats, nullptr, nullptr, 0, nullptr);
+}
+
+// ---- bins longer than maxsearch ---------------------------------------------------------------------------------
+// The scan walks the LIVE part of a bin from its end for at most maxsearch entries (kthread_hash_realign.c:388,
+// bbhashdict.c:33-67), and claimed reads leave every bin after the visit that claimed them (:420-435): a read deep in
+// a long bin becomes visible once enough of the reads above it are gone.  That is sequential, but only for the
+// members of such bins: they are marked here, the pass hands back every tuple they pass, and the host replays the
+// visits of those few reads in order.
+__global__ void k_dict_bigbins(const uint64_t *__restrict__ sgbits, int W, const uint32_t *__restrict__ ids, size_t n,
+                               const uint64_t *__restrict__ slots, uint32_t log2cap, int start, int len, uint32_t maxsearch,
+                               uint32_t *__restrict__ binstart, uint8_t *__restrict__ mark)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = ids[i];
+	uint32_t s = 0, c = 0;
+	const bool f = dict_find(slots, log2cap, bits_key(sgbits + (size_t)sg * W, start, len), s, c);
+	if (f && c > maxsearch) { binstart[sg] = s; mark[sg] = 1; }
+	else binstart[sg] = 0xFFFFFFFFu;
+}
+
+extern "C" int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_binstart, uint8_t *d_mark)
+{
+	if (!ctx || !d) return MCOM_E_ARG;
+	if (d->n_sg == 0) return MCOM_OK;
+	if (!d_sgbits || !d_binstart || !d_mark || maxsearch < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad arguments");
+	MCOM_HIP(ctx, hipMemsetAsync(d_mark, 0, d->n_sg, ctx->stream));
+	for (int l = 0; l < d->nd; ++l)
+		hipLaunchKernelGGL(k_dict_bigbins, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
+		                   d->slots[l], d->log2cap[l], d->ds[l], d->kl[l], (uint32_t)maxsearch, d_binstart + (size_t)l * d->n_sg, d_mark);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+                                        const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg, const uint64_t *d_cbits,
+                                        const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
+                                        uint64_t *d_claim, uint64_t *d_stats, uint64_t *d_tuples, uint64_t cap, uint64_t *h_ntuples)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!d_mark || !d_tuples || !h_ntuples) return mcom_fail(ctx, MCOM_E_ARG, "null tuple buffer");
+	unsigned long long *d_count = nullptr;
+	int rc = MCOM_OK;
+	hipError_t e = mcom_dmalloc(&d_count, 8);
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "tuple counter");
+	e = hipMemsetAsync(d_count, 0, 8, ctx->stream);
+	if (e == hipSuccess) {
+		rc = realign_reads_launch(ctx, d_keys, log2lines, d_sgbits, d_sgflag, nullptr, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
+		                          d_claim, d_stats, d_mark, (ulonglong2*)d_tuples, cap, d_count);
+		if (!rc) {
+			unsigned long long h = 0;
+			e = hipMemcpyAsync(&h, d_count, 8, hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			*h_ntuples = h;
+		}
+	}
+	mcom_dfree(d_count);
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, hipGetErrorString(e));
+	return rc;
+}
+
+__global__ void k_claims_patch(unsigned long long *__restrict__ claim, const uint32_t *__restrict__ idx, const unsigned long long *__restrict__ val, size_t n)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) claim[idx[i]] = val[i];
+}
+
+extern "C" int mcom_claims_patch(mcom_ctx *ctx, uint64_t *d_claim, const uint32_t *d_idx, const uint64_t *d_val, size_t n)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_claim || !d_idx || !d_val) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_claims_patch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_claim, d_idx,
+	                   (const unsigned long long*)d_val, n);
+	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
 

@@ -183,7 +183,7 @@ struct mcomh_pipeline {
 	hipStream_t stream = nullptr;
 	std::string err;
 	size_t n = 0; int L = 0, W = 0, NW = 0;
-	int k = 0, e = 0, m = 0, rw = 0, cbthr = 0, max_rounds = 0, step = 0, maxthr = 0, numdict = 0, maxsearch = 500;
+	int k = 0, e = 0, m = 0, rw = 0, cbthr = 0, max_rounds = 0, step = 0, maxthr = 0, numdict = 0, maxsearch = 500, maxsearch_forced = 0;
 	int host_threads = 1;
 	// device
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
@@ -269,6 +269,8 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->numdict = pp->numdict;
 	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }
 	{ const char *fc = getenv("MCOMH_FULL_CONSENSUS"); p->full_consensus = fc && fc[0] == '1'; }   // A/B switch for measurements
+	// test hook: the reference fixes maxsearch at 500 / 2000; a small value lets a small input exercise the cut of long bins
+	{ const char *mv = getenv("MCOMH_MAXSEARCH"); p->maxsearch_forced = mv ? atoi(mv) : 0; }
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
 	if (host_reads) {
@@ -454,6 +456,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		}
 	}
 	if (p->sg.size() <= 5000000) p->maxsearch = 2000;                               // preprocess.c:169-172
+	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
 	p->stat["n_sg0"] = (double)p->sg.size();
 	p->stat["t_bucket"] += now_ms() - t0;
 	return MCOM_OK;
@@ -798,6 +801,106 @@ static int materialize(P *p)
 	return MCOM_OK;
 }
 
+// ---- bins longer than maxsearch: replay of their members in visiting order -----------------------------------
+// kthread_hash_realign.c:374-435 with findpos / remove of bbhashdict.c:33-67: a visit scans the last maxsearch LIVE
+// entries of the bin; the reads it claims leave every bin after the visit.  Reads that sit in no long bin are
+// unaffected (all of their bins are scanned completely) and are settled by the kernel's minimum; for the members of
+// long bins the kernel hands back every tuple they pass and the visits are replayed here, in key order.
+struct Fenwick {
+	std::vector<uint32_t> t;
+	void init(size_t n) { t.assign(n + 1, 0); }
+	void add(size_t i) { for (++i; i < t.size(); i += i & (~i + 1)) ++t[i]; }
+	uint32_t prefix(size_t i) const { uint32_t s = 0; for (; i; i -= i & (~i + 1)) s += t[i]; return s; }   // removed among [0, i)
+};
+static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgbits, const uint8_t *d_flag, size_t n_sg, size_t nc, int thr,
+                            uint64_t *d_claim, uint64_t *d_st)
+{
+	int rc, nd = 0; uint32_t nk[16], mb[16];
+	mcom_dicts_info(dicts, &nd, nk, mb);
+	DevBuf<uint32_t> d_bs; DevBuf<uint8_t> d_mark;
+	if (!d_bs.reserve((size_t)nd * n_sg) || !d_mark.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "long bins");
+	if ((rc = p->gpu(mcom_dicts_bigbins(p->ctx, dicts, d_sgbits, p->maxsearch, d_bs.p, d_mark.p)))) return rc;
+	std::vector<uint8_t> mark(n_sg);
+	std::vector<uint32_t> bs((size_t)nd * n_sg);
+	if ((rc = p->d2h(mark.data(), d_mark.p, n_sg, "copy marks")) || (rc = p->d2h(bs.data(), d_bs.p, (size_t)nd * n_sg, "copy bins")) || (rc = p->sync("long bins"))) return rc;
+	std::vector<uint32_t> M;                                                           // the marked singletons, ascending
+	for (size_t i = 0; i < n_sg; ++i) if (mark[i]) M.push_back((uint32_t)i);
+	p->stat["big_bin_reads"] += (double)M.size();
+	// every tuple the marked singletons pass
+	DevBuf<uint64_t> d_tup;
+	uint64_t cap = (1ull << 20) + 64ull * M.size(), nt = 0;
+	for (;;) {
+		if (!d_tup.reserve(2 * cap)) return p->fail(MCOM_E_NOMEM, "tuples");
+		if ((rc = p->gpu(mcom_realign_pass_tuples(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits, d_flag, d_mark.p, n_sg, p->d_cbits.p, p->d_coff_words.p,
+		                                          p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim, d_st, d_tup.p, cap, &nt)))) return rc;
+		if (nt <= cap) break;
+		cap = nt + (nt >> 3);
+	}
+	std::vector<std::pair<uint64_t, uint64_t>> tup(nt);
+	static_assert(sizeof(std::pair<uint64_t, uint64_t>) == 16, "tuple layout");
+	if (nt && ((rc = p->d2h((uint64_t*)tup.data(), d_tup.p, 2 * nt, "copy tuples")) || (rc = p->sync("tuples")))) return rc;
+	p->stat["big_bin_tuples"] += (double)nt;
+	std::sort(tup.begin(), tup.end());
+	// the long bins: members ascending (the order of read_id inside a bin), one tree of removed positions each
+	auto dense = [&](uint32_t sg) { return (size_t)(std::lower_bound(M.begin(), M.end(), sg) - M.begin()); };
+	struct Bin { std::vector<uint32_t> mem; Fenwick gone; };
+	std::vector<Bin> bins;
+	std::vector<uint32_t> bin_of((size_t)nd * M.size(), UINT32_MAX), pos_of((size_t)nd * M.size(), 0);
+	for (int l = 0; l < nd; ++l) {
+		std::vector<std::pair<uint32_t, uint32_t>> v;                                   // (bin start, singleton)
+		for (uint32_t sg : M) { const uint32_t b = bs[(size_t)l * n_sg + sg]; if (b != UINT32_MAX) v.emplace_back(b, sg); }
+		std::sort(v.begin(), v.end());
+		for (size_t a = 0; a < v.size();) {
+			size_t e = a; while (e < v.size() && v[e].first == v[a].first) ++e;
+			Bin B; B.mem.reserve(e - a);
+			for (size_t q = a; q < e; ++q) {
+				const size_t d = dense(v[q].second);
+				bin_of[(size_t)l * M.size() + d] = (uint32_t)bins.size(); pos_of[(size_t)l * M.size() + d] = (uint32_t)(q - a);
+				B.mem.push_back(v[q].second);
+			}
+			B.gone.init(B.mem.size());
+			bins.push_back(std::move(B));
+			a = e;
+		}
+	}
+	std::vector<uint64_t> won(M.size(), UINT64_MAX);
+	std::vector<size_t> batch;
+	const uint32_t ms = (uint32_t)p->maxsearch;
+	for (size_t a = 0; a < tup.size();) {
+		size_t e = a; while (e < tup.size() && tup[e].first == tup[a].first) ++e;     // one visit of one bin
+		const int l = (int)(tup[a].first & 15);
+		batch.clear();
+		for (size_t q = a; q < e; ++q) {
+			const size_t d = dense((uint32_t)tup[q].second);
+			if (won[d] != UINT64_MAX) continue;                                           // claimed earlier: gone from the bin (or not re-claimed, :395)
+			const uint32_t b = bin_of[(size_t)l * M.size() + d];
+			if (b != UINT32_MAX) {
+				const Bin &B = bins[b];
+				const size_t pos = pos_of[(size_t)l * M.size() + d];
+				const uint32_t above = (uint32_t)(B.mem.size() - 1 - pos), gone_above = B.gone.prefix(B.mem.size()) - B.gone.prefix(pos + 1);
+				if (above - gone_above >= ms) { p->stat["big_bin_deferred"] += 1; continue; }   // deeper than the scan reaches (:388)
+			}
+			batch.push_back(d);
+		}
+		for (size_t d : batch) {                                                          // :420-435, after the visit
+			won[d] = tup[a].first;
+			for (int l1 = 0; l1 < nd; ++l1) {
+				const uint32_t b = bin_of[(size_t)l1 * M.size() + d];
+				if (b != UINT32_MAX) bins[b].gone.add(pos_of[(size_t)l1 * M.size() + d]);
+			}
+		}
+		a = e;
+	}
+	size_t nw = 0; for (uint64_t w : won) nw += w != UINT64_MAX;
+	p->stat["big_bin_claims"] += (double)nw;
+	if (M.empty()) return MCOM_OK;
+	DevBuf<uint32_t> d_idx; DevBuf<uint64_t> d_val;
+	if (!d_idx.reserve(M.size()) || !d_val.reserve(M.size())) return p->fail(MCOM_E_NOMEM, "claims of long bins");
+	if ((rc = p->h2d(d_idx.p, M.data(), M.size(), "upload claims")) || (rc = p->h2d(d_val.p, won.data(), M.size(), "upload claims"))) return rc;
+	if ((rc = p->gpu(mcom_claims_patch(p->ctx, d_claim, d_idx.p, d_val.p, M.size())))) return rc;
+	return p->sync("claims of long bins");
+}
+
 // ----------------------------------------------------------------------------------------------------
 // realign_hash: one Stage-2 pass                                    kthread_hash_realign.c:569-594
 // ----------------------------------------------------------------------------------------------------
@@ -883,15 +986,14 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
 			                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
 		else {
-			DevBuf<uint32_t> d_elig; DevBuf<uint64_t> d_st;
+			DevBuf<uint64_t> d_st;
 			rc = MCOM_OK;
-			if (big) {                                                                           // bins cut at maxsearch (:388)
-				if (!d_elig.reserve(n_sg)) rc = p->fail(MCOM_E_NOMEM, "eligibility");
-				else rc = p->gpu(mcom_dicts_eligible(p->ctx, dicts, d_sgbits.p, p->maxsearch, d_elig.p));
-			}
-			if (!rc && !d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
-			if (!rc) rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits.p, d_flag.p, big ? d_elig.p : nullptr,
-			                                             n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
+			if (!d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
+			if (!rc && !big)
+				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits.p, d_flag.p, nullptr,
+				                                    n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
+			else if (!rc)
+				rc = realign_big_bins(p, dicts, d_sgbits.p, d_flag.p, n_sg, nc, thr, d_claim.p, d_st.p);
 			PinVec<uint64_t> hst; hst.resize(3);
 			if (!rc) rc = p->d2h(hst.data(), d_st.p, 3, "copy pass counters");
 			if (!rc) rc = p->sync("realign pass");

@@ -54,6 +54,7 @@ def lib():
     L.mcomo_dict_layout.restype = i32; L.mcomo_dict_layout.argtypes = [i32, i32, vp, vp]
     L.mcomo_new.restype = vp; L.mcomo_new.argtypes = [vp, sz, i32, C.POINTER(Params)]
     L.mcomo_free.restype = None; L.mcomo_free.argtypes = [vp]
+    L.mcomo_force_maxsearch.restype = None; L.mcomo_force_maxsearch.argtypes = [vp, i32]
     for f in ("mcomo_stage_reads", "mcomo_stage_bucket", "mcomo_stage_combine", "mcomo_update_single", "mcomo_run_all"):
         getattr(L, f).restype = None; getattr(L, f).argtypes = [vp]
     L.mcomo_stage_realign_pass.restype = C.c_long; L.mcomo_stage_realign_pass.argtypes = [vp, i32]
@@ -162,6 +163,10 @@ class Pipeline:
         self.n, self.L = reads.shape
         p = Params(**{k: int(v) for k, v in params.items()})
         self._h = lib().mcomo_new(_ptr(reads), self.n, self.L, C.byref(p))
+
+    def force_maxsearch(self, v: int):
+        """Test hook: cut bins at v entries instead of the reference's 500 / 2000."""
+        lib().mcomo_force_maxsearch(self._h, int(v))
 
     def close(self):
         if self._h:

@@ -329,7 +329,7 @@ int mcomo_dict_layout(int L, int ininumdict, int *start, int *end)
 struct mcomo_ctx {
 	size_t n; int L, W;
 	int k, e, m, rw, cbthr, max_rounds, step, maxthr, numdict_param;
-	int maxsearch;
+	int maxsearch, maxsearch_forced;
 	char *seq;              /* [n][L+1] */
 	uint8_t *cls;
 	mcomo_mm128 *rec0;
@@ -587,6 +587,7 @@ void mcomo_stage_bucket(mcomo_ctx *c)
 	}
 	buckets_clear(c->B[index]);
 	if (c->sg.n <= 5000000) c->maxsearch = 2000;                          /* preprocess.c:169-172 */
+	if (c->maxsearch_forced > 0) c->maxsearch = c->maxsearch_forced;
 }
 
 /* ---- mm_idx: sort each bucket; equal keys keep the order radix_sort_128x leaves them in
@@ -788,6 +789,10 @@ static int const_base_len(const char *s, int L, char base)
 	}
 	return len ? len : 1;
 }
+
+/* test hook: the reference fixes maxsearch at 500 / 2000 (minicommain.c:77, preprocess.c:169-172); a small value lets a
+ * small input exercise the cut of long bins (kthread_hash_realign.c:388) */
+void mcomo_force_maxsearch(mcomo_ctx *c, int v) { c->maxsearch_forced = v; if (v > 0) c->maxsearch = v; }
 
 /* ---- realign_hash                                                 kthread_hash_realign.c:569-594 */
 long mcomo_stage_realign_pass(mcomo_ctx *c, int thr)

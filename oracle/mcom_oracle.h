@@ -69,6 +69,7 @@ typedef struct {
 
 mcomo_ctx *mcomo_new(const char *reads, size_t n, int L, const mcomo_params *p);
 void mcomo_free(mcomo_ctx *c);
+void mcomo_force_maxsearch(mcomo_ctx *c, int v);   /* test hook, see mcom_oracle.c */
 void mcomo_stage_reads(mcomo_ctx *c);     /* kt_for_reads      kthread_reads.c:247 */
 void mcomo_stage_bucket(mcomo_ctx *c);    /* kt_for_bucket     kthread_bucket.c:562 */
 void mcomo_stage_combine(mcomo_ctx *c);   /* combine_cluster   kthread_cb.c:570 */

@@ -107,3 +107,92 @@ def test_pipeline_device_resident_input_and_lossless_accounting():
     assert bad == 0
     assert p.stat("t_gpu") > 0
     p.close(); ctx.close()
+
+
+def _repeat_pileup_reads(seed, L, n_clean, n_noisy, starts=None):
+    """A genome with one segment repeated at four loci, clean reads that assemble into contigs and noisy reads
+    (5-9 substitutions) piled up on few start positions: they end as singletons that share dictionary keys, inside
+    and outside the repeat, so Stage-2 bins grow long and the same long bin is visited from several windows."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    g = acgt[rng.integers(0, 4, 8000)]
+    rep = acgt[rng.integers(0, 4, 2 * L + 40)]
+    for at in (500, 2500, 4500, 6500):
+        g[at:at + len(rep)] = rep
+    rows = []
+    for _ in range(n_clean):
+        j = int(rng.integers(0, len(g) - L + 1))
+        r = g[j:j + L].copy()
+        if rng.random() < 0.3:
+            r[rng.integers(0, L)] = acgt[rng.integers(0, 4)]
+        rows.append(comp[r][::-1] if rng.random() < 0.5 else r)
+    if starts is None:
+        starts = np.r_[np.arange(0, len(g) - L, 173), 500 + np.arange(0, L + 40, 7), 2500 + np.arange(0, L + 40, 7)]
+    for _ in range(n_noisy):
+        j = int(starts[rng.integers(0, len(starts))])
+        r = g[j:j + L].copy()
+        for q in rng.integers(0, L, int(rng.integers(5, 10))):
+            r[q] = acgt[rng.integers(0, 4)]
+        rows.append(comp[r][::-1] if rng.random() < 0.5 else r)
+    rows = np.stack(rows)
+    return rows[rng.permutation(len(rows))].copy()
+
+
+@pytest.mark.parametrize("L,maxsearch", [(100, 2), (150, 3), (100, 7)])
+def test_stage2_bins_longer_than_maxsearch_follow_the_sequential_scan(monkeypatch, L, maxsearch):
+    """The reference scans the last `maxsearch` LIVE reads of a bin and removes claimed reads from every bin after the
+    visit (kthread_hash_realign.c:388, :420-435): which reads a visit sees depends on what was claimed before.  With
+    the limit forced low (test hook on both sides) the pipeline must still equal the sequential oracle."""
+    import oracle
+    from minicom_amd.pipeline import Pipeline
+    reads = _repeat_pileup_reads(9000 + L + maxsearch, L, 2400, 2500)
+    o = oracle.Pipeline(reads); o.force_maxsearch(maxsearch); o.run_all()
+    monkeypatch.setenv("MCOMH_MAXSEARCH", str(maxsearch))
+    p = Pipeline(reads, host_threads=4); p.pre_process()
+    assert p.stat("maxsearch") == maxsearch == o.counter("maxsearch")
+    assert p.stat("big_bins") > 0 and p.stat("big_bin_claims") > 0 and p.stat("big_bin_deferred") > 0
+    oc, pc = o.contigs(), p.contigs()
+    assert len(oc) == len(pc) > 3
+    for c, ((r0, m0), (r1, m1)) in enumerate(zip(oc, pc)):
+        assert r0 == r1 and np.array_equal(m0, m1), c
+    for name in ("sg", "fpA", "fpT"):
+        assert np.array_equal(o.id_list(name), p.id_list(name)), name
+    p.close(); o.close()
+
+
+def test_stage2_long_bins_at_the_reference_limit_of_2000():
+    """No test hook: 12 000 noisy copies of two loci inside a four-fold repeat keep their first 17-mer, so the first
+    dictionary holds bins of ~6000 reads, three times the reference's maxsearch of 2000 (preprocess.c:169-172), and
+    each is visited from four windows."""
+    import oracle
+    from minicom_amd.pipeline import Pipeline
+    L = 100
+    rng = np.random.default_rng(4711)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    g = acgt[rng.integers(0, 4, 8000)]
+    rep = acgt[rng.integers(0, 4, 2 * L + 40)]
+    for at in (500, 2500, 4500, 6500):
+        g[at:at + len(rep)] = rep
+    rows = []
+    for _ in range(2400):
+        j = int(rng.integers(0, len(g) - L + 1))
+        r = g[j:j + L]
+        rows.append(comp[r][::-1] if rng.random() < 0.5 else r.copy())
+    for _ in range(12000):
+        r = g[(520, 2533)[int(rng.integers(0, 2))]:][:L].copy()
+        for q in rng.integers(17, L, int(rng.integers(10, 15))):
+            r[q] = acgt[rng.integers(0, 4)]
+        rows.append(r)
+    reads = np.stack(rows)[rng.permutation(len(rows))].copy()
+    o = oracle.Pipeline(reads); o.run_all()
+    p = Pipeline(reads, host_threads=4); p.pre_process()
+    assert p.stat("maxsearch") == 2000 and p.stat("big_bins") > 0 and p.stat("big_bin_deferred") > 0
+    assert p.stat("big_bin_claims") > 4000
+    oc, pc = o.contigs(), p.contigs()
+    assert len(oc) == len(pc)
+    for c, ((r0, m0), (r1, m1)) in enumerate(zip(oc, pc)):
+        assert r0 == r1 and np.array_equal(m0, m1), c
+    assert np.array_equal(o.id_list("sg"), p.id_list("sg"))
+    p.close(); o.close()
