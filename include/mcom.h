@@ -336,6 +336,18 @@ int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_so
 int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_keepidx, size_t nkeep,
                        uint32_t first_id, uint32_t base, mcom_mm128 *d_rec2, size_t cap2, uint32_t *d_roff2, uint64_t *h_total);
 
+/* The minimizers of the merged contigs of one round without sketching them whole (csrc/resketch.hip): a merged contig
+ * differs from its parents only inside their overlap, and whether a k-mer becomes a record is decided by the w
+ * entries either side of it (sketch.c:138-161), so the parents' records outside that reach are taken over and only a
+ * segment around the overlap is sketched.  Result identical to mcom_sketch_contigs on the merged contigs (k odd).
+ *   d_jobs [nj][4] claimed pairs as in mcom_merge_members;  d_soff / d_rec / d_roff: string offsets, records and
+ *   record offsets of the PARENT set;  d_seq2 / d_soff2: the merged contigs (jobs first, mcom_merge_consensus_jobs);
+ *   out: d_roff2 [nj + 1], d_rec2 [<= cap2] with ids j<<8; *h_total records, *h_sketched_chars bases actually sketched.
+ * MCOM_E_OVERFLOW with *h_total = the room needed.  Synchronous.                                                  */
+int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
+                         const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
+                         uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

@@ -72,6 +72,7 @@ __device__ __forceinline__ uint64_t spread32(uint64_t x)
 struct SkChunk { uint32_t start, count; };
 
 __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                       const uint64_t *__restrict__ off_end,
                                                        const uint32_t *__restrict__ ids, size_t n, int w, int k, uint32_t limit,
                                                        const uint32_t *__restrict__ piece_off, SkChunk *__restrict__ chunks,
                                                        mcom_mm128 *__restrict__ tmp, uint64_t arena_cap, uint32_t arena_mask,
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	if (t >= n) return;
 	const int lane = threadIdx.x;
 	const uint8_t *s = seq + off[t];
-	const int len = (int)(off[t + 1] - off[t]);
+	const int len = (int)((off_end ? off_end[t] : off[t + 1]) - off[t]);   // off_end: string t is [off[t], off_end[t]), a segment
 	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
 	const uint64_t mask = (1ull << (2 * k)) - 1;
 	SkChunk *my_chunks = chunks + piece_off[t];
@@ -299,11 +300,11 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	}
 }
 
-__global__ void k_sketch_slots(const uint64_t *__restrict__ off, size_t n, uint32_t *__restrict__ slots)
+__global__ void k_sketch_slots(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, size_t n, uint32_t *__restrict__ slots)
 {
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > n) return;
-	slots[t] = t == n ? 0u : (uint32_t)((off[t + 1] - off[t] + PIECE - 1) / PIECE) + 1u;
+	slots[t] = t == n ? 0u : (uint32_t)(((off_end ? off_end[t] : off[t + 1]) - off[t] + PIECE - 1) / PIECE) + 1u;
 }
 // the chunks of contig t, in piece order, to out[moff[t] ...)
 __global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restrict__ piece_off, const SkChunk *__restrict__ chunks,
@@ -325,9 +326,22 @@ __global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restric
 int mcom_sketch_contigs_flat(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n, uint64_t n_chars,
                              int w, int k, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap, uint64_t *h_total, int *used);
 
+// d_off_end = NULL: string t is [d_off[t], d_off[t+1]) and their total is read from d_off[n]; otherwise string t is the
+// segment [d_off[t], d_off_end[t]) and chars_bound bounds the sum of their lengths
+int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars_bound,
+                        const uint32_t *d_ids, size_t n, int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                        uint64_t *h_total);
+
 extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
                                    int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
                                    uint64_t *h_total)
+{
+	return mcom_sketch_strings(ctx, d_seq, d_off, nullptr, 0, d_ids, n, w, k, max_per_contig, d_moff, d_out, cap, h_total);
+}
+
+int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars_bound,
+                        const uint32_t *d_ids, size_t n, int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                        uint64_t *h_total)
 {
 	if (!ctx) return MCOM_E_ARG;
 	if (h_total) *h_total = 0;
@@ -339,10 +353,12 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	if (!d_seq || !d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (cap && !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null output pointer");
 	const uint32_t limit = max_per_contig ? max_per_contig : 0xFFFFFFFFu;
-	uint64_t chars = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (!max_per_contig && getenv("MCOM_SKETCH_FLAT")) {                   // alternative: one thread per position (sketchflat.hip); measured equal, not faster
+	uint64_t chars = chars_bound;
+	if (!d_off_end) {
+		MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	if (!max_per_contig && !d_off_end && getenv("MCOM_SKETCH_FLAT")) {                   // alternative: one thread per position (sketchflat.hip); measured equal, not faster
 		int used = 0;
 		const int rcf = mcom_sketch_contigs_flat(ctx, d_seq, d_off, d_ids, n, chars, w, k, d_moff, d_out, cap, h_total, &used);
 		if (rcf || used) return rcf;
@@ -362,12 +378,12 @@ extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const ui
 	SkChunk *chunks = (SkChunk*)(base + slot_b + scr_b);
 	unsigned long long *cursor = (unsigned long long*)(base + slot_b + scr_b + chunk_b);
 	mcom_mm128 *tmp = (mcom_mm128*)(base + slot_b + scr_b + chunk_b + cur_b);
-	hipLaunchKernelGGL(k_sketch_slots, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, n, piece_off);
+	hipLaunchKernelGGL(k_sketch_slots, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_off_end, n, piece_off);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, piece_off, piece_off, n + 1, scr))) return rc;
 	MCOM_HIP(ctx, hipMemsetAsync(chunks, 0, chunk_b + cur_b, ctx->stream));             // chunk table and the cursors behind it
 	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL(k_sketch_contigs, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_seq, d_off, d_ids, n, w, k, limit, piece_off, chunks, tmp,
+	hipLaunchKernelGGL(k_sketch_contigs, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_seq, d_off, d_off_end, d_ids, n, w, k, limit, piece_off, chunks, tmp,
 	                   arena_cap, arenas - 1, cursor, d_moff); }
 	MCOM_LAUNCH_CHECK(ctx);
 	// counts are in d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]

@@ -105,6 +105,8 @@ def load_library():
     L.mcom_merge_members.restype = i32; L.mcom_merge_members.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp, vp, C.POINTER(u64)]
     L.mcom_merge_consensus_jobs.restype = i32; L.mcom_merge_consensus_jobs.argtypes = [vp, vp, vp, vp, vp, sz, u64, i32, vp, vp, vp, vp]
     L.mcom_contigs_carry.restype = i32; L.mcom_contigs_carry.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    L.mcom_resketch_merged.restype = i32
+    L.mcom_resketch_merged.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
     L.mcom_records_carry.restype = i32; L.mcom_records_carry.argtypes = [vp, vp, vp, vp, sz, u32, u32, vp, sz, vp, C.POINTER(u64)]
     L.mcom_claim_pairs.restype = i32
     L.mcom_claim_pairs.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(u64), C.POINTER(i32)]
@@ -436,6 +438,24 @@ class Context:
         self._check(self.lib.mcom_records_carry(self._h, self._p(rec), self._p(roff, torch.int32), self._p(keepidx, torch.int32), int(keepidx.shape[0]), first_id, base,
                                                 self._p(rec2), int(rec2.shape[0]), self._p(roff2, torch.int32), C.byref(tot)))
         return int(tot.value)
+
+    def resketch_merged(self, jobs, soff, rec, roff, seq2, soff2, merged_chars: int, w: int, k: int):
+        """mcom_resketch_merged.  Returns (roff2 int32 [nj+1], records int64 [total,2], bases sketched)."""
+        torch = _torch()
+        nj = int(jobs.shape[0])
+        roff2 = torch.empty(nj + 1, dtype=torch.int32, device=self.device)
+        tot, sk = C.c_uint64(), C.c_uint64()
+        cap = max(1024, merged_chars // 8 + nj)
+        while True:
+            out = self.empty_records(cap)
+            rc = self.lib.mcom_resketch_merged(self._h, self._p(jobs, torch.int32), nj, self._p(soff), self._p(rec), self._p(roff, torch.int32),
+                                               self._p(seq2), self._p(soff2), merged_chars, w, k, self._p(roff2), self._p(out), cap,
+                                               C.byref(tot), C.byref(sk))
+            if rc == -4 and int(tot.value) > cap:
+                cap = int(tot.value)
+                continue
+            self._check(rc)
+            return roff2, out[: int(tot.value)], int(sk.value)
 
     def claim_pairs(self, pairs, n_contigs: int, max_rounds: int = 4096):
         """mcom_claim_pairs.  pairs: int64 [n, 2] records in visiting order.  Returns (jobs int32 [nj, 4], flag uint8 [n_contigs], rounds)."""

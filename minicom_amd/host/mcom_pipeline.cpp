@@ -184,6 +184,7 @@ struct mcomh_pipeline {
 	std::string err;
 	size_t n = 0; int L = 0, W = 0, NW = 0;
 	int k = 0, e = 0, m = 0, rw = 0, cbthr = 0, max_rounds = 0, step = 0, maxthr = 0, numdict = 0, maxsearch = 500, maxsearch_forced = 0;
+	bool resketch = true;
 	int host_threads = 1;
 	// device
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
@@ -269,6 +270,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->numdict = pp->numdict;
 	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }
 	{ const char *fc = getenv("MCOMH_FULL_CONSENSUS"); p->full_consensus = fc && fc[0] == '1'; }   // A/B switch for measurements
+	{ const char *fs = getenv("MCOMH_FULL_SKETCH"); p->resketch = !(fs && fs[0] == '1'); }               // A/B switch: sketch merged contigs whole
 	// test hook: the reference fixes maxsearch at 500 / 2000; a small value lets a small input exercise the cut of long bins
 	{ const char *mv = getenv("MCOMH_MAXSEARCH"); p->maxsearch_forced = mv ? atoi(mv) : 0; }
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
@@ -652,7 +654,21 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			lap("t_cb_copy");
 			// minimizers: merged contigs are sketched, the untouched ones keep theirs under their new index
 			uint64_t tn = 0;
-			if ((rc = sketch_first(p, B, nj, tot[1], (size_t)A.nrec, tn))) return rc;
+			if (p->resketch && (p->k & 1)) {
+				// only around the overlaps; the parents' records carry the rest (csrc/resketch.hip)
+				B.n = nn;
+				if (!B.roff.reserve(nn + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+				size_t cap = std::max<size_t>(1024, tot[1] / 8 + nj);
+				uint64_t sk = 0;
+				for (int attempt = 0;; ++attempt) {
+					if (!B.rec.reserve(cap + (size_t)A.nrec)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+					rc = mcom_resketch_merged(p->ctx, d_jobs.p, nj, A.soff.p, A.rec.p, A.roff.p, B.seq.p, B.soff.p, tot[1], p->rw, p->k, B.roff.p, B.rec.p, cap, &tn, &sk);
+					if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tn; continue; }
+					if (rc) return p->gpu(rc);
+					break;
+				}
+				p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tn; p->stat["resketch_saved_bases"] += (double)(tot[1] - sk);
+			} else if ((rc = sketch_first(p, B, nj, tot[1], (size_t)A.nrec, tn))) return rc;
 			if ((rc = p->gpu(mcom_records_carry(p->ctx, A.rec.p, A.roff.p, d_keepidx.p, nkeep, (uint32_t)nj, (uint32_t)tn, B.rec.p, B.rec.cap, B.roff.p, &B.nrec)))) return rc;
 			lap("t_cb_sketch");
 			A.swap(B);
