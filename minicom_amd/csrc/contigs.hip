@@ -39,8 +39,10 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 //   phase 1b  ballots over the flags give, per position, the run counter (valid, non-palindromic bases since
 //             the last ambiguous base) and the ENTRY index (palindromic k-mers store no entry, sketch.c:133);
 //             every position writes its entry (hash or "empty", pos<<1|strand, run) into an LDS ring by entry index;
-//   phase 1c  a sparse table over the entries (log2 w levels) gives the newest smallest entry of any window,
-//             plus a flag "another entry of the window has the same hash";
+//   phase 1c  every new entry gets the newest smallest entry of the four entries ending at it, then -- from w/4 such
+//             blocks and w%4 single entries -- the newest smallest entry of the window of w entries ending at it, plus
+//             a flag "another entry of the window has the same hash"; both stay in LDS rings (two dependent LDS
+//             steps instead of the log2 w levels of a sparse table, and each window is evaluated once);
 //   phase 2   one lane per entry: the reference's statements (sketch.c:138-161) with the window minimum looked
 //             up instead of scanned; counts, wave prefix sums, one atomicAdd per piece reserves room in a
 //             temporary record array, then the same once more to write.
@@ -50,6 +52,7 @@ __device__ __forceinline__ int nt4_of(uint8_t ch)
 #define NGRP (PIECE / 64)
 #define ERING 256                          // >= PIECE + MAXW, power of two
 #define EMASK (ERING - 1)
+#define RBCAP 64                           // records collected in LDS before room is reserved for them (one atomic)
 
 // reverse the order of the 32 bases of a word (2-bit groups)
 __device__ __forceinline__ uint64_t rev_groups64(uint64_t x)
@@ -71,7 +74,7 @@ __device__ __forceinline__ uint64_t spread32(uint64_t x)
 
 struct SkChunk { uint32_t start, count; };
 
-__global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_sketch_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                        const uint64_t *__restrict__ off_end,
                                                        const uint32_t *__restrict__ ids, size_t n, int w, int k, uint32_t limit,
                                                        const uint32_t *__restrict__ piece_off, SkChunk *__restrict__ chunks,
@@ -82,8 +85,11 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	__shared__ uint64_t EX[ERING];          // per entry (index mod ERING): hash or U64MAX when empty
 	__shared__ uint32_t EP[ERING];          // pos<<1|strand, 0xFFFFFFFF when empty
 	__shared__ uint16_t ER[ERING];          // run counter after the entry (saturating)
-	__shared__ uint8_t ST[8][ERING];        // sparse table, level j >= 1, entry e: bits 0-6 offset of the newest smallest
-	                                        // entry of [e, e+2^j), bit 7: another entry of that range has the same hash
+	__shared__ uint8_t M4O[ERING];          // newest smallest entry of entries [e-3, e]: bits 0-1 how far it lies before e;
+	                                        //   bit 7: another entry of the four has the same hash
+	__shared__ uint8_t WQ[ERING];           // window of w entries ending at e: bits 0-6 distance of its newest smallest entry
+	                                        //   before e, bit 7: another entry of the window has the same hash
+	__shared__ mcom_mm128 RB[RBCAP];        // records waiting for room in the temporary array
 	const size_t t = blockIdx.x;
 	if (t >= n) return;
 	const int lane = threadIdx.x;
@@ -100,27 +106,47 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 	uint32_t run_in = 0;                    // run counter before the current piece       (wave uniform)
 	uint32_t ne_base = 0;                   // minimizers emitted before the current piece (wave uniform)
 	uint64_t qbase = 0;                     // unambiguous bases before the current group (wave uniform)
-	int LG = 0; while ((2 << LG) <= w) ++LG;                            // floor(log2 w)
 	const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));   // bits 0..lane-1
 
-	// entry e (may be negative = the ring's initial fill) as the scan sees it
-	auto EXat = [&](int e) -> uint64_t { return e < 0 ? U64MAX : EX[e & EMASK]; };
-	auto EPat = [&](int e) -> uint32_t { return e < 0 ? 0xFFFFFFFFu : EP[e & EMASK]; };
-	// newest smallest entry of [e, e+2^j) and its duplicate flag, from level j of the table
-	auto lvl = [&](int j, int e, bool &dup) -> int {
-		if (j == 0) { dup = false; return e; }
-		const uint8_t v = ST[j][e & EMASK]; dup = (v & 128) != 0; return e + (v & 127);
+	// The rings start out as the scan's initial fill (all-ones entries): entry e >= -128 lives in slot e & EMASK, and a
+	// negative e is only looked at while the entries written so far are below 128, so no access needs a guard.
+	for (int i = lane; i < ERING; i += 64) { EX[i] = U64MAX; EP[i] = 0xFFFFFFFFu; M4O[i] = 128; WQ[i] = 0; }
+	auto EXat = [&](int e) -> uint64_t { return EX[e & EMASK]; };
+	auto EPat = [&](int e) -> uint32_t { return EP[e & EMASK]; };
+	// newest smallest entry of the window of w entries ending at te (the reference's "min" after storing te) and whether
+	// another entry of the window has the same hash: the w entries are w%4 single ones (the oldest) and w/4 blocks of
+	// four whose newest smallest entries M4O points at, visited oldest first so that equal hashes leave the newest
+	auto wscan = [&](int te, bool &dup) -> int {
+		uint64_t x = U64MAX; int idx = te - w; dup = false;
+		bool first = true;
+		const int r = w & 3, q = w >> 2;
+		for (int i = 0; i < r; ++i) {
+			const int e = te - w + 1 + i;
+			const uint64_t xe = EXat(e);
+			if (first || xe <= x) { dup = !first && xe == x; x = xe; idx = e; }
+			first = false;
+		}
+		// four blocks at a time: their eight LDS reads are in flight together, a loop of single blocks would wait for each
+		for (int b0 = q - 1; b0 >= 0; b0 -= 4) {
+			uint64_t xs[4]; uint8_t os[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const int b = b0 - j < 0 ? 0 : b0 - j; os[j] = M4O[(te - 4 * b) & EMASK]; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const int b = b0 - j < 0 ? 0 : b0 - j; xs[j] = EX[(te - 4 * b - (os[j] & 3)) & EMASK]; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (b0 - j < 0) break;
+				const int e = te - 4 * (b0 - j);
+				const uint64_t xb = xs[j]; const uint8_t o = os[j];
+				const int ib = e - (o & 3); const bool db = (o & 128) != 0;
+				if (first || xb <= x) { dup = (!first && xb == x) ? true : db; x = xb; idx = ib; }
+				first = false;
+			}
+		}
+		return idx;
 	};
-	// newest smallest entry of the window of w entries ending at te (the reference's "min" after storing te)
-	auto wquery = [&](int te, bool &dup) -> int {
-		const int lo = te - w + 1, lo2 = te - (1 << LG) + 1;
-		bool da, db;
-		const int a = lvl(LG, lo, da), b = lvl(LG, lo2, db);
-		if (a == b) { dup = da || db; return a; }
-		const uint64_t xa = EXat(a), xb = EXat(b);
-		if (xa < xb) { dup = da; return a; }
-		dup = xa == xb ? true : db;
-		return b;                                                    // equal hashes: the newer one (b > a)
+	auto wquery = [&](int te, bool &dup) -> int {                    // the same, looked up (te >= 0, scanned already)
+		const uint8_t v = WQ[te & EMASK]; dup = (v & 128) != 0; return te - (v & 127);
 	};
 	auto make_rec = [&](uint64_t x, uint32_t pp) -> mcom_mm128 {
 		mcom_mm128 v; v.x = x; v.y = (x == U64MAX && pp == 0xFFFFFFFFu) ? U64MAX : (idhi | pp); return v;
@@ -148,16 +174,35 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 		}
 	};
 
-	int piece = 0;
-	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE, ++piece) {
+	// Global round trips are what a wave of this kernel waits for (PMC: 60 % of its cycles in s_waitcnt, LDS conflicts
+	// negligible), so the bases of the next piece are fetched while this one is worked on, and records collect in LDS
+	// until RBCAP of them (or the contig's end) make one reservation worthwhile instead of one per piece.
+	uint32_t rb_n = 0; int nchunk = 0;                                   // wave uniform
+	auto flush = [&]() {
+		if (!rb_n) return;
+		unsigned long long st = 0;
+		if (lane == 0) st = atomicAdd(cursor, (unsigned long long)rb_n);
+		st = __shfl(st, 0, 64);
+		if (lane == 0) { SkChunk ck; ck.start = (uint32_t)(arena0 + st); ck.count = rb_n; my_chunks[nchunk] = ck; }
+		++nchunk;
+		if (st + rb_n <= arena_cap) for (uint32_t i = lane; i < rb_n; i += 64) tmp[arena0 + st + i] = RB[i];
+		rb_n = 0;
+	};
+	uint8_t nx[NGRP];
+#pragma unroll
+	for (int g = 0; g < NGRP; ++g) { const int p = g * 64 + lane; nx[g] = p < len ? s[p] : 0; }
+	for (int ps = 0; ps < len && ne_base < limit; ps += PIECE) {
 		const int pe = ps + PIECE < len ? ps + PIECE : len;
 		__syncthreads();                                   // everybody is done with the rings of the previous piece
+		uint8_t ch[NGRP];
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) { ch[g] = nx[g]; const int p = ps + PIECE + g * 64 + lane; nx[g] = p < len ? s[p] : 0; }
 		// ---- phase 1a: this piece's unambiguous bases into the packed ring
 		int cc[NGRP]; uint64_t QQ[NGRP];
 #pragma unroll
 		for (int g = 0; g < NGRP; ++g) {
 			const int p = ps + g * 64 + lane;
-			const int c = p < pe ? nt4_of(s[p]) : 5;                      // 4 = ambiguous, 5 = beyond the end
+			const int c = p < pe ? nt4_of(ch[g]) : 5;                     // 4 = ambiguous, 5 = beyond the end
 			const bool valid = c < 4;
 			const uint64_t vM = __ballot(valid);
 			const int nv = __popcll(vM);
@@ -228,22 +273,24 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			ent_run += (int)__popcll(entM);
 		}
 		__syncthreads();
-		// ---- phase 1c: sparse table over entries [ent_in - w, ent_run)
-		{
-			const int lo = ent_in - w, hi = ent_run;
-			for (int j = 1; j <= LG; ++j) {
-				const int h = 1 << (j - 1);
-				for (int e = lo + lane; e + 2 * h <= hi; e += 64) {
-					bool da, db;
-					const int a = lvl(j - 1, e, da), b = lvl(j - 1, e + h, db);
-					const uint64_t xa = EXat(a), xb = EXat(b);
-					const int win = xa < xb ? a : b;                       // equal: b, the newer
-					const bool dup = xa == xb ? true : (xa < xb ? da : db);
-					ST[j][e & EMASK] = (uint8_t)((win - e) | (dup ? 128 : 0));
-				}
-				__syncthreads();
+		// ---- phase 1c: minima of blocks of four for the new entries, then their window minima
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
+			const int te = ent_in + 64 * g + lane;
+			if (te < ent_run) {
+				uint64_t x = EXat(te - 3); int o = 3; bool dup = false;
+#pragma unroll
+				for (int d = 2; d >= 0; --d) { const uint64_t xe = EXat(te - d); if (xe <= x) { dup = xe == x; x = xe; o = d; } }
+				M4O[te & EMASK] = (uint8_t)(o | (dup ? 128 : 0));
 			}
 		}
+		__syncthreads();
+#pragma unroll
+		for (int g = 0; g < NGRP; ++g) {
+			const int te = ent_in + 64 * g + lane;
+			if (te < ent_run) { bool d; const int i = wscan(te, d); WQ[te & EMASK] = (uint8_t)((te - i) | (d ? 128 : 0)); }
+		}
+		__syncthreads();
 		// ---- phase 2: one lane per entry (at most PIECE entries per piece), emission order = entry order
 		uint32_t mine[NGRP], excl[NGRP], gbase[NGRP], piece_total = 0;
 		uint64_t fx[NGRP]; uint32_t fp[NGRP];                              // an entry's first record: nearly always its only one
@@ -253,51 +300,62 @@ __global__ __launch_bounds__(64) void k_sketch_contigs(const uint8_t *__restrict
 			uint32_t m = 0;
 			fx[g] = 0; fp[g] = 0;
 			if (te < ent_run) entry_emits(te, [&](uint64_t x, uint32_t pp) { if (m == 0) { fx[g] = x; fp[g] = pp; } ++m; });
-			uint32_t incl = m;
+			// an entry emits one record at most unless equal hashes meet in a window: then (rarely) a real prefix sum
+			const uint64_t anyM = __ballot(m != 0);
+			uint32_t ex, tot;
+			if (__ballot(m > 1) == 0) { ex = (uint32_t)__popcll(anyM & below); tot = (uint32_t)__popcll(anyM); }
+			else {
+				uint32_t incl = m;
 #pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-			mine[g] = m; excl[g] = incl - m; gbase[g] = piece_total;
-			piece_total += __shfl(incl, 63, 64);
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+				ex = incl - m; tot = __shfl(incl, 63, 64);
+			}
+			mine[g] = m; excl[g] = ex; gbase[g] = piece_total;
+			piece_total += tot;
 		}
 		const uint32_t room = limit - ne_base;
 		const uint32_t take = piece_total < room ? piece_total : room;
+		// a piece's records go to the LDS buffer; a piece with more than the buffer holds (tiny w) reserves its own room
+		const bool direct = take > RBCAP;
+		if (direct || rb_n + take > RBCAP) flush();
 		unsigned long long start = 0;
-		if (take) {
+		if (direct) {
 			if (lane == 0) start = atomicAdd(cursor, (unsigned long long)take);
 			start = __shfl(start, 0, 64);
+			if (lane == 0) { SkChunk ck; ck.start = (uint32_t)(arena0 + start); ck.count = take; my_chunks[nchunk] = ck; }
+			++nchunk;
 		}
 		const bool fits = start + take <= arena_cap;
-		if (lane == 0) { SkChunk ck; ck.start = (uint32_t)(arena0 + start); ck.count = take; my_chunks[piece] = ck; }
+		auto emit = [&](uint32_t rel, const mcom_mm128 &v) {
+			if (rel >= take) return;
+			if (!direct) RB[rb_n + rel] = v;
+			else if (fits) tmp[arena0 + start + rel] = v;
+		};
 #pragma unroll
 		for (int g = 0; g < NGRP; ++g) {
 			if (!mine[g]) continue;
 			uint32_t rel = gbase[g] + excl[g];
-			if (mine[g] == 1) { if (rel < take && fits) tmp[arena0 + start + rel] = make_rec(fx[g], fp[g]); continue; }
-			entry_emits(ent_in + 64 * g + lane, [&](uint64_t x, uint32_t pp) {
-				if (rel < take && fits) tmp[arena0 + start + rel] = make_rec(x, pp);
-				++rel;
-			});
+			if (mine[g] == 1) { emit(rel, make_rec(fx[g], fp[g])); continue; }
+			entry_emits(ent_in + 64 * g + lane, [&](uint64_t x, uint32_t pp) { emit(rel, make_rec(x, pp)); ++rel; });
 		}
+		if (!direct) rb_n += take;
 		ne_base = ne_base + piece_total < ne_base ? 0xFFFFFFFFu : ne_base + piece_total;
 		ent_in = ent_run; run_in = run_run;
 	}
 	__syncthreads();
-	if (lane == 0) {
-		// the minimum still held after the last entry is written out (sketch.c:163-164)
-		const int tail = (len + PIECE - 1) / PIECE;                       // chunk slot behind the pieces
-		if (ne_base < limit && ent_in > 0) {
-			// the table of the last piece covers the window ending at the last entry
-			bool d; const int b = wquery(ent_in - 1, d);
-			const uint64_t bx = EXat(b);
-			if (bx != U64MAX) {
-				const unsigned long long at = atomicAdd(cursor, 1ull);
-				SkChunk ck; ck.start = (uint32_t)(arena0 + at); ck.count = 1; my_chunks[tail] = ck;
-				if (at < arena_cap) tmp[arena0 + at] = make_rec(bx, EPat(b));
-				++ne_base;
-			}
+	// the minimum still held after the last entry is written out (sketch.c:163-164)
+	if (ne_base < limit && ent_in > 0) {
+		// the window minimum of the last piece covers the window ending at the last entry
+		bool d; const int b = wquery(ent_in - 1, d);
+		const uint64_t bx = EXat(b);
+		if (bx != U64MAX) {
+			if (rb_n == RBCAP) flush();
+			if (lane == 0) RB[rb_n] = make_rec(bx, EPat(b));
+			++rb_n; ++ne_base;
 		}
-		cnt[t] = ne_base < limit ? ne_base : limit;
 	}
+	flush();
+	if (lane == 0) cnt[t] = ne_base < limit ? ne_base : limit;
 }
 
 __global__ void k_sketch_slots(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, size_t n, uint32_t *__restrict__ slots)

@@ -199,3 +199,34 @@ def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, n
         lo = int(s[q]); cnt = int(c[q])
         assert cnt == int((rec["x"] == keys[q]).sum()) and np.all(got["x"][lo:lo + cnt] == keys[q])
     idx.close()
+
+
+@pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24)])
+def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k):
+    """Tie-rich strings (short-period repeats, homopolymers, copied blocks, ambiguous bases): equal hashes inside a
+    window exercise the duplicate rules of sketch.c:138-161 and the exact fallback of the prefix window scan."""
+    import oracle
+    from test_gpu_resketch import _string
+    rng = np.random.default_rng(100 * w + k)
+    refs = []
+    for i in range(160):
+        n = int(rng.integers(1, 1500))
+        s = _string(rng, n, int(rng.integers(0, 3)))
+        if i % 7 == 0:
+            s[:] = s[0]                                               # a homopolymer
+        if i % 5 == 0 and n > 10:
+            s[rng.integers(0, n, 3)] = ord("N")
+        if i % 11 == 0 and n > 200:                                   # two copies of a block at a distance below w + k
+            s[100:140] = s[40:80]
+        refs.append(s.tobytes())
+    cg = ctx.upload_contigs(refs)
+    moff, out = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k)
+    ctx.sync()
+    moff = moff.cpu().numpy(); r = _recs(out)
+    total = 0
+    for i, ref in enumerate(refs):
+        want = oracle.sketch_lh_ori(ref, w, k, i << 8)
+        seg = r[moff[i]:moff[i + 1]]
+        assert np.array_equal(seg["x"], want["x"]) and np.array_equal(seg["y"], want["y"]), (w, k, i, len(ref))
+        total += len(want)
+    assert total > 500
