@@ -219,8 +219,8 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
 
 /* The same pass driven from the singletons (results identical to mcom_realign_pass; it is the production path).
  * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed
- * ONCE: mcom_cindex_plan sizes the index (d_keys: 8 << log2lines uint64; a slot is a 12-bit tag of the key, the
- * contig (24 bits) and the position (28 bits)) for a contig set, mcom_cindex_build fills it from the packed
+ * ONCE: mcom_cindex_plan sizes the index (d_keys: 8 << log2lines uint64 in lines of eight: an insert counter and
+ * seven slots; a slot is a 12-bit tag of the key, the contig (24 bits) and the position (28 bits)) for a contig set, mcom_cindex_build fills it from the packed
  * contigs (d_woff must hold n_contigs + 1 entries).  mcom_realign_pass_reads then looks up, for every
  * unflagged singleton, the key of each dictionary l at contig position window + ds[l] and the reverse complement
  * of that key at window + L - ds[l] - klen (the two probes of kthread_hash_realign.c:380 and :446 seen from the

@@ -382,13 +382,15 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 // reverse complement of the key at jj + L - ds[l] - klen) and verify exactly the tuples the window scan would have
 // verified.  Probes per pass drop from (2nd-1) * windows to (2nd-1) * singletons.
 //
-// Index: multi-map in HBM, lines of 8 slots = one 64-B sector; a slot is tag<<52 | contig<<28 | position with a
-// 12-bit tag of the key: a hit is only a candidate, the verification re-checks the key bits exactly (the XOR of read
+// Index: multi-map in HBM, lines of 8 words = one 64-B sector: word 0 counts the line's inserts (minus one), words
+// 1-7 are slots; a slot is tag<<52 | contig<<28 | position with a 12-bit tag of the key: a hit is only a candidate, the verification re-checks the key bits exactly (the XOR of read
 // and window is zero over the key's bases), so a tag collision costs one wasted verification and nothing else.
 // A key's probe sequence is line h1, h1+s, h1+2s, ... with an odd key-dependent stride s (so a repeat with 10^5
-// copies does not bury its neighbours the way linear probing would); inside a line slots fill from 0 up.  Slots are
-// never emptied, hence every copy of a key lies before the first EMPTY slot of its sequence.
+// copies does not bury its neighbours the way linear probing would); an entry moves on to the next line of its
+// sequence only when the line's counter says it is full, and counters only grow, hence every copy of a key lies in
+// the lines of its sequence up to and including the first one that saw at most seven inserts.
 #define CIX_EMPTY (~0ull)
+#define CIX_WAYS 7ull                       // entries per line of eight words; word 0 is the line's insert counter
 #define CIX_CBITS 24
 #define CIX_PBITS 28
 struct CixGeom { uint32_t log2lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };
@@ -429,23 +431,26 @@ extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, i
 	return MCOM_OK;
 }
 
+// first_contig[b] = the contig that owns position 256*b: contig c writes the entries of the block starts inside its own
+// range (a search per block -- nineteen dependent loads by one thread while 255 wait -- was a third of the insert's time)
+__global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_blocks, uint32_t *__restrict__ first_contig)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_contigs) return;
+	const uint64_t a = woff[c] + (uint64_t)maxoff * c, b = woff[c + 1] + (uint64_t)maxoff * (c + 1);
+	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
+}
+
 // position space: contig c owns [woff[c] + maxoff*c, woff[c+1] + maxoff*(c+1)); positions p = 0 .. nw-1+maxoff of a
 // contig with nw > 0 windows are indexed, the maxoff phantom positions of a contig without windows are skipped
 __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
                                                        const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_pos,
-                                                       unsigned long long *__restrict__ keys)
+                                                       const uint32_t *__restrict__ first_contig, unsigned long long *__restrict__ keys)
 {
-	__shared__ uint32_t c0s;
 	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
-	if (threadIdx.x == 0) {                                                // (the block-wide search measured 8 % slower here: more barriers)
-		uint32_t lo = 0, hi = n_contigs;
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (woff[mid] + (uint64_t)g.maxoff * mid <= g0) lo = mid; else hi = mid; }
-		c0s = lo;
-	}
-	__syncthreads();
 	const uint64_t gi = g0 + threadIdx.x;
 	if (gi >= n_pos) return;
-	uint32_t c = c0s;
+	uint32_t c = first_contig[blockIdx.x];                                  // k_cindex_blocks: no search, no barrier
 	while (c + 1 < n_contigs && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) <= gi) ++c;
 	const uint64_t nw = woff[c + 1] - woff[c];
 	if (nw == 0) return;
@@ -459,11 +464,19 @@ __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t
 	cix_seq(key, g.log2lines, line, stride);
 	const uint32_t lmask = (1u << g.log2lines) - 1u;
 	const unsigned long long slot = (cix_tag(key) << 52) | ((unsigned long long)c << CIX_PBITS) | p;
+	// Word 0 of a line counts its inserts (it starts at all-ones, so the count is word + 1): one returning atomic hands
+	// out the slot, one store fills it -- two L2 requests per entry where reading along the line to its first empty
+	// slot and a CAS took four to five; the kernel is bound by L2 request rate, not by bytes.  A line that is full
+	// (seven entries) passes the entry on to the next line of the key's probe sequence.
 	for (;;) {
 		unsigned long long *kl = keys + (size_t)line * 8;
-		for (int s = 0; s < 8; ++s) {
-			if (kl[s] != CIX_EMPTY) continue;
-			if (atomicCAS(&kl[s], CIX_EMPTY, slot) == CIX_EMPTY) return;
+		// (a plain read first: it brings the line into L2 -- an atomic that misses costs several times one that hits -- and a
+		// line whose counter already shows an overflow is passed without an atomic; one that shows exactly seven still
+		// gets it, the lookup continues behind a line only when its counter exceeds seven)
+		const unsigned long long seen = *(volatile unsigned long long*)&kl[0] + 1ull;
+		if (seen <= CIX_WAYS) {
+			const unsigned long long at = atomicAdd(&kl[0], 1ull) + 1ull;
+			if (at < CIX_WAYS) { kl[1 + at] = slot; return; }
 		}
 		line = (line + stride) & lmask;
 	}
@@ -486,7 +499,12 @@ extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const u
 	if ((8ull << log2lines) * 7 < n_pos * 8) return mcom_fail(ctx, MCOM_E_ARG, "contig index too small: %llu entries", (unsigned long long)n_pos);
 	const uint64_t blocks = (n_pos + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions for one launch");
-	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, n_contigs, n_pos,
+	int rcw = mcom_ws_reserve(ctx, blocks * 4 + 256);
+	if (rcw) return rcw;
+	uint32_t *first_contig = (uint32_t*)ctx->ws;
+	hipLaunchKernelGGL(k_cindex_blocks, dim3((n_contigs + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, n_contigs, blocks, first_contig);
+	MCOM_LAUNCH_CHECK(ctx);
+	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, n_contigs, n_pos, first_contig,
 	                   (unsigned long long*)d_keys);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -636,9 +654,11 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 			unsigned long long ks[8];
 #pragma unroll
 			for (int s = 0; s < 8; ++s) ks[s] = kl[s];
+			const unsigned long long filled = ks[0] + 1ull;                               // inserts this line has seen
+			more = filled > CIX_WAYS;                                                     // some went on to the next line
 #pragma unroll
-			for (int s = 0; s < 8; ++s) {
-				if (ks[s] == CIX_EMPTY) { more = false; break; }
+			for (int s = 1; s < 8; ++s) {
+				if ((unsigned long long)s > filled) break;
 				if ((ks[s] >> 52) != tag) continue;
 				const uint64_t v = ks[s];
 				if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;

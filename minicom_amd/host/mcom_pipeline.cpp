@@ -1042,9 +1042,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				for (size_t q = i; q < i + 8 && q < n_sg; ++q) { if (f[q] == 1) p->fpA.push_back(p->sg[q]); else if (f[q] == 2) p->fpT.push_back(p->sg[q]); }
 			}
 		}
-		if (nwon) { p->n_pending += nwon; p->pend.push_back(std::move(app)); }
+		// a pass that appends nothing still counts: its scan sorts every contig first (:318), the appends of the pass before
+		// it included, and materialize() takes "the last pass" from the number of entries here
+		p->n_pending += nwon; p->pend.push_back(std::move(app));
 		p->stat["t_ra_append"] += now_ms() - tw0;
-	}
+	} else p->pend.emplace_back();
 	if (cluster_reads) *cluster_reads = (long)(C.mem.size() + p->n_pending);
 	p->stat["t_realign"] += now_ms() - t0;
 	return MCOM_OK;

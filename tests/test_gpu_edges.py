@@ -1,0 +1,67 @@
+"""GPU parity on inputs at the edges: one read, identical reads, reads that are all one base or all N, the shortest
+and longest read lengths, many exact duplicates, N-heavy reads.  Final contigs, members and every id list must equal
+the sequential oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    from minicom_amd import synth
+    yield "one_read", synth.synth_reads(1, 1, 100)
+    yield "two_identical", np.repeat(synth.synth_reads(2, 1, 100), 2, axis=0)
+    yield "three_reads", synth.synth_reads(3, 3, 150)
+    yield "all_A", np.full((50, 100), ord("A"), dtype=np.uint8)
+    yield "all_N", np.full((20, 100), ord("N"), dtype=np.uint8)
+    yield "L32", synth.synth_reads(4, 3000, 32)
+    yield "L40", synth.synth_reads(4, 3000, 40)
+    yield "L64", synth.synth_reads(5, 3000, 64)
+    yield "L255", synth.synth_reads(6, 1500, 255)
+    yield "L256", synth.synth_reads(7, 1500, 256)
+    yield "duplicates", np.repeat(synth.synth_reads(8, 40, 100), 50, axis=0)
+    r = synth.synth_reads(9, 2000, 100, plumbing=True)
+    r[::3, 10:60] = ord("N")
+    yield "N_heavy", r
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _cases()])
+def test_pipeline_equals_oracle_at_the_edges(name):
+    import oracle
+    from minicom_amd.pipeline import Pipeline
+    reads = dict(_cases())[name]
+    o = oracle.Pipeline(reads); o.run_all()
+    p = Pipeline(reads, host_threads=2); p.pre_process()
+    oc, pc = o.contigs(), p.contigs()
+    assert len(oc) == len(pc)
+    for c, ((r0, m0), (r1, m1)) in enumerate(zip(oc, pc)):
+        assert r0 == r1 and np.array_equal(m0, m1), (name, c)
+    for lst in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        assert np.array_equal(o.id_list(lst), p.id_list(lst)), (name, lst)
+    p.close(); o.close()
+
+
+def test_pipeline_on_an_empty_read_set():
+    """No reads (the reference reads none and goes on, bseq.c:38-66): every stage runs and leaves nothing."""
+    from minicom_amd.pipeline import Pipeline
+    p = Pipeline(np.zeros((0, 100), dtype=np.uint8))
+    p.pre_process()
+    assert p.contigs() == []
+    for lst in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        assert len(p.id_list(lst)) == 0
+    p.close()
+
+
+def test_last_pass_without_appends_still_sorts_the_appends_before_it():
+    """Stage 2 sorts every contig at the start of each scan (kthread_hash_realign.c:318): when the last pass claims
+    nothing, the members appended by the pass before it must still end up sorted (seen at L = 32)."""
+    import oracle
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = synth.synth_reads(4, 3000, 32)
+    o = oracle.Pipeline(reads); o.run_all()
+    p = Pipeline(reads); p.pre_process()
+    assert p.stat("passes") == o.counter("passes") == 2
+    for (r0, m0), (r1, m1) in zip(o.contigs(), p.contigs()):
+        assert r0 == r1 and np.array_equal(m0, m1)
+    p.close(); o.close()
