@@ -38,7 +38,7 @@ def special_reads(L, rng):
     out.append("N" * L)
     out.append("A" * L)
     out.append("T" * L)
-    s = list("A" * L); s[3] = "C"; s[50] = "G"; s[L - 1] = "T"; out.append("".join(s))            # near poly-A (3 others)
+    s = list("A" * L); s[3] = "C"; s[50 if L > 51 else L // 2] = "G"; s[L - 1] = "T"; out.append("".join(s))   # near poly-A (3 others)
     s = list("T" * L); s[0] = "C"; s[7] = "N"; s[L - 2] = "G"; s[20] = "A"; out.append("".join(s))  # near poly-T with N (4 others)
     s = list("N" * L); s[1] = "C"; s[2] = "G"; out.append("".join(s))                              # near poly-N
     s = list(rnd(L)); nn = int(0.4 * L)
@@ -52,7 +52,7 @@ def special_reads(L, rng):
     s = list(("AT" * L)[:L]); out.append("".join(s))                                               # palindromic k-mers (even k)
     s = list(("ACGT" * L)[:L]); out.append("".join(s))
     s = list("A" * L)
-    for i in range(5): s[10 * i + 1] = "C"
+    for i in range(5): s[(10 if L > 41 else L // 10) * i + 1] = "C"
     out.append("".join(s))                                                                          # 5 others: not near poly-A
     base = rnd(L)
     out.append(base); out.append(base)                                                              # exact duplicates
@@ -217,3 +217,4 @@ if __name__ == "__main__":
         make_stages("L100", 100, 1001, 3000)
         make_stages("L150", 150, 1002, 2000)
     make_stages("L100", 100, 1003, 1500, k=24, tag="stages_L100_k24")
+    make_stages("L40", 40, 1004, 2500)                       # short reads: k = 17, w = 3, L/11 dictionaries

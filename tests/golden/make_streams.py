@@ -50,7 +50,11 @@ def make(tag, variant, prefix="streams_", paired=False):
 
 
 if __name__ == "__main__":
+    if "--only-L40" in sys.argv:
+        make("stages_L40", "L40")                                     # short reads: k = 17, w = 3
+        sys.exit(0)
     make("stages_L100", "L100")
     make("stages_L150", "L150")
     make("stages_L100", "L100_order", prefix="streams_order_")       # -p: the order-preserving file set (ids streams)
     make("stages_L100", "L100_pe", prefix="streams_pe_", paired=True)  # paired end: pairing streams
+    make("stages_L40", "L40")

@@ -65,3 +65,24 @@ def test_last_pass_without_appends_still_sorts_the_appends_before_it():
     for (r0, m0), (r1, m1) in zip(o.contigs(), p.contigs()):
         assert r0 == r1 and np.array_equal(m0, m1)
     p.close(); o.close()
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _cases()])
+@pytest.mark.parametrize("order", [False, True])
+def test_stream_round_trip_at_the_edges(tmp_path, name, order):
+    """cluster_dump + decompress give the reads back (as a multiset, or in input order with -p) for every edge input."""
+    from minicom_amd.pipeline import Pipeline, decompress
+    reads = dict(_cases())[name]
+    n, L = reads.shape
+    p = Pipeline(reads, host_threads=2); p.pre_process()
+    d = tmp_path / "s"; d.mkdir()
+    p.cluster_dump(str(d), order=order)
+    p.close()
+    out = tmp_path / "reads.txt"
+    assert decompress(str(d), str(out), order=order) == n
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(n, L + 1)[:, :L]
+    if order:
+        assert np.array_equal(got, reads)
+    else:
+        a = np.sort(np.ascontiguousarray(got).view("S%d" % L).ravel()); b = np.sort(np.ascontiguousarray(reads).view("S%d" % L).ravel())
+        assert np.array_equal(a, b)

@@ -24,7 +24,7 @@ def _first_diff(got, want):
     return f"length differs: {len(gl)} vs {len(wl)} lines"
 
 
-@pytest.mark.parametrize("tag,k,threads", [("stages_L100", 0, 1), ("stages_L150", 0, 4), ("stages_L100_k24", 24, 2)])
+@pytest.mark.parametrize("tag,k,threads", [("stages_L100", 0, 1), ("stages_L150", 0, 4), ("stages_L100_k24", 24, 2), ("stages_L40", 0, 2)])
 def test_pipeline_stage_dumps_equal_reference(golden_dir, tmp_path, tag, k, threads):
     from minicom_amd.pipeline import Pipeline
     reads = _golden_reads(golden_dir, tag)

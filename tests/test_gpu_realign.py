@@ -124,7 +124,7 @@ def _check_dicts(ctx, dicts, sgbits, L):
                 assert int(c[q]) == 0
 
 
-@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150", "stages_L40"])
 def test_every_realign_pass_matches_sequential_reference_semantics(ctx, golden_dir, tag):
     """All passes of Stage 2 on the reference fixture reads: flags and the members appended to every contig,
     in order, equal the sequential scan (itself byte-identical to the reference dump)."""

@@ -63,7 +63,7 @@ def test_encode_byte_matches_reference(kat):
     assert seen == {0, 1}
 
 
-@pytest.mark.parametrize("tag,k", [("stages_L100", 0), ("stages_L150", 0), ("stages_L100_k24", 24)])
+@pytest.mark.parametrize("tag,k", [("stages_L100", 0), ("stages_L150", 0), ("stages_L100_k24", 24), ("stages_L40", 0)])
 def test_all_stages_match_reference_dump(golden_dir, tmp_path, tag, k):
     """Whole hot path (reads -> buckets -> contigs -> merged contigs -> every realign pass): the
     oracle's state after each stage must equal the reference's, byte for byte."""

@@ -20,7 +20,7 @@ def _golden_streams(golden_dir, tag):
         return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
 
 
-@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150", "stages_L40"])
 def test_our_decoder_inverts_the_reference_streams(golden_dir, tmp_path, tag):
     """CPU: the decoder (minicom_amd/host/mcom_decompress.cpp) applied to streams written by the reference itself."""
     from minicom_amd.pipeline import decompress
@@ -36,7 +36,7 @@ def test_our_decoder_inverts_the_reference_streams(golden_dir, tmp_path, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150", "stages_L40"])
 def test_stream_files_byte_identical_to_reference_and_lossless(golden_dir, tmp_path, tag):
     from minicom_amd.pipeline import Pipeline, decompress
     rows = _golden_reads(golden_dir, tag)
