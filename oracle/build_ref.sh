@@ -28,7 +28,8 @@ build_variant() {   # name readlen extra_defines...
     echo "#define num_thr ${NUM_THR:-1}"
     echo "#define uniqid \"uref\""
     echo "#define output \"output_ref/\""
-    for m in inik inithr inimaxthr inistep ininumdict iniw inim inicbthr inimaxrounds; do echo "#define $m 0"; done
+    for m in inik inithr inimaxthr inistep iniw inim inicbthr inimaxrounds; do echo "#define $m 0"; done
+    echo "#define ininumdict ${ININUMDICT:-0}"       # -s is compiled in (kthread_hash_realign.c:153); the others reach refdump as arguments
   } > "$d/config.h"
   local defs=""
   for x in "$@"; do defs="$defs -D$x"; done
@@ -57,6 +58,7 @@ build_variant() {   # name readlen extra_defines...
 build_variant L100 100
 build_variant L150 150
 build_variant L40 40
+ININUMDICT=4 build_variant L100_s4 100
 build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE
 # multi-threaded builds, used only as the CPU baseline of bench.py (their output is not reproducible run to run)

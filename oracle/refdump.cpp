@@ -108,16 +108,25 @@ static void dump_buckets(const char *name, cluster_bucket_t *B, int nb)
 // State after each stage of the reference's Stage 1 + Stage 2 at one thread.  The call sequence is
 // the one the reference's own driver performs (preprocess.c:141-233); every compute call below is a
 // reference function.
-static void do_stages(const char *fn, int k_override)
+/* non-default parameters, set the way the reference's main() sets them from config.h (minicommain.c:112-143);
+ * the number of dictionaries (-s) is a compile-time macro of kthread_hash_realign.c:153: it needs its own build variant */
+struct StageParams { int k, e, m, w, g, R, S, E; };
+
+static void do_stages(const char *fn, const StageParams &sp)
 {
 	n_threads = 1;
 	int k = readlen < 80 ? 17 : 31;
-	if (k_override > 0) k = k_override;
-	cbthreshold = 2 * diff_threshold;
+	if (sp.k > 0) k = sp.k;
+	if (sp.e > 0) diff_threshold = sp.e;
+	if (sp.m > 0) first_mininum = sp.m;
+	cbthreshold = sp.g > 0 ? sp.g : 2 * diff_threshold;
+	if (sp.R > 0 && sp.R < max_rounds) max_rounds = sp.R;
 	thr_step = diff_threshold;
+	if (sp.S > 0) thr_step = sp.S; else if (thr_step > 10) thr_step = 5;
 	maxthr = readlen / 2;
+	if (sp.E > 0) maxthr = sp.E;
 	maxmatch = readlen / 2;
-	rw = 0;
+	rw = sp.w;
 	int b = 14;
 
 	bseq_file_t *fp = bseq_open(fn);
@@ -128,6 +137,7 @@ static void do_stages(const char *fn, int k_override)
 	bseq_close(fp);
 	reads->f = 0; reads->k = k; reads->b = b;
 	reads->rw = readlen >= 70 ? readlen / 2 - k : 3;
+	if (sp.w > 0) reads->rw = sp.w;                                      /* preprocess.c:105-107 */
 	reads->B = (cluster_bucket_t**)calloc(2, sizeof(cluster_bucket_t*));
 	reads->B[0] = (cluster_bucket_t*)calloc(1 << b, sizeof(cluster_bucket_t));
 	reads->B[1] = (cluster_bucket_t*)calloc(1 << b, sizeof(cluster_bucket_t));
@@ -225,7 +235,20 @@ static void do_stages(const char *fn, int k_override)
 int main(int argc, char **argv)
 {
 	if (argc >= 2 && !strcmp(argv[1], "kat")) { do_kat(); return 0; }
-	if (argc >= 3 && !strcmp(argv[1], "stages")) { do_stages(argv[2], argc >= 4 ? atoi(argv[3]) : 0); return 0; }
-	fprintf(stderr, "usage: refdump kat | refdump stages IN.fastq [k]\n");
+	if (argc >= 3 && !strcmp(argv[1], "stages")) {
+		StageParams sp = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int i = 3; i < argc; ++i) {
+			const char *a = argv[i];
+			if (a[0] && a[1] == '=') {
+				const int v = atoi(a + 2);
+				switch (a[0]) { case 'k': sp.k = v; break; case 'e': sp.e = v; break; case 'm': sp.m = v; break; case 'w': sp.w = v; break;
+				                case 'g': sp.g = v; break; case 'R': sp.R = v; break; case 'S': sp.S = v; break; case 'E': sp.E = v; break;
+				                default: fprintf(stderr, "unknown parameter %s\n", a); return 2; }
+			} else sp.k = atoi(a);
+		}
+		do_stages(argv[2], sp);
+		return 0;
+	}
+	fprintf(stderr, "usage: refdump kat | refdump stages IN.fastq [k] [e=.. m=.. w=.. g=.. R=.. S=.. E=..]\n");
 	return 2;
 }

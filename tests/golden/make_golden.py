@@ -189,7 +189,7 @@ def make_kat():
     print("kat:", {k: len(v) for k, v in kat.items()})
 
 
-def make_stages(variant, L, seed, n, k=0, tag=None):
+def make_stages(variant, L, seed, n, k=0, tag=None, params=()):
     rng = np.random.default_rng(seed)
     r = synth.synth_reads(seed, n, L, plumbing=True)
     sp = special_reads(L, rng)
@@ -202,7 +202,7 @@ def make_stages(variant, L, seed, n, k=0, tag=None):
     fq = os.path.join("/tmp", tag + ".fastq")
     synth.write_fastq(fq, reads)
     exe = os.path.join(REF, variant, "refdump")
-    args = [exe, "stages", fq] + ([str(k)] if k else [])
+    args = [exe, "stages", fq] + ([str(k)] if k else []) + list(params)
     p = subprocess.run(args, stdout=subprocess.PIPE, check=True, cwd=os.path.join(REF, variant))
     with gzip.open(os.path.join(HERE, tag + ".reads.gz"), "wb") as f:
         f.write(b"\n".join(x.tobytes() for x in reads) + b"\n")
@@ -218,3 +218,5 @@ if __name__ == "__main__":
         make_stages("L150", 150, 1002, 2000)
     make_stages("L100", 100, 1003, 1500, k=24, tag="stages_L100_k24")
     make_stages("L40", 40, 1004, 2500)                       # short reads: k = 17, w = 3, L/11 dictionaries
+    # every tunable off its default at once: -e 6 -m 4 -w 12 -g 9 -R 3 -S 5 -E 30 -s 4 (the last compiled into the variant)
+    make_stages("L100_s4", 100, 1005, 2500, tag="stages_L100_params", params=("e=6", "m=4", "w=12", "g=9", "R=3", "S=5", "E=30"))

@@ -24,13 +24,17 @@ def _first_diff(got, want):
     return f"length differs: {len(gl)} vs {len(wl)} lines"
 
 
-@pytest.mark.parametrize("tag,k,threads", [("stages_L100", 0, 1), ("stages_L150", 0, 4), ("stages_L100_k24", 24, 2), ("stages_L40", 0, 2)])
-def test_pipeline_stage_dumps_equal_reference(golden_dir, tmp_path, tag, k, threads):
+NONDEFAULT = dict(e=6, m=4, w=12, cbthr=9, max_rounds=3, step=5, maxthr=30, numdict=4)   # tests/golden/make_golden.py
+
+
+@pytest.mark.parametrize("tag,params,threads", [("stages_L100", {}, 1), ("stages_L150", {}, 4), ("stages_L100_k24", dict(k=24), 2), ("stages_L40", {}, 2),
+                                                ("stages_L100_params", NONDEFAULT, 3)])
+def test_pipeline_stage_dumps_equal_reference(golden_dir, tmp_path, tag, params, threads):
     from minicom_amd.pipeline import Pipeline
     reads = _golden_reads(golden_dir, tag)
     with gzip.open(os.path.join(golden_dir, tag + ".dump.gz"), "rb") as f:
         want = f.read()
-    p = Pipeline(reads, k=k, host_threads=threads)
+    p = Pipeline(reads, host_threads=threads, **params)
     out = str(tmp_path / "dump.txt")
     p.dump_stages(out)
     got = open(out, "rb").read()

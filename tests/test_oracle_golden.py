@@ -63,8 +63,12 @@ def test_encode_byte_matches_reference(kat):
     assert seen == {0, 1}
 
 
-@pytest.mark.parametrize("tag,k", [("stages_L100", 0), ("stages_L150", 0), ("stages_L100_k24", 24), ("stages_L40", 0)])
-def test_all_stages_match_reference_dump(golden_dir, tmp_path, tag, k):
+NONDEFAULT = dict(e=6, m=4, w=12, cbthr=9, max_rounds=3, step=5, maxthr=30, numdict=4)   # tests/golden/make_golden.py
+
+
+@pytest.mark.parametrize("tag,params", [("stages_L100", {}), ("stages_L150", {}), ("stages_L100_k24", dict(k=24)), ("stages_L40", {}),
+                                        ("stages_L100_params", NONDEFAULT)])
+def test_all_stages_match_reference_dump(golden_dir, tmp_path, tag, params):
     """Whole hot path (reads -> buckets -> contigs -> merged contigs -> every realign pass): the
     oracle's state after each stage must equal the reference's, byte for byte."""
     with gzip.open(os.path.join(golden_dir, tag + ".reads.gz"), "rb") as f:
@@ -72,7 +76,7 @@ def test_all_stages_match_reference_dump(golden_dir, tmp_path, tag, k):
     reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0]))
     with gzip.open(os.path.join(golden_dir, tag + ".dump.gz"), "rb") as f:
         want = f.read()
-    p = oracle.Pipeline(reads, k=k)
+    p = oracle.Pipeline(reads, **params)
     out = str(tmp_path / "dump.txt")
     p.dump_stages(out)
     p.close()
