@@ -265,6 +265,17 @@ int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log
                              uint64_t *d_tuples, uint64_t cap, uint64_t *h_ntuples);
 int mcom_claims_patch(mcom_ctx *ctx, uint64_t *d_claim, const uint32_t *d_idx, const uint64_t *d_val, size_t n);
 
+/* The member lists after Stage 2 (csrc/finalize.hip).  The reference sorts a contig's members at the start of every
+ * scan (cmpcluster2, kthread_hash_realign.c:318) and appends behind them, so after m passes contig c holds
+ * stable_sort(C(c) + P_1(c) + ... + P_{m-1}(c)) + P_m(c); Stage 2 never reads the lists, so they are assembled once.
+ *   d_mem / d_moff [n_contigs + 1]: the lists before Stage 2;  d_app_contig[i] / d_app_member[i] (HOST arrays of device
+ *   pointers) and h_app_n[i]: what pass i appended, as mcom_claims_resolve returned it (a pass that appended nothing
+ *   still counts: n_passes is the number of scans);  key_bits: 2^key_bits - 1 exceeds every offset<<1|dir.
+ *   out: d_mem2 [n_members + sum h_app_n], d_moff2 [n_contigs + 1].  Synchronous.                                  */
+int mcom_members_finalize(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members,
+                          const uint32_t *const *d_app_contig, const uint64_t *const *d_app_member, const uint64_t *h_app_n,
+                          int n_passes, int key_bits, uint64_t *d_mem2, uint64_t *d_moff2);
+
 /* The members one pass appends, in the order the sequential scan appends them (claim key ascending, singleton
  * index descending: the bin is walked from its end, kthread_hash_realign.c:388, :408-409, :474-475).
  *   d_claim [n_sg] from mcom_realign_pass(_reads);  d_rids [n_sg] read id of every singleton

@@ -885,8 +885,10 @@ __global__ void k_bin_screen(const uint64_t *__restrict__ sgbits, size_t n_sg, i
 	if (sg >= n_sg) return;
 	const uint64_t key = bits_key(sgbits + sg * (size_t)W, g.ds[l], g.klen);
 	const uint64_t h = (key * 8 + (uint64_t)l + 1) * 0x9E3779B97F4A7C15ull;
-	const unsigned int old = atomicAdd(&table[h >> (64 - log2t)], 1u);
-	if (old + 1 > maxsearch) *exceeded = 1;
+	unsigned int *slot = &table[h >> (64 - log2t)];
+	const unsigned int seen = *(volatile unsigned int*)slot;                 // brings the line into L2: an atomic that misses costs several times one that hits
+	const unsigned int old = atomicAdd(slot, 1u);
+	if ((old > seen ? old : seen) + 1 > maxsearch) *exceeded = 1;
 }
 
 extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)

@@ -120,6 +120,11 @@ DevicePool &device_pool() { static DevicePool *pool = new DevicePool(); return *
 template <class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;            // cap in elements
 	size_t bytes_ = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf&) = delete;
+	DevBuf &operator=(const DevBuf&) = delete;
+	DevBuf(DevBuf &&o) noexcept { swap(o); }
+	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { device_pool().put(p, bytes_); p = nullptr; cap = 0; bytes_ = 0; swap(o); } return *this; }
 	~DevBuf() { device_pool().put(p, bytes_); }
 	void swap(DevBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(bytes_, o.bytes_); }
 	// reserve that keeps the first `keep` elements
@@ -196,18 +201,17 @@ struct mcomh_pipeline {
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
 	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
-	std::vector<uint8_t> unsorted;           // Stage 2: contigs whose member list changed since it was last sorted
-	// Stage 2 never reads the member lists, so the appends of the passes are kept aside (contig, member; in the
-	// reference's appending order) and folded into C by materialize() when somebody looks at the members.
-	struct Appended { PinVec<uint32_t> contig; PinVec<uint64_t> member; };
+	// Stage 2 never reads the member lists, so the appends of the passes stay on the device (contig, member; in the
+	// reference's appending order) and are folded into the lists by materialize() (mcom_members_finalize) when Stage 2 ends
+	// or somebody looks at the members.  A pass that appended nothing has an entry too: its scan sorted the contigs.
+	struct Appended { DevBuf<uint32_t> contig; DevBuf<uint64_t> member; size_t n = 0; };
 	std::vector<Appended> pend;
 	size_t n_pending = 0;
-	DevSet dC;                               // the contig set while it lives on the device (bucket stage -> combine_cluster)
-	bool dC_valid = false, hostC_valid = true;
-	hipStream_t copy_stream = nullptr;       // the final set of combine_cluster comes to the host beside Stage 2's GPU work
-	hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
-	bool copy_pending = false;
-	std::thread presort;                     // the sort at the start of a pass (:318), running beside the GPU work
+	// The contig set lives on the device from the bucket stage on (strings, members, offsets); the host gets the offsets
+	// when a stage needs them and everything when somebody asks for it (accessors, stage dumps, the stream writer).
+	DevSet dC;
+	bool dC_valid = false, hostC_valid = true, host_off_valid = true;
+	uint64_t maxlen = 0;                     // longest contig (bounds the member offsets)
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
@@ -234,7 +238,6 @@ struct mcomh_pipeline {
 };
 
 using P = mcomh_pipeline;
-static void join_presort(P *p);
 static int materialize(P *p);
 static int ensure_host_contigs(P *p, bool wait_data = true);
 static const char ACGT[] = "ACGT";
@@ -254,8 +257,6 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	P *p = new P();
 	p->stream = (hipStream_t)hip_stream;
 	int rc = mcom_create(&p->ctx, device, hip_stream);
-	if (!rc && (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) != hipSuccess ||
-	            hipEventCreateWithFlags(&p->ev_copied, hipEventDisableTiming) != hipSuccess)) rc = MCOM_E_HIP;
 	if (rc) { delete p; return rc; }
 	p->n = n; p->L = L; p->W = (2 * L + 63) / 64; p->NW = (L + 63) / 64;
 	p->k = pp->k > 0 ? pp->k : (L < 80 ? 17 : 31);                                  // minicommain.c:92-114
@@ -304,11 +305,7 @@ extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_s
 extern "C" void mcomh_destroy(mcomh_pipeline *p)
 {
 	if (!p) return;
-	join_presort(p);
 	(void)hipStreamSynchronize(p->stream);
-	if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
-	if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
-	if (p->ev_copied) (void)hipEventDestroy(p->ev_copied);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
 }
@@ -379,7 +376,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	// the contigs are built on the device (p->dC) and stay there for combine_cluster; the host copy is made on demand
 	p->C.clear();
 	p->dC.n = 0; p->dC.chars = 0; p->dC.members = 0; p->dC.nrec = 0;
-	p->dC_valid = true; p->hostC_valid = false;
+	p->dC_valid = true; p->hostC_valid = false; p->host_off_valid = false;
 	int last_rounds = 0; long pre = 0;
 	for (int r = 1;; ++r) {
 		if (p->k - r <= 9) ++last_rounds;                                           // :584-585
@@ -679,25 +676,11 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		if (std::labs(pre - tot) < 100) break;                                              // :625
 		pre = tot;
 	}
-	// the final set stays on the device for Stage 2; its copy for the member bookkeeping and the output stage travels on
-	// a second stream beside Stage 2's kernels (offsets first, they are needed at once)
-	{
-		const size_t n = A.n;
-		C.moff.assign(n + 1, 0); C.roff.assign(n + 1, 0);
-		if (!C.mem.resize(A.members) || !C.ref.resize(A.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
-		if (n) {
-			if ((rc = p->d2h(C.roff.data(), A.soff.p, n + 1, "copy offsets")) || (rc = p->d2h(C.moff.data(), A.moff.p, n + 1, "copy offsets")) || (rc = p->sync("copy offsets"))) return rc;
-			if ((rc = p->hipc(hipEventRecord(p->ev_ready, p->stream), "event")) || (rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_ready, 0), "event")) ||
-			    (rc = p->hipc(hipMemcpyAsync(C.mem.data(), A.mem.p, A.members * 8, hipMemcpyDeviceToHost, p->copy_stream), "copy members")) ||
-			    (rc = p->hipc(hipMemcpyAsync(C.ref.data(), A.seq.p, A.chars, hipMemcpyDeviceToHost, p->copy_stream), "copy contigs")) ||
-			    (rc = p->hipc(hipEventRecord(p->ev_copied, p->copy_stream), "event"))) return rc;
-			p->copy_pending = true;
-		}
-		p->dC.swap(A); p->dC_valid = true;
-		p->hostC_valid = true;                                                              // once the pending copy has landed
-		lap("t_cb_download");
-	}
-	p->unsorted.assign(p->C.n(), 1);
+	// the final set stays on the device, for Stage 2 and beyond; the host learns the offsets when Stage 2 asks for them
+	p->maxlen = maxlen;
+	p->dC.swap(A); p->dC_valid = true;
+	p->hostC_valid = false; p->host_off_valid = false;
+	lap("t_cb_download");
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -724,95 +707,49 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	return MCOM_OK;
 }
 
-static void join_presort(P *p) { if (p->presort.joinable()) p->presort.join(); }
-
-// the contig set of the bucket stage is built on the device; whoever wants it on the host (stage dumps, accessors,
-// a Stage 2 without combine_cluster) gets a copy here
+// The contig set is built and kept on the device; whoever wants it on the host (stage dumps, accessors, the stream
+// writer) gets a copy here.  wait_data = false: the offsets are enough (Stage 2 needs the contig lengths).
 static int ensure_host_contigs(P *p, bool wait_data)
 {
-	if (wait_data && p->copy_pending) {                     // offsets are there already, members and strings still travel
-		p->copy_pending = false;
-		if (hipEventSynchronize(p->ev_copied) != hipSuccess) return p->fail(MCOM_E_HIP, "copy of the contig set failed");
-	}
-	if (p->hostC_valid) return MCOM_OK;
+	if (p->hostC_valid || (!wait_data && p->host_off_valid)) return MCOM_OK;
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set");
 	DevSet &D = p->dC; ContigSet &C = p->C;
-	C.moff.assign(D.n + 1, 0); C.roff.assign(D.n + 1, 0);
-	if (!C.mem.resize(D.members) || !C.ref.resize(D.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
 	int rc;
-	if (D.n && ((rc = p->d2h((uint8_t*)C.ref.data(), D.seq.p, D.chars, "copy contigs")) || (rc = p->d2h(C.roff.data(), D.soff.p, D.n + 1, "copy offsets")) ||
-	            (rc = p->d2h(C.mem.data(), D.mem.p, D.members, "copy members")) || (rc = p->d2h(C.moff.data(), D.moff.p, D.n + 1, "copy offsets")) ||
+	if (!p->host_off_valid) {
+		C.moff.assign(D.n + 1, 0); C.roff.assign(D.n + 1, 0);
+		if (D.n && ((rc = p->d2h(C.roff.data(), D.soff.p, D.n + 1, "copy offsets")) || (rc = p->d2h(C.moff.data(), D.moff.p, D.n + 1, "copy offsets")) ||
+		            (rc = p->sync("copy offsets")))) return rc;
+		p->host_off_valid = true;
+	}
+	if (!wait_data) return MCOM_OK;
+	if (!C.mem.resize(D.members) || !C.ref.resize(D.chars)) return p->fail(MCOM_E_NOMEM, "contig set");
+	if (D.n && ((rc = p->d2h((uint8_t*)C.ref.data(), D.seq.p, D.chars, "copy contigs")) || (rc = p->d2h(C.mem.data(), D.mem.p, D.members, "copy members")) ||
 	            (rc = p->sync("copy contig set")))) return rc;
 	p->hostC_valid = true;
 	return MCOM_OK;
 }
 
-// Folds the pending appends of passes 1..m into the member lists.  The reference sorts a contig at the start of every
-// scan and appends behind it, so after m passes contig c holds
-//     stable_sort(C(c) + P_1(c) + ... + P_{m-1}(c)) + P_m(c)
-// (a stable sort of [sorted part + tail] = stable sort of the tail merged behind equal elements).
+// Folds the pending appends of passes 1..m into the member lists, on the device (mcom_members_finalize): the reference
+// sorts a contig at the start of every scan and appends behind it, so after m passes contig c holds
+//     stable_sort(C(c) + P_1(c) + ... + P_{m-1}(c)) + P_m(c).
 static int materialize(P *p)
 {
-	const double tj = now_ms();
-	join_presort(p);
-	{ const int rch = ensure_host_contigs(p); if (rch) return rch; }
 	const size_t m = p->pend.size();
 	if (!m) return MCOM_OK;
+	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set on the device");
 	const double t0 = now_ms();
-	p->stat["t_mat_join"] += t0 - tj;
-	ContigSet &C = p->C;
-	const size_t nc = C.n();
-	const int nt = p->host_threads;
-	std::vector<std::vector<uint64_t>> off(m);
-	{
-		std::vector<std::thread> th;
-		for (size_t i = 0; i < m; ++i)
-			th.emplace_back([&, i]() {
-				std::vector<uint64_t> &o = off[i];
-				o.assign(nc + 1, 0);
-				const P::Appended &a = p->pend[i];
-				for (size_t u = 0; u < a.contig.size(); ++u) ++o[(size_t)a.contig[u] + 1];
-				for (size_t c = 0; c < nc; ++c) o[c + 1] += o[c];
-			});
-		for (std::thread &t : th) t.join();
-	}
-	p->stat["t_mat_count"] += now_ms() - t0;
-	PinVec<uint64_t> &nmem = p->Cnext.mem; std::vector<uint64_t> &nmoff = p->Cnext.moff;       // spare buffers of the merge stage
-	if (!nmem.resize(C.mem.size() + p->n_pending)) return p->fail(MCOM_E_NOMEM, "member lists");
-	nmoff.resize(nc + 1);
-	parallel_for(nt, nc + 1, [&](int, size_t cb, size_t ce) {
-		for (size_t c = cb; c < ce; ++c) { uint64_t s = C.moff[c]; for (size_t i = 0; i < m; ++i) s += off[i][c]; nmoff[c] = s; }
-	});
-	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
-	parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
-		std::vector<uint64_t> tail;                                          // per thread: no allocation per contig
-		for (size_t c = cb; c < ce; ++c) {
-			uint64_t *dst = nmem.data() + nmoff[c];
-			const size_t n0 = C.msize(c);
-			const uint64_t *old = C.mem.data() + C.moff[c];
-			if (nmoff[c + 1] - nmoff[c] == n0) { memcpy(dst, old, n0 * 8); continue; }
-			tail.clear();
-			for (size_t i = 0; i + 1 < m; ++i) { const uint64_t *a = p->pend[i].member.data() + off[i][c]; tail.insert(tail.end(), a, a + (off[i][c + 1] - off[i][c])); }
-			size_t n1 = n0 + tail.size();
-			if (p->unsorted[c]) {                                             // only when no pass sorted it yet
-				memcpy(dst, old, n0 * 8); memcpy(dst + n0, tail.data(), tail.size() * 8);
-				std::stable_sort(dst, dst + n1, less_cluster2);
-			} else if (tail.empty()) memcpy(dst, old, n0 * 8);
-			else {
-				// stable sort of [sorted list + tail] = the tail, sorted stably, merged in behind equal elements
-				for (size_t i = 1; i < tail.size(); ++i) { const uint64_t v = tail[i]; size_t j = i; while (j > 0 && less_cluster2(v, tail[j - 1])) { tail[j] = tail[j - 1]; --j; } tail[j] = v; }
-				size_t i = 0, j = 0, o = 0;
-				while (i < n0 && j < tail.size()) dst[o++] = less_cluster2(tail[j], old[i]) ? tail[j++] : old[i++];
-				if (i < n0) memcpy(dst + o, old + i, (n0 - i) * 8);
-				else if (j < tail.size()) memcpy(dst + o, tail.data() + j, (tail.size() - j) * 8);
-			}
-			const size_t k = off[m - 1][c + 1] - off[m - 1][c];
-			if (k) memcpy(dst + n1, p->pend[m - 1].member.data() + off[m - 1][c], k * 8);
-			p->unsorted[c] = k ? 1 : 0;
-		}
-	});
-	C.mem.swap(nmem); C.moff.swap(nmoff);
+	DevSet &D = p->dC;
+	std::vector<const uint32_t*> ac(m); std::vector<const uint64_t*> am(m); std::vector<uint64_t> an(m);
+	for (size_t i = 0; i < m; ++i) { ac[i] = p->pend[i].contig.p; am[i] = p->pend[i].member.p; an[i] = p->pend[i].n; }
+	int kb = 2; while ((1ull << kb) < 4 * std::max<uint64_t>(p->maxlen, 2 * (uint64_t)p->L) + 4) ++kb;
+	DevBuf<uint64_t> mem2, moff2;
+	if (!mem2.reserve(D.members + p->n_pending + 1) || !moff2.reserve(D.n + 2)) return p->fail(MCOM_E_NOMEM, "member lists");
+	int rc = p->gpu(mcom_members_finalize(p->ctx, D.mem.p, D.moff.p, D.n, D.members, ac.data(), am.data(), an.data(), (int)m, kb, mem2.p, moff2.p));
+	if (rc) return rc;
+	D.mem.swap(mem2); D.moff.swap(moff2);
+	D.members += p->n_pending;
 	p->pend.clear(); p->n_pending = 0;
+	p->hostC_valid = false; p->host_off_valid = false;
 	p->stat["t_ra_materialize"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -924,7 +861,6 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	const int nt = p->host_threads;
 	{ const int rch = ensure_host_contigs(p, false); if (rch) return rch; }
 	mcomh_update_single(p);                                                                 // preprocess.c:203
 	ContigSet &C = p->C;
@@ -939,9 +875,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
 			if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
 			           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
-		} else {
-			if ((rc = ensure_host_contigs(p)) || (rc = upload_contigs(p, C))) return rc;
-		}
+		} else return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
 		std::vector<uint64_t> woff(nc + 1, 0);
 		for (size_t i = 0; i < nc; ++i) woff[i + 1] = woff[i] + (C.rsize(i) >= (size_t)p->L ? C.rsize(i) - p->L + 1 : 0);
 		p->n_windows = woff[nc];
@@ -960,22 +894,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	p->stat["t_ra_setup"] += now_ms() - t0;
 	p->stat["passes"] += 1;
 	p->stat["windows"] += (double)p->n_windows;
-	const double tr0 = now_ms();
-	// every contig is re-sorted at the start of its scan (:318); a stable sort of a sorted list is the identity,
-	// so only contigs that changed since their last sort are touched.  The scan itself never looks at the members:
-	// the sort runs beside the GPU work, and while appends are pending it is folded into materialize().
-	join_presort(p);
-	if (p->unsorted.size() != nc) p->unsorted.assign(nc, 1);
-	if (p->pend.empty())
-		p->presort = std::thread([p, nt, nc]() {
-			if (p->copy_pending) (void)hipEventSynchronize(p->ev_copied);     // the members are still on their way from the device
-			ContigSet &S = p->C;
-			parallel_for(nt, nc, [&](int, size_t cb, size_t ce) {
-				for (size_t c = cb; c < ce; ++c)
-					if (p->unsorted[c]) { std::stable_sort(S.mem.data() + S.moff[c], S.mem.data() + S.moff[c + 1], less_cluster2); p->unsorted[c] = 0; }
-			});
-		});
-	p->stat["t_ra_sort"] += now_ms() - tr0;
+	// every contig is re-sorted at the start of its scan (:318), but the scan itself never looks at the members: the sorts
+	// of all passes are folded into materialize()
 	if (n_sg) {
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
@@ -1020,14 +940,12 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if (rc) return rc;
 		// the appends in the order of the sequential scan (claim key ascending, singleton index descending, :388),
 		// resolved on the device; they stay pending until somebody needs the member lists
-		DevBuf<uint32_t> d_ac; DevBuf<uint64_t> d_am;
-		if (!d_ac.reserve(n_sg) || !d_am.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "claim buffers");
-		uint64_t nwon = 0;
-		if ((rc = p->gpu(mcom_claims_resolve(p->ctx, d_claim.p, d_sg.p, n_sg, (uint32_t)nc, d_flag.p, d_ac.p, d_am.p, &nwon)))) return rc;
 		P::Appended app;
-		if (!app.contig.resize(nwon) || !app.member.resize(nwon)) return p->fail(MCOM_E_NOMEM, "appended members");
+		if (!app.contig.reserve(n_sg) || !app.member.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+		uint64_t nwon = 0;
+		if ((rc = p->gpu(mcom_claims_resolve(p->ctx, d_claim.p, d_sg.p, n_sg, (uint32_t)nc, d_flag.p, app.contig.p, app.member.p, &nwon)))) return rc;
+		app.n = (size_t)nwon;
 		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
-		if (nwon && ((rc = p->d2h(app.contig.data(), d_ac.p, nwon, "copy appended members")) || (rc = p->d2h(app.member.data(), d_am.p, nwon, "copy appended members")))) return rc;
 		if ((rc = p->sync("realign pass"))) return rc;
 		p->stat["t_gpu"] += now_ms() - tg;
 		p->stat["t_ra_gpu"] += now_ms() - tg;
@@ -1047,7 +965,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		p->n_pending += nwon; p->pend.push_back(std::move(app));
 		p->stat["t_ra_append"] += now_ms() - tw0;
 	} else p->pend.emplace_back();
-	if (cluster_reads) *cluster_reads = (long)(C.mem.size() + p->n_pending);
+	if (cluster_reads) *cluster_reads = (long)(p->dC.members + p->n_pending);
 	p->stat["t_realign"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -1114,7 +1032,7 @@ static int run_stage2(P *p, FILE *f)
 			for (uint8_t v : p->sg_flag) fprintf(f, " %d", v ? 1 : 0);
 			fprintf(f, "\n");
 			dump_list(f, "fpA", p->fpA); dump_list(f, "fpT", p->fpT);
-			if ((rc = materialize(p))) return rc;
+			if ((rc = materialize(p)) || (rc = ensure_host_contigs(p))) return rc;
 			dump_contigs(f, "realign", p->C);
 		}
 		const long lim = (p->sg.size() > 1000000 && p->L >= 68) ? 10000 : 1000;
@@ -1200,8 +1118,9 @@ extern "C" const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_
 	if (len) *len = p->C.rsize(i);
 	return p->C.ref.data() + p->C.roff[i];                 // NOT NUL-terminated: use *len
 }
-extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { (void)materialize(const_cast<mcomh_pipeline*>(p)); return p->C.msize(i); }
-extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { (void)materialize(const_cast<mcomh_pipeline*>(p)); return p->C.mem.data() + p->C.moff[i]; }
+static int host_members(P *p) { const int rc = materialize(p); return rc ? rc : ensure_host_contigs(p); }
+extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { if (host_members(const_cast<mcomh_pipeline*>(p))) return 0; return p->C.msize(i); }
+extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { if (host_members(const_cast<mcomh_pipeline*>(p))) return nullptr; return p->C.mem.data() + p->C.moff[i]; }
 extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 {
 	const std::vector<uint32_t> *v = nullptr;
@@ -1276,7 +1195,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
-	{ const int rcm = materialize(p); if (rcm) return rcm; }
+	{ int rcm = materialize(p); if (!rcm) rcm = ensure_host_contigs(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
 	const size_t n = p->n;
 	int rc;
