@@ -212,6 +212,9 @@ struct mcomh_pipeline {
 	DevSet dC;
 	bool dC_valid = false, hostC_valid = true, host_off_valid = true;
 	uint64_t maxlen = 0;                     // longest contig (bounds the member offsets)
+	// the singleton list of the bucket stage is put together by a host thread beside combine_cluster's GPU work
+	std::thread sg_thread;
+	void join_sg() { if (sg_thread.joinable()) sg_thread.join(); }
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
@@ -305,6 +308,7 @@ extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_s
 extern "C" void mcomh_destroy(mcomh_pipeline *p)
 {
 	if (!p) return;
+	p->join_sg();
 	(void)hipStreamSynchronize(p->stream);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
@@ -371,7 +375,9 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
 	std::vector<uint32_t> resk;
-	PinVec<uint32_t> h_singles, h_sord, h_rej, h_rejg;
+	struct SgRound { PinVec<uint32_t> singles, sord, rej, rejg; size_t ns = 0, nrej = 0; bool last = false; };
+	std::vector<SgRound> sg_rounds;
+	size_t n_sg_total = p->sg.size();
 	DevBuf<uint32_t> d_rej, d_rejg;
 	// the contigs are built on the device (p->dC) and stay there for combine_cluster; the host copy is made on demand
 	p->C.clear();
@@ -413,27 +419,16 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			if (rc) return p->gpu(rc);
 			D.n += gc[0]; D.chars += gc[1]; D.members += gc[2];
 			const size_t nrej = gc[3];
-			h_singles.resize(ns); h_sord.resize(ns); h_rej.resize(nrej); h_rejg.resize(nrej);
-			if ((rc = p->d2h(h_singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(h_sord.data(), d_sord.p, ns, "copy")) ||
-			    (rc = p->d2h(h_rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(h_rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
+			SgRound R; R.ns = ns; R.nrej = nrej; R.last = last;
+			if (!R.singles.resize(ns) || !R.sord.resize(ns) || !R.rej.resize(nrej) || !R.rejg.resize(nrej)) return p->fail(MCOM_E_NOMEM, "round lists");
+			if ((rc = p->d2h(R.singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(R.sord.data(), d_sord.p, ns, "copy")) ||
+			    (rc = p->d2h(R.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(R.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["t_bk_gpu"] += now_ms() - tg;
-			const double tb2 = now_ms();
-			// singletons and rejects in the reference's visiting order (process_bucket, :398-505): a single whose ordinal
-			// is g was visited before group g
-			size_t si = 0;
-			auto singles_upto = [&](uint32_t g) {                                       // groups of one (:402-413)
-				size_t sj = si;
-				while (sj < ns && h_sord[sj] <= g) ++sj;
-				p->sg.insert(p->sg.end(), h_singles.data() + si, h_singles.data() + sj);
-				si = sj;
-			};
-			for (size_t u = 0; u < nrej; ++u) {
-				singles_upto(h_rejg[u]);
-				if (last) p->sg.push_back(h_rej[u]); else resk.push_back(h_rej[u]);
-			}
-			p->sg.insert(p->sg.end(), h_singles.data() + si, h_singles.data() + ns);
-			p->stat["t_bk_replay"] += now_ms() - tb2;
+			// the next round only needs the rejects; where singles and rejects go in the singleton list is settled later
+			if (!last) resk.assign(R.rej.data(), R.rej.data() + nrej);
+			n_sg_total += ns + (last ? nrej : 0);
+			sg_rounds.push_back(std::move(R));
 		}
 		p->stat["rounds"] += 1;
 		if (last_rounds) ++last_rounds;                                             // :594
@@ -454,9 +449,26 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			cur = d_cur.p;
 		}
 	}
-	if (p->sg.size() <= 5000000) p->maxsearch = 2000;                               // preprocess.c:169-172
+	// singletons and rejects in the reference's visiting order (process_bucket, :398-505): a single whose ordinal is g was
+	// visited before group g.  Nobody needs the list before Stage 2: a thread builds it beside combine_cluster.
+	p->join_sg();
+	p->sg_thread = std::thread([p, n_sg_total](std::vector<SgRound> rounds) {
+		p->sg.reserve(n_sg_total);
+		for (const SgRound &R : rounds) {
+			size_t si = 0;
+			for (size_t u = 0; u < R.nrej; ++u) {
+				size_t sj = si;
+				while (sj < R.ns && R.sord[sj] <= R.rejg[u]) ++sj;                   // groups of one (:402-413)
+				p->sg.insert(p->sg.end(), R.singles.data() + si, R.singles.data() + sj);
+				si = sj;
+				if (R.last) p->sg.push_back(R.rej[u]);
+			}
+			p->sg.insert(p->sg.end(), R.singles.data() + si, R.singles.data() + R.ns);
+		}
+	}, std::move(sg_rounds));
+	if (n_sg_total <= 5000000) p->maxsearch = 2000;                                 // preprocess.c:169-172
 	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
-	p->stat["n_sg0"] = (double)p->sg.size();
+	p->stat["n_sg0"] = (double)n_sg_total;
 	p->stat["t_bucket"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -681,6 +693,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->dC.swap(A); p->dC_valid = true;
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");
+	p->join_sg();
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -693,6 +706,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 extern "C" int mcomh_update_single(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
+	p->join_sg();
 	const size_t n = p->sg.size();
 	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); return MCOM_OK; }
 	// nothing flagged (the state after combine_cluster): nothing to compact; eight flags per test
@@ -861,6 +875,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
+	p->join_sg();
 	{ const int rch = ensure_host_contigs(p, false); if (rch) return rch; }
 	mcomh_update_single(p);                                                                 // preprocess.c:203
 	ContigSet &C = p->C;
@@ -1017,6 +1032,7 @@ static void dump_buckets(FILE *f, const char *name, const std::vector<mcom_mm128
 
 static int run_stage2(P *p, FILE *f)
 {
+	p->join_sg();
 	long pre = 0; int pass = 0;
 	for (int thr = p->e;; thr += p->step) {                                                 // preprocess.c:197-232
 		if (thr > p->maxthr) break;
@@ -1085,6 +1101,7 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 	if ((rc = mcomh_kt_for_bucket(p)) || (rc = ensure_host_contigs(p))) { fclose(f); return rc; }
 	fprintf(f, "STAGE bucket\n");
 	dump_contigs(f, "bucket", p->C);
+	p->join_sg();
 	dump_list(f, "sg", p->sg);
 	// the first-m minimizers the reference pushed into mi[0] while building the contigs (:458-474)
 	{
@@ -1123,6 +1140,7 @@ extern "C" size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i) { if (host_m
 extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i) { if (host_members(const_cast<mcomh_pipeline*>(p))) return nullptr; return p->C.mem.data() + p->C.moff[i]; }
 extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 {
+	const_cast<mcomh_pipeline*>(p)->join_sg();
 	const std::vector<uint32_t> *v = nullptr;
 	if (!strcmp(name, "allA")) v = &p->allA; else if (!strcmp(name, "allT")) v = &p->allT; else if (!strcmp(name, "allN")) v = &p->allN;
 	else if (!strcmp(name, "fpA")) v = &p->fpA; else if (!strcmp(name, "fpT")) v = &p->fpT; else if (!strcmp(name, "fpN")) v = &p->fpN;
@@ -1195,6 +1213,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
+	p->join_sg();
 	{ int rcm = materialize(p); if (!rcm) rcm = ensure_host_contigs(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
 	const size_t n = p->n;
