@@ -319,6 +319,10 @@ int mcom_scan_u64(mcom_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, size_t n
 /* packed layout of a set for mcom_pack_contigs: d_coff_words[n+1], d_clen[n], *h_total_words                 */
 int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, uint64_t *d_coff_words, uint32_t *d_clen,
                        uint64_t *h_total_words);
+/* Window offsets of a contig set for Stage 2: d_woff[c] = windows of L bases before contig c (a contig shorter than L
+ * has none, kthread_hash_realign.c:320), d_woff[n] = *h_n_windows; *h_maxlen (optional) = the longest contig.
+ * Synchronous.                                                                                                      */
+int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, int L, uint64_t *d_woff, uint64_t *h_n_windows, uint64_t *h_maxlen);
 /* Member lists of the nj claimed pairs (find_next :297-325): d_jobs = nj x {ci, cj, pos_ori, pos} (uint32);
  * the list of the contig whose anchor lies further right first, the other one shifted behind it, then in
  * cmpcluster2 order (stable, as construct_ref2's sort :107 with glibc's merge sort).  key_bits: every

@@ -114,6 +114,40 @@ extern "C" int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	return MCOM_OK;
 }
 
+// windows of L bases per contig (kthread_hash_realign.c:320: j < strlen(ref) - readlen + 1) and their running total
+__global__ void k_window_counts(const uint64_t *__restrict__ soff, size_t n, int L, uint64_t *__restrict__ nw, unsigned long long *__restrict__ maxlen)
+{
+	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > n) return;
+	if (c == n) { nw[c] = 0; return; }
+	const uint64_t len = soff[c + 1] - soff[c];
+	nw[c] = len >= (uint64_t)L ? len - (uint64_t)L + 1 : 0;
+	if (len > *maxlen) atomicMax(maxlen, (unsigned long long)len);           // filtered: a single address
+}
+
+extern "C" int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, int L, uint64_t *d_woff, uint64_t *h_n_windows, uint64_t *h_maxlen)
+{
+	if (!ctx || !h_n_windows) return MCOM_E_ARG;
+	*h_n_windows = 0;
+	if (h_maxlen) *h_maxlen = 0;
+	if (!d_woff || L < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad window layout arguments");
+	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_woff, 0, 8, ctx->stream)); return MCOM_OK; }
+	if (!d_soff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(n + 1) * 8) + 512);
+	if (rc) return rc;
+	unsigned long long *mx = (unsigned long long*)((char*)ctx->ws + al256(scan64_scratch_elems(n + 1) * 8));
+	MCOM_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+	hipLaunchKernelGGL(k_window_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, L, d_woff, mx);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan64(ctx, d_woff, d_woff, n + 1, (uint64_t*)ctx->ws))) return rc;
+	unsigned long long hm = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(h_n_windows, d_woff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&hm, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h_maxlen) *h_maxlen = hm;
+	return MCOM_OK;
+}
+
 // ---- member merge ------------------------------------------------------------------------------------------------
 struct Job { uint32_t ci, cj, pos_ori, pos; };
 

@@ -213,8 +213,10 @@ struct mcomh_pipeline {
 	bool dC_valid = false, hostC_valid = true, host_off_valid = true;
 	uint64_t maxlen = 0;                     // longest contig (bounds the member offsets)
 	// the singleton list of the bucket stage is put together by a host thread beside combine_cluster's GPU work
-	std::thread sg_thread;
-	void join_sg() { if (sg_thread.joinable()) sg_thread.join(); }
+	std::thread sg_thread, cls_thread;       // (and the class lists of kt_for_reads beside the bucket stage)
+	hipEvent_t ev_cls = nullptr; bool cls_failed = false;
+	void join_cls() { if (cls_thread.joinable()) cls_thread.join(); }
+	void join_sg() { join_cls(); if (sg_thread.joinable()) sg_thread.join(); }
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
@@ -310,6 +312,7 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (!p) return;
 	p->join_sg();
 	(void)hipStreamSynchronize(p->stream);
+	if (p->ev_cls) (void)hipEventDestroy(p->ev_cls);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
 }
@@ -338,25 +341,32 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 	}
 	if (rc) return rc;
 	if (!p->h_cls.resize(n + 8)) return p->fail(MCOM_E_NOMEM, "classes");
-	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->sync("kt_for_reads"))) return rc;
 	memset(p->h_cls.data() + n, 0, 8);
-	for (size_t r = 0; r < n; ++r) {                                              // one thread: rid order
-		if ((r & 7) == 0) {                                                       // nearly every read is class 0: skip eight at a time
-			uint64_t w8; memcpy(&w8, p->h_cls.data() + r, 8);
-			if (w8 == 0) { r += 7; continue; }
+	// the classes travel while the bucket stage starts; a thread sorts the special reads into their lists (rid order) once
+	// they have arrived -- nobody reads those lists before Stage 2
+	p->join_cls();
+	if (!p->ev_cls && (rc = p->hipc(hipEventCreateWithFlags(&p->ev_cls, hipEventDisableTiming), "event"))) return rc;
+	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->hipc(hipEventRecord(p->ev_cls, p->stream), "event"))) return rc;
+	p->cls_thread = std::thread([p, n]() {
+		if (hipEventSynchronize(p->ev_cls) != hipSuccess) { p->cls_failed = true; return; }
+		for (size_t r = 0; r < n; ++r) {
+			if ((r & 7) == 0) {                                                   // nearly every read is class 0: skip eight at a time
+				uint64_t w8; memcpy(&w8, p->h_cls.data() + r, 8);
+				if (w8 == 0) { r += 7; continue; }
+			}
+			switch (p->h_cls[r]) {
+			case MCOM_CLS_SKETCH: break;
+			case MCOM_CLS_ALLA: p->allA.push_back((uint32_t)r); break;
+			case MCOM_CLS_ALLT: p->allT.push_back((uint32_t)r); break;
+			case MCOM_CLS_ALLN: p->allN.push_back((uint32_t)r); break;
+			case MCOM_CLS_NEARA: p->fpA.push_back((uint32_t)r); break;
+			case MCOM_CLS_NEART: p->fpT.push_back((uint32_t)r); break;
+			case MCOM_CLS_NEARN: p->fpN.push_back((uint32_t)r); break;
+			case MCOM_CLS_NHEAVY: p->Nfile.push_back((uint32_t)r); break;
+			default: break;
+			}
 		}
-		switch (p->h_cls[r]) {
-		case MCOM_CLS_SKETCH: break;
-		case MCOM_CLS_ALLA: p->allA.push_back((uint32_t)r); break;
-		case MCOM_CLS_ALLT: p->allT.push_back((uint32_t)r); break;
-		case MCOM_CLS_ALLN: p->allN.push_back((uint32_t)r); break;
-		case MCOM_CLS_NEARA: p->fpA.push_back((uint32_t)r); break;
-		case MCOM_CLS_NEART: p->fpT.push_back((uint32_t)r); break;
-		case MCOM_CLS_NEARN: p->fpN.push_back((uint32_t)r); break;
-		case MCOM_CLS_NHEAVY: p->Nfile.push_back((uint32_t)r); break;
-		default: break;
-		}
-	}
+	});
 	p->stat["t_reads"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -714,9 +724,18 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	size_t i = 0;
 	for (; i + 8 <= n; i += 8) { uint64_t w8; memcpy(&w8, f + i, 8); if (w8) break; }
 	if (i + 8 > n) { while (i < n && !f[i]) ++i; if (i == n) return MCOM_OK; }
-	size_t nn = i;                                                       // the first flagged entry is at or behind i
-	for (; i < n; ++i) if (!f[i]) p->sg[nn++] = p->sg[i];
-	p->sg.resize(nn);
+	// the first flagged entry is at or behind i: compact [i, n) in chunks (count, then copy to each chunk's place)
+	const size_t head = i;
+	const int nt = std::max(1, std::min(p->host_threads, 16));
+	std::vector<size_t> cnt((size_t)nt + 1, 0);
+	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { size_t c = 0; for (size_t q = head + b; q < head + e; ++q) c += !f[q]; cnt[(size_t)t + 1] = c; });
+	for (int t = 0; t < nt; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
+	const size_t nn = head + cnt[(size_t)nt];
+	std::vector<uint32_t> out(nn);
+	memcpy(out.data(), p->sg.data(), head * 4);
+	const uint32_t *src = p->sg.data();
+	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { uint32_t *dst = out.data() + head + cnt[(size_t)t]; for (size_t q = head + b; q < head + e; ++q) if (!f[q]) *dst++ = src[q]; });
+	p->sg.swap(out);
 	p->sg_flag.assign(nn, 0);
 	return MCOM_OK;
 }
@@ -876,13 +895,12 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
 	p->join_sg();
-	{ const int rch = ensure_host_contigs(p, false); if (rch) return rch; }
+	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
 	mcomh_update_single(p);                                                                 // preprocess.c:203
-	ContigSet &C = p->C;
-	const size_t nc = C.n(), n_sg = p->sg.size();
+	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
-		if (p->dC_valid && p->dC.n == nc) {                   // the set is still on the device from combine_cluster: pack it there
+		{                                                      // the set is on the device: lay it out and pack it there
 			uint64_t tw = 0;
 			if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
 			if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
@@ -890,12 +908,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
 			if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
 			           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
-		} else return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
-		std::vector<uint64_t> woff(nc + 1, 0);
-		for (size_t i = 0; i < nc; ++i) woff[i + 1] = woff[i] + (C.rsize(i) >= (size_t)p->L ? C.rsize(i) - p->L + 1 : 0);
-		p->n_windows = woff[nc];
-		if (!p->d_woff.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "window offsets");
-		if ((rc = p->h2d(p->d_woff.p, woff.data(), nc + 1, "upload window offsets")) || (rc = p->sync("upload"))) return rc;
+		}
+		if (!p->d_woff.reserve(nc + 2)) return p->fail(MCOM_E_NOMEM, "window offsets");
+		uint64_t nwin = 0, mlen = 0;
+		if ((rc = p->gpu(mcom_window_layout(p->ctx, p->dC.soff.p, nc, p->L, p->d_woff.p, &nwin, &mlen)))) return rc;
+		p->n_windows = nwin; p->maxlen = std::max(p->maxlen, mlen);
 		if (!p->window_scan) {
 			uint64_t ne = 0;
 			if (mcom_cindex_plan(p->n_windows, (uint32_t)nc, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
@@ -1068,6 +1085,7 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 	if (!f) return p->fail(MCOM_E_ARG, "cannot write %s", path);
 	int rc = mcomh_kt_for_reads(p);
 	if (rc) { fclose(f); return rc; }
+	p->join_cls();
 	const int L = p->L, W = p->W;
 	fprintf(f, "PARAMS L %d k %d b %d rw %d e %d cbthr %d m %d n %zu\n", L, p->k, NB_BITS, p->rw, p->e, p->cbthr, p->m, p->n);
 	fprintf(f, "STAGE reads\nREADS %zu\n", p->n);
