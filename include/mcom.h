@@ -323,6 +323,9 @@ int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, uint64_t
  * has none, kthread_hash_realign.c:320), d_woff[n] = *h_n_windows; *h_maxlen (optional) = the longest contig.
  * Synchronous.                                                                                                      */
 int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, int L, uint64_t *d_woff, uint64_t *h_n_windows, uint64_t *h_maxlen);
+/* updateSingle (preprocess.c:243-255) on the device: d_out = the ids whose flag is zero, in order; *h_n_out their number.
+ * Synchronous.                                                                                                      */
+int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_flag, size_t n, uint32_t *d_out, uint64_t *h_n_out);
 /* Member lists of the nj claimed pairs (find_next :297-325): d_jobs = nj x {ci, cj, pos_ori, pos} (uint32);
  * the list of the contig whose anchor lies further right first, the other one shifted behind it, then in
  * cmpcluster2 order (stable, as construct_ref2's sort :107 with glibc's merge sort).  key_bits: every

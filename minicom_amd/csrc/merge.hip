@@ -350,6 +350,42 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	return MCOM_OK;
 }
 
+// ---- updateSingle on the device: the ids whose flag is zero, in order (preprocess.c:243-255) ----------------------------
+__global__ void k_live_flags(const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ kf)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n) kf[i] = (i < n && !flag[i]) ? 1u : 0u;
+}
+__global__ void k_live_scatter(const uint32_t *__restrict__ ids, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ at, size_t n, uint32_t *__restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && !flag[i]) out[at[i]] = ids[i];
+}
+
+extern "C" int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_flag, size_t n, uint32_t *d_out, uint64_t *h_n_out)
+{
+	if (!ctx || !h_n_out) return MCOM_E_ARG;
+	*h_n_out = 0;
+	if (n == 0) return MCOM_OK;
+	if (!d_ids || !d_flag || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many ids");
+	int rc = mcom_ws_reserve(ctx, al256((n + 1) * 4) + al256(mcom_scan_scratch_elems(n + 1) * 4 + 1024) + 256);
+	if (rc) return rc;
+	WsCut w{(char*)ctx->ws, 0};
+	uint32_t *at = w.take<uint32_t>(n + 1);
+	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(n + 1) + 256);
+	hipLaunchKernelGGL(k_live_flags, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_flag, n, at);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_scan_u32(ctx, at, at, n + 1, scr))) return rc;
+	hipLaunchKernelGGL(k_live_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, at, n, d_out);
+	MCOM_LAUNCH_CHECK(ctx);
+	uint32_t cnt = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&cnt, at + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*h_n_out = cnt;
+	return MCOM_OK;
+}
+
 // ---- untouched contigs ------------------------------------------------------------------------------------------------
 __global__ void k_keep_flags(const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ kf)
 {

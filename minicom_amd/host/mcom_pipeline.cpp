@@ -212,6 +212,10 @@ struct mcomh_pipeline {
 	DevSet dC;
 	bool dC_valid = false, hostC_valid = true, host_off_valid = true;
 	uint64_t maxlen = 0;                     // longest contig (bounds the member offsets)
+	// updateSingle (preprocess.c:243-255) happens on the device at the end of a pass: the next pass finds its singleton ids
+	// in d_sg_live, the host its compacted list in sg_next
+	DevBuf<uint32_t> d_sg_live; size_t n_sg_live = 0; bool sg_live_valid = false;
+	std::vector<uint32_t> sg_next; bool sg_next_valid = false;
 	// the singleton list of the bucket stage is put together by a host thread beside combine_cluster's GPU work
 	std::thread sg_thread, cls_thread;       // (and the class lists of kt_for_reads beside the bucket stage)
 	hipEvent_t ev_cls = nullptr; bool cls_failed = false;
@@ -717,6 +721,12 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	p->join_sg();
+	if (p->sg_next_valid) {                                             // compacted on the device when the pass ended
+		p->sg.swap(p->sg_next); p->sg_next_valid = false;
+		p->sg_flag.assign(p->sg.size(), 0);
+		return MCOM_OK;
+	}
+	p->sg_live_valid = false;
 	const size_t n = p->sg.size();
 	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); return MCOM_OK; }
 	// nothing flagged (the state after combine_cluster): nothing to compact; eight flags per test
@@ -896,7 +906,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	const double t0 = now_ms();
 	p->join_sg();
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
-	mcomh_update_single(p);                                                                 // preprocess.c:203
+	{ const double tu = now_ms(); mcomh_update_single(p); p->stat["t_ra_update"] += now_ms() - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
@@ -932,7 +942,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
 		if (!d_sg.reserve(n_sg) || !d_sgbits.reserve(n_sg * p->W) || !d_claim.reserve(n_sg) || !d_flag.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
-		if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
+		if (p->sg_live_valid && p->n_sg_live == n_sg) { d_sg.swap(p->d_sg_live); p->sg_live_valid = false; }      // left by the pass before
+		else if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
 		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
 		PinVec<uint8_t> pf;
@@ -978,6 +989,14 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->gpu(mcom_claims_resolve(p->ctx, d_claim.p, d_sg.p, n_sg, (uint32_t)nc, d_flag.p, app.contig.p, app.member.p, &nwon)))) return rc;
 		app.n = (size_t)nwon;
 		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
+		{                                                                                    // updateSingle for the next pass, on the device
+			uint64_t n_next = 0;
+			if (!p->d_sg_live.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton ids");
+			if ((rc = p->gpu(mcom_compact_live(p->ctx, d_sg.p, d_flag.p, n_sg, p->d_sg_live.p, &n_next)))) return rc;
+			p->sg_next.resize((size_t)n_next);
+			if ((rc = p->d2h(p->sg_next.data(), p->d_sg_live.p, (size_t)n_next, "copy live singletons"))) return rc;
+			p->n_sg_live = (size_t)n_next; p->sg_live_valid = true; p->sg_next_valid = true;
+		}
 		if ((rc = p->sync("realign pass"))) return rc;
 		p->stat["t_gpu"] += now_ms() - tg;
 		p->stat["t_ra_gpu"] += now_ms() - tg;
