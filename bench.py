@@ -82,8 +82,8 @@ def algorithmic_bytes(name, st, L, nd):
 
 # HBM traffic per kernel class from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs
 # of this same command at the default workload; kernels cannot be counted while bench.py itself is timing them)
-PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_pmc_traffic_100m.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_contigs"], "cindex_build": ["k_cindex_insert"], "realign_reads": ["k_realign_reads<5, 16>"],
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_f_pmc_traffic_100m.json")
+PMC_KERNELS = {"sketch_contigs": ["k_sketch_contigs"], "cindex_build": ["k_cindex_insert"], "realign_reads": ["k_realign_reads<5, 16, false>"],
                "classify_pack": ["k_classify_pack<32>"], "sketch_reads": ["k_sketch_reads<5, true>"]}
 
 
@@ -199,13 +199,14 @@ def main():
                 default_workload = n_local == 100_000_000 and L == 150
                 roof = {"kernel": cand, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(cand) if default_workload else None,
-                        "traffic_source": "profiles/r01_e_pmc_traffic_100m.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None,
+                        "traffic_source": "profiles/r01_f_pmc_traffic_100m.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None,
                         "launches": int(calls),
                         "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
                         "device_ms_per_step_by_kernel": {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in names}}
                 if cand == "sketch_contigs":
-                    roof["note"] = ("integer VALU / LDS-latency bound (PMC: 23 % of wave cycles issuing, 59 % parked): 1 byte in and 0.07 records out per "
-                                    "position against ~500 lane-instructions of hashing and window minima; the HBM fraction is small by construction")
+                    roof["note"] = ("integer VALU bound (PMC profiles/r01_f_pmc_sq_32m.txt: about a third of the wave cycles issuing, a third waiting "
+                                    "for an issue slot): 1 byte in and 0.07 records out per position against ~35 wave instructions of hashing "
+                                    "and window minima; the HBM fraction is small by construction")
                 # the heaviest kernel that IS bound by HBM (random 64-B sectors), for comparison
                 bh = algorithmic_bytes("cindex_build", st, L, nd)
                 if bh and agg.get("ms_cindex_build", 0.0) > 0:
