@@ -714,25 +714,26 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 // walks each contig's candidates in this order and takes the first whose partner is still free.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ q, size_t nq,
-                            uint32_t *__restrict__ hits)
+                            uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
 	uint32_t s = 0, c = 0;
 	if (q[i].x != U64MAX) mcom_table_find(slots, log2cap, q[i].x, s, c);
-	hits[i] = c;
+	hits[i] = c; first[i] = s;                     // the later passes read these instead of probing the table again
 }
 // one thread per query: walks its hits, tests, writes a pass flag per (query, hit) pair at pair_off[q] + k
-__global__ void k_fn_eval(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ irec,
+__global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
                           const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
                           const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
                           int cbthr, uint32_t *__restrict__ pass)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
+	const uint32_t p0 = pair_off[i], c = pair_off[i + 1] - p0;
+	if (!c) return;
+	const uint32_t s = first[i];
 	const mcom_mm128 m = q[i];
-	uint32_t s = 0, c = 0;
-	if (m.x == U64MAX || !mcom_table_find(slots, log2cap, m.x, s, c)) return;
 	const uint32_t rid_ori = (uint32_t)(m.y >> 32), pos_ori = (uint32_t)m.y >> 1, dir_ori = (uint32_t)(m.y & 1);
 	const uint32_t ci = rid_ori >> 8;
 	for (uint32_t u = 0; u < c; ++u) {
@@ -744,23 +745,24 @@ __global__ void k_fn_eval(const uint64_t *__restrict__ slots, uint32_t log2cap, 
 			const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
 			ok = mis <= (uint32_t)cbthr;
 		}
-		pass[pair_off[i] + u] = ok;
+		pass[p0 + u] = ok;
 	}
 }
-__global__ void k_fn_emit(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ irec,
+__global__ void k_fn_emit(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
                           const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
                           const uint32_t *__restrict__ pass_pre, uint32_t n_pairs, uint32_t last_flag,
                           mcom_mm128 *__restrict__ out)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
-	const mcom_mm128 m = q[i];
-	uint32_t s = 0, c = 0;
-	if (m.x == U64MAX || !mcom_table_find(slots, log2cap, m.x, s, c)) return;
+	const uint32_t p0 = pair_off[i], c = pair_off[i + 1] - p0;
+	if (!c) return;
+	const uint32_t s = first[i];
+	const uint64_t my = q[i].y;
 	for (uint32_t u = 0; u < c; ++u) {
-		const uint32_t p = pair_off[i] + u;
+		const uint32_t p = p0 + u;
 		const uint32_t here = pass_pre[p], nxt = (p + 1 < n_pairs) ? pass_pre[p + 1] : pass_pre[p] + last_flag;
-		if (nxt != here) { mcom_mm128 v; v.x = m.y; v.y = irec[s + u].y; out[here] = v; }   // x = query y (contig i, pos_ori, dir), y = hit y
+		if (nxt != here) { mcom_mm128 v; v.x = my; v.y = irec[s + u].y; out[here] = v; }   // x = query y (contig i, pos_ori, dir), y = hit y
 	}
 }
 
@@ -780,8 +782,11 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	int rc = mcom_ws_reserve(ctx, hit_b + scr1_b);
 	if (rc) return rc;
 	uint32_t *hits = (uint32_t*)ctx->ws;
+	uint32_t *first = nullptr;
+	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
+	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
-	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_query, n_query, hits);
+	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
@@ -804,7 +809,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	rc = mcom_ws_reserve(ctx, scr2_b);
 	if (rc) { cleanup(); return rc; }
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
-	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
+	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
 	uint32_t last_flag = 0, n_pass = 0;
 	e1 = hipMemcpyAsync(&last_flag, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
 	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
@@ -819,7 +824,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
-		hipLaunchKernelGGL(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
+		hipLaunchKernelGGL(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
 		e1 = hipStreamSynchronize(ctx->stream);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}
