@@ -107,6 +107,10 @@ def load_library():
     L.mcom_contigs_carry.restype = i32; L.mcom_contigs_carry.argtypes = [vp, vp, vp, vp, vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, C.POINTER(u64)]
     L.mcom_resketch_merged.restype = i32
     L.mcom_resketch_merged.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, u64, i32, i32, vp, vp, sz, C.POINTER(u64), C.POINTER(u64)]
+    L.mcom_members_finalize.restype = i32
+    L.mcom_members_finalize.argtypes = [vp, vp, vp, sz, u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), i32, i32, vp, vp]
+    L.mcom_compact_live.restype = i32; L.mcom_compact_live.argtypes = [vp, vp, vp, sz, vp, C.POINTER(u64)]
+    L.mcom_window_layout.restype = i32; L.mcom_window_layout.argtypes = [vp, vp, sz, i32, vp, C.POINTER(u64), C.POINTER(u64)]
     L.mcom_records_carry.restype = i32; L.mcom_records_carry.argtypes = [vp, vp, vp, vp, sz, u32, u32, vp, sz, vp, C.POINTER(u64)]
     L.mcom_claim_pairs.restype = i32
     L.mcom_claim_pairs.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(u64), C.POINTER(i32)]
@@ -431,6 +435,40 @@ class Context:
                                                 self._p(flag, torch.uint8), nj, nkeep, self._p(seq2), self._p(soff2, torch.int64), self._p(mem2, torch.int64),
                                                 self._p(moff2, torch.int64), self._p(keepidx), tot))
         return keepidx[:nkeep], (int(tot[0]), int(tot[1]))
+
+    def members_finalize(self, mem, moff, passes, key_bits: int):
+        """mcom_members_finalize.  mem int64 [M], moff int64 [n+1]; passes: list of (contig int32 [k], member int64 [k]).
+        Returns (mem2 int64, moff2 int64 [n+1])."""
+        torch = _torch()
+        n = int(moff.shape[0]) - 1
+        m = len(passes)
+        total = int(mem.shape[0]) + sum(int(c.shape[0]) for c, _ in passes)
+        mem2 = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        moff2 = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        ac = (C.c_void_p * max(m, 1))(*[self._p(c, torch.int32).value if c.shape[0] else None for c, _ in passes])
+        am = (C.c_void_p * max(m, 1))(*[self._p(v, torch.int64).value if v.shape[0] else None for _, v in passes])
+        an = (C.c_uint64 * max(m, 1))(*[int(c.shape[0]) for c, _ in passes])
+        self._check(self.lib.mcom_members_finalize(self._h, self._p(mem, torch.int64), self._p(moff, torch.int64), n, int(mem.shape[0]), ac, am, an, m, key_bits,
+                                                   self._p(mem2), self._p(moff2)))
+        return mem2[:total], moff2
+
+    def compact_live(self, ids, flag):
+        """mcom_compact_live: the ids whose flag is zero, in order."""
+        torch = _torch()
+        n = int(ids.shape[0])
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        cnt = C.c_uint64()
+        self._check(self.lib.mcom_compact_live(self._h, self._p(ids, torch.int32), self._p(flag, torch.uint8), n, self._p(out), C.byref(cnt)))
+        return out[: int(cnt.value)]
+
+    def window_layout(self, soff, L: int):
+        """mcom_window_layout.  Returns (woff int64 [n+1], n_windows, longest contig)."""
+        torch = _torch()
+        n = int(soff.shape[0]) - 1
+        woff = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        nw, ml = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.mcom_window_layout(self._h, self._p(soff, torch.int64), n, L, self._p(woff), C.byref(nw), C.byref(ml)))
+        return woff, int(nw.value), int(ml.value)
 
     def records_carry(self, rec, roff, keepidx, first_id: int, base: int, rec2, roff2):
         torch = _torch()

@@ -254,3 +254,54 @@ def test_merge_round_pieces_against_numpy(ctx):
         assert ro2[nj + u] == at and np.array_equal(r2[at:at + len(seg)], seg), u
         at += len(seg)
     assert ro2[nn] == at == total
+
+
+def test_members_finalize_equals_the_sort_and_append_of_every_pass(ctx):
+    """mcom_members_finalize against a numpy restatement of what m Stage-2 passes leave in a contig: the reference
+    sorts the members at the start of each scan (stable, by offset then direction, kthread_hash_realign.c:318) and
+    appends behind them; a pass that appends nothing still sorts."""
+    import torch
+    rng = np.random.default_rng(11)
+    nc, kb = 3000, 12
+    sizes = rng.integers(0, 40, nc)
+    sizes[:5] = 0
+    moff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    def members(k):
+        rid = rng.integers(0, 1 << 30, k).astype(np.uint64)
+        pos = rng.integers(0, 1 << (kb - 2), k).astype(np.uint64)
+        pos[rng.random(k) < 0.3] = 7                                          # equal keys: the stable order shows
+        return (rid << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, k).astype(np.uint64)
+    mem = members(int(moff[-1]))
+    for n_passes, empty_last in ((1, False), (3, False), (3, True), (2, True)):
+        passes = []
+        for i in range(n_passes):
+            k = 0 if (empty_last and i == n_passes - 1) else int(rng.integers(200, 4000))
+            c = np.sort(rng.integers(0, nc, k)).astype(np.int32)                # a pass appends in contig order
+            passes.append((c, members(k)))
+        lists = [list(mem[int(moff[c]):int(moff[c + 1])]) for c in range(nc)]
+        key = lambda y: (int(y) & 0xFFFFFFFF)
+        for c_arr, m_arr in passes:
+            lists = [sorted(l, key=key) for l in lists]                          # sorted() is stable
+            for c, y in zip(c_arr.tolist(), m_arr.tolist()):
+                lists[c].append(np.uint64(y))
+        want_off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+        want = np.array([y for l in lists for y in l], dtype=np.uint64)
+        d = lambda a, t: torch.from_numpy(a.view(t)).cuda()
+        got, got_off = ctx.members_finalize(d(mem, np.int64), d(moff, np.int64), [(d(c, np.int32), d(m, np.int64)) for c, m in passes], kb)
+        ctx.sync()
+        assert np.array_equal(got_off.cpu().numpy(), want_off), (n_passes, empty_last)
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), want), (n_passes, empty_last)
+
+
+def test_compact_live_and_window_layout(ctx):
+    import torch
+    rng = np.random.default_rng(12)
+    ids = rng.integers(0, 1 << 31, 100001).astype(np.int32)
+    flag = (rng.random(len(ids)) < 0.7).astype(np.uint8) * rng.integers(1, 4, len(ids)).astype(np.uint8)
+    got = ctx.compact_live(torch.from_numpy(ids).cuda(), torch.from_numpy(flag).cuda())
+    assert np.array_equal(got.cpu().numpy(), ids[flag == 0])
+    lens = rng.integers(1, 400, 5000); lens[:3] = [99, 100, 101]
+    soff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    woff, nw, ml = ctx.window_layout(torch.from_numpy(soff).cuda(), 100)
+    want = np.concatenate([[0], np.cumsum(np.maximum(lens - 99, 0))])
+    assert np.array_equal(woff.cpu().numpy(), want) and nw == int(want[-1]) and ml == int(lens.max())
