@@ -222,6 +222,15 @@ def main():
                     roof["note"] = ("integer VALU bound (PMC profiles/r01_f_pmc_sq_32m.txt: about a third of the wave cycles issuing, a third waiting "
                                     "for an issue slot): 1 byte in and 0.07 records out per position against ~35 wave instructions of hashing "
                                     "and window minima; the HBM fraction is small by construction")
+                # the per-read sketch kernel alone (SURVEY section 8d asks for it): mm_sketch_two over the packed rows
+                bs = algorithmic_bytes("sketch_reads", st, L, nd)
+                if bs and agg.get("ms_sketch_reads", 0.0) > 0:
+                    ms1, calls1 = agg["ms_sketch_reads"], agg["calls_sketch_reads"]
+                    ach1 = bs / (ms1 * 1e-3) / 1e9
+                    roof["sketch_kernel"] = {"kernel": "sketch_reads", "achieved": round(ach1, 2), "frac": round(ach1 / 8000.0, 4), "launches": int(calls1),
+                                             "ms_per_step": round(ms1 / a.steps, 3), "algorithmic_bytes_per_read": 8 * ((2 * L + 63) // 64) + 16,
+                                             "mreads_per_s": round((st["n"] + st["resketch"]) / (ms1 * 1e-3) / 1e6, 1), "traffic": pmc_traffic("sketch_reads") if default_workload else None,
+                                             "note": "ALU bound: ~75 integer operations per base for the rolling k-mers and hash64 (PMC: 73 % of wave cycles waiting for an issue slot)"}
                 # the heaviest kernel that IS bound by HBM (random 64-B sectors), for comparison
                 bh = algorithmic_bytes("cindex_build", st, L, nd)
                 if bh and agg.get("ms_cindex_build", 0.0) > 0:
