@@ -55,35 +55,44 @@ def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tens
     world = dist.get_world_size(group)
     n, W = int(rows.shape[0]), int(rows.shape[1])
     owner_all = bucket_owner(rec_x, world)
-    # the largest slice any rank needs decides the number of rounds for everybody (collectives must match)
-    per_slice = max(1, max_message_bytes // (8 * W))
+    # The cap is per MESSAGE (one peer's share of a slice).  Buckets are spread evenly, so a slice of `world` times the
+    # cap (taken at 0.6 of it) sends messages of about 0.6 cap: with eight ranks that is a sixth of the slices -- and of
+    # their argsorts, splits and read-backs -- that a cap on the whole slice would need.  The largest message any rank is
+    # about to send is agreed on first; a skewed slice is cut further, so the cap holds whatever the data.
+    per_slice = max(1, int(0.6 * (max_message_bytes // (8 * W))) * world)
     rounds = torch.tensor([(n + per_slice - 1) // per_slice], dtype=torch.int64, device=rows.device)
     dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
     rounds = max(1, int(rounds.item()))
     out_rids, out_rows = [], []
     for r in range(rounds):
-        lo, hi = min(n, r * per_slice), min(n, (r + 1) * per_slice)
-        owner = owner_all[lo:hi]
-        perm = torch.argsort(owner, stable=True)
-        send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        m = int(sum(rc))
-        rids_s = rids[lo:hi][perm].contiguous()
-        rows_s = rows[lo:hi][perm].contiguous()
-        rids_r = torch.empty(m, dtype=rids.dtype, device=rids.device)
-        rows_r = torch.empty((m, W), dtype=rows.dtype, device=rows.device)
-        dist.all_to_all_single(rids_r, rids_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
-        dist.all_to_all_single(rows_r.view(-1), rows_s.view(-1), output_split_sizes=[c * W for c in rc],
-                               input_split_sizes=[c * W for c in sc], group=group)
-        # what left must be what arrived
-        sums_s = _checksums(rows_s, sc) + _checksums(rids_s, sc)
-        sums_r = torch.empty_like(sums_s)
-        dist.all_to_all_single(sums_r, sums_s, group=group)
-        if not torch.equal(sums_r, _checksums(rows_r, rc) + _checksums(rids_r, rc)):
-            raise RuntimeError(f"minimizer-bucket exchange: slice {r} did not arrive intact (collective library fault)")
-        out_rids.append(rids_r); out_rows.append(rows_r)
+        lo0, hi0 = min(n, r * per_slice), min(n, (r + 1) * per_slice)
+        biggest = torch.bincount(owner_all[lo0:hi0], minlength=world).max().reshape(1).to(torch.int64) if hi0 > lo0 else torch.zeros(1, dtype=torch.int64, device=rows.device)
+        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+        parts = max(1, -(-int(biggest.item()) * 8 * W // max_message_bytes))              # ceil: 1 unless the slice is skewed
+        for q in range(parts):
+            lo = lo0 + (hi0 - lo0) * q // parts
+            hi = lo0 + (hi0 - lo0) * (q + 1) // parts
+            owner = owner_all[lo:hi]
+            perm = torch.argsort(owner, stable=True)
+            send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+            recv_counts = torch.empty_like(send_counts)
+            dist.all_to_all_single(recv_counts, send_counts, group=group)
+            sc, rc = send_counts.tolist(), recv_counts.tolist()
+            m = int(sum(rc))
+            rids_s = rids[lo:hi][perm].contiguous()
+            rows_s = rows[lo:hi][perm].contiguous()
+            rids_r = torch.empty(m, dtype=rids.dtype, device=rids.device)
+            rows_r = torch.empty((m, W), dtype=rows.dtype, device=rows.device)
+            dist.all_to_all_single(rids_r, rids_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
+            dist.all_to_all_single(rows_r.view(-1), rows_s.view(-1), output_split_sizes=[c * W for c in rc],
+                                   input_split_sizes=[c * W for c in sc], group=group)
+            # what left must be what arrived
+            sums_s = _checksums(rows_s, sc) + _checksums(rids_s, sc)
+            sums_r = torch.empty_like(sums_s)
+            dist.all_to_all_single(sums_r, sums_s, group=group)
+            if not torch.equal(sums_r, _checksums(rows_r, rc) + _checksums(rids_r, rc)):
+                raise RuntimeError(f"minimizer-bucket exchange: slice {r}.{q} did not arrive intact (collective library fault)")
+            out_rids.append(rids_r); out_rows.append(rows_r)
     if len(out_rows) == 1:
         return out_rids[0], out_rows[0]
     return torch.cat(out_rids), torch.cat(out_rows)

@@ -82,3 +82,30 @@ def test_reads_sharing_a_minimizer_land_on_one_rank():
         for x, o in zip(rec["x"].tolist(), own.tolist()):
             assert by_x.setdefault(x, o) == o
         assert len(set(own.tolist())) == world
+
+
+def _skew_worker(rank, world, port, n, W, cap):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from minicom_amd.distributed import exchange_by_bucket
+    g = torch.Generator().manual_seed(7 + rank)
+    rows = torch.randint(-(1 << 62), 1 << 62, (n, W), dtype=torch.int64, generator=g)
+    rids = torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64)
+    x = torch.zeros(n, dtype=torch.int64)                                     # every read belongs to bucket 0: rank 0 owns them all
+    rids_r, rows_r = exchange_by_bucket(x, rids, rows, max_message_bytes=cap)
+    if rank == 0:
+        assert rids_r.shape[0] == world * n and torch.equal(torch.sort(rids_r).values, torch.arange(world * n))
+        mine = rids_r < n
+        assert torch.equal(rows_r[mine][torch.argsort(rids_r[mine])], rows)
+    else:
+        assert rids_r.shape[0] == 0 and rows_r.shape[0] == 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_skewed_exchange_splits_its_slices_world_size_2_gloo():
+    """All reads owned by one rank: a slice sized for an even spread would send a message of twice the cap; the ranks
+    agree on the largest message first and cut the slice."""
+    port = _free_port()
+    mp.spawn(_skew_worker, args=(2, port, 3000, 4, 8000), nprocs=2, join=True)
