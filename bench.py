@@ -155,10 +155,11 @@ def main():
             out = ctx.process_reads(reads, L, 31, rid0=0)
             keep = (out["cls"] == 0).nonzero().squeeze(1)
             x = out["rec"][:, 0][keep]
+            ylow = (out["rec"][:, 1][keep] & 0xFFFFFFFF).to(torch.int32)           # position<<1 | strand: travels with the read
             rids = keep + rank * n_local
-            _, rows = exchange_by_bucket(x, rids, out["packed"][keep])
+            _, rows, (x_r, ylow_r) = exchange_by_bucket(x, rids, out["packed"][keep], extras=[x, ylow])
             del out
-            p = Pipeline(rows, L=L, device=local_rank, host_threads=threads, packed=True)
+            p = Pipeline(rows, L=L, device=local_rank, host_threads=threads, packed=True, records=(x_r, ylow_r))
         p.prof_enable(True)
         p.pre_process()
         if timed:

@@ -78,6 +78,10 @@ int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size
  * kthread_bucket.c:205, :489); NULL: rows rid0+i... i.e. row i with rid rid0+i.                 */
 int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, size_t n, int L,
                       int k, uint32_t rid0, mcom_mm128 *d_rec);
+/* The records of reads whose minimizers are known already (they were sketched with the same k on another rank and
+ * came through the bucket exchange): d_rec[i] = { d_x[i], (rid0+i)<<32 | d_ylow[i] } with d_ylow = position<<1 | strand
+ * as mm_sketch_two left it (sketch.c:271); x = UINT64_MAX (no minimizer) gives the all-ones record.                */
+int mcom_records_assemble(mcom_ctx *ctx, const uint64_t *d_x, const uint32_t *d_ylow, size_t n, uint32_t rid0, mcom_mm128 *d_rec);
 
 /* ---- a5 + a6: sort and group ------------------------------------------------------------------- */
 /* radix_sort_128x (misc.c:22, ksort.h:153): sorts n records in place by x ascending.  Stable: equal keys

@@ -41,6 +41,10 @@ int  mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, const uint
  * entry used after the multi-GPU minimizer-bucket exchange, where a rank receives its partition packed.  */
 int  mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, const uint64_t *d_packed, size_t n, int L,
                          const mcomh_params *p);
+/* Optional, between mcomh_create_packed and mcomh_kt_for_reads: the minimizers of the packed rows are known (sketched
+ * with the pipeline's k by the rank that sent them); d_x [n] hashes, d_ylow [n] position<<1 | strand.  kt_for_reads then
+ * assembles the records instead of sketching the rows again.  The arrays must stay valid until kt_for_reads returns. */
+int  mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow);
 void mcomh_destroy(mcomh_pipeline *p);
 const char *mcomh_last_error(const mcomh_pipeline *p);
 

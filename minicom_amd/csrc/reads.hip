@@ -299,3 +299,28 @@ extern "C" int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, 
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
+
+
+// ---- records that travelled: the minimizer of a read does not change when the read changes rank ---------------------
+// After the multi-GPU bucket exchange a rank holds reads that were sketched by their sender; x and the low half of y
+// (position<<1 | strand) came along, only the read id is new: the row's index on this rank.
+__global__ void k_records_assemble(const uint64_t *__restrict__ x, const uint32_t *__restrict__ ylow, size_t n, uint32_t rid0, mcom_mm128 *__restrict__ rec)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	mcom_mm128 r;
+	r.x = x[i];
+	r.y = r.x == U64MAX ? U64MAX : (((uint64_t)(rid0 + (uint32_t)i) << 32) | (uint64_t)ylow[i]);
+	rec[i] = r;
+}
+
+extern "C" int mcom_records_assemble(mcom_ctx *ctx, const uint64_t *d_x, const uint32_t *d_ylow, size_t n, uint32_t rid0, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_x || !d_ylow || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if ((uint64_t)rid0 + n > (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "read ids exceed 32 bits");
+	hipLaunchKernelGGL(k_records_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x, d_ylow, n, rid0, d_rec);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

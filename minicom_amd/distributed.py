@@ -43,12 +43,15 @@ def _checksums(rows_s: torch.Tensor, counts: list) -> torch.Tensor:
     return torch.stack(out)
 
 
-def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tensor, group=None, max_message_bytes: int = MAX_MESSAGE_BYTES):
+def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tensor, group=None, max_message_bytes: int = MAX_MESSAGE_BYTES,
+                       extras=None):
     """All-to-all of the reads of this rank to the owners of their minimizer buckets.
 
     rec_x : int64 [n]     minimizer hash of every kept read of this rank
     rids  : int64 [n]     global read ids
     rows  : int64 [n, W]  packed rows
+    extras: optional list of 1-D tensors [n] that travel with the reads (e.g. the minimizer hash and position of every
+            read, so that the receiver need not sketch again); then a third result, the list of received tensors.
     Returns (rids_recv int64 [m], rows_recv int64 [m, W]).  The reads travel in slices of the sender's order (so that no
     message exceeds max_message_bytes); inside a slice they arrive ordered by source rank, then by the sender's order.
     Raises RuntimeError when a slice does not arrive intact."""
@@ -63,7 +66,8 @@ def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tens
     rounds = torch.tensor([(n + per_slice - 1) // per_slice], dtype=torch.int64, device=rows.device)
     dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
     rounds = max(1, int(rounds.item()))
-    out_rids, out_rows = [], []
+    extras = list(extras) if extras is not None else None
+    out_rids, out_rows, out_extras = [], [], [[] for _ in (extras or [])]
     for r in range(rounds):
         lo0, hi0 = min(n, r * per_slice), min(n, (r + 1) * per_slice)
         biggest = torch.bincount(owner_all[lo0:hi0], minlength=world).max().reshape(1).to(torch.int64) if hi0 > lo0 else torch.zeros(1, dtype=torch.int64, device=rows.device)
@@ -93,6 +97,17 @@ def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tens
             if not torch.equal(sums_r, _checksums(rows_r, rc) + _checksums(rids_r, rc)):
                 raise RuntimeError(f"minimizer-bucket exchange: slice {r}.{q} did not arrive intact (collective library fault)")
             out_rids.append(rids_r); out_rows.append(rows_r)
-    if len(out_rows) == 1:
-        return out_rids[0], out_rows[0]
-    return torch.cat(out_rids), torch.cat(out_rows)
+            for j, t in enumerate(extras or []):
+                t_s = t[lo:hi][perm].contiguous()
+                t_r = torch.empty(m, dtype=t.dtype, device=t.device)
+                dist.all_to_all_single(t_r, t_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
+                cs_s = _checksums(t_s.to(torch.int64), sc)
+                cs_r = torch.empty_like(cs_s)
+                dist.all_to_all_single(cs_r, cs_s, group=group)
+                if not torch.equal(cs_r, _checksums(t_r.to(torch.int64), rc)):
+                    raise RuntimeError(f"minimizer-bucket exchange: slice {r}.{q}, extra {j} did not arrive intact (collective library fault)")
+                out_extras[j].append(t_r)
+    cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)
+    if extras is not None:
+        return cat(out_rids), cat(out_rows), [cat(e) for e in out_extras]
+    return cat(out_rids), cat(out_rows)

@@ -194,6 +194,7 @@ struct mcomh_pipeline {
 	// device
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
 	const uint64_t *ext_packed = nullptr;    // packed-row input (mcomh_create_packed): no classification stage
+	const uint64_t *ext_x = nullptr; const uint32_t *ext_ylow = nullptr;   // ... whose minimizers came along (mcomh_set_records)
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
@@ -311,6 +312,15 @@ extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_s
 	return MCOM_OK;
 }
 
+extern "C" int mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow)
+{
+	if (!p) return MCOM_E_ARG;
+	if (!p->ext_packed && p->n) return p->fail(MCOM_E_ARG, "records can only be handed over with packed rows");
+	if (p->n && (!d_x || !d_ylow)) return p->fail(MCOM_E_ARG, "null device pointer");
+	p->ext_x = d_x; p->ext_ylow = d_ylow;
+	return MCOM_OK;
+}
+
 extern "C" void mcomh_destroy(mcomh_pipeline *p)
 {
 	if (!p) return;
@@ -339,7 +349,9 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		if (n && ((rc = p->hipc(hipMemcpyAsync(p->d_packed.p, p->ext_packed, n * (size_t)p->W * 8, hipMemcpyDeviceToDevice, p->stream), "copy packed rows")) ||
 		          (rc = p->hipc(hipMemsetAsync(p->d_cls.p, 0, n, p->stream), "clear")) ||
 		          (rc = p->hipc(hipMemsetAsync(p->d_nmask.p, 0, n * (size_t)p->NW * 8, p->stream), "clear")))) return rc;
-		rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, nullptr, n, p->L, p->k, 0, p->d_rec.p));
+		if (p->ext_x && p->ext_ylow) rc = p->gpu(mcom_records_assemble(p->ctx, p->ext_x, p->ext_ylow, n, 0, p->d_rec.p));
+		else rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, nullptr, n, p->L, p->k, 0, p->d_rec.p));
+		if (!rc && p->ext_x) rc = p->sync("records");                         // the caller may release its arrays now
 	} else {
 		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
 	}

@@ -34,6 +34,7 @@ def load_host_library():
     vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.mcomh_create.restype = i32
     L.mcomh_create.argtypes = [C.POINTER(vp), i32, vp, vp, vp, sz, sz, i32, C.POINTER(Params)]
+    L.mcomh_set_records.restype = i32; L.mcomh_set_records.argtypes = [vp, vp, vp]
     L.mcomh_create_packed.restype = i32
     L.mcomh_create_packed.argtypes = [C.POINTER(vp), i32, vp, vp, sz, i32, C.POINTER(Params)]
     L.mcomh_destroy.restype = None; L.mcomh_destroy.argtypes = [vp]
@@ -66,7 +67,7 @@ def load_host_library():
     return L
 
 
-HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
+HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
@@ -111,7 +112,9 @@ def read_fastq(path: str, L: int = 0) -> np.ndarray:
 class Pipeline:
     """Stage 1 + Stage 2 of minicom on one GPU.  reads: numpy uint8 [n, L] (host) or a torch uint8 CUDA tensor [n, pitch]."""
 
-    def __init__(self, reads, L: int | None = None, device: int = 0, stream=None, packed: bool = False, **params):
+    def __init__(self, reads, L: int | None = None, device: int = 0, stream=None, packed: bool = False, records=None, **params):
+        """records (packed=True only): (x int64 [n], ylow int32 [n]) CUDA tensors, the minimizers the rows were sketched to with
+        this pipeline's k on the rank that sent them: kt_for_reads then assembles the records instead of sketching again."""
         self.lib = load_host_library()
         p = Params(**{k: int(v) for k, v in params.items()})
         h = C.c_void_p()
@@ -136,6 +139,14 @@ class Pipeline:
             raise McomError(f"mcomh_create failed ({rc}): no usable GPU or bad arguments; there is no CPU fallback")
         self._h = h
         self.n, self.L = n, L
+        if records is not None:
+            assert packed, "records travel with packed rows"
+            x, ylow = records
+            import torch
+            assert x.is_cuda and ylow.is_cuda and x.is_contiguous() and ylow.is_contiguous() and x.dtype == torch.int64 and ylow.dtype == torch.int32
+            assert int(x.shape[0]) == n and int(ylow.shape[0]) == n
+            self._keep = (self._keep, x, ylow)
+            self._check(self.lib.mcomh_set_records(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(ylow.data_ptr())))
 
     @classmethod
     def from_fastq(cls, path: str, L: int = 0, device: int = 0, chunk_reads: int = 0, path2: str | None = None, **params):

@@ -33,7 +33,10 @@ def _worker(rank, world, port, n, L, k, out_dir, max_bytes=None):
     rows = torch.from_numpy(pack_nt4(reads).view(np.int64))
     x = torch.from_numpy(rec["x"].view(np.int64).copy())
     rids = torch.arange(first, first + per, dtype=torch.int64)
-    rids_r, rows_r = exchange_by_bucket(x, rids, rows) if max_bytes is None else exchange_by_bucket(x, rids, rows, max_message_bytes=max_bytes)
+    ylow = torch.from_numpy((rec["y"] & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32).copy())
+    kw = {} if max_bytes is None else {"max_message_bytes": max_bytes}
+    rids_r, rows_r, (x_r, ylow_r) = exchange_by_bucket(x, rids, rows, extras=[x, ylow], **kw)
+    assert rids_r.shape == x_r.shape == ylow_r.shape
     # every received read belongs to a bucket this rank owns; one slice: ascending global rid; several slices (messages
     # capped at max_bytes): slice after slice, ascending inside a (slice, source rank) run
     all_reads = synth.synth_reads(4321, n, L)
@@ -46,6 +49,9 @@ def _worker(rank, world, port, n, L, k, out_dir, max_bytes=None):
     else:
         assert np.array_equal(np.sort(got), want) and not np.array_equal(got, want)
     assert np.array_equal(rows_r.numpy().view(np.uint64), pack_nt4(all_reads[got]))
+    # the minimizers that travelled are those of the reads they arrived with
+    assert np.array_equal(x_r.numpy().view(np.uint64), rec_all["x"][got])
+    assert np.array_equal(ylow_r.numpy().view(np.uint32), (rec_all["y"][got] & np.uint64(0xFFFFFFFF)).astype(np.uint32))
     np.save(os.path.join(out_dir, f"rids_{rank}.npy"), rids_r.numpy())
     dist.barrier()
     dist.destroy_process_group()

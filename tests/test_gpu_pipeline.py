@@ -200,3 +200,28 @@ def test_stage2_long_bins_at_the_reference_limit_of_2000():
         assert r0 == r1 and np.array_equal(m0, m1), c
     assert np.array_equal(o.id_list("sg"), p.id_list("sg"))
     p.close(); o.close()
+
+
+def test_packed_rows_with_forwarded_minimizers_equal_resketching():
+    """The multi-GPU entry: packed rows handed over together with their minimizers (mcomh_set_records) must give what
+    sketching the rows again gives."""
+    import torch
+    import minicom_amd
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    L, n = 150, 60000
+    reads = synth.synth_reads(2718, n, L)                                         # no N: every read is kept, as after the exchange
+    ctx = minicom_amd.Context(0)
+    out = ctx.process_reads(torch.from_numpy(reads).cuda(), L, 31)
+    ctx.sync()
+    assert int((out["cls"] != 0).sum()) == 0
+    rows = out["packed"].contiguous()
+    x = out["rec"][:, 0].contiguous()
+    ylow = (out["rec"][:, 1] & 0xFFFFFFFF).to(torch.int32).contiguous()
+    a = Pipeline(rows, L=L, packed=True, host_threads=4); a.pre_process()
+    b = Pipeline(rows, L=L, packed=True, records=(x, ylow), host_threads=4); b.pre_process()
+    ca, cb = a.contigs(), b.contigs()
+    assert len(ca) == len(cb) > 100
+    assert all(r0 == r1 and np.array_equal(m0, m1) for (r0, m0), (r1, m1) in zip(ca, cb))
+    assert np.array_equal(a.id_list("sg"), b.id_list("sg"))
+    a.close(); b.close(); ctx.close()
