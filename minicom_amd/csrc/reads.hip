@@ -114,6 +114,76 @@ __global__ __launch_bounds__(256) void k_classify_pack(const uint8_t *__restrict
 	}
 }
 
+// The same with SIXTEEN bases per lane, for 128 < L <= 256: 16 lanes per read (four reads per wave instead of two with
+// eight bases on 32 lanes, of which L = 150 keeps only 19 busy), one 16-byte load per lane, two lanes per packed word.
+__device__ __forceinline__ uint32_t spread16(uint32_t m)                 // bit i of the low 16 -> bit 2i
+{
+	m = (m | (m << 8)) & 0x00FF00FFu; m = (m | (m << 4)) & 0x0F0F0F0Fu; m = (m | (m << 2)) & 0x33333333u; m = (m | (m << 1)) & 0x55555555u;
+	return m;
+}
+__global__ __launch_bounds__(256) void k_classify_pack16(const uint8_t *__restrict__ ascii, size_t pitch, size_t n,
+                                                         int L, int e, uint64_t *__restrict__ packed, int W,
+                                                         uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt,
+                                                         uint64_t *__restrict__ nmask, int NW)
+{
+	constexpr int G = 16, RPW = 64 / G;
+	const int lane = threadIdx.x & 63;
+	const int sub = lane / G, j = lane % G;
+	const size_t wave0 = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+	const size_t total_bytes = n ? (n - 1) * pitch + (size_t)L : 0;
+	for (size_t base = wave0 * RPW; base < n; base += nwaves * RPW) {
+		const size_t r = base + sub;
+		const bool live = r < n;
+		const int c0 = 16 * j;
+		int nv = L - c0; nv = nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+		if (!live) nv = 0;
+		uint32_t d[4] = {0, 0, 0, 0};
+		if (nv > 0) {
+			const size_t off = r * pitch + (size_t)c0;
+			if (off + 16 <= total_bytes) { d[0] = load_u32_any(ascii + off); d[1] = load_u32_any(ascii + off + 4); d[2] = load_u32_any(ascii + off + 8); d[3] = load_u32_any(ascii + off + 12); }
+			else for (int q = 0; q < nv; ++q) d[q >> 2] |= (uint32_t)ascii[off + q] << (8 * (q & 3));
+		}
+		const uint32_t vmask = nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u);
+		const uint32_t codes = ascii4_to_codes(d[0]) | (ascii4_to_codes(d[1]) << 8) | (ascii4_to_codes(d[2]) << 16) | (ascii4_to_codes(d[3]) << 24);   // 16 x 2 bits
+		const uint32_t nb = (ascii4_nbits(d[0]) | (ascii4_nbits(d[1]) << 4) | (ascii4_nbits(d[2]) << 8) | (ascii4_nbits(d[3]) << 12)) & vmask;       // 16 N flags
+		const uint32_t lo = codes & 0x55555555u, hi = (codes >> 1) & 0x55555555u;
+		const uint32_t ok = spread16(vmask & ~nb);
+		const uint32_t cA = __popc(~lo & ~hi & ok), cC = __popc(lo & ~hi & ok), cG = __popc(~lo & hi & ok), cT = __popc(lo & hi & ok);
+		uint32_t acc0 = cA | (cT << 16), acc1 = cG | (cC << 16), accN = __popc(nb);
+#pragma unroll
+		for (int s = 1; s < G; s <<= 1) { acc0 += __shfl_xor(acc0, s, 64); acc1 += __shfl_xor(acc1, s, 64); accN += __shfl_xor(accN, s, 64); }
+		const int nA = acc0 & 0xFFFF, nT = acc0 >> 16, nG = acc1 & 0xFFFF, nC = acc1 >> 16, nN = (int)accN;
+		int c;                                                               // kthread_reads.c:84-224
+		if (nA == L) c = MCOM_CLS_ALLA;
+		else if (nT == L) c = MCOM_CLS_ALLT;
+		else if (nN == L) c = MCOM_CLS_ALLN;
+		else if (nT + nG + nC + nN <= e) c = MCOM_CLS_NEARA;
+		else if (nA + nG + nC + nN <= e) c = MCOM_CLS_NEART;
+		else if (nA + nT + nG + nC <= e) c = MCOM_CLS_NEARN;
+		else if (!((double)nN <= 0.4 * (double)L)) c = MCOM_CLS_NHEAVY;
+		else c = MCOM_CLS_SKETCH;
+		uint32_t rep = 0;                                                    // majority base, ties A,T,G,C (:185-201)
+		if (c == MCOM_CLS_SKETCH && nN > 0) {
+			int mx = nA; if (nT > mx) mx = nT; if (nG > mx) mx = nG; if (nC > mx) mx = nC;
+			rep = (mx == nA) ? 0u : (mx == nT) ? 3u : (mx == nG) ? 2u : 1u;
+		}
+		const uint32_t nsp = spread16(nb);
+		const uint32_t keep = ok | (ok << 1);
+		const uint32_t fill = (rep & 1 ? nsp : 0u) | (rep & 2 ? (nsp << 1) : 0u);
+		const uint32_t out32 = (codes & keep) | fill;
+		uint64_t word = (uint64_t)out32 << (32 * (j & 1));                   // two lanes make one 64-bit word
+		word |= __shfl_xor(word, 1, 64);
+		if (live && (j & 1) == 0 && (j >> 1) < W) packed[r * (size_t)W + (j >> 1)] = word;
+		if (nmask) {
+			uint64_t nw = (uint64_t)nb << (16 * (j & 3));                    // four lanes make one word of N flags
+			nw |= __shfl_xor(nw, 1, 64); nw |= __shfl_xor(nw, 2, 64);
+			if (live && (j & 3) == 0 && (j >> 2) < NW) nmask[r * (size_t)NW + (j >> 2)] = nw;
+		}
+		if (live && j == 0) { cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN; }
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_sketch_reads: one thread per read, rolling forward / reverse-complement k-mers out of the packed
 // row held in registers; 64 reads of a wave run the same control flow (the only divergent branch is the
@@ -266,14 +336,14 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 	if (n == 0) return MCOM_OK;
 	if (!d_ascii || !d_packed || !d_cls || !d_ncnt || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const int W = mcom_words_per_read(L), NW = (L + 63) / 64;
-	const int G = L <= 128 ? 16 : 32;
+	const int G = 16;                                                       // L <= 128: 8 bases per lane; above: 16 bases per lane
 	const size_t waves = (n + (64 / G) - 1) / (64 / G);
 	size_t blocks = (waves + 3) / 4;
 	const size_t cap = (size_t)ctx->n_cu * 16;
 	if (blocks > cap) blocks = cap;
 	{ McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
-	if (G == 16) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
-	else         hipLaunchKernelGGL((k_classify_pack<32>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
+	if (L <= 128) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
+	else          hipLaunchKernelGGL(k_classify_pack16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
 	MCOM_LAUNCH_CHECK(ctx);
 	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
 	if (rc) return rc;
