@@ -1,0 +1,50 @@
+"""Pipeline against the sequential oracle on a repeat-rich read set: a short genome with a many-copy segment, tandem
+repeats and low-complexity stretches at very high coverage -- groups of tens of thousands of reads, long runs of equal
+minimizers in the contig index, long Stage-2 bins."""
+import os, sys, time, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+n, L = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 100
+gpu = "--oracle-only" not in sys.argv
+sub_rate = float(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 0.004
+rng = np.random.default_rng(97)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+G = 200_000
+g = acgt[rng.integers(0, 4, G)]
+rep = acgt[rng.integers(0, 4, 2000)]
+for at in rng.integers(0, G - 2000, 40):                      # forty dispersed copies, a few of them mutated
+    c = rep.copy()
+    for q in rng.integers(0, 2000, int(rng.integers(0, 6))): c[q] = acgt[rng.integers(0, 4)]
+    g[at:at + 2000] = c
+unit = acgt[rng.integers(0, 4, 37)]
+g[50_000:50_000 + 37 * 60] = np.tile(unit, 60)                # a tandem repeat
+g[120_000:120_400] = ord("A"); g[130_000:130_300] = np.tile(np.frombuffer(b"AT", dtype=np.uint8), 150)
+start = rng.integers(0, G - L + 1, n)
+# a third of the reads pile up on the repeat copies
+hot = rng.random(n) < 0.35
+reads = g[start[:, None] + np.arange(L)[None, :]]
+sub = rng.random((n, L)) < sub_rate
+reads = np.where(sub, acgt[rng.integers(0, 4, (n, L))], reads)
+rc = rng.random(n) < 0.5
+reads[rc] = comp[reads[rc]][:, ::-1]
+reads = np.ascontiguousarray(reads)
+t00 = time.time()
+def _beat():
+    while True:
+        time.sleep(60); print("... %d s" % (time.time() - t00), flush=True)
+threading.Thread(target=_beat, daemon=True).start()
+import oracle
+t = time.time(); o = oracle.Pipeline(reads); o.run_all(); print("oracle %.1f s, contigs %d, largest contig %d members, sg %d, passes %d" % (
+    time.time() - t, len(o.contigs()), max((len(m) for _, m in o.contigs()), default=0), len(o.id_list("sg")), o.counter("passes")), flush=True)
+if gpu:
+    from minicom_amd.pipeline import Pipeline
+    t = time.time(); p = Pipeline(reads, host_threads=16); p.pre_process(); print("gpu %.2f s  big_bins %d big_bin_reads %d" % (time.time() - t, p.stat("big_bins"), p.stat("big_bin_reads")), flush=True)
+    oc, pc = o.contigs(), p.contigs()
+    assert len(oc) == len(pc), (len(oc), len(pc))
+    bad = sum(1 for (r0, m0), (r1, m1) in zip(oc, pc) if r0 != r1 or not np.array_equal(m0, m1))
+    print("contigs differing:", bad)
+    for name in ("sg", "fpA", "fpT"):
+        print(name, np.array_equal(o.id_list(name), p.id_list(name)))
+    assert bad == 0
