@@ -48,3 +48,16 @@ if gpu:
     for name in ("sg", "fpA", "fpT"):
         print(name, np.array_equal(o.id_list(name), p.id_list(name)))
     assert bad == 0
+if "--e2e" in sys.argv:                                      # FASTQ -> .minicom -> reads, order-preserving and default
+    import tempfile
+    from minicom_amd import container, synth
+    with tempfile.TemporaryDirectory() as td:
+        fq = os.path.join(td, "a.fastq"); synth.write_fastq(fq, reads)
+        for order in (True, False):
+            arc, out = os.path.join(td, "a.minicom"), os.path.join(td, "a.reads")
+            container.compress_fastq(fq, arc, order=order, codec="gz", threads=16)
+            assert container.decompress_file(arc, out, threads=16) == n
+            got = np.frombuffer(open(out, "rb").read(), dtype=np.uint8).reshape(n, L + 1)[:, :L]
+            ok = np.array_equal(got, reads) if order else np.array_equal(np.sort(np.ascontiguousarray(got).view("S%d" % L).ravel()), np.sort(reads.view("S%d" % L).ravel()))
+            print("round trip (order=%s): %s, %.3f bits/base" % (order, ok, 8 * os.path.getsize(arc) / reads.size), flush=True)
+            assert ok
