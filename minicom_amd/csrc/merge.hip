@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256) void k_keep_copy(const uint32_t *__restrict__ 
 	const int lane = threadIdx.x & 63;
 	const uint32_t i = keepidx[u];
 	const uint64_t s0 = soff[i], sl = soff[i + 1] - s0, d0 = soff2[nj + u];
-	for (uint64_t t = lane; t < sl; t += 64) seq2[d0 + t] = seq[s0 + t];
+	// eight characters per lane and step (unaligned 8-byte accesses are fine on this hardware), the last few one by one
+	const uint64_t n8 = sl >> 3;
+	for (uint64_t t = lane; t < n8; t += 64) { uint64_t v; __builtin_memcpy(&v, seq + s0 + 8 * t, 8); __builtin_memcpy(seq2 + d0 + 8 * t, &v, 8); }
+	for (uint64_t t = (n8 << 3) + lane; t < sl; t += 64) seq2[d0 + t] = seq[s0 + t];
 	const uint64_t m0 = moff[i], ml = moff[i + 1] - m0, e0 = moff2[nj + u];
 	for (uint64_t t = lane; t < ml; t += 64) mem2[e0 + t] = mem[m0 + t];
 }
