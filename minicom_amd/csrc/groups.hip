@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void k_group_emit(const uint64_t *__restrict__
 		const uint32_t len = reflen[g];
 		const uint8_t *src = refs + g * (size_t)ref_stride;
 		uint8_t *out = seq + chars_have + rof[g];
-		for (uint32_t i = lane; i < len; i += 64) out[i] = src[i];
+		{                                                                    // eight characters per lane and step, then the last few
+			const uint32_t n8 = len >> 3;
+			for (uint32_t i = lane; i < n8; i += 64) { uint64_t v; __builtin_memcpy(&v, src + 8 * i, 8); __builtin_memcpy(out + 8 * i, &v, 8); }
+			for (uint32_t i = (n8 << 3) + lane; i < len; i += 64) out[i] = src[i];
+		}
 		if (lane == 0) { moff[c + 1] = members_have + mof[g] + nk; soff[c + 1] = chars_have + rof[g] + len; }
 	}
 	if (!(nk == sz && nk > 1)) {

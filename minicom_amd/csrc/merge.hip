@@ -308,8 +308,17 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Job *__restrict__ jobs
 	const uint64_t len = jroff[j + 1] - jroff[j];
 	uint8_t *out = refs + jroff[j];
 	const uint64_t lo = olo[j], hi = ohi[j];
-	for (uint64_t c = lane; c < lo; c += 64) out[c] = sf[c];                 // before the overlap: the first parent alone
-	for (uint64_t c = hi + lane; c < len; c += 64) out[c] = c < lf ? sf[c] : ss[c - sh];   // behind it: whichever parent reaches there
+	// eight characters per lane and step (unaligned 8-byte accesses), the last few of a stretch one by one
+	auto copy8 = [&](uint8_t *dst, const uint8_t *src, uint64_t cnt) {
+		const uint64_t n8 = cnt >> 3;
+		for (uint64_t t = lane; t < n8; t += 64) { uint64_t v; __builtin_memcpy(&v, src + 8 * t, 8); __builtin_memcpy(dst + 8 * t, &v, 8); }
+		for (uint64_t t = (n8 << 3) + lane; t < cnt; t += 64) dst[t] = src[t];
+	};
+	copy8(out, sf, lo);                                                      // before the overlap: the first parent alone
+	if (hi < len) {                                                          // behind it: whichever parent reaches there
+		if (hi < lf) copy8(out + hi, sf + hi, len - hi);                      // (the second one ends inside the first: len = lf)
+		else copy8(out + hi, ss + (hi - sh), len - hi);
+	}
 }
 
 extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_jm, const uint64_t *d_jmoff,
