@@ -4,8 +4,9 @@
  * and meaning (pre_process preprocess.c:39, kt_for_reads kthread_reads.c:247, kt_for_bucket
  * kthread_bucket.c:562, combine_cluster kthread_cb.c:570, realign_hash kthread_hash_realign.c:569,
  * updateSingle preprocess.c:243) but run their hot loops as HIP kernels through include/mcom.h.
- * The contig set lives on the device from kt_for_bucket to the end of Stage 2; the host orders singletons and
- * rejects, keeps the loop control of the stages and folds Stage 2's appends into the member lists.
+ * The contig set lives on the device from kt_for_bucket on and is still there, complete (Stage 2's appends folded into
+ * the member lists, in the reference's order), when pre_process returns; accessors, stage dumps and the stream writer
+ * copy it to the host on demand.  The host keeps the loop control of the stages and orders the singleton list.
  * No CPU fallback: every stage needs the GPU.
  * Results equal the reference at one thread (-t 1, its only deterministic mode).
  */
