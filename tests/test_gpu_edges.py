@@ -17,6 +17,10 @@ def _cases():
     yield "L32", synth.synth_reads(4, 3000, 32)
     yield "L40", synth.synth_reads(4, 3000, 40)
     yield "L64", synth.synth_reads(5, 3000, 64)
+    yield "L75", synth.synth_reads(10, 3000, 75)                 # 70 <= L < 80: k = 17 with w = L/2 - k
+    yield "L101", synth.synth_reads(11, 3000, 101)
+    yield "L151", synth.synth_reads(12, 2500, 151)
+    yield "L199", synth.synth_reads(13, 2000, 199)
     yield "L255", synth.synth_reads(6, 1500, 255)
     yield "L256", synth.synth_reads(7, 1500, 256)
     yield "duplicates", np.repeat(synth.synth_reads(8, 40, 100), 50, axis=0)
