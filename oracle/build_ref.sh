@@ -58,6 +58,7 @@ build_variant() {   # name readlen extra_defines...
 build_variant L100 100
 build_variant L150 150
 build_variant L40 40
+build_variant L75 75
 ININUMDICT=4 build_variant L100_s4 100
 build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE

@@ -218,5 +218,6 @@ if __name__ == "__main__":
         make_stages("L150", 150, 1002, 2000)
     make_stages("L100", 100, 1003, 1500, k=24, tag="stages_L100_k24")
     make_stages("L40", 40, 1004, 2500)                       # short reads: k = 17, w = 3, L/11 dictionaries
+    make_stages("L75", 75, 1006, 2500)                       # 70 <= L < 80: k = 17 with w = L/2 - k = 20
     # every tunable off its default at once: -e 6 -m 4 -w 12 -g 9 -R 3 -S 5 -E 30 -s 4 (the last compiled into the variant)
     make_stages("L100_s4", 100, 1005, 2500, tag="stages_L100_params", params=("e=6", "m=4", "w=12", "g=9", "R=3", "S=5", "E=30"))

@@ -27,7 +27,7 @@ def _first_diff(got, want):
 NONDEFAULT = dict(e=6, m=4, w=12, cbthr=9, max_rounds=3, step=5, maxthr=30, numdict=4)   # tests/golden/make_golden.py
 
 
-@pytest.mark.parametrize("tag,params,threads", [("stages_L100", {}, 1), ("stages_L150", {}, 4), ("stages_L100_k24", dict(k=24), 2), ("stages_L40", {}, 2),
+@pytest.mark.parametrize("tag,params,threads", [("stages_L100", {}, 1), ("stages_L150", {}, 4), ("stages_L100_k24", dict(k=24), 2), ("stages_L40", {}, 2), ("stages_L75", {}, 2),
                                                 ("stages_L100_params", NONDEFAULT, 3)])
 def test_pipeline_stage_dumps_equal_reference(golden_dir, tmp_path, tag, params, threads):
     from minicom_amd.pipeline import Pipeline

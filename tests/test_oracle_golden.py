@@ -66,7 +66,7 @@ def test_encode_byte_matches_reference(kat):
 NONDEFAULT = dict(e=6, m=4, w=12, cbthr=9, max_rounds=3, step=5, maxthr=30, numdict=4)   # tests/golden/make_golden.py
 
 
-@pytest.mark.parametrize("tag,params", [("stages_L100", {}), ("stages_L150", {}), ("stages_L100_k24", dict(k=24)), ("stages_L40", {}),
+@pytest.mark.parametrize("tag,params", [("stages_L100", {}), ("stages_L150", {}), ("stages_L100_k24", dict(k=24)), ("stages_L40", {}), ("stages_L75", {}),
                                         ("stages_L100_params", NONDEFAULT)])
 def test_all_stages_match_reference_dump(golden_dir, tmp_path, tag, params):
     """Whole hot path (reads -> buckets -> contigs -> merged contigs -> every realign pass): the
