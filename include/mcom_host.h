@@ -30,6 +30,14 @@ typedef struct {
 	int maxthr;     /* -E  0 = L/2                       minicommain.c:140    */
 	int numdict;    /* -s  0 = L/17 (L/11 when L <= 80)  kthread_hash_realign.c:153 */
 	int host_threads; /* host worker threads for the consensus loops (0 = 1); results do not depend on it */
+	/* The library reads NO environment variable: what changes results or the kernels used is said here.            */
+	int maxsearch;      /* 0 = the reference's 500 / 2000 (preprocess.c:169-172); > 0 forces the bin cut of
+	                       kthread_hash_realign.c:388 (test hook: lets a small input exercise bins above the cut)   */
+	int window_scan;    /* 1 = Stage 2 with the window-driven kernel (realign_hash_search as written) instead of the
+	                       read-driven one; same claims, ~50x slower: the cross-check of tests/test_gpu_realign.py   */
+	int full_consensus; /* 1 = count every column of a merged contig (construct_ref2 as written) instead of only the
+	                       parents' overlap; same strings (A/B switch for measurements)                             */
+	int full_sketch;    /* 1 = sketch merged contigs whole instead of around the overlap; same records (A/B switch) */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

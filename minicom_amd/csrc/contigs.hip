@@ -381,9 +381,6 @@ __global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restric
 	}
 }
 
-int mcom_sketch_contigs_flat(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n, uint64_t n_chars,
-                             int w, int k, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap, uint64_t *h_total, int *used);
-
 // d_off_end = NULL: string t is [d_off[t], d_off[t+1]) and their total is read from d_off[n]; otherwise string t is the
 // segment [d_off[t], d_off_end[t]) and chars_bound bounds the sum of their lengths
 int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars_bound,
@@ -415,11 +412,6 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	if (!d_off_end) {
 		MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
 		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	}
-	if (!max_per_contig && !d_off_end && getenv("MCOM_SKETCH_FLAT")) {                   // alternative: one thread per position (sketchflat.hip); measured equal, not faster
-		int used = 0;
-		const int rcf = mcom_sketch_contigs_flat(ctx, d_seq, d_off, d_ids, n, chars, w, k, d_moff, d_out, cap, h_total, &used);
-		if (rcf || used) return rcf;
 	}
 	const uint64_t max_slots = chars / PIECE + 2 * (uint64_t)n + 1;
 	if (max_slots >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig pieces");

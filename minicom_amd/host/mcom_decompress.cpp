@@ -37,19 +37,34 @@ struct BitReader {                      // getDir (decompress.c:40-54): 8 flags 
 
 // text of a read against a reference string: letters are literal bases, digits a run of matching bases
 // (decompress.c:573-590); the missing tail matches
-void decode_line(const char *txt, size_t n, const char *ref, int L, std::string &seq)
+// The archive is untrusted input: a digit run that would read past the L bases of the reference string, a character
+// that is neither a base letter nor a digit, or a line that decodes to more than L bases is an error, not a crash.
+bool decode_line(const char *txt, size_t n, const char *ref, int L, std::string &seq)
 {
 	seq.clear();
-	int eq = 0;
+	long eq = 0;
 	for (size_t i = 0; i < n; ++i) {
 		const char ch = txt[i];
 		if (ch >= 'A' && ch <= 'Z') {
-			for (int j = 0; j < eq; ++j) seq.push_back(ref[seq.size()]);
+			if ((long)seq.size() + eq + 1 > (long)L) return false;
+			for (long j = 0; j < eq; ++j) seq.push_back(ref[seq.size()]);
 			eq = 0;
 			seq.push_back(ch);
-		} else eq = eq * 10 + (ch - '0');
+		} else if (ch >= '0' && ch <= '9') {
+			eq = eq * 10 + (ch - '0');
+			if (eq > (long)L) return false;
+		} else return false;
 	}
 	while ((int)seq.size() < L) seq.push_back(ref[seq.size()]);
+	return (int)seq.size() == L;
+}
+
+size_t file_bytes(const std::string &path)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return 0;
+	fseek(f, 0, SEEK_END); const long n = ftell(f); fclose(f);
+	return n > 0 ? (size_t)n : 0;
 }
 
 void revcomp(std::string &s)
@@ -61,7 +76,7 @@ void revcomp(std::string &s)
 
 } // namespace
 
-extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads)
+static int decompress_impl(const char *folder, const char *out_path, uint64_t *n_reads)
 {
 	if (!folder || !out_path) return -1;
 	const std::string dir(folder);
@@ -70,7 +85,7 @@ extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64
 	int L = 0, nth = 0; long na = 0, nt = 0, nn = 0;
 	if (fscanf(fi, "%d %d %ld %ld %ld", &L, &nth, &na, &nt, &nn) != 5) { fclose(fi); return -1; }
 	fclose(fi);
-	if (L < 1 || L > 256 || nth < 1) return -1;
+	if (L < 1 || L > 256 || nth < 1 || nth > 4096 || na < 0 || nt < 0 || nn < 0) return -1;
 	FILE *out = fopen(out_path, "w");
 	if (!out) return -1;
 	uint64_t total = 0;
@@ -87,11 +102,11 @@ extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64
 		if (!slurp(dir + "/" + names[q], buf)) { fclose(out); return -1; }
 		const std::string cref((size_t)L, bases[q]);
 		size_t s = 0;
-		for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); line(seq); s = i + 1; }
+		for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { if (!decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq)) { fclose(out); return -1; } line(seq); s = i + 1; }
 	}
 	// reads kept as text because they contain N
 	if (!slurp(dir + "/single_N.seq", buf)) { fclose(out); return -1; }
-	{ size_t s = 0; for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { line(std::string((const char*)buf.data() + s, i - s)); s = i + 1; } }
+	{ size_t s = 0; for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { if (i - s != (size_t)L) { fclose(out); return -1; } line(std::string((const char*)buf.data() + s, i - s)); s = i + 1; } }
 	// unclustered reads, 2 bits per base (:612-644); a trailing partial byte carries no complete read
 	if (!slurp(dir + "/single.seq", buf)) { fclose(out); return -1; }
 	{
@@ -124,7 +139,7 @@ extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64
 				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) { fclose(out); return -1; } ref.push_back("ACGT"[c]); }   // getRef (:92-100)
 				const int rev = dr.next();
 				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
-				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				if (e >= bdif.size() || !decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq)) { fclose(out); return -1; }
 				dp = e + 1;
 				if (rev) revcomp(seq);
 				line(seq);
@@ -141,7 +156,7 @@ extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64
 // the reads are rebuilt into a table indexed by their original position and written out in that order.  Id streams
 // are uint32, delta coded inside a list (lists are sorted by id); in ids.bin.T a member carries its id when it is the
 // first of its contig or starts at a new position, else the difference to the previous member's id (:164-167).
-extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, uint64_t *n_reads)
+static int decompress_order_impl(const char *folder, const char *out_path, uint64_t *n_reads)
 {
 	if (!folder || !out_path) return -1;
 	const std::string dir(folder);
@@ -150,7 +165,13 @@ extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, 
 	int L = 0, nth = 0; long na = 0, nt = 0, nn = 0; unsigned long n_seq = 0;
 	if (fscanf(fi, "%d %d %ld %ld %ld %lu", &L, &nth, &na, &nt, &nn, &n_seq) != 6) { fclose(fi); return -1; }
 	fclose(fi);
-	if (L < 1 || L > 256 || nth < 1) return -1;
+	if (L < 1 || L > 256 || nth < 1 || nth > 4096 || na < 0 || nt < 0 || nn < 0) return -1;
+	{   // every read of this mode has a 4-byte entry in one of the id streams: n_seq cannot exceed what they hold
+		size_t idb = 0;
+		for (const char *nm : {"allA.ids.bin", "allT.ids.bin", "allN.ids.bin", "AA.ids.bin", "TT.ids.bin", "NN.ids.bin", "singleFile.ids.bin", "Nfile.ids.bin"}) idb += file_bytes(dir + "/" + nm);
+		for (int th = 0; th < nth; ++th) idb += file_bytes(dir + "/ids.bin." + std::to_string(th));
+		if ((size_t)n_seq > idb / 4) return -1;
+	}
 	std::vector<char> table((size_t)n_seq * (size_t)L, 0);
 	std::vector<uint8_t> seen((size_t)n_seq, 0);
 	bool bad = false;
@@ -182,7 +203,8 @@ extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, 
 			const std::string cref((size_t)L, bases[q]);
 			size_t s = 0;
 			for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') {
-				decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); s = i + 1;
+				if (!decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq)) return -1;
+				s = i + 1;
 				if (!ids.next(idx)) return -1;
 				put(idx, seq);
 			}
@@ -230,7 +252,7 @@ extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, 
 				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) return -1; ref.push_back("ACGT"[c]); }
 				const int rev = dr.next();
 				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
-				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				if (e >= bdif.size() || !decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq)) return -1;
 				dp = e + 1;
 				if (rev) revcomp(seq);
 				put(id & 0xFFFFFFFFull, seq);
@@ -251,7 +273,7 @@ extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, 
 // Reads of the first file are written to out_path1 in stream order (the eight lists, then the contig members); a read
 // of the second file carries the line number of its mate (peids streams, one file bit per read says which kind a
 // read is) and goes to that line of out_path2: line i of the two outputs is a pair.
-extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, const char *out_path2, uint64_t *n_pairs)
+static int decompress_pe_impl(const char *folder, const char *out_path1, const char *out_path2, uint64_t *n_pairs)
 {
 	if (!folder || !out_path1 || !out_path2) return -1;
 	const std::string dir(folder);
@@ -260,7 +282,12 @@ extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, co
 	int L = 0, nth = 0; long half = 0, na = 0, nt = 0, nn = 0;
 	if (fscanf(fi, "%d %d %ld %ld %ld %ld", &L, &nth, &half, &na, &nt, &nn) != 6) { fclose(fi); return -1; }
 	fclose(fi);
-	if (L < 1 || L > 256 || nth < 1 || half < 0) return -1;
+	if (L < 1 || L > 256 || nth < 1 || nth > 4096 || half < 0 || na < 0 || nt < 0 || nn < 0) return -1;
+	{   // every read has one bit in a file.bin stream: the number of pairs cannot exceed what they hold
+		size_t fbb = file_bytes(dir + "/file.bin.sp");
+		for (int th = 0; th < nth; ++th) fbb += file_bytes(dir + "/file.bin." + std::to_string(th));
+		if ((size_t)half > fbb * 8) return -1;
+	}
 	std::vector<char> table((size_t)half * (size_t)L, 0);
 	std::vector<uint8_t> seen((size_t)half, 0);
 	FILE *out = fopen(out_path1, "w");
@@ -291,7 +318,7 @@ extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, co
 			if (!slurp(dir + "/" + names[q], buf)) { fclose(out); return -1; }
 			const std::string cref((size_t)L, bases[q]);
 			size_t s = 0;
-			for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq); s = i + 1; place(sp, seq); }
+			for (size_t i = 0; i < buf.size(); ++i) if (buf[i] == '\n') { if (!decode_line((const char*)buf.data() + s, i - s, cref.c_str(), L, seq)) { fclose(out); return -1; } s = i + 1; place(sp, seq); }
 		}
 	}
 	if (!slurp(dir + "/single_N.seq", buf)) { fclose(out); return -1; }
@@ -327,7 +354,7 @@ extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, co
 				while ((int)ref.size() < pos + L) { const int c = rr.next(); if (c < 0) { fclose(out); return -1; } ref.push_back("ACGT"[c]); }
 				const int rev = dr.next();
 				size_t e = dp; while (e < bdif.size() && bdif[e] != '\n') ++e;
-				decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq);
+				if (e >= bdif.size() || !decode_line((const char*)bdif.data() + dp, e - dp, ref.c_str() + pos, L, seq)) { fclose(out); return -1; }
 				dp = e + 1;
 				if (rev) revcomp(seq);
 				place(pr, seq);
@@ -343,4 +370,22 @@ extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, co
 	fclose(out2);
 	if (n_pairs) *n_pairs = (uint64_t)half;
 	return 0;
+}
+
+// no C++ exception crosses the C boundary (a corrupt info.txt can ask for more memory than there is)
+extern "C" int mcomh_decompress(const char *folder, const char *out_path, uint64_t *n_reads)
+{
+	try { return decompress_impl(folder, out_path, n_reads); } catch (...) { return -1; }
+}
+
+// no C++ exception crosses the C boundary (a corrupt info.txt can ask for more memory than there is)
+extern "C" int mcomh_decompress_order(const char *folder, const char *out_path, uint64_t *n_reads)
+{
+	try { return decompress_order_impl(folder, out_path, n_reads); } catch (...) { return -1; }
+}
+
+// no C++ exception crosses the C boundary (a corrupt info.txt can ask for more memory than there is)
+extern "C" int mcomh_decompress_pe(const char *folder, const char *out_path1, const char *out_path2, uint64_t *n_pairs)
+{
+	try { return decompress_pe_impl(folder, out_path1, out_path2, n_pairs); } catch (...) { return -1; }
 }

@@ -23,12 +23,17 @@ class SeqReader {
 	gzFile f_;
 	std::vector<unsigned char> buf_;
 	size_t pos_ = 0, end_ = 0;
-	bool eof_ = false;
+	bool eof_ = false, io_error_ = false;
 	int last_ = 0;                         // the '>' or '@' that starts the next record, once seen
 	bool fill() {
 		if (eof_) return false;
 		const int n = gzread(f_, buf_.data(), (unsigned)buf_.size());
-		if (n <= 0) { eof_ = true; pos_ = end_ = 0; return false; }
+		if (n <= 0) {
+			// a clean end of file has n == 0 and gzeof() set; anything else is a read error or a truncated / corrupt gzip stream
+			int zerr = 0; (void)gzerror(f_, &zerr);
+			if (n < 0 || !gzeof(f_) || (zerr != Z_OK && zerr != Z_STREAM_END)) io_error_ = true;
+			eof_ = true; pos_ = end_ = 0; return false;
+		}
 		pos_ = 0; end_ = (size_t)n; return true;
 	}
 	int getc() { if (pos_ >= end_ && !fill()) return -1; return buf_[pos_++]; }
@@ -48,8 +53,18 @@ class SeqReader {
 	}
 public:
 	explicit SeqReader(gzFile f) : f_(f), buf_((size_t)4 << 20) {}
-	// 1 = a record was read into seq, 0 = end of file, -1 = malformed (quality string shorter than the sequence)
+	bool io_error() const { return io_error_; }
+	// 1 = a record was read into seq, 0 = end of file, -1 = malformed (quality string shorter than the sequence, read error,
+	// truncated gzip stream), -2 = a sequence character outside ACGTN (the archive could not give it back: the packed rows
+	// hold two bits per base plus an N mask, so lower-case and IUPAC codes are refused instead of silently changed)
 	int next(std::string &seq) {
+		const int st = next_record(seq);
+		if (io_error_) return -1;
+		if (st == 1) for (const char ch : seq) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') return -2;
+		return st;
+	}
+private:
+	int next_record(std::string &seq) {
 		seq.clear();
 		int c = last_;
 		if (!c) { while ((c = getc()) != -1 && c != '>' && c != '@') {} if (c == -1) return 0; }
@@ -155,7 +170,8 @@ extern "C" int mcomh_fastq_to_device(const char *path, int device, int *L, size_
 		memcpy(ch[cur].p + in_chunk * (size_t)*L, seq.data(), (size_t)*L);
 		if (++in_chunk == chunk_reads && (rc = flush(false))) { fail(rc, "upload failed"); break; }
 	}
-	if (!rc && st < 0) rc = fail(MCOM_E_ARG, "malformed record (quality string shorter than the sequence)");
+	if (!rc && st == -2) rc = fail(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)");
+	if (!rc && st < 0) rc = fail(MCOM_E_ARG, rd.io_error() ? "read error or truncated / corrupt gzip stream" : "malformed record (quality string shorter than the sequence)");
 	if (!rc && (rc = flush(true))) fail(rc, "upload failed");
 	if (!rc && cs && hipStreamSynchronize(cs) != hipSuccess) rc = fail(MCOM_E_HIP, "upload failed");
 	cleanup();

@@ -279,11 +279,10 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->rw = L >= 70 ? L / 2 - p->k : 3;                                             // preprocess.c:89-107
 	if (pp->w > 0) p->rw = pp->w;
 	p->numdict = pp->numdict;
-	{ const char *ws = getenv("MCOMH_WINDOW_SCAN"); p->window_scan = ws && ws[0] == '1'; }
-	{ const char *fc = getenv("MCOMH_FULL_CONSENSUS"); p->full_consensus = fc && fc[0] == '1'; }   // A/B switch for measurements
-	{ const char *fs = getenv("MCOMH_FULL_SKETCH"); p->resketch = !(fs && fs[0] == '1'); }               // A/B switch: sketch merged contigs whole
-	// test hook: the reference fixes maxsearch at 500 / 2000; a small value lets a small input exercise the cut of long bins
-	{ const char *mv = getenv("MCOMH_MAXSEARCH"); p->maxsearch_forced = mv ? atoi(mv) : 0; }
+	p->window_scan = pp->window_scan == 1;
+	p->full_consensus = pp->full_consensus == 1;
+	p->resketch = pp->full_sketch != 1;
+	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
 	if (host_reads) {
@@ -361,6 +360,8 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 	// the classes travel while the bucket stage starts; a thread sorts the special reads into their lists (rid order) once
 	// they have arrived -- nobody reads those lists before Stage 2
 	p->join_cls();
+	p->cls_failed = false;
+	for (std::vector<uint32_t> *v : {&p->allA, &p->allT, &p->allN, &p->fpA, &p->fpT, &p->fpN, &p->Nfile}) v->clear();   // a second call must not append twice
 	if (!p->ev_cls && (rc = p->hipc(hipEventCreateWithFlags(&p->ev_cls, hipEventDisableTiming), "event"))) return rc;
 	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->hipc(hipEventRecord(p->ev_cls, p->stream), "event"))) return rc;
 	p->cls_thread = std::thread([p, n]() {
@@ -917,6 +918,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
 	p->join_sg();
+	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
 	{ const double tu = now_ms(); mcomh_update_single(p); p->stat["t_ra_update"] += now_ms() - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
@@ -1081,6 +1083,7 @@ static void dump_buckets(FILE *f, const char *name, const std::vector<mcom_mm128
 static int run_stage2(P *p, FILE *f)
 {
 	p->join_sg();
+	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	long pre = 0; int pass = 0;
 	for (int thr = p->e;; thr += p->step) {                                                 // preprocess.c:197-232
 		if (thr > p->maxthr) break;
@@ -1190,6 +1193,7 @@ extern "C" const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t 
 extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n)
 {
 	const_cast<mcomh_pipeline*>(p)->join_sg();
+	if (p->cls_failed) { const_cast<mcomh_pipeline*>(p)->fail(MCOM_E_HIP, "the read classes did not arrive from the device"); if (n) *n = 0; return nullptr; }
 	const std::vector<uint32_t> *v = nullptr;
 	if (!strcmp(name, "allA")) v = &p->allA; else if (!strcmp(name, "allT")) v = &p->allT; else if (!strcmp(name, "allN")) v = &p->allN;
 	else if (!strcmp(name, "fpA")) v = &p->fpA; else if (!strcmp(name, "fpT")) v = &p->fpT; else if (!strcmp(name, "fpN")) v = &p->fpN;
@@ -1263,6 +1267,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
 	p->join_sg();
+	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	{ int rcm = materialize(p); if (!rcm) rcm = ensure_host_contigs(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
 	const size_t n = p->n;

@@ -144,7 +144,7 @@ def _repeat_pileup_reads(seed, L, n_clean, n_noisy, starts=None):
 
 
 @pytest.mark.parametrize("L,maxsearch", [(100, 2), (150, 3), (100, 7)])
-def test_stage2_bins_longer_than_maxsearch_follow_the_sequential_scan(monkeypatch, L, maxsearch):
+def test_stage2_bins_longer_than_maxsearch_follow_the_sequential_scan(L, maxsearch):
     """The reference scans the last `maxsearch` LIVE reads of a bin and removes claimed reads from every bin after the
     visit (kthread_hash_realign.c:388, :420-435): which reads a visit sees depends on what was claimed before.  With
     the limit forced low (test hook on both sides) the pipeline must still equal the sequential oracle."""
@@ -152,8 +152,7 @@ def test_stage2_bins_longer_than_maxsearch_follow_the_sequential_scan(monkeypatc
     from minicom_amd.pipeline import Pipeline
     reads = _repeat_pileup_reads(9000 + L + maxsearch, L, 2400, 2500)
     o = oracle.Pipeline(reads); o.force_maxsearch(maxsearch); o.run_all()
-    monkeypatch.setenv("MCOMH_MAXSEARCH", str(maxsearch))
-    p = Pipeline(reads, host_threads=4); p.pre_process()
+    p = Pipeline(reads, host_threads=4, maxsearch=maxsearch); p.pre_process()
     assert p.stat("maxsearch") == maxsearch == o.counter("maxsearch")
     assert p.stat("big_bins") > 0 and p.stat("big_bin_claims") > 0 and p.stat("big_bin_deferred") > 0
     oc, pc = o.contigs(), p.contigs()

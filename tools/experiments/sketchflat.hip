@@ -1,4 +1,5 @@
-// minicom_amd/csrc/sketchflat.hip -- mm_sketch_lh_ori (reference sketch.c:116-165) for the regular case, one thread per
+// tools/experiments/sketchflat.hip -- NOT PART OF THE PRODUCT (not compiled into libmcom_hip.so): a measured dead end kept for reference.
+// mm_sketch_lh_ori (reference sketch.c:116-165) for the regular case, one thread per
 // contig POSITION instead of one wave per contig.
 //
 // Regular = k odd and no ambiguous base in any contig (what every contig of the pipeline is: consensus strings are
@@ -18,9 +19,9 @@
 //
 // MEASURED (round 1, 100 M reads): bit-exact, and as fast as the wave-per-contig kernel but not faster (80 ms per step
 // either way: 8 VALU wave-instructions per position here -- hash 3, sparse table 3, emission rules 2 -- against 15 there,
-// but at a lower issue rate).  Kept as an opt-in alternative (MCOM_SKETCH_FLAT=1); a cheaper window minimum than the
+// but at a lower issue rate).  Removed from the library in round 2; a cheaper window minimum than the
 // log2(w)-level table is what would make it win.
-#include "mcom_dev.hpp"
+#include "../../minicom_amd/csrc/mcom_dev.hpp"
 #include <vector>
 #include <algorithm>
 
