@@ -238,6 +238,11 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
 int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines);
 int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                       uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys);
+/* mcom_cindex_build for contigs [c0, c1) of the set only: the multi-GPU path gives every rank a range of the replicated
+ * contig set (size the index with mcom_cindex_plan(windows of the range, c1 - c0, ...)); entries carry the global
+ * contig index, so that claim keys found against different ranks' parts are comparable.                        */
+int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                            uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys);
 int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
 /* Screen before mcom_dicts_build: *h_may_exceed = 0 proves that no bin of any dictionary over these singletons
  * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
@@ -369,6 +374,23 @@ int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d
 int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
                          const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
                          uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars);
+
+/* ---- multi-GPU helpers (no reference counterpart: the reference is a shared-memory program) ---- */
+/* Stable partition of n records by the rank that owns their minimizer bucket: bucket beta = x & (2^b - 1) belongs to
+ * rank (beta * ranks) >> b -- contiguous bucket ranges in rank order, so that rank-major order is the reference's
+ * bucket-ascending visiting order (kthread_bucket.c:531-560).  Records without a minimizer (x = UINT64_MAX) are dropped.
+ * d_out: the records grouped by owner, each group in input order; h_counts[ranks] (HOST).  Synchronous.           */
+int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int b, int ranks, mcom_mm128 *d_out, uint64_t *h_counts);
+/* stable sort by read id (y >> 32): the parts received from several senders, each in rid order, become the rid-ordered
+ * list mcom_sort_group expects                                                                                    */
+int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
+/* d_out[i] = min over q < n_parts of d_parts[q * stride + i]: folds the ranks' shares of the Stage-2 claim keys      */
+int mcom_min_fold_u64(mcom_ctx *ctx, const uint64_t *d_parts, int n_parts, size_t stride, size_t n, uint64_t *d_out);
+/* *h_max = largest element (0 for n = 0).  Synchronous.                                                             */
+int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32_t *h_max);
+/* records sketched for contigs [first_contig, ...) of a set as if they were contigs 0, 1, ...: ids += first_contig << 8;
+ * their n_off record offsets += first_record                                                                        */
+int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_rec, uint32_t first_contig, uint32_t *d_roff, size_t n_off, uint32_t first_record);
 
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,

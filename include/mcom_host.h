@@ -103,6 +103,60 @@ int mcomh_fastq_read(const char *path, int *L, uint8_t *out, size_t cap_reads, s
 int mcomh_fastq_to_device(const char *path, int device, int *L, size_t chunk_reads, uint8_t **d_reads, size_t *n, char *err, size_t err_cap);
 void mcomh_device_free(void *d_ptr);
 
+/* ---- multi-GPU: one process per GPU, reads sharded, results identical to the single-process run ----
+ * The reference is a shared-memory program (pthreads, kthread_*.c); it has no communication layer to mirror, so this
+ * is new interface.  A communicator carries ONE primitive, a byte-wise all-to-all with per-peer offsets and sizes
+ * (everything else -- all-gather, the sums / minima of a few counters, the MIN-reduction of the Stage-2 claim keys --
+ * is built on it), over one of two transports:
+ *   RCCL      ncclSend / ncclRecv between ncclGroupStart / ncclGroupEnd on the pipeline's HIP stream: every peer pair
+ *             talks over its own xGMI link, no ring.  Messages are cut at 256 MiB.  librccl.so.1 is loaded on first use.
+ *   callbacks the caller supplies the all-to-all for HOST buffers (MPI_Alltoallv, torch.distributed over gloo, ...);
+ *             device data is staged through pinned memory.  This is what the multi-process tests use on one GPU.
+ * All collective calls are synchronous and must be made by every rank in the same order.                            */
+typedef struct mcomh_comm mcomh_comm;
+#define MCOMH_UNIQUE_ID_BYTES 128
+typedef struct {
+	/* send + send_off[q] .. + send_bytes[q] goes to rank q; what rank q sent to this rank arrives at recv + recv_off[q]
+	 * (recv_bytes[q] bytes; sizes agree pairwise).  Host memory.  Returns 0 on success.                              */
+	int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes,
+	                 void *recv, const uint64_t *recv_off, const uint64_t *recv_bytes);
+} mcomh_comm_ops;
+/* rank 0 makes the id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by any means it has */
+int  mcomh_comm_unique_id(void *id128);
+int  mcomh_comm_create_rccl(mcomh_comm **out, int rank, int world, const void *id128, int device);
+int  mcomh_comm_create_ops(mcomh_comm **out, int rank, int world, const mcomh_comm_ops *ops, void *user);
+void mcomh_comm_destroy(mcomh_comm *c);
+int  mcomh_comm_rank(const mcomh_comm *c);
+int  mcomh_comm_world(const mcomh_comm *c);
+const char *mcomh_comm_last_error(const mcomh_comm *c);
+/* the primitive and what is built on it; on_device: the buffers are HBM pointers (ordered behind hip_stream's work)  */
+int  mcomh_comm_alltoallv(mcomh_comm *c, const void *send, const uint64_t *send_off, const uint64_t *send_bytes,
+                          void *recv, const uint64_t *recv_off, const uint64_t *recv_bytes, int on_device, void *hip_stream);
+/* rank q's part lies at buf + off[q] (bytes[q] bytes) on every rank afterwards; send = NULL: this rank's part is
+ * already in place                                                                                                  */
+int  mcomh_comm_allgatherv(mcomh_comm *c, const void *send, void *buf, const uint64_t *off, const uint64_t *bytes,
+                           int on_device, void *hip_stream);
+/* element-wise over n host values: op 0 = sum, 1 = min, 2 = max                                                     */
+int  mcomh_comm_allreduce_u64(mcomh_comm *c, uint64_t *vals, size_t n, int op);
+/* bytes this rank has sent to OTHER ranks so far, and the number of all-to-alls                                     */
+void mcomh_comm_stats(const mcomh_comm *c, uint64_t *bytes_sent, uint64_t *calls);
+
+/* The distributed pipeline: this rank holds reads [rid0, rid0 + n_local) of n_total (shards are contiguous, in rank
+ * order, and cover [0, n_total); paired end: the second file's reads follow the first file's, as in mcomh_create).
+ * Every stage function below works as for one GPU and must be called by all ranks; afterwards EVERY rank holds the
+ * complete result (contig set, lists), identical to what mcomh_create + the same calls give on one GPU over all reads:
+ *   kt_for_reads     shard-local classify / pack / sketch; packed rows, classes and N masks all-gathered
+ *   kt_for_bucket    per round the minimizer records go to the owner of their bucket (bucket ranges in rank order, so
+ *                    that rank-major = the reference's visiting order; rejects re-sketched with k-r move again,
+ *                    kthread_bucket.c:205-212, :489-496); new contigs are all-gathered into the replicated set
+ *   combine_cluster  replicated set; contig sketching and the candidate evaluation of find_next sharded by contig
+ *   realign_hash     contig 17-mer index sharded by contig range, every rank probes all singletons against its part,
+ *                    claim keys MIN-reduced (the claim is a minimum)
+ * comm is borrowed: it must outlive the pipeline.                                                                    */
+int  mcomh_create_dist(mcomh_pipeline **out, int device, void *hip_stream, mcomh_comm *comm, const uint8_t *host_reads,
+                       const uint8_t *d_reads, size_t pitch, size_t n_local, uint64_t rid0, uint64_t n_total, int L,
+                       const mcomh_params *p);
+
 /* results */
 size_t mcomh_n_contigs(const mcomh_pipeline *p);
 const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len);   /* consensus, NOT NUL-terminated */

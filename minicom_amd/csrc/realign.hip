@@ -432,29 +432,30 @@ extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, i
 }
 
 // first_contig[b] = the contig that owns position 256*b: contig c writes the entries of the block starts inside its own
-// range (a search per block -- nineteen dependent loads by one thread while 255 wait -- was a third of the insert's time)
-__global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_blocks, uint32_t *__restrict__ first_contig)
+// range (a search per block -- nineteen dependent loads by one thread while 255 wait -- was a third of the insert's time).
+// Positions are counted from pos0 = the first position of contig c0: a rank of the multi-GPU path indexes contigs [c0, c1).
+__global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, uint32_t c0, uint32_t c1, uint64_t pos0, uint64_t n_blocks, uint32_t *__restrict__ first_contig)
 {
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= n_contigs) return;
-	const uint64_t a = woff[c] + (uint64_t)maxoff * c, b = woff[c + 1] + (uint64_t)maxoff * (c + 1);
+	const uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= c1) return;
+	const uint64_t a = woff[c] + (uint64_t)maxoff * c - pos0, b = woff[c + 1] + (uint64_t)maxoff * (c + 1) - pos0;
 	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
 }
 
 // position space: contig c owns [woff[c] + maxoff*c, woff[c+1] + maxoff*(c+1)); positions p = 0 .. nw-1+maxoff of a
 // contig with nw > 0 windows are indexed, the maxoff phantom positions of a contig without windows are skipped
 __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
-                                                       const uint64_t *__restrict__ woff, uint32_t n_contigs, uint64_t n_pos,
+                                                       const uint64_t *__restrict__ woff, uint32_t c1, uint64_t pos0, uint64_t n_pos,
                                                        const uint32_t *__restrict__ first_contig, unsigned long long *__restrict__ keys)
 {
 	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
 	const uint64_t gi = g0 + threadIdx.x;
 	if (gi >= n_pos) return;
 	uint32_t c = first_contig[blockIdx.x];                                  // k_cindex_blocks: no search, no barrier
-	while (c + 1 < n_contigs && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) <= gi) ++c;
+	while (c + 1 < c1 && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) - pos0 <= gi) ++c;
 	const uint64_t nw = woff[c + 1] - woff[c];
 	if (nw == 0) return;
-	const uint64_t p = gi - (woff[c] + (uint64_t)g.maxoff * c);
+	const uint64_t p = gi - (woff[c] + (uint64_t)g.maxoff * c - pos0);
 	const uint64_t *src = cbits + coff[c] + ((2 * p) >> 6);
 	const int sh = (int)((2 * p) & 63);
 	uint64_t v = src[0] >> sh;
@@ -482,32 +483,48 @@ __global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t
 	}
 }
 
-extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
+// contigs [c0, c1) of the set only (the whole set: 0, n_contigs): the multi-GPU path gives every rank a range of the
+// replicated contig set; entries carry the GLOBAL contig index, so claim keys of different ranks are comparable
+extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                       uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
 {
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
 	if (!d_keys || log2lines < 4 || log2lines > 31) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
 	g.log2lines = log2lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
 	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, (8ull << log2lines) * 8, ctx->stream));
-	if (n_contigs == 0 || n_windows == 0) return MCOM_OK;
+	if (c0 == c1) return MCOM_OK;
 	if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n_contigs >= (1u << CIX_CBITS) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the index slots");
-	const uint64_t n_pos = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;
+	uint64_t w01[2] = {0, 0};
+	MCOM_HIP(ctx, hipMemcpyAsync(&w01[0], d_woff + c0, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&w01[1], d_woff + c1, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (w01[1] == w01[0]) return MCOM_OK;
+	const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
+	const uint64_t n_pos = (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff;
 	if ((8ull << log2lines) * 7 < n_pos * 8) return mcom_fail(ctx, MCOM_E_ARG, "contig index too small: %llu entries", (unsigned long long)n_pos);
 	const uint64_t blocks = (n_pos + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions for one launch");
 	int rcw = mcom_ws_reserve(ctx, blocks * 4 + 256);
 	if (rcw) return rcw;
 	uint32_t *first_contig = (uint32_t*)ctx->ws;
-	hipLaunchKernelGGL(k_cindex_blocks, dim3((n_contigs + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, n_contigs, blocks, first_contig);
+	hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks, first_contig);
 	MCOM_LAUNCH_CHECK(ctx);
-	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, n_contigs, n_pos, first_contig,
+	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, c1, pos0, n_pos, first_contig,
 	                   (unsigned long long*)d_keys);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
+}
+
+extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
+{
+	(void)n_windows;                                                       // = d_woff[n_contigs]; read from the device
+	return mcom_cindex_build_range(ctx, d_cbits, d_coff, d_woff, n_contigs, 0, n_contigs, L, ininumdict, log2lines, d_keys);
 }
 
 // which dictionaries may still see a singleton when bins are cut at maxsearch: the window scan walks a bin from its

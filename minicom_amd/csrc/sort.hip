@@ -17,7 +17,8 @@
 #define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 records = 64 KiB staged in LDS
 
 struct KeySpec {
-	int mode;       // 0: key = x (64 bits);  1: composite minimizer key
+	int mode;       // 0: key = x (64 bits);  1: composite minimizer key;  2: low kbits of x;  3: owner rank of the bucket
+	                // (b bucket bits, kbits = number of ranks; records without a minimizer get the digit `ranks`);  4: read id
 	int b;          // bucket bits
 	int kbits;      // 2 * k of the sketch that produced x
 	int L, k_orig;  // for the aligned position of cmpcluster
@@ -28,6 +29,8 @@ __device__ __forceinline__ void make_key(const KeySpec &ks, uint64_t x, uint64_t
 {
 	if (ks.mode == 0) { lo = x; hi = 0; return; }
 	if (ks.mode == 2) { lo = x & ((1ull << ks.kbits) - 1); hi = 0; return; }   // only the low kbits of x (bucket id)
+	if (ks.mode == 3) { lo = x == U64MAX ? (uint64_t)ks.kbits : ((x & ((1ull << ks.b) - 1)) * (uint64_t)ks.kbits) >> ks.b; hi = 0; return; }
+	if (ks.mode == 4) { lo = y >> 32; hi = 0; return; }
 	if (x == U64MAX) { lo = U64MAX; hi = 0xFFFFFFFFu; return; }           // records without a minimizer sort last
 	const uint64_t bucket = x & ((1ull << ks.b) - 1);
 	const uint64_t K = (bucket << (ks.kbits - ks.b)) | (x >> ks.b);
@@ -257,6 +260,55 @@ int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, vo
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
+	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	return MCOM_OK;
+}
+
+// ---- multi-GPU exchange -------------------------------------------------------------------
+// Bucket beta = x & (2^b - 1) belongs to rank (beta * ranks) >> b: contiguous bucket ranges in rank order, so that
+// "rank 0's groups, then rank 1's, ..." is the reference's visiting order (buckets ascending, kthread_bucket.c:531-560).
+// One stable pass of the radix kernels on the owner digit; the scanned histogram gives the per-owner counts.
+extern "C" int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int b, int ranks, mcom_mm128 *d_out, uint64_t *h_counts)
+{
+	if (!ctx || !h_counts || ranks < 1 || ranks > 254 || b < 1 || b > 24) return MCOM_E_ARG;
+	for (int q = 0; q < ranks; ++q) h_counts[q] = 0;
+	if (n == 0) return MCOM_OK;
+	if (!d_rec || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-1 records");
+	const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+	const size_t hist_b = ((size_t)256 * nblocks * 4 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, hist_b + scan_scratch_elems((size_t)256 * nblocks) * 4 + 1024);
+	if (rc) return rc;
+	uint32_t *hist = (uint32_t*)ctx->ws, *scratch = (uint32_t*)((char*)ctx->ws + hist_b);
+	KeySpec ks{3, b, ranks, 0, 0};
+	{
+		McomProfScope ps_(ctx, PROF_RADIX_PASS);
+		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, n, ks, 0, hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = scan_u32(ctx, hist, hist, (size_t)256 * nblocks, scratch))) return rc;
+		hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, d_out, n, ks, 0, hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	std::vector<uint32_t> start((size_t)ranks + 1);
+	for (int q = 0; q <= ranks; ++q) MCOM_HIP(ctx, hipMemcpyAsync(&start[q], hist + (size_t)q * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int q = 0; q < ranks; ++q) h_counts[q] = start[q + 1] - start[q];
+	return MCOM_OK;
+}
+
+// records by read id ascending (stable): what a rank receives from R senders, each part in rid order, becomes one rid-ordered list
+extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_a) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-1 records");
+	int rc = mcom_ws_reserve(ctx, sort_ws_layout(n, nullptr, nullptr));
+	if (rc) return rc;
+	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
+	KeySpec ks{4, 0, 32, 0, 0};
+	mcom_mm128 *res = nullptr;
+	if ((rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 4, w.hist, w.scratch, &res))) return rc;
 	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
 	return MCOM_OK;
 }

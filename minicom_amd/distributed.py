@@ -1,113 +1,176 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL ("nccl") / gloo.
+"""ctypes binding of the multi-GPU entry points of libmcom_host.so (include/mcom_host.h, "multi-GPU").
 
-The path has ONE real exchange step: after every rank has sketched its shard of the
-reads, the 16-byte minimizer records -- here together with the 2-bit packed rows they belong to -- are
-redistributed so that minimizer bucket  beta = x & (2^b - 1)  lives on rank  beta mod R.  All reads that share
-a minimizer then sit on one rank, which runs the rest of the path (grouping, contigs, merging, realignment)
-on its partition without further data-path collectives.  Every rank therefore produces an independent
-archive of its partition: lossless for the union, not byte-identical to a single-process run (contigs never
-span partitions).
+One process per GPU.  The product code -- the exchange of minimizer records to the owners of their buckets every bucket
+round, the all-gathers of the replicated contig set, the MIN-reduction of the Stage-2 claim keys -- is C++
+(minicom_amd/host/mcom_comm.cpp, mcom_pipeline.cpp) over ONE primitive, a byte-wise all-to-all, with two transports:
 
-xGMI is point to point (7 links x ~153 GB/s per GPU): an all-to-all drives all links at once, each peer pair on
-its own link, so one large all_to_all_single per tensor is used, never a ring all-reduce of payload.
+  Comm.rccl(...)   ncclSend / ncclRecv groups over xGMI (every peer pair on its own link; no ring): production, bench.py
+  Comm.torch(...)  the all-to-all handed to the library as a callback over torch.distributed (gloo): what the tests use to
+                   run several ranks on one GPU, or on no GPU at all for the host-side collectives
 
-Everything here is torch-only plumbing (argsort / bincount / all_to_all_single), device agnostic, so the same
-code is exercised with gloo on CPU in tests/test_distributed_cpu.py.
+A DistPipeline gives, on every rank, exactly the result Pipeline gives on one GPU over all reads (tests/test_gpu_distributed.py).
 """
 from __future__ import annotations
 
-import torch
-import torch.distributed as dist
+import ctypes as C
+import traceback
 
-BUCKET_BITS = 14
+import numpy as np
 
+from .hip import McomError
+from .pipeline import Params, Pipeline, load_host_library
 
-def bucket_owner(x: torch.Tensor, world: int) -> torch.Tensor:
-    """Owner rank of every record: (x & 0x3fff) % world (x: int64 view of the unsigned hash)."""
-    return (x & ((1 << BUCKET_BITS) - 1)) % world
-
-
-# A single all_to_all_single message above about 1 GiB arrives HALF on this stack (RCCL of PyTorch 2.10 / ROCm 7.0,
-# measured on MI355X: 1024 MiB intact, 1536 MiB and more only the first half -- tools/dbg_a2a.py), without any error.
-# The exchange is therefore cut into slices whose per-peer messages stay far below that, and every slice is verified
-# with a checksum that travels beside it.
-MAX_MESSAGE_BYTES = 256 << 20
+UNIQUE_ID_BYTES = 128
+_u64p = C.POINTER(C.c_uint64)
+_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, _u64p, _u64p, C.c_void_p, _u64p, _u64p)
 
 
-def _checksums(rows_s: torch.Tensor, counts: list) -> torch.Tensor:
-    """Wrapping int64 sum of every per-peer segment of the send buffer."""
-    out, o = [], 0
-    for c in counts:
-        out.append(rows_s[o:o + c].sum() if c else rows_s.new_zeros(()))
-        o += c
-    return torch.stack(out)
+class _Ops(C.Structure):
+    _fields_ = [("alltoallv", _ALLTOALLV)]
 
 
-def exchange_by_bucket(rec_x: torch.Tensor, rids: torch.Tensor, rows: torch.Tensor, group=None, max_message_bytes: int = MAX_MESSAGE_BYTES,
-                       extras=None):
-    """All-to-all of the reads of this rank to the owners of their minimizer buckets.
+_bound = False
 
-    rec_x : int64 [n]     minimizer hash of every kept read of this rank
-    rids  : int64 [n]     global read ids
-    rows  : int64 [n, W]  packed rows
-    extras: optional list of 1-D tensors [n] that travel with the reads (e.g. the minimizer hash and position of every
-            read, so that the receiver need not sketch again); then a third result, the list of received tensors.
-    Returns (rids_recv int64 [m], rows_recv int64 [m, W]).  The reads travel in slices of the sender's order (so that no
-    message exceeds max_message_bytes); inside a slice they arrive ordered by source rank, then by the sender's order.
-    Raises RuntimeError when a slice does not arrive intact."""
-    world = dist.get_world_size(group)
-    n, W = int(rows.shape[0]), int(rows.shape[1])
-    owner_all = bucket_owner(rec_x, world)
-    # The cap is per MESSAGE (one peer's share of a slice).  Buckets are spread evenly, so a slice of `world` times the
-    # cap (taken at 0.6 of it) sends messages of about 0.6 cap: with eight ranks that is a sixth of the slices -- and of
-    # their argsorts, splits and read-backs -- that a cap on the whole slice would need.  The largest message any rank is
-    # about to send is agreed on first; a skewed slice is cut further, so the cap holds whatever the data.
-    per_slice = max(1, int(0.6 * (max_message_bytes // (8 * W))) * world)
-    rounds = torch.tensor([(n + per_slice - 1) // per_slice], dtype=torch.int64, device=rows.device)
-    dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
-    rounds = max(1, int(rounds.item()))
-    extras = list(extras) if extras is not None else None
-    out_rids, out_rows, out_extras = [], [], [[] for _ in (extras or [])]
-    for r in range(rounds):
-        lo0, hi0 = min(n, r * per_slice), min(n, (r + 1) * per_slice)
-        biggest = torch.bincount(owner_all[lo0:hi0], minlength=world).max().reshape(1).to(torch.int64) if hi0 > lo0 else torch.zeros(1, dtype=torch.int64, device=rows.device)
-        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
-        parts = max(1, -(-int(biggest.item()) * 8 * W // max_message_bytes))              # ceil: 1 unless the slice is skewed
-        for q in range(parts):
-            lo = lo0 + (hi0 - lo0) * q // parts
-            hi = lo0 + (hi0 - lo0) * (q + 1) // parts
-            owner = owner_all[lo:hi]
-            perm = torch.argsort(owner, stable=True)
-            send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-            recv_counts = torch.empty_like(send_counts)
-            dist.all_to_all_single(recv_counts, send_counts, group=group)
-            sc, rc = send_counts.tolist(), recv_counts.tolist()
-            m = int(sum(rc))
-            rids_s = rids[lo:hi][perm].contiguous()
-            rows_s = rows[lo:hi][perm].contiguous()
-            rids_r = torch.empty(m, dtype=rids.dtype, device=rids.device)
-            rows_r = torch.empty((m, W), dtype=rows.dtype, device=rows.device)
-            dist.all_to_all_single(rids_r, rids_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
-            dist.all_to_all_single(rows_r.view(-1), rows_s.view(-1), output_split_sizes=[c * W for c in rc],
-                                   input_split_sizes=[c * W for c in sc], group=group)
-            # what left must be what arrived
-            sums_s = _checksums(rows_s, sc) + _checksums(rids_s, sc)
-            sums_r = torch.empty_like(sums_s)
-            dist.all_to_all_single(sums_r, sums_s, group=group)
-            if not torch.equal(sums_r, _checksums(rows_r, rc) + _checksums(rids_r, rc)):
-                raise RuntimeError(f"minimizer-bucket exchange: slice {r}.{q} did not arrive intact (collective library fault)")
-            out_rids.append(rids_r); out_rows.append(rows_r)
-            for j, t in enumerate(extras or []):
-                t_s = t[lo:hi][perm].contiguous()
-                t_r = torch.empty(m, dtype=t.dtype, device=t.device)
-                dist.all_to_all_single(t_r, t_s, output_split_sizes=rc, input_split_sizes=sc, group=group)
-                cs_s = _checksums(t_s.to(torch.int64), sc)
-                cs_r = torch.empty_like(cs_s)
-                dist.all_to_all_single(cs_r, cs_s, group=group)
-                if not torch.equal(cs_r, _checksums(t_r.to(torch.int64), rc)):
-                    raise RuntimeError(f"minimizer-bucket exchange: slice {r}.{q}, extra {j} did not arrive intact (collective library fault)")
-                out_extras[j].append(t_r)
-    cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts)
-    if extras is not None:
-        return cat(out_rids), cat(out_rows), [cat(e) for e in out_extras]
-    return cat(out_rids), cat(out_rows)
+
+def _lib():
+    global _bound
+    L = load_host_library()
+    if not _bound:
+        vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.mcomh_comm_unique_id.restype = i32; L.mcomh_comm_unique_id.argtypes = [vp]
+        L.mcomh_comm_create_rccl.restype = i32; L.mcomh_comm_create_rccl.argtypes = [C.POINTER(vp), i32, i32, vp, i32]
+        L.mcomh_comm_create_ops.restype = i32; L.mcomh_comm_create_ops.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(_Ops), vp]
+        L.mcomh_comm_destroy.restype = None; L.mcomh_comm_destroy.argtypes = [vp]
+        L.mcomh_comm_rank.restype = i32; L.mcomh_comm_rank.argtypes = [vp]
+        L.mcomh_comm_world.restype = i32; L.mcomh_comm_world.argtypes = [vp]
+        L.mcomh_comm_last_error.restype = C.c_char_p; L.mcomh_comm_last_error.argtypes = [vp]
+        L.mcomh_comm_alltoallv.restype = i32; L.mcomh_comm_alltoallv.argtypes = [vp, vp, _u64p, _u64p, vp, _u64p, _u64p, i32, vp]
+        L.mcomh_comm_allgatherv.restype = i32; L.mcomh_comm_allgatherv.argtypes = [vp, vp, vp, _u64p, _u64p, i32, vp]
+        L.mcomh_comm_allreduce_u64.restype = i32; L.mcomh_comm_allreduce_u64.argtypes = [vp, _u64p, sz, i32]
+        L.mcomh_comm_stats.restype = None; L.mcomh_comm_stats.argtypes = [vp, _u64p, _u64p]
+        L.mcomh_create_dist.restype = i32
+        L.mcomh_create_dist.argtypes = [C.POINTER(vp), i32, vp, vp, vp, vp, sz, sz, C.c_uint64, C.c_uint64, i32, C.POINTER(Params)]
+        _bound = True
+    return L
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(_u64p)
+
+
+class Comm:
+    """A communicator of the library (mcomh_comm)."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self._h, self.rank, self.world, self._keep = handle, rank, world, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """ncclGetUniqueId: made by rank 0, handed to the other ranks by whatever means the job has."""
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        if _lib().mcomh_comm_unique_id(buf):
+            raise McomError("mcomh_comm_unique_id failed: no RCCL")
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, rank: int, world: int, unique_id: bytes, device: int):
+        h = C.c_void_p()
+        if _lib().mcomh_comm_create_rccl(C.byref(h), rank, world, C.c_char_p(unique_id), device):
+            raise McomError("mcomh_comm_create_rccl failed (see stderr)")
+        return cls(h, rank, world)
+
+    @classmethod
+    def torch(cls, group=None):
+        """The all-to-all over torch.distributed (any backend that moves CPU uint8 tensors: gloo)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def alltoallv(_user, send, so, sb, recv, ro, rb):
+            try:
+                sbl = [int(sb[q]) for q in range(world)]; rbl = [int(rb[q]) for q in range(world)]
+                parts = [np.frombuffer((C.c_uint8 * sbl[q]).from_address(send + int(so[q])), dtype=np.uint8) for q in range(world) if sbl[q]]
+                inp = torch.from_numpy(np.concatenate(parts)) if parts else torch.empty(0, dtype=torch.uint8)
+                out = torch.empty(sum(rbl), dtype=torch.uint8)
+                dist.all_to_all_single(out, inp, output_split_sizes=rbl, input_split_sizes=sbl, group=group)
+                o, at = out.numpy(), 0
+                for q in range(world):
+                    if rbl[q]:
+                        C.memmove(recv + int(ro[q]), o[at:at + rbl[q]].ctypes.data, rbl[q])
+                        at += rbl[q]
+                return 0
+            except Exception:                                                    # never let an exception cross the C boundary
+                traceback.print_exc()
+                return 1
+
+        cb = _ALLTOALLV(alltoallv)
+        ops = _Ops(cb)
+        h = C.c_void_p()
+        if _lib().mcomh_comm_create_ops(C.byref(h), rank, world, C.byref(ops), None):
+            raise McomError("mcomh_comm_create_ops failed")
+        return cls(h, rank, world, keep=(cb, ops))
+
+    def _check(self, rc):
+        if rc:
+            raise McomError(f"communicator error {rc}: {_lib().mcomh_comm_last_error(self._h).decode()}")
+
+    # host-side forms of the collectives (tests; numpy uint8 / uint64 arrays)
+    def alltoallv(self, send: np.ndarray, send_bytes, recv_bytes) -> np.ndarray:
+        send = np.ascontiguousarray(send, dtype=np.uint8)
+        sb, sbp = _u64(send_bytes); rb, rbp = _u64(recv_bytes)
+        so, sop = _u64(np.concatenate(([0], np.cumsum(sb)[:-1]))); ro, rop = _u64(np.concatenate(([0], np.cumsum(rb)[:-1])))
+        recv = np.zeros(int(rb.sum()), dtype=np.uint8)
+        self._check(_lib().mcomh_comm_alltoallv(self._h, send.ctypes.data_as(C.c_void_p), sop, sbp, recv.ctypes.data_as(C.c_void_p), rop, rbp, 0, None))
+        return recv
+
+    def allgatherv(self, mine: np.ndarray, sizes) -> np.ndarray:
+        mine = np.ascontiguousarray(mine, dtype=np.uint8)
+        b, bp = _u64(sizes)
+        off, offp = _u64(np.concatenate(([0], np.cumsum(b)[:-1])))
+        buf = np.zeros(int(b.sum()), dtype=np.uint8)
+        self._check(_lib().mcomh_comm_allgatherv(self._h, mine.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p), offp, bp, 0, None))
+        return buf
+
+    def allreduce(self, vals, op: str = "sum") -> np.ndarray:
+        v, vp = _u64(np.array(vals, dtype=np.uint64, copy=True))
+        self._check(_lib().mcomh_comm_allreduce_u64(self._h, vp, v.size, {"sum": 0, "min": 1, "max": 2}[op]))
+        return v
+
+    def stats(self):
+        b, c = C.c_uint64(), C.c_uint64()
+        _lib().mcomh_comm_stats(self._h, C.byref(b), C.byref(c))
+        return int(b.value), int(c.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().mcomh_comm_destroy(self._h)
+            self._h = None
+
+
+class DistPipeline(Pipeline):
+    """Stage 1 + Stage 2 over the GPUs of one node: this rank's shard of the reads in, the complete result on every rank.
+
+    reads: numpy uint8 [n_local, L] (host) or a torch uint8 CUDA tensor [n_local, pitch]: reads rid0 .. rid0 + n_local - 1
+    of n_total (shards contiguous, in rank order)."""
+
+    def __init__(self, reads, rid0: int, n_total: int, comm: Comm, L: int | None = None, device: int = 0, stream=None, **params):
+        self.lib = _lib()
+        p = Params(**{k: int(v) for k, v in params.items()})
+        h = C.c_void_p()
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(0)
+        self._keep = (reads, comm)
+        if isinstance(reads, np.ndarray):
+            reads = np.ascontiguousarray(reads, dtype=np.uint8)
+            n, L = reads.shape if reads.ndim == 2 and reads.shape[0] else (0, L)
+            assert L is not None
+            self._keep = (reads, comm)
+            rc = self.lib.mcomh_create_dist(C.byref(h), device, s, comm._h, reads.ctypes.data_as(C.c_void_p) if n else None, None, L, n, rid0, n_total, L, C.byref(p))
+        else:
+            assert reads.is_cuda and reads.is_contiguous() and L is not None
+            n, pitch = reads.shape
+            rc = self.lib.mcomh_create_dist(C.byref(h), device, s, comm._h, None, C.c_void_p(reads.data_ptr()), pitch, n, rid0, n_total, L, C.byref(p))
+        if rc:
+            raise McomError(f"mcomh_create_dist failed ({rc}): no usable GPU, bad arguments or shards that do not tile [0, n_total)")
+        self._h = h
+        self.n, self.L, self.n_local, self.rid0 = n_total, L, n, rid0

@@ -231,6 +231,14 @@ struct mcomh_pipeline {
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
 	std::map<std::string, double> stat;
+	// multi-GPU (include/mcom_host.h, mcomh_create_dist): this rank holds reads [rid0, rid0 + n_local) of n; packed rows,
+	// classes, N masks and -- from the bucket stage on -- the contig set are replicated on every rank
+	mcomh_comm *comm = nullptr; int rank = 0, world = 1;
+	size_t n_local = 0; uint64_t rid0 = 0;
+	std::vector<uint64_t> shard_lo;                                        // [world + 1] first read of every rank
+	std::vector<uint64_t> sg_round_len;                                    // this rank's singles + rejects per bucket round
+	bool sg_gathered = true;
+	uint32_t cix_c0 = 0, cix_c1 = 0;                                       // contigs whose 17-mers this rank indexes in Stage 2
 
 	int fail(int code, const char *fmt, ...) {
 		char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -251,6 +259,46 @@ using P = mcomh_pipeline;
 static int materialize(P *p);
 static int ensure_host_contigs(P *p, bool wait_data = true);
 static const char ACGT[] = "ACGT";
+
+// ---- multi-GPU plumbing: everything goes through the one all-to-all of host/mcom_comm.cpp ---------------------------
+static int comm_rc(P *p, int rc) { if (rc) p->err = std::string("communicator: ") + mcomh_comm_last_error(p->comm); return rc; }
+// k values of every rank, rank-major: all[q * k + i]
+static int gather_host(P *p, const uint64_t *mine, size_t k, std::vector<uint64_t> &all)
+{
+	const int R = p->world;
+	all.assign((size_t)R * k, 0);
+	std::vector<uint64_t> off(R), bytes(R);
+	for (int q = 0; q < R; ++q) { off[q] = (uint64_t)q * k * 8; bytes[q] = k * 8; }
+	if (k) memcpy(all.data() + (size_t)p->rank * k, mine, k * 8);
+	return comm_rc(p, mcomh_comm_allgatherv(p->comm, nullptr, all.data(), off.data(), bytes.data(), 0, p->stream));
+}
+// all-gather of a device array: rank q's part is elements [first[q], first[q] + cnt[q]); send = NULL: mine is in place
+template <class T> static int gatherv(P *p, T *buf, const std::vector<uint64_t> &first, const std::vector<uint64_t> &cnt, const T *send = nullptr)
+{
+	const int R = p->world;
+	std::vector<uint64_t> off(R), bytes(R);
+	for (int q = 0; q < R; ++q) { off[q] = first[q] * sizeof(T); bytes[q] = cnt[q] * sizeof(T); }
+	return comm_rc(p, mcomh_comm_allgatherv(p->comm, send, buf, off.data(), bytes.data(), 1, p->stream));
+}
+// Stage-2 claim keys: every rank holds the minimum over ITS contigs; the claim is the minimum over all.
+// Reduce-scatter by all-to-all (rank q folds slice q of everybody), then all-gather of the folded slices: direct
+// peer-to-peer traffic on every link, not a ring.
+static int dist_min_claims(P *p, uint64_t *d_claim, size_t n)
+{
+	const int R = p->world, me = p->rank;
+	if (R == 1 || n == 0) return MCOM_OK;
+	std::vector<uint64_t> lo(R + 1), so(R), sb(R), ro(R), rb(R), first(R), cnt(R);
+	for (int q = 0; q <= R; ++q) lo[q] = (uint64_t)n * q / R;
+	const uint64_t len = lo[me + 1] - lo[me];
+	DevBuf<uint64_t> parts;
+	if (!parts.reserve((size_t)R * len + 1)) return p->fail(MCOM_E_NOMEM, "claim shares");
+	for (int q = 0; q < R; ++q) { so[q] = lo[q] * 8; sb[q] = (lo[q + 1] - lo[q]) * 8; ro[q] = (uint64_t)q * len * 8; rb[q] = len * 8; first[q] = lo[q]; cnt[q] = lo[q + 1] - lo[q]; }
+	int rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, d_claim, so.data(), sb.data(), parts.p, ro.data(), rb.data(), 1, p->stream));
+	if (rc) return rc;
+	if ((rc = p->gpu(mcom_min_fold_u64(p->ctx, parts.p, R, (size_t)len, (size_t)len, d_claim + lo[me])))) return rc;
+	if ((rc = gatherv(p, d_claim, first, cnt))) return rc;
+	return p->sync("claim minimum");
+}
 
 // ----------------------------------------------------------------------------------------------------
 // construction
@@ -293,6 +341,30 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 		p->d_ascii = p->d_ascii_own.p;
 	} else { p->d_ascii = d_reads; p->pitch = pitch; }
 	*out = p;
+	return MCOM_OK;
+}
+
+extern "C" int mcomh_create_dist(mcomh_pipeline **out, int device, void *hip_stream, mcomh_comm *comm, const uint8_t *host_reads,
+                                 const uint8_t *d_reads, size_t pitch, size_t n_local, uint64_t rid0, uint64_t n_total, int L, const mcomh_params *pp)
+{
+	if (!out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (!comm || n_total >= (1ull << 32) || rid0 + n_local > n_total) return MCOM_E_ARG;
+	int rc = mcomh_create(out, device, hip_stream, host_reads, d_reads, pitch, n_local, L, pp);
+	if (rc) return rc;
+	P *p = *out;
+	p->comm = comm; p->rank = mcomh_comm_rank(comm); p->world = mcomh_comm_world(comm);
+	p->n_local = n_local; p->rid0 = rid0; p->n = (size_t)n_total;
+	std::vector<uint8_t>().swap(p->h_ascii);                                // a rank holds only its shard: no stage dump here
+	// the shards must be contiguous, in rank order, and cover [0, n_total): then "rank-major" is "rid ascending"
+	const uint64_t mine[2] = {rid0, (uint64_t)n_local};
+	std::vector<uint64_t> all;
+	if ((rc = gather_host(p, mine, 2, all))) { mcomh_destroy(p); *out = nullptr; return rc; }
+	p->shard_lo.assign((size_t)p->world + 1, 0);
+	uint64_t at = 0; bool ok = true;
+	for (int q = 0; q < p->world; ++q) { if (all[2 * q] != at) ok = false; p->shard_lo[q] = at; at += all[2 * q + 1]; }
+	p->shard_lo[p->world] = at;
+	if (!ok || at != n_total) { fprintf(stderr, "mcomh_create_dist: the shards are not contiguous in rank order or do not cover %llu reads\n", (unsigned long long)n_total); mcomh_destroy(p); *out = nullptr; return MCOM_E_ARG; }
 	return MCOM_OK;
 }
 
@@ -339,9 +411,13 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = now_ms();
-	const size_t n = p->n;
+	const size_t n = p->n;                                              // all reads of the job
+	const bool dist = p->comm != nullptr;
+	const size_t nl = dist ? p->n_local : n;                            // ... and those this rank classifies and sketches
+	const uint64_t r0 = dist ? p->rid0 : 0;
+	if (dist && p->ext_packed) return p->fail(MCOM_E_ARG, "packed-row input is a single-GPU entry");
 	if (!p->d_packed.reserve(n * p->W + 1) || !p->d_nmask.reserve(n * p->NW + 1) || !p->d_cls.reserve(n + 1) ||
-	    !p->d_ncnt.reserve(n + 1) || !p->d_rec.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "read buffers");
+	    !p->d_ncnt.reserve(nl + 1) || !p->d_rec.reserve(nl + 1)) return p->fail(MCOM_E_NOMEM, "read buffers");
 	int rc;
 	if (p->ext_packed) {
 		// packed rows handed over by the caller: every read is a kept read (class 0) without N
@@ -352,9 +428,31 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		else rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, nullptr, n, p->L, p->k, 0, p->d_rec.p));
 		if (!rc && p->ext_x) rc = p->sync("records");                         // the caller may release its arrays now
 	} else {
-		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
+		// rows, classes and N masks are indexed by the global read id: a rank writes its shard's part of the whole arrays
+		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, nl, p->L, p->k, p->e, (uint32_t)r0, p->d_packed.p + r0 * p->W, p->d_cls.p + r0, p->d_ncnt.p,
+		                               p->d_nmask.p + r0 * p->NW, p->d_rec.p));
 	}
 	if (rc) return rc;
+	if (dist) {
+		// Every later stage reads rows by read id (group consensus, merged consensus, the Stage-2 singletons), and a group or a
+		// contig holds reads of any shard: the packed rows (and the classes, 1 byte per read) are replicated once, here.
+		// The N masks travel only when some read of the job holds an N.
+		const int R = p->world;
+		std::vector<uint64_t> first(R), cnt(R), fW(R), cW(R), fN(R), cN(R);
+		for (int q = 0; q < R; ++q) { first[q] = p->shard_lo[q]; cnt[q] = p->shard_lo[q + 1] - p->shard_lo[q]; fW[q] = first[q] * p->W; cW[q] = cnt[q] * p->W; fN[q] = first[q] * p->NW; cN[q] = cnt[q] * p->NW; }
+		const double tx = now_ms();
+		if ((rc = gatherv(p, p->d_packed.p, fW, cW)) || (rc = gatherv(p, p->d_cls.p, first, cnt))) return rc;
+		uint32_t mx = 0;
+		if ((rc = p->gpu(mcom_max_u16(p->ctx, p->d_ncnt.p, nl, &mx)))) return rc;
+		uint64_t any = mx;
+		if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &any, 1, 2)))) return rc;
+		if (any) { if ((rc = gatherv(p, p->d_nmask.p, fN, cN))) return rc; }
+		else {
+			if (r0 && (rc = p->hipc(hipMemsetAsync(p->d_nmask.p, 0, r0 * p->NW * 8, p->stream), "clear"))) return rc;
+			if (r0 + nl < n && (rc = p->hipc(hipMemsetAsync(p->d_nmask.p + (r0 + nl) * p->NW, 0, (n - r0 - nl) * p->NW * 8, p->stream), "clear"))) return rc;
+		}
+		p->stat["t_x_reads"] += now_ms() - tx;
+	}
 	if (!p->h_cls.resize(n + 8)) return p->fail(MCOM_E_NOMEM, "classes");
 	memset(p->h_cls.data() + n, 0, 8);
 	// the classes travel while the bucket stage starts; a thread sorts the special reads into their lists (rid order) once
@@ -397,19 +495,32 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	const double t0 = now_ms();
 	const int L = p->L;
 	const int RS = (2 * L + 15) & ~15;                       // stride of one group's consensus on the device
-	size_t n_cur = p->n;
-	DevBuf<mcom_mm128> d_cur, d_sorted; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
+	// Multi-GPU: the records of a round go to the owner of their bucket (bucket ranges in rank order); a rank then does what
+	// the single GPU does, on its buckets, and the new contigs of all ranks are all-gathered into the replicated set in
+	// rank order -- which is the reference's visiting order (buckets ascending, kthread_bucket.c:531-560).
+	const bool dist = p->comm != nullptr;
+	const int R = p->world, me = p->rank;
+	size_t n_cur = dist ? p->n_local : p->n;
+	DevBuf<mcom_mm128> d_cur, d_sorted, d_part, d_recv; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
 	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
 	std::vector<uint32_t> resk;
 	struct SgRound { PinVec<uint32_t> singles, sord, rej, rejg; size_t ns = 0, nrej = 0; bool last = false; };
 	std::vector<SgRound> sg_rounds;
+	p->join_sg();
+	if (dist) p->sg.clear();
 	size_t n_sg_total = p->sg.size();
 	DevBuf<uint32_t> d_rej, d_rejg;
 	// the contigs are built on the device (p->dC) and stay there for combine_cluster; the host copy is made on demand
 	p->C.clear();
 	p->dC.n = 0; p->dC.chars = 0; p->dC.members = 0; p->dC.nrec = 0;
 	p->dC_valid = true; p->hostC_valid = false; p->host_off_valid = false;
+	DevSet &D = p->dC;
+	int rc;
+	if (dist) {                                              // offset entry 0 of the replicated set: nobody's contig writes it
+		if (!D.soff.reserve(2) || !D.moff.reserve(2)) return p->fail(MCOM_E_NOMEM, "contig set");
+		if ((rc = p->hipc(hipMemsetAsync(D.soff.p, 0, 8, p->stream), "clear")) || (rc = p->hipc(hipMemsetAsync(D.moff.p, 0, 8, p->stream), "clear"))) return rc;
+	}
 	int last_rounds = 0; long pre = 0;
 	for (int r = 1;; ++r) {
 		if (p->k - r <= 9) ++last_rounds;                                           // :584-585
@@ -418,44 +529,99 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		const int kmer_in = p->k - (r - 1);                  // k the incoming records were sketched with
 		const int kmer_next = p->k - r;                       // k for the rejects of this round (:592)
 		resk.clear();
+		if (dist) {
+			// the exchange of the round: round 1 moves every kept read's record, later rounds the re-sketched rejects
+			// (kthread_bucket.c:205-212, :489-496 push them into the other bucket set)
+			const double tx = now_ms();
+			std::vector<uint64_t> cnt(R, 0), all;
+			if (!d_part.reserve(n_cur + 1)) return p->fail(MCOM_E_NOMEM, "exchange buffers");
+			if ((rc = p->gpu(mcom_partition_by_owner(p->ctx, cur, n_cur, NB_BITS, R, d_part.p, cnt.data()))) || (rc = gather_host(p, cnt.data(), R, all))) return rc;
+			std::vector<uint64_t> so(R), sb(R), ro(R), rb(R);
+			uint64_t a = 0, b = 0;
+			for (int q = 0; q < R; ++q) { so[q] = a * 16; sb[q] = cnt[q] * 16; a += cnt[q]; ro[q] = b * 16; rb[q] = all[(size_t)q * R + me] * 16; b += all[(size_t)q * R + me]; }
+			if (!d_recv.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "exchange buffers");
+			if ((rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, d_part.p, so.data(), sb.data(), d_recv.p, ro.data(), rb.data(), 1, p->stream)))) return rc;
+			// what arrives is ordered by sender, each part by rid.  Round 1: shards are rid ranges in rank order, so this is
+			// rid order already; later rounds: one stable sort by rid restores what mcom_sort_group's tie rule expects
+			if (r > 1 && (rc = p->gpu(mcom_sort_by_rid(p->ctx, d_recv.p, (size_t)b)))) return rc;
+			cur = d_recv.p; n_cur = (size_t)b;
+			p->stat["x_records"] += (double)b;
+			p->stat["t_x_records"] += now_ms() - tx;
+		}
+		size_t ns = 0, ng = 0, nm = 0, nrej = 0;
+		const double tg = now_ms();
 		if (n_cur) {
 			if (!d_sorted.reserve(n_cur) || !d_singles.reserve(n_cur) || !d_sord.reserve(n_cur) || !d_members.reserve(n_cur) || !d_goff.reserve(n_cur / 2 + 2))
 				return p->fail(MCOM_E_NOMEM, "round buffers");
 			uint64_t cnts[4];
-			const double tg = now_ms();
-			int rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts));
-			if (rc) return rc;
-			const size_t ns = cnts[1], ng = cnts[2], nm = cnts[3];
+			if ((rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts)))) return rc;
+			ns = cnts[1]; ng = cnts[2]; nm = cnts[3];
 			p->stat["t_bk_sort"] += now_ms() - tg;
 			if (!d_keep.reserve(nm + 1) || !d_nkept.reserve(ng + 1) || !d_sv.reserve(ng + 1) || !d_reflen.reserve(ng + 1) || !d_refs.reserve(ng * (size_t)RS + 16))
 				return p->fail(MCOM_E_NOMEM, "consensus buffers");
 			// construct_ref of every group on the device (:446)
 			if ((rc = p->gpu(mcom_group_consensus(p->ctx, p->d_packed.p, d_members.p, d_goff.p, (uint32_t)ng, L, p->k, p->e, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS)))) return rc;
-			// groups that stay contigs (more than one member kept, :451) join the device-resident contig set; the others'
-			// members come back as rejects, in visiting order
-			DevSet &D = p->dC;
 			if (!d_rej.reserve(nm + 1) || !d_rejg.reserve(nm + 1)) return p->fail(MCOM_E_NOMEM, "reject buffers");
-			uint64_t gc[4] = {0, 0, 0, 0};
-			for (int attempt = 0; attempt < 2; ++attempt) {
-				rc = mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, D.n, D.chars, D.members,
-				                            D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc);
-				if (rc != MCOM_E_OVERFLOW) break;
-				if (!D.seq.grow(D.chars + gc[1] + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + 1, D.members, p->stream) ||
-				    !D.soff.grow(D.n + gc[0] + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+		}
+		// groups that stay contigs (more than one member kept, :451) join the device-resident contig set; the others'
+		// members come back as rejects, in visiting order
+		uint64_t gc[4] = {0, 0, 0, 0};
+		if (!dist) {
+			if (n_cur) {
+				for (int attempt = 0; attempt < 2; ++attempt) {
+					rc = mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, D.n, D.chars, D.members,
+					                            D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc);
+					if (rc != MCOM_E_OVERFLOW) break;
+					if (!D.seq.grow(D.chars + gc[1] + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + 1, D.members, p->stream) ||
+					    !D.soff.grow(D.n + gc[0] + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+				}
+				if (rc) return p->gpu(rc);
+				D.n += gc[0]; D.chars += gc[1]; D.members += gc[2];
 			}
-			if (rc) return p->gpu(rc);
-			D.n += gc[0]; D.chars += gc[1]; D.members += gc[2];
-			const size_t nrej = gc[3];
-			SgRound R; R.ns = ns; R.nrej = nrej; R.last = last;
-			if (!R.singles.resize(ns) || !R.sord.resize(ns) || !R.rej.resize(nrej) || !R.rejg.resize(nrej)) return p->fail(MCOM_E_NOMEM, "round lists");
-			if ((rc = p->d2h(R.singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(R.sord.data(), d_sord.p, ns, "copy")) ||
-			    (rc = p->d2h(R.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(R.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
+			nrej = gc[3];
+			n_sg_total += ns + (last ? nrej : 0);
+		} else {
+			// sizes first (the call reports them with MCOM_E_OVERFLOW when given no room), so that every rank knows where its
+			// contigs go in the replicated set: behind those of the lower ranks of this round
+			if (ng) {
+				rc = mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, 0, 0, 0,
+				                            nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, gc);
+				if (rc != MCOM_E_OVERFLOW && rc != MCOM_OK) return p->gpu(rc);
+			}
+			const uint64_t mine[5] = {gc[0], gc[1], gc[2], (uint64_t)ns, gc[3]};
+			std::vector<uint64_t> all;
+			if ((rc = gather_host(p, mine, 5, all))) return rc;
+			std::vector<uint64_t> fn(R), cn(R), fc(R), cc(R), fm(R), cm(R);
+			uint64_t tn = 0, tc = 0, tm = 0;
+			for (int q = 0; q < R; ++q) {
+				fn[q] = D.n + 1 + tn; cn[q] = all[5 * q]; fc[q] = D.chars + tc; cc[q] = all[5 * q + 1]; fm[q] = D.members + tm; cm[q] = all[5 * q + 2];
+				tn += cn[q]; tc += cc[q]; tm += cm[q];
+				n_sg_total += all[5 * q + 3] + (last ? all[5 * q + 4] : 0);
+			}
+			if (!D.seq.grow(D.chars + tc + 16, D.chars, p->stream) || !D.mem.grow(D.members + tm + 1, D.members, p->stream) ||
+			    !D.soff.grow(D.n + tn + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + tn + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+			if (ng) {
+				uint64_t gc2[4];
+				if ((rc = p->gpu(mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, fn[me] - 1, fc[me], fm[me],
+				                                        D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc2)))) return rc;
+				if (gc2[0] != gc[0] || gc2[1] != gc[1] || gc2[2] != gc[2] || gc2[3] != gc[3]) return p->fail(MCOM_E_ARG, "contig counts changed between the two calls");
+			}
+			const double tx = now_ms();
+			if ((rc = gatherv(p, D.seq.p, fc, cc)) || (rc = gatherv(p, D.soff.p, fn, cn)) || (rc = gatherv(p, D.mem.p, fm, cm)) || (rc = gatherv(p, D.moff.p, fn, cn))) return rc;
+			p->stat["t_x_contigs"] += now_ms() - tx;
+			D.n += tn; D.chars += tc; D.members += tm;
+			nrej = gc[3];
+		}
+		if (n_cur || dist) {
+			SgRound Rd; Rd.ns = ns; Rd.nrej = nrej; Rd.last = last;
+			if (!Rd.singles.resize(ns) || !Rd.sord.resize(ns) || !Rd.rej.resize(nrej) || !Rd.rejg.resize(nrej)) return p->fail(MCOM_E_NOMEM, "round lists");
+			if ((rc = p->d2h(Rd.singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(Rd.sord.data(), d_sord.p, ns, "copy")) ||
+			    (rc = p->d2h(Rd.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(Rd.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["t_bk_gpu"] += now_ms() - tg;
 			// the next round only needs the rejects; where singles and rejects go in the singleton list is settled later
-			if (!last) resk.assign(R.rej.data(), R.rej.data() + nrej);
-			n_sg_total += ns + (last ? nrej : 0);
-			sg_rounds.push_back(std::move(R));
+			if (!last) resk.assign(Rd.rej.data(), Rd.rej.data() + nrej);
+			sg_rounds.push_back(std::move(Rd));
 		}
 		p->stat["rounds"] += 1;
 		if (last_rounds) ++last_rounds;                                             // :594
@@ -469,34 +635,70 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		p->stat["resketch"] += (double)n_cur;
 		if (n_cur) {
 			if (!d_rids.reserve(n_cur) || !d_cur.reserve(n_cur)) return p->fail(MCOM_E_NOMEM, "re-sketch buffers");
-			int rc = p->h2d(d_rids.p, resk.data(), n_cur, "upload rids");
-			if (rc) return rc;
+			if ((rc = p->h2d(d_rids.p, resk.data(), n_cur, "upload rids"))) return rc;
 			if ((rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, d_rids.p, n_cur, L, kmer_next, 0, d_cur.p)))) return rc;
 			if ((rc = p->sync("re-sketch"))) return rc;
-			cur = d_cur.p;
 		}
+		cur = d_cur.p;
 	}
 	// singletons and rejects in the reference's visiting order (process_bucket, :398-505): a single whose ordinal is g was
 	// visited before group g.  Nobody needs the list before Stage 2: a thread builds it beside combine_cluster.
+	// (multi-GPU: this rank's part, round by round; combine_cluster puts the ranks' parts together, dist_gather_sg)
 	p->join_sg();
+	p->sg_round_len.assign(sg_rounds.size(), 0);
+	p->sg_gathered = !dist;
 	p->sg_thread = std::thread([p, n_sg_total](std::vector<SgRound> rounds) {
 		p->sg.reserve(n_sg_total);
-		for (const SgRound &R : rounds) {
+		size_t ri = 0;
+		for (const SgRound &Rd : rounds) {
+			const size_t before = p->sg.size();
 			size_t si = 0;
-			for (size_t u = 0; u < R.nrej; ++u) {
+			for (size_t u = 0; u < Rd.nrej; ++u) {
 				size_t sj = si;
-				while (sj < R.ns && R.sord[sj] <= R.rejg[u]) ++sj;                   // groups of one (:402-413)
-				p->sg.insert(p->sg.end(), R.singles.data() + si, R.singles.data() + sj);
+				while (sj < Rd.ns && Rd.sord[sj] <= Rd.rejg[u]) ++sj;                   // groups of one (:402-413)
+				p->sg.insert(p->sg.end(), Rd.singles.data() + si, Rd.singles.data() + sj);
 				si = sj;
-				if (R.last) p->sg.push_back(R.rej[u]);
+				if (Rd.last) p->sg.push_back(Rd.rej[u]);
 			}
-			p->sg.insert(p->sg.end(), R.singles.data() + si, R.singles.data() + R.ns);
+			p->sg.insert(p->sg.end(), Rd.singles.data() + si, Rd.singles.data() + Rd.ns);
+			p->sg_round_len[ri++] = p->sg.size() - before;
 		}
 	}, std::move(sg_rounds));
 	if (n_sg_total <= 5000000) p->maxsearch = 2000;                                 // preprocess.c:169-172
 	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
 	p->stat["n_sg0"] = (double)n_sg_total;
 	p->stat["t_bucket"] += now_ms() - t0;
+	return MCOM_OK;
+}
+
+// Multi-GPU: the singleton list of the job = round by round, rank by rank (the reference visits a round's buckets in
+// ascending order, and the ranks own ascending bucket ranges), each part as the rank's own thread ordered it.
+static int dist_gather_sg(P *p)
+{
+	if (!p->comm || p->sg_gathered) return MCOM_OK;
+	const int R = p->world, me = p->rank;
+	const size_t nr = p->sg_round_len.size();
+	int rc;
+	uint64_t mn = nr, mx = nr;
+	if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mn, 1, 1))) || (rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mx, 1, 2)))) return rc;
+	if (mn != mx) return p->fail(MCOM_E_ARG, "the ranks ran different numbers of bucket rounds");
+	std::vector<uint64_t> all;
+	if ((rc = gather_host(p, p->sg_round_len.data(), nr, all))) return rc;
+	std::vector<uint64_t> first(R), tot(R, 0);
+	uint64_t total = 0;
+	for (int q = 0; q < R; ++q) { for (size_t r = 0; r < nr; ++r) tot[q] += all[(size_t)q * nr + r]; first[q] = total; total += tot[q]; }
+	if (tot[me] != p->sg.size()) return p->fail(MCOM_E_ARG, "singleton list: %zu entries, the rounds say %llu", p->sg.size(), (unsigned long long)tot[me]);
+	DevBuf<uint32_t> d;
+	if (!d.reserve(total + 1)) return p->fail(MCOM_E_NOMEM, "singleton list");
+	if ((rc = p->h2d(d.p + first[me], p->sg.data(), p->sg.size(), "upload singletons")) || (rc = p->sync("upload singletons")) || (rc = gatherv(p, d.p, first, tot))) return rc;
+	std::vector<uint32_t> flat(total), out;
+	if ((rc = p->d2h(flat.data(), d.p, total, "copy singletons")) || (rc = p->sync("copy singletons"))) return rc;
+	out.reserve(total);
+	std::vector<uint64_t> cursor(first);
+	for (size_t r = 0; r < nr; ++r)
+		for (int q = 0; q < R; ++q) { const uint64_t len = all[(size_t)q * nr + r]; out.insert(out.end(), flat.begin() + cursor[q], flat.begin() + cursor[q] + len); cursor[q] += len; }
+	p->sg.swap(out);
+	p->sg_gathered = true;
 	return MCOM_OK;
 }
 
@@ -558,6 +760,43 @@ static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, s
 	return p->fail(MCOM_E_OVERFLOW, "minimizer buffer");
 }
 
+// Multi-GPU form of sketch_first: the contig set is replicated, so a rank sketches its share of the contigs (as if they
+// were contigs 0, 1, ...), moves ids and offsets to their global values and the shares are all-gathered in contig order.
+static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_first, size_t room, uint64_t &total)
+{
+	total = 0;
+	const int R = p->world, me = p->rank;
+	const size_t c0 = n_first * (size_t)me / R, c1 = n_first * (size_t)(me + 1) / R, nloc = c1 - c0;
+	if (!S.roff.reserve(S.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	DevBuf<mcom_mm128> tmp; DevBuf<uint32_t> toff;
+	if (!toff.reserve(nloc + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	size_t cap = std::max<size_t>(1024, chars_first / 8 / R + nloc + 1024);
+	uint64_t tl = 0;
+	int rc = MCOM_OK;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (!tmp.reserve(cap)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+		rc = mcom_sketch_contigs(p->ctx, S.seq.p, S.soff.p + c0, nullptr, nloc, p->rw, p->k, 0, toff.p, tmp.p, cap, &tl);
+		if (rc == MCOM_E_OVERFLOW) { cap = tl; continue; }
+		break;
+	}
+	if (rc) return p->gpu(rc);
+	uint64_t hs[2] = {0, 0};
+	if (nloc && ((rc = p->d2h(&hs[0], S.soff.p + c0, 1, "copy")) || (rc = p->d2h(&hs[1], S.soff.p + c1, 1, "copy")) || (rc = p->sync("copy")))) return rc;
+	p->stat["sketch_bases"] += (double)(hs[1] - hs[0]); p->stat["sketch_records"] += (double)tl;
+	std::vector<uint64_t> all, first(R), cnt(R), fo(R), co(R);
+	if ((rc = gather_host(p, &tl, 1, all))) return rc;
+	for (int q = 0; q < R; ++q) { first[q] = total; cnt[q] = all[q]; total += all[q]; fo[q] = n_first * (size_t)q / R; co[q] = n_first * (size_t)(q + 1) / R - fo[q]; }
+	if (total >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records");
+	if (!S.rec.reserve(total + room + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+	if ((rc = p->gpu(mcom_records_rebase(p->ctx, tmp.p, tl, (uint32_t)c0, toff.p, nloc, (uint32_t)first[me])))) return rc;
+	const double tx = now_ms();
+	if ((rc = gatherv(p, S.rec.p, first, cnt, tmp.p)) || (rc = gatherv(p, S.roff.p, fo, co, toff.p))) return rc;
+	p->stat["t_x_sketch"] += now_ms() - tx;
+	const uint32_t t32 = (uint32_t)total;
+	if ((rc = p->h2d(S.roff.p + n_first, &t32, 1, "upload")) || (rc = p->sync("upload"))) return rc;
+	return MCOM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // combine_cluster: merge rounds                                                kthread_cb.c:570-630
 // The contig set (consensus strings, members, minimizers) lives on the device for the whole stage; per round only the
@@ -572,7 +811,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	int rc;
 	ContigSet &C = p->C;
 	DevSet A, B;
-	DevBuf<uint32_t> moff_m, d_jobs, d_keepidx; DevBuf<mcom_mm128> rec_m, d_pairs; DevBuf<uint8_t> d_flag;
+	DevBuf<uint32_t> moff_m, d_jobs, d_keepidx; DevBuf<mcom_mm128> rec_m, d_pairs, d_pairs_loc; DevBuf<uint8_t> d_flag;
 	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
 	struct Job { uint32_t ci, cj, pos_ori, pos; };
 	PinVec<Job> jobs;
@@ -594,7 +833,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	if (A.n) {
 		const double tg = now_ms();
 		lap("t_cb_upload");
-		if ((rc = sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;                                  // find_next's own sketch (:234)
+		if ((rc = p->comm ? sketch_first_dist(p, A, A.n, A.chars, 0, A.nrec) : sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;   // find_next's own sketch (:234)
 		lap("t_cb_sketch");
 		p->stat["t_gpu"] += now_ms() - tg;
 	}
@@ -618,12 +857,38 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;           // mm_idx_generation (:580)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
-			size_t cap = std::max<size_t>(1024, A.nrec);
-			for (int attempt = 0; attempt < 2; ++attempt) {
-				if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-				rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
-				if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
-				break;
+			if (!p->comm) {
+				size_t cap = std::max<size_t>(1024, A.nrec);
+				for (int attempt = 0; attempt < 2; ++attempt) {
+					if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
+					rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
+					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
+					break;
+				}
+			} else {
+				// multi-GPU: every rank holds the whole index (6 minimizers per contig) and evaluates the queries of its share of
+				// the contigs; the passing pairs come out in visiting order, so the shares concatenate in rank order
+				const int R = p->world, me = p->rank;
+				const size_t c0 = n * (size_t)me / R, c1 = n * (size_t)(me + 1) / R;
+				uint32_t qr[2] = {0, 0};
+				if ((rc = p->d2h(&qr[0], A.roff.p + c0, 1, "copy")) || (rc = p->d2h(&qr[1], A.roff.p + c1, 1, "copy")) || (rc = p->sync("copy"))) { mcom_idx_destroy(p->ctx, mi); return rc; }
+				size_t cap = std::max<size_t>(1024, (size_t)(qr[1] - qr[0]));
+				for (int attempt = 0; attempt < 2; ++attempt) {
+					if (!d_pairs_loc.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
+					rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p + qr[0], qr[1] - qr[0], p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs_loc.p, d_pairs_loc.cap, hc);
+					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
+					break;
+				}
+				if (rc) { p->gpu(rc); mcom_idx_destroy(p->ctx, mi); return rc; }
+				std::vector<uint64_t> all, first(R), cnt(R);
+				if ((rc = gather_host(p, hc, 2, all))) { mcom_idx_destroy(p->ctx, mi); return rc; }
+				hc[0] = hc[1] = 0;
+				for (int q = 0; q < R; ++q) { first[q] = hc[1]; cnt[q] = all[2 * q + 1]; hc[0] += all[2 * q]; hc[1] += all[2 * q + 1]; }
+				if (!d_pairs.reserve(hc[1] + 1)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
+				const double tx = now_ms();
+				rc = gatherv(p, d_pairs.p, first, cnt, d_pairs_loc.p);
+				p->stat["t_x_pairs"] += now_ms() - tx;
+				if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
 			}
 			mcom_idx_destroy(p->ctx, mi);
 			if (rc) return p->gpu(rc);
@@ -721,6 +986,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");
 	p->join_sg();
+	if ((rc = dist_gather_sg(p))) return rc;
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -845,6 +1111,20 @@ static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgb
 		if (nt <= cap) break;
 		cap = nt + (nt >> 3);
 	}
+	if (p->comm) {
+		// multi-GPU: this rank saw the tuples against ITS contigs; the unmarked singletons' claims are MIN-reduced, the marked
+		// ones' tuples are put together, and every rank replays the same list
+		if ((rc = dist_min_claims(p, d_claim, n_sg))) return rc;
+		const int R = p->world;
+		std::vector<uint64_t> all, first(R), cnt(R);
+		if ((rc = gather_host(p, &nt, 1, all))) return rc;
+		uint64_t total = 0;
+		for (int q = 0; q < R; ++q) { first[q] = 2 * total; cnt[q] = 2 * all[q]; total += all[q]; }
+		DevBuf<uint64_t> d_all;
+		if (!d_all.reserve(2 * total + 2)) return p->fail(MCOM_E_NOMEM, "tuples");
+		if ((rc = gatherv(p, d_all.p, first, cnt, d_tup.p))) return rc;
+		d_tup.swap(d_all); nt = total;
+	}
 	std::vector<std::pair<uint64_t, uint64_t>> tup(nt);
 	static_assert(sizeof(std::pair<uint64_t, uint64_t>) == 16, "tuple layout");
 	if (nt && ((rc = p->d2h((uint64_t*)tup.data(), d_tup.p, 2 * nt, "copy tuples")) || (rc = p->sync("tuples")))) return rc;
@@ -938,12 +1218,25 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->gpu(mcom_window_layout(p->ctx, p->dC.soff.p, nc, p->L, p->d_woff.p, &nwin, &mlen)))) return rc;
 		p->n_windows = nwin; p->maxlen = std::max(p->maxlen, mlen);
 		if (!p->window_scan) {
+			// Multi-GPU: the index is sharded by contig range (equal shares of the windows), every rank probes ALL singletons
+			// against its part and the claim keys are MIN-reduced (dist_min_claims): the index -- the largest object of
+			// Stage 2 and its most expensive kernel -- is built once across the ranks, not once per rank.
+			uint32_t c0 = 0, c1 = (uint32_t)nc; uint64_t nwin_mine = p->n_windows;
+			if (p->comm && nc) {
+				std::vector<uint64_t> hw(nc + 1);
+				if ((rc = p->d2h(hw.data(), p->d_woff.p, nc + 1, "copy window offsets")) || (rc = p->sync("copy window offsets"))) return rc;
+				auto bound = [&](int q) { return q >= p->world ? (size_t)nc : (size_t)(std::lower_bound(hw.begin(), hw.begin() + nc, p->n_windows * (uint64_t)q / p->world) - hw.begin()); };
+				c0 = (uint32_t)bound(p->rank); c1 = (uint32_t)bound(p->rank + 1);
+				if (p->rank == 0) c0 = 0;
+				nwin_mine = hw[c1] - hw[c0];
+			}
+			p->cix_c0 = c0; p->cix_c1 = c1;
 			uint64_t ne = 0;
-			if (mcom_cindex_plan(p->n_windows, (uint32_t)nc, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			if (mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
 			if (!p->d_cix_keys.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
 			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)(8ull << p->cix_log2);
-			if ((rc = p->gpu(mcom_cindex_build(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->n_windows, p->L, p->numdict,
-			                                   p->cix_log2, p->d_cix_keys.p)))) return rc;
+			if ((rc = p->gpu(mcom_cindex_build_range(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict,
+			                                         p->cix_log2, p->d_cix_keys.p)))) return rc;
 		}
 		p->stage2_uploaded = true;
 	}
@@ -987,6 +1280,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				                                    n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
 			else if (!rc)
 				rc = realign_big_bins(p, dicts, d_sgbits.p, d_flag.p, n_sg, nc, thr, d_claim.p, d_st.p);
+			if (!rc && !big && p->comm) rc = dist_min_claims(p, d_claim.p, n_sg);
 			PinVec<uint64_t> hst; hst.resize(3);
 			if (!rc) rc = p->d2h(hst.data(), d_st.p, 3, "copy pass counters");
 			if (!rc) rc = p->sync("realign pass");

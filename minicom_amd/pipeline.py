@@ -73,7 +73,11 @@ HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_set_records", 
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
                     "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order",
-                    "mcomh_cluster_dump_pe", "mcomh_decompress_pe", "mcomh_fastq_pair_to_device"]
+                    "mcomh_cluster_dump_pe", "mcomh_decompress_pe", "mcomh_fastq_pair_to_device",
+                    # multi-GPU (bound in minicom_amd/distributed.py)
+                    "mcomh_comm_unique_id", "mcomh_comm_create_rccl", "mcomh_comm_create_ops", "mcomh_comm_destroy", "mcomh_comm_rank",
+                    "mcomh_comm_world", "mcomh_comm_last_error", "mcomh_comm_alltoallv", "mcomh_comm_allgatherv", "mcomh_comm_allreduce_u64",
+                    "mcomh_comm_stats", "mcomh_create_dist"]
 
 
 def decompress(folder: str, out_path: str, order: bool = False) -> int:
