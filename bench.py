@@ -5,12 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One step = one full pass of the hot path (the reference's timed region, Stage 1 + Stage 2,
-preprocess.c:137-234) over one batch of synthetic reads that are already resident in HBM:
-BASELINE.json configs[1], 100 M x 150 bp, k = 31, default parameters, per GPU.
-N > 1: one process per GPU; every rank sketches its shard, the reads move to the owners of their minimizer
-buckets with one RCCL all-to-all (minicom_amd/distributed.py), then every rank runs the rest of the path on
-its partition ("weak" scaling: reads per GPU fixed).  Prints ONE JSON line on rank 0.
+One step = one full pass of the hot path (the reference's timed region, Stage 1 + Stage 2, preprocess.c:137-234) over one
+batch of synthetic reads that are already resident in HBM: BASELINE.json configs[1], 100 M x 150 bp, k = 31, default
+parameters, per GPU.  The step ends with the result digest read back (mcomh_result_digest), which every timed step must
+share with an untimed run whose result was CHECKED (minicom_amd/check.py: every read in exactly one place, every member on
+and like its contig).
+N > 1: one process per GPU; the distributed pipeline of libmcom_host.so (mcomh_create_dist): reads sharded, minimizer
+records exchanged to bucket owners every bucket round over RCCL (ncclSend/ncclRecv groups), contig set replicated by
+all-gather, Stage-2 claims MIN-reduced; every rank ends with the complete result, identical to the single-GPU result over all
+N x reads ("weak" scaling: reads per GPU fixed).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -25,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 1002            # seed = 1000 + config number
+CLOCK_HZ = 2.4e9       # MI355X engine clock; 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK = 1024 * CLOCK_HZ / 2
 
 
 def cpu_baseline(L, sample):
@@ -46,15 +51,16 @@ def cpu_baseline(L, sample):
                 p = subprocess.run([exe, fq, out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
                 t = [float(x) for x in re.findall(r"\[Stage \d\] Real time: ([\d.]+)", p.stdout.decode())]
                 if p.returncode == 0 and len(t) == 2:
-                    return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": cores, "kind": "reference",
-                            "sample": tag + f"; reference's own Stage 1 + Stage 2 timers, -t {cores}", "seconds": round(sum(t), 3)}
+                    return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": cores, "kind": "reference", "sample_reads": sample,
+                            "sample": tag + f"; reference's own Stage 1 + Stage 2 timers, -t {cores} (the reference slows down with size: "
+                                            "0.056 Mreads/s on 8 M reads, DESIGN.md section 6)", "seconds": round(sum(t), 3)}
         except Exception:
             pass
     import oracle
     p = oracle.Pipeline(reads)
     t0 = time.perf_counter(); p.run_all(); dt = time.perf_counter() - t0
     p.close()
-    return {"value": round(sample / dt / 1e6, 6), "unit": "Mreads/s", "cores": 1, "kind": "port",
+    return {"value": round(sample / dt / 1e6, 6), "unit": "Mreads/s", "cores": 1, "kind": "port", "sample_reads": sample,
             "sample": tag + "; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
 
 
@@ -62,8 +68,9 @@ KERNELS = ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "fin
            "cindex_build", "realign_reads")
 
 
-# algorithmic bytes per unit of every timed kernel class
-def algorithmic_bytes(name, st, L, nd):
+def algorithmic_bytes(name, st, L, nd, model="word"):
+    """Algorithmic bytes of every launch of a timed kernel class over the timed steps.
+    model "word": the words an entry touches, as section 8d counts them; "sector": the 64-byte lines a random access moves."""
     W = (2 * L + 63) // 64
     if name == "realign_windows":      # per (window, dir, dict): 8 key + 8 table word + 8 rank + 8 startpos + 4 id + 8W verify
         return (36 + 8 * W) * (2 * nd - 1) * st["windows"]
@@ -73,29 +80,33 @@ def algorithmic_bytes(name, st, L, nd):
         return (L + 8 * W + 3) * st["n"]
     if name == "realign_reads":        # per lookup one 64-B line of keys; per verified window value + offsets + packed window; per singleton row, flag, claim
         return 64 * st["ra_lookups"] + (8 + 24 + 8 * (W + 1)) * st["ra_verified"] + (8 * W + 9) * st["ra_singletons"]
-    if name == "cindex_build":         # table cleared (8 B per slot), per indexed position a 64-B key line read + 8 B key + 8 B value written + 2 words of packed contig
-        return 8 * st["cix_slots"] + (64 + 16 + 16) * st["cix_entries"]
+    if name == "cindex_build":
+        return cindex_bytes(st, model)
     if name == "sketch_contigs":       # every contig base (1 byte) in, 16 B per minimizer out, one launch per call
         return (st.get("sketch_bases", 0) + 16 * st.get("sketch_records", 0)) or None
     return None                        # radix_pass / dict_build / find_next: launches of many sizes, no single byte model
 
 
-# HBM traffic per kernel class from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs
-# of this same command at the default workload; kernels cannot be counted while bench.py itself is timing them)
-PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_f_pmc_traffic_100m.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_contigs"], "cindex_build": ["k_cindex_insert"], "realign_reads": ["k_realign_reads<5, 16, false>"],
-               "classify_pack": ["k_classify_pack<32>"], "sketch_reads": ["k_sketch_reads<5, true>"]}
+def cindex_bytes(st, model):
+    """The contig 17-mer index of Stage 2, per build: the table cleared (8 B per slot) plus, per indexed position,
+    word: 16 B of packed contig read + 8 B counter read + 8 B atomic + 8 B slot written = 40 B;
+    sector: one 64-B line read and written + 16 B of packed contig = 96 B (what a scattered insert makes the memory move)."""
+    per = 40 if model == "word" else 96
+    return 8 * st.get("cix_slots", 0) + per * st.get("cix_entries", 0)
 
 
-def pmc_traffic(cls):
-    """Bytes per launch of a kernel class, or None when no PMC pass is on file."""
+# HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
+# this same command; kernels cannot be counted while bench.py itself is timing them)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
+PMC_KERNELS = {"sketch_contigs": "k_sketch_contigs", "cindex_build": "k_cindex_insert", "realign_reads": "k_realign_reads<5, 16, false>",
+               "classify_pack": "k_classify_pack<32>", "sketch_reads": "k_sketch_reads<5, true>"}
+
+
+def pmc(cls, field):
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
-        rows = [d[k] for k in PMC_KERNELS.get(cls, []) if k in d]
-        if not rows:
-            return None
-        return int(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / max(1, sum(r["launches"] for r in rows)))
+        return d["kernels"][PMC_KERNELS[cls]][field]
     except Exception:
         return None
 
@@ -109,8 +120,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--force-exchange", action="store_true", help="run the N>1 bucket exchange path even with one rank (testing)")
+    ap.add_argument("--force-exchange", action="store_true", help="run the distributed pipeline (one-rank RCCL communicator) even with one GPU (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the checked run (the digest comparison between steps stays)")
+    ap.add_argument("--no-host-to-host", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -121,15 +134,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    exchange = world > 1 or a.force_exchange
-    if exchange:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    distributed = world > 1 or a.force_exchange
+    comm = None
+    if world > 1:
+        # torch.distributed (gloo) only bootstraps: it hands the RCCL unique id round and carries the barriers around the timed
+        # region; the data path is the library's own communicator (ncclSend / ncclRecv groups over xGMI)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if distributed:
+        from minicom_amd.distributed import Comm, DistPipeline
+        box = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        comm = Comm.rccl(rank, world, box[0], local_rank)
     dev = torch.device("cuda", local_rank)
     L, n_local = a.read_len, a.reads
     n_total = n_local * world
@@ -140,33 +160,32 @@ def main():
     reads = ctx.synth_reads(SEED, n_total, L, first=rank * n_local, count=n_local)
     ctx.sync()
 
-    agg = {}
+    def make():
+        if not distributed:
+            return Pipeline(reads, L=L, device=local_rank, host_threads=threads)
+        return DistPipeline(reads, rank * n_local, n_total, comm, L=L, device=local_rank, host_threads=threads)
+
+    agg, digests = {}, []
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    STATS = ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine",
+             "t_realign", "t_gpu", "ra_lookups", "ra_verified", "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "t_x_reads",
+             "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_pairs")
+
     def step(timed):
-        if not exchange:
-            p = Pipeline(reads, L=L, device=local_rank, host_threads=threads)
-        else:
-            from minicom_amd.distributed import exchange_by_bucket
-            out = ctx.process_reads(reads, L, 31, rid0=0)
-            keep = (out["cls"] == 0).nonzero().squeeze(1)
-            x = out["rec"][:, 0][keep]
-            ylow = (out["rec"][:, 1][keep] & 0xFFFFFFFF).to(torch.int32)           # position<<1 | strand: travels with the read
-            rids = keep + rank * n_local
-            _, rows, (x_r, ylow_r) = exchange_by_bucket(x, rids, out["packed"][keep], extras=[x, ylow])
-            del out
-            p = Pipeline(rows, L=L, device=local_rank, host_threads=threads, packed=True, records=(x_r, ylow_r))
+        p = make()
         p.prof_enable(True)
         p.pre_process()
+        dg = p.result_digest()
         if timed:
-            for k in ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu",
-                      "ra_lookups", "ra_verified", "ra_singletons", "cix_slots", "cix_entries", "sketch_records"):
+            digests.append(dg)
+            for k in STATS:
                 agg[k] = agg.get(k, 0.0) + p.stat(k)
-            agg["n"] = agg.get("n", 0.0) + p.n
+            agg["n"] = agg.get("n", 0.0) + (n_local if distributed else p.n)
             for name in KERNELS:
                 ms, calls = p.prof_read(name)
                 agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
@@ -182,64 +201,119 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # The step leaves its results (contig strings, member lists) in HBM, like its input; what bringing them to the host
-    # costs is measured once, outside the timed region, and reported beside the metric (it is never part of `value`).
-    host_copy_ms = None
-    if rank == 0 and not exchange:
-        host_copy_ms = {}
-        for label in ("first", "steady"):                                       # first: the pinned host buffers are allocated too
-            p = Pipeline(reads, L=L, device=local_rank, host_threads=threads)
-            p.pre_process()
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            n_contigs = int(p.lib.mcomh_n_contigs(p._h))                      # first accessor: copies the whole set
-            host_copy_ms[label] = round((time.perf_counter() - tc) * 1e3, 1)
-            agg["n_contigs"] = n_contigs
-            p.close()
+    # ---- the checked run (untimed): the result the timed steps must reproduce
+    checked = None
+    if not a.no_check:
+        from minicom_amd.check import check_result
+        p = make()
+        p.pre_process()
+        ref_digest = p.result_digest()
+        checked = check_result(p, reads, L, rid0=rank * n_local)
+        p.close()
+        for i, dg in enumerate(digests):
+            assert dg == ref_digest, f"timed step {i} gave another result than the checked run: {dg} vs {ref_digest}"
+    else:
+        ref_digest = digests[0]
+        assert all(dg == ref_digest for dg in digests), "the timed steps disagree with each other"
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, ref_digest)
+        assert all(dg == every[0] for dg in every), f"the ranks hold different results: {every}"
+
+    # ---- host to host (one GPU): reads in page-locked host memory, uploaded in chunks beside classify / pack / sketch, and the
+    # whole result copied back, all inside the timed region -- what a caller pays who hands over host buffers (never `value`)
+    h2h = None
+    if world == 1 and not distributed and not a.no_host_to_host and rank == 0:
+        try:
+            import psutil
+            need = n_local * L
+            if psutil.virtual_memory().available < 3 * need + (8 << 30):
+                h2h = {"value": None, "note": "not enough host memory for a page-locked copy of the reads"}
+            else:
+                host = torch.empty((n_local, L), dtype=torch.uint8, pin_memory=True)
+                host.copy_(reads[:, :L])
+                torch.cuda.synchronize()
+
+                def h_step():
+                    p = Pipeline.from_host_streamed(host, device=local_rank, host_threads=threads)
+                    p.pre_process()
+                    nc = int(p.lib.mcomh_n_contigs(p._h))                        # first accessor: copies strings, members, offsets to the host
+                    dg = p.result_digest()
+                    p.close()
+                    return nc, dg
+                h_step()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    nc, dg = h_step()
+                    assert dg == ref_digest, "the host-to-host run gave another result"
+                dth = time.perf_counter() - t1
+                h2h = {"value": round(n_local * a.steps / dth / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dth / a.steps * 1e3, 2),
+                       "h2d_bytes": need, "d2h": "contig strings + member lists + offsets", "n_contigs": nc,
+                       "note": "reads in page-locked host memory, chunked upload overlapped with classify/pack/sketch; results copied to the host inside the timed region"}
+                del host
+        except Exception as e:                                                   # never lose the bench line to the extra measurement
+            h2h = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
 
     if rank == 0:
         nd = len(minicom_amd.hip.dict_layout(L)[0])
         st = dict(agg)
-        # dominant kernel class by device time over the timed steps (HIP events on the launch stream)
-        names = list(KERNELS)
+        default_workload = n_local == 100_000_000 and L == 150 and not distributed
+        per_step = {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in KERNELS}
+
+        def hbm_line(cls, model="word"):
+            b = algorithmic_bytes(cls, st, L, nd, model)
+            ms, calls = agg.get("ms_" + cls, 0.0), agg.get("calls_" + cls, 0)
+            if not b or ms <= 0 or not calls:
+                return None
+            ach = (b / calls) / (ms / calls * 1e-3) / 1e9
+            return {"kernel": cls, "bound": "hbm", "model": model, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "launches": int(calls), "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
+                    "traffic": pmc(cls, "traffic_bytes_per_launch") if default_workload else None}
+
+        def issue_line(cls, waves):
+            """Integer-issue roofline of an ALU-bound kernel: VALU wave-instructions per second against 1024 SIMDs x clock / 2."""
+            v = pmc(cls, "valu_per_wave")
+            ms = agg.get("ms_" + cls, 0.0)
+            if not v or ms <= 0:
+                return None
+            rate = v * waves / (ms * 1e-3)
+            return {"bound": "valu_issue", "valu_insts_per_wave": v, "waves": int(waves), "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK / 1e9, 1),
+                    "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK, 4), "source": "profiles/pmc_constants.json (SQ_INSTS_VALU / SQ_WAVES, PMC pass)"}
+
         roof = None
-        for cand in sorted(names, key=lambda q: -agg.get("ms_" + q, 0.0)):   # the dominant class that has a byte model
-            b = algorithmic_bytes(cand, st, L, nd)
-            if b and agg.get("ms_" + cand, 0.0) > 0:
-                ms, calls = agg["ms_" + cand], agg["calls_" + cand]
-                achieved = (b / calls) / (ms / calls * 1e-3) / 1e9
-                default_workload = n_local == 100_000_000 and L == 150
-                roof = {"kernel": cand, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(cand) if default_workload else None,
-                        "traffic_source": "profiles/r01_f_pmc_traffic_100m.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None,
-                        "launches": int(calls),
-                        "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
-                        "device_ms_per_step_by_kernel": {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in names}}
-                if cand == "sketch_contigs":
-                    roof["note"] = ("integer VALU bound (PMC profiles/r01_f_pmc_sq_32m.txt: about a third of the wave cycles issuing, a third waiting "
-                                    "for an issue slot): 1 byte in and 0.07 records out per position against ~35 wave instructions of hashing "
-                                    "and window minima; the HBM fraction is small by construction")
-                # the per-read sketch kernel alone (SURVEY section 8d asks for it): mm_sketch_two over the packed rows
-                bs = algorithmic_bytes("sketch_reads", st, L, nd)
-                if bs and agg.get("ms_sketch_reads", 0.0) > 0:
-                    ms1, calls1 = agg["ms_sketch_reads"], agg["calls_sketch_reads"]
-                    ach1 = bs / (ms1 * 1e-3) / 1e9
-                    roof["sketch_kernel"] = {"kernel": "sketch_reads", "achieved": round(ach1, 2), "frac": round(ach1 / 8000.0, 4), "launches": int(calls1),
-                                             "ms_per_step": round(ms1 / a.steps, 3), "algorithmic_bytes_per_read": 8 * ((2 * L + 63) // 64) + 16,
-                                             "mreads_per_s": round((st["n"] + st["resketch"]) / (ms1 * 1e-3) / 1e6, 1), "traffic": pmc_traffic("sketch_reads") if default_workload else None,
-                                             "note": "ALU bound: ~75 integer operations per base for the rolling k-mers and hash64 (PMC: 73 % of wave cycles waiting for an issue slot)"}
-                # the heaviest kernel that IS bound by HBM (random 64-B sectors), for comparison
-                bh = algorithmic_bytes("cindex_build", st, L, nd)
-                if bh and agg.get("ms_cindex_build", 0.0) > 0:
-                    ms2, calls2 = agg["ms_cindex_build"], agg["calls_cindex_build"]
-                    ach2 = (bh / calls2) / (ms2 / calls2 * 1e-3) / 1e9
-                    roof["hbm_bound_kernel"] = {"kernel": "cindex_build", "achieved": round(ach2, 2), "frac": round(ach2 / 8000.0, 4), "avg_launch_ms": round(ms2 / calls2, 3),
-                                                "algorithmic_bytes_per_launch": int(bh / calls2), "traffic": pmc_traffic("cindex_build") if default_workload else None}
+        for cand in sorted(KERNELS, key=lambda q: -agg.get("ms_" + q, 0.0)):      # the dominant class that has a byte model
+            roof = hbm_line(cand)
+            if roof:
                 break
+        if roof:
+            roof["traffic_source"] = "profiles/pmc_constants.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None
+            roof["device_ms_per_step_by_kernel"] = per_step
+            if roof["kernel"] == "cindex_build":
+                roof["sector_model"] = hbm_line("cindex_build", "sector")
+            if roof["kernel"] == "sketch_contigs":
+                roof["note"] = "integer-issue bound (see issue_roofline): 1 byte in and 0.07 records out per position; the HBM fraction is small by construction"
+            # the per-read sketch kernel alone (SURVEY section 8d asks for it): ALU bound, so both rooflines
+            sk = hbm_line("sketch_reads")
+            if sk:
+                sk["ms_per_step"] = round(agg["ms_sketch_reads"] / a.steps, 3)
+                sk["mreads_per_s"] = round((st["n"] + st["resketch"]) / (agg["ms_sketch_reads"] * 1e-3) / 1e6, 1)
+                sk["algorithmic_bytes_per_read"] = 8 * ((2 * L + 63) // 64) + 16
+                sk["issue_roofline"] = issue_line("sketch_reads", (st["n"] + st["resketch"]) / 64)
+                sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers (48 VALU instructions per base, PMC); the HBM fraction cannot be high"
+                roof["sketch_kernel"] = sk
+            sc = hbm_line("sketch_contigs")
+            if sc and roof["kernel"] != "sketch_contigs":
+                roof["sketch_contigs"] = sc
+            # the heaviest kernel that IS bound by HBM, both byte models
+            if roof["kernel"] != "cindex_build":
+                hb = hbm_line("cindex_build")
+                if hb:
+                    hb["sector_model"] = hbm_line("cindex_build", "sector")
+                    roof["hbm_bound_kernel"] = hb
         res = {
             "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",
             "value": round(n_total * a.steps / dt / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -247,20 +321,30 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{n_local // 1_000_000}M x {L}bp synthetic reads per GPU, k=31 default params (BASELINE configs[1]); "
                                    "full Stage 1 + Stage 2 per step", "reads_per_gpu": n_local, "read_len": L, "k": 31,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: reads sharded, minimizer-bucket all-to-all over RCCL",
+                       "parallelism": "1 GPU" if not distributed else f"{world} GPU(s): reads sharded, per-round minimizer-record exchange to bucket owners + all-gathers over RCCL "
+                                                                     "send/recv groups, result replicated and identical to the single-GPU result",
                        "host_threads": threads,
-                       "per_step": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("rounds", "merge_rounds", "passes", "windows", "resketch", "n_sg0", "big_bins")},
-                       "stage_ms_rank0": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu")},
-                       "results": "contig set (strings + member lists) complete in HBM at the end of a step; host copy on demand",
-                       "host_copy_of_results_ms": host_copy_ms, "n_contigs": int(agg.get("n_contigs", 0)) or None},
+                       "per_step": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("rounds", "merge_rounds", "passes", "windows", "resketch", "n_sg0", "big_bins", "x_records")},
+                       "stage_ms_rank0": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
+                                                                                           "t_x_contigs", "t_x_sketch", "t_x_pairs")},
+                       "results": "contig set (strings + member lists) complete in HBM at the end of a step, its digest read back inside the step; host copy on demand"},
+            "result": {"digest": [str(v) for v in ref_digest], "digest_fields": "contigs, chars, members, unclustered, strings, member words, offsets, lists",
+                       "every_timed_step_equal": True, "checked_run": checked},
+            "value_host_to_host": h2h,
             "roofline": roof,
         }
+        if comm is not None:
+            sent, calls = comm.stats()
+            res["config"]["rccl_bytes_sent_rank0_per_step"] = int(sent / (a.steps + a.warmup + (0 if a.no_check else 1)))
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(L, a.cpu_sample)
         elif not a.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if exchange:
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -392,6 +392,11 @@ int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32_t *h_max);
  * their n_off record offsets += first_record                                                                        */
 int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_rec, uint32_t first_contig, uint32_t *d_roff, size_t n_off, uint32_t first_record);
 
+/* Digest of a device array: h_sum_xor[0] = wrapping sum of its little-endian 64-bit words, each weighted by an odd
+ * function of its index, h_sum_xor[1] = their xor (a tail of fewer than 8 bytes is zero-extended).  d_data 8-byte
+ * aligned.  Synchronous.                                                                                            */
+int mcom_digest(mcom_ctx *ctx, const void *d_data, size_t bytes, uint64_t *h_sum_xor);
+
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);

@@ -46,6 +46,12 @@ typedef struct mcomh_pipeline mcomh_pipeline;
  * alternatively d_reads [n][pitch] is already resident in HBM (exactly one of the two is non-NULL).      */
 int  mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, const uint8_t *host_reads,
                   const uint8_t *d_reads, size_t pitch, size_t n, int L, const mcomh_params *p);
+/* Host-to-host form: host_reads [n][L] stays with the caller (valid until mcomh_kt_for_reads has returned) and is NOT
+ * copied on the host; kt_for_reads uploads it in chunks through two device staging blocks, the copy of chunk c+1 running
+ * beside classify / pack / sketch of chunk c.  Page-locked memory (hipHostMalloc, hipHostRegister) makes that overlap
+ * real; pageable memory works, serialised by the runtime.  No stage dump for such a pipeline (the reads are not kept).  */
+int  mcomh_create_streamed(mcomh_pipeline **out, int device, void *hip_stream, const uint8_t *host_reads, size_t n, int L,
+                           const mcomh_params *p);
 /* Same, from 2-bit packed rows already in HBM (include/mcom.h format, ACGT only, every read kept): the
  * entry used after the multi-GPU minimizer-bucket exchange, where a rank receives its partition packed.  */
 int  mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, const uint64_t *d_packed, size_t n, int L,
@@ -163,6 +169,16 @@ const char *mcomh_contig_ref(const mcomh_pipeline *p, size_t i, size_t *len);   
 size_t mcomh_contig_n(const mcomh_pipeline *p, size_t i);
 const uint64_t *mcomh_contig_members(const mcomh_pipeline *p, size_t i);   /* rid<<32 | offset<<1 | dir */
 const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name, size_t *n); /* allA allT allN fpA fpT fpN Nfile sg */
+/* The whole contig set at once, as the flat host arrays the accessors above index into: consensus strings back to back
+ * (ref, string i = [ref_off[i], ref_off[i+1])), member words back to back (mem, list i = [mem_off[i], mem_off[i+1])).
+ * Any of the out pointers may be NULL.  The arrays belong to the pipeline.                                          */
+int mcomh_contig_set(const mcomh_pipeline *p, size_t *n_contigs, const char **ref, const uint64_t **ref_off,
+                     const uint64_t **mem, const uint64_t **mem_off);
+/* Digest of the result, computed where the result lives (the contig set in HBM, the lists on the host); two runs over the
+ * same reads must give the same eight numbers: out = { contigs, consensus characters, members, unclustered reads (sg),
+ * digest of the strings, digest of the member words, digest of the string + member offsets, digest of sg and the class
+ * lists } (digests: mcom_digest sum ^ rotated xor).  Call after mcomh_pre_process.                                  */
+int mcomh_result_digest(mcomh_pipeline *p, uint64_t out[8]);
 /* counters: rounds merge_rounds passes windows resketch n_sg0 big_bins; timers (ms): t_reads t_bucket
  * t_combine t_realign t_gpu t_host */
 double mcomh_stat(const mcomh_pipeline *p, const char *name);

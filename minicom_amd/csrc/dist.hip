@@ -77,3 +77,49 @@ extern "C" int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_re
 	}
 	return MCOM_OK;
 }
+
+// ---- result digest: wrapping sum and xor of the little-endian 64-bit words of a device array (a tail of fewer than 8
+// bytes is zero-extended).  bench.py prints it for every step and compares it with the digest of a run whose result was
+// checked; two runs with the same digest of strings, members and offsets hold the same contig set.
+__global__ void k_digest(const uint8_t *__restrict__ p, size_t bytes, unsigned long long *__restrict__ out)
+{
+	const size_t nw = bytes >> 3;
+	unsigned long long s = 0, x = 0;
+	const unsigned long long *w = (const unsigned long long*)p;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (size_t)gridDim.x * blockDim.x) {
+		const unsigned long long v = w[i];
+		s += v * (unsigned long long)(2 * (i & 0xFFFFF) + 1); x ^= v;           // the sum is position-weighted: it notices swapped words
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (bytes & 7)) {
+		unsigned long long v = 0;
+		for (size_t b = 0; b < (bytes & 7); ++b) v |= (unsigned long long)p[(nw << 3) + b] << (8 * b);
+		s += v * (unsigned long long)(2 * (nw & 0xFFFFF) + 1); x ^= v;
+	}
+	for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o); x ^= __shfl_xor(x, o); }
+	if ((threadIdx.x & 63) == 0) { unsigned long long *slot = out + 2 * (blockIdx.x & 255); atomicAdd(&slot[0], s); atomicXor(&slot[1], x); }
+}
+__global__ void k_digest_fold(unsigned long long *__restrict__ out)
+{
+	unsigned long long s = 0, x = 0;
+	for (int i = 0; i < 256; ++i) { s += out[2 * i]; x ^= out[2 * i + 1]; }
+	out[512] = s; out[513] = x;
+}
+extern "C" int mcom_digest(mcom_ctx *ctx, const void *d_data, size_t bytes, uint64_t *h_sum_xor)
+{
+	if (!ctx || !h_sum_xor) return MCOM_E_ARG;
+	h_sum_xor[0] = h_sum_xor[1] = 0;
+	if (bytes == 0) return MCOM_OK;
+	if (!d_data || ((uintptr_t)d_data & 7)) return mcom_fail(ctx, MCOM_E_ARG, "digest: null or unaligned device pointer");
+	int rc = mcom_ws_reserve(ctx, 514 * 8);
+	if (rc) return rc;
+	unsigned long long *d = (unsigned long long*)ctx->ws;
+	MCOM_HIP(ctx, hipMemsetAsync(d, 0, 514 * 8, ctx->stream));
+	const size_t nw = bytes >> 3;
+	const unsigned blocks = (unsigned)(nw / 256 + 1 < 4096 ? nw / 256 + 1 : 4096);
+	hipLaunchKernelGGL(k_digest, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_data, bytes, d);
+	hipLaunchKernelGGL(k_digest_fold, dim3(1), dim3(1), 0, ctx->stream, d);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemcpyAsync(h_sum_xor, d + 512, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MCOM_OK;
+}

@@ -193,6 +193,7 @@ struct mcomh_pipeline {
 	int host_threads = 1;
 	// device
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
+	const uint8_t *stream_host = nullptr;    // reads in caller-owned host memory, uploaded chunk by chunk (mcomh_create_streamed)
 	const uint64_t *ext_packed = nullptr;    // packed-row input (mcomh_create_packed): no classification stage
 	const uint64_t *ext_x = nullptr; const uint32_t *ext_ylow = nullptr;   // ... whose minimizers came along (mcomh_set_records)
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
@@ -344,6 +345,19 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	return MCOM_OK;
 }
 
+extern "C" int mcomh_create_streamed(mcomh_pipeline **out, int device, void *hip_stream, const uint8_t *host_reads, size_t n, int L, const mcomh_params *pp)
+{
+	if (!out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (n && !host_reads) return MCOM_E_ARG;
+	static const uint8_t dummy = 0;
+	int rc = mcomh_create(out, device, hip_stream, nullptr, n ? host_reads : &dummy, (size_t)L, n, L, pp);   // parameter resolution; no upload
+	if (rc) return rc;
+	(*out)->d_ascii = nullptr;
+	(*out)->stream_host = host_reads;
+	return MCOM_OK;
+}
+
 extern "C" int mcomh_create_dist(mcomh_pipeline **out, int device, void *hip_stream, mcomh_comm *comm, const uint8_t *host_reads,
                                  const uint8_t *d_reads, size_t pitch, size_t n_local, uint64_t rid0, uint64_t n_total, int L, const mcomh_params *pp)
 {
@@ -427,6 +441,31 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		if (p->ext_x && p->ext_ylow) rc = p->gpu(mcom_records_assemble(p->ctx, p->ext_x, p->ext_ylow, n, 0, p->d_rec.p));
 		else rc = p->gpu(mcom_sketch_reads(p->ctx, p->d_packed.p, nullptr, n, p->L, p->k, 0, p->d_rec.p));
 		if (!rc && p->ext_x) rc = p->sync("records");                         // the caller may release its arrays now
+	} else if (p->stream_host) {
+		// host-to-host: two staging blocks; the copy engine fills one while the kernels read the other
+		const size_t CH = (size_t)4 << 20;
+		DevBuf<uint8_t> stage[2];
+		hipStream_t cs = nullptr; hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+		rc = MCOM_OK;
+		if (!stage[0].reserve(std::min(CH, n) * (size_t)p->L + 16) || !stage[1].reserve(std::min(CH, n) * (size_t)p->L + 16)) rc = p->fail(MCOM_E_NOMEM, "staging blocks");
+		if (!rc) rc = p->hipc(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "copy stream");
+		for (int b = 0; b < 2 && !rc; ++b) { rc = p->hipc(hipEventCreateWithFlags(&up[b], hipEventDisableTiming), "event"); if (!rc) rc = p->hipc(hipEventCreateWithFlags(&done[b], hipEventDisableTiming), "event"); }
+		size_t c = 0;
+		for (size_t lo = 0; lo < n && !rc; lo += CH, ++c) {
+			const int b = (int)(c & 1);
+			const size_t cnt = std::min(CH, n - lo);
+			if (c >= 2) rc = p->hipc(hipStreamWaitEvent(cs, done[b], 0), "wait");                    // the kernels of chunk c-2 have read this block
+			if (!rc) rc = p->hipc(hipMemcpyAsync(stage[b].p, p->stream_host + lo * (size_t)p->L, cnt * (size_t)p->L, hipMemcpyHostToDevice, cs), "upload reads");
+			if (!rc) rc = p->hipc(hipEventRecord(up[b], cs), "event");
+			if (!rc) rc = p->hipc(hipStreamWaitEvent(p->stream, up[b], 0), "wait");
+			if (!rc) rc = p->gpu(mcom_process_reads(p->ctx, stage[b].p, (size_t)p->L, cnt, p->L, p->k, p->e, (uint32_t)lo, p->d_packed.p + lo * p->W, p->d_cls.p + lo, p->d_ncnt.p + lo,
+			                                        p->d_nmask.p + lo * p->NW, p->d_rec.p + lo));
+			if (!rc) rc = p->hipc(hipEventRecord(done[b], p->stream), "event");
+		}
+		if (!rc) rc = p->sync("upload reads");
+		if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+		for (int b = 0; b < 2; ++b) { if (up[b]) (void)hipEventDestroy(up[b]); if (done[b]) (void)hipEventDestroy(done[b]); }
+		p->stat["h2d_chunks"] += (double)c;
 	} else {
 		// rows, classes and N masks are indexed by the global read id: a rank writes its shard's part of the whole arrays
 		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, nl, p->L, p->k, p->e, (uint32_t)r0, p->d_packed.p + r0 * p->W, p->d_cls.p + r0, p->d_ncnt.p,
@@ -1496,6 +1535,47 @@ extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name,
 	if (n) *n = v->size();
 	return v->data();
 }
+extern "C" int mcomh_contig_set(const mcomh_pipeline *cp, size_t *n_contigs, const char **ref, const uint64_t **ref_off, const uint64_t **mem, const uint64_t **mem_off)
+{
+	mcomh_pipeline *p = const_cast<mcomh_pipeline*>(cp);
+	if (!p) return MCOM_E_ARG;
+	const int rc = host_members(p);
+	if (rc) return rc;
+	if (n_contigs) *n_contigs = p->C.n();
+	if (ref) *ref = p->C.ref.data();
+	if (ref_off) *ref_off = p->C.roff.data();
+	if (mem) *mem = p->C.mem.data();
+	if (mem_off) *mem_off = p->C.moff.data();
+	return MCOM_OK;
+}
+
+extern "C" int mcomh_result_digest(mcomh_pipeline *p, uint64_t out[8])
+{
+	if (!p || !out) return MCOM_E_ARG;
+	for (int i = 0; i < 8; ++i) out[i] = 0;
+	p->join_sg();
+	int rc = materialize(p);
+	if (rc) return rc;
+	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set on the device");
+	const DevSet &D = p->dC;
+	auto mix = [](const uint64_t sx[2]) { return sx[0] ^ ((sx[1] << 23) | (sx[1] >> 41)); };
+	uint64_t sx[2], so[2];
+	out[0] = D.n; out[1] = D.chars; out[2] = D.members;
+	if ((rc = p->gpu(mcom_digest(p->ctx, D.seq.p, D.chars, sx)))) return rc;
+	out[4] = mix(sx);
+	if ((rc = p->gpu(mcom_digest(p->ctx, D.mem.p, D.members * 8, sx)))) return rc;
+	out[5] = mix(sx);
+	if ((rc = p->gpu(mcom_digest(p->ctx, D.soff.p, D.n ? (D.n + 1) * 8 : 0, sx))) || (rc = p->gpu(mcom_digest(p->ctx, D.moff.p, D.n ? (D.n + 1) * 8 : 0, so)))) return rc;
+	out[6] = mix(sx) + 3 * mix(so);
+	// the lists live on the host
+	uint64_t h = 0, nsg = 0;
+	for (size_t i = 0; i < p->sg.size(); ++i) if (p->sg_flag.size() != p->sg.size() || !p->sg_flag[i]) { h = h * 0x9E3779B97F4A7C15ull + p->sg[i] + 1; ++nsg; }
+	out[3] = nsg;
+	for (const std::vector<uint32_t> *v : {&p->allA, &p->allT, &p->allN, &p->fpA, &p->fpT, &p->fpN, &p->Nfile}) { h = h * 0xD6E8FEB86659FD93ull + v->size(); for (uint32_t x : *v) h = h * 0x9E3779B97F4A7C15ull + x + 1; }
+	out[7] = h;
+	return MCOM_OK;
+}
+
 extern "C" int mcomh_prof_enable(mcomh_pipeline *p, int on) { return p ? mcom_prof_enable(p->ctx, on) : MCOM_E_ARG; }
 extern "C" int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *total_ms, uint64_t *launches)
 {

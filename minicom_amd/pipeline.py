@@ -35,6 +35,8 @@ def load_host_library():
     vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.mcomh_create.restype = i32
     L.mcomh_create.argtypes = [C.POINTER(vp), i32, vp, vp, vp, sz, sz, i32, C.POINTER(Params)]
+    L.mcomh_create_streamed.restype = i32
+    L.mcomh_create_streamed.argtypes = [C.POINTER(vp), i32, vp, vp, sz, i32, C.POINTER(Params)]
     L.mcomh_set_records.restype = i32; L.mcomh_set_records.argtypes = [vp, vp, vp]
     L.mcomh_create_packed.restype = i32
     L.mcomh_create_packed.argtypes = [C.POINTER(vp), i32, vp, vp, sz, i32, C.POINTER(Params)]
@@ -57,6 +59,9 @@ def load_host_library():
     L.mcomh_contig_n.restype = sz; L.mcomh_contig_n.argtypes = [vp, sz]
     L.mcomh_contig_members.restype = vp; L.mcomh_contig_members.argtypes = [vp, sz]
     L.mcomh_list.restype = vp; L.mcomh_list.argtypes = [vp, cp, C.POINTER(sz)]
+    L.mcomh_contig_set.restype = i32
+    L.mcomh_contig_set.argtypes = [vp, C.POINTER(sz), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.mcomh_result_digest.restype = i32; L.mcomh_result_digest.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mcomh_stat.restype = C.c_double; L.mcomh_stat.argtypes = [vp, cp]
     L.mcomh_prof_enable.restype = i32; L.mcomh_prof_enable.argtypes = [vp, i32]
     L.mcomh_prof_read.restype = i32; L.mcomh_prof_read.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -68,12 +73,13 @@ def load_host_library():
     return L
 
 
-HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
+HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
                     "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order",
                     "mcomh_cluster_dump_pe", "mcomh_decompress_pe", "mcomh_fastq_pair_to_device",
+                    "mcomh_contig_set", "mcomh_result_digest",
                     # multi-GPU (bound in minicom_amd/distributed.py)
                     "mcomh_comm_unique_id", "mcomh_comm_create_rccl", "mcomh_comm_create_ops", "mcomh_comm_destroy", "mcomh_comm_rank",
                     "mcomh_comm_world", "mcomh_comm_last_error", "mcomh_comm_alltoallv", "mcomh_comm_allgatherv", "mcomh_comm_allreduce_u64",
@@ -152,6 +158,24 @@ class Pipeline:
             assert int(x.shape[0]) == n and int(ylow.shape[0]) == n
             self._keep = (self._keep, x, ylow)
             self._check(self.lib.mcomh_set_records(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(ylow.data_ptr())))
+
+    @classmethod
+    def from_host_streamed(cls, reads, device: int = 0, **params):
+        """mcomh_create_streamed: reads = torch uint8 CPU tensor (ideally pinned) or numpy array [n, L], NOT copied on the
+        host; kt_for_reads uploads it chunk by chunk beside the classification kernels.  Keep `reads` alive."""
+        lib = load_host_library()
+        n, L = int(reads.shape[0]), int(reads.shape[1])
+        ptr = reads.ctypes.data if isinstance(reads, np.ndarray) else reads.data_ptr()
+        self = cls.__new__(cls)
+        self.lib = lib
+        p = Params(**{k: int(v) for k, v in params.items()})
+        h = C.c_void_p()
+        rc = lib.mcomh_create_streamed(C.byref(h), device, C.c_void_p(0), C.c_void_p(ptr), n, L, C.byref(p))
+        if rc:
+            raise McomError(f"mcomh_create_streamed failed ({rc})")
+        self._h, self._keep = h, reads
+        self.n, self.L = n, L
+        return self
 
     @classmethod
     def from_fastq(cls, path: str, L: int = 0, device: int = 0, chunk_reads: int = 0, path2: str | None = None, **params):
@@ -233,6 +257,27 @@ class Pipeline:
         if not n.value:
             return np.zeros(0, dtype=np.uint32)
         return np.frombuffer((C.c_char * (4 * n.value)).from_address(ptr), dtype=np.uint32).copy()
+
+    def contig_set(self):
+        """(ref uint8 [chars], ref_off uint64 [n + 1], mem uint64 [members], mem_off uint64 [n + 1]): the whole contig set as
+        flat numpy arrays (copies), mcomh_contig_set."""
+        n = C.c_size_t(); ref, ro, mem, mo = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.mcomh_contig_set(self._h, C.byref(n), C.byref(ref), C.byref(ro), C.byref(mem), C.byref(mo)))
+        nc = n.value
+
+        def arr(ptr, dtype, count):
+            if not count:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr.value), dtype=dtype).copy()
+        roff = arr(ro, np.uint64, nc + 1) if nc else np.zeros(1, np.uint64)
+        moff = arr(mo, np.uint64, nc + 1) if nc else np.zeros(1, np.uint64)
+        return arr(ref, np.uint8, int(roff[-1])), roff, arr(mem, np.uint64, int(moff[-1])), moff
+
+    def result_digest(self):
+        """mcomh_result_digest: eight numbers that two runs over the same reads must share."""
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.mcomh_result_digest(self._h, out))
+        return [int(v) for v in out]
 
     def contigs(self):
         out = []
