@@ -1,0 +1,19 @@
+// minicomsg IN.fastq OUTDIR [options] -- the single-end compressor binary of the reference (minicommain.c:81-216, run by the
+// script as `./minicomsg $filename $compfiles`, minicom:106), over libmcom_host.so: FASTQ -> HBM -> Stage 1 + Stage 2 ->
+// the stream files of cluster_dump in OUTDIR (which must exist).  -p = the reference built with ORDER (minicom:59-62).
+#include "cli_common.hpp"
+
+int main(int argc, char **argv)
+{
+	CliOptions o;
+	if (argc < 3 || !cli_parse(argc, argv, 3, o)) { fprintf(stderr, "usage: minicomsg IN.fastq OUTDIR [-k K -e E -m M -w W -s S -S STEP -E MAXTHR -g CBTHR -R ROUNDS -t THREADS -p -D GPU]\n"); return 1; }
+	int L = 0; size_t n = 0; uint8_t *d_reads = nullptr; char err[256] = "";
+	int rc = mcomh_fastq_to_device(argv[1], o.device, &L, 0, &d_reads, &n, err, sizeof err);
+	if (rc) { fprintf(stderr, "%s: %s\n", argv[1], err[0] ? err : "cannot read"); return 1; }
+	mcomh_pipeline *mp = nullptr;
+	if ((rc = mcomh_create(&mp, o.device, nullptr, nullptr, d_reads, (size_t)L, n, L, &o.prm))) { fprintf(stderr, "mcomh_create failed (%d): no usable GPU or bad parameters\n", rc); return 1; }
+	if ((rc = cli_run(mp, n, L)) || (rc = o.order ? mcomh_cluster_dump_order(mp, argv[2]) : mcomh_cluster_dump(mp, argv[2]))) { fprintf(stderr, "%s\n", mcomh_last_error(mp)); return 1; }
+	mcomh_destroy(mp);
+	mcomh_device_free(d_reads);
+	return 0;
+}

@@ -1585,6 +1585,9 @@ extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 {
 	if (!p) return 0;
 	if (!strcmp(name, "k")) return p->k;
+	if (!strcmp(name, "e")) return p->e;
+	if (!strcmp(name, "step")) return p->step;
+	if (!strcmp(name, "maxthr")) return p->maxthr;
 	if (!strcmp(name, "rw")) return p->rw;
 	if (!strcmp(name, "maxsearch")) return p->maxsearch;
 	auto it = p->stat.find(name);
