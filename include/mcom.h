@@ -62,6 +62,13 @@ int mcom_prof_enable(mcom_ctx *ctx, int on);
 int mcom_prof_reset(mcom_ctx *ctx);
 int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
 
+/* Diagnostics.  mcom_counter: "sort_overflow_segments" = segments of mcom_sort_group that did not fit its in-LDS sort and
+ * went through the nine-pass sort instead (a minimizer shared by thousands of reads).  mcom_set_segment_capacity lowers
+ * the size above which a segment takes that route (0 = default, at most 4096): lets a small test input exercise it;
+ * results never depend on it.                                                                                        */
+uint64_t mcom_counter(const mcom_ctx *ctx, const char *name);
+int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records);
+
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:
  * classify, substitute N by the majority base (tie order A,T,G,C), 2-bit pack, and sketch the kept

@@ -182,3 +182,17 @@ extern "C" int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms,
 	}
 	return mcom_fail(ctx, MCOM_E_ARG, "unknown profiler name %s", name);
 }
+
+// ---- diagnostics -----------------------------------------------------------------------------------------------
+extern "C" uint64_t mcom_counter(const mcom_ctx *ctx, const char *name)
+{
+	if (!ctx || !name) return 0;
+	if (!strcmp(name, "sort_overflow_segments")) return ctx->sort_overflow_segments;
+	return 0;
+}
+extern "C" int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records)
+{
+	if (!ctx || records > 4096) return MCOM_E_ARG;
+	ctx->seg_cap = records;
+	return MCOM_OK;
+}

@@ -24,6 +24,9 @@ struct mcom_ctx {
 	std::vector<McomProfSpan> prof_open;
 	double prof_ms[PROF_COUNT] = {0};
 	uint64_t prof_calls[PROF_COUNT] = {0};
+	// bucket sort: capacity of an in-LDS segment (0 = the kernel's own 4096; tests lower it to reach the fallback on small
+	// inputs) and how many segments went through the fallback so far
+	uint32_t seg_cap = 0; uint64_t sort_overflow_segments = 0;
 };
 
 // brackets one kernel launch (or a short launch sequence) with events when the profiler is on

@@ -11,6 +11,7 @@
 // cmpcluster order (aligned position descending, rid ascending).  HBM-bound: every pass streams the
 // 16-byte records once for the histogram and once for the scatter, and writes them once.
 #include "mcom_dev.hpp"
+#include <algorithm>
 
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -22,6 +23,7 @@ struct KeySpec {
 	int b;          // bucket bits
 	int kbits;      // 2 * k of the sketch that produced x
 	int L, k_orig;  // for the aligned position of cmpcluster
+	int t;          // mode 5: the MSD key is bucket (b bits) || top t bits of x, records without a minimizer get the largest key
 };
 
 // 128-bit composite key as (lo, hi); digit p = bits [8p, 8p+8)
@@ -31,6 +33,7 @@ __device__ __forceinline__ void make_key(const KeySpec &ks, uint64_t x, uint64_t
 	if (ks.mode == 2) { lo = x & ((1ull << ks.kbits) - 1); hi = 0; return; }   // only the low kbits of x (bucket id)
 	if (ks.mode == 3) { lo = x == U64MAX ? (uint64_t)ks.kbits : ((x & ((1ull << ks.b) - 1)) * (uint64_t)ks.kbits) >> ks.b; hi = 0; return; }
 	if (ks.mode == 4) { lo = y >> 32; hi = 0; return; }
+	if (ks.mode == 5) { lo = x == U64MAX ? (1ull << (ks.b + ks.t)) - 1 : ((x & ((1ull << ks.b) - 1)) << ks.t) | (ks.t ? x >> (ks.kbits - ks.t) : 0ull); hi = 0; return; }
 	if (x == U64MAX) { lo = U64MAX; hi = 0xFFFFFFFFu; return; }           // records without a minimizer sort last
 	const uint64_t bucket = x & ((1ull << ks.b) - 1);
 	const uint64_t K = (bucket << (ks.kbits - ks.b)) | (x >> ks.b);
@@ -144,6 +147,125 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const mcom_mm128 *
 	}
 }
 
+
+// ---- bucket sort in three passes --------------------------------------------------------------------------------------
+// The composite key of a Stage-1 round is 71 bits wide (62 of hash), nine 8-bit LSD passes of 48 bytes per record.  But
+// only its top bits need a global pass: two stable passes on the MSD key [bucket | top t bits of the hash] cut the
+// records into 2^(14+t) segments of about 1500, in final order; what is left of the key is settled inside a segment by
+// one workgroup, in LDS: keys as 64-bit words [x >> b | aligned position], a stable 8-bit LSD sort of 16-bit indices (the
+// per-wave ballot ranking of k_radix_scatter), then the records are written once, in order.  3 passes of the records
+// instead of 9.  A segment larger than the LDS arrays (a repeat: tens of thousands of reads with ONE minimizer, which no
+// prefix can split) is left alone and sorted afterwards by the nine-pass sort, together with the others of its kind.
+#define SS_THREADS 256
+#define SS_CAP 4096
+#define SS_ITEMS (SS_CAP / SS_THREADS)
+
+__device__ __forceinline__ uint32_t msd_key(const KeySpec &ks, uint64_t x)
+{
+	uint64_t lo; uint32_t hi; make_key(ks, x, 0, lo, hi);
+	return (uint32_t)lo;
+}
+// seg_start[k] = first record whose MSD key is >= k (records sorted by it); seg_start[nseg] = n
+__global__ void k_seg_bounds(const mcom_mm128 *__restrict__ s, size_t n, KeySpec ks, uint32_t nseg, uint32_t *__restrict__ seg_start)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t cur = msd_key(ks, s[i].x);
+	const uint32_t first = i ? msd_key(ks, s[i - 1].x) + 1 : 0u;
+	for (uint32_t k = first; k <= cur; ++k) seg_start[k] = (uint32_t)i;
+	if (i == n - 1) for (uint32_t k = cur + 1; k <= nseg; ++k) seg_start[k] = (uint32_t)n;
+}
+
+__global__ __launch_bounds__(SS_THREADS) void k_segment_sort(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out, const uint32_t *__restrict__ seg_start,
+                                                             KeySpec full, int sig_bits, uint32_t cap, uint32_t *__restrict__ ovf_count, uint2 *__restrict__ ovf_list)
+{
+	__shared__ uint64_t keys[SS_CAP];
+	__shared__ uint16_t idx[2][SS_CAP];
+	__shared__ uint32_t wcnt[SS_THREADS / 64][256];
+	__shared__ uint32_t wsum[SS_THREADS / 64];
+	const uint32_t s0 = seg_start[blockIdx.x], n = seg_start[blockIdx.x + 1] - s0;
+	if (n == 0) return;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (n == 1) { if (tid == 0) out[s0] = in[s0]; return; }
+	if (n > cap) {                                                             // left in place; the caller sorts these segments afterwards
+		if (tid == 0) { const uint32_t at = atomicAdd(ovf_count, 1u); ovf_list[at] = make_uint2(s0, s0 + n); }
+		for (uint32_t i = tid; i < n; i += SS_THREADS) out[s0 + i] = in[s0 + i];
+		return;
+	}
+	for (uint32_t i = tid; i < n; i += SS_THREADS) {
+		const mcom_mm128 r = in[s0 + i];
+		uint64_t lo; uint32_t hi; make_key(full, r.x, r.y, lo, hi);           // [bucket | x >> b | position key]: the low sig_bits are what is left to sort
+		keys[i] = lo;
+		idx[0][i] = (uint16_t)i;
+	}
+	// wave w ranks elements [w * per, (w + 1) * per), 64 at a time
+	const uint32_t per = ((n + SS_THREADS - 1) / SS_THREADS) * 64;
+	const int iters = (int)(per >> 6);
+	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+	int cur = 0;
+	for (int shift = 0; shift < sig_bits; shift += 8) {
+		for (int q = tid; q < (SS_THREADS / 64) * 256; q += SS_THREADS) (&wcnt[0][0])[q] = 0;
+		__syncthreads();
+		uint16_t id[SS_ITEMS], rank[SS_ITEMS]; uint8_t dig[SS_ITEMS];
+#pragma unroll
+		for (int c = 0; c < SS_ITEMS; ++c) if (c < iters) {                      // wave-uniform: the arrays stay in registers
+			const uint32_t i = (uint32_t)wv * per + (uint32_t)c * 64 + lane;
+			const bool valid = i < n;
+			uint32_t d = 0;
+			id[c] = 0;
+			if (valid) { id[c] = idx[cur][i]; d = (uint32_t)(keys[id[c]] >> shift) & 255u; }
+			uint64_t peers = __ballot(valid);
+#pragma unroll
+			for (int bit = 0; bit < 8; ++bit) {
+				const bool one = (d >> bit) & 1;
+				const uint64_t bl = __ballot(one);
+				peers &= one ? bl : ~bl;
+			}
+			uint32_t old = 0;
+			const int leader = __ffsll((unsigned long long)peers) - 1;
+			if (valid && lane == leader) { old = wcnt[wv][d]; wcnt[wv][d] = old + (uint32_t)__popcll(peers); }
+			old = __shfl(old, leader < 0 ? 0 : leader, 64);
+			rank[c] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
+			dig[c] = (uint8_t)d;
+		}
+		__syncthreads();
+		{   // digit totals -> exclusive prefix over the 256 digits -> start of every wave's share of a digit
+			const int d = tid;
+			uint32_t c[SS_THREADS / 64], tot = 0;
+#pragma unroll
+			for (int w = 0; w < SS_THREADS / 64; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+			uint32_t v = tot;
+#pragma unroll
+			for (int s = 1; s < 64; s <<= 1) { const uint32_t t = __shfl_up(v, s, 64); if (lane >= s) v += t; }
+			if (lane == 63) wsum[wv] = v;
+			__syncthreads();
+			uint32_t add = 0;
+			for (int q = 0; q < wv; ++q) add += wsum[q];
+			uint32_t run = v + add - tot;
+#pragma unroll
+			for (int w = 0; w < SS_THREADS / 64; ++w) { wcnt[w][d] = run; run += c[w]; }
+		}
+		__syncthreads();
+#pragma unroll
+		for (int c = 0; c < SS_ITEMS; ++c) if (c < iters) {
+			const uint32_t i = (uint32_t)wv * per + (uint32_t)c * 64 + lane;
+			if (i < n) idx[cur ^ 1][wcnt[wv][dig[c]] + rank[c]] = id[c];
+		}
+		__syncthreads();
+		cur ^= 1;
+	}
+	__syncthreads();
+	for (uint32_t j = tid; j < n; j += SS_THREADS) out[s0 + j] = in[s0 + idx[cur][j]];
+}
+
+// gather / scatter of the oversized segments: compact[dst[q] + i] <-> arr[list[q].x + i]
+__global__ void k_seg_move(mcom_mm128 *__restrict__ arr, mcom_mm128 *__restrict__ compact, const uint2 *__restrict__ list, const uint32_t *__restrict__ dst, int back)
+{
+	const uint2 sg = list[blockIdx.x];
+	const uint32_t d0 = dst[blockIdx.x];
+	for (uint32_t i = threadIdx.x; i < sg.y - sg.x; i += blockDim.x) { if (back) arr[sg.x + i] = compact[d0 + i]; else compact[d0 + i] = arr[sg.x + i]; }
+}
+
 // ---- generic exclusive scan of uint32 (2048 elements per block, recursive on the block sums) -------
 #define SC_THREADS 256
 #define SC_PER 8
@@ -243,7 +365,7 @@ int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws)
 {
 	if (n == 0) return MCOM_OK;
 	SortWs w; sort_ws_layout(n, &w, (char*)ws);
-	KeySpec ks{0, 0, 64, 0, 0};
+	KeySpec ks{0, 0, 64, 0, 0, 0};
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -256,7 +378,7 @@ int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, vo
 {
 	if (n == 0) return MCOM_OK;
 	SortWs w; sort_ws_layout(n, &w, (char*)ws);
-	KeySpec ks{2, 0, bits, 0, 0};
+	KeySpec ks{2, 0, bits, 0, 0, 0};
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -280,7 +402,7 @@ extern "C" int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, s
 	int rc = mcom_ws_reserve(ctx, hist_b + scan_scratch_elems((size_t)256 * nblocks) * 4 + 1024);
 	if (rc) return rc;
 	uint32_t *hist = (uint32_t*)ctx->ws, *scratch = (uint32_t*)((char*)ctx->ws + hist_b);
-	KeySpec ks{3, b, ranks, 0, 0};
+	KeySpec ks{3, b, ranks, 0, 0, 0};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
 		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, n, ks, 0, hist, nblocks);
@@ -306,7 +428,7 @@ extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 	int rc = mcom_ws_reserve(ctx, sort_ws_layout(n, nullptr, nullptr));
 	if (rc) return rc;
 	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
-	KeySpec ks{4, 0, 32, 0, 0};
+	KeySpec ks{4, 0, 32, 0, 0, 0};
 	mcom_mm128 *res = nullptr;
 	if ((rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 4, w.hist, w.scratch, &res))) return rc;
 	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
@@ -326,7 +448,7 @@ extern "C" int mcom_radix_sort_128x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 	int rc = mcom_ws_reserve(ctx, need);
 	if (rc) return rc;
 	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
-	KeySpec ks{0, 0, 64, 0, 0};
+	KeySpec ks{0, 0, 64, 0, 0, 0};
 	mcom_mm128 *res = nullptr;
 	rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -391,7 +513,14 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	const size_t sort_bytes = sort_ws_layout(n, nullptr, nullptr);
 	const size_t flag_bytes = ((n * 4 + 255) & ~(size_t)255);
 	const size_t scr_bytes = ((scan_scratch_elems(n) * 4 + 1024 + 255) & ~(size_t)255);
-	const size_t need = sort_bytes + 3 * flag_bytes + scr_bytes + 256;
+	// the sort: passes on the MSD key [bucket | top t bits of the hash] until a segment holds about 1500 records, the rest of the
+	// key inside the segments (k_segment_sort); the last global pass lands in the workspace, the segment sort in d_sorted
+	int t = 0;
+	while ((n >> (b + t)) > 2048 && b + t < 24 && b + t < 2 * kmer) ++t;
+	const int B = b + t, passes = (B + 7) / 8;
+	const uint32_t nseg = 1u << B;
+	const size_t segs_b = (((size_t)nseg + 2) * 4 + 255) & ~(size_t)255, list_b = ((size_t)nseg * 8 + 255) & ~(size_t)255, dst_b = ((size_t)nseg * 4 + 255) & ~(size_t)255;
+	const size_t need = sort_bytes + 3 * flag_bytes + scr_bytes + 256 + segs_b + list_b + dst_b + 256;
 	int rc = mcom_ws_reserve(ctx, need);
 	if (rc) return rc;
 	char *base = (char*)ctx->ws;
@@ -399,15 +528,62 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	uint32_t *f0 = (uint32_t*)(base + sort_bytes), *f1 = (uint32_t*)(base + sort_bytes + flag_bytes), *f2 = (uint32_t*)(base + sort_bytes + 2 * flag_bytes);
 	uint32_t *scr = (uint32_t*)(base + sort_bytes + 3 * flag_bytes);
 	uint64_t *d_counts = (uint64_t*)(base + sort_bytes + 3 * flag_bytes + scr_bytes);
+	char *segbase = base + sort_bytes + 3 * flag_bytes + scr_bytes + 256;
+	uint32_t *seg_start = (uint32_t*)segbase, *ovf_dst = (uint32_t*)(segbase + segs_b + list_b), *ovf_count = (uint32_t*)(segbase + segs_b + list_b + dst_b);
+	uint2 *ovf_list = (uint2*)(segbase + segs_b);
 
-	MCOM_HIP(ctx, hipMemcpyAsync(d_sorted, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
-	KeySpec ks{1, b, 2 * kmer, L, k_orig};
-	const int bits = 2 * kmer + 9 + 1;                 // +1: the all-ones key of records without a minimizer
-	const int passes = (bits + 7) / 8;
-	mcom_mm128 *res = nullptr;
-	rc = radix_sort_records(ctx, d_sorted, w.tmp, n, ks, passes, w.hist, w.scratch, &res);
-	if (rc) return rc;
-	if (res != d_sorted) MCOM_HIP(ctx, hipMemcpyAsync(d_sorted, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	const KeySpec full{1, b, 2 * kmer, L, k_orig, 0};
+	const KeySpec msd{5, b, 2 * kmer, L, k_orig, t};
+	const int sig_bits = 9 + 2 * kmer - B;
+	{
+		const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+		const mcom_mm128 *src = d_rec;
+		mcom_mm128 *dst = (passes & 1) ? w.tmp : d_sorted;
+		for (int p = 0; p < passes; ++p) {
+			McomProfScope ps_(ctx, PROF_RADIX_PASS);
+			hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, msd, p, w.hist, nblocks);
+			MCOM_LAUNCH_CHECK(ctx);
+			if ((rc = scan_u32(ctx, w.hist, w.hist, (size_t)256 * nblocks, w.scratch))) return rc;
+			hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, msd, p, w.hist, nblocks);
+			MCOM_LAUNCH_CHECK(ctx);
+			src = dst; dst = dst == w.tmp ? d_sorted : w.tmp;
+		}
+		uint32_t novf = 0;
+		{
+			McomProfScope ps_(ctx, PROF_RADIX_PASS);
+			hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
+			MCOM_HIP(ctx, hipMemsetAsync(ovf_count, 0, 4, ctx->stream));
+			hipLaunchKernelGGL(k_segment_sort, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits,
+			                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf_count, ovf_list);
+			MCOM_LAUNCH_CHECK(ctx);
+		}
+		MCOM_HIP(ctx, hipMemcpyAsync(&novf, ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->sort_overflow_segments += novf;
+		if (novf) {
+			// segments beyond the LDS arrays (one minimizer shared by thousands of reads): gathered, sorted by the whole key with the
+			// nine-pass sort -- whose order refines the MSD order, so the segments stay apart and in place --, put back
+			std::vector<uint2> list(novf);
+			MCOM_HIP(ctx, hipMemcpy(list.data(), ovf_list, (size_t)novf * sizeof(uint2), hipMemcpyDeviceToHost));
+			std::sort(list.begin(), list.end(), [](const uint2 &a, const uint2 &c) { return a.x < c.x; });
+			std::vector<uint32_t> dst_off(novf);
+			size_t m = 0;
+			for (uint32_t q = 0; q < novf; ++q) { dst_off[q] = (uint32_t)m; m += list[q].y - list[q].x; }
+			MCOM_HIP(ctx, hipMemcpyAsync(ovf_list, list.data(), (size_t)novf * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+			MCOM_HIP(ctx, hipMemcpyAsync(ovf_dst, dst_off.data(), (size_t)novf * 4, hipMemcpyHostToDevice, ctx->stream));
+			void *ws2 = nullptr;
+			if (mcom_dmalloc(&ws2, sort_ws_layout(m, nullptr, nullptr)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "workspace for %zu records of oversized segments", m);
+			SortWs w2; sort_ws_layout(m, &w2, (char*)ws2);
+			hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, w.tmp, ovf_list, ovf_dst, 0);
+			mcom_mm128 *res = nullptr;
+			rc = radix_sort_records(ctx, w.tmp, w2.tmp, m, full, (2 * kmer + 9 + 7) / 8, w2.hist, w2.scratch, &res);
+			if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, res, ovf_list, ovf_dst, 1);
+			hipError_t e2 = hipStreamSynchronize(ctx->stream);
+			mcom_dfree(ws2);
+			if (rc) return rc;
+			if (e2 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "oversized segments: %s", hipGetErrorString(e2));
+		}
+	}
 	const unsigned blocks = (unsigned)((n + 255) / 256);
 	hipLaunchKernelGGL(k_group_flags, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2);
 	MCOM_LAUNCH_CHECK(ctx);

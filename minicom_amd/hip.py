@@ -208,6 +208,15 @@ class Context:
         self._check(self.lib.mcom_radix_sort_128x(self._h, self._p(rec, torch.int64), int(rec.shape[0])))
         return rec
 
+    def counter(self, name: str) -> int:
+        self.lib.mcom_counter.restype = C.c_uint64; self.lib.mcom_counter.argtypes = [C.c_void_p, C.c_char_p]
+        return int(self.lib.mcom_counter(self._h, name.encode()))
+
+    def set_segment_capacity(self, records: int):
+        """Test hook of mcom_sort_group: segments above `records` go through the nine-pass fallback (0 = default 4096)."""
+        self.lib.mcom_set_segment_capacity.restype = C.c_int; self.lib.mcom_set_segment_capacity.argtypes = [C.c_void_p, C.c_uint32]
+        self._check(self.lib.mcom_set_segment_capacity(self._h, records))
+
     def sort_group(self, rec, L: int, k_orig: int, kmer: int, b: int = 14):
         """mcom_sort_group.  Returns dict(sorted, singles, members, group_off) trimmed to their counts."""
         torch = _torch()

@@ -57,16 +57,16 @@ def _expected_groups(rec, L, k_orig, b=14):
     return np.array(singles, dtype=np.uint32), np.array(members, dtype=np.uint64), np.array(goff, dtype=np.uint32)
 
 
-def _check_sort_group(ctx, rec, L, k_orig, kmer):
-    out = ctx.sort_group(_to_dev(rec), L, k_orig, kmer)
-    s, m, g = _expected_groups(rec, L, k_orig)
+def _check_sort_group(ctx, rec, L, k_orig, kmer, b=14):
+    out = ctx.sort_group(_to_dev(rec), L, k_orig, kmer, b=b)
+    s, m, g = _expected_groups(rec, L, k_orig, b)
     assert out["n_valid"] == int((rec["x"] != MAXU).sum())
     assert np.array_equal(out["singles"].cpu().numpy().view(np.uint32), s)
     assert np.array_equal(out["members"].cpu().numpy().view(np.uint64), m)
     assert np.array_equal(out["group_off"].cpu().numpy().view(np.uint32), g)
     srt = _from_dev(out["sorted"])
     nv = out["n_valid"]
-    bucket = srt["x"][:nv] & np.uint64(0x3FFF)
+    bucket = srt["x"][:nv] & np.uint64((1 << b) - 1)
     assert np.all(np.diff(bucket.astype(np.int64)) >= 0)
     assert np.all(srt["x"][nv:] == MAXU)
     return len(s), len(g) - 1
@@ -107,6 +107,44 @@ def test_sort_group_heavy_duplicates_and_big_groups(ctx):
     rec["y"] = (rid << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, n).astype(np.uint64)
     rec["x"][5] = MAXU; rec["y"][5] = MAXU
     _check_sort_group(ctx, rec, 100, 31, 31)
+
+
+def test_sort_group_segments_beyond_the_lds_sort(ctx):
+    """One minimizer shared by 20 000 reads cannot be split by any key prefix: such segments leave the in-LDS segment sort
+    for the nine-pass sort (sort.hip).  Three of them, beside ordinary records; then the same with the capacity lowered so
+    that nearly every segment takes that route."""
+    rng = np.random.default_rng(11)
+    n = 90000
+    big = rng.integers(0, 1 << 62, 3, dtype=np.uint64)
+    rec = np.zeros(n, dtype=[("x", "<u8"), ("y", "<u8")])
+    rec["x"] = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    rec["x"][:60000] = big[rng.integers(0, 3, 60000)]
+    rec["x"][60000:70000] = rec["x"][70000:80000]                                        # pairs
+    perm = rng.permutation(n)
+    rec["x"] = rec["x"][perm]
+    pos = rng.integers(30, 100, n).astype(np.uint64)
+    rec["y"] = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, n).astype(np.uint64)
+    rec["x"][17] = MAXU; rec["y"][17] = MAXU
+    before = ctx.counter("sort_overflow_segments")
+    _check_sort_group(ctx, rec, 100, 31, 31)
+    assert ctx.counter("sort_overflow_segments") - before == 3
+    ctx.set_segment_capacity(2)
+    try:
+        before = ctx.counter("sort_overflow_segments")
+        _check_sort_group(ctx, rec, 100, 31, 31)
+        assert ctx.counter("sort_overflow_segments") - before > 1000
+    finally:
+        ctx.set_segment_capacity(0)
+
+
+def test_sort_group_two_million_records_use_wider_msd_keys(ctx):
+    """Above 2048 records per bucket the MSD key takes hash bits too (three global passes instead of two at 2^25 records)."""
+    import oracle
+    from minicom_amd import synth
+    n, L, k = 2_400_000, 100, 31
+    reads = synth.synth_reads(77, n, L)
+    rec = oracle.sketch_two_batch(reads, k)
+    _check_sort_group(ctx, rec, L, k, k, b=6)                                           # few buckets: 37 500 records each, t = 5
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 4096, 4097, 8193])
