@@ -88,17 +88,16 @@ def algorithmic_bytes(name, st, L, nd, model="word"):
 
 
 def cindex_bytes(st, model):
-    """The contig 17-mer index of Stage 2, per build: the table cleared (8 B per slot) plus, per indexed position,
-    word: 16 B of packed contig read + 8 B counter read + 8 B atomic + 8 B slot written = 40 B;
-    sector: one 64-B line read and written + 16 B of packed contig = 96 B (what a scattered insert makes the memory move)."""
-    per = 40 if model == "word" else 96
-    return 8 * st.get("cix_slots", 0) + per * st.get("cix_entries", 0)
+    """The contig 17-mer index of Stage 2 (csrc/cindex.hip), per build: radix-partitioned, everything streams, so words and
+    sectors coincide.  Per entry (12 bytes: 4 of partition + home bits, 8 of slot): written by pass 1, read twice (histogram: the
+    4-byte half only) and written by pass 2, read by the placement (its second read comes from L2); plus the table, written once."""
+    return (12 + 4 + 12 + 12 + 12) * st.get("cix_entries", 0) + 8 * st.get("cix_slots", 0)
 
 
 # HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": "k_sketch_contigs", "cindex_build": "k_cindex_insert", "realign_reads": "k_realign_reads<5, 16, false>",
+PMC_KERNELS = {"sketch_contigs": "k_sketch_contigs", "cindex_build": "k_cx_scatter2", "realign_reads": "k_realign_reads<5, 16, false>",
                "classify_pack": "k_classify_pack<32>", "sketch_reads": "k_sketch_reads<5, true>"}
 
 
@@ -292,8 +291,6 @@ def main():
         if roof:
             roof["traffic_source"] = "profiles/pmc_constants.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None
             roof["device_ms_per_step_by_kernel"] = per_step
-            if roof["kernel"] == "cindex_build":
-                roof["sector_model"] = hbm_line("cindex_build", "sector")
             if roof["kernel"] == "sketch_contigs":
                 roof["note"] = "integer-issue bound (see issue_roofline): 1 byte in and 0.07 records out per position; the HBM fraction is small by construction"
             # the per-read sketch kernel alone (SURVEY section 8d asks for it): ALU bound, so both rooflines
@@ -312,7 +309,7 @@ def main():
             if roof["kernel"] != "cindex_build":
                 hb = hbm_line("cindex_build")
                 if hb:
-                    hb["sector_model"] = hbm_line("cindex_build", "sector")
+                    hb["note"] = "radix-partitioned build (two streaming passes + one placement pass per partition): word and sector models coincide"
                     roof["hbm_bound_kernel"] = hb
         res = {
             "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",

@@ -68,6 +68,9 @@ int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *
  * results never depend on it.                                                                                        */
 uint64_t mcom_counter(const mcom_ctx *ctx, const char *name);
 int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records);
+/* Likewise for mcom_cindex_build: partitions with more than `entries` entries are placed by the scattered kernel instead of
+ * the sorted one (0 = all of them; negative = default).  Same index either way.                                       */
+int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
 
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:
@@ -229,33 +232,42 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
                       uint64_t n_windows, int thr, int maxsearch, uint64_t *d_claim, uint64_t *d_stats);
 
 /* The same pass driven from the singletons (results identical to mcom_realign_pass; it is the production path).
- * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed
- * ONCE: mcom_cindex_plan sizes the index (d_keys: 8 << log2lines uint64 in lines of eight: an insert counter and
- * seven slots; a slot is a 12-bit tag of the key, the contig (24 bits) and the position (28 bits)) for a contig set, mcom_cindex_build fills it from the packed
- * contigs (d_woff must hold n_contigs + 1 entries).  mcom_realign_pass_reads then looks up, for every
- * unflagged singleton, the key of each dictionary l at contig position window + ds[l] and the reverse complement
- * of that key at window + L - ds[l] - klen (the two probes of kthread_hash_realign.c:380 and :446 seen from the
- * read), verifies every hit like :390-393 / :458-461 -- including the exact key comparison of :385-386, which
- * the tags leave open -- and keeps the minimum claim key per singleton.
+ * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed ONCE.
+ * The index (csrc/cindex.hip) is a multi-map of 64-byte lines -- word 0: entries in the line (| 0x100 when entries were
+ * pushed past it), words 1-7: entries = 12-bit tag of the key | contig (24 bits) | position (28 bits) -- cut into
+ * partitions of equal size; a key hashes to a partition and a home line, its entries lie in the home line and the lines
+ * behind it; a key with more copies than a few lines hold (a repeat) keeps them in a run of lines of its own in the
+ * extension area behind the partitions.  It is BUILT BY RADIX PARTITIONING: two streaming passes split
+ * the entries by partition, then one workgroup per partition places its entries and writes its lines once (no scattered
+ * insert, no memset, no atomics in HBM).
+ *   mcom_cindex_plan   sizes it for a contig set: *geom (partitions | lines per partition << 16, handed to the build and
+ *                      the lookups), *n_words = uint64 words of d_keys (header, partitions, extension area)
+ *   mcom_cindex_build  fills d_keys from the packed contigs (d_woff must hold n_contigs + 1 entries); temporaries of
+ *                      24 bytes per entry come from the library's block pool.  MCOM_E_OVERFLOW: the extension area is
+ *                      too small for this set's repeats -- build again with a larger n_words.  Synchronous.
+ * mcom_realign_pass_reads then looks up, for every unflagged singleton, the key of each dictionary l at contig position
+ * window + ds[l] and the reverse complement of that key at window + L - ds[l] - klen (the two probes of
+ * kthread_hash_realign.c:380 and :446 seen from the read), verifies every hit like :390-393 / :458-461 -- including the
+ * exact key comparison of :385-386, which the tags leave open -- and keeps the minimum claim key per singleton.
  *   d_elig : NULL, or [n_sg] bit l set = the singleton is within the last `maxsearch` entries of its bin of
  *            dictionary l as built (mcom_dicts_eligible).  This static cut equals mcom_realign_pass with its
  *            maxsearch argument; both equal the reference only while no bin exceeds maxsearch -- for longer
  *            bins use mcom_dicts_bigbins / mcom_realign_pass_tuples below
  *   d_stats: optional [3] = { lookups, windows verified, tuples passing }                                */
-int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines);
+int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *geom, uint64_t *n_words);
 int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                      uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys);
+                      uint64_t n_windows, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words);
 /* mcom_cindex_build for contigs [c0, c1) of the set only: the multi-GPU path gives every rank a range of the replicated
  * contig set (size the index with mcom_cindex_plan(windows of the range, c1 - c0, ...)); entries carry the global
  * contig index, so that claim keys found against different ranks' parts are comparable.                        */
 int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                            uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys);
+                            uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words);
 int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
 /* Screen before mcom_dicts_build: *h_may_exceed = 0 proves that no bin of any dictionary over these singletons
  * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
  * neither the dictionaries nor d_elig; 1 = build them and look.  Synchronous.                                */
 int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed);
-int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines,
+int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom,
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
@@ -274,7 +286,7 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2
  *   mcom_claims_patch        d_claim[d_idx[i]] = d_val[i]: the result of replaying the marked singletons
  * The replay itself (a few thousand reads, in visiting order) is host work: minicom_amd/host/mcom_pipeline.cpp.  */
 int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_binstart, uint8_t *d_mark);
-int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines,
+int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom,
                              const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg,
                              const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                              int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats,

@@ -196,3 +196,9 @@ extern "C" int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records)
 	ctx->seg_cap = records;
 	return MCOM_OK;
 }
+extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
+{
+	if (!ctx) return MCOM_E_ARG;
+	ctx->cix_cap_set = entries >= 0; ctx->cix_cap = entries >= 0 ? (uint32_t)entries : 0u;
+	return MCOM_OK;
+}

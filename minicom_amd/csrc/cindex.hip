@@ -1,0 +1,584 @@
+// minicom_amd/csrc/cindex.hip -- the Stage-2 contig index, built by radix partitioning (no scattered insert).
+//
+// What it is for (realign.hip): every klen-mer of the Stage-2 contigs, findable by key, so that a
+// singleton looks up its own 2*nd - 1 keys instead of every contig window asking every dictionary.
+//
+// Structure: a multi-map of lines of 8 words (64 bytes): word 0 = number of entries in the line (| 0x100 when entries
+// were pushed past it), words 1-7 = entries tag12 | contig24 | position28.  The table is cut into partitions of equal size
+// (a few thousand lines); a key hashes to a partition and to a HOME line inside it -- an address computed from the key
+// alone -- and its entries lie in the home line and, when that is full, in the lines behind it (wrapping inside the
+// partition): bucketed linear probing, placed exactly: entries in home order take consecutive slot positions,
+// pos = max(7 * home, previous + 1).  A home line with more entries than a few lines' worth (a repeat: 10^5 copies of one
+// key) keeps them out of the partition, in a run of lines of its own in the extension area behind the table, and says where.
+//
+// Build.  Round 1 inserted entry by entry into the whole 17 GB table: one random 64-byte line read and written per entry,
+// DRAM-random bound (2 TB/s of line traffic for 0.25 of the roofline by sectors, 0.13 by words).  Now everything streams:
+//   1. two radix passes split the entries {partition | home bits, slot word} (12 bytes, two arrays) by partition: the
+//      first pass computes them straight from the packed contigs (one thread per contig position), tiles of 4096, LDS-staged
+//      so that every digit's run leaves the tile in one piece; the second is the stable pass of sort.hip on two arrays;
+//   2. the starts of the partitions in the sorted arrays are found;
+//   3. one workgroup per partition places its entries: home counts (LDS atomics), the carry into every line (what the
+//      lines before it could not hold: a max-plus scan, wrapped once round the partition), slot positions, and writes
+//      the partition's lines -- a region of ~150 KB that one workgroup fills within microseconds, so the writes meet in
+//      L2 and every line goes to HBM once.  No memset, no atomics in HBM.
+#include "cindex.hpp"
+#include <algorithm>
+
+#define CX_THREADS 256
+#define CX_ITEMS 16
+#define CX_TILE (CX_THREADS * CX_ITEMS)
+
+// ---- position space (as before): contig c owns [woff[c] + maxoff*c, woff[c+1] + maxoff*(c+1)); positions p = 0 .. nw-1+maxoff
+// of a contig with nw > 0 windows are indexed.  first_contig[b] = the contig that owns position 256*b (counted from pos0).
+__global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, uint32_t c0, uint32_t c1, uint64_t pos0, uint64_t n_blocks, uint32_t *__restrict__ first_contig)
+{
+	const uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= c1) return;
+	const uint64_t a = woff[c] + (uint64_t)maxoff * c - pos0, b = woff[c + 1] + (uint64_t)maxoff * (c + 1) - pos0;
+	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
+}
+
+struct CxSrc { const uint64_t *cbits, *coff, *woff; const uint32_t *first_contig; uint32_t c1; uint64_t pos0, n_pos; };
+
+// the entry of position gi: false when the position holds none (a contig without windows, the end of the range)
+__device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint64_t gi, uint32_t &key32, uint64_t &slot)
+{
+	if (gi >= s.n_pos) return false;
+	uint32_t c = s.first_contig[gi >> 8];
+	while (c + 1 < s.c1 && s.woff[c + 1] + (uint64_t)g.maxoff * (c + 1) - s.pos0 <= gi) ++c;
+	if (s.woff[c + 1] == s.woff[c]) return false;
+	const uint64_t p = gi - (s.woff[c] + (uint64_t)g.maxoff * c - s.pos0);
+	const uint64_t *src = s.cbits + s.coff[c] + ((2 * p) >> 6);
+	const int sh = (int)((2 * p) & 63);
+	uint64_t v = src[0] >> sh;
+	if (sh + 2 * g.klen > 64) v |= src[1] << (64 - sh);
+	const uint64_t key = v & ((1ull << (2 * g.klen)) - 1);
+	uint32_t part, h16;
+	cix_hash(key, g.n_parts, part, h16);
+	key32 = (part << 16) | h16;
+	slot = (cix_tag(key) << 52) | ((uint64_t)c << CIX_PBITS) | p;
+	return true;
+}
+
+// pass 1, histogram: digit = low byte of the partition
+__global__ __launch_bounds__(CX_THREADS) void k_cx_hist1(CixGeom g, CxSrc s, uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
+#pragma unroll 4
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		uint32_t k32; uint64_t sl;
+		if (cx_entry(g, s, base + (uint64_t)it * CX_THREADS + threadIdx.x, k32, sl)) atomicAdd(&h[(k32 >> 16) & 255u], 1u);
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// pass 1, scatter: the tile's entries grouped by digit in LDS (order inside a digit is free), every digit's run written in one piece
+__global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, const uint32_t *__restrict__ offs, uint32_t nblocks,
+                                                            uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot)
+{
+	__shared__ uint64_t st_slot[CX_TILE];
+	__shared__ uint32_t st_key[CX_TILE];
+	__shared__ uint32_t cnt[256], start[256], gofs[256], wsum[CX_THREADS / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	cnt[tid] = 0;
+	__syncthreads();
+	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
+	uint32_t k32[CX_ITEMS], rank[CX_ITEMS]; uint64_t sl[CX_ITEMS]; bool ok[CX_ITEMS];
+#pragma unroll
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		ok[it] = cx_entry(g, s, base + (uint64_t)it * CX_THREADS + tid, k32[it], sl[it]);
+		rank[it] = ok[it] ? atomicAdd(&cnt[(k32[it] >> 16) & 255u], 1u) : 0u;
+	}
+	__syncthreads();
+	{
+		const uint32_t tot = cnt[tid];
+		uint32_t v = tot;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+		if (lane == 63) wsum[wv] = v;
+		__syncthreads();
+		uint32_t add = 0;
+		for (int q = 0; q < wv; ++q) add += wsum[q];
+		start[tid] = v + add - tot;
+		gofs[tid] = offs[(size_t)tid * nblocks + blockIdx.x];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int it = 0; it < CX_ITEMS; ++it) if (ok[it]) {
+		const uint32_t at = start[(k32[it] >> 16) & 255u] + rank[it];
+		st_key[at] = k32[it]; st_slot[at] = sl[it];
+	}
+	__syncthreads();
+	const uint32_t total = start[255] + cnt[255];
+	for (uint32_t q = tid; q < total; q += CX_THREADS) {
+		const uint32_t k = st_key[q], d = (k >> 16) & 255u;
+		const size_t o = (size_t)gofs[d] + (q - start[d]);
+		out_key[o] = k; out_slot[o] = st_slot[q];
+	}
+}
+
+// pass 2 (digit = high byte of the partition), stable: the tile logic of sort.hip's k_radix_scatter on two arrays
+__global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+	__shared__ uint32_t h[256];
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * CX_TILE;
+#pragma unroll 4
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		const size_t i = base + (size_t)it * CX_THREADS + threadIdx.x;
+		if (i < n) atomicAdd(&h[key[i] >> 24], 1u);
+	}
+	__syncthreads();
+	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__restrict__ in_key, const uint64_t *__restrict__ in_slot, size_t n,
+                                                            const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot)
+{
+	__shared__ uint64_t st_slot[CX_TILE];
+	__shared__ uint32_t st_key[CX_TILE];
+	__shared__ uint32_t wcnt[CX_THREADS / 64][256];
+	__shared__ uint32_t tstart[256], gofs[256], wsum[CX_THREADS / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	for (int q = tid; q < (CX_THREADS / 64) * 256; q += CX_THREADS) (&wcnt[0][0])[q] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * CX_TILE + (size_t)wv * (CX_TILE / (CX_THREADS / 64));
+	uint32_t k32[CX_ITEMS]; uint64_t sl[CX_ITEMS]; uint16_t rank[CX_ITEMS];
+	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+	for (int c = 0; c < CX_ITEMS; ++c) {
+		const size_t i = base + (size_t)c * 64 + lane;
+		const bool valid = i < n;
+		uint32_t d = 0;
+		if (valid) { k32[c] = in_key[i]; sl[c] = in_slot[i]; d = k32[c] >> 24; }
+		uint64_t peers = __ballot(valid);
+#pragma unroll
+		for (int bit = 0; bit < 8; ++bit) {
+			const bool one = (d >> bit) & 1;
+			const uint64_t bl = __ballot(one);
+			peers &= one ? bl : ~bl;
+		}
+		uint32_t old = 0;
+		const int leader = __ffsll((unsigned long long)peers) - 1;
+		if (valid && lane == leader) { old = wcnt[wv][d]; wcnt[wv][d] = old + (uint32_t)__popcll(peers); }
+		old = __shfl(old, leader < 0 ? 0 : leader, 64);
+		rank[c] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
+	}
+	__syncthreads();
+	{
+		const int d = tid;
+		uint32_t c[CX_THREADS / 64], tot = 0;
+#pragma unroll
+		for (int w = 0; w < CX_THREADS / 64; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+		uint32_t v = tot;
+#pragma unroll
+		for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = __shfl_up(v, sft, 64); if (lane >= sft) v += t; }
+		if (lane == 63) wsum[wv] = v;
+		__syncthreads();
+		uint32_t add = 0;
+		for (int q = 0; q < wv; ++q) add += wsum[q];
+		uint32_t run = v + add - tot;
+		tstart[d] = run;
+#pragma unroll
+		for (int w = 0; w < CX_THREADS / 64; ++w) { wcnt[w][d] = run; run += c[w]; }
+		gofs[d] = offs[(size_t)d * nblocks + blockIdx.x];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int c = 0; c < CX_ITEMS; ++c) {
+		const size_t i = base + (size_t)c * 64 + lane;
+		if (i < n) { const uint32_t at = wcnt[wv][k32[c] >> 24] + rank[c]; st_key[at] = k32[c]; st_slot[at] = sl[c]; }
+	}
+	__syncthreads();
+	const size_t tile_base = (size_t)blockIdx.x * CX_TILE;
+	const uint32_t total = (uint32_t)((n - tile_base) < (size_t)CX_TILE ? (n - tile_base) : (size_t)CX_TILE);
+	for (uint32_t q = tid; q < total; q += CX_THREADS) {
+		const uint32_t k = st_key[q], d = k >> 24;
+		const size_t o = (size_t)gofs[d] + (q - tstart[d]);
+		out_key[o] = k; out_slot[o] = st_slot[q];
+	}
+}
+
+// first entry of every partition in the sorted key array: pstart[v] = first index whose partition is >= v
+__global__ void k_cx_bounds(const uint32_t *__restrict__ key, size_t n, uint32_t n_parts, uint32_t *__restrict__ pstart)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	const uint32_t cur = i < n ? key[i] >> 16 : n_parts;
+	const uint32_t first = i > 0 ? (key[i - 1] >> 16) + 1 : 0;
+	for (uint32_t v = first; v <= cur && v <= n_parts; ++v) pstart[v] = (uint32_t)i;
+}
+// ---- placement: one workgroup per partition ------------------------------------------------------------------------------
+#define CA_THREADS 512
+#define CA_BATCH 8
+__global__ __launch_bounds__(CA_THREADS) void k_cx_assemble(const uint32_t *__restrict__ key, const uint64_t *__restrict__ slot, const uint32_t *__restrict__ pstart,
+                                                            uint32_t n_parts, uint32_t NL, unsigned long long *__restrict__ head, uint64_t ext_cap,
+                                                            const uint8_t *__restrict__ redo)
+{
+	extern __shared__ uint32_t sm[];
+	if (!redo[blockIdx.x]) return;                              // k_cx_assemble_sorted did this partition
+	uint32_t *cnt = sm;                                     // [NL] entries per home line, later the running counter of the placement
+	int32_t *carry = (int32_t*)(sm + NL);                   // [NL] entries carried into the line
+	uint32_t *runb = sm + 2 * (size_t)NL;                   // [NL] first extension line of a heavy home line, 0xFFFFFFFF = light
+	__shared__ int32_t agg_sum[CA_THREADS / 64], agg_min[CA_THREADS / 64];
+	__shared__ uint32_t red[CA_THREADS / 64];
+	__shared__ int32_t s_c0;
+	const uint32_t part = blockIdx.x;
+	const uint32_t s0 = pstart[part], n = pstart[part + 1] - s0;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	unsigned long long *lines = head + CIX_HEAD_WORDS;
+	unsigned long long *L0 = lines + (size_t)part * NL * 8;
+	unsigned long long *X0 = lines + (size_t)n_parts * NL * 8;                  // extension area
+	for (uint32_t l = tid; l < NL; l += CA_THREADS) { cnt[l] = 0; runb[l] = 0xFFFFFFFFu; }
+	__syncthreads();
+	// (the loads of a batch are issued together: with one load in flight per thread the kernel waited on HBM latency)
+	for (uint32_t i0 = tid; i0 < n; i0 += CA_THREADS * CA_BATCH) {
+		uint32_t kk[CA_BATCH];
+#pragma unroll
+		for (int q = 0; q < CA_BATCH; ++q) { const uint32_t i = i0 + q * CA_THREADS; kk[q] = i < n ? key[s0 + i] : 0u; }
+#pragma unroll
+		for (int q = 0; q < CA_BATCH; ++q) if (i0 + q * CA_THREADS < n) atomicAdd(&cnt[cix_home(kk[q] & 0xFFFFu, NL)], 1u);
+	}
+	__syncthreads();
+	// heavy home lines: more than T entries; T falls until the light ones fit the partition with room to spare
+	uint32_t T = 8 * CIX_WAYS;
+	const uint32_t room = (uint32_t)(((uint64_t)CIX_WAYS * NL * 15) / 16);
+	for (;;) {
+		uint32_t sum = 0;
+		for (uint32_t l = tid; l < NL; l += CA_THREADS) sum += cnt[l] <= T ? cnt[l] : 0u;
+		for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+		if (lane == 0) red[wv] = sum;
+		__syncthreads();
+		sum = 0;
+		for (int q = 0; q < CA_THREADS / 64; ++q) sum += red[q];
+		__syncthreads();
+		if (sum <= room || T == 0) break;
+		T >>= 1;
+	}
+	for (uint32_t l = tid; l < NL; l += CA_THREADS) if (cnt[l] > T) {
+		const uint32_t rl = (cnt[l] + CIX_WAYS - 1) / CIX_WAYS;
+		const unsigned long long at = atomicAdd(&head[0], (unsigned long long)rl);
+		if (at + rl <= ext_cap && rl < (1u << 22) && at + rl < (1ull << 32)) {
+			runb[l] = (uint32_t)at;
+			for (uint32_t j = 0; j < rl; ++j) X0[(size_t)(at + j) * 8] = (unsigned long long)std::min(CIX_WAYS, cnt[l] - j * CIX_WAYS);
+		} else runb[l] = 0xFFFFFFFEu;                                          // no room: the caller sees head[0] > ext_cap and builds again with more
+	}
+	__syncthreads();
+	// carry into line l = what the lines before it could not hold: x_0 = 0, x_{l+1} = max(0, x_l + c_l - 7), c = light counts.  With S =
+	// prefix sums of (c - 7): x_l = S_{l-1} - min_{j <= l} S_{j-1}; wrapped once round the partition: x'_l = max(x_l, x_NL + S_{l-1}).
+	auto light = [&](uint32_t l) -> int32_t { return runb[l] == 0xFFFFFFFFu ? (int32_t)cnt[l] : 0; };
+	const uint32_t per = (NL + CA_THREADS - 1) / CA_THREADS;
+	const uint32_t lo = std::min(NL, (uint32_t)tid * per), hi = std::min(NL, lo + per);
+	int32_t sum = 0, mn = 0;
+	for (uint32_t l = lo; l < hi; ++l) { mn = l == lo ? 0 : std::min(mn, sum); sum += light(l) - (int32_t)CIX_WAYS; }
+	// exclusive scan over the threads of the pairs (sum, min of the running sums before a line): (s1, m1) o (s2, m2) = (s1 + s2, min(m1, s1 + m2))
+	int32_t before = 0, minbefore = 0;
+	{
+		int32_t ps = sum, pm = mn;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int32_t s1 = __shfl_up(ps, d, 64), m1 = __shfl_up(pm, d, 64);
+			if (lane >= d) { pm = std::min(m1, s1 + pm); ps = s1 + ps; }
+		}
+		if (lane == 63) { agg_sum[wv] = ps; agg_min[wv] = pm; }
+		__syncthreads();
+		int32_t ws = 0, wm = 0;                                                  // everything before this wave
+		for (int q = 0; q < wv; ++q) { wm = std::min(wm, ws + agg_min[q]); ws += agg_sum[q]; }
+		const int32_t is = ws + ps, im = std::min(wm, ws + pm);                  // inclusive at this thread
+		const int32_t es = __shfl_up(is, 1, 64), em = __shfl_up(im, 1, 64);      // exclusive: the thread before (the wave's prefix for lane 0)
+		before = lane ? es : ws;
+		minbefore = std::min(0, lane ? em : wm);
+	}
+	{
+		int32_t S = before, M = std::min(minbefore, before);
+		for (uint32_t l = lo; l < hi; ++l) { M = std::min(M, S); carry[l] = S - M; S += light(l) - (int32_t)CIX_WAYS; }
+		if (hi == NL && lo < hi) s_c0 = std::max(0, S - std::min(M, S));          // carry out of the last line
+	}
+	__syncthreads();
+	const int32_t c0 = s_c0;
+	if (c0 > 0) {
+		int32_t S = before;
+		for (uint32_t l = lo; l < hi; ++l) { carry[l] = std::max(carry[l], c0 + S); S += light(l) - (int32_t)CIX_WAYS; }
+	}
+	__syncthreads();
+	// word 0 of every line, then the entries: the k-th entry of light home h takes slot position 7 h + carry[h] + k, the k-th of
+	// a heavy one slot k of its run
+	for (uint32_t l = tid; l < NL; l += CA_THREADS) {
+		const int32_t have = carry[l] + light(l);
+		unsigned long long w0 = (unsigned long long)std::min<int32_t>(have, (int32_t)CIX_WAYS) | (have > (int32_t)CIX_WAYS ? CIX_MORE : 0ull);
+		if (runb[l] < 0xFFFFFFFEu) w0 |= CIX_HEAVY | ((unsigned long long)((cnt[l] + CIX_WAYS - 1) / CIX_WAYS) << 10) | ((unsigned long long)runb[l] << 32);
+		L0[(size_t)l * 8] = w0;
+	}
+	__syncthreads();
+	for (uint32_t l = tid; l < NL; l += CA_THREADS) cnt[l] = 0;
+	__syncthreads();
+	for (uint32_t i0 = tid; i0 < n; i0 += CA_THREADS * CA_BATCH) {
+		uint32_t kk[CA_BATCH]; uint64_t ss[CA_BATCH];
+#pragma unroll
+		for (int q = 0; q < CA_BATCH; ++q) { const uint32_t i = i0 + q * CA_THREADS; kk[q] = i < n ? key[s0 + i] : 0u; ss[q] = i < n ? slot[s0 + i] : 0ull; }
+#pragma unroll
+		for (int q = 0; q < CA_BATCH; ++q) if (i0 + q * CA_THREADS < n) {
+			const uint32_t h = cix_home(kk[q] & 0xFFFFu, NL);
+			const uint32_t k = atomicAdd(&cnt[h], 1u);
+			const uint32_t rb = runb[h];
+			if (rb == 0xFFFFFFFFu) {
+				const uint32_t pos = CIX_WAYS * h + (uint32_t)carry[h] + k;
+				uint32_t line = pos / CIX_WAYS;
+				const uint32_t sl = pos - line * CIX_WAYS;
+				if (line >= NL) line -= NL;
+				L0[(size_t)line * 8 + 1 + sl] = ss[q];
+			} else if (rb != 0xFFFFFFFEu) X0[((size_t)rb + k / CIX_WAYS) * 8 + 1 + k % CIX_WAYS] = ss[q];
+		}
+	}
+}
+
+// ---- placement, sorted: the same result with every line written whole ------------------------------------------------------
+// k_cx_assemble stores every slot word where it belongs: 13 000 eight-byte stores to 13 000 different lines per partition, and the
+// store path of a CU takes one line per transaction whatever its size -- that, not HBM, bounded it.  Here the slot words of
+// a partition are first sorted by home line in LDS (a counting sort: the counts are there anyway); since slot positions rise
+// with the home line, line l then holds the sorted entries [first(l) - carry(l), ... ) and ONE thread writes its 64 bytes:
+// a wave writes 4 KB in a row.  Heavy homes (rare) keep the scattered stores.  Partitions with more entries or lines than the
+// LDS arrays hold, or with many heavy homes, are left to k_cx_assemble (redo list).
+#define CS_THREADS 1024
+#define CS_CAP 14336                        // entries of a partition whose slot words fit in LDS
+#define CS_NL 4096                          // lines
+#define CS_HEAVY 32
+__global__ __launch_bounds__(CS_THREADS) void k_cx_assemble_sorted(const uint32_t *__restrict__ key, const uint64_t *__restrict__ slot, const uint32_t *__restrict__ pstart,
+                                                                   uint32_t n_parts, uint32_t NL, unsigned long long *__restrict__ head, uint64_t ext_cap,
+                                                                   uint8_t *__restrict__ redo, uint32_t cap)
+{
+	__shared__ unsigned long long sorted[CS_CAP];
+	__shared__ uint32_t cnt[CS_NL];                         // entries per home line, later the running counter of the sort
+	__shared__ uint16_t first[CS_NL + 1];                   // start of the home line's light entries in `sorted`
+	__shared__ uint16_t carry[CS_NL];                       // entries carried into the line
+	__shared__ int32_t agg_sum[CS_THREADS / 64], agg_min[CS_THREADS / 64];
+	__shared__ uint32_t red[CS_THREADS / 64], hv_line[CS_HEAVY], hv_base[CS_HEAVY], hv_cnt[CS_HEAVY];
+	__shared__ uint32_t n_heavy;
+	__shared__ int32_t s_c0;
+	const uint32_t part = blockIdx.x;
+	const uint32_t s0 = pstart[part], n = pstart[part + 1] - s0;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (n > cap || NL > CS_NL) { if (tid == 0) redo[part] = 1; return; }
+	unsigned long long *lines = head + CIX_HEAD_WORDS;
+	unsigned long long *L0 = lines + (size_t)part * NL * 8;
+	unsigned long long *X0 = lines + (size_t)n_parts * NL * 8;
+	for (uint32_t l = tid; l < NL; l += CS_THREADS) cnt[l] = 0;
+	if (tid == 0) n_heavy = 0;
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += CS_THREADS) atomicAdd(&cnt[cix_home(key[s0 + i] & 0xFFFFu, NL)], 1u);
+	__syncthreads();
+	uint32_t T = 8 * CIX_WAYS;
+	const uint32_t room = (uint32_t)(((uint64_t)CIX_WAYS * NL * 15) / 16);
+	for (;;) {
+		uint32_t sum = 0;
+		for (uint32_t l = tid; l < NL; l += CS_THREADS) sum += cnt[l] <= T ? cnt[l] : 0u;
+		for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+		if (lane == 0) red[wv] = sum;
+		__syncthreads();
+		sum = 0;
+		for (int q = 0; q < CS_THREADS / 64; ++q) sum += red[q];
+		__syncthreads();
+		if (sum <= room || T == 0) break;
+		T >>= 1;
+	}
+	for (uint32_t l = tid; l < NL; l += CS_THREADS) if (cnt[l] > T) {
+		const uint32_t at = atomicAdd(&n_heavy, 1u);
+		if (at < CS_HEAVY) { hv_line[at] = l; hv_cnt[at] = cnt[l]; }
+	}
+	__syncthreads();
+	if (n_heavy > CS_HEAVY) { if (tid == 0) redo[part] = 1; return; }
+	for (uint32_t q = tid; q < n_heavy; q += CS_THREADS) {
+		const uint32_t rl = (hv_cnt[q] + CIX_WAYS - 1) / CIX_WAYS;
+		const unsigned long long at = atomicAdd(&head[0], (unsigned long long)rl);
+		if (at + rl <= ext_cap && rl < (1u << 22) && at + rl < (1ull << 32)) {
+			hv_base[q] = (uint32_t)at;
+			for (uint32_t j = 0; j < rl; ++j) X0[(size_t)(at + j) * 8] = (unsigned long long)std::min(CIX_WAYS, hv_cnt[q] - j * CIX_WAYS);
+		} else hv_base[q] = 0xFFFFFFFEu;
+		cnt[hv_line[q]] = 0;                                                    // its entries are not the partition's
+	}
+	__syncthreads();
+	// per thread a chunk of lines: sums for `first` (prefix of the light counts) and for the carry (max-plus scan, see k_cx_assemble)
+	const uint32_t per = (NL + CS_THREADS - 1) / CS_THREADS;
+	const uint32_t lo = std::min(NL, (uint32_t)tid * per), hi = std::min(NL, lo + per);
+	int32_t sum = 0, mn = 0; uint32_t tot = 0;
+	for (uint32_t l = lo; l < hi; ++l) { mn = l == lo ? 0 : std::min(mn, sum); sum += (int32_t)cnt[l] - (int32_t)CIX_WAYS; tot += cnt[l]; }
+	int32_t before = 0, minbefore = 0; uint32_t tbefore = 0;
+	{
+		int32_t ps = sum, pm = mn; uint32_t pt = tot;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int32_t s1 = __shfl_up(ps, d, 64), m1 = __shfl_up(pm, d, 64); const uint32_t t1 = __shfl_up(pt, d, 64);
+			if (lane >= d) { pm = std::min(m1, s1 + pm); ps = s1 + ps; pt += t1; }
+		}
+		if (lane == 63) { agg_sum[wv] = ps; agg_min[wv] = pm; red[wv] = pt; }
+		__syncthreads();
+		int32_t ws = 0, wm = 0; uint32_t wt = 0;
+		for (int q = 0; q < wv; ++q) { wm = std::min(wm, ws + agg_min[q]); ws += agg_sum[q]; wt += red[q]; }
+		const int32_t is = ws + ps, im = std::min(wm, ws + pm); const uint32_t it = wt + pt;
+		const int32_t es = __shfl_up(is, 1, 64), em = __shfl_up(im, 1, 64); const uint32_t et = __shfl_up(it, 1, 64);
+		before = lane ? es : ws;
+		minbefore = std::min(0, lane ? em : wm);
+		tbefore = lane ? et : wt;
+		if (tid == CS_THREADS - 1) first[NL] = (uint16_t)it;
+	}
+	{
+		int32_t S = before, M = std::min(minbefore, before); uint32_t f = tbefore;
+		for (uint32_t l = lo; l < hi; ++l) { M = std::min(M, S); carry[l] = (uint16_t)(S - M); first[l] = (uint16_t)f; S += (int32_t)cnt[l] - (int32_t)CIX_WAYS; f += cnt[l]; }
+		if (hi == NL && lo < hi) s_c0 = std::max(0, S - std::min(M, S));
+	}
+	__syncthreads();
+	const int32_t c0 = s_c0;
+	if (c0 > 0) {
+		int32_t S = before;
+		for (uint32_t l = lo; l < hi; ++l) { carry[l] = (uint16_t)std::max((int32_t)carry[l], c0 + S); S += (int32_t)cnt[l] - (int32_t)CIX_WAYS; }
+	}
+	__syncthreads();
+	for (uint32_t l = tid; l < NL; l += CS_THREADS) cnt[l] = 0;
+	__syncthreads();
+	// the counting sort of the slot words; a heavy home's entries go straight to their run
+	for (uint32_t i = tid; i < n; i += CS_THREADS) {
+		const uint32_t h = cix_home(key[s0 + i] & 0xFFFFu, NL);
+		const uint32_t k = atomicAdd(&cnt[h], 1u);
+		uint32_t hq = CS_HEAVY;
+		for (uint32_t q = 0; q < n_heavy; ++q) if (hv_line[q] == h) hq = q;
+		if (hq == CS_HEAVY) sorted[first[h] + k] = slot[s0 + i];
+		else if (hv_base[hq] != 0xFFFFFFFEu) X0[((size_t)hv_base[hq] + k / CIX_WAYS) * 8 + 1 + k % CIX_WAYS] = slot[s0 + i];
+	}
+	__syncthreads();
+	// one thread per line: its 64 bytes in one piece
+	const uint32_t nlight = first[NL];
+	for (uint32_t l = tid; l < NL; l += CS_THREADS) {
+		const uint32_t cl = (uint32_t)first[l + 1] - first[l];
+		const uint32_t have = (uint32_t)carry[l] + cl, occ = std::min(have, CIX_WAYS);
+		unsigned long long w[8];
+		w[0] = (unsigned long long)occ | (have > CIX_WAYS ? CIX_MORE : 0ull);
+		for (uint32_t q = 0; q < n_heavy; ++q) if (hv_line[q] == l && hv_base[q] != 0xFFFFFFFEu)
+			w[0] |= CIX_HEAVY | ((unsigned long long)((hv_cnt[q] + CIX_WAYS - 1) / CIX_WAYS) << 10) | ((unsigned long long)hv_base[q] << 32);
+		int32_t f = (int32_t)first[l] - (int32_t)carry[l];
+		if (f < 0) f += (int32_t)nlight;                                          // entries carried round the end of the partition
+#pragma unroll
+		for (uint32_t j = 0; j < CIX_WAYS; ++j) {
+			uint32_t at = (uint32_t)f + j;
+			if (at >= nlight) at -= nlight;
+			w[1 + j] = j < occ ? sorted[at] : 0ull;
+		}
+		ulonglong2 *dst = (ulonglong2*)(L0 + (size_t)l * 8);
+		dst[0] = make_ulonglong2(w[0], w[1]); dst[1] = make_ulonglong2(w[2], w[3]); dst[2] = make_ulonglong2(w[4], w[5]); dst[3] = make_ulonglong2(w[6], w[7]);
+	}
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------
+extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *geom, uint64_t *n_words)
+{
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return MCOM_E_ARG;
+	const uint64_t ne = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;          // an upper bound: contigs without windows hold no entry
+	if (ne >= (1ull << 32)) return MCOM_E_ARG;
+	uint64_t P = ne / 12288;                                                           // ~12 k entries = ~3500 lines = ~220 KB per partition
+	if (P < 1) P = 1;
+	if (P > CIX_MAX_PARTS) P = CIX_MAX_PARTS;
+	uint64_t NL = (2 * ((ne + P - 1) / P) + 6) / 7;                                    // entries / 3.5: half full -- a lookup nearly always ends in its home line
+	if (NL < 16) NL = 16;
+	if (NL > 12000) return MCOM_E_ARG;                                                 // the counters of a partition live in LDS
+	const uint64_t ext = std::max<uint64_t>(1024, P * NL / 16);
+	if ((P * NL + ext) >= (1ull << 32)) return MCOM_E_ARG;
+	if (n_entries) *n_entries = ne;
+	if (geom) *geom = cix_pack((uint32_t)P, (uint32_t)NL);
+	if (n_words) *n_words = CIX_HEAD_WORDS + 8 * (P * NL + ext);
+	return MCOM_OK;
+}
+
+// contigs [c0, c1) of the set only (the whole set: 0, n_contigs): the multi-GPU path gives every rank a range of the
+// replicated contig set; entries carry the GLOBAL contig index, so claim keys of different ranks are comparable
+extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                       uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words)
+{
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	g.n_parts = geom & 0xFFFFu; g.n_lines = geom >> 16;
+	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
+	if (!d_keys || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
+	if (n_contigs >= (1u << CIX_CBITS) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the index slots");
+	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
+	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
+	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
+	uint64_t w01[2] = {0, 0};
+	if (c0 < c1) {
+		if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+		MCOM_HIP(ctx, hipMemcpyAsync(&w01[0], d_woff + c0, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipMemcpyAsync(&w01[1], d_woff + c1, 8, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	const uint64_t n_pos = (w01[1] - w01[0]) ? (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff : 0;
+	if (n_pos >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions");
+	const uint32_t nblocks = (uint32_t)((n_pos + CX_TILE - 1) / CX_TILE);
+	const uint64_t blocks256 = (n_pos + 255) / 256;
+	// temporaries: two key / slot array pairs, histogram + scan scratch, block map, partition starts
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const size_t key_b = al((size_t)n_pos * 4 + 4), slot_b = al((size_t)n_pos * 8 + 8), hist_b = al((size_t)256 * std::max(1u, nblocks) * 4 + 64),
+	             scr_b = al(mcom_scan_scratch_elems((size_t)256 * std::max(1u, nblocks) + 2) * 4 + 1024), map_b = al((size_t)blocks256 * 4 + 4),
+	             tab_b = al(((size_t)g.n_parts + 2) * 4);
+	char *tmp = nullptr;
+	if (mcom_dmalloc(&tmp, 2 * key_b + 2 * slot_b + hist_b + scr_b + map_b + 2 * tab_b + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: %zu bytes of temporaries", 2 * key_b + 2 * slot_b);
+	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
+	size_t o = 0;
+	auto take = [&](size_t b) { char *q = tmp + o; o += b; return q; };
+	uint32_t *keyA = (uint32_t*)take(key_b), *keyB = (uint32_t*)take(key_b);
+	uint64_t *slotA = (uint64_t*)take(slot_b), *slotB = (uint64_t*)take(slot_b);
+	uint32_t *hist = (uint32_t*)take(hist_b), *scr = (uint32_t*)take(scr_b), *first_contig = (uint32_t*)take(map_b);
+	uint32_t *pstart = (uint32_t*)take(tab_b);
+	uint8_t *redo = (uint8_t*)take(tab_b);
+	uint32_t n_ent = 0;
+	int rc;
+	if (n_pos) {
+		const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
+		hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
+		MCOM_LAUNCH_CHECK(ctx);
+		const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos};
+		hipLaunchKernelGGL(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
+		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;   // the extra element becomes the number of entries
+		MCOM_HIP(ctx, hipMemcpyAsync(&n_ent, hist + (size_t)256 * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+		hipLaunchKernelGGL(k_cx_scatter1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, keyA, slotA);
+		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	if (n_ent) {
+		const uint32_t nb2 = (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE);
+		hipLaunchKernelGGL(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, keyA, (size_t)n_ent, hist, nb2);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nb2, scr))) return rc;
+		hipLaunchKernelGGL(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, keyA, slotA, (size_t)n_ent, hist, nb2, keyB, slotB);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	hipLaunchKernelGGL(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, keyB, (size_t)n_ent, g.n_parts, pstart);
+	MCOM_LAUNCH_CHECK(ctx);
+	const size_t lds = (size_t)3 * g.n_lines * 4;
+	if (lds > 150 * 1024) return mcom_fail(ctx, MCOM_E_ARG, "contig index: partitions of %u lines", g.n_lines);
+	MCOM_HIP(ctx, hipMemsetAsync(redo, 0, g.n_parts, ctx->stream));
+	hipLaunchKernelGGL(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
+	                   ctx->cix_cap_set ? std::min<uint32_t>(ctx->cix_cap, CS_CAP) : (uint32_t)CS_CAP);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_cx_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
+	MCOM_LAUNCH_CHECK(ctx);
+	uint64_t used = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&used, d_keys, 8, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (used > ext_cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index: %llu extension lines needed, room for %llu", (unsigned long long)used, (unsigned long long)ext_cap);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                 uint64_t n_windows, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words)
+{
+	(void)n_windows;                                                       // = d_woff[n_contigs]; read from the device
+	return mcom_cindex_build_range(ctx, d_cbits, d_coff, d_woff, n_contigs, 0, n_contigs, L, ininumdict, geom, d_keys, n_words);
+}

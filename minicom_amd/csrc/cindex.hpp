@@ -1,0 +1,59 @@
+// minicom_amd/csrc/cindex.hpp -- geometry of the Stage-2 contig index shared by its build (cindex.hip) and its lookups
+// (realign.hip).  See cindex.hip for the structure.
+#pragma once
+#include "mcom_dev.hpp"
+
+#define MAXDICT 16
+
+__host__ __device__ static inline int dict_layout(int L, int ininumdict, int *start, int *len)
+{
+	// setglobalarrays_realign (kthread_hash_realign.c:153-206)
+	const int len_t = L <= 80 ? 11 : 17;
+	int nd = L / len_t;
+	if (ininumdict > 1 && ininumdict < nd) nd = ininumdict;
+	if (nd > MAXDICT) nd = MAXDICT;
+	start[0] = (ininumdict > 0 && ininumdict < nd) ? L / 2 - (len_t * nd) / 2 : 0;
+	len[0] = len_t;
+	for (int i = 1; i < nd; ++i) { start[i] = start[i - 1] + len_t; len[i] = len_t; }
+	return nd;
+}
+
+#define CIX_WAYS 7u                         // entries per line of eight words
+// word 0 of a line: bits 0-7 entries in the line; CIX_MORE: entries were pushed past it (the lookup goes on to the next line);
+// CIX_HEAVY: the keys whose home this line is have so many entries (a repeat) that they live in a run of lines of the
+// extension area instead: bits 10-31 = lines of the run, bits 32-63 = its first line (counted from the extension's start)
+#define CIX_MORE 0x100ull
+#define CIX_HEAVY 0x200ull
+#define CIX_CBITS 24
+#define CIX_PBITS 28
+#define CIX_MAX_PARTS 65535u
+#define CIX_HEAD_WORDS 8                    // d_keys[0] = lines of the extension area in use
+struct CixGeom { uint32_t n_parts, n_lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };   // n_lines: lines per partition
+
+static inline int cix_geom(int L, int ininumdict, CixGeom &g)
+{
+	int len[MAXDICT];
+	g.L = L; g.nd = dict_layout(L, ininumdict, g.ds, len);
+	if (g.nd < 1) return -1;
+	g.klen = len[0];
+	int mo = 0;
+	for (int l = 0; l < g.nd; ++l) {
+		if (g.ds[l] > mo) mo = g.ds[l];
+		if (g.ds[l] > 0 && L - g.ds[l] - g.klen > mo) mo = L - g.ds[l] - g.klen;
+	}
+	g.maxoff = mo;
+	return 0;
+}
+
+// d_keys = [ 8 words of header | n_parts * n_lines lines of 8 words | extension lines ]; geom = n_parts | n_lines << 16
+__host__ __device__ static inline uint32_t cix_pack(uint32_t n_parts, uint32_t n_lines) { return n_parts | (n_lines << 16); }
+
+// where a key lives: its partition, the 16 bits that pick its home line inside the partition, its 12-bit tag
+__device__ __forceinline__ void cix_hash(uint64_t key, uint32_t n_parts, uint32_t &part, uint32_t &h16)
+{
+	const uint64_t h = key * 0x9E3779B97F4A7C15ull;
+	part = (uint32_t)(((h >> 32) * (uint64_t)n_parts) >> 32);
+	h16 = (uint32_t)(h >> 16) & 0xFFFFu;
+}
+__device__ __forceinline__ uint64_t cix_tag(uint64_t key) { return (key * 0xD6E8FEB86659FD93ull) >> 52; }
+__device__ __forceinline__ uint32_t cix_home(uint32_t h16, uint32_t n_lines) { return (h16 * n_lines) >> 16; }

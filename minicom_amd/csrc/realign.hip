@@ -15,10 +15,8 @@
 //    the MINIMUM over all passing (contig, window, dir, dict) tuples: one 64-bit atomicMin per passing
 //    candidate, no locks, same result as the sequential scan (exception: bins larger than maxsearch, see
 //    DESIGN.md).  Random-access HBM-bound.
-#include "mcom_dev.hpp"
+#include "cindex.hpp"
 #include <cstring>
-
-#define MAXDICT 16
 
 struct mcom_dicts {
 	int L, W, nd;
@@ -37,19 +35,6 @@ struct DictDev {
 	uint32_t log2cap[MAXDICT];
 	const uint32_t *ids[MAXDICT];
 };
-
-__host__ __device__ static inline int dict_layout(int L, int ininumdict, int *start, int *len)
-{
-	// setglobalarrays_realign (kthread_hash_realign.c:153-206)
-	const int len_t = L <= 80 ? 11 : 17;
-	int nd = L / len_t;
-	if (ininumdict > 1 && ininumdict < nd) nd = ininumdict;
-	if (nd > MAXDICT) nd = MAXDICT;
-	start[0] = (ininumdict > 0 && ininumdict < nd) ? L / 2 - (len_t * nd) / 2 : 0;
-	len[0] = len_t;
-	for (int i = 1; i < nd; ++i) { start[i] = start[i - 1] + len_t; len[i] = len_t; }
-	return nd;
-}
 
 extern "C" int mcom_dict_layout(int L, int ininumdict, int *start, int *end)
 {
@@ -389,143 +374,7 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 // copies does not bury its neighbours the way linear probing would); an entry moves on to the next line of its
 // sequence only when the line's counter says it is full, and counters only grow, hence every copy of a key lies in
 // the lines of its sequence up to and including the first one that saw at most seven inserts.
-#define CIX_EMPTY (~0ull)
-#define CIX_WAYS 7ull                       // entries per line of eight words; word 0 is the line's insert counter
-#define CIX_CBITS 24
-#define CIX_PBITS 28
-struct CixGeom { uint32_t log2lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };
-
-__device__ __forceinline__ void cix_seq(uint64_t key, uint32_t log2lines, uint32_t &line, uint32_t &stride)
-{
-	const uint64_t h = key * 0x9E3779B97F4A7C15ull;
-	line = (uint32_t)(h >> (64 - log2lines));
-	stride = ((uint32_t)(h >> 5) | 1u) & ((1u << log2lines) - 1u);
-}
-__device__ __forceinline__ uint64_t cix_tag(uint64_t key) { return (key * 0xD6E8FEB86659FD93ull) >> 52; }
-
-static int cix_geom(int L, int ininumdict, CixGeom &g)
-{
-	int len[MAXDICT];
-	g.L = L; g.nd = dict_layout(L, ininumdict, g.ds, len);
-	if (g.nd < 1) return -1;
-	g.klen = len[0];
-	int mo = 0;
-	for (int l = 0; l < g.nd; ++l) {
-		if (g.ds[l] > mo) mo = g.ds[l];
-		if (g.ds[l] > 0 && L - g.ds[l] - g.klen > mo) mo = L - g.ds[l] - g.klen;
-	}
-	g.maxoff = mo;
-	return 0;
-}
-
-extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *log2lines)
-{
-	CixGeom g;
-	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return MCOM_E_ARG;
-	const uint64_t ne = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;
-	uint32_t lg = 4;
-	while (lg < 31 && (8ull << lg) * 5 < ne * 8) ++lg;                    // load <= 0.625
-	if ((8ull << lg) * 5 < ne * 8) return MCOM_E_ARG;
-	if (n_entries) *n_entries = ne;
-	if (log2lines) *log2lines = lg;
-	return MCOM_OK;
-}
-
-// first_contig[b] = the contig that owns position 256*b: contig c writes the entries of the block starts inside its own
-// range (a search per block -- nineteen dependent loads by one thread while 255 wait -- was a third of the insert's time).
-// Positions are counted from pos0 = the first position of contig c0: a rank of the multi-GPU path indexes contigs [c0, c1).
-__global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, uint32_t c0, uint32_t c1, uint64_t pos0, uint64_t n_blocks, uint32_t *__restrict__ first_contig)
-{
-	const uint32_t c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= c1) return;
-	const uint64_t a = woff[c] + (uint64_t)maxoff * c - pos0, b = woff[c + 1] + (uint64_t)maxoff * (c + 1) - pos0;
-	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
-}
-
-// position space: contig c owns [woff[c] + maxoff*c, woff[c+1] + maxoff*(c+1)); positions p = 0 .. nw-1+maxoff of a
-// contig with nw > 0 windows are indexed, the maxoff phantom positions of a contig without windows are skipped
-__global__ __launch_bounds__(256) void k_cindex_insert(CixGeom g, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
-                                                       const uint64_t *__restrict__ woff, uint32_t c1, uint64_t pos0, uint64_t n_pos,
-                                                       const uint32_t *__restrict__ first_contig, unsigned long long *__restrict__ keys)
-{
-	const uint64_t g0 = (uint64_t)blockIdx.x * 256;
-	const uint64_t gi = g0 + threadIdx.x;
-	if (gi >= n_pos) return;
-	uint32_t c = first_contig[blockIdx.x];                                  // k_cindex_blocks: no search, no barrier
-	while (c + 1 < c1 && woff[c + 1] + (uint64_t)g.maxoff * (c + 1) - pos0 <= gi) ++c;
-	const uint64_t nw = woff[c + 1] - woff[c];
-	if (nw == 0) return;
-	const uint64_t p = gi - (woff[c] + (uint64_t)g.maxoff * c - pos0);
-	const uint64_t *src = cbits + coff[c] + ((2 * p) >> 6);
-	const int sh = (int)((2 * p) & 63);
-	uint64_t v = src[0] >> sh;
-	if (sh + 2 * g.klen > 64) v |= src[1] << (64 - sh);
-	const uint64_t key = v & ((1ull << (2 * g.klen)) - 1);
-	uint32_t line, stride;
-	cix_seq(key, g.log2lines, line, stride);
-	const uint32_t lmask = (1u << g.log2lines) - 1u;
-	const unsigned long long slot = (cix_tag(key) << 52) | ((unsigned long long)c << CIX_PBITS) | p;
-	// Word 0 of a line counts its inserts (it starts at all-ones, so the count is word + 1): one returning atomic hands
-	// out the slot, one store fills it -- two L2 requests per entry where reading along the line to its first empty
-	// slot and a CAS took four to five; the kernel is bound by L2 request rate, not by bytes.  A line that is full
-	// (seven entries) passes the entry on to the next line of the key's probe sequence.
-	for (;;) {
-		unsigned long long *kl = keys + (size_t)line * 8;
-		// (a plain read first: it brings the line into L2 -- an atomic that misses costs several times one that hits -- and a
-		// line whose counter already shows an overflow is passed without an atomic; one that shows exactly seven still
-		// gets it, the lookup continues behind a line only when its counter exceeds seven)
-		const unsigned long long seen = *(volatile unsigned long long*)&kl[0] + 1ull;
-		if (seen <= CIX_WAYS) {
-			const unsigned long long at = atomicAdd(&kl[0], 1ull) + 1ull;
-			if (at < CIX_WAYS) { kl[1 + at] = slot; return; }
-		}
-		line = (line + stride) & lmask;
-	}
-}
-
-// contigs [c0, c1) of the set only (the whole set: 0, n_contigs): the multi-GPU path gives every rank a range of the
-// replicated contig set; entries carry the GLOBAL contig index, so claim keys of different ranks are comparable
-extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                       uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
-{
-	if (!ctx) return MCOM_E_ARG;
-	CixGeom g;
-	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
-	if (!d_keys || log2lines < 4 || log2lines > 31) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
-	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
-	g.log2lines = log2lines;
-	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
-	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, (8ull << log2lines) * 8, ctx->stream));
-	if (c0 == c1) return MCOM_OK;
-	if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	if (n_contigs >= (1u << CIX_CBITS) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the index slots");
-	uint64_t w01[2] = {0, 0};
-	MCOM_HIP(ctx, hipMemcpyAsync(&w01[0], d_woff + c0, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&w01[1], d_woff + c1, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (w01[1] == w01[0]) return MCOM_OK;
-	const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
-	const uint64_t n_pos = (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff;
-	if ((8ull << log2lines) * 7 < n_pos * 8) return mcom_fail(ctx, MCOM_E_ARG, "contig index too small: %llu entries", (unsigned long long)n_pos);
-	const uint64_t blocks = (n_pos + 255) / 256;
-	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions for one launch");
-	int rcw = mcom_ws_reserve(ctx, blocks * 4 + 256);
-	if (rcw) return rcw;
-	uint32_t *first_contig = (uint32_t*)ctx->ws;
-	hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks, first_contig);
-	MCOM_LAUNCH_CHECK(ctx);
-	hipLaunchKernelGGL(k_cindex_insert, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_cbits, d_coff, d_woff, c1, pos0, n_pos, first_contig,
-	                   (unsigned long long*)d_keys);
-	MCOM_LAUNCH_CHECK(ctx);
-	return MCOM_OK;
-}
-
-extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                 uint64_t n_windows, int L, int ininumdict, uint32_t log2lines, uint64_t *d_keys)
-{
-	(void)n_windows;                                                       // = d_woff[n_contigs]; read from the device
-	return mcom_cindex_build_range(ctx, d_cbits, d_coff, d_woff, n_contigs, 0, n_contigs, L, ininumdict, log2lines, d_keys);
-}
+// (geometry, hashing and the build of the index: cindex.hpp / cindex.hip)
 
 // which dictionaries may still see a singleton when bins are cut at maxsearch: the window scan walks a bin from its
 // end and stops after maxsearch entries (:388), flagged reads included
@@ -661,18 +510,25 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		uint64_t key = bits_key(row, g.ds[l], g.klen);
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
 		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
-		uint32_t line, stride;
-		cix_seq(key, g.log2lines, line, stride);
-		const uint32_t lmask = (1u << g.log2lines) - 1u;
+		uint32_t part, h16;
+		cix_hash(key, g.n_parts, part, h16);
+		const uint32_t nl = g.n_lines;
+		const unsigned long long *lines = keys + CIX_HEAD_WORDS;
+		const unsigned long long *L0 = lines + (size_t)part * nl * 8;
+		uint32_t line = cix_home(h16, nl);
 		const unsigned long long tag = cix_tag(key);
 		++n_look;
-		for (bool more = true; more;) {
-			const unsigned long long *kl = keys + (size_t)line * 8;
+		// the home line, then the lines behind it while entries were pushed on; when the home line says its keys are heavy (a repeat
+		// with more copies than a few lines hold) their entries are in a run of lines in the extension area, read afterwards
+		unsigned long long heavy = 0;
+		for (bool more = true, home = true; more; home = false) {
+			const unsigned long long *kl = L0 + (size_t)line * 8;
 			unsigned long long ks[8];
 #pragma unroll
 			for (int s = 0; s < 8; ++s) ks[s] = kl[s];
-			const unsigned long long filled = ks[0] + 1ull;                               // inserts this line has seen
-			more = filled > CIX_WAYS;                                                     // some went on to the next line
+			const unsigned long long filled = ks[0] & 0xFFull;                            // entries in this line
+			more = (ks[0] & CIX_MORE) != 0;                                               // some were pushed on to the next line
+			if (home && (ks[0] & CIX_HEAVY)) heavy = ks[0];
 #pragma unroll
 			for (int s = 1; s < 8; ++s) {
 				if ((unsigned long long)s > filled) break;
@@ -682,7 +538,23 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 				else verify(v);                                                                // a repeat: more copies than registers
 				++nc;
 			}
-			line = (line + stride) & lmask;
+			line = line + 1 == nl ? 0 : line + 1;
+		}
+		if (heavy) {
+			const unsigned long long *X = lines + ((size_t)g.n_parts * nl + (heavy >> 32)) * 8;
+			const uint32_t rl = (uint32_t)(heavy >> 10) & 0x3FFFFFu;
+#pragma unroll 1
+			for (uint32_t j = 0; j < rl; ++j) {
+				const uint32_t cn = (uint32_t)X[(size_t)j * 8] & 0xFFu;
+#pragma unroll 1
+				for (uint32_t s = 1; s <= cn; ++s) {
+					const unsigned long long v = X[(size_t)j * 8 + s];
+					if ((v >> 52) != tag) continue;
+					if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
+					else verify(v);
+					++nc;
+				}
+			}
 		}
 	}
 #pragma unroll 1
@@ -706,7 +578,7 @@ __global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsign
 	out[c] = s;
 }
 
-static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom, const uint64_t *d_sgbits,
                                 const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
                                 const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                 uint64_t *d_claim, uint64_t *d_stats, const uint8_t *d_mark, ulonglong2 *d_tuples, uint64_t cap,
@@ -715,7 +587,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
-	g.log2lines = log2lines;
+	g.n_parts = geom & 0xFFFFu; g.n_lines = geom >> 16;
 	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
 	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
 	if (n_contigs == 0 || n_sg == 0) return MCOM_OK;
@@ -726,7 +598,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 		sets = (unsigned long long*)ctx->ws;
 		MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 1024 * 4 * 8, ctx->stream));
 	}
-	if (!d_keys || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || log2lines < 4 || log2lines > 31)
+	if (!d_keys || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || g.n_parts < 1 || g.n_lines < 1)
 		return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const int W = mcom_words_per_read(L);
 	const int G = 2 * g.nd <= 16 ? 16 : 32;
@@ -748,12 +620,12 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 	return MCOM_OK;
 }
 
-extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t n_parts, const uint64_t *d_sgbits,
                                        const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
                                        const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                        uint64_t *d_claim, uint64_t *d_stats)
 {
-	return realign_reads_launch(ctx, d_keys, log2lines, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
+	return realign_reads_launch(ctx, d_keys, n_parts, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
 	                            d_claim, d_stats, nullptr, nullptr, 0, nullptr);
 }
 
@@ -789,7 +661,7 @@ extern "C" int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint
 	return MCOM_OK;
 }
 
-extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t log2lines, const uint64_t *d_sgbits,
+extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t n_parts, const uint64_t *d_sgbits,
                                         const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg, const uint64_t *d_cbits,
                                         const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                         uint64_t *d_claim, uint64_t *d_stats, uint64_t *d_tuples, uint64_t cap, uint64_t *h_ntuples)
@@ -802,7 +674,7 @@ extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, u
 	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "tuple counter");
 	e = hipMemsetAsync(d_count, 0, 8, ctx->stream);
 	if (e == hipSuccess) {
-		rc = realign_reads_launch(ctx, d_keys, log2lines, d_sgbits, d_sgflag, nullptr, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
+		rc = realign_reads_launch(ctx, d_keys, n_parts, d_sgbits, d_sgflag, nullptr, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
 		                          d_claim, d_stats, d_mark, (ulonglong2*)d_tuples, cap, d_count);
 		if (!rc) {
 			unsigned long long h = 0;

@@ -12,6 +12,7 @@
 // 16-byte records once for the histogram and once for the scatter, and writes them once.
 #include "mcom_dev.hpp"
 #include <algorithm>
+#include <cmath>
 
 #define RS_THREADS 256
 #define RS_ITEMS 16
@@ -23,7 +24,9 @@ struct KeySpec {
 	int b;          // bucket bits
 	int kbits;      // 2 * k of the sketch that produced x
 	int L, k_orig;  // for the aligned position of cmpcluster
-	int t;          // mode 5: the MSD key is bucket (b bits) || top t bits of x, records without a minimizer get the largest key
+	int t;          // mode 5: the MSD key is bucket (b bits) || sub (t <= 3 bits), sub = number of thresholds thr[] that x reaches;
+	                // records without a minimizer get the largest key
+	uint64_t thr[7];
 };
 
 // 128-bit composite key as (lo, hi); digit p = bits [8p, 8p+8)
@@ -33,7 +36,13 @@ __device__ __forceinline__ void make_key(const KeySpec &ks, uint64_t x, uint64_t
 	if (ks.mode == 2) { lo = x & ((1ull << ks.kbits) - 1); hi = 0; return; }   // only the low kbits of x (bucket id)
 	if (ks.mode == 3) { lo = x == U64MAX ? (uint64_t)ks.kbits : ((x & ((1ull << ks.b) - 1)) * (uint64_t)ks.kbits) >> ks.b; hi = 0; return; }
 	if (ks.mode == 4) { lo = y >> 32; hi = 0; return; }
-	if (ks.mode == 5) { lo = x == U64MAX ? (1ull << (ks.b + ks.t)) - 1 : ((x & ((1ull << ks.b) - 1)) << ks.t) | (ks.t ? x >> (ks.kbits - ks.t) : 0ull); hi = 0; return; }
+	if (ks.mode == 5) {
+		if (x == U64MAX) { lo = (1ull << (ks.b + ks.t)) - 1; hi = 0; return; }
+		uint32_t sub = 0;
+#pragma unroll
+		for (int j = 0; j < 7; ++j) sub += (j < (1 << ks.t) - 1 && x >= ks.thr[j]) ? 1u : 0u;
+		lo = ((x & ((1ull << ks.b) - 1)) << ks.t) | sub; hi = 0; return;
+	}
 	if (x == U64MAX) { lo = U64MAX; hi = 0xFFFFFFFFu; return; }           // records without a minimizer sort last
 	const uint64_t bucket = x & ((1ull << ks.b) - 1);
 	const uint64_t K = (bucket << (ks.kbits - ks.b)) | (x >> ks.b);
@@ -197,6 +206,20 @@ __global__ __launch_bounds__(SS_THREADS) void k_segment_sort(const mcom_mm128 *_
 		uint64_t lo; uint32_t hi; make_key(full, r.x, r.y, lo, hi);           // [bucket | x >> b | position key]: the low sig_bits are what is left to sort
 		keys[i] = lo;
 		idx[0][i] = (uint16_t)i;
+	}
+	__syncthreads();
+	{   // digits above the highest bit in which two keys of the segment differ need no pass (the hashes of one sub-range share their top bits)
+		uint64_t diff = 0;
+		const uint64_t k0 = keys[0];
+		for (uint32_t i = tid; i < n; i += SS_THREADS) diff |= keys[i] ^ k0;
+		for (int o = 32; o; o >>= 1) diff |= __shfl_xor(diff, o);
+		__shared__ uint64_t wdiff[SS_THREADS / 64];
+		if (lane == 0) wdiff[wv] = diff;
+		__syncthreads();
+		diff = 0;
+		for (int q = 0; q < SS_THREADS / 64; ++q) diff |= wdiff[q];
+		const int top = diff ? 64 - __clzll((long long)diff) : 0;
+		if (top < sig_bits) sig_bits = top;
 	}
 	// wave w ranks elements [w * per, (w + 1) * per), 64 at a time
 	const uint32_t per = ((n + SS_THREADS - 1) / SS_THREADS) * 64;
@@ -365,7 +388,7 @@ int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws)
 {
 	if (n == 0) return MCOM_OK;
 	SortWs w; sort_ws_layout(n, &w, (char*)ws);
-	KeySpec ks{0, 0, 64, 0, 0, 0};
+	KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -378,7 +401,7 @@ int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, vo
 {
 	if (n == 0) return MCOM_OK;
 	SortWs w; sort_ws_layout(n, &w, (char*)ws);
-	KeySpec ks{2, 0, bits, 0, 0, 0};
+	KeySpec ks{2, 0, bits, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, (bits + 7) / 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -402,7 +425,7 @@ extern "C" int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, s
 	int rc = mcom_ws_reserve(ctx, hist_b + scan_scratch_elems((size_t)256 * nblocks) * 4 + 1024);
 	if (rc) return rc;
 	uint32_t *hist = (uint32_t*)ctx->ws, *scratch = (uint32_t*)((char*)ctx->ws + hist_b);
-	KeySpec ks{3, b, ranks, 0, 0, 0};
+	KeySpec ks{3, b, ranks, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
 		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, n, ks, 0, hist, nblocks);
@@ -428,7 +451,7 @@ extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 	int rc = mcom_ws_reserve(ctx, sort_ws_layout(n, nullptr, nullptr));
 	if (rc) return rc;
 	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
-	KeySpec ks{4, 0, 32, 0, 0, 0};
+	KeySpec ks{4, 0, 32, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	mcom_mm128 *res = nullptr;
 	if ((rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 4, w.hist, w.scratch, &res))) return rc;
 	if (res != d_a) MCOM_HIP(ctx, hipMemcpyAsync(d_a, res, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
@@ -448,7 +471,7 @@ extern "C" int mcom_radix_sort_128x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 	int rc = mcom_ws_reserve(ctx, need);
 	if (rc) return rc;
 	SortWs w; sort_ws_layout(n, &w, (char*)ctx->ws);
-	KeySpec ks{0, 0, 64, 0, 0, 0};
+	KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	mcom_mm128 *res = nullptr;
 	rc = radix_sort_records(ctx, d_a, w.tmp, n, ks, 8, w.hist, w.scratch, &res);
 	if (rc) return rc;
@@ -516,7 +539,7 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	// the sort: passes on the MSD key [bucket | top t bits of the hash] until a segment holds about 1500 records, the rest of the
 	// key inside the segments (k_segment_sort); the last global pass lands in the workspace, the segment sort in d_sorted
 	int t = 0;
-	while ((n >> (b + t)) > 2048 && b + t < 24 && b + t < 2 * kmer) ++t;
+	while ((n >> (b + t)) > 2048 && t < 3 && b + t < 24) ++t;
 	const int B = b + t, passes = (B + 7) / 8;
 	const uint32_t nseg = 1u << B;
 	const size_t segs_b = (((size_t)nseg + 2) * 4 + 255) & ~(size_t)255, list_b = ((size_t)nseg * 8 + 255) & ~(size_t)255, dst_b = ((size_t)nseg * 4 + 255) & ~(size_t)255;
@@ -532,9 +555,16 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	uint32_t *seg_start = (uint32_t*)segbase, *ovf_dst = (uint32_t*)(segbase + segs_b + list_b), *ovf_count = (uint32_t*)(segbase + segs_b + list_b + dst_b);
 	uint2 *ovf_list = (uint2*)(segbase + segs_b);
 
-	const KeySpec full{1, b, 2 * kmer, L, k_orig, 0};
-	const KeySpec msd{5, b, 2 * kmer, L, k_orig, t};
-	const int sig_bits = 9 + 2 * kmer - B;
+	const KeySpec full{1, b, 2 * kmer, L, k_orig, 0, {0, 0, 0, 0, 0, 0, 0}};
+	KeySpec msd{5, b, 2 * kmer, L, k_orig, t, {0, 0, 0, 0, 0, 0, 0}};
+	{
+		// Where to cut a bucket into 2^t sub-ranges of the hash: x is the MINIMUM of the hashes of a read's m = L - kmer + 1 k-mers,
+		// far from uniform (its top bits are nearly always zero): P(x > v) = (1 - v / 2^2k)^m, so the j-th of 2^t equal shares
+		// ends at 2^2k (1 - (1 - j / 2^t)^(1/m)).  Any ascending thresholds give a correct sort; these give even segments.
+		const double m = (double)std::max(1, L - kmer + 1), top = ldexp(1.0, 2 * kmer);
+		for (int j = 1; j < (1 << t); ++j) msd.thr[j - 1] = (uint64_t)(top * (1.0 - pow(1.0 - (double)j / (double)(1 << t), 1.0 / m)));
+	}
+	const int sig_bits = 9 + 2 * kmer - b;                  // everything above the bucket bits: the sub-ranges are cut by value, not by bit
 	{
 		const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
 		const mcom_mm128 *src = d_rec;

@@ -86,9 +86,9 @@ def load_library():
     L.mcom_realign_pass.restype = i32
     L.mcom_realign_pass.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u64, i32, i32, vp, vp]
     L.mcom_cindex_plan.restype = i32
-    L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u32)]
+    L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]
     L.mcom_cindex_build.restype = i32
-    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp]
+    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp, u64]
     L.mcom_dicts_eligible.restype = i32
     L.mcom_dicts_eligible.argtypes = [vp, vp, vp, i32, vp]
     L.mcom_realign_pass_reads.restype = i32
@@ -217,6 +217,11 @@ class Context:
         self.lib.mcom_set_segment_capacity.restype = C.c_int; self.lib.mcom_set_segment_capacity.argtypes = [C.c_void_p, C.c_uint32]
         self._check(self.lib.mcom_set_segment_capacity(self._h, records))
 
+    def set_index_capacity(self, entries: int):
+        """Test hook of mcom_cindex_build: partitions above `entries` use the scattered placement (negative = default)."""
+        self.lib.mcom_set_index_capacity.restype = C.c_int; self.lib.mcom_set_index_capacity.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_index_capacity(self._h, entries))
+
     def sort_group(self, rec, L: int, k_orig: int, kmer: int, b: int = 14):
         """mcom_sort_group.  Returns dict(sorted, singles, members, group_off) trimmed to their counts."""
         torch = _torch()
@@ -328,15 +333,21 @@ class Context:
         return claim[:n_sg], st
 
     def cindex_build(self, cbits, coff, woff, n_windows: int, L: int, ininumdict: int = 0):
-        """mcom_cindex_plan + mcom_cindex_build.  Returns (slots int64, log2lines)."""
+        """mcom_cindex_plan + mcom_cindex_build.  Returns (index words int64, n_parts)."""
         torch = _torch()
-        ne, lg = C.c_uint64(), C.c_uint32()
+        ne, parts, nw = C.c_uint64(), C.c_uint32(), C.c_uint64()
         n_contigs = int(coff.shape[0])
-        self._check(self.lib.mcom_cindex_plan(int(n_windows), n_contigs, L, ininumdict, C.byref(ne), C.byref(lg)))
-        keys = torch.empty(8 << lg.value, dtype=torch.int64, device=self.device)
-        self._check(self.lib.mcom_cindex_build(self._h, self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
-                                               n_contigs, int(n_windows), L, ininumdict, lg.value, self._p(keys)))
-        return keys, lg.value
+        self._check(self.lib.mcom_cindex_plan(int(n_windows), n_contigs, L, ininumdict, C.byref(ne), C.byref(parts), C.byref(nw)))
+        words = int(nw.value)
+        for attempt in range(5):                                            # MCOM_E_OVERFLOW: this set's repeats need a larger extension area
+            keys = torch.empty(words, dtype=torch.int64, device=self.device)
+            rc = self.lib.mcom_cindex_build(self._h, self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64),
+                                            n_contigs, int(n_windows), L, ininumdict, parts.value, self._p(keys), words)
+            if rc != -4:
+                break
+            words += max(words, 8 * (int(ne.value) // 7 + 1024))
+        self._check(rc)
+        return keys, parts.value
 
     def dicts_eligible(self, dicts, sgbits, maxsearch: int):
         torch = _torch()

@@ -227,7 +227,7 @@ struct mcomh_pipeline {
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
-	DevBuf<uint64_t> d_cix_keys; uint32_t cix_log2 = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
+	DevBuf<uint64_t> d_cix_keys; uint32_t cix_parts = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
@@ -1145,7 +1145,7 @@ static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgb
 	uint64_t cap = (1ull << 20) + 64ull * M.size(), nt = 0;
 	for (;;) {
 		if (!d_tup.reserve(2 * cap)) return p->fail(MCOM_E_NOMEM, "tuples");
-		if ((rc = p->gpu(mcom_realign_pass_tuples(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits, d_flag, d_mark.p, n_sg, p->d_cbits.p, p->d_coff_words.p,
+		if ((rc = p->gpu(mcom_realign_pass_tuples(p->ctx, p->d_cix_keys.p, p->cix_parts, d_sgbits, d_flag, d_mark.p, n_sg, p->d_cbits.p, p->d_coff_words.p,
 		                                          p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim, d_st, d_tup.p, cap, &nt)))) return rc;
 		if (nt <= cap) break;
 		cap = nt + (nt >> 3);
@@ -1270,12 +1270,17 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				nwin_mine = hw[c1] - hw[c0];
 			}
 			p->cix_c0 = c0; p->cix_c1 = c1;
-			uint64_t ne = 0;
-			if (mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &ne, &p->cix_log2)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
-			if (!p->d_cix_keys.reserve(8ull << p->cix_log2)) return p->fail(MCOM_E_NOMEM, "contig index");
-			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)(8ull << p->cix_log2);
-			if ((rc = p->gpu(mcom_cindex_build_range(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict,
-			                                         p->cix_log2, p->d_cix_keys.p)))) return rc;
+			uint64_t ne = 0, nwords = 0;
+			if (mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &ne, &p->cix_parts, &nwords)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			for (int attempt = 0;; ++attempt) {                                 // a repeat-rich set may need a larger extension area for its heavy keys
+				if (!p->d_cix_keys.reserve(nwords)) return p->fail(MCOM_E_NOMEM, "contig index");
+				rc = mcom_cindex_build_range(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict, p->cix_parts, p->d_cix_keys.p, nwords);
+				if (rc != MCOM_E_OVERFLOW || attempt == 3) break;
+				nwords += std::max<uint64_t>(nwords / 4, 8 * (ne / 7 + 1024) / (attempt < 2 ? 4 : 1));
+				p->stat["cix_rebuilds"] += 1;
+			}
+			if (rc) return p->gpu(rc);
+			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)nwords;
 		}
 		p->stage2_uploaded = true;
 	}
@@ -1315,7 +1320,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			rc = MCOM_OK;
 			if (!d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
 			if (!rc && !big)
-				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_log2, d_sgbits.p, d_flag.p, nullptr,
+				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_parts, d_sgbits.p, d_flag.p, nullptr,
 				                                    n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
 			else if (!rc)
 				rc = realign_big_bins(p, dicts, d_sgbits.p, d_flag.p, n_sg, nc, thr, d_claim.p, d_st.p);

@@ -221,6 +221,54 @@ def test_read_driven_pass_equals_window_scan_also_with_bins_above_maxsearch(ctx,
     dicts.close()
 
 
+def test_index_keeps_heavy_repeats_in_runs_of_their_own(ctx):
+    """Keys with hundreds of copies among the contigs (a 1 kb segment in 120 contigs, poly-A and (AC)n stretches): their
+    entries leave the partitions for runs in the extension area (csrc/cindex.hip, CIX_HEAVY).  The claims must still be the
+    window scan's; the index reports how many extension lines it used."""
+    import torch
+    from minicom_amd.hip import pack_nt4, pack_contigs
+    L = 100
+    rng = np.random.default_rng(321)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    seg = acgt[rng.integers(0, 4, 1000)]
+    refs = [np.concatenate([acgt[rng.integers(0, 4, int(rng.integers(50, 300)))], seg, acgt[rng.integers(0, 4, int(rng.integers(50, 300)))]]) for _ in range(120)]
+    refs += [acgt[rng.integers(0, 4, int(n))] for n in rng.integers(L, 5 * L, 200)]
+    refs.append(np.full(700, ord("A"), dtype=np.uint8))
+    refs.append(np.frombuffer(b"AC" * 450, dtype=np.uint8).copy())
+    reads = []
+    for _ in range(5000):
+        c = int(rng.integers(0, len(refs)))
+        j = int(rng.integers(0, len(refs[c]) - L + 1))
+        r = refs[c][j:j + L].copy()
+        for q in rng.integers(0, L, int(rng.integers(0, 5))):
+            r[q] = acgt[rng.integers(0, 4)]
+        reads.append(comp[r][::-1] if rng.random() < 0.5 else r)
+    reads = np.stack(reads)
+    sgbits = torch.from_numpy(pack_nt4(reads).view(np.int64)).cuda()
+    flag = torch.zeros(len(reads), dtype=torch.uint8, device="cuda")
+    cbits, coff, clen = pack_contigs([r.tobytes() for r in refs])
+    nwin = np.maximum(clen.astype(np.int64) - L + 1, 0)
+    woff = np.concatenate([[0], np.cumsum(nwin)]).astype(np.uint64)
+    d_cbits, d_coff, d_woff = (torch.from_numpy(a.view(np.int64)).cuda() for a in (cbits, coff, woff))
+    dicts = ctx.dicts_build(sgbits, L)
+    cix = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
+    assert int(cix[0][0]) > 100                                            # extension lines in use: the heavy keys went there
+    ctx.set_index_capacity(0)                                              # ... and the same index placed by the scattered kernel
+    try:
+        cix2 = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
+    finally:
+        ctx.set_index_capacity(-1)
+    for thr in (4, 16):
+        want, _ = ctx.realign_pass(dicts, sgbits, flag, d_cbits, d_coff, d_woff, int(nwin.sum()), thr, 100000)
+        for index in (cix, cix2):
+            got, _ = ctx.realign_pass_reads(index, sgbits, flag, d_cbits, d_coff, d_woff, L, thr)
+            ctx.sync()
+            assert torch.equal(want, got), (thr, int((want != got).sum()))
+        assert int((want != -1).sum()) > 2000
+    dicts.close()
+
+
 def test_realign_empty_inputs(ctx):
     import torch
     z64 = torch.zeros((0, 5), dtype=torch.int64, device="cuda")

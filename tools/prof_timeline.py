@@ -1,0 +1,31 @@
+"""Timeline of ONE step of bench.py from a rocprofv3 rocpd database: busy time per kernel, idle gaps, launches.
+   prof_timeline.py RESULTS.db [STEP]   (a step starts at a k_classify_pack* dispatch; default: the last one)"""
+import collections
+import sqlite3
+import sys
+
+db = sys.argv[1]
+con = sqlite3.connect(db)
+rows = list(con.execute("select name, start, end from kernels order by start"))
+starts = [i for i, r in enumerate(rows) if r[0].startswith("k_classify_pack") or r[0].startswith("void k_classify_pack")]
+step = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 1
+a = starts[step]; b = starts[step + 1] if step + 1 < len(starts) else len(rows)
+rows = rows[a:b]
+t0, t1 = rows[0][1], max(r[2] for r in rows)
+busy = collections.Counter(); calls = collections.Counter()
+gap = 0; last_end = rows[0][1]; gaps = []
+for name, s, e in rows:
+    k = name.split("(")[0].replace("void ", "")
+    busy[k] += e - s; calls[k] += 1
+    if s > last_end:
+        gap += s - last_end; gaps.append((s - last_end, k))
+    last_end = max(last_end, e)
+tot = sum(busy.values())
+print(f"step {step}: {len(rows)} launches, span {(t1 - t0) / 1e6:.1f} ms, kernel time {tot / 1e6:.1f} ms, idle {gap / 1e6:.1f} ms")
+for k, v in busy.most_common(45):
+    print(f"{v / 1e6:8.2f} ms {calls[k]:5d}  {k[:70]}")
+print("largest gaps (ms, before kernel):", [(round(g / 1e6, 2), k[:24]) for g, k in sorted(gaps, reverse=True)[:14]])
+hist = collections.Counter()
+for g, _ in gaps:
+    hist[min(6, len(str(g // 1000)))] += g
+print("idle by gap size (digits of us):", {k: round(v / 1e6, 1) for k, v in sorted(hist.items())})
