@@ -585,6 +585,7 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 	int rc = mcom_ws_reserve(ctx, sort_b + head_b + scr_b + 256 + bst_b);
 	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 	char *base = (char*)ctx->ws;
+	bool have_bst = false; uint32_t max_bucket = 0;
 	if (n) {
 		hipError_t e1 = hipMemcpyAsync(mi->rec, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream);
 		if (e1 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e1)); }
@@ -605,6 +606,7 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 			if (e2 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "bucket bounds: %s", hipGetErrorString(e2)); }
 			uint32_t mx = 0;
 			for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
+			have_bst = true; max_bucket = mx;
 			uint32_t *ovf = (uint32_t*)(base + sort_b + head_b + scr_b);           // the 256-byte meta area, reused below
 			(void)hipMemsetAsync(ovf, 0, 4, ctx->stream);
 			if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
@@ -618,19 +620,22 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 		}
 	}
-	rc = mcom_table_build(ctx, mi->rec, n, (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
+	if (n && b > 0 && have_bst)                                               // records sorted by bucket first: the table is built bucket by bucket in LDS
+		rc = mcom_table_build_bucketed(ctx, mi->rec, n, (const uint32_t*)(base + sort_b + head_b + scr_b + 256), b, max_bucket,
+		                               (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
+	else rc = mcom_table_build(ctx, mi->rec, n, (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
 	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 	*out = mi;
 	return MCOM_OK;
 }
 
-__global__ void k_idx_get(const uint64_t *__restrict__ slots, uint32_t log2cap, const uint64_t *__restrict__ x, size_t n,
+__global__ void k_idx_get(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t log2region, uint32_t bbits, const uint64_t *__restrict__ x, size_t n,
                           uint32_t *__restrict__ start, uint32_t *__restrict__ count)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t s = 0, c = 0;
-	if (x[i] != U64MAX) mcom_table_find(slots, log2cap, x[i], s, c);
+	if (x[i] != U64MAX) mcom_table_find_any(slots, log2cap, log2region, bbits, x[i], s, c);
 	start[i] = s; count[i] = c;
 }
 
@@ -639,7 +644,7 @@ extern "C" int mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d
 	if (!ctx || !mi) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_x || !d_start || !d_count) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_x, n, d_start, d_count);
+	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.log2region, mi->tab.bbits, d_x, n, d_start, d_count);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -705,13 +710,13 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 // The flags the reference also tests (:286) change while it merges, so they are left to the caller, who
 // walks each contig's candidates in this order and takes the first whose partner is still free.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, const mcom_mm128 *__restrict__ q, size_t nq,
+__global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t log2region, uint32_t bbits, const mcom_mm128 *__restrict__ q, size_t nq,
                             uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
 	uint32_t s = 0, c = 0;
-	if (q[i].x != U64MAX) mcom_table_find(slots, log2cap, q[i].x, s, c);
+	if (q[i].x != U64MAX) mcom_table_find_any(slots, log2cap, log2region, bbits, q[i].x, s, c);
 	hits[i] = c; first[i] = s;                     // the later passes read these instead of probing the table again
 }
 // one thread per query: walks its hits, tests, writes a pass flag per (query, hit) pair at pair_off[q] + k
@@ -778,7 +783,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
-	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, d_query, n_query, hits, first);
+	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.log2region, mi->tab.bbits, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
