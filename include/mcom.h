@@ -354,6 +354,10 @@ int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t n, int L, u
 /* updateSingle (preprocess.c:243-255) on the device: d_out = the ids whose flag is zero, in order; *h_n_out their number.
  * Synchronous.                                                                                                      */
 int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_flag, size_t n, uint32_t *d_out, uint64_t *h_n_out);
+/* The entries whose flag is 1 or 2 (the near-poly-A / -T singletons mcom_poly_filter found, bbhashdict.c:177-216), in any
+ * order: d_out[3 i] = index, d_out[3 i + 1] = d_ids[index], d_out[3 i + 2] = flag for the first `cap` of them; *d_count
+ * (DEVICE) = how many there are (more than cap: look at the flags themselves).  Asynchronous.                        */
+int mcom_list_flagged(mcom_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_flag, size_t n, uint32_t *d_out, uint32_t cap, uint32_t *d_count);
 /* Member lists of the nj claimed pairs (find_next :297-325): d_jobs = nj x {ci, cj, pos_ori, pos} (uint32);
  * the list of the contig whose anchor lies further right first, the other one shifted behind it, then in
  * cmpcluster2 order (stable, as construct_ref2's sort :107 with glibc's merge sort).  key_bits: every

@@ -150,19 +150,37 @@ __global__ __launch_bounds__(64) void k_flag_sort_bucket(const mcom_mm128 *__res
 				bb[4 * lane + 3] = a; a += c3; be[4 * lane + 3] = a;
 			}
 			__syncthreads();
-			if (lane == 0) {                                                   // the cycle-leader permutation, as written
-				for (int q = 0; q < 256;) {
-					if (bb[q] != be[q]) {
-						int l = (int)digit(E[bb[q]], s);
-						if (l != q) {
-							uint64_t hold = E[bb[q]], moved;
+			// The cycle-leader permutation, as written (ksort.h:132-144) -- except that the elements it merely steps over are stepped
+			// over 64 at a time: an element at bb[q] whose digit is q is "in place", the reference does ++bb[q] and nothing else,
+			// and nothing ever writes into bin q ahead of bb[q] (a cycle closes AT bb[q]), so the first element of the bin that is
+			// not in place can be found by all lanes at once.  At the top levels nearly every element is in place (the hashes of a
+			// bucket are minima of many k-mer hashes: their top byte is almost always 0), and walking them one by one was half of
+			// this kernel's time.  The cycles themselves stay with one lane: they are the reference's order of equal keys.
+			for (int q = 0; q < 256; ++q) {
+				for (;;) {
+					const uint32_t b0 = bb[q], e0 = be[q];                       // uniform
+					if (b0 == e0) break;
+					uint32_t found = e0;
+					for (uint32_t p0 = b0; p0 < e0; p0 += 64) {
+						const uint32_t p = p0 + (uint32_t)lane;
+						const bool neq = p < e0 && (int)digit(E[p < e0 ? p : b0], s) != q;
+						const uint64_t m = __ballot(neq);
+						if (m) { found = p0 + (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
+					}
+					if (lane == 0) {
+						bb[q] = found;
+						if (found != e0) {
+							int l = (int)digit(E[found], s);
+							uint64_t hold = E[found], moved;
 							do {
 								moved = hold; hold = E[bb[l]]; E[bb[l]++] = moved;
 								l = (int)digit(hold, s);
 							} while (l != q);
 							E[bb[q]++] = hold;
-						} else ++bb[q];
-					} else ++q;
+						}
+					}
+					__syncthreads();
+					if (found == e0) break;
 				}
 			}
 			__syncthreads();

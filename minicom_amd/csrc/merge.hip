@@ -395,6 +395,28 @@ extern "C" int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uin
 	return MCOM_OK;
 }
 
+// the few entries whose flag is 1 or 2 (near-poly-A / -T singletons of a Stage-2 pass, bbhashdict.c:177-216): {index, id, flag}
+__global__ void k_list_flagged(const uint32_t *__restrict__ ids, const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ out, uint32_t cap, uint32_t *__restrict__ count)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const uint8_t f = flag[i];
+	if (f != 1 && f != 2) return;
+	const uint32_t at = atomicAdd(count, 1u);
+	if (at < cap) { out[3 * (size_t)at] = (uint32_t)i; out[3 * (size_t)at + 1] = ids[i]; out[3 * (size_t)at + 2] = f; }
+}
+extern "C" int mcom_list_flagged(mcom_ctx *ctx, const uint32_t *d_ids, const uint8_t *d_flag, size_t n, uint32_t *d_out, uint32_t cap, uint32_t *d_count)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!d_count || (cap && !d_out)) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
+	if (n == 0) return MCOM_OK;
+	if (!d_ids || !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_list_flagged, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, n, d_out, cap, d_count);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
 // ---- untouched contigs ------------------------------------------------------------------------------------------------
 __global__ void k_keep_flags(const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ kf)
 {

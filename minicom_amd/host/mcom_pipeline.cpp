@@ -202,6 +202,13 @@ struct mcomh_pipeline {
 	PinVec<uint8_t> h_cls;
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
 	std::vector<uint8_t> sg_flag;
+	// the flags of the last Stage-2 pass as they came from the device (0 live, 1 / 2 near-poly, 3 claimed); sg_flag (1 = gone) is
+	// made from them only when somebody looks (ensure_sg_flag): a pass does not wait for a 16 M-entry host loop
+	PinVec<uint8_t> raw_flags; bool raw_flags_valid = false;
+	// second stream: transfers that nobody on the main stream waits for (the read classes going to the host, the singleton list
+	// coming up for Stage 2); in-stream they held the next kernels back for milliseconds
+	hipStream_t copy_stream = nullptr; hipEvent_t ev_main = nullptr, ev_sg = nullptr;
+	PinVec<uint32_t> sg_pin; bool sg_uploaded = false;
 	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
 	// Stage 2 never reads the member lists, so the appends of the passes stay on the device (contig, member; in the
 	// reference's appending order) and are folded into the lists by materialize() (mcom_members_finalize) when Stage 2 ends
@@ -258,6 +265,15 @@ struct mcomh_pipeline {
 
 using P = mcomh_pipeline;
 static int materialize(P *p);
+static void ensure_sg_flag(P *p)
+{
+	if (!p->raw_flags_valid) return;
+	const size_t n = p->sg.size();
+	p->sg_flag.resize(n);
+	const uint8_t *f = p->raw_flags.data(); uint8_t *sf = p->sg_flag.data();
+	for (size_t i = 0; i < n; ++i) sf[i] = f[i] ? 1 : 0;                       // flagged or claimed
+	p->raw_flags_valid = false;
+}
 static int ensure_host_contigs(P *p, bool wait_data = true);
 static const char ACGT[] = "ACGT";
 
@@ -334,6 +350,8 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
+	if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&p->ev_sg, hipEventDisableTiming) != hipSuccess) { mcom_destroy(p->ctx); delete p; return MCOM_E_HIP; }
 	if (host_reads) {
 		p->pitch = (size_t)L;
 		p->h_ascii.assign(host_reads, host_reads + n * (size_t)L);
@@ -411,6 +429,9 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (!p) return;
 	p->join_sg();
 	(void)hipStreamSynchronize(p->stream);
+	if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+	if (p->ev_main) (void)hipEventDestroy(p->ev_main);
+	if (p->ev_sg) (void)hipEventDestroy(p->ev_sg);
 	if (p->ev_cls) (void)hipEventDestroy(p->ev_cls);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
@@ -500,7 +521,10 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 	p->cls_failed = false;
 	for (std::vector<uint32_t> *v : {&p->allA, &p->allT, &p->allN, &p->fpA, &p->fpT, &p->fpN, &p->Nfile}) v->clear();   // a second call must not append twice
 	if (!p->ev_cls && (rc = p->hipc(hipEventCreateWithFlags(&p->ev_cls, hipEventDisableTiming), "event"))) return rc;
-	if ((rc = p->d2h(p->h_cls.data(), p->d_cls.p, n, "copy classes")) || (rc = p->hipc(hipEventRecord(p->ev_cls, p->stream), "event"))) return rc;
+	// on the copy stream, behind the kernels that wrote the classes: the bucket stage does not wait for 100 MB of PCIe
+	if ((rc = p->hipc(hipEventRecord(p->ev_main, p->stream), "event")) || (rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_main, 0), "wait")) ||
+	    (n && (rc = p->hipc(hipMemcpyAsync(p->h_cls.data(), p->d_cls.p, n, hipMemcpyDeviceToHost, p->copy_stream), "copy classes"))) ||
+	    (rc = p->hipc(hipEventRecord(p->ev_cls, p->copy_stream), "event"))) return rc;
 	p->cls_thread = std::thread([p, n]() {
 		if (hipEventSynchronize(p->ev_cls) != hipSuccess) { p->cls_failed = true; return; }
 		for (size_t r = 0; r < n; ++r) {
@@ -546,7 +570,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	std::vector<uint32_t> resk;
 	struct SgRound { PinVec<uint32_t> singles, sord, rej, rejg; size_t ns = 0, nrej = 0; bool last = false; };
 	std::vector<SgRound> sg_rounds;
-	p->join_sg();
+	if (p->sg_thread.joinable()) p->sg_thread.join();        // (not join_sg(): the class-list thread of kt_for_reads is still waiting for its copy)
 	if (dist) p->sg.clear();
 	size_t n_sg_total = p->sg.size();
 	DevBuf<uint32_t> d_rej, d_rejg;
@@ -589,6 +613,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		}
 		size_t ns = 0, ng = 0, nm = 0, nrej = 0;
 		const double tg = now_ms();
+		if (r == 1) p->stat["t_bk_pre"] += tg - t0;
 		if (n_cur) {
 			if (!d_sorted.reserve(n_cur) || !d_singles.reserve(n_cur) || !d_sord.reserve(n_cur) || !d_members.reserve(n_cur) || !d_goff.reserve(n_cur / 2 + 2))
 				return p->fail(MCOM_E_NOMEM, "round buffers");
@@ -702,6 +727,8 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			p->sg.insert(p->sg.end(), Rd.singles.data() + si, Rd.singles.data() + Rd.ns);
 			p->sg_round_len[ri++] = p->sg.size() - before;
 		}
+		// a page-locked copy, so that the list goes up to the device beside the Stage-2 set-up instead of in front of the first pass
+		if (p->sg_gathered && p->sg_pin.resize(p->sg.size()) && !p->sg.empty()) memcpy(p->sg_pin.data(), p->sg.data(), p->sg.size() * 4);
 	}, std::move(sg_rounds));
 	if (n_sg_total <= 5000000) p->maxsearch = 2000;                                 // preprocess.c:169-172
 	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
@@ -1025,7 +1052,18 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");
 	p->join_sg();
-	if ((rc = dist_gather_sg(p))) return rc;
+	if (p->comm) {
+		if ((rc = dist_gather_sg(p))) return rc;
+		if (p->sg_pin.resize(p->sg.size()) && !p->sg.empty()) memcpy(p->sg_pin.data(), p->sg.data(), p->sg.size() * 4);
+	}
+	// the singleton list goes up on the copy stream while Stage 2 packs the contigs and builds its index
+	p->sg_uploaded = false;
+	if (!p->sg.empty() && p->sg_pin.size() == p->sg.size() && p->d_sg_live.reserve(p->sg.size())) {
+		if ((rc = p->hipc(hipMemcpyAsync(p->d_sg_live.p, p->sg_pin.data(), p->sg.size() * 4, hipMemcpyHostToDevice, p->copy_stream), "upload singletons")) ||
+		    (rc = p->hipc(hipEventRecord(p->ev_sg, p->copy_stream), "event"))) return rc;
+		p->n_sg_live = p->sg.size(); p->sg_live_valid = true; p->sg_uploaded = true;
+	}
+	p->raw_flags_valid = false;
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->stat["t_combine"] += now_ms() - t0;
@@ -1041,10 +1079,13 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	p->join_sg();
 	if (p->sg_next_valid) {                                             // compacted on the device when the pass ended
 		p->sg.swap(p->sg_next); p->sg_next_valid = false;
+		p->raw_flags_valid = false;
 		p->sg_flag.assign(p->sg.size(), 0);
 		return MCOM_OK;
 	}
-	p->sg_live_valid = false;
+	ensure_sg_flag(p);
+	if (!p->sg_uploaded) p->sg_live_valid = false;
+	p->sg_uploaded = false;
 	const size_t n = p->sg.size();
 	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); return MCOM_OK; }
 	// nothing flagged (the state after combine_cluster): nothing to compact; eight flags per test
@@ -1064,6 +1105,7 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	const uint32_t *src = p->sg.data();
 	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { uint32_t *dst = out.data() + head + cnt[(size_t)t]; for (size_t q = head + b; q < head + e; ++q) if (!f[q]) *dst++ = src[q]; });
 	p->sg.swap(out);
+	p->sg_live_valid = false;                                           // the list on the device is the uncompacted one
 	p->sg_flag.assign(nn, 0);
 	return MCOM_OK;
 }
@@ -1293,12 +1335,18 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
 		if (!d_sg.reserve(n_sg) || !d_sgbits.reserve(n_sg * p->W) || !d_claim.reserve(n_sg) || !d_flag.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
-		if (p->sg_live_valid && p->n_sg_live == n_sg) { d_sg.swap(p->d_sg_live); p->sg_live_valid = false; }      // left by the pass before
-		else if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
+		if (p->sg_live_valid && p->n_sg_live == n_sg) {                                       // left by the pass before, or sent up beside the set-up
+			d_sg.swap(p->d_sg_live); p->sg_live_valid = false;
+			if ((rc = p->hipc(hipStreamWaitEvent(p->stream, p->ev_sg, 0), "wait"))) return rc;
+		} else if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
 		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
-		PinVec<uint8_t> pf;
+		PinVec<uint8_t> &pf = p->raw_flags;
+		p->raw_flags_valid = false;
 		if (!pf.resize(n_sg)) return p->fail(MCOM_E_NOMEM, "flags");
+		DevBuf<uint32_t> d_np; PinVec<uint32_t> h_np;                                        // near-poly singletons of this pass: {index, read, flag}
+		const uint32_t np_cap = 1u << 16;
+		if (!d_np.reserve(3 * (size_t)np_cap + 1) || !h_np.resize(3 * (size_t)np_cap + 1)) return p->fail(MCOM_E_NOMEM, "flag list");
 		// constructdictionary_realign: the read-driven pass needs the dictionaries only where a bin is cut at maxsearch;
 		// a screen with hashed counters proves (nearly always) that none is
 		mcom_dicts *dicts = nullptr;
@@ -1340,6 +1388,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		uint64_t nwon = 0;
 		if ((rc = p->gpu(mcom_claims_resolve(p->ctx, d_claim.p, d_sg.p, n_sg, (uint32_t)nc, d_flag.p, app.contig.p, app.member.p, &nwon)))) return rc;
 		app.n = (size_t)nwon;
+		if ((rc = p->gpu(mcom_list_flagged(p->ctx, d_sg.p, d_flag.p, n_sg, d_np.p, np_cap, d_np.p + 3 * (size_t)np_cap)))) return rc;
+		if ((rc = p->d2h(h_np.data(), d_np.p, 3 * (size_t)np_cap + 1, "copy flag list"))) return rc;
 		if ((rc = p->d2h(pf.data(), d_flag.p, n_sg, "copy flags"))) return rc;
 		{                                                                                    // updateSingle for the next pass, on the device
 			uint64_t n_next = 0;
@@ -1354,13 +1404,18 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		p->stat["t_ra_gpu"] += now_ms() - tg;
 		const double tw0 = now_ms();
 		{                                                                                    // bbhashdict.c:177-216, singleton order
-			uint8_t *sf = p->sg_flag.data(); const uint8_t *f = pf.data();
-			for (size_t i = 0; i < n_sg; ++i) sf[i] = f[i] ? 1 : 0;                           // flagged or claimed (vectorises)
-			// the near-poly-A / -T reads (flag 1 / 2) are rare: eight flags per test, a byte is 1 or 2 iff its two low bits differ
-			for (size_t i = 0; i < n_sg; i += 8) {
-				uint64_t w8 = 0; memcpy(&w8, f + i, n_sg - i < 8 ? n_sg - i : 8);
-				if (!(((w8) ^ (w8 >> 1)) & 0x0101010101010101ull)) continue;
-				for (size_t q = i; q < i + 8 && q < n_sg; ++q) { if (f[q] == 1) p->fpA.push_back(p->sg[q]); else if (f[q] == 2) p->fpT.push_back(p->sg[q]); }
+			// sg_flag is made from the raw flags when somebody looks (ensure_sg_flag); the near-poly-A / -T reads (flag 1 / 2) are rare
+			// and come as a list from the device, which only has to be put back into singleton order
+			p->raw_flags_valid = true;
+			const uint32_t nnp = h_np[3 * (size_t)np_cap];
+			if (nnp <= np_cap) {
+				std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> v(nnp);     // index -> (read, flag)
+				for (uint32_t q = 0; q < nnp; ++q) v[q] = std::make_pair(h_np[3 * (size_t)q], std::make_pair(h_np[3 * (size_t)q + 1], h_np[3 * (size_t)q + 2]));
+				std::sort(v.begin(), v.end());
+				for (const auto &e : v) { if (e.second.second == 1) p->fpA.push_back(e.second.first); else p->fpT.push_back(e.second.first); }
+			} else {
+				const uint8_t *f = pf.data();
+				for (size_t q = 0; q < n_sg; ++q) { if (f[q] == 1) p->fpA.push_back(p->sg[q]); else if (f[q] == 2) p->fpT.push_back(p->sg[q]); }
 			}
 		}
 		// a pass that appends nothing still counts: its scan sorts every contig first (:318), the appends of the pass before
@@ -1426,13 +1481,14 @@ static int run_stage2(P *p, FILE *f)
 	for (int thr = p->e;; thr += p->step) {                                                 // preprocess.c:197-232
 		if (thr > p->maxthr) break;
 		std::vector<uint32_t> before;
-		if (f) for (size_t i = 0; i < p->sg.size(); ++i) if (!p->sg_flag[i]) before.push_back(p->sg[i]);
+		if (f) { ensure_sg_flag(p); for (size_t i = 0; i < p->sg.size(); ++i) if (!p->sg_flag[i]) before.push_back(p->sg[i]); }
 		long cr = 0;
 		int rc = mcomh_realign_hash(p, thr, &cr);
 		if (rc) return rc;
 		if (f) {
 			fprintf(f, "STAGE realign %d thr %d\n", pass, thr);
 			dump_list(f, "sg_in", before);
+			ensure_sg_flag(p);
 			fprintf(f, "SGFLAG %zu", p->sg.size());
 			for (uint8_t v : p->sg_flag) fprintf(f, " %d", v ? 1 : 0);
 			fprintf(f, "\n");
@@ -1574,6 +1630,7 @@ extern "C" int mcomh_result_digest(mcomh_pipeline *p, uint64_t out[8])
 	out[6] = mix(sx) + 3 * mix(so);
 	// the lists live on the host
 	uint64_t h = 0, nsg = 0;
+	ensure_sg_flag(p);
 	for (size_t i = 0; i < p->sg.size(); ++i) if (p->sg_flag.size() != p->sg.size() || !p->sg_flag[i]) { h = h * 0x9E3779B97F4A7C15ull + p->sg[i] + 1; ++nsg; }
 	out[3] = nsg;
 	for (const std::vector<uint32_t> *v : {&p->allA, &p->allT, &p->allN, &p->fpA, &p->fpT, &p->fpN, &p->Nfile}) { h = h * 0xD6E8FEB86659FD93ull + v->size(); for (uint32_t x : *v) h = h * 0x9E3779B97F4A7C15ull + x + 1; }
@@ -1649,6 +1706,7 @@ static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
 	p->join_sg();
+	ensure_sg_flag(p);
 	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	{ int rcm = materialize(p); if (!rcm) rcm = ensure_host_contigs(p); if (rcm) return rcm; }
 	const int L = p->L, W = p->W, NW = p->NW;
