@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 	if (PK ? (m1 - m0 >= GC_BIG) : (m1 - m0 < GC_BIG)) { if (PK && lane == 0) *big_seen = 1; return; }
 	auto cadd = [&](uint32_t *t, int idx) { if (PK) atomicAdd(&t[idx >> 1], 1u << (16 * (idx & 1))); else atomicAdd(&t[idx], 1u); };
 	auto cget = [&](const uint32_t *t, int idx) -> uint32_t { return PK ? (t[idx >> 1] >> (16 * (idx & 1))) & 0xFFFFu : t[idx]; };
-	for (int c = lane; c < TW; c += 64) { c1[c] = 0; c2[c] = 0; }
+	auto csub = [&](uint32_t *t, int idx) { if (PK) atomicSub(&t[idx >> 1], 1u << (16 * (idx & 1))); else atomicSub(&t[idx], 1u); };
+	for (int c = lane; c < TW; c += 64) c1[c] = 0;
 	__syncthreads();
 	// pass 1: offsets, first counts
 	// Members are taken eight at a time: lane 8i+w loads word w of member i's packed row, so the two dependent global
@@ -85,6 +86,9 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		}
 	}
 	__syncthreads();
+	// The counts of the KEPT members (second consensus) start as a copy of all members' counts; pass 2 takes the rejected
+	// members out again.  Nearly every member is kept, so this replaces ~L LDS atomics per member by ~L per rejected member.
+	for (int c = lane; c < TW; c += 64) c2[c] = c1[c];
 	// first consensus: majority base per column, ties to the smaller code (strict '>'), ends at the first empty column
 	for (int c = lane; c < TL; c += 64) {
 		uint32_t mx = cget(c1, c); uint8_t b = 0;
@@ -126,10 +130,11 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 		}
 		const bool kp = dif <= e;                                          // kthread_bucket.c:189
 		if (kp) {
-#pragma unroll
-			for (int u = 0; u < 4; ++u) { const int s = u * 64 + lane; if (s < L) cadd(c2, bs[u] * TL + off + s); }
 			++nk;
 			if (off + L > rend) rend = off + L;
+		} else {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int s = u * 64 + lane; if (s < L) csub(c2, bs[u] * TL + off + s); }
 		}
 		if (lane == 0) { keep[q] = kp ? 1 : 0; members[q] = (y >> 32 << 32) | ((uint64_t)off << 1) | dir; }   // :101
 		}
