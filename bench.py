@@ -97,15 +97,18 @@ def cindex_bytes(st, model):
 # HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": "k_sketch_contigs", "cindex_build": "k_cx_scatter2", "realign_reads": "k_realign_reads<5, 16, false>",
-               "classify_pack": "k_classify_pack<32>", "sketch_reads": "k_sketch_reads<5, true>"}
+PMC_KERNELS = {"sketch_contigs": ["k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false>"], "classify_pack": ["k_classify_pack16"],
+               "sketch_reads": ["k_sketch_reads<5, true>"],
+               "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
 
 def pmc(cls, field):
+    """A PMC figure of a kernel class (summed over the kernels of the class that were counted), or None."""
     try:
         with open(PMC_FILE) as f:
             d = json.load(f)
-        return d["kernels"][PMC_KERNELS[cls]][field]
+        vals = [d["kernels"][k][field] for k in PMC_KERNELS[cls] if k in d["kernels"] and field in d["kernels"][k]]
+        return sum(vals) if vals else None
     except Exception:
         return None
 
