@@ -238,6 +238,7 @@ struct mcomh_pipeline {
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
+	bool screen_clear = false;                                             // a pass of this Stage 2 proved that no dictionary bin exceeds maxsearch
 	std::map<std::string, double> stat;
 	// multi-GPU (include/mcom_host.h, mcomh_create_dist): this rank holds reads [rid0, rid0 + n_local) of n; packed rows,
 	// classes, N masks and -- from the bucket stage on -- the contig set are replicated on every rank
@@ -564,7 +565,12 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	const bool dist = p->comm != nullptr;
 	const int R = p->world, me = p->rank;
 	size_t n_cur = dist ? p->n_local : p->n;
-	DevBuf<mcom_mm128> d_cur, d_sorted, d_part, d_recv; DevBuf<uint32_t> d_singles, d_sord, d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
+	DevBuf<mcom_mm128> d_cur, d_sorted, d_part, d_recv; DevBuf<uint32_t> d_singles_ab[2], d_sord_ab[2], d_goff, d_rids, d_nkept; DevBuf<uint64_t> d_members;
+	// the singles of a round (tens of MB in round 1) go to the host on the copy stream while the next round runs: two sets of
+	// buffers, a set is written again only after its copy has finished
+	hipEvent_t ev_set[2] = {nullptr, nullptr}; bool set_busy[2] = {false, false};
+	struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int q = 0; q < 2; ++q) if (e[q]) (void)hipEventDestroy(e[q]); } } ev_guard{ev_set};
+	for (int q = 0; q < 2; ++q) if (hipEventCreateWithFlags(&ev_set[q], hipEventDisableTiming) != hipSuccess) return p->fail(MCOM_E_HIP, "event");
 	DevBuf<uint8_t> d_keep, d_refs; DevBuf<uint16_t> d_sv, d_reflen;
 	const mcom_mm128 *cur = p->d_rec.p;                      // round 1 works on the records of kt_for_reads
 	std::vector<uint32_t> resk;
@@ -614,6 +620,9 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		size_t ns = 0, ng = 0, nm = 0, nrej = 0;
 		const double tg = now_ms();
 		if (r == 1) p->stat["t_bk_pre"] += tg - t0;
+		const int set = r & 1;
+		DevBuf<uint32_t> &d_singles = d_singles_ab[set], &d_sord = d_sord_ab[set];
+		if (set_busy[set]) { if ((rc = p->hipc(hipStreamWaitEvent(p->stream, ev_set[set], 0), "wait"))) return rc; set_busy[set] = false; }
 		if (n_cur) {
 			if (!d_sorted.reserve(n_cur) || !d_singles.reserve(n_cur) || !d_sord.reserve(n_cur) || !d_members.reserve(n_cur) || !d_goff.reserve(n_cur / 2 + 2))
 				return p->fail(MCOM_E_NOMEM, "round buffers");
@@ -679,8 +688,14 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 		if (n_cur || dist) {
 			SgRound Rd; Rd.ns = ns; Rd.nrej = nrej; Rd.last = last;
 			if (!Rd.singles.resize(ns) || !Rd.sord.resize(ns) || !Rd.rej.resize(nrej) || !Rd.rejg.resize(nrej)) return p->fail(MCOM_E_NOMEM, "round lists");
-			if ((rc = p->d2h(Rd.singles.data(), d_singles.p, ns, "copy")) || (rc = p->d2h(Rd.sord.data(), d_sord.p, ns, "copy")) ||
-			    (rc = p->d2h(Rd.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(Rd.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
+			if (ns) {
+				if ((rc = p->hipc(hipEventRecord(p->ev_main, p->stream), "event")) || (rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_main, 0), "wait")) ||
+				    (rc = p->hipc(hipMemcpyAsync(Rd.singles.data(), d_singles.p, ns * 4, hipMemcpyDeviceToHost, p->copy_stream), "copy")) ||
+				    (rc = p->hipc(hipMemcpyAsync(Rd.sord.data(), d_sord.p, ns * 4, hipMemcpyDeviceToHost, p->copy_stream), "copy")) ||
+				    (rc = p->hipc(hipEventRecord(ev_set[set], p->copy_stream), "event"))) return rc;
+				set_busy[set] = true;
+			}
+			if ((rc = p->d2h(Rd.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(Rd.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
 			p->stat["t_gpu"] += now_ms() - tg;
 			p->stat["t_bk_gpu"] += now_ms() - tg;
 			// the next round only needs the rejects; where singles and rejects go in the singleton list is settled later
@@ -709,6 +724,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	// visited before group g.  Nobody needs the list before Stage 2: a thread builds it beside combine_cluster.
 	// (multi-GPU: this rank's part, round by round; combine_cluster puts the ranks' parts together, dist_gather_sg)
 	p->join_sg();
+	if ((rc = p->hipc(hipStreamSynchronize(p->copy_stream), "round lists"))) return rc;
 	p->sg_round_len.assign(sg_rounds.size(), 0);
 	p->sg_gathered = !dist;
 	p->sg_thread = std::thread([p, n_sg_total](std::vector<SgRound> rounds) {
@@ -1066,6 +1082,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->raw_flags_valid = false;
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
+	p->screen_clear = false;
 	p->stat["t_combine"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -1352,7 +1369,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		mcom_dicts *dicts = nullptr;
 		bool big = false;
 		int may_exceed = 1;
-		if (!p->window_scan && (rc = p->gpu(mcom_dicts_screen(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, &may_exceed)))) return rc;
+		// (singletons only leave between the passes of one Stage 2, so a bin never grows: once the screen has proved that none
+		// exceeds maxsearch, it holds for the later passes too)
+		if (p->screen_clear) may_exceed = 0;
+		else if (!p->window_scan && (rc = p->gpu(mcom_dicts_screen(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, &may_exceed)))) return rc;
+		if (!may_exceed && !p->window_scan) p->screen_clear = true;
 		if (may_exceed) {
 			if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;
 			int nd = 0; uint32_t nk[16], mb[16];
