@@ -160,6 +160,148 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 	if (lane == 0) { nkept[g] = nk; svout[g] = (uint16_t)sv; reflen[g] = (uint16_t)(nk ? rend - sv : 0); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same with the column counts in REGISTERS (round 2).  Lane c owns columns c, c + 64, c + 128, ...: four 16-bit counters
+// (one per base) in one 64-bit register per column.  A member is walked by column block instead of by read position, so a lane
+// always updates its own columns: no LDS table, no LDS atomics, nothing to clear or read back -- the first consensus, the
+// mismatch test of pass 2 and the second consensus all work on the lane's registers.  Groups of 65 535 members or more keep
+// the LDS kernel with 32-bit counters (k_group_consensus<false>).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t best_base(uint64_t c, uint32_t &mx)
+{
+	mx = (uint32_t)c & 0xFFFFu; uint32_t b = 0;
+#pragma unroll
+	for (uint32_t q = 1; q < 4; ++q) { const uint32_t v = (uint32_t)(c >> (16 * q)) & 0xFFFFu; if (v > mx) { mx = v; b = q; } }   // ties to the smaller code (strict '>')
+	return b;
+}
+template <int NU>
+__global__ __launch_bounds__(64) void k_group_consensus_reg(const uint64_t *__restrict__ packed, int W, uint64_t *__restrict__ members,
+                                                            const uint32_t *__restrict__ goff, uint32_t ng, int L, int k_orig, int e,
+                                                            uint8_t *__restrict__ keep, uint32_t *__restrict__ nkept,
+                                                            uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
+                                                            uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen)
+{
+	const uint32_t g = blockIdx.x;
+	if (g >= ng) return;
+	const int lane = threadIdx.x;
+	const int TL = 2 * L;
+	const uint32_t m0 = goff[g], m1 = goff[g + 1];
+	if (m1 - m0 >= GC_BIG) { if (lane == 0) *big_seen = 1; return; }
+	// Members are taken eight at a time: lane 8i+w holds word w of member i's packed row.  The first GR_HELD batches (32 members:
+	// nearly every group) are loaded up front -- all member words together, then all rows together: two dependent round trips
+	// for the whole group instead of two per batch -- and stay in registers for pass 2.
+	constexpr int GR_HELD = 4;
+	const int il = lane >> 3, wl = lane & 7;
+	uint64_t ys[GR_HELD], rows[GR_HELD];
+#pragma unroll
+	for (int h = 0; h < GR_HELD; ++h) { const uint32_t ql = m0 + 8u * h + (uint32_t)il; ys[h] = ql < m1 ? members[ql] : 0ull; }
+#pragma unroll
+	for (int h = 0; h < GR_HELD; ++h) { const uint32_t ql = m0 + 8u * h + (uint32_t)il; rows[h] = (ql < m1 && wl < W) ? packed[(size_t)(ys[h] >> 32) * W + wl] : 0ull; }
+	uint64_t c1[NU];
+#pragma unroll
+	for (int u = 0; u < NU; ++u) c1[u] = 0;
+	int pos0 = 0;
+	// pass 1: offsets, counts of all members
+	auto count_batch = [&](uint32_t q0, uint64_t yl, uint64_t rowl) {
+		const int nm = (int)(m1 - q0 < 8u ? m1 - q0 : 8u);
+		for (int i = 0; i < nm; ++i) {
+			const uint64_t y = __shfl(yl, 8 * i, 64);
+			const uint32_t dir = (uint32_t)(y & 1);
+			int pos = (int)((uint32_t)y >> 1);
+			if (dir) pos = L - pos + k_orig - 2;
+			if (q0 == m0 && i == 0) pos0 = pos;
+			const int off = pos0 - pos;
+#pragma unroll
+			for (int u = 0; u < NU; ++u) {
+				if (64 * u + 63 < off || 64 * u >= off + L) continue;           // uniform: the read does not reach this block of columns
+				const int sidx = 64 * u + lane - off;
+				const bool valid = (unsigned)sidx < (unsigned)L;
+				const uint32_t b = obase_w(rowl, L, dir, valid ? sidx : 0, 8 * i);
+				if (valid) c1[u] += 1ull << (16 * b);
+			}
+		}
+	};
+#pragma unroll
+	for (int h = 0; h < GR_HELD; ++h) if (m0 + 8u * h < m1) count_batch(m0 + 8u * h, ys[h], rows[h]);
+	for (uint32_t q0 = m0 + 8u * GR_HELD; q0 < m1; q0 += 8) {
+		const uint32_t ql = q0 + (uint32_t)il;
+		const uint64_t yl = ql < m1 ? members[ql] : 0ull;
+		const uint64_t rowl = (ql < m1 && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+		count_batch(q0, yl, rowl);
+	}
+	// first consensus: majority base per column, ends at the first empty column
+	uint8_t rcu[NU];
+	int ref_len = TL;
+#pragma unroll
+	for (int u = 0; u < NU; ++u) { uint32_t mx; const uint32_t b = best_base(c1[u], mx); rcu[u] = mx ? (uint8_t)b : (uint8_t)0xFF; }
+#pragma unroll
+	for (int u = NU - 1; u >= 0; --u) {
+		const uint64_t z = __ballot(64 * u + lane < TL && rcu[u] == 0xFF);
+		if (z) ref_len = 64 * u + __ffsll((unsigned long long)z) - 1;
+	}
+	// pass 2: mismatches against the first consensus; the kept members' counts = all counts minus the rejected members'
+	uint64_t c2[NU];
+#pragma unroll
+	for (int u = 0; u < NU; ++u) c2[u] = c1[u];
+	uint32_t nk = 0; int rend = 0;
+	auto judge_batch = [&](uint32_t q0, uint64_t yl, uint64_t rowl) {
+		const int nm = (int)(m1 - q0 < 8u ? m1 - q0 : 8u);
+		for (int i = 0; i < nm; ++i) {
+			const uint32_t q = q0 + (uint32_t)i;
+			const uint64_t y = __shfl(yl, 8 * i, 64);
+			const uint32_t dir = (uint32_t)(y & 1);
+			int pos = (int)((uint32_t)y >> 1);
+			if (dir) pos = L - pos + k_orig - 2;
+			const int off = pos0 - pos;
+			int dif = 0;
+			uint64_t sub[NU];
+#pragma unroll
+			for (int u = 0; u < NU; ++u) {
+				sub[u] = 0;
+				if (64 * u + 63 < off || 64 * u >= off + L) continue;
+				const int col = 64 * u + lane, sidx = col - off;
+				const bool valid = (unsigned)sidx < (unsigned)L;
+				const uint32_t b = obase_w(rowl, L, dir, valid ? sidx : 0, 8 * i);
+				const bool mis = valid && (col >= ref_len || rcu[u] != (uint8_t)b);
+				dif += __popcll(__ballot(mis));
+				if (valid) sub[u] = 1ull << (16 * b);
+			}
+			const bool kp = dif <= e;                                          // kthread_bucket.c:189
+			if (kp) { ++nk; if (off + L > rend) rend = off + L; }
+			else {
+#pragma unroll
+				for (int u = 0; u < NU; ++u) c2[u] -= sub[u];
+			}
+			if (lane == 0) { keep[q] = kp ? 1 : 0; members[q] = (y >> 32 << 32) | ((uint64_t)off << 1) | dir; }   // :101
+		}
+	};
+#pragma unroll
+	for (int h = 0; h < GR_HELD; ++h) if (m0 + 8u * h < m1) judge_batch(m0 + 8u * h, ys[h], rows[h]);
+	for (uint32_t q0 = m0 + 8u * GR_HELD; q0 < m1; q0 += 8) {
+		const uint32_t ql = q0 + (uint32_t)il;
+		const uint64_t yl = ql < m1 ? members[ql] : 0ull;                  // still the sketch records: rewritten by this pass
+		const uint64_t rowl = (ql < m1 && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+		judge_batch(q0, yl, rowl);
+	}
+	// second consensus over [sv, rend): sv = first column (inside the first consensus) any kept member covers
+	int sv = 0;
+	if (nk) {
+		sv = ref_len;
+#pragma unroll
+		for (int u = NU - 1; u >= 0; --u) {
+			const uint64_t z = __ballot(64 * u + lane < ref_len && c2[u] != 0);
+			if (z) sv = 64 * u + __ffsll((unsigned long long)z) - 1;
+		}
+		uint8_t *out = refs + (size_t)g * ref_stride;
+#pragma unroll
+		for (int u = 0; u < NU; ++u) {
+			const int c = 64 * u + lane;
+			if (c >= sv && c < rend) { uint32_t mx; out[c - sv] = (uint8_t)"ACGT"[best_base(c2[u], mx)]; }
+		}
+	}
+	if (lane == 0) { nkept[g] = nk; svout[g] = (uint16_t)sv; reflen[g] = (uint16_t)(nk ? rend - sv : 0); }
+}
+
 extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t *d_members, const uint32_t *d_group_off,
                                     uint32_t n_groups, int L, int k_orig, int e, uint8_t *d_keep, uint32_t *d_nkept,
                                     uint16_t *d_sv, uint16_t *d_reflen, uint8_t *d_refs, int ref_stride)
@@ -173,8 +315,11 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	unsigned int *big = (unsigned int*)ctx->ws;
 	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
 	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL((k_group_consensus<true>), dim3(n_groups), dim3(64), (size_t)(4 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
-	                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big); }
+#define MCOM_GC(NU) case NU: hipLaunchKernelGGL((k_group_consensus_reg<NU>), dim3(n_groups), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
+	                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big); break;
+	switch ((2 * L + 63) / 64) { MCOM_GC(1) MCOM_GC(2) MCOM_GC(3) MCOM_GC(4) MCOM_GC(5) MCOM_GC(6) MCOM_GC(7) MCOM_GC(8) default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_GC
+	}
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned int hb = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -250,6 +395,70 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
 	}
 }
 
+// The same with the column counts in registers (see k_group_consensus_reg): lane c owns columns lo + c + 64 u of the tile.
+__global__ __launch_bounds__(64) void k_merge_consensus_reg(const uint64_t *__restrict__ packed, int W, const uint64_t *__restrict__ members,
+                                                            const uint64_t *__restrict__ joff, const uint64_t *__restrict__ roff,
+                                                            const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
+                                                            uint32_t n_tiles, int L, uint8_t *__restrict__ refs,
+                                                            const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi,
+                                                            unsigned int *__restrict__ big_seen)
+{
+	constexpr int NU = MC_TILE / 64;
+	const uint32_t t = blockIdx.x;
+	if (t >= n_tiles) return;
+	const int lane = threadIdx.x;
+	const uint32_t j = tile_job[t];
+	const uint64_t m0 = joff[j], m1 = joff[j + 1];
+	if (m1 - m0 >= GC_BIG) { if (lane == 0) *big_seen = 1; return; }
+	const long len = reg_hi ? (long)reg_hi[j] : (long)(roff[j + 1] - roff[j]);
+	const long lo = (reg_lo ? (long)reg_lo[j] : 0) + (long)tile_idx[t] * MC_TILE, hi = lo + MC_TILE < len ? lo + MC_TILE : len;
+	uint64_t cc[NU];
+#pragma unroll
+	for (int u = 0; u < NU; ++u) cc[u] = 0;
+	// first member whose read can reach column lo: offset > lo - L (members are sorted by offset)
+	uint64_t a = m0, b = m1;
+	while (a < b) { const uint64_t mid = (a + b) >> 1; if ((long)((uint32_t)members[mid] >> 1) + L <= lo) a = mid + 1; else b = mid; }
+	const int il = lane >> 3, wl = lane & 7;                                 // eight members per round of global loads
+	// two batches ahead for the member words, one ahead for the rows: the loads of the next batch travel while this one is counted
+	auto load_y = [&](uint64_t q0) -> uint64_t { const uint64_t ql = q0 + (uint64_t)il; return ql < m1 ? members[ql] : 0ull; };
+	auto load_row = [&](uint64_t q0, uint64_t yl) -> uint64_t {
+		const uint64_t ql = q0 + (uint64_t)il;
+		return (ql < m1 && (long)((uint32_t)yl >> 1) < hi && wl < W) ? packed[(size_t)(yl >> 32) * W + wl] : 0ull;
+	};
+	uint64_t y_cur = load_y(a), y_nxt = load_y(a + 8);
+	uint64_t row_cur = load_row(a, y_cur);
+	bool past = false;
+	for (uint64_t q0 = a; q0 < m1 && !past; q0 += 8) {
+		const uint64_t row_nxt = load_row(q0 + 8, y_nxt);
+		const uint64_t y_nn = load_y(q0 + 16);
+		const uint64_t yl = y_cur, rowl = row_cur;
+		const int nm = (int)(m1 - q0 < 8ull ? m1 - q0 : 8ull);
+		for (int i = 0; i < nm; ++i) {
+			const uint64_t y = __shfl(yl, 8 * i, 64);
+			const long off = (long)((uint32_t)y >> 1);
+			if (off >= hi) { past = true; break; }
+			const uint32_t dir = (uint32_t)(y & 1);
+			const long rel = off - lo;                                         // the read covers tile columns [rel, rel + L)
+#pragma unroll
+			for (int u = 0; u < NU; ++u) {
+				if (64 * u + 63 < rel || 64 * u >= rel + L) continue;            // uniform
+				const long c = 64 * u + lane;
+				const long sidx = c - rel;
+				const bool valid = sidx >= 0 && sidx < L && lo + c < hi;
+				const uint32_t bb = obase_w(rowl, L, dir, valid ? (int)sidx : 0, 8 * i);
+				if (valid) cc[u] += 1ull << (16 * bb);
+			}
+		}
+		y_cur = y_nxt; row_cur = row_nxt; y_nxt = y_nn;
+	}
+	uint8_t *out = refs + roff[j];
+#pragma unroll
+	for (int u = 0; u < NU; ++u) {
+		const long c = lo + 64 * u + lane;
+		if (c < hi) { uint32_t mx; out[c] = (uint8_t)"ACGT"[best_base(cc[u], mx)]; }
+	}
+}
+
 extern "C" int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off,
                                     const uint64_t *d_ref_off, const uint32_t *d_tile_job, const uint32_t *d_tile_idx,
                                     uint32_t n_tiles, int L, uint8_t *d_refs)
@@ -272,7 +481,7 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	MCOM_HIP(ctx, mcom_dmalloc((void**)&big, 256));
 	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
 	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL((k_merge_consensus<true>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+	hipLaunchKernelGGL(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big); }
 	unsigned int hb = 0;
 	hipError_t e1 = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
