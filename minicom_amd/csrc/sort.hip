@@ -458,6 +458,42 @@ extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 	return MCOM_OK;
 }
 
+// ---- records already grouped (the members of one merged contig, of one contig) need no global pass at all ------------------------
+// Groups goff[0..ng] of consecutive records, each to be sorted by x (whose high bits are the group's number, so that x
+// ascends from group to group): whole groups are packed into tiles of about 3000 records and every tile goes through
+// k_segment_sort -- its "highest differing bit" test makes it sort just the key bits plus the few bits in which the group
+// numbers of one tile differ.  One read and one write of the records where the LSD sort of (group | key) made five passes.
+// The caller guarantees that no group holds more than MCOM_GROUP_TILE_MAX records.
+__global__ void k_tile_starts(const uint64_t *__restrict__ goff, size_t ng, size_t n, uint32_t ntiles, uint32_t *__restrict__ start)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > ntiles) return;
+	if (t == ntiles) { start[t] = (uint32_t)n; return; }
+	const uint64_t target = (uint64_t)t * 3072ull;
+	size_t lo = 0, hi = ng;                                                  // first group boundary at or behind the target
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (goff[mid] < target) lo = mid + 1; else hi = mid; }
+	start[t] = (uint32_t)(goff[lo] < n ? goff[lo] : n);
+}
+int mcom_sort_groups_by_x(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, uint32_t *d_scratch /* MCOM_GROUP_SCRATCH(n) uint32, 8-byte aligned */)
+{
+	if (n == 0) return MCOM_OK;
+	const uint32_t ntiles = (uint32_t)(n / 3072 + 1);
+	uint32_t *start = d_scratch, *ovf = d_scratch + ((ntiles + 3) & ~1u);     // [count, pad, list of ntiles pairs]
+	hipLaunchKernelGGL(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
+	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
+	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
+	{
+		McomProfScope ps_(ctx, PROF_RADIX_PASS);
+		hipLaunchKernelGGL(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64, (uint32_t)SS_CAP, ovf, (uint2*)(ovf + 2));
+	}
+	MCOM_LAUNCH_CHECK(ctx);
+	uint32_t novf = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&novf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (novf) return mcom_fail(ctx, MCOM_E_ARG, "a tile of grouped records exceeded the segment sort (%u)", novf);
+	return MCOM_OK;
+}
+
 // a5: radix_sort_128x (misc.c:22).  Stable, so equal keys keep their input order; the reference is stable
 // only up to 64 elements (ksort.h:155) and leaves equal keys of larger arrays in an order that depends on
 // its in-place cycle walk.
