@@ -58,11 +58,9 @@ size_t mcom_scan_scratch_elems(size_t n);
 size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
-// grouped records (x ascends from group to group) sorted by x inside their groups, in tiles of whole groups (sort.hip); no group
-// above MCOM_GROUP_TILE_MAX records
-#define MCOM_GROUP_TILE_MAX 1024u
-#define MCOM_GROUP_SCRATCH(n) (3 * ((size_t)(n) / 3072 + 1) + 16)
-int mcom_sort_groups_by_x(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, uint32_t *d_scratch);
+// grouped records (x < 2^bits ascends from group to group) sorted by x inside their groups, in tiles of whole groups (sort.hip)
+#define MCOM_GROUP_SCRATCH(n) (4 * ((size_t)(n) / 3072 + 1) + 16)
+int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, int bits, uint32_t *d_scratch);
 // consensus of one column range per job (consensus.hip)
 int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
                                  const uint32_t *d_tile_job, const uint32_t *d_tile_idx, uint32_t n_tiles, int L, uint8_t *d_refs,

@@ -151,15 +151,13 @@ extern "C" int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 // ---- member merge ------------------------------------------------------------------------------------------------
 struct Job { uint32_t ci, cj, pos_ori, pos; };
 
-__global__ void k_job_counts(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ moff, uint64_t *__restrict__ cnt, unsigned long long *__restrict__ largest)
+__global__ void k_job_counts(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ moff, uint64_t *__restrict__ cnt)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j > nj) return;
 	if (j == nj) { cnt[j] = 0; return; }
 	const Job J = jobs[j];
-	const uint64_t c = (moff[J.ci + 1] - moff[J.ci]) + (moff[J.cj + 1] - moff[J.cj]);
-	cnt[j] = c;
-	if (c > *largest) atomicMax(largest, (unsigned long long)c);        // filtered: a single address
+	cnt[j] = (moff[J.ci + 1] - moff[J.ci]) + (moff[J.cj + 1] - moff[J.cj]);
 }
 
 // one wave per job: the list of the contig whose anchor lies further right first, the other one shifted behind it
@@ -228,14 +226,11 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(nj + 1) * 8) + 1024);
 	if (rc) return rc;
 	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
-	unsigned long long *largest = (unsigned long long*)((char*)ctx->ws + al256(scan64_scratch_elems(nj + 1) * 8));
-	MCOM_HIP(ctx, hipMemsetAsync(largest, 0, 8, ctx->stream));
-	hipLaunchKernelGGL(k_job_counts, dim3(jblocks), dim3(256), 0, ctx->stream, jobs, nj, d_moff, d_jmoff, largest);
+	hipLaunchKernelGGL(k_job_counts, dim3(jblocks), dim3(256), 0, ctx->stream, jobs, nj, d_moff, d_jmoff);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_jmoff, d_jmoff, nj + 1, (uint64_t*)ctx->ws))) return rc;
-	uint64_t total = 0; unsigned long long biggest = 0;
+	uint64_t total = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_jmoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&biggest, largest, 8, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (total >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many members in one merge round");
 	const size_t rec_b = al256(total * sizeof(mcom_mm128));
@@ -250,12 +245,12 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	hipLaunchKernelGGL(k_job_fill, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
 	                   (unsigned int*)(meta + 1));
 	MCOM_LAUNCH_CHECK(ctx);
-	if (biggest <= MCOM_GROUP_TILE_MAX) {
+	{
 		// the records lie job by job already: tiles of whole jobs, sorted in LDS (sort.hip); the sort workspace starts with a record buffer
 		mcom_mm128 *sorted = (mcom_mm128*)sortws;
-		if ((rc = mcom_sort_groups_by_x(ctx, rec, sorted, total, d_jmoff, nj, tiles))) return rc;
+		if ((rc = mcom_sort_groups_by_x(ctx, rec, sorted, total, d_jmoff, nj, key_bits + jb, tiles))) return rc;
 		rec = sorted;
-	} else if ((rc = mcom_sort_by_x(ctx, rec, total, key_bits + jb, sortws))) return rc;   // a list of thousands of members: the global radix sort
+	}
 	hipLaunchKernelGGL(k_job_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rec, (size_t)total, d_jm);
 	hipLaunchKernelGGL(k_job_len, dim3(jblocks), dim3(256), 0, ctx->stream, rec, d_jmoff, nj, L, d_jroff, meta);
 	MCOM_LAUNCH_CHECK(ctx);

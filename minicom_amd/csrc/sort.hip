@@ -463,7 +463,7 @@ extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 // ascends from group to group): whole groups are packed into tiles of about 3000 records and every tile goes through
 // k_segment_sort -- its "highest differing bit" test makes it sort just the key bits plus the few bits in which the group
 // numbers of one tile differ.  One read and one write of the records where the LSD sort of (group | key) made five passes.
-// The caller guarantees that no group holds more than MCOM_GROUP_TILE_MAX records.
+// A tile swollen by a group of thousands of records goes through the global passes instead.
 __global__ void k_tile_starts(const uint64_t *__restrict__ goff, size_t ng, size_t n, uint32_t ntiles, uint32_t *__restrict__ start)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,23 +474,50 @@ __global__ void k_tile_starts(const uint64_t *__restrict__ goff, size_t ng, size
 	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (goff[mid] < target) lo = mid + 1; else hi = mid; }
 	start[t] = (uint32_t)(goff[lo] < n ? goff[lo] : n);
 }
-int mcom_sort_groups_by_x(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, uint32_t *d_scratch /* MCOM_GROUP_SCRATCH(n) uint32, 8-byte aligned */)
+int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, int bits,
+                          uint32_t *d_scratch /* MCOM_GROUP_SCRATCH(n) uint32, 8-byte aligned */)
 {
 	if (n == 0) return MCOM_OK;
 	const uint32_t ntiles = (uint32_t)(n / 3072 + 1);
-	uint32_t *start = d_scratch, *ovf = d_scratch + ((ntiles + 3) & ~1u);     // [count, pad, list of ntiles pairs]
+	uint32_t *start = d_scratch, *ovf = d_scratch + ((ntiles + 3) & ~1u);     // [count, pad, list of ntiles pairs, ntiles offsets]
+	uint2 *ovf_list = (uint2*)(ovf + 2);
+	uint32_t *ovf_dst = ovf + 2 + 2 * (size_t)ntiles;
 	hipLaunchKernelGGL(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
 	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
 	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
-		hipLaunchKernelGGL(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64, (uint32_t)SS_CAP, ovf, (uint2*)(ovf + 2));
+		hipLaunchKernelGGL(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64,
+		                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf, ovf_list);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t novf = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&novf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (novf) return mcom_fail(ctx, MCOM_E_ARG, "a tile of grouped records exceeded the segment sort (%u)", novf);
+	if (!novf) return MCOM_OK;
+	// tiles that hold a group of thousands of records: gathered, sorted by the whole of x with the global passes (x ascends from
+	// group to group, so the tiles stay apart and their groups in place), put into the output
+	std::vector<uint2> list(novf);
+	MCOM_HIP(ctx, hipMemcpy(list.data(), ovf_list, (size_t)novf * sizeof(uint2), hipMemcpyDeviceToHost));
+	std::sort(list.begin(), list.end(), [](const uint2 &a, const uint2 &c) { return a.x < c.x; });
+	std::vector<uint32_t> dst_off(novf);
+	size_t m = 0;
+	for (uint32_t q = 0; q < novf; ++q) { dst_off[q] = (uint32_t)m; m += list[q].y - list[q].x; }
+	MCOM_HIP(ctx, hipMemcpyAsync(ovf_list, list.data(), (size_t)novf * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(ovf_dst, dst_off.data(), (size_t)novf * 4, hipMemcpyHostToDevice, ctx->stream));
+	void *ws2 = nullptr;
+	const size_t rec_b = (m * sizeof(mcom_mm128) + 255) & ~(size_t)255;
+	if (mcom_dmalloc(&ws2, rec_b + sort_ws_layout(m, nullptr, nullptr)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "workspace for %zu records of oversized groups", m);
+	mcom_mm128 *compact = (mcom_mm128*)ws2;
+	SortWs w2; sort_ws_layout(m, &w2, (char*)ws2 + rec_b);
+	hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_in, compact, ovf_list, ovf_dst, 0);
+	mcom_mm128 *res = nullptr;
+	int rc = radix_sort_records(ctx, compact, w2.tmp, m, ks, (bits + 7) / 8, w2.hist, w2.scratch, &res);
+	if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_out, res, ovf_list, ovf_dst, 1);
+	hipError_t e2 = hipStreamSynchronize(ctx->stream);
+	mcom_dfree(ws2);
+	if (rc) return rc;
+	if (e2 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "oversized groups: %s", hipGetErrorString(e2));
 	return MCOM_OK;
 }
 
