@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
                                                         const uint32_t *__restrict__ goff, uint32_t ng, int L, int k_orig, int e,
                                                         uint8_t *__restrict__ keep, uint32_t *__restrict__ nkept,
                                                         uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
-                                                        uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen)
+                                                        uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen,
+                                                        const uint32_t *__restrict__ glist)
 {
 	extern __shared__ uint32_t gc_lds[];
 	const int TL = 2 * L;
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(64) void k_group_consensus(const uint64_t *__restri
 	uint32_t *c1 = gc_lds;                      // counts of all members            [4][TL]
 	uint32_t *c2 = gc_lds + TW;                 // counts of the kept members       [4][TL]
 	uint8_t *rc = (uint8_t*)(gc_lds + 2 * TW);  // first consensus, 0xFF beyond its end
-	const uint32_t g = blockIdx.x;
-	if (g >= ng) return;
+	if (blockIdx.x >= ng) return;
+	const uint32_t g = glist ? glist[blockIdx.x] : blockIdx.x;         // glist: the ng groups to do
 	const int lane = threadIdx.x;
 	const uint32_t m0 = goff[g], m1 = goff[g + 1];
 	if (PK ? (m1 - m0 >= GC_BIG) : (m1 - m0 < GC_BIG)) { if (PK && lane == 0) *big_seen = 1; return; }
@@ -179,10 +180,11 @@ __global__ __launch_bounds__(64) void k_group_consensus_reg(const uint64_t *__re
                                                             const uint32_t *__restrict__ goff, uint32_t ng, int L, int k_orig, int e,
                                                             uint8_t *__restrict__ keep, uint32_t *__restrict__ nkept,
                                                             uint16_t *__restrict__ svout, uint16_t *__restrict__ reflen,
-                                                            uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen)
+                                                            uint8_t *__restrict__ refs, int ref_stride, unsigned int *__restrict__ big_seen,
+                                                            const uint32_t *__restrict__ glist)
 {
-	const uint32_t g = blockIdx.x;
-	if (g >= ng) return;
+	if (blockIdx.x >= ng) return;
+	const uint32_t g = glist ? glist[blockIdx.x] : blockIdx.x;         // glist: the ng groups to do
 	const int lane = threadIdx.x;
 	const int TL = 2 * L;
 	const uint32_t m0 = goff[g], m1 = goff[g + 1];
@@ -302,6 +304,11 @@ __global__ __launch_bounds__(64) void k_group_consensus_reg(const uint64_t *__re
 	if (lane == 0) { nkept[g] = nk; svout[g] = (uint16_t)sv; reflen[g] = (uint16_t)(nk ? rend - sv : 0); }
 }
 
+// the groups below 32 members, bit-sliced (consensus_bs.hip)
+int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t *d_members, const uint32_t *d_group_off, uint32_t n_groups,
+                               int L, int k_orig, int e, uint8_t *d_keep, uint32_t *d_nkept, uint16_t *d_sv, uint16_t *d_reflen, uint8_t *d_refs,
+                               int ref_stride, uint32_t **d_perm_out, uint32_t *n_small);
+
 extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t *d_members, const uint32_t *d_group_off,
                                     uint32_t n_groups, int L, int k_orig, int e, uint8_t *d_keep, uint32_t *d_nkept,
                                     uint16_t *d_sv, uint16_t *d_reflen, uint8_t *d_refs, int ref_stride)
@@ -312,24 +319,38 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	if (!d_packed || !d_members || !d_group_off || !d_keep || !d_nkept || !d_sv || !d_reflen || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_ws_reserve(ctx, 256);
 	if (rc) return rc;
+	// nearly every group holds a handful of members: those go through the bit-sliced kernel, several groups per wave; what is left
+	// (32 members or more) takes a wave per group
+	uint32_t *perm = nullptr, n_small = 0;
+	if (ref_stride % 4 == 0 && ((uintptr_t)d_refs & 3) == 0) {
+		if ((rc = mcom_group_consensus_small(ctx, d_packed, d_members, d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, &perm, &n_small)))
+			return rc;
+	}
+	const uint32_t n_rest = n_groups - n_small;
+	const uint32_t *glist = perm ? perm + n_small : nullptr;
+	if (n_rest == 0) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); mcom_dfree(perm); return MCOM_OK; }
 	unsigned int *big = (unsigned int*)ctx->ws;
-	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
-	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
-#define MCOM_GC(NU) case NU: hipLaunchKernelGGL((k_group_consensus_reg<NU>), dim3(n_groups), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
-	                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big); break;
-	switch ((2 * L + 63) / 64) { MCOM_GC(1) MCOM_GC(2) MCOM_GC(3) MCOM_GC(4) MCOM_GC(5) MCOM_GC(6) MCOM_GC(7) MCOM_GC(8) default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+	hipError_t er = hipMemsetAsync(big, 0, 4, ctx->stream);
+	if (er == hipSuccess) {
+		McomProfScope ps_(ctx, PROF_CONSENSUS);
+#define MCOM_GC(NU) case NU: hipLaunchKernelGGL((k_group_consensus_reg<NU>), dim3(n_rest), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
+	                   d_group_off, n_rest, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big, glist); break;
+		switch ((2 * L + 63) / 64) { MCOM_GC(1) MCOM_GC(2) MCOM_GC(3) MCOM_GC(4) MCOM_GC(5) MCOM_GC(6) MCOM_GC(7) MCOM_GC(8) default: er = hipErrorInvalidValue; }
 #undef MCOM_GC
 	}
-	MCOM_LAUNCH_CHECK(ctx);
+	if (er == hipSuccess) er = hipGetLastError();
 	unsigned int hb = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (hb) {                                                                // groups of 65535 members or more: 32-bit counters
+	if (er == hipSuccess) er = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
+	if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
+	if (er == hipSuccess && hb) {                                            // groups of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-		hipLaunchKernelGGL((k_group_consensus<false>), dim3(n_groups), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
-		                   d_group_off, n_groups, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big);
-		MCOM_LAUNCH_CHECK(ctx);
+		hipLaunchKernelGGL((k_group_consensus<false>), dim3(n_rest), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
+		                   d_group_off, n_rest, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big, glist);
+		er = hipGetLastError();
+		if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
 	}
+	mcom_dfree(perm);
+	if (er != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "group consensus: %s", hipGetErrorString(er));
 	return MCOM_OK;
 }
 
@@ -345,11 +366,11 @@ __global__ __launch_bounds__(64) void k_merge_consensus(const uint64_t *__restri
                                                         const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
                                                         uint32_t n_tiles, int L, uint8_t *__restrict__ refs,
                                                         const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi,
-                                                        unsigned int *__restrict__ big_seen)
+                                                        unsigned int *__restrict__ big_seen, const uint32_t *__restrict__ tlist)
 {
 	__shared__ uint32_t cc[PK ? 2 * MC_TILE : 4 * MC_TILE];                  // PK: two 16-bit counters per word (see k_group_consensus)
-	const uint32_t t = blockIdx.x;
-	if (t >= n_tiles) return;
+	if (blockIdx.x >= n_tiles) return;
+	const uint32_t t = tlist ? tlist[blockIdx.x] : blockIdx.x;                // tlist: the n_tiles tiles to do
 	const int lane = threadIdx.x;
 	const uint32_t j = tile_job[t];
 	const uint64_t m0 = joff[j], m1 = joff[j + 1];
@@ -401,11 +422,11 @@ __global__ __launch_bounds__(64) void k_merge_consensus_reg(const uint64_t *__re
                                                             const uint32_t *__restrict__ tile_job, const uint32_t *__restrict__ tile_idx,
                                                             uint32_t n_tiles, int L, uint8_t *__restrict__ refs,
                                                             const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi,
-                                                            unsigned int *__restrict__ big_seen)
+                                                            unsigned int *__restrict__ big_seen, const uint32_t *__restrict__ tlist)
 {
 	constexpr int NU = MC_TILE / 64;
-	const uint32_t t = blockIdx.x;
-	if (t >= n_tiles) return;
+	if (blockIdx.x >= n_tiles) return;
+	const uint32_t t = tlist ? tlist[blockIdx.x] : blockIdx.x;                // tlist: the n_tiles tiles to do
 	const int lane = threadIdx.x;
 	const uint32_t j = tile_job[t];
 	const uint64_t m0 = joff[j], m1 = joff[j + 1];
@@ -467,13 +488,13 @@ extern "C" int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, con
 	if (n_tiles == 0) return MCOM_OK;
 	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad read length");
 	if (!d_packed || !d_members || !d_job_off || !d_ref_off || !d_tile_job || !d_tile_idx || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	return mcom_merge_consensus_regions(ctx, d_packed, d_members, d_job_off, d_ref_off, d_tile_job, d_tile_idx, n_tiles, L, d_refs, nullptr, nullptr);
+	return mcom_merge_consensus_regions(ctx, d_packed, d_members, d_job_off, d_ref_off, d_tile_job, d_tile_idx, n_tiles, L, d_refs, nullptr, nullptr, nullptr);
 }
 
 // the same over one column range per job (merge.hip: only the overlap of the two parents is counted again)
 int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
                                  const uint32_t *d_tile_job, const uint32_t *d_tile_idx, uint32_t n_tiles, int L, uint8_t *d_refs,
-                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi)
+                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi, const uint32_t *d_tlist)
 {
 	if (n_tiles == 0) return MCOM_OK;
 	// the flag lives behind everything the callers keep in the workspace (they reserve their own part first)
@@ -482,14 +503,14 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
 	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
 	hipLaunchKernelGGL(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big); }
+	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist); }
 	unsigned int hb = 0;
 	hipError_t e1 = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
 	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
 	if (e1 == hipSuccess && hb) {                                            // a job of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
 		hipLaunchKernelGGL((k_merge_consensus<false>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big);
+		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist);
 		e1 = hipStreamSynchronize(ctx->stream);
 	}
 	mcom_dfree(big);

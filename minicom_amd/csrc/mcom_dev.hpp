@@ -62,9 +62,15 @@ int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, vo
 #define MCOM_GROUP_SCRATCH(n) (4 * ((size_t)(n) / 3072 + 1) + 16)
 int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, int bits, uint32_t *d_scratch);
 // consensus of one column range per job (consensus.hip)
+// d_tlist: the n_tiles tiles to do out of the tile arrays (NULL: all of them)
 int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
                                  const uint32_t *d_tile_job, const uint32_t *d_tile_idx, uint32_t n_tiles, int L, uint8_t *d_refs,
-                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi);
+                                 const uint32_t *d_reg_lo, const uint32_t *d_reg_hi, const uint32_t *d_tlist);
+// the same by units of 32 columns, bit-sliced (consensus_bs.hip); tiles holding a unit that too many members reach come back as a list
+int mcom_merge_consensus_units(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_members, const uint64_t *d_job_off, const uint64_t *d_ref_off,
+                               const uint32_t *d_ujob, const uint32_t *d_uoff, uint32_t n_units, int L, uint8_t *d_refs,
+                               const uint32_t *d_reg_lo, const uint32_t *d_reg_hi, const uint32_t *d_toff, uint32_t n_tiles,
+                               unsigned int *d_tflag, uint32_t *d_tlist, uint32_t *h_nlist);
 // 64-bit exclusive scan (merge.hip): scratch of mcom_scan64_scratch_elems(n) uint64
 size_t mcom_scan64_scratch_elems(size_t n);
 int mcom_scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch);

@@ -266,29 +266,31 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 
 // ---- consensus tiles made on the device -----------------------------------------------------------------------------
 #define MC_TILE 512
-__global__ void k_tile_counts(const uint64_t *__restrict__ jroff, size_t nj, uint32_t *__restrict__ cnt)
+__global__ void k_tile_counts(const uint64_t *__restrict__ jroff, size_t nj, uint32_t *__restrict__ cnt, uint32_t *__restrict__ ucnt)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j > nj) return;
 	cnt[j] = j == nj ? 0u : (uint32_t)((jroff[j + 1] - jroff[j] + MC_TILE - 1) / MC_TILE);
+	ucnt[j] = j == nj ? 0u : (uint32_t)((jroff[j + 1] - jroff[j] + 31) / 32);
 }
+// tjob / tidx: job and index inside the job of every tile (or NULL, NULL: ujob only, for the units of 32 columns)
 __global__ void k_tile_fill(const uint32_t *__restrict__ toff, size_t nj, uint32_t *__restrict__ tjob, uint32_t *__restrict__ tidx)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nj) return;
 	const uint32_t a = toff[j], b = toff[j + 1];
-	for (uint32_t t = a; t < b; ++t) { tjob[t] = (uint32_t)j; tidx[t] = t - a; }
+	for (uint32_t t = a; t < b; ++t) { tjob[t] = (uint32_t)j; if (tidx) tidx[t] = t - a; }
 }
 
 // Outside the overlap of its two parents a merged contig's columns see exactly the members one parent had, so the
 // majority there is the parent's consensus character: only the overlap [shift, min(len_first, shift + len_second)) is
 // counted again (k_merge_consensus over that column range), the rest is copied from the parents' strings.
 __global__ void k_job_regions(const Job *__restrict__ jobs, size_t nj, const uint64_t *__restrict__ soff, uint32_t *__restrict__ olo, uint32_t *__restrict__ ohi,
-                              uint32_t *__restrict__ tcnt)
+                              uint32_t *__restrict__ tcnt, uint32_t *__restrict__ ucnt)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j > nj) return;
-	if (j == nj) { tcnt[j] = 0; return; }
+	if (j == nj) { tcnt[j] = 0; ucnt[j] = 0; return; }
 	const Job J = jobs[j];
 	const bool afirst = J.pos_ori >= J.pos;
 	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
@@ -297,6 +299,7 @@ __global__ void k_job_regions(const Job *__restrict__ jobs, size_t nj, const uin
 	const uint64_t lo = sh < lf ? sh : lf, hi = lf < sh + ls ? lf : sh + ls;
 	olo[j] = (uint32_t)lo; ohi[j] = (uint32_t)(hi > lo ? hi : lo);
 	tcnt[j] = (uint32_t)((ohi[j] - olo[j] + MC_TILE - 1) / MC_TILE);
+	ucnt[j] = (uint32_t)((ohi[j] - olo[j] + 31) / 32);
 }
 __global__ __launch_bounds__(256) void k_merge_copy(const Job *__restrict__ jobs, size_t nj, const uint8_t *__restrict__ seq, const uint64_t *__restrict__ soff,
                                                     const uint64_t *__restrict__ jroff, const uint32_t *__restrict__ olo, const uint32_t *__restrict__ ohi,
@@ -335,27 +338,37 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	if (nj == 0) return MCOM_OK;
 	if (!d_packed || !d_jm || !d_jmoff || !d_jroff || !d_refs) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const bool regions = d_jobs && d_seq && d_soff;                          // parents known: count the overlaps only
-	const size_t max_tiles = (size_t)(total_chars / MC_TILE) + nj + 1;
-	if (max_tiles >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many consensus tiles");
-	int rc = mcom_ws_reserve(ctx, 3 * al256((nj + 1) * 4) + al256(mcom_scan_scratch_elems(nj + 1) * 4 + 1024) + 2 * al256(max_tiles * 4) + 256);
+	const size_t max_tiles = (size_t)(total_chars / MC_TILE) + nj + 1, max_units = (size_t)(total_chars / 32) + nj + 1;
+	if (max_units >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many consensus tiles");
+	int rc = mcom_ws_reserve(ctx, 4 * al256((nj + 1) * 4) + al256(mcom_scan_scratch_elems(nj + 1) * 4 + 1024) + 4 * al256((max_tiles + 1) * 4) + al256(max_units * 4) + 256);
 	if (rc) return rc;
 	WsCut w{(char*)ctx->ws, 0};
-	uint32_t *toff = w.take<uint32_t>(nj + 1), *olo = w.take<uint32_t>(nj + 1), *ohi = w.take<uint32_t>(nj + 1);
+	uint32_t *toff = w.take<uint32_t>(nj + 1), *uoff = w.take<uint32_t>(nj + 1), *olo = w.take<uint32_t>(nj + 1), *ohi = w.take<uint32_t>(nj + 1);
 	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(nj + 1) + 256);
-	uint32_t *tjob = w.take<uint32_t>(max_tiles), *tidx = w.take<uint32_t>(max_tiles);
+	uint32_t *tjob = w.take<uint32_t>(max_tiles + 1), *tidx = w.take<uint32_t>(max_tiles + 1), *tflag = w.take<uint32_t>(max_tiles + 1), *tlist = w.take<uint32_t>(max_tiles + 1);
+	uint32_t *ujob = w.take<uint32_t>(max_units);
 	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
-	if (regions) hipLaunchKernelGGL(k_job_regions, dim3(jblocks), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, olo, ohi, toff);
-	else hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff);
+	if (regions) hipLaunchKernelGGL(k_job_regions, dim3(jblocks), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, olo, ohi, toff, uoff);
+	else hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff, uoff);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, toff, toff, nj + 1, scr))) return rc;
-	uint32_t nt = 0;
+	if ((rc = mcom_scan_u32(ctx, uoff, uoff, nj + 1, scr))) return rc;
+	uint32_t nt = 0, nu = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&nt, toff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&nu, uoff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (nt > max_tiles) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
-	if (nt) {
+	if (nt > max_tiles || nu > max_units) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
+	if (nu) {
+		// units of 32 columns through the bit-sliced kernel; the tiles it hands back (a unit that more than 31 members reach) through
+		// the wave-per-tile kernel
+		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, uoff, nj, ujob, (uint32_t*)nullptr);
 		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
 		MCOM_LAUNCH_CHECK(ctx);
-		if ((rc = mcom_merge_consensus_regions(ctx, d_packed, d_jm, d_jmoff, d_jroff, tjob, tidx, nt, L, d_refs, regions ? olo : nullptr, regions ? ohi : nullptr))) return rc;
+		uint32_t nlist = 0;
+		if ((rc = mcom_merge_consensus_units(ctx, d_packed, d_jm, d_jmoff, d_jroff, ujob, uoff, nu, L, d_refs, regions ? olo : nullptr, regions ? ohi : nullptr,
+		                                     toff, nt, tflag, tlist, &nlist))) return rc;
+		if (nlist && (rc = mcom_merge_consensus_regions(ctx, d_packed, d_jm, d_jmoff, d_jroff, tjob, tidx, nlist, L, d_refs, regions ? olo : nullptr, regions ? ohi : nullptr, tlist)))
+			return rc;
 	}
 	if (regions) {
 		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
