@@ -71,6 +71,9 @@ int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records);
 /* Likewise for mcom_cindex_build: partitions with more than `entries` entries are placed by the scattered kernel instead of
  * the sorted one (0 = all of them; negative = default).  Same index either way.                                       */
 int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
+/* Likewise for the merge consensus: a unit of 32 columns that more than `members` members reach sends its tile to the
+ * wave-per-tile kernel (0 = default, the 127 the bit-sliced counters hold).  Same consensus either way.              */
+int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
 
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:

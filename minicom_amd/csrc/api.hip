@@ -196,6 +196,12 @@ extern "C" int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records)
 	ctx->seg_cap = records;
 	return MCOM_OK;
 }
+extern "C" int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members)
+{
+	if (!ctx) return MCOM_E_ARG;
+	ctx->bs_cap = members;
+	return MCOM_OK;
+}
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
 {
 	if (!ctx) return MCOM_E_ARG;

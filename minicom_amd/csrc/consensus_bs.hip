@@ -16,51 +16,52 @@
 // Results are the same arrays as mcom_group_consensus's other kernels write; groups of 32 members or more keep those kernels.
 #include "mcom_dev.hpp"
 
-#define BS_K 5
+#define BS_K 5                       // counter bits of the group kernel: up to 31 members
 #define BS_NMAX 31u
+#define BS_KM 7                      // of the merge kernel: up to 127 members reaching one unit (the coverage of the data set decides)
 #define BS_EVEN 0x5555555555555555ull
 
 namespace {
-struct BsCnt { uint64_t p[BS_K], q[BS_K]; };
+template <int K> struct BsCnt { uint64_t p[K], q[K]; };
 
-__device__ __forceinline__ void bs_add(BsCnt &c, uint64_t P, uint64_t Q)
+template <int K> __device__ __forceinline__ void bs_add(BsCnt<K> &c, uint64_t P, uint64_t Q)
 {
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) { uint64_t t = c.p[b] & P; c.p[b] ^= P; P = t; t = c.q[b] & Q; c.q[b] ^= Q; Q = t; }
+	for (int b = 0; b < K; ++b) { uint64_t t = c.p[b] & P; c.p[b] ^= P; P = t; t = c.q[b] & Q; c.q[b] ^= Q; Q = t; }
 }
-__device__ __forceinline__ void bs_sub(BsCnt &c, uint64_t P, uint64_t Q)
+template <int K> __device__ __forceinline__ void bs_sub(BsCnt<K> &c, uint64_t P, uint64_t Q)
 {
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) { uint64_t t = ~c.p[b] & P; c.p[b] ^= P; P = t; t = ~c.q[b] & Q; c.q[b] ^= Q; Q = t; }
+	for (int b = 0; b < K; ++b) { uint64_t t = ~c.p[b] & P; c.p[b] ^= P; P = t; t = ~c.q[b] & Q; c.q[b] ^= Q; Q = t; }
 }
 // per column (even bit 2j): lo / hi bit of the majority base, ties to the smaller code; nz: any base counted at all
-__device__ __forceinline__ void bs_best(const BsCnt &c, uint64_t &lo, uint64_t &hi, uint64_t &nz)
+template <int K> __device__ __forceinline__ void bs_best(const BsCnt<K> &c, uint64_t &lo, uint64_t &hi, uint64_t &nz)
 {
-	uint64_t best[BS_K], cand[BS_K];
+	uint64_t best[K], cand[K];
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) best[b] = c.p[b] & BS_EVEN;
+	for (int b = 0; b < K; ++b) best[b] = c.p[b] & BS_EVEN;
 	lo = 0; hi = 0;
 	auto challenge = [&](int code) {
 		uint64_t gt = 0, eq = BS_EVEN;
 #pragma unroll
-		for (int b = BS_K - 1; b >= 0; --b) { gt |= eq & cand[b] & ~best[b]; eq &= ~(cand[b] ^ best[b]); }
+		for (int b = K - 1; b >= 0; --b) { gt |= eq & cand[b] & ~best[b]; eq &= ~(cand[b] ^ best[b]); }
 #pragma unroll
-		for (int b = 0; b < BS_K; ++b) best[b] = (cand[b] & gt) | (best[b] & ~gt);
+		for (int b = 0; b < K; ++b) best[b] = (cand[b] & gt) | (best[b] & ~gt);
 		lo = (code & 1) ? (lo | gt) : (lo & ~gt);
 		hi = (code & 2) ? (hi | gt) : (hi & ~gt);
 	};
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) cand[b] = (c.p[b] >> 1) & BS_EVEN;
+	for (int b = 0; b < K; ++b) cand[b] = (c.p[b] >> 1) & BS_EVEN;
 	challenge(1);
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) cand[b] = c.q[b] & BS_EVEN;
+	for (int b = 0; b < K; ++b) cand[b] = c.q[b] & BS_EVEN;
 	challenge(2);
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) cand[b] = (c.q[b] >> 1) & BS_EVEN;
+	for (int b = 0; b < K; ++b) cand[b] = (c.q[b] >> 1) & BS_EVEN;
 	challenge(3);
 	nz = 0;
 #pragma unroll
-	for (int b = 0; b < BS_K; ++b) nz |= best[b];
+	for (int b = 0; b < K; ++b) nz |= best[b];
 }
 // reverse the order of the 32 bases of a word
 __device__ __forceinline__ uint64_t bs_rev(uint64_t x)
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 		Q = (hh & ~lo) | ((hh & lo) << 1);
 	};
 	// ---- pass 1: counts of all members
-	BsCnt c;
+	BsCnt<BS_K> c;
 #pragma unroll
 	for (int b = 0; b < BS_K; ++b) { c.p[b] = 0; c.q[b] = 0; }
 	for (uint32_t i = 0; i < nmax; ++i) {
@@ -242,14 +243,14 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 
 // ---- construct_ref2 (kthread_cb.c:105-218), the same way: one lane per 32 columns of one job's column range -------------------------
 // The members of a job are sorted by offset, so the ones that reach a unit's columns are a run of the list: found by a binary
-// search, walked until the first offset behind the unit.  A unit that more than 31 members reach marks its 512-column tile for the
+// search, walked until the first offset behind the unit.  A unit that more than 127 members reach marks its 512-column tile for the
 // wave-per-tile kernel (consensus.hip), which then writes the whole tile.
 __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__restrict__ packed, int W, const uint64_t *__restrict__ members,
                                                            const uint64_t *__restrict__ joff, const uint64_t *__restrict__ roff,
                                                            const uint32_t *__restrict__ ujob, const uint32_t *__restrict__ uoff, uint32_t n_units, int L,
                                                            uint8_t *__restrict__ refs, const uint32_t *__restrict__ reg_lo, const uint32_t *__restrict__ reg_hi,
                                                            const uint32_t *__restrict__ toff, unsigned int *__restrict__ tflag, uint32_t *__restrict__ tlist,
-                                                           unsigned int *__restrict__ tcount)
+                                                           unsigned int *__restrict__ tcount, uint32_t depth_cap)
 {
 	const uint32_t q = blockIdx.x * 64u + threadIdx.x;
 	const bool valid = q < n_units;
@@ -266,9 +267,9 @@ __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__res
 	// first member whose read reaches column c0: offset + L > c0
 	uint64_t a = m0, b = m1;
 	while (a < b) { const uint64_t mid = (a + b) >> 1; if ((long)((uint32_t)members[mid] >> 1) + L <= c0) a = mid + 1; else b = mid; }
-	BsCnt c;
+	BsCnt<BS_KM> c;
 #pragma unroll
-	for (int t = 0; t < BS_K; ++t) { c.p[t] = 0; c.q[t] = 0; }
+	for (int t = 0; t < BS_KM; ++t) { c.p[t] = 0; c.q[t] = 0; }
 	uint32_t n = 0; bool over = false;
 	uint64_t i = a;
 	uint64_t y = (valid && i < m1) ? members[i] : ~0ull;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__res
 		if (!__ballot(act)) break;
 		const uint64_t y_next = (act && i + 1 < m1) ? members[i + 1] : ~0ull;   // travels while this member is counted
 		if (act) {
-			if (n == BS_NMAX) over = true;
+			if (n == depth_cap) over = true;
 			else {
 				const uint32_t dir = (uint32_t)(y & 1);
 				const int s0 = (int)(c0 - off);                                // read position under the unit's first column (> -32, < L)
@@ -372,7 +373,8 @@ int mcom_merge_consensus_units(mcom_ctx *ctx, const uint64_t *d_packed, const ui
 	{
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
 		hipLaunchKernelGGL(k_merge_consensus_bs, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
-		                   d_ujob, d_uoff, n_units, L, d_refs, d_reg_lo, d_reg_hi, d_toff, d_tflag, d_tlist, tcount);
+		                   d_ujob, d_uoff, n_units, L, d_refs, d_reg_lo, d_reg_hi, d_toff, d_tflag, d_tlist, tcount,
+		                   ctx->bs_cap && ctx->bs_cap < (1u << BS_KM) ? ctx->bs_cap : (1u << BS_KM) - 1u);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemcpyAsync(h_nlist, tcount, 4, hipMemcpyDeviceToHost, ctx->stream));

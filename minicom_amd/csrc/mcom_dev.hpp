@@ -29,6 +29,8 @@ struct mcom_ctx {
 	uint32_t seg_cap = 0; uint64_t sort_overflow_segments = 0;
 	// contig index: entries of a partition above which the scattered placement is used (tests lower it; 0 entries = always)
 	bool cix_cap_set = false; uint32_t cix_cap = 0;
+	// merge consensus: members reaching one unit of 32 columns above which its tile goes to the wave-per-tile kernel (0 = the counters' 127)
+	uint32_t bs_cap = 0;
 };
 
 // brackets one kernel launch (or a short launch sequence) with events when the profiler is on

@@ -359,7 +359,7 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (nt > max_tiles || nu > max_units) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
 	if (nu) {
-		// units of 32 columns through the bit-sliced kernel; the tiles it hands back (a unit that more than 31 members reach) through
+		// units of 32 columns through the bit-sliced kernel; the tiles it hands back (a unit that more than 127 members reach) through
 		// the wave-per-tile kernel
 		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, uoff, nj, ujob, (uint32_t*)nullptr);
 		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);

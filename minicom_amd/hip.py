@@ -222,6 +222,11 @@ class Context:
         self.lib.mcom_set_index_capacity.restype = C.c_int; self.lib.mcom_set_index_capacity.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.mcom_set_index_capacity(self._h, entries))
 
+    def set_consensus_capacity(self, members: int):
+        """Test hook of the merge consensus: units that more than `members` members reach use the wave-per-tile kernel (0 = default 127)."""
+        self.lib.mcom_set_consensus_capacity.restype = C.c_int; self.lib.mcom_set_consensus_capacity.argtypes = [C.c_void_p, C.c_uint32]
+        self._check(self.lib.mcom_set_consensus_capacity(self._h, members))
+
     def sort_group(self, rec, L: int, k_orig: int, kmer: int, b: int = 14):
         """mcom_sort_group.  Returns dict(sorted, singles, members, group_off) trimmed to their counts."""
         torch = _torch()

@@ -223,6 +223,13 @@ def test_merge_round_pieces_against_numpy(ctx):
     part = ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L, jobs=d_jobs, seq=d_seq, soff=d_soff)
     assert full.cpu().numpy().tobytes() == b"".join(want_refs)
     assert torch.equal(full, part)                                               # counting only the overlap changes nothing
+    # units deeper than the bit-sliced counters hold go tile by tile through the wave-per-tile kernel: the same consensus
+    ctx.set_consensus_capacity(3)
+    try:
+        assert torch.equal(ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L), full)
+        assert torch.equal(ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L, jobs=d_jobs, seq=d_seq, soff=d_soff), full)
+    finally:
+        ctx.set_consensus_capacity(0)
     # cp_cluster: merged first, then the untouched ones in their order
     nj = len(jobs); nkeep = int((flag == 0).sum()); nn = nj + nkeep
     seq2 = torch.zeros(len(seq) + 16, dtype=torch.uint8, device="cuda"); seq2[: tot[1]] = full

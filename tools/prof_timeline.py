@@ -15,7 +15,7 @@ t0, t1 = rows[0][1], max(r[2] for r in rows)
 busy = collections.Counter(); calls = collections.Counter()
 gap = 0; last_end = rows[0][1]; gaps = []
 for name, s, e in rows:
-    k = name.split("(")[0].replace("void ", "")
+    k = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     busy[k] += e - s; calls[k] += 1
     if s > last_end:
         gap += s - last_end; gaps.append((s - last_end, k))
