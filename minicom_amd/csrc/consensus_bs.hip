@@ -138,28 +138,31 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 	const int col0 = 32 * u;
 	int pos0 = 0;
 	if (n) { const uint64_t y = members[m0]; int pos = (int)((uint32_t)y >> 1); if (y & 1) pos = L - pos + k_orig - 2; pos0 = pos; }
-	// member i of the lane's group: its word y, its offset and -- cut out of its packed row -- the 32 bases under the lane's columns
-	// (x: 2 bits per column) with the columns it covers (cov, even bits)
-	auto member = [&](uint32_t i, uint64_t &y, int &off, uint64_t &x, uint64_t &cov) {
-		const bool act = i < n;
-		y = act ? members[m0 + i] : 0ull;
+	// Member i of the lane's group in three steps, so that the two dependent round trips (member word, then its packed row) of the
+	// NEXT members travel while this one is counted: its word y; its offset and the two row words under the lane's columns; the
+	// 32 bases cut out of them (x: 2 bits per column) with the columns the read covers (cov, even bits).
+	struct Fetch { uint64_t y, wa, wb; int off, s0, sh; bool covered; };
+	auto fetch_y = [&](uint32_t i) -> uint64_t { return i < n ? members[m0 + i] : 0ull; };
+	auto fetch_rows = [&](uint32_t i, uint64_t y) -> Fetch {
+		Fetch f; f.y = y;
 		const uint32_t dir = (uint32_t)(y & 1);
 		int pos = (int)((uint32_t)y >> 1);
 		if (dir) pos = L - pos + k_orig - 2;
-		off = pos0 - pos;
-		const int s0 = col0 - off;                                      // read position under the unit's first column
-		const bool covered = act && s0 < L && s0 + 32 > 0;
-		x = 0; cov = 0;
-		if (covered) {
-			const int t0 = dir ? L - 32 - s0 : s0;                        // first of the 32 stored bases (may lie before or behind the row)
-			const int wj = t0 >> 5, sh = 2 * (t0 & 31);
-			const uint64_t *row = packed + (size_t)(y >> 32) * W;
-			const uint64_t wa = (wj >= 0 && wj < W) ? row[wj] : 0ull;
-			const uint64_t wb = (sh && wj + 1 >= 0 && wj + 1 < W) ? row[wj + 1] : 0ull;
-			x = sh ? (wa >> sh) | (wb << (64 - sh)) : wa;
-			if (dir) x = ~bs_rev(x);                                      // reverse complement (preprocess.c:22-37)
-			cov = bs_span(s0 < 0 ? -s0 : 0, L - s0 < 32 ? L - s0 : 32);
-		}
+		f.off = pos0 - pos;
+		f.s0 = col0 - f.off;                                            // read position under the unit's first column
+		f.covered = i < n && f.s0 < L && f.s0 + 32 > 0;
+		const int t0 = dir ? L - 32 - f.s0 : f.s0;                      // first of the 32 stored bases (may lie before or behind the row)
+		const int wj = t0 >> 5;
+		f.sh = 2 * (t0 & 31);
+		const uint64_t *row = packed + (size_t)(y >> 32) * W;
+		f.wa = (f.covered && wj >= 0 && wj < W) ? row[wj] : 0ull;
+		f.wb = (f.covered && f.sh && wj + 1 >= 0 && wj + 1 < W) ? row[wj + 1] : 0ull;
+		return f;
+	};
+	auto finish = [&](const Fetch &f, uint64_t &x, uint64_t &cov) {
+		x = f.sh ? (f.wa >> f.sh) | (f.wb << (64 - f.sh)) : f.wa;
+		if (f.y & 1) x = ~bs_rev(x);                                    // reverse complement (preprocess.c:22-37)
+		cov = f.covered ? bs_span(f.s0 < 0 ? -f.s0 : 0, L - f.s0 < 32 ? L - f.s0 : 32) : 0ull;
 	};
 	auto planes = [&](uint64_t x, uint64_t cov, uint64_t &P, uint64_t &Q) {
 		const uint64_t lo = x & BS_EVEN, hi = (x >> 1) & BS_EVEN;
@@ -171,11 +174,19 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 	BsCnt<BS_K> c;
 #pragma unroll
 	for (int b = 0; b < BS_K; ++b) { c.p[b] = 0; c.q[b] = 0; }
-	for (uint32_t i = 0; i < nmax; ++i) {
-		uint64_t y, x, cov, P, Q; int off;
-		member(i, y, off, x, cov);
-		planes(x, cov, P, Q);
-		bs_add(c, P, Q);
+	{
+		uint64_t yn = fetch_y(0);
+		Fetch cur = fetch_rows(0, yn);
+		yn = fetch_y(1);
+		for (uint32_t i = 0; i < nmax; ++i) {
+			const Fetch nxt = fetch_rows(i + 1, yn);
+			yn = fetch_y(i + 2);
+			uint64_t x, cov, P, Q;
+			finish(cur, x, cov);
+			planes(x, cov, P, Q);
+			bs_add(c, P, Q);
+			cur = nxt;
+		}
 	}
 	// ---- first consensus: majority base per column; it ends at the first empty column (:172-180)
 	uint64_t rlo, rhi, nz;
@@ -191,16 +202,25 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 	const uint64_t inref = bs_span(0, ref_len - col0 < 0 ? 0 : (ref_len - col0 > 32 ? 32 : ref_len - col0));   // the unit's columns inside it
 	// ---- pass 2: mismatches against the first consensus (:182-190); the counts of the kept members = all counts minus the rejected members'
 	uint32_t nk = 0; int rend = 0;
+	uint64_t yn = fetch_y(0);
+	Fetch cur = fetch_rows(0, yn);
+	yn = fetch_y(1);
 	for (uint32_t i = 0; i < nmax; ++i) {
-		uint64_t y, x, cov, P, Q; int off;
-		member(i, y, off, x, cov);
+		const Fetch nxt = fetch_rows(i + 1, yn);                        // members[] is rewritten at i only: what travels ahead is still the sketch record
+		yn = fetch_y(i + 2);
+		uint64_t x, cov, P, Q;
+		finish(cur, x, cov);
+		const uint64_t y = cur.y; const int off = cur.off;
 		const uint64_t lo = x & BS_EVEN, hi = (x >> 1) & BS_EVEN;
 		const uint64_t mis = cov & (((lo ^ rlo) | (hi ^ rhi)) | ~inref);
 		const uint32_t slot = i & 1u;
+		// one wave per workgroup: its LDS operations execute in order, so the sum needs no barrier (which would also wait for the
+		// loads travelling ahead) -- only the compiler has to keep the order
 		if (mis) atomicAdd(&S[slot][gs], (uint32_t)__popcll(mis));
-		__syncthreads();
-		const uint32_t dif = S[slot][gs];
-		if (u == 0) S[slot ^ 1u][gs] = 0;                               // everybody read it an iteration ago
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t dif = ((volatile uint32_t*)S[slot])[gs];
+		__builtin_amdgcn_wave_barrier();
+		if (u == 0) ((volatile uint32_t*)S[slot ^ 1u])[gs] = 0;           // everybody read it an iteration ago
 		const bool act = i < n;
 		const bool kp = (int)dif <= e;                                   // kthread_bucket.c:189
 		if (act && kp) { ++nk; if (off + L > rend) rend = off + L; }
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 			bs_sub(c, P, Q);
 		}
 		if (act && u == 0) { keep[m0 + i] = kp ? 1 : 0; members[m0 + i] = (y >> 32 << 32) | ((uint64_t)off << 1) | (y & 1); }   // :101
+		cur = nxt;
 	}
 	// ---- second consensus over [sv, rend): sv = first column inside the first consensus that a kept member covers
 	bs_best(c, rlo, rhi, nz);
