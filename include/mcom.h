@@ -74,6 +74,9 @@ int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
 /* Likewise for the merge consensus: a unit of 32 columns that more than `members` members reach sends its tile to the
  * wave-per-tile kernel (0 = default, the 127 the bit-sliced counters hold).  Same consensus either way.              */
 int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
+/* mcom_sketch_contigs has two kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) and one
+ * wave per string; wave_per_string != 0 forces the second.  Same sketch either way.                                    */
+int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
 
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:

@@ -202,6 +202,12 @@ extern "C" int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members)
 	ctx->bs_cap = members;
 	return MCOM_OK;
 }
+extern "C" int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string)
+{
+	if (!ctx) return MCOM_E_ARG;
+	ctx->sketch_wave_only = wave_per_string != 0;
+	return MCOM_OK;
+}
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
 {
 	if (!ctx) return MCOM_E_ARG;

@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) void k_sketch_gather(const uint32_t *__restric
 int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars_bound,
                         const uint32_t *d_ids, size_t n, int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
                         uint64_t *h_total);
+int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars,
+                             const uint32_t *d_ids, size_t n, int w, int k, uint32_t limit, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                             uint64_t *h_total);
 
 extern "C" int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint32_t *d_ids, size_t n,
                                    int w, int k, uint32_t max_per_contig, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
@@ -412,6 +415,11 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	if (!d_off_end) {
 		MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
 		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	// millions of short strings: one lane per string (sketch_scan.hip); wide windows and very long strings stay with the wave per string
+	if (!ctx->sketch_wave_only) {
+		const int rs = mcom_sketch_strings_scan(ctx, d_seq, d_off, d_off_end, chars, d_ids, n, w, k, limit, d_moff, d_out, cap, h_total);
+		if (rs != -1) return rs;
 	}
 	const uint64_t max_slots = chars / PIECE + 2 * (uint64_t)n + 1;
 	if (max_slots >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig pieces");

@@ -31,6 +31,8 @@ struct mcom_ctx {
 	bool cix_cap_set = false; uint32_t cix_cap = 0;
 	// merge consensus: members reaching one unit of 32 columns above which its tile goes to the wave-per-tile kernel (0 = the counters' 127)
 	uint32_t bs_cap = 0;
+	// contig sketch: true = always the wave-per-string kernel (tests compare the two)
+	bool sketch_wave_only = false;
 };
 
 // brackets one kernel launch (or a short launch sequence) with events when the profiler is on

@@ -1,0 +1,267 @@
+// minicom_amd/csrc/sketch_scan.hip -- mm_sketch_lh_ori (reference sketch.c:116-165) with ONE LANE PER STRING.
+//
+// The wave-per-contig kernel (contigs.hip) spreads the positions of one contig over the lanes and pays for it with ballots,
+// prefix sums, block minima and LDS rings shared by the wave: ~1100 wave instructions per 64 positions.  The strings sketched
+// in a merge round are millions of short ones (the 7.8 M first contigs of ~200 bases, then the segments around the overlaps of
+// merged contigs), so here every lane runs the reference's own sequential scan over its own string -- k-mer registers, run
+// counter, the ring of the last w entries (in LDS, slot-major: a lane always hits its own banks), the current minimum -- and
+// 64 strings advance one position per iteration: ~150 wave instructions per 64 positions.  The one loop of the reference that
+// would ruin this is the rescan of the ring when the minimum leaves the window: every ~w positions per lane, i.e. in most
+// iterations for SOME lane of the wave, and w entries long.  The scan's minimum is always the newest smallest entry of the ring
+// (sketch.c:145-153), and the ring is, at any moment, the lap being written (slots 0..slot, newest) plus what is left of the
+// lap before (slots slot+1..w-1): so the minimum is the better of the running minimum of this lap (registers) and the minimum
+// of the suffix slot+1..w-1 of the last lap -- a table of w suffix minima made once per lap, when the slot wraps, by all lanes
+// at once (van Herk / Gil-Werman).  A rescan becomes two LDS reads.
+// Strings are handed out longest first in bins of similar length, so the lanes of a wave finish together.
+//
+// Output without a second scan: every string gets room for ~1.5x the expected number of minimizers in a temporary array,
+// counts everything it would emit, the counts are scanned and the records gathered; a string that emitted more than its room
+// is scanned once more, straight into its final place.
+#include "mcom_dev.hpp"
+#include <algorithm>
+
+namespace {
+#define SSC_BINS 1024
+#define SSC_STRIDE 64
+
+__device__ __forceinline__ uint32_t ssc_len(const uint64_t *off, const uint64_t *off_end, size_t t)
+{
+	return (uint32_t)((off_end ? off_end[t] : off[t + 1]) - off[t]);
+}
+
+// room, length bin and the longest string
+__global__ __launch_bounds__(256) void k_ssc_prepare(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, uint32_t n, int w,
+                                                     uint32_t *__restrict__ room, uint32_t *__restrict__ bins, uint32_t *__restrict__ longest)
+{
+	__shared__ uint32_t h[SSC_BINS];
+	__shared__ uint32_t mx;
+	for (int q = threadIdx.x; q < SSC_BINS; q += 256) h[q] = 0;
+	if (threadIdx.x == 0) mx = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t < n) {
+		const uint32_t len = ssc_len(off, off_end, t);
+		room[t] = len ? 3u * len / (uint32_t)(w + 1) + 6u : 0u;
+		atomicAdd(&h[len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1], 1u);
+		atomicMax(&mx, len);
+	} else if (t == n) room[t] = 0;
+	__syncthreads();
+	for (int q = threadIdx.x; q < SSC_BINS; q += 256) if (h[q]) atomicAdd(&bins[q], h[q]);
+	if (threadIdx.x == 0 && mx > *longest) atomicMax(longest, mx);
+}
+// start[b]: the strings in longer bins
+__global__ void k_ssc_starts(const uint32_t *__restrict__ bins, uint32_t *__restrict__ start)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	uint32_t a = 0;
+	for (int q = SSC_BINS - 1; q >= 0; --q) { start[q] = a; a += bins[q]; }
+}
+// perm: the strings, longest bin first
+__global__ __launch_bounds__(256) void k_ssc_order(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, uint32_t n,
+                                                   const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ perm)
+{
+	__shared__ uint32_t h[SSC_BINS], base[SSC_BINS];
+	for (int q = threadIdx.x; q < SSC_BINS; q += 256) h[q] = 0;
+	__syncthreads();
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	uint32_t bin = 0, r = 0;
+	if (t < n) { const uint32_t len = ssc_len(off, off_end, t); bin = len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1; r = atomicAdd(&h[bin], 1u); }
+	__syncthreads();
+	for (int q = threadIdx.x; q < SSC_BINS; q += 256) base[q] = h[q] ? start[q] + atomicAdd(&cursor[q], h[q]) : 0u;
+	__syncthreads();
+	if (t < n) perm[base[bin] + r] = t;
+}
+
+// lane q of workgroup b scans string list[64 b + q] (list = NULL: the string of that index); at most room[t] records go to
+// dst[base[t] ...], all of them are counted in cnt[t] (capped at `limit`)
+__global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end,
+                                                    const uint32_t *__restrict__ ids, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    int w, int k, uint32_t limit, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
+                                                    int room_is_count, mcom_mm128 *__restrict__ dst, uint32_t *__restrict__ cnt)
+{
+	extern __shared__ __align__(8) unsigned char ssc_lds[];
+	uint64_t *RX = (uint64_t*)ssc_lds;                                     // [w][SSC_STRIDE]: hash of the entry, U64MAX when empty
+	uint16_t *RY = (uint16_t*)(RX + (size_t)w * SSC_STRIDE);               // [w][64]: pos<<1 | strand, 0xFFFF when empty
+	uint8_t *SM = (uint8_t*)(RY + (size_t)w * 64);                         // [w][64]: newest smallest slot of the last lap's slots j..w-1; bit 7: its hash occurs again there
+	const int lane = threadIdx.x;
+	const uint32_t li = blockIdx.x * 64u + (uint32_t)lane;
+	const bool have = li < nlist;
+	const uint32_t t = have ? (list ? list[li] : li) : 0u;
+	const uint32_t len = have ? ssc_len(off, off_end, t) : 0u;
+	const uint8_t *s = seq + (have ? off[t] : 0);
+	const uint64_t idhi = (uint64_t)(ids ? (have ? ids[t] : 0u) : (uint32_t)(t << 8)) << 32;
+	const uint32_t mybase = have ? base[t] : 0u;
+	const uint32_t myroom = have ? (room_is_count ? cnt[t] : room[t]) : 0u;
+	uint32_t maxlen = len;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxlen, d, 64); maxlen = o > maxlen ? o : maxlen; }
+	for (int j = 0; j < w; ++j) { RX[j * SSC_STRIDE + lane] = U64MAX; RY[j * 64 + lane] = 0xFFFFu; SM[j * 64 + lane] = (uint8_t)((w - 1) | 0x80); }
+	const uint64_t mask = (1ull << (2 * k)) - 1;
+	const int shift1 = 2 * (k - 1);
+	uint64_t fwd = 0, rev = 0;
+	int run = 0, slot = 0, best_slot = 0;
+	uint64_t best_x = U64MAX; uint32_t best_y = 0xFFFFFFFFu;
+	uint64_t lap_x = U64MAX; int lap_slot = 0; bool lap_dup = false;           // newest smallest entry of the lap being written
+	uint32_t ne = 0;
+	auto y32 = [](uint16_t v) -> uint32_t { return v == 0xFFFFu ? 0xFFFFFFFFu : (uint32_t)v; };
+	auto put = [&](uint64_t x, uint32_t y) {
+		if (ne < limit) {
+			if (ne < myroom) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && y == 0xFFFFFFFFu) ? U64MAX : (idhi | y); dst[(size_t)mybase + ne] = v; }
+			++ne;
+		}
+	};
+	// every other entry of the ring, oldest first, that has the minimum's hash but is not the minimum itself (sketch.c:140-143, :156-160)
+	auto put_equals = [&](bool with_current) {
+		for (int j = slot + 1; j < w; ++j) { const uint64_t x = RX[j * SSC_STRIDE + lane]; if (x == best_x) { const uint32_t y = y32(RY[j * 64 + lane]); if (y != best_y) put(x, y); } }
+		const int e = with_current ? slot + 1 : slot;
+		for (int j = 0; j < e; ++j) { const uint64_t x = RX[j * SSC_STRIDE + lane]; if (x == best_x) { const uint32_t y = y32(RY[j * 64 + lane]); if (y != best_y) put(x, y); } }
+	};
+	auto load8 = [&](uint32_t p) -> uint64_t {
+		uint64_t v = 0;
+		if (p + 8 <= len) __builtin_memcpy(&v, s + p, 8);
+		else for (uint32_t q = 0; p + q < len; ++q) v |= (uint64_t)s[p + q] << (8 * q);
+		return v;
+	};
+	uint64_t chunk = 0, ahead = load8(0);
+	for (uint32_t i = 0; i < maxlen; ++i) {
+		if ((i & 7u) == 0) { chunk = ahead; ahead = load8(i + 8); }          // the next eight characters travel while these are scanned
+		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
+		const uint32_t u = ch & 0xDFu;                                       // fold case
+		const bool acgt = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;                     // A0 C1 G2 T3
+		bool stored = false;
+		uint64_t cx = U64MAX; uint32_t cy = 0xFFFFFFFFu;
+		if (i < len) {
+			if (acgt) {
+				fwd = (fwd << 2 | c) & mask;
+				rev = (rev >> 2) | ((3ull ^ c) << shift1);
+				if (fwd != rev) {                                            // a k-mer equal to its reverse complement stores nothing (:133)
+					stored = true;
+					const uint32_t z = fwd < rev ? 0u : 1u;
+					if (++run >= k) { cx = mcom_hash64(z ? rev : fwd, mask); cy = (i << 1) | z; }
+				}
+			} else { run = 0; stored = true; }
+		}
+		if (stored) {
+			RX[slot * SSC_STRIDE + lane] = cx; RY[slot * 64 + lane] = (uint16_t)cy;
+			if (slot == 0 || cx < lap_x) { lap_x = cx; lap_slot = slot; lap_dup = false; }
+			else if (cx == lap_x) { lap_slot = slot; lap_dup = true; }
+		}
+		const bool firstwin = stored && run == w + k - 1;
+		if (__ballot(firstwin)) { if (firstwin) put_equals(false); }        // first full window: earlier copies of the minimum (:139-144)
+		bool again = false;
+		if (stored) {
+			if (cx <= best_x) {                                              // '<=': the rightmost of equal hashes wins
+				if (run >= w + k) put(best_x, best_y);
+				best_x = cx; best_y = cy; best_slot = slot;
+			} else if (slot == best_slot) {                                  // the minimum has just left the window
+				if (run >= w + k - 1) put(best_x, best_y);
+				// the reference scans slot+1..w-1, then 0..slot, with '>=': the last smallest entry in that order
+				best_x = lap_x; best_slot = lap_slot;
+				bool dup = lap_dup;
+				if (slot + 1 < w) {
+					const uint32_t sm = SM[(slot + 1) * 64 + lane];
+					const int sj = (int)(sm & 63u);
+					const uint64_t sx = RX[sj * SSC_STRIDE + lane];
+					if (sx < lap_x) { best_x = sx; best_slot = sj; dup = (sm & 0x80u) != 0; }
+					else if (sx == lap_x) dup = true;
+				}
+				best_y = y32(RY[best_slot * 64 + lane]);
+				again = dup && run >= w + k - 1;
+			}
+		}
+		if (__ballot(again)) { if (again) put_equals(true); }               // identical k-mers of the new minimum (:155-161)
+		bool wrapped = false;
+		if (stored) { if (++slot == w) { slot = 0; wrapped = true; } }
+		if (__ballot(wrapped)) {
+			if (wrapped) {                                                   // the lap is complete: its suffix minima, newest (highest slot) first among equals
+				uint64_t mx = RX[(w - 1) * SSC_STRIDE + lane]; uint32_t ms = (uint32_t)(w - 1);
+				SM[(w - 1) * 64 + lane] = (uint8_t)ms;
+				for (int j = w - 2; j >= 0; --j) {
+					const uint64_t x = RX[j * SSC_STRIDE + lane];
+					if (x < mx) { mx = x; ms = (uint32_t)j; } else if (x == mx) ms |= 0x80u;
+					SM[j * 64 + lane] = (uint8_t)ms;
+				}
+			}
+		}
+	}
+	if (best_x != U64MAX) put(best_x, best_y);                               // the minimum still held (:163-164)
+	if (have) cnt[t] = ne;
+}
+
+// the records of every string from its room to its place; strings that emitted more than their room are listed
+__global__ __launch_bounds__(256) void k_ssc_gather(const mcom_mm128 *__restrict__ tmp, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
+                                                    const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ moff, uint32_t n,
+                                                    mcom_mm128 *__restrict__ out, uint32_t *__restrict__ over_list, uint32_t *__restrict__ n_over)
+{
+	// four lanes per string
+	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t t = g >> 2, q = g & 3u;
+	if (t >= n) return;
+	const uint32_t c = cnt[t], r = room[t];
+	if (c > r) { if (q == 0) over_list[atomicAdd(n_over, 1u)] = t; return; }
+	const mcom_mm128 *src = tmp + base[t];
+	mcom_mm128 *dstp = out + moff[t];
+	for (uint32_t i = q; i < c; i += 4) dstp[i] = src[i];
+}
+}  // namespace
+
+// -1: not applicable (window above 64 entries or a string of 32768 characters or more: the caller uses the wave-per-string kernel)
+int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_off_end, uint64_t chars,
+                             const uint32_t *d_ids, size_t n, int w, int k, uint32_t limit, uint32_t *d_moff, mcom_mm128 *d_out, size_t cap,
+                             uint64_t *h_total)
+{
+	if (w > 64 || n >= (1ull << 31)) return -1;
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const uint32_t nn = (uint32_t)n;
+	const size_t n4 = al((n + 1) * 4);
+	const size_t scr_b = al(mcom_scan_scratch_elems(n + 1) * 4 + 1024);
+	const size_t head = 5 * n4 + scr_b + al((3 * SSC_BINS + 16) * 4);
+	const uint64_t tmp_bound = 3 * chars / (uint64_t)(w + 1) + 6 * (uint64_t)n + 64;  // the rooms of all strings
+	if (tmp_bound >= (1ull << 32)) return -1;
+	int rc = mcom_ws_reserve(ctx, head + al(tmp_bound * sizeof(mcom_mm128)));
+	if (rc) return rc;
+	char *b0 = (char*)ctx->ws;
+	uint32_t *room = (uint32_t*)b0, *base = (uint32_t*)(b0 + n4), *perm = (uint32_t*)(b0 + 2 * n4), *cnt = (uint32_t*)(b0 + 3 * n4), *over = (uint32_t*)(b0 + 4 * n4);
+	uint32_t *scr = (uint32_t*)(b0 + 5 * n4);
+	uint32_t *bins = (uint32_t*)(b0 + 5 * n4 + scr_b), *cursor = bins + SSC_BINS, *start = cursor + SSC_BINS, *misc = start + SSC_BINS;   // misc[0] longest, [1] overflowed strings
+	mcom_mm128 *tmp = (mcom_mm128*)(b0 + head);
+	MCOM_HIP(ctx, hipMemsetAsync(bins, 0, (3 * SSC_BINS + 16) * 4, ctx->stream));
+	hipLaunchKernelGGL(k_ssc_prepare, dim3((nn + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = mcom_scan_u32(ctx, room, base, n + 1, scr))) return rc;
+	hipLaunchKernelGGL(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
+	hipLaunchKernelGGL(k_ssc_order, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
+	uint32_t h2[2] = {0, 0};
+	MCOM_HIP(ctx, hipMemcpyAsync(&h2[0], misc, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipMemcpyAsync(&h2[1], base + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h2[0] >= 32768u) return -1;
+	if (h2[1] > tmp_bound) return mcom_fail(ctx, MCOM_E_HIP, "sketch rooms %u above their bound", h2[1]);
+	const size_t lds = (size_t)w * SSC_STRIDE * 8 + (size_t)w * 64 * 2 + (size_t)w * 64;
+	{
+		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
+		hipLaunchKernelGGL(k_sketch_scan, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
+	}
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
+	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;
+	uint32_t total = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (h_total) *h_total = total;
+	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
+	if (total == 0) return MCOM_OK;
+	hipLaunchKernelGGL(k_ssc_gather, dim3((unsigned)(((size_t)nn * 4 + 255) / 256)), dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1);
+	MCOM_LAUNCH_CHECK(ctx);
+	uint32_t n_over = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&n_over, misc + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (n_over) {                                                            // denser than their room: once more, into their final places
+		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
+		hipLaunchKernelGGL(k_sketch_scan, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
+		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return MCOM_OK;
+}

@@ -222,6 +222,11 @@ class Context:
         self.lib.mcom_set_index_capacity.restype = C.c_int; self.lib.mcom_set_index_capacity.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.mcom_set_index_capacity(self._h, entries))
 
+    def set_sketch_kernel(self, wave_per_string: bool):
+        """Test hook of mcom_sketch_contigs: force the wave-per-string kernel (the default picks the lane-per-string one where it applies)."""
+        self.lib.mcom_set_sketch_kernel.restype = C.c_int; self.lib.mcom_set_sketch_kernel.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_sketch_kernel(self._h, 1 if wave_per_string else 0))
+
     def set_consensus_capacity(self, members: int):
         """Test hook of the merge consensus: units that more than `members` members reach use the wave-per-tile kernel (0 = default 127)."""
         self.lib.mcom_set_consensus_capacity.restype = C.c_int; self.lib.mcom_set_consensus_capacity.argtypes = [C.c_void_p, C.c_uint32]

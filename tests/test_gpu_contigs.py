@@ -201,11 +201,17 @@ def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, n
     idx.close()
 
 
-@pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24)])
-def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k):
+@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24), (64, 31)])
+def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, wave):
     """Tie-rich strings (short-period repeats, homopolymers, copied blocks, ambiguous bases): equal hashes inside a
-    window exercise the duplicate rules of sketch.c:138-161 and the exact fallback of the prefix window scan."""
+    window exercise the duplicate rules of sketch.c:138-161 and the exact fallback of the prefix window scan.
+    Both kernels: one lane per string (windows up to 64; homopolymers overflow their room and are scanned again) and
+    one wave per string."""
     import oracle
+    if wave and w == 128:
+        pytest.skip("w = 128 takes the wave-per-string kernel anyway")
+    ctx.set_sketch_kernel(wave)
     from test_gpu_resketch import _string
     rng = np.random.default_rng(100 * w + k)
     refs = []
@@ -220,8 +226,11 @@ def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k):
             s[100:140] = s[40:80]
         refs.append(s.tobytes())
     cg = ctx.upload_contigs(refs)
-    moff, out = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k)
-    ctx.sync()
+    try:
+        moff, out = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k)
+        ctx.sync()
+    finally:
+        ctx.set_sketch_kernel(False)
     moff = moff.cpu().numpy(); r = _recs(out)
     total = 0
     for i, ref in enumerate(refs):
