@@ -156,31 +156,44 @@ __global__ __launch_bounds__(64) void k_flag_sort_bucket(const mcom_mm128 *__res
 			// not in place can be found by all lanes at once.  At the top levels nearly every element is in place (the hashes of a
 			// bucket are minima of many k-mer hashes: their top byte is almost always 0), and walking them one by one was half of
 			// this kernel's time.  The cycles themselves stay with one lane: they are the reference's order of equal keys.
-			for (int q = 0; q < 256; ++q) {
-				for (;;) {
-					const uint32_t b0 = bb[q], e0 = be[q];                       // uniform
-					if (b0 == e0) break;
-					uint32_t found = e0;
-					for (uint32_t p0 = b0; p0 < e0; p0 += 64) {
-						const uint32_t p = p0 + (uint32_t)lane;
-						const bool neq = p < e0 && (int)digit(E[p < e0 ? p : b0], s) != q;
-						const uint64_t m = __ballot(neq);
-						if (m) { found = p0 + (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
-					}
-					if (lane == 0) {
-						bb[q] = found;
-						if (found != e0) {
-							int l = (int)digit(E[found], s);
-							uint64_t hold = E[found], moved;
-							do {
-								moved = hold; hold = E[bb[l]]; E[bb[l]++] = moved;
-								l = (int)digit(hold, s);
-							} while (l != q);
-							E[bb[q]++] = hold;
+			// Only the bins that hold something are visited (a barrier round per empty bin was a quarter of a millisecond per level),
+			// and lane 0 keeps going on its own from cycle to cycle -- as the reference does -- until it has stepped over eight
+			// in-place elements in a row: only then is the wave asked to find the next element that is not in place.
+			for (int q0 = 0; q0 < 256; q0 += 64) {
+				uint64_t live = __ballot(bb[q0 + lane] != be[q0 + lane]);         // uniform
+				while (live) {
+					const int q = q0 + __ffsll((unsigned long long)live) - 1;
+					live &= live - 1;
+					for (;;) {
+						const uint32_t b0 = bb[q], e0 = be[q];                       // uniform
+						if (b0 == e0) break;
+						uint32_t found = e0;
+						for (uint32_t p0 = b0; p0 < e0; p0 += 64) {
+							const uint32_t p = p0 + (uint32_t)lane;
+							const bool neq = p < e0 && (int)digit(E[p < e0 ? p : b0], s) != q;
+							const uint64_t m = __ballot(neq);
+							if (m) { found = p0 + (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
 						}
+						if (lane == 0) {
+							uint32_t at = found, inplace = 0;
+							while (at != e0 && inplace < 8) {
+								int l = (int)digit(E[at], s);
+								if (l == q) { ++at; ++inplace; continue; }              // in place: ++bb[q] (ksort.h:143)
+								inplace = 0;
+								bb[q] = at;
+								uint64_t hold = E[at], moved;
+								do {
+									moved = hold; hold = E[bb[l]]; E[bb[l]++] = moved;
+									l = (int)digit(hold, s);
+								} while (l != q);
+								E[bb[q]++] = hold;
+								at = bb[q];
+							}
+							bb[q] = at;
+						}
+						__syncthreads();
+						if (found == e0) break;
 					}
-					__syncthreads();
-					if (found == e0) break;
 				}
 			}
 			__syncthreads();
