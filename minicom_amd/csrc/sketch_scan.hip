@@ -20,6 +20,7 @@
 #include "mcom_dev.hpp"
 #include <algorithm>
 
+
 namespace {
 #define SSC_BINS 1024
 #define SSC_STRIDE 64
@@ -74,6 +75,11 @@ __global__ __launch_bounds__(256) void k_ssc_order(const uint64_t *__restrict__ 
 
 // lane q of workgroup b scans string list[64 b + q] (list = NULL: the string of that index); at most room[t] records go to
 // dst[base[t] ...], all of them are counted in cnt[t] (capped at `limit`)
+// ODDK: k is odd, so no k-mer equals its reverse complement and every position of the string stores exactly one entry: the
+// position of a ring entry follows from its slot, its strand bit rides in bit 62 of the hash word (hashes have 2k <= 62 bits),
+// and the ring of positions (a sixth of the LDS, i.e. one more wave per CU) is not needed.
+#define SSC_ZBIT (1ull << 62)
+template <bool ODDK>
 __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end,
                                                     const uint32_t *__restrict__ ids, const uint32_t *__restrict__ list, uint32_t nlist,
                                                     int w, int k, uint32_t limit, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
@@ -81,8 +87,8 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 {
 	extern __shared__ __align__(8) unsigned char ssc_lds[];
 	uint64_t *RX = (uint64_t*)ssc_lds;                                     // [w][SSC_STRIDE]: hash of the entry, U64MAX when empty
-	uint16_t *RY = (uint16_t*)(RX + (size_t)w * SSC_STRIDE);               // [w][64]: pos<<1 | strand, 0xFFFF when empty
-	uint8_t *SM = (uint8_t*)(RY + (size_t)w * 64);                         // [w][64]: newest smallest slot of the last lap's slots j..w-1; bit 7: its hash occurs again there
+	uint16_t *RY = (uint16_t*)(RX + (size_t)w * SSC_STRIDE);               // [w][64]: pos<<1 | strand, 0xFFFF when empty (not ODDK)
+	uint8_t *SM = ODDK ? (uint8_t*)RY : (uint8_t*)(RY + (size_t)w * 64);                         // [w][64]: newest smallest slot of the last lap's slots j..w-1; bit 7: its hash occurs again there
 	const int lane = threadIdx.x;
 	const uint32_t li = blockIdx.x * 64u + (uint32_t)lane;
 	const bool have = li < nlist;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	uint32_t maxlen = len;
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxlen, d, 64); maxlen = o > maxlen ? o : maxlen; }
-	for (int j = 0; j < w; ++j) { RX[j * SSC_STRIDE + lane] = U64MAX; RY[j * 64 + lane] = 0xFFFFu; SM[j * 64 + lane] = (uint8_t)((w - 1) | 0x80); }
+	for (int j = 0; j < w; ++j) { RX[j * SSC_STRIDE + lane] = U64MAX; if (!ODDK) RY[j * 64 + lane] = 0xFFFFu; SM[j * 64 + lane] = (uint8_t)((w - 1) | 0x80); }
 	const uint64_t mask = (1ull << (2 * k)) - 1;
 	const int shift1 = 2 * (k - 1);
 	uint64_t fwd = 0, rev = 0;
@@ -104,81 +110,109 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	uint64_t lap_x = U64MAX; int lap_slot = 0; bool lap_dup = false;           // newest smallest entry of the lap being written
 	uint32_t ne = 0;
 	auto y32 = [](uint16_t v) -> uint32_t { return v == 0xFFFFu ? 0xFFFFFFFFu : (uint32_t)v; };
+	uint32_t step = 0;                                                         // the current position (for ring_y)
+	auto ring_x = [&](int j) -> uint64_t { const uint64_t v = RX[j * SSC_STRIDE + lane]; return ODDK ? (v == U64MAX ? v : v & ~SSC_ZBIT) : v; };
+	// pos<<1 | strand of the entry in slot j (0xFFFFFFFF when empty); xw: the ring word of that slot
+	auto ring_y = [&](int j, uint64_t xw) -> uint32_t {
+		if (!ODDK) return y32(RY[j * 64 + lane]);
+		if (xw == U64MAX) return 0xFFFFFFFFu;
+		const int age = slot - j < 0 ? slot - j + w : slot - j;               // stored that many positions ago
+		return ((step - (uint32_t)age) << 1) | (uint32_t)((xw >> 62) & 1u);
+	};
 	auto put = [&](uint64_t x, uint32_t y) {
 		if (ne < limit) {
 			if (ne < myroom) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && y == 0xFFFFFFFFu) ? U64MAX : (idhi | y); dst[(size_t)mybase + ne] = v; }
 			++ne;
 		}
 	};
+	auto put_if = [&](bool cond, uint64_t x, uint32_t y) {
+		const bool counted = cond && ne < limit;
+		if (counted && ne < myroom) { mcom_mm128 v; v.x = x; v.y = (x == U64MAX && y == 0xFFFFFFFFu) ? U64MAX : (idhi | y); dst[(size_t)mybase + ne] = v; }
+		ne += counted ? 1u : 0u;
+	};
 	// every other entry of the ring, oldest first, that has the minimum's hash but is not the minimum itself (sketch.c:140-143, :156-160)
 	auto put_equals = [&](bool with_current) {
-		for (int j = slot + 1; j < w; ++j) { const uint64_t x = RX[j * SSC_STRIDE + lane]; if (x == best_x) { const uint32_t y = y32(RY[j * 64 + lane]); if (y != best_y) put(x, y); } }
+		for (int j = slot + 1; j < w; ++j) { const uint64_t xw = RX[j * SSC_STRIDE + lane], x = ODDK && xw != U64MAX ? xw & ~SSC_ZBIT : xw; if (x == best_x) { const uint32_t y = ring_y(j, xw); if (y != best_y) put(x, y); } }
 		const int e = with_current ? slot + 1 : slot;
-		for (int j = 0; j < e; ++j) { const uint64_t x = RX[j * SSC_STRIDE + lane]; if (x == best_x) { const uint32_t y = y32(RY[j * 64 + lane]); if (y != best_y) put(x, y); } }
+		for (int j = 0; j < e; ++j) { const uint64_t xw = RX[j * SSC_STRIDE + lane], x = ODDK && xw != U64MAX ? xw & ~SSC_ZBIT : xw; if (x == best_x) { const uint32_t y = ring_y(j, xw); if (y != best_y) put(x, y); } }
 	};
-	auto load8 = [&](uint32_t p) -> uint64_t {
-		uint64_t v = 0;
-		if (p + 8 <= len) __builtin_memcpy(&v, s + p, 8);
-		else for (uint32_t q = 0; p + q < len; ++q) v |= (uint64_t)s[p + q] << (8 * q);
+	// Eight characters from position p on: one unaligned 8-byte load whatever p is -- a string of at least eight characters is
+	// read at min(p, len - 8) and shifted when the characters are taken, a shorter one (all of it in the first chunk, read byte by
+	// byte up front) reads a harmless word -- so that no branch joins behind the load and it stays in flight until its characters
+	// are needed, eight iterations later.
+	const bool tiny = len < 8;
+	auto issue8 = [&](uint32_t p, uint32_t &sh) -> uint64_t {
+		const uint32_t a = tiny ? 0u : (p + 8 <= len ? p : len - 8);
+		const uint8_t *src = tiny ? (const uint8_t*)off : s + a;
+		uint64_t v; __builtin_memcpy(&v, src, 8);
+		sh = tiny ? 64u : 8 * (p - a);
 		return v;
 	};
-	uint64_t chunk = 0, ahead = load8(0);
+	uint64_t chunk = 0;
+	uint32_t ahead_sh = 0;
+	uint64_t ahead = issue8(0, ahead_sh);
+	uint64_t first8 = 0;
+	if (tiny) for (uint32_t q = 0; q < len; ++q) first8 |= (uint64_t)s[q] << (8 * q);
 	for (uint32_t i = 0; i < maxlen; ++i) {
-		if ((i & 7u) == 0) { chunk = ahead; ahead = load8(i + 8); }          // the next eight characters travel while these are scanned
-		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
-		const uint32_t u = ch & 0xDFu;                                       // fold case
-		const bool acgt = u == 'A' || u == 'C' || u == 'G' || u == 'T';
-		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;                     // A0 C1 G2 T3
-		bool stored = false;
-		uint64_t cx = U64MAX; uint32_t cy = 0xFFFFFFFFu;
-		if (i < len) {
-			if (acgt) {
-				fwd = (fwd << 2 | c) & mask;
-				rev = (rev >> 2) | ((3ull ^ c) << shift1);
-				if (fwd != rev) {                                            // a k-mer equal to its reverse complement stores nothing (:133)
-					stored = true;
-					const uint32_t z = fwd < rev ? 0u : 1u;
-					if (++run >= k) { cx = mcom_hash64(z ? rev : fwd, mask); cy = (i << 1) | z; }
-				}
-			} else { run = 0; stored = true; }
+		if ((i & 7u) == 0) {                                                 // the next eight characters travel while these are scanned
+			chunk = ahead_sh < 64 ? ahead >> ahead_sh : (i == 0 ? first8 : 0ull);
+			ahead = issue8(i + 8, ahead_sh);
 		}
-		if (stored) {
-			RX[slot * SSC_STRIDE + lane] = cx; RY[slot * 64 + lane] = (uint16_t)cy;
-			if (slot == 0 || cx < lap_x) { lap_x = cx; lap_slot = slot; lap_dup = false; }
-			else if (cx == lap_x) { lap_slot = slot; lap_dup = true; }
+		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
+		step = i;
+		const uint32_t u = ch & 0xDFu;                                       // fold case
+		const bool in = i < len;
+		const bool base = in && (u == 'A' || u == 'C' || u == 'G' || u == 'T');
+		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;                     // A0 C1 G2 T3
+		// Straight-line code with selects: a wave that is alone on its SIMD (the rings fill the LDS) pays for every taken branch with
+		// an instruction-fetch bubble, and this loop body used to hold nineteen of them.
+		const uint64_t nf = (fwd << 2 | c) & mask, nr = (rev >> 2) | ((3ull ^ c) << shift1);
+		fwd = base ? nf : fwd; rev = base ? nr : rev;
+		const bool pal = base && fwd == rev;                                 // a k-mer equal to its reverse complement stores nothing (:133)
+		const bool stored = in && !pal;                                      // an ambiguous base stores an empty entry and resets the run
+		const uint32_t z = fwd < rev ? 0u : 1u;
+		run = base ? (pal ? run : run + 1) : (in ? 0 : run);
+		const bool real = base && !pal && run >= k;
+		const uint64_t hx = mcom_hash64(z ? rev : fwd, mask);
+		const uint64_t cx = real ? hx : U64MAX;
+		const uint32_t cy = real ? ((i << 1) | z) : 0xFFFFFFFFu;
+		if (stored) { RX[slot * SSC_STRIDE + lane] = (ODDK && real) ? (cx | (z ? SSC_ZBIT : 0ull)) : cx; if (!ODDK) RY[slot * 64 + lane] = (uint16_t)cy; }
+		{
+			const bool lt = stored && (slot == 0 || cx < lap_x), eq = stored && !lt && cx == lap_x;
+			lap_x = lt ? cx : lap_x; lap_slot = (lt || eq) ? slot : lap_slot; lap_dup = lt ? false : (eq ? true : lap_dup);
 		}
 		const bool firstwin = stored && run == w + k - 1;
-		if (__ballot(firstwin)) { if (firstwin) put_equals(false); }        // first full window: earlier copies of the minimum (:139-144)
-		bool again = false;
-		if (stored) {
-			if (cx <= best_x) {                                              // '<=': the rightmost of equal hashes wins
-				if (run >= w + k) put(best_x, best_y);
-				best_x = cx; best_y = cy; best_slot = slot;
-			} else if (slot == best_slot) {                                  // the minimum has just left the window
-				if (run >= w + k - 1) put(best_x, best_y);
-				// the reference scans slot+1..w-1, then 0..slot, with '>=': the last smallest entry in that order
-				best_x = lap_x; best_slot = lap_slot;
-				bool dup = lap_dup;
-				if (slot + 1 < w) {
-					const uint32_t sm = SM[(slot + 1) * 64 + lane];
-					const int sj = (int)(sm & 63u);
-					const uint64_t sx = RX[sj * SSC_STRIDE + lane];
-					if (sx < lap_x) { best_x = sx; best_slot = sj; dup = (sm & 0x80u) != 0; }
-					else if (sx == lap_x) dup = true;
-				}
-				best_y = y32(RY[best_slot * 64 + lane]);
-				again = dup && run >= w + k - 1;
+		if (__builtin_expect(__ballot(firstwin) != 0, 0)) { if (firstwin) put_equals(false); }   // first full window: earlier copies of the minimum (:139-144)
+		const bool newmin = stored && cx <= best_x;                          // '<=': the rightmost of equal hashes wins
+		const bool left = stored && !newmin && slot == best_slot;            // the minimum has just left the window
+		put_if((newmin && run >= w + k) || (left && run >= w + k - 1), best_x, best_y);
+		// the reference scans slot+1..w-1, then 0..slot, with '>=': the last smallest entry in that order = the better of the lap's
+		// minimum and the minimum of what is left of the lap before
+		uint64_t nx = lap_x; int ns = lap_slot; bool dup = lap_dup; uint32_t ny = 0xFFFFFFFFu;
+		if (left) {
+			if (slot + 1 < w) {
+				const uint32_t sm = SM[(slot + 1) * 64 + lane];
+				const int sj = (int)(sm & 63u);
+				const uint64_t sx = ring_x(sj);
+				const bool older = sx < lap_x;
+				dup = older ? (sm & 0x80u) != 0 : (dup || sx == lap_x);
+				nx = older ? sx : nx; ns = older ? sj : ns;
 			}
+			ny = ring_y(ns, RX[ns * SSC_STRIDE + lane]);
 		}
-		if (__ballot(again)) { if (again) put_equals(true); }               // identical k-mers of the new minimum (:155-161)
-		bool wrapped = false;
-		if (stored) { if (++slot == w) { slot = 0; wrapped = true; } }
-		if (__ballot(wrapped)) {
+		best_x = newmin ? cx : (left ? nx : best_x);
+		best_y = newmin ? cy : (left ? ny : best_y);
+		best_slot = newmin ? slot : (left ? ns : best_slot);
+		const bool again = left && dup && run >= w + k - 1;
+		if (__builtin_expect(__ballot(again) != 0, 0)) { if (again) put_equals(true); }           // identical k-mers of the new minimum (:155-161)
+		const bool wrapped = stored && slot + 1 == w;
+		slot = stored ? (wrapped ? 0 : slot + 1) : slot;
+		if (__builtin_expect(__ballot(wrapped) != 0, 0)) {
 			if (wrapped) {                                                   // the lap is complete: its suffix minima, newest (highest slot) first among equals
-				uint64_t mx = RX[(w - 1) * SSC_STRIDE + lane]; uint32_t ms = (uint32_t)(w - 1);
+				uint64_t mx = ring_x(w - 1); uint32_t ms = (uint32_t)(w - 1);
 				SM[(w - 1) * 64 + lane] = (uint8_t)ms;
 				for (int j = w - 2; j >= 0; --j) {
-					const uint64_t x = RX[j * SSC_STRIDE + lane];
+					const uint64_t x = ring_x(j);
 					if (x < mx) { mx = x; ms = (uint32_t)j; } else if (x == mx) ms |= 0x80u;
 					SM[j * 64 + lane] = (uint8_t)ms;
 				}
@@ -238,10 +272,12 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (h2[0] >= 32768u) return -1;
 	if (h2[1] > tmp_bound) return mcom_fail(ctx, MCOM_E_HIP, "sketch rooms %u above their bound", h2[1]);
-	const size_t lds = (size_t)w * SSC_STRIDE * 8 + (size_t)w * 64 * 2 + (size_t)w * 64;
+	const bool oddk = (k & 1) != 0;
+	const size_t lds = (size_t)w * SSC_STRIDE * 8 + (oddk ? 0 : (size_t)w * 64 * 2) + (size_t)w * 64;
 	{
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-		hipLaunchKernelGGL(k_sketch_scan, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
+		if (oddk) hipLaunchKernelGGL(k_sketch_scan<true>, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
+		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
@@ -259,7 +295,8 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (n_over) {                                                            // denser than their room: once more, into their final places
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-		hipLaunchKernelGGL(k_sketch_scan, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
+		if (oddk) hipLaunchKernelGGL(k_sketch_scan<true>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
+		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
