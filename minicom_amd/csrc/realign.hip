@@ -709,24 +709,29 @@ extern "C" int mcom_claims_patch(mcom_ctx *ctx, uint64_t *d_claim, const uint32_
 // The scan visits (contig, window, dir, dict) ascending and walks a bin from its end, so the members a pass appends
 // are ordered by claim key ascending, singleton index descending (:388, :408-409, :474-475).  One stable radix sort
 // of {key, index} fed in descending index order gives exactly that.
-__global__ void k_claim_records(const unsigned long long *__restrict__ claim, size_t n, unsigned long long sentinel, mcom_mm128 *__restrict__ rec)
+// Only the singletons that claimed something take part (a tenth of them): flags and a scan compact them, still in descending index
+// order, before the sort.
+__global__ void k_claim_flags(const unsigned long long *__restrict__ claim, size_t n, uint32_t *__restrict__ f)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j <= n) f[j] = (j < n && claim[n - 1 - j] != U64MAX) ? 1u : 0u;
+}
+__global__ void k_claim_records(const unsigned long long *__restrict__ claim, size_t n, const uint32_t *__restrict__ at, mcom_mm128 *__restrict__ rec)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n) return;
 	const size_t i = n - 1 - j;
 	const unsigned long long ck = claim[i];
-	mcom_mm128 r; r.x = ck == U64MAX ? sentinel : ck; r.y = i;
-	rec[j] = r;
+	if (ck == U64MAX) return;
+	mcom_mm128 r; r.x = ck; r.y = i;
+	rec[at[j]] = r;
 }
-__global__ void k_claim_emit(const mcom_mm128 *__restrict__ rec, size_t n, unsigned long long sentinel, const uint32_t *__restrict__ rids,
-                             uint8_t *__restrict__ flag, uint32_t *__restrict__ app_contig, uint64_t *__restrict__ app_member,
-                             unsigned long long *__restrict__ nwon)
+__global__ void k_claim_emit(const mcom_mm128 *__restrict__ rec, size_t n, const uint32_t *__restrict__ rids,
+                             uint8_t *__restrict__ flag, uint32_t *__restrict__ app_contig, uint64_t *__restrict__ app_member)
 {
 	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n) return;
 	const mcom_mm128 r = rec[j];
-	if (r.x == sentinel) return;
-	if (j + 1 == n || rec[j + 1].x == sentinel) *nwon = j + 1;
 	const uint64_t jj = (r.x >> 5) & ((1ull << 28) - 1), dir = (r.x >> 4) & 1;
 	app_contig[j] = (uint32_t)(r.x >> 33);
 	app_member[j] = ((uint64_t)rids[r.y] << 32) | (jj << 1) | dir;
@@ -740,25 +745,36 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	*h_nwon = 0;
 	if (n_sg == 0) return MCOM_OK;
 	if (!d_claim || !d_rids || !d_flag || !d_app_contig || !d_app_member) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_sg >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons");
 	int cb = 1; while ((1ull << cb) < (uint64_t)n_contigs + 1 && cb < 31) ++cb;
 	const int kb = 33 + cb;                                                  // claim keys are < 2^kb
-	const unsigned long long sentinel = 1ull << kb;
-	const size_t rec_b = ((n_sg * sizeof(mcom_mm128)) + 255) & ~(size_t)255;
-	int rc = mcom_ws_reserve(ctx, rec_b + mcom_sort_ws_bytes(n_sg) + 256);
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const size_t f_b = al((n_sg + 1) * 4), scr_b = al(mcom_scan_scratch_elems(n_sg + 1) * 4 + 1024);
+	int rc = mcom_ws_reserve(ctx, f_b + scr_b);
 	if (rc) return rc;
-	mcom_mm128 *rec = (mcom_mm128*)ctx->ws;
-	void *sortws = (char*)ctx->ws + rec_b;
-	unsigned long long *d_n = (unsigned long long*)((char*)ctx->ws + rec_b + mcom_sort_ws_bytes(n_sg));
-	const unsigned blocks = (unsigned)((n_sg + 255) / 256);
-	MCOM_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
-	hipLaunchKernelGGL(k_claim_records, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, sentinel, rec);
-	if ((rc = mcom_sort_by_x(ctx, rec, n_sg, kb + 1, sortws))) return rc;
-	hipLaunchKernelGGL(k_claim_emit, dim3(blocks), dim3(256), 0, ctx->stream, rec, n_sg, sentinel, d_rids, d_flag, d_app_contig, d_app_member, d_n);
+	uint32_t *f = (uint32_t*)ctx->ws, *scr = (uint32_t*)((char*)ctx->ws + f_b);
+	const unsigned blocks = (unsigned)((n_sg + 1 + 255) / 256);
+	hipLaunchKernelGGL(k_claim_flags, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f);
 	MCOM_LAUNCH_CHECK(ctx);
-	unsigned long long hn = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&hn, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+	if ((rc = mcom_scan_u32(ctx, f, f, n_sg + 1, scr))) return rc;
+	uint32_t nw = 0;
+	MCOM_HIP(ctx, hipMemcpyAsync(&nw, f + n_sg, 4, hipMemcpyDeviceToHost, ctx->stream));
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	*h_nwon = hn;
+	*h_nwon = nw;
+	if (nw == 0) return MCOM_OK;
+	// the records and the sort workspace live in their own block: the flags above stay where they are
+	const size_t rec_b = al((size_t)nw * sizeof(mcom_mm128));
+	char *blk = nullptr;
+	if (mcom_dmalloc(&blk, rec_b + mcom_sort_ws_bytes(nw)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "claim records");
+	mcom_mm128 *rec = (mcom_mm128*)blk;
+	hipLaunchKernelGGL(k_claim_records, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f, rec);
+	rc = mcom_sort_by_x(ctx, rec, nw, kb, blk + rec_b);
+	if (!rc) hipLaunchKernelGGL(k_claim_emit, dim3((nw + 255) / 256), dim3(256), 0, ctx->stream, rec, (size_t)nw, d_rids, d_flag, d_app_contig, d_app_member);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	mcom_dfree(blk);
+	if (rc) return rc;
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "claim resolution: %s", hipGetErrorString(e));
 	return MCOM_OK;
 }
 
