@@ -97,7 +97,7 @@ def cindex_bytes(st, model):
 # HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false>"], "classify_pack": ["k_classify_pack16"],
+PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan<true>", "k_sketch_scan<false>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false>"], "classify_pack": ["k_classify_pack16"],
                "sketch_reads": ["k_sketch_reads<5, true>"],
                "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
@@ -174,7 +174,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    STATS = ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "t_reads", "t_bucket", "t_combine",
+    STATS = ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "sketch_strings", "t_reads", "t_bucket", "t_combine",
              "t_realign", "t_gpu", "ra_lookups", "ra_verified", "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "t_x_reads",
              "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_pairs")
 
@@ -306,8 +306,15 @@ def main():
                 sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers (48 VALU instructions per base, PMC); the HBM fraction cannot be high"
                 roof["sketch_kernel"] = sk
             sc = hbm_line("sketch_contigs")
-            if sc and roof["kernel"] != "sketch_contigs":
-                roof["sketch_contigs"] = sc
+            if sc:
+                # one lane per string: 64 strings per wave; the kernel is neither byte- nor issue-bound (5-6 waves per CU: latency),
+                # both fractions are given so that this can be seen
+                sc["issue_roofline"] = issue_line("sketch_contigs", st.get("sketch_strings", 0.0) / 64)
+                sc["note"] = "one lane per string, LDS rings allow 5-6 waves per CU: bound by latency (PMC: SQ_WAIT_ANY 55 % of wave cycles), neither by bytes nor by issue"
+                if roof["kernel"] != "sketch_contigs":
+                    roof["sketch_contigs"] = sc
+                else:
+                    roof["issue_roofline"] = sc["issue_roofline"]
             # the heaviest kernel that IS bound by HBM, both byte models
             if roof["kernel"] != "cindex_build":
                 hb = hbm_line("cindex_build")

@@ -63,7 +63,8 @@ int mcom_prof_reset(mcom_ctx *ctx);
 int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
 
 /* Diagnostics.  mcom_counter: "sort_overflow_segments" = segments of mcom_sort_group that did not fit its in-LDS sort and
- * went through the nine-pass sort instead (a minimizer shared by thousands of reads).  mcom_set_segment_capacity lowers
+ * went through the nine-pass sort instead (a minimizer shared by thousands of reads); "sketch_strings" = strings sketched by the
+ * lane-per-string kernel of mcom_sketch_contigs so far (64 per wave).  mcom_set_segment_capacity lowers
  * the size above which a segment takes that route (0 = default, at most 4096): lets a small test input exercise it;
  * results never depend on it.                                                                                        */
 uint64_t mcom_counter(const mcom_ctx *ctx, const char *name);

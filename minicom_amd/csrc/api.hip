@@ -188,6 +188,7 @@ extern "C" uint64_t mcom_counter(const mcom_ctx *ctx, const char *name)
 {
 	if (!ctx || !name) return 0;
 	if (!strcmp(name, "sort_overflow_segments")) return ctx->sort_overflow_segments;
+	if (!strcmp(name, "sketch_strings")) return ctx->sketch_strings;
 	return 0;
 }
 extern "C" int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records)

@@ -27,6 +27,8 @@ struct mcom_ctx {
 	// bucket sort: capacity of an in-LDS segment (0 = the kernel's own 4096; tests lower it to reach the fallback on small
 	// inputs) and how many segments went through the fallback so far
 	uint32_t seg_cap = 0; uint64_t sort_overflow_segments = 0;
+	// strings sketched by the lane-per-string kernel so far (64 per wave: bench.py's issue roofline)
+	uint64_t sketch_strings = 0;
 	// contig index: entries of a partition above which the scattered placement is used (tests lower it; 0 entries = always)
 	bool cix_cap_set = false; uint32_t cix_cap = 0;
 	// merge consensus: members reaching one unit of 32 columns above which its tile goes to the wave-per-tile kernel (0 = the counters' 127)

@@ -280,6 +280,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
+	ctx->sketch_strings += n;
 	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
 	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;
 	uint32_t total = 0;

@@ -1673,6 +1673,7 @@ extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 	if (!strcmp(name, "maxthr")) return p->maxthr;
 	if (!strcmp(name, "rw")) return p->rw;
 	if (!strcmp(name, "maxsearch")) return p->maxsearch;
+	if (!strcmp(name, "sketch_strings")) return (double)mcom_counter(p->ctx, "sketch_strings");
 	auto it = p->stat.find(name);
 	return it == p->stat.end() ? 0.0 : it->second;
 }

@@ -9,7 +9,7 @@ for path in sys.argv[1:]:
     seen = set()
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"]); calls[k] += 1

@@ -30,7 +30,7 @@ def pmc(fetch_csv, write_csv, out):
             for r in csv.DictReader(f):
                 if r["Counter_Name"] != counter:
                     continue
-                k = r["Kernel_Name"].split("(")[0]
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
                 if k.startswith("void "):
                     k = k[5:]
                 res[k][key] += float(r["Counter_Value"]) * 1024.0
