@@ -469,17 +469,19 @@ __global__ __launch_bounds__(256) void k_keep_copy(const uint32_t *__restrict__ 
                                                    uint8_t *__restrict__ seq2, const uint64_t *__restrict__ soff2, uint64_t *__restrict__ mem2,
                                                    const uint64_t *__restrict__ moff2)
 {
-	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	// sixteen lanes per contig, four contigs per wave: the kernel waits for its dependent loads (index, offsets, then the data:
+	// PMC 93 % dependency wait), and a contig is a few hundred bytes -- four of them in flight per wave instead of one
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
 	if (u >= nkeep) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	const uint32_t i = keepidx[u];
 	const uint64_t s0 = soff[i], sl = soff[i + 1] - s0, d0 = soff2[nj + u];
+	const uint64_t m0 = moff[i], ml = moff[i + 1] - m0, e0 = moff2[nj + u];
 	// eight characters per lane and step (unaligned 8-byte accesses are fine on this hardware), the last few one by one
 	const uint64_t n8 = sl >> 3;
-	for (uint64_t t = lane; t < n8; t += 64) { uint64_t v; __builtin_memcpy(&v, seq + s0 + 8 * t, 8); __builtin_memcpy(seq2 + d0 + 8 * t, &v, 8); }
-	for (uint64_t t = (n8 << 3) + lane; t < sl; t += 64) seq2[d0 + t] = seq[s0 + t];
-	const uint64_t m0 = moff[i], ml = moff[i + 1] - m0, e0 = moff2[nj + u];
-	for (uint64_t t = lane; t < ml; t += 64) mem2[e0 + t] = mem[m0 + t];
+	for (uint64_t t = lane; t < n8; t += 16) { uint64_t v; __builtin_memcpy(&v, seq + s0 + 8 * t, 8); __builtin_memcpy(seq2 + d0 + 8 * t, &v, 8); }
+	for (uint64_t t = (n8 << 3) + lane; t < sl; t += 16) seq2[d0 + t] = seq[s0 + t];
+	for (uint64_t t = lane; t < ml; t += 16) mem2[e0 + t] = mem[m0 + t];
 }
 
 extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_soff, const uint64_t *d_mem, const uint64_t *d_moff, size_t n,
@@ -512,7 +514,7 @@ extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uin
 		MCOM_LAUNCH_CHECK(ctx);
 		if ((rc = scan64(ctx, ss, ss, nkeep + 1, scr64)) || (rc = scan64(ctx, ms, ms, nkeep + 1, scr64))) return rc;
 		hipLaunchKernelGGL(k_keep_offsets, dim3(kb), dim3(256), 0, ctx->stream, ss, ms, nkeep, nj, d_soff2, d_moff2);
-		hipLaunchKernelGGL(k_keep_copy, dim3((unsigned)((nkeep * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, nj, d_seq, d_soff, d_mem, d_moff,
+		hipLaunchKernelGGL(k_keep_copy, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, nj, d_seq, d_soff, d_mem, d_moff,
 		                   d_seq2, d_soff2, d_mem2, d_moff2);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
@@ -535,15 +537,15 @@ __global__ __launch_bounds__(256) void k_carry_copy(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ roff, const uint32_t *__restrict__ sc, uint32_t first_id, uint32_t base,
                                                     mcom_mm128 *__restrict__ rec2, uint32_t *__restrict__ roff2)
 {
-	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // sixteen lanes per contig (see k_keep_copy)
 	if (u > nkeep) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	if (lane == 0) roff2[first_id + u] = base + sc[u];
 	if (u == nkeep) return;
 	const uint32_t i = keepidx[u];
 	const uint32_t r0 = roff[i], cnt = roff[i + 1] - r0, d0 = base + sc[u];
 	const uint64_t id = (uint64_t)((first_id + (uint32_t)u) << 8) << 32;     // (index<<8)+tid at tid 0, kthread_bucket.c:458
-	for (uint32_t t = lane; t < cnt; t += 64) { mcom_mm128 r = rec[r0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); rec2[d0 + t] = r; }
+	for (uint32_t t = lane; t < cnt; t += 16) { mcom_mm128 r = rec[r0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); rec2[d0 + t] = r; }
 }
 
 extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_keepidx, size_t nkeep,
@@ -568,7 +570,7 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*h_total = (uint64_t)base + kept;
 	if ((uint64_t)base + kept > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", (unsigned long long)base + kept, cap2);
-	hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,
+	hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,
 	                   d_rec2, d_roff2);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
