@@ -77,24 +77,6 @@ __device__ __forceinline__ uint64_t bs_span(int a, int b)
 	return BS_EVEN & mb & ~ma;
 }
 
-// The two words wj, wj + 1 of a packed row (zero outside the row) with ONE 16-byte load when the row has two words or more: the
-// kernels below are bound by the address path (64 separate addresses per load instruction: PMC, 53 % of the merge kernel's wave
-// cycles waiting to issue), so halving the load instructions is what counts.  -1 <= wj <= W - 1.
-__device__ __forceinline__ void bs_row_pair(const uint64_t *row, int W, int wj, bool want, uint64_t &wa, uint64_t &wb)
-{
-	wa = 0; wb = 0;
-	if (W >= 2) {
-		const int b = wj < 0 ? 0 : (wj > W - 2 ? W - 2 : wj);
-		ulonglong2 v = make_ulonglong2(0, 0);
-		if (want) __builtin_memcpy(&v, row + b, 16);
-		wa = wj == b ? v.x : (wj == b + 1 ? v.y : 0ull);
-		wb = wj == b ? v.y : (wj + 1 == b ? v.x : 0ull);
-	} else if (want) {
-		if (wj == 0) wa = row[0];
-		if (wj == -1) wb = row[0];
-	}
-}
-
 // ---- the groups in order of their size: bins[n] = groups of n members (n = 32: 32 or more) ------------------------------------
 __global__ __launch_bounds__(256) void k_bs_sizes(const uint32_t *__restrict__ goff, uint32_t ng, uint32_t *__restrict__ bins)
 {
@@ -173,7 +155,8 @@ __global__ __launch_bounds__(64) void k_group_consensus_bs(const uint64_t *__res
 		const int wj = t0 >> 5;
 		f.sh = 2 * (t0 & 31);
 		const uint64_t *row = packed + (size_t)(y >> 32) * W;
-		bs_row_pair(row, W, wj, f.covered, f.wa, f.wb);
+		f.wa = (f.covered && wj >= 0 && wj < W) ? row[wj] : 0ull;
+		f.wb = (f.covered && f.sh && wj + 1 >= 0 && wj + 1 < W) ? row[wj + 1] : 0ull;
 		return f;
 	};
 	auto finish = [&](const Fetch &f, uint64_t &x, uint64_t &cov) {
@@ -324,8 +307,8 @@ __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__res
 				const int t0 = dir ? L - 32 - s0 : s0;
 				const int wj = t0 >> 5, sh = 2 * (t0 & 31);
 				const uint64_t *row = packed + (size_t)(y >> 32) * W;
-				uint64_t wa, wb;
-				bs_row_pair(row, W, wj, true, wa, wb);
+				const uint64_t wa = (wj >= 0 && wj < W) ? row[wj] : 0ull;
+				const uint64_t wb = (sh && wj + 1 >= 0 && wj + 1 < W) ? row[wj + 1] : 0ull;
 				uint64_t x = sh ? (wa >> sh) | (wb << (64 - sh)) : wa;
 				if (dir) x = ~bs_rev(x);
 				const int e0 = L - s0 < (int)(ce - c0) ? L - s0 : (int)(ce - c0);

@@ -19,7 +19,6 @@ __global__ void k_group_sizes(const uint32_t *__restrict__ goff, const uint32_t 
 	rej[g] = (nk == sz && nk > 1) ? 0u : (sz - nk) + (nk == 1 ? 1u : 0u);     // :194-213, :477-498
 }
 
-// one wave per group
 __global__ __launch_bounds__(256) void k_group_emit(const uint64_t *__restrict__ members, const uint32_t *__restrict__ goff, size_t ng,
                                                     const uint8_t *__restrict__ keep, const uint32_t *__restrict__ nkept, const uint16_t *__restrict__ sv,
                                                     const uint16_t *__restrict__ reflen, const uint8_t *__restrict__ refs, int ref_stride,
@@ -28,44 +27,47 @@ __global__ __launch_bounds__(256) void k_group_emit(const uint64_t *__restrict__
                                                     uint8_t *__restrict__ seq, uint64_t *__restrict__ soff, uint64_t *__restrict__ mem, uint64_t *__restrict__ moff,
                                                     uint32_t *__restrict__ rej_rid, uint32_t *__restrict__ rej_group)
 {
-	const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	// sixteen lanes per group, four groups per wave (a group is six members and two hundred characters: with a wave per group the
+	// kernel waited for its dependent loads, PMC 89 % dependency wait); the ballots are cut to the group's sixteen lanes
+	const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
 	if (g >= ng) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15, seg = (threadIdx.x & 63) >> 4;
 	const uint32_t m0 = goff[g], m1 = goff[g + 1], nk = nkept[g], sz = m1 - m0;
-	const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+	const uint32_t below = (1u << lane) - 1u;
+	auto ballot16 = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (16 * seg)) & 0xFFFFu; };
 	if (nk > 1) {
 		const uint64_t c = n_have + slot[g];
 		uint64_t *dst = mem + members_have + mof[g];
 		const uint64_t sv2 = (uint64_t)sv[g] << 1;
 		uint32_t done = 0;
-		for (uint32_t q0 = m0; q0 < m1; q0 += 64) {
+		for (uint32_t q0 = m0; q0 < m1; q0 += 16) {
 			const uint32_t q = q0 + lane;
 			const bool kp = q < m1 && keep[q];
-			const uint64_t km = __ballot(kp);
-			if (kp) dst[done + (uint32_t)__popcll(km & below)] = members[q] - sv2;
-			done += (uint32_t)__popcll(km);
+			const uint32_t km = ballot16(kp);
+			if (kp) dst[done + (uint32_t)__popc(km & below)] = members[q] - sv2;
+			done += (uint32_t)__popc(km);
 		}
 		const uint32_t len = reflen[g];
 		const uint8_t *src = refs + g * (size_t)ref_stride;
 		uint8_t *out = seq + chars_have + rof[g];
 		{                                                                    // eight characters per lane and step, then the last few
 			const uint32_t n8 = len >> 3;
-			for (uint32_t i = lane; i < n8; i += 64) { uint64_t v; __builtin_memcpy(&v, src + 8 * i, 8); __builtin_memcpy(out + 8 * i, &v, 8); }
-			for (uint32_t i = (n8 << 3) + lane; i < len; i += 64) out[i] = src[i];
+			for (uint32_t i = lane; i < n8; i += 16) { uint64_t v; __builtin_memcpy(&v, src + 8 * i, 8); __builtin_memcpy(out + 8 * i, &v, 8); }
+			for (uint32_t i = (n8 << 3) + lane; i < len; i += 16) out[i] = src[i];
 		}
 		if (lane == 0) { moff[c + 1] = members_have + mof[g] + nk; soff[c + 1] = chars_have + rof[g] + len; }
 	}
 	if (!(nk == sz && nk > 1)) {
 		uint32_t at = rjo[g];
-		for (uint32_t q0 = m0; q0 < m1; q0 += 64) {                            // the rejected ones first (:194-213)
+		for (uint32_t q0 = m0; q0 < m1; q0 += 16) {                            // the rejected ones first (:194-213)
 			const uint32_t q = q0 + lane;
 			const bool rj = q < m1 && !keep[q];
-			const uint64_t rm = __ballot(rj);
-			if (rj) { const uint32_t o = at + (uint32_t)__popcll(rm & below); rej_rid[o] = (uint32_t)(members[q] >> 32); rej_group[o] = (uint32_t)g; }
-			at += (uint32_t)__popcll(rm);
+			const uint32_t rm = ballot16(rj);
+			if (rj) { const uint32_t o = at + (uint32_t)__popc(rm & below); rej_rid[o] = (uint32_t)(members[q] >> 32); rej_group[o] = (uint32_t)g; }
+			at += (uint32_t)__popc(rm);
 		}
 		if (nk == 1)                                                           // a contig of one is dissolved (:477-498)
-			for (uint32_t q = m0 + lane; q < m1; q += 64) if (keep[q]) { rej_rid[at] = (uint32_t)(members[q] >> 32); rej_group[at] = (uint32_t)g; }
+			for (uint32_t q = m0 + lane; q < m1; q += 16) if (keep[q]) { rej_rid[at] = (uint32_t)(members[q] >> 32); rej_group[at] = (uint32_t)g; }
 	}
 }
 
@@ -105,7 +107,7 @@ extern "C" int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, 
 		return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig set buffers too small for %u contigs, %llu chars, %u members, %u rejects", h32[0], (unsigned long long)chars, h32[1], h32[2]);
 	if (!d_seq || !d_soff || !d_mem || !d_moff || (h32[2] && (!d_rej_rid || !d_rej_group))) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n_have == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_soff, 0, 8, ctx->stream)); MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 8, ctx->stream)); }
-	hipLaunchKernelGGL(k_group_emit, dim3((unsigned)((ng * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_members, d_goff, ng, d_keep, d_nkept, d_sv, d_reflen,
+	hipLaunchKernelGGL(k_group_emit, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_members, d_goff, ng, d_keep, d_nkept, d_sv, d_reflen,
 	                   d_refs, ref_stride, slot, msz, rsz, rej, n_have, chars_have, members_have, d_seq, d_soff, d_mem, d_moff, d_rej_rid, d_rej_group);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // the workspace arrays are in use until here

@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256) void k_job_fill(const Job *__restrict__ jobs, 
                                                   const uint64_t *__restrict__ moff, const uint64_t *__restrict__ jmoff, int kb,
                                                   mcom_mm128 *__restrict__ rec, unsigned int *__restrict__ err)
 {
-	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;     // sixteen lanes per job: a job is two dozen members
 	if (j >= nj) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	const Job J = jobs[j];
 	const bool afirst = J.pos_ori >= J.pos;
 	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void k_job_fill(const Job *__restrict__ jobs, 
 	mcom_mm128 *dst = rec + jmoff[j];
 	const uint64_t jk = (uint64_t)j << kb, kmask = (1ull << kb) - 1;
 	bool bad = false;
-	for (uint64_t t = lane; t < nf; t += 64) {
+	for (uint64_t t = lane; t < nf; t += 16) {
 		const uint64_t y = mem[f0 + t];
 		const uint64_t key = (uint32_t)y;
 		bad |= key > kmask;
 		mcom_mm128 r; r.x = jk | (key & kmask); r.y = y; dst[t] = r;
 	}
-	for (uint64_t t = lane; t < ns; t += 64) {
+	for (uint64_t t = lane; t < ns; t += 16) {
 		const uint64_t y = mem[s0 + t] + sh;
 		const uint64_t key = (uint32_t)y;
 		bad |= key > kmask;
@@ -242,7 +242,7 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	uint32_t *tiles = w.take<uint32_t>(MCOM_GROUP_SCRATCH(total));
 	unsigned long long *meta = w.take<unsigned long long>(4);               // [0] maxlen, [1] error flag
 	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 32, ctx->stream));
-	hipLaunchKernelGGL(k_job_fill, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
+	hipLaunchKernelGGL(k_job_fill, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
 	                   (unsigned int*)(meta + 1));
 	MCOM_LAUNCH_CHECK(ctx);
 	{
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Job *__restrict__ jobs
                                                     const uint64_t *__restrict__ jroff, const uint32_t *__restrict__ olo, const uint32_t *__restrict__ ohi,
                                                     uint8_t *__restrict__ refs)
 {
-	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;     // sixteen lanes per job (see k_keep_copy)
 	if (j >= nj) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	const Job J = jobs[j];
 	const bool afirst = J.pos_ori >= J.pos;
 	const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256) void k_merge_copy(const Job *__restrict__ jobs
 	// eight characters per lane and step (unaligned 8-byte accesses), the last few of a stretch one by one
 	auto copy8 = [&](uint8_t *dst, const uint8_t *src, uint64_t cnt) {
 		const uint64_t n8 = cnt >> 3;
-		for (uint64_t t = lane; t < n8; t += 64) { uint64_t v; __builtin_memcpy(&v, src + 8 * t, 8); __builtin_memcpy(dst + 8 * t, &v, 8); }
-		for (uint64_t t = (n8 << 3) + lane; t < cnt; t += 64) dst[t] = src[t];
+		for (uint64_t t = lane; t < n8; t += 16) { uint64_t v; __builtin_memcpy(&v, src + 8 * t, 8); __builtin_memcpy(dst + 8 * t, &v, 8); }
+		for (uint64_t t = (n8 << 3) + lane; t < cnt; t += 16) dst[t] = src[t];
 	};
 	copy8(out, sf, lo);                                                      // before the overlap: the first parent alone
 	if (hi < len) {                                                          // behind it: whichever parent reaches there
@@ -371,7 +371,7 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 			return rc;
 	}
 	if (regions) {
-		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
+		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // the workspace arrays are in use until here
