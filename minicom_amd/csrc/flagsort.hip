@@ -84,139 +84,158 @@ __global__ __launch_bounds__(64) void k_flag_sort(mcom_mm128 *__restrict__ rec, 
 	}
 }
 
-// ---- index buckets: the same algorithm on 8-byte elements, several buckets per CU ------------------------------------
-// All records of an index bucket share their low `low_bits` bits, so inside a bucket the order by x is the order by
-// x >> low_bits, which fits 48 bits; with the record's position in the bucket (16 bits) an element is one uint64 and a
-// bucket of thousands of records takes half the LDS, i.e. twice the buckets in flight for the latency-bound
-// cycle-leader permutation, which stays with one lane.  Histogram, prefix sums and the insertion sorts of the
-// sub-ranges (the bulk of the instructions) use all 64 lanes.  The records are moved once, at the end.
-#define FSB_STACK 192
-
-__global__ __launch_bounds__(64) void k_flag_sort_bucket(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out,
-                                                         const uint32_t *__restrict__ bstart, uint32_t nr, int low_bits, uint32_t lds_cap,
+// ---- index buckets: the same algorithm with three bytes per element in LDS, a dozen buckets per CU --------------------------------
+// The cycle-leader permutation is one lane's chain of dependent LDS accesses per bucket (it is the reference's order of equal keys,
+// it cannot be split), so what counts is how many buckets a CU holds while one lane of each walks: with 8-byte elements (key,
+// position) six buckets of ~2900 records.  The walk only needs an element's DIGIT at the current level and its identity, so here
+// an element is a digit byte and a 16-bit index (D, I): 13 buckets per CU (34 -> 15 ms per step with the rest of round 2's changes:
+// only non-empty bins are visited, runs of in-place elements -- the top byte of a minimum of hashes is nearly always 0 -- are
+// skipped 64 at a time by the wave, lane 0 goes from cycle to cycle on its own).  The keys stay in HBM / L2 and are gathered when
+// a level's digits are made and when the small ranges are finished:
+//   * a range of at most 64 elements is finished by rs_insertsort, which is a STABLE sort of the range as it stands, so every element
+//     can find its final rank by itself (elements of the range with a smaller key, plus equal ones before it): one lane per position,
+//     the keys of a 192-position window staged in LDS, and the record goes straight to its final place in the output -- no
+//     insertion loop, no second index array;
+//   * larger ranges go on the stack for the next level, as in the reference (ksort.h:146-151).
+#define FST_STACK 96
+__global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out,
+                                                         const uint32_t *__restrict__ bstart, uint32_t nr, uint32_t lds_cap,
                                                          uint32_t *__restrict__ overflow)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	uint32_t *bb = (uint32_t*)smem, *be = bb + 256;
+	uint32_t *bb = (uint32_t*)smem, *be = bb + 256;                           // fill pointer / end of every bin of the current level
 	FsRange *stk = (FsRange*)(be + 256);
-	uint64_t *E = (uint64_t*)(stk + FSB_STACK);
+	uint64_t *KW = (uint64_t*)(stk + FST_STACK);                             // keys of a window of 192 positions
+	uint16_t *I = (uint16_t*)(KW + 192);                                     // [cap] which record of the bucket stands at a position
+	uint8_t *D = (uint8_t*)(I + lds_cap);                                    // [cap] its digit at the current level
 	const uint32_t r = blockIdx.x;
 	if (r >= nr) return;
 	const int lane = threadIdx.x;
 	const uint32_t beg = bstart[r], end = bstart[r + 1], n = end - beg;
 	if (n == 0) return;
-	if (n > lds_cap || n > 65536u) {                                           // does not fit: the record form, in HBM
+	if (n > lds_cap || n > 65535u) {                                           // does not fit: the record form, in HBM, by one lane
 		for (uint32_t i = lane; i < n; i += 64) out[beg + i] = in[beg + i];
 		__threadfence(); __syncthreads();
-		if (lane == 0) flag_sort_range(out + beg, n, bb, be, stk, FSB_STACK, overflow);
+		if (lane == 0) flag_sort_range(out + beg, n, bb, be, stk, FST_STACK, overflow);
 		return;
 	}
-	for (uint32_t i = lane; i < n; i += 64) E[i] = ((in[beg + i].x >> low_bits) << 16) | (uint64_t)i;
+	const mcom_mm128 *rec = in + beg;
+	for (uint32_t i = lane; i < n; i += 64) I[i] = (uint16_t)i;
 	__syncthreads();
-	auto digit = [&](uint64_t e, uint32_t s) -> uint32_t { return (uint32_t)(((((e >> 16) << low_bits) | (uint64_t)r) >> s) & 255); };
-	auto insertion = [&](uint32_t b0, uint32_t e0) {                           // rs_insertsort (ksort.h:112-122)
-		for (uint32_t i = b0 + 1; i < e0; ++i) {
-			if ((E[i] >> 16) < (E[i - 1] >> 16)) {
-				const uint64_t t = E[i]; uint32_t j = i;
-				while (j > b0 && (t >> 16) < (E[j - 1] >> 16)) { E[j] = E[j - 1]; --j; }
-				E[j] = t;
+	// rs_insertsort of every range of at most 64 positions among the bins [first bin .. ] of [rb, re): bin of position p = D[p]
+	// when by_bins, else the one range [rb, re) itself.  The ranks are final: the records are written out.
+	auto finish_small = [&](uint32_t rb, uint32_t re, bool by_bins) {
+		for (uint32_t base = rb; base < re; base += 64) {
+			const uint32_t w0 = base >= rb + 64 ? base - 64 : rb;                // the window starts at most 64 positions before the chunk
+			const uint32_t w1 = base + 128 < re ? base + 128 : re;
+			__syncthreads();
+			for (uint32_t q = w0 + lane; q < w1; q += 64) KW[q - w0] = rec[I[q]].x;
+			__syncthreads();
+			const uint32_t p = base + (uint32_t)lane;
+			if (p < re) {
+				uint32_t b0 = rb, e0 = re;
+				if (by_bins) { const uint32_t d = D[p]; e0 = be[d]; b0 = d ? be[d - 1] : rb; }
+				if (e0 - b0 <= 64) {
+					const uint64_t mine = KW[p - w0];
+					uint32_t rank = b0;
+					for (uint32_t q = b0; q < e0; ++q) { const uint64_t k = KW[q - w0]; rank += (k < mine || (k == mine && q < p)) ? 1u : 0u; }
+					out[beg + rank] = rec[I[p]];
+				}
 			}
 		}
 	};
-	if (n <= 64) { if (lane == 0) insertion(0, n); }                           // radix_sort (ksort.h:153-157)
-	else {
-		uint32_t sp = 1;                                                       // uniform: every lane keeps the same count
-		if (lane == 0) stk[0] = FsRange{0, n, 56};
-		__syncthreads();
-		while (sp) {
-			const FsRange rg = stk[--sp];
-			const uint32_t rb = rg.b, re = rg.e, s = rg.shift;
-			__syncthreads();                                                   // everybody has read the entry before a push reuses it
-			// rs_sort (ksort.h:123-152): histogram and bucket bounds by all lanes
-			for (int q = lane; q < 256; q += 64) be[q] = 0;
-			__syncthreads();
-			for (uint32_t i = rb + lane; i < re; i += 64) atomicAdd(&be[digit(E[i], s)], 1u);
-			__syncthreads();
-			{
-				const uint32_t c0 = be[4 * lane], c1 = be[4 * lane + 1], c2 = be[4 * lane + 2], c3 = be[4 * lane + 3];
-				const uint32_t tot = c0 + c1 + c2 + c3;
-				uint32_t incl = tot;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-				uint32_t a = rb + incl - tot;
-				bb[4 * lane] = a; a += c0; be[4 * lane] = a;
-				bb[4 * lane + 1] = a; a += c1; be[4 * lane + 1] = a;
-				bb[4 * lane + 2] = a; a += c2; be[4 * lane + 2] = a;
-				bb[4 * lane + 3] = a; a += c3; be[4 * lane + 3] = a;
-			}
-			__syncthreads();
-			// The cycle-leader permutation, as written (ksort.h:132-144) -- except that the elements it merely steps over are stepped
-			// over 64 at a time: an element at bb[q] whose digit is q is "in place", the reference does ++bb[q] and nothing else,
-			// and nothing ever writes into bin q ahead of bb[q] (a cycle closes AT bb[q]), so the first element of the bin that is
-			// not in place can be found by all lanes at once.  At the top levels nearly every element is in place (the hashes of a
-			// bucket are minima of many k-mer hashes: their top byte is almost always 0), and walking them one by one was half of
-			// this kernel's time.  The cycles themselves stay with one lane: they are the reference's order of equal keys.
-			// Only the bins that hold something are visited (a barrier round per empty bin was a quarter of a millisecond per level),
-			// and lane 0 keeps going on its own from cycle to cycle -- as the reference does -- until it has stepped over eight
-			// in-place elements in a row: only then is the wave asked to find the next element that is not in place.
-			for (int q0 = 0; q0 < 256; q0 += 64) {
-				uint64_t live = __ballot(bb[q0 + lane] != be[q0 + lane]);         // uniform
-				while (live) {
-					const int q = q0 + __ffsll((unsigned long long)live) - 1;
-					live &= live - 1;
-					for (;;) {
-						const uint32_t b0 = bb[q], e0 = be[q];                       // uniform
-						if (b0 == e0) break;
-						uint32_t found = e0;
-						for (uint32_t p0 = b0; p0 < e0; p0 += 64) {
-							const uint32_t p = p0 + (uint32_t)lane;
-							const bool neq = p < e0 && (int)digit(E[p < e0 ? p : b0], s) != q;
-							const uint64_t m = __ballot(neq);
-							if (m) { found = p0 + (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
-						}
-						if (lane == 0) {
-							uint32_t at = found, inplace = 0;
-							while (at != e0 && inplace < 8) {
-								int l = (int)digit(E[at], s);
-								if (l == q) { ++at; ++inplace; continue; }              // in place: ++bb[q] (ksort.h:143)
-								inplace = 0;
-								bb[q] = at;
-								uint64_t hold = E[at], moved;
-								do {
-									moved = hold; hold = E[bb[l]]; E[bb[l]++] = moved;
-									l = (int)digit(hold, s);
-								} while (l != q);
-								E[bb[q]++] = hold;
-								at = bb[q];
-							}
-							bb[q] = at;
-						}
-						__syncthreads();
-						if (found == e0) break;
-					}
-				}
-			}
-			__syncthreads();
-			if (s) {
-				const uint32_t nxt = s > 8 ? s - 8 : 0;
-				for (int q0 = 0; q0 < 256; q0 += 64) {
-					const int q = q0 + lane;
-					const uint32_t b0 = q ? be[q - 1] : rb, e0 = be[q], cnt = e0 - b0;
-					const bool big = cnt > 64;
-					const uint64_t bm = __ballot(big);
-					if (big) {
-						const uint32_t at = sp + (uint32_t)__popcll(bm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-						if (at < FSB_STACK) stk[at] = FsRange{b0, e0, nxt}; else *overflow = 1;
-					} else if (cnt > 1) insertion(b0, e0);
-					sp += (uint32_t)__popcll(bm);
-				}
-				if (sp > FSB_STACK) sp = FSB_STACK;
-			}
-			__syncthreads();
-		}
-	}
+	if (n <= 64) { finish_small(0, n, false); return; }                        // radix_sort (ksort.h:153-157)
+	uint32_t sp = 1;                                                           // uniform: every lane keeps the same count
+	if (lane == 0) stk[0] = FsRange{0, n, 56};
 	__syncthreads();
-	for (uint32_t i = lane; i < n; i += 64) out[beg + i] = in[beg + (uint32_t)(E[i] & 0xFFFFull)];
+	while (sp) {
+		const FsRange rg = stk[--sp];
+		const uint32_t rb = rg.b, re = rg.e, s = rg.shift;
+		__syncthreads();                                                       // everybody has read the entry before a push reuses it
+		// rs_sort (ksort.h:123-152): digits, histogram and bin bounds by all lanes
+		for (int q = lane; q < 256; q += 64) be[q] = 0;
+		__syncthreads();
+		for (uint32_t i = rb + lane; i < re; i += 64) { const uint32_t d = (uint32_t)(rec[I[i]].x >> s) & 255u; D[i] = (uint8_t)d; atomicAdd(&be[d], 1u); }
+		__syncthreads();
+		{
+			const uint32_t c0 = be[4 * lane], c1 = be[4 * lane + 1], c2 = be[4 * lane + 2], c3 = be[4 * lane + 3];
+			const uint32_t tot = c0 + c1 + c2 + c3;
+			uint32_t incl = tot;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+			uint32_t a = rb + incl - tot;
+			bb[4 * lane] = a; a += c0; be[4 * lane] = a;
+			bb[4 * lane + 1] = a; a += c1; be[4 * lane + 1] = a;
+			bb[4 * lane + 2] = a; a += c2; be[4 * lane + 2] = a;
+			bb[4 * lane + 3] = a; a += c3; be[4 * lane + 3] = a;
+		}
+		__syncthreads();
+		// The cycle-leader permutation as written (ksort.h:132-144), with two short cuts that change nothing: only the bins that hold
+		// something are visited, and an element at bb[q] whose digit is q is "in place" -- the reference does ++bb[q] and nothing else,
+		// nothing ever writes into bin q ahead of bb[q] (a cycle closes AT bb[q]) -- so the first element of a bin that is not in place
+		// is found by all lanes at once.  Lane 0 then goes from cycle to cycle on its own and asks the wave again only after eight
+		// in-place elements in a row.  The cycles themselves stay with one lane: they are the reference's order of equal keys.
+		for (int q0 = 0; q0 < 256; q0 += 64) {
+			uint64_t live = __ballot(bb[q0 + lane] != be[q0 + lane]);             // uniform
+			while (live) {
+				const int q = q0 + __ffsll((unsigned long long)live) - 1;
+				live &= live - 1;
+				for (;;) {
+					const uint32_t b0 = bb[q], e0 = be[q];                           // uniform
+					if (b0 == e0) break;
+					uint32_t found = e0;
+					for (uint32_t p0 = b0; p0 < e0; p0 += 64) {
+						const uint32_t p = p0 + (uint32_t)lane;
+						const bool neq = p < e0 && (int)D[p] != q;
+						const uint64_t m = __ballot(neq);
+						if (m) { found = p0 + (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
+					}
+					if (lane == 0) {
+						uint32_t at = found, inplace = 0;
+						while (at != e0 && inplace < 8) {
+							int l = (int)D[at];
+							if (l == q) { ++at; ++inplace; continue; }                  // in place: ++bb[q] (ksort.h:143)
+							inplace = 0;
+							uint8_t hd = D[at]; uint16_t hi = I[at];
+							do {
+								const uint8_t md = hd; const uint16_t mi = hi;
+								const uint32_t pos = bb[l];
+								hd = D[pos]; hi = I[pos];
+								D[pos] = md; I[pos] = mi; bb[l] = pos + 1;
+								l = (int)hd;
+							} while (l != q);
+							D[at] = hd; I[at] = hi;
+							++at;
+						}
+						bb[q] = at;
+					}
+					__syncthreads();
+					if (found == e0) break;
+				}
+			}
+		}
+		__syncthreads();
+		// the bins: above 64 elements to the next level, the others finished (at the last level every bin is one key: in order as it is)
+		if (s) {
+			const uint32_t nxt = s > 8 ? s - 8 : 0;
+			for (int q0 = 0; q0 < 256; q0 += 64) {
+				const int q = q0 + lane;
+				const uint32_t b0 = q ? be[q - 1] : rb, e0 = be[q], cnt = e0 - b0;
+				const bool big = cnt > 64;
+				const uint64_t bm = __ballot(big);
+				if (big) {
+					const uint32_t at = sp + (uint32_t)__popcll(bm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+					if (at < FST_STACK) stk[at] = FsRange{b0, e0, nxt}; else *overflow = 1;
+				}
+				sp += (uint32_t)__popcll(bm);
+			}
+			if (sp > FST_STACK) sp = FST_STACK;
+			finish_small(rb, re, true);
+		} else {
+			for (uint32_t p = rb + lane; p < re; p += 64) out[beg + p] = rec[I[p]];
+		}
+		__syncthreads();
+	}
 }
 
 // every bucket [d_bstart[r], d_bstart[r+1]) of d_in (all of whose x share their low low_bits bits = r) in the
@@ -225,14 +244,16 @@ int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_
                            uint32_t max_range, uint32_t *d_overflow)
 {
 	if (nr == 0) return MCOM_OK;
-	const size_t fixed = 2 * 256 * 4 + FSB_STACK * sizeof(FsRange);
+	(void)low_bits;                                                            // (the records of a bucket share their low bits: their order by x is the order of the keys)
+	const size_t fixed = 2 * 256 * 4 + FST_STACK * sizeof(FsRange) + 192 * 8;
 	size_t cap = max_range < 64 ? 64 : max_range;
 	const size_t lds_max = 150 * 1024;
-	if (cap > 65536) cap = 65536;
-	if (fixed + cap * 8 > lds_max) cap = (lds_max - fixed) / 8;
-	const size_t lds = fixed + cap * 8;
-	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_flag_sort_bucket, dim3(nr), dim3(64), lds, ctx->stream, d_in, d_out, d_bstart, nr, low_bits, (uint32_t)cap, d_overflow);
+	if (cap > 65535) cap = 65535;
+	cap = (cap + 7) & ~(size_t)7;                                            // the digit bytes start behind the 16-bit indices: keep that 8-byte aligned
+	if (fixed + cap * 3 > lds_max) cap = ((lds_max - fixed) / 3) & ~(size_t)7;
+	const size_t lds = fixed + cap * 3;
+	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort_tokens, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(k_flag_sort_tokens, dim3(nr), dim3(64), lds, ctx->stream, d_in, d_out, d_bstart, nr, (uint32_t)cap, d_overflow);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
