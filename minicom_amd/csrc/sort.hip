@@ -291,7 +291,7 @@ __global__ void k_seg_move(mcom_mm128 *__restrict__ arr, mcom_mm128 *__restrict_
 
 // ---- generic exclusive scan of uint32 (2048 elements per block, recursive on the block sums) -------
 #define SC_THREADS 256
-#define SC_PER 8
+#define SC_PER 8                             // (k_scan_tile's vector path assumes eight)
 #define SC_TILE (SC_THREADS * SC_PER)
 __global__ __launch_bounds__(SC_THREADS) void k_scan_tile(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
                                                           uint32_t *__restrict__ sums)
@@ -299,8 +299,16 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_tile(const uint32_t *__rest
 	__shared__ uint32_t wsum[SC_THREADS / 64];
 	const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_PER;
 	uint32_t v[SC_PER], tot = 0;
+	const bool vec = base + SC_PER <= n && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;   // eight elements as two 16-byte accesses
+	if (vec) {
+		const uint4 a = *(const uint4*)(in + base), b = *(const uint4*)(in + base + 4);
+		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-	for (int q = 0; q < SC_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0u; tot += v[q]; }
+		for (int q = 0; q < SC_PER; ++q) tot += v[q];
+	} else {
+#pragma unroll
+		for (int q = 0; q < SC_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0u; tot += v[q]; }
+	}
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	uint32_t inc = tot;
 #pragma unroll
@@ -310,8 +318,16 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_tile(const uint32_t *__rest
 	uint32_t add = 0, all = 0;
 	for (int q = 0; q < SC_THREADS / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
 	uint32_t run = inc + add - tot;
+	if (vec) {
+		uint32_t o[SC_PER];
 #pragma unroll
-	for (int q = 0; q < SC_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+		for (int q = 0; q < SC_PER; ++q) { o[q] = run; run += v[q]; }
+		*(uint4*)(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+		*(uint4*)(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+	} else {
+#pragma unroll
+		for (int q = 0; q < SC_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
+	}
 	if (sums && threadIdx.x == 0) sums[blockIdx.x] = all;
 }
 __global__ void k_scan_add(uint32_t *__restrict__ out, size_t n, const uint32_t *__restrict__ sums)

@@ -70,7 +70,9 @@ int mcom_table_build_bucketed(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n,
                               uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t)
 {
 	uint32_t lr = 4;
-	while ((1u << lr) < 2 * max_bucket + 16) ++lr;                              // a region is at most half full
+	while ((1u << lr) < max_bucket + (max_bucket >> 2) + (max_bucket >> 3) + 16) ++lr;   // a region is at most 0.73 full if every record of the bucket were a key of its own
+	                                                                            // (about half of them are): half the LDS per workgroup and half the table to write and to
+	                                                                            // miss in, against a rare third probe
 	if (n == 0 || bbits < 1 || lr > 13 || ((size_t)16 << (lr + bbits)) > ((size_t)64 << 30))   // 2^13 slots = 128 KB of LDS; a larger bucket: the global table
 		return mcom_table_build(ctx, sorted, n, head, scr, meta, t);
 	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->log2region = lr; t->bbits = (uint32_t)bbits; t->log2cap = lr + (uint32_t)bbits;
