@@ -138,6 +138,12 @@ int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
  * (so d_coff[c+1] - d_coff[c] = ceil(2*len/64) + 1; total_words = their sum).  Non-ACGT packs as A.   */
 int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                       uint64_t total_words, uint64_t *d_cbits);
+/* The same for the set after a merge round (cp_cluster, kthread_cb.c:397-434: the merged contigs first, then the untouched ones
+ * in their order): contigs [0, n_first) are packed from their strings, contig n_first + u takes the packed words of contig
+ * d_keepidx[u] of the set before the round (d_cbits_old / d_coff_old).  Same words as mcom_pack_contigs.                        */
+int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                             uint64_t total_words, uint32_t n_first, const uint64_t *d_cbits_old, const uint64_t *d_coff_old,
+                             const uint32_t *d_keepidx, uint64_t *d_cbits);
 
 /* mm_idx_init + mm_idx_generation (kthread_idx.c:77, :116-170): index over n minimizer records sketched
  * with k, given in the order the reference pushes them (contig order, minimizer order).

@@ -474,13 +474,17 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 #define PK_T 256
 __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                        const uint64_t *__restrict__ coff, uint32_t n, uint64_t total_words,
-                                                       uint64_t *__restrict__ cbits)
+                                                       uint64_t *__restrict__ cbits, uint32_t n_first)
 {
 	__shared__ uint64_t CO[PK_T / 2 + 4], OF[PK_T / 2 + 4];
 	__shared__ uint32_t SB[PK_T * 8 + 16];
 	__shared__ uint32_t srch[16];
 	__shared__ uint64_t lo_s, hi_s;
 	const uint64_t g0 = (uint64_t)blockIdx.x * PK_T;
+	if (n_first < n) {                                                       // only the first n_first contigs: the words below coff[n_first]
+		total_words = coff[n_first]; n = n_first;
+		if (g0 >= total_words) return;
+	}
 	const uint64_t g = g0 + threadIdx.x;
 	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return coff[c] <= g0; }, srch);
 	if (threadIdx.x == 0) { lo_s = 0; hi_s = 0; }
@@ -545,7 +549,40 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 	const uint64_t blocks = (total_words + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
 	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
-	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits);
+	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// A merge round changes the merged contigs only: they (the first n_first of the new set) are packed, the packed words of the
+// untouched ones (contig nj + u of the new set = contig keepidx[u] of the old one) are copied -- a quarter of a byte per base
+// instead of a byte.
+__global__ __launch_bounds__(256) void k_packed_carry(const uint64_t *__restrict__ cbits_old, const uint64_t *__restrict__ coff_old,
+                                                      const uint32_t *__restrict__ keepidx, size_t nkeep, size_t first,
+                                                      const uint64_t *__restrict__ coff_new, uint64_t *__restrict__ cbits_new)
+{
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;       // sixteen lanes per contig
+	if (u >= nkeep) return;
+	const int lane = threadIdx.x & 15;
+	const uint32_t i = keepidx[u];
+	const uint64_t s0 = coff_old[i], cnt = coff_old[i + 1] - s0, d0 = coff_new[first + u];
+	for (uint64_t t = lane; t < cnt; t += 16) cbits_new[d0 + t] = cbits_old[s0 + t];
+}
+extern "C" int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                                        uint64_t total_words, uint32_t n_first, const uint64_t *d_cbits_old, const uint64_t *d_coff_old,
+                                        const uint32_t *d_keepidx, uint64_t *d_cbits)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0 || total_words == 0) return MCOM_OK;
+	if (n_first > n) return mcom_fail(ctx, MCOM_E_ARG, "bad pack arguments");
+	if (!d_seq || !d_off || !d_coff || !d_cbits || (n_first < n && (!d_cbits_old || !d_coff_old || !d_keepidx))) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const uint64_t blocks = (total_words + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
+	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
+	if (n_first) hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n_first);
+	const size_t nkeep = n - n_first;
+	if (nkeep) hipLaunchKernelGGL(k_packed_carry, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits_old, d_coff_old, d_keepidx, nkeep,
+	                              (size_t)n_first, d_coff, d_cbits);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

@@ -232,6 +232,10 @@ struct mcomh_pipeline {
 	void join_sg() { join_cls(); if (sg_thread.joinable()) sg_thread.join(); }
 	// contigs of the current stage on the device
 	DevBuf<uint8_t> d_cseq; DevBuf<uint64_t> d_coff_chars, d_coff_words, d_cbits, d_woff; DevBuf<uint32_t> d_clen;
+	// the packed form of the set after a merge round is made from the round's own (merged contigs packed, the others' words copied):
+	// the second set of buffers, and whether d_cbits / d_coff_words / d_clen describe the set in dC
+	DevBuf<uint64_t> d_coff_words_alt, d_cbits_alt; DevBuf<uint32_t> d_clen_alt;
+	bool cbits_for_dC = false;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint32_t cix_parts = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
@@ -583,7 +587,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	// the contigs are built on the device (p->dC) and stay there for combine_cluster; the host copy is made on demand
 	p->C.clear();
 	p->dC.n = 0; p->dC.chars = 0; p->dC.members = 0; p->dC.nrec = 0;
-	p->dC_valid = true; p->hostC_valid = false; p->host_off_valid = false;
+	p->dC_valid = true; p->hostC_valid = false; p->host_off_valid = false; p->cbits_for_dC = false;
 	DevSet &D = p->dC;
 	int rc;
 	if (dist) {                                              // offset entry 0 of the replicated set: nobody's contig writes it
@@ -919,18 +923,23 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		lap("t_cb_sketch");
 		p->stat["t_gpu"] += now_ms() - tg;
 	}
+	bool packed_ready = false;                                                 // d_cbits & co. describe A (made at the end of the round before)
+	p->cbits_for_dC = false;
 	for (;;) {
 		const size_t n = A.n;
 		uint64_t n_pass = 0;
 		if (n) {
 			const double tg = now_ms();
 			uint64_t tw = 0, tm = 0;
-			if (!p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
-			if ((rc = p->gpu(mcom_contig_layout(p->ctx, A.soff.p, n, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
-			p->total_words = tw;
-			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-			if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
-			if ((rc = p->gpu(mcom_pack_contigs(p->ctx, A.seq.p, A.soff.p, p->d_coff_words.p, (uint32_t)n, tw, p->d_cbits.p)))) return rc;
+			if (!packed_ready) {
+				if (!p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, A.soff.p, n, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+				p->total_words = tw;
+				if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
+				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, A.seq.p, A.soff.p, p->d_coff_words.p, (uint32_t)n, tw, p->d_cbits.p)))) return rc;
+				packed_ready = true;
+			}
 			// the first m minimizers are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
 			if (!moff_m.reserve(n + 2) || !rec_m.reserve(n * (size_t)p->m + 16)) return p->fail(MCOM_E_NOMEM, "index records");
 			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, A.roff.p, A.rec.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
@@ -1054,9 +1063,22 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			} else if ((rc = sketch_first(p, B, nj, tot[1], (size_t)A.nrec, tn))) return rc;
 			if ((rc = p->gpu(mcom_records_carry(p->ctx, A.rec.p, A.roff.p, d_keepidx.p, nkeep, (uint32_t)nj, (uint32_t)tn, B.rec.p, B.rec.cap, B.roff.p, &B.nrec)))) return rc;
 			lap("t_cb_sketch");
+			{
+				// the packed form of the new set: the merged contigs are packed, the others' words copied from this round's
+				uint64_t tw2 = 0;
+				if (!p->d_coff_words_alt.reserve(nn + 1) || !p->d_clen_alt.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, B.soff.p, nn, p->d_coff_words_alt.p, p->d_clen_alt.p, &tw2)))) return rc;
+				if (!p->d_cbits_alt.reserve(tw2 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits_alt.p + tw2, 0, 2 * 8, p->stream), "clear"))) return rc;
+				if ((rc = p->gpu(mcom_pack_contigs_merged(p->ctx, B.seq.p, B.soff.p, p->d_coff_words_alt.p, (uint32_t)nn, tw2, (uint32_t)nj, p->d_cbits.p, p->d_coff_words.p,
+				                                          d_keepidx.p, p->d_cbits_alt.p)))) return rc;
+				p->d_cbits.swap(p->d_cbits_alt); p->d_coff_words.swap(p->d_coff_words_alt); p->d_clen.swap(p->d_clen_alt);
+				p->total_words = tw2;
+				lap("t_cb_pack");
+			}
 			A.swap(B);
 			p->stat["t_gpu"] += now_ms() - tg;
-		}
+		} else packed_ready = packed_ready && n != 0;
 		p->stat["merge_rounds"] += 1;
 		const long tot = (long)A.n;
 		if (std::labs(pre - tot) < 100) break;                                              // :625
@@ -1065,6 +1087,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	// the final set stays on the device, for Stage 2 and beyond; the host learns the offsets when Stage 2 asks for them
 	p->maxlen = maxlen;
 	p->dC.swap(A); p->dC_valid = true;
+	p->cbits_for_dC = packed_ready && p->dC.n != 0;                          // Stage 2 takes the packed set as it is
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");
 	p->join_sg();
@@ -1304,12 +1327,15 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
 		{                                                      // the set is on the device: lay it out and pack it there
 			uint64_t tw = 0;
-			if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
-			if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
-			p->total_words = tw;
-			if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-			if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
-			           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
+			if (!p->cbits_for_dC) {                                // (combine_cluster leaves the packed form of its last set behind)
+				if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+				p->total_words = tw;
+				if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+				if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
+				           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
+				p->cbits_for_dC = true;
+			}
 		}
 		if (!p->d_woff.reserve(nc + 2)) return p->fail(MCOM_E_NOMEM, "window offsets");
 		uint64_t nwin = 0, mlen = 0;
