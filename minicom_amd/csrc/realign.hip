@@ -790,10 +790,12 @@ __global__ void k_bin_screen(const uint64_t *__restrict__ sgbits, size_t n_sg, i
 	if (sg >= n_sg) return;
 	const uint64_t key = bits_key(sgbits + sg * (size_t)W, g.ds[l], g.klen);
 	const uint64_t h = (key * 8 + (uint64_t)l + 1) * 0x9E3779B97F4A7C15ull;
-	unsigned int *slot = &table[h >> (64 - log2t)];
-	const unsigned int seen = *(volatile unsigned int*)slot;                 // brings the line into L2: an atomic that misses costs several times one that hits
-	const unsigned int old = atomicAdd(slot, 1u);
-	if ((old > seen ? old : seen) + 1 > maxsearch) *exceeded = 1;
+	atomicAdd(&table[h >> (64 - log2t)], 1u);                                // nothing comes back: the counters are looked at afterwards (k_bin_screen_max)
+}
+__global__ void k_bin_screen_max(const unsigned int *__restrict__ table, size_t n, uint32_t maxsearch, unsigned int *__restrict__ exceeded)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && table[i] > maxsearch) *exceeded = 1;
 }
 
 extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)
@@ -804,7 +806,9 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 	CixGeom g;
 	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
 	const uint64_t nkeys = (uint64_t)n_sg * (uint64_t)g.nd;
-	uint32_t lg = 10; while (lg < 30 && (1ull << lg) < nkeys) ++lg;
+	// a counter per ~8 keys: collisions only add (the count stays an upper bound of every bin in it) and ~8 is far below any limit worth
+	// asking about, while the table (64 MB at 16 M singletons instead of 512) stays in the Infinity Cache, where the atomics are served
+	uint32_t lg = 10; while (lg < 30 && (8ull << lg) < nkeys) ++lg;
 	int rc = mcom_ws_reserve(ctx, ((size_t)4 << lg) + 256);
 	if (rc) return rc;
 	unsigned int *table = (unsigned int*)ctx->ws;
@@ -813,7 +817,8 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 	const uint64_t blocks = (nkeys + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
-	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag); }
+	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag);
+	hipLaunchKernelGGL(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned int hf = 0;
 	MCOM_HIP(ctx, hipMemcpyAsync(&hf, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
