@@ -11,8 +11,30 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	if (ctx) ctx->err = buf;
+	if (ctx) { ctx->err = buf; ctx->pin_wait.clear(); ctx->pin_off = 0; }
 	return code;
+}
+
+#define MCOM_PIN_BYTES 4096
+hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+	if (bytes <= 256) {
+		if (!ctx->pin && hipHostMalloc((void**)&ctx->pin, MCOM_PIN_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; (void)hipGetLastError(); }
+		const size_t need = (bytes + 7) & ~(size_t)7;
+		if (ctx->pin && ctx->pin_off + need <= MCOM_PIN_BYTES) {
+			const hipError_t e = hipMemcpyAsync(ctx->pin + ctx->pin_off, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) { ctx->pin_wait.push_back(mcom_ctx::PinWait{dst, ctx->pin_off, bytes}); ctx->pin_off += need; }
+			return e;
+		}
+	}
+	return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+hipError_t mcom_stream_sync(mcom_ctx *ctx)
+{
+	const hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, ctx->pin + w.off, w.bytes);
+	ctx->pin_wait.clear(); ctx->pin_off = 0;
+	return e;
 }
 
 // One spare workspace per device outlives its context: a job creates a context per run and the workspace reaches
@@ -120,6 +142,7 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 		}
 		if (drop) (void)hipFree(drop);
 	}
+	if (ctx->pin) (void)hipHostFree(ctx->pin);
 	delete ctx;
 }
 
@@ -133,7 +156,7 @@ extern "C" int mcom_set_stream(mcom_ctx *ctx, void *hip_stream)
 extern "C" int mcom_sync(mcom_ctx *ctx)
 {
 	if (!ctx) return MCOM_E_ARG;
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }
 

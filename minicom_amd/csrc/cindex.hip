@@ -511,9 +511,9 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 	uint64_t w01[2] = {0, 0};
 	if (c0 < c1) {
 		if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-		MCOM_HIP(ctx, hipMemcpyAsync(&w01[0], d_woff + c0, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipMemcpyAsync(&w01[1], d_woff + c1, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[0], d_woff + c0, 8));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[1], d_woff + c1, 8));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
 	const uint64_t n_pos = (w01[1] - w01[0]) ? (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff : 0;
 	if (n_pos >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions");
@@ -545,10 +545,10 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
 		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;   // the extra element becomes the number of entries
-		MCOM_HIP(ctx, hipMemcpyAsync(&n_ent, hist + (size_t)256 * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_ent, hist + (size_t)256 * nblocks, 4));
 		hipLaunchKernelGGL(k_cx_scatter1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, keyA, slotA);
 		MCOM_LAUNCH_CHECK(ctx);
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
 	if (n_ent) {
 		const uint32_t nb2 = (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE);
@@ -570,8 +570,8 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint64_t used = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&used, d_keys, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &used, d_keys, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (used > ext_cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index: %llu extension lines needed, room for %llu", (unsigned long long)used, (unsigned long long)ext_cap);
 	return MCOM_OK;
 }

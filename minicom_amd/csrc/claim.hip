@@ -72,8 +72,8 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 		hipLaunchKernelGGL(k_claim_take, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_flag, dead, best, sel);
 		MCOM_LAUNCH_CHECK(ctx);
 		unsigned int hl = 0;
-		MCOM_HIP(ctx, hipMemcpyAsync(&hl, live, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &hl, live, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 		if (!hl) break;
 		++rounds;
 	}
@@ -81,11 +81,11 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	// the taken edges in list order = the reference's claiming order
 	if ((rc = mcom_scan_u32(ctx, sel, spre, n_pairs + 1, scr))) return rc;          // sel[n_pairs] = 0 from the memset
 	uint32_t nj = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&nj, spre + n_pairs, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nj, spre + n_pairs, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_nj = nj;
 	if (nj) hipLaunchKernelGGL(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                                // the workspace is in use until here
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));                                // the workspace is in use until here
 	return MCOM_OK;
 }

@@ -328,7 +328,7 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	}
 	const uint32_t n_rest = n_groups - n_small;
 	const uint32_t *glist = perm ? perm + n_small : nullptr;
-	if (n_rest == 0) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); mcom_dfree(perm); return MCOM_OK; }
+	if (n_rest == 0) { MCOM_HIP(ctx, mcom_stream_sync(ctx)); mcom_dfree(perm); return MCOM_OK; }
 	unsigned int *big = (unsigned int*)ctx->ws;
 	hipError_t er = hipMemsetAsync(big, 0, 4, ctx->stream);
 	if (er == hipSuccess) {
@@ -340,14 +340,14 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	}
 	if (er == hipSuccess) er = hipGetLastError();
 	unsigned int hb = 0;
-	if (er == hipSuccess) er = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
-	if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
+	if (er == hipSuccess) er = mcom_d2h_async(ctx, &hb, big, 4);
+	if (er == hipSuccess) er = mcom_stream_sync(ctx);
 	if (er == hipSuccess && hb) {                                            // groups of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
 		hipLaunchKernelGGL((k_group_consensus<false>), dim3(n_rest), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
 		                   d_group_off, n_rest, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big, glist);
 		er = hipGetLastError();
-		if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
+		if (er == hipSuccess) er = mcom_stream_sync(ctx);
 	}
 	mcom_dfree(perm);
 	if (er != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "group consensus: %s", hipGetErrorString(er));
@@ -505,13 +505,13 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	hipLaunchKernelGGL(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist); }
 	unsigned int hb = 0;
-	hipError_t e1 = hipMemcpyAsync(&hb, big, 4, hipMemcpyDeviceToHost, ctx->stream);
-	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	hipError_t e1 = mcom_d2h_async(ctx, &hb, big, 4);
+	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
 	if (e1 == hipSuccess && hb) {                                            // a job of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
 		hipLaunchKernelGGL((k_merge_consensus<false>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist);
-		e1 = hipStreamSynchronize(ctx->stream);
+		e1 = mcom_stream_sync(ctx);
 	}
 	mcom_dfree(big);
 	if (e1 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "merge consensus: %s", hipGetErrorString(e1));
@@ -558,8 +558,8 @@ extern "C" int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, cons
 	MCOM_LAUNCH_CHECK(ctx);
 	if (h_total) {
 		uint32_t total = 0;
-		MCOM_HIP(ctx, hipMemcpyAsync(&total, d_out_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_out_moff + n, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 		*h_total = total;
 	}
 	return MCOM_OK;

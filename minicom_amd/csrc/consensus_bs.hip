@@ -364,8 +364,8 @@ int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t
 		er = hipGetLastError();
 	}
 	uint32_t nbig = 0;
-	if (er == hipSuccess) er = hipMemcpyAsync(&nbig, bins + 32, 4, hipMemcpyDeviceToHost, ctx->stream);
-	if (er == hipSuccess) er = hipStreamSynchronize(ctx->stream);
+	if (er == hipSuccess) er = mcom_d2h_async(ctx, &nbig, bins + 32, 4);
+	if (er == hipSuccess) er = mcom_stream_sync(ctx);
 	if (er != hipSuccess) { mcom_dfree(perm); return mcom_fail(ctx, MCOM_E_HIP, "group order: %s", hipGetErrorString(er)); }
 	const uint32_t nsmall = n_groups - nbig;
 	const int LG = (2 * L + 31) / 32, GPW = 64 / LG;
@@ -398,7 +398,7 @@ int mcom_merge_consensus_units(mcom_ctx *ctx, const uint64_t *d_packed, const ui
 		                   ctx->bs_cap && ctx->bs_cap < (1u << BS_KM) ? ctx->bs_cap : (1u << BS_KM) - 1u);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemcpyAsync(h_nlist, tcount, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_nlist, tcount, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }

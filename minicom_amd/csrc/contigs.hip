@@ -413,8 +413,8 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	const uint32_t limit = max_per_contig ? max_per_contig : 0xFFFFFFFFu;
 	uint64_t chars = chars_bound;
 	if (!d_off_end) {
-		MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_off + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &chars, d_off + n, 8));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
 	// millions of short strings: one lane per string (sketch_scan.hip); wide windows and very long strings stay with the wave per string
 	if (!ctx->sketch_wave_only) {
@@ -448,8 +448,8 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
 	if ((rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, scr))) return rc;
 	std::vector<unsigned long long> fill(arenas);
-	MCOM_HIP(ctx, hipMemcpyAsync(fill.data(), cursor, arenas * 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, fill.data(), cursor, arenas * 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	unsigned long long total = 0, most = 0;
 	for (unsigned long long f : fill) { total += f; most = std::max(most, f); }
 	if (h_total) *h_total = total;
@@ -600,7 +600,7 @@ struct mcom_idx {
 extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 {
 	if (!mi) return;
-	if (ctx) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx) (void)mcom_stream_sync(ctx);
 	if (mi->rec) mcom_dfree(mi->rec);
 	mcom_table_free(&mi->tab);
 	delete mi;
@@ -646,8 +646,8 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 			if (!rc) rc = mcom_bucket_starts(ctx, mi->rec, n, b, bst);
 			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 			std::vector<uint32_t> hb(nb + 1);
-			hipError_t e2 = hipMemcpyAsync(hb.data(), bst, (nb + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
-			if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+			hipError_t e2 = mcom_d2h_async(ctx, hb.data(), bst, (nb + 1) * 4);
+			if (e2 == hipSuccess) e2 = mcom_stream_sync(ctx);
 			if (e2 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "bucket bounds: %s", hipGetErrorString(e2)); }
 			uint32_t mx = 0;
 			for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
@@ -660,7 +660,7 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 				if (!rc) { e2 = hipMemcpyAsync(mi->rec, tmp, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e2)); }
 			} else rc = mcom_flag_sort_ranges(ctx, mi->rec, bst, nb, mx, ovf);
 			uint32_t ov = 0;
-			if (!rc) { e2 = hipMemcpyAsync(&ov, ovf, 4, hipMemcpyDeviceToHost, ctx->stream); if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "index sort: %s", hipGetErrorString(e2)); }
+			if (!rc) { e2 = mcom_d2h_async(ctx, &ov, ovf, 4); if (e2 == hipSuccess) e2 = mcom_stream_sync(ctx); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "index sort: %s", hipGetErrorString(e2)); }
 			if (!rc && ov) rc = mcom_fail(ctx, MCOM_E_OVERFLOW, "index bucket sort ran out of range stack");
 			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 		}
@@ -834,8 +834,8 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
 	uint32_t n_pairs = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&n_pairs, hits + n_query, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_pairs, hits + n_query, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h_counts) h_counts[0] = n_pairs;
 	if (n_pairs == 0) return MCOM_OK;
 	// pass 2: evaluate pairs; the workspace may move, so the offsets are kept in a fresh allocation
@@ -853,13 +853,13 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
 	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
 	uint32_t last_flag = 0, n_pass = 0;
-	e1 = hipMemcpyAsync(&last_flag, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
-	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	e1 = mcom_d2h_async(ctx, &last_flag, pass + (n_pairs - 1), 4);
+	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
 	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate evaluation: %s", hipGetErrorString(e1)); }
 	rc = mcom_scan_u32(ctx, pass, pass, n_pairs, (uint32_t*)ctx->ws);
 	if (rc) { cleanup(); return rc; }
-	e1 = hipMemcpyAsync(&n_pass, pass + (n_pairs - 1), 4, hipMemcpyDeviceToHost, ctx->stream);
-	if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+	e1 = mcom_d2h_async(ctx, &n_pass, pass + (n_pairs - 1), 4);
+	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
 	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate scan: %s", hipGetErrorString(e1)); }
 	n_pass += last_flag;
 	if (h_counts) h_counts[1] = n_pass;
@@ -867,7 +867,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
 		hipLaunchKernelGGL(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
-		e1 = hipStreamSynchronize(ctx->stream);
+		e1 = mcom_stream_sync(ctx);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}
 	cleanup();

@@ -45,8 +45,8 @@ extern "C" int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32
 	const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
 	hipLaunchKernelGGL(k_max_u16, dim3(blocks), dim3(256), 0, ctx->stream, d_v, n, d);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemcpyAsync(h_max, d, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_max, d, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }
 
@@ -119,7 +119,7 @@ extern "C" int mcom_digest(mcom_ctx *ctx, const void *d_data, size_t bytes, uint
 	hipLaunchKernelGGL(k_digest, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_data, bytes, d);
 	hipLaunchKernelGGL(k_digest_fold, dim3(1), dim3(1), 0, ctx->stream, d);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemcpyAsync(h_sum_xor, d + 512, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_sum_xor, d + 512, 16));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }

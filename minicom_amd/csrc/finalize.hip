@@ -123,7 +123,7 @@ extern "C" int mcom_members_finalize(mcom_ctx *ctx, const uint64_t *d_mem, const
 			}
 		}
 	}
-	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);               // the temporaries go back to the pool
+	if (e == hipSuccess) e = mcom_stream_sync(ctx);               // the temporaries go back to the pool
 	mcom_dfree(rec); mcom_dfree(cnt);
 	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "%s", hipGetErrorString(e));
 	return rc;

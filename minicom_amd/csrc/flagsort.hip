@@ -307,8 +307,8 @@ extern "C" int mcom_radix_sort_128x_ref_order(mcom_ctx *ctx, mcom_mm128 *d_a, si
 	rc = mcom_flag_sort_ranges(ctx, d_a, d, 1, (uint32_t)n, d + 2);
 	if (rc) return rc;
 	uint32_t ov = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&ov, d + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &ov, d + 2, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (ov) return mcom_fail(ctx, MCOM_E_OVERFLOW, "radix sort emulation ran out of range stack");
 	return MCOM_OK;
 }

@@ -97,11 +97,11 @@ extern "C" int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, 
 	if ((rc = mcom_scan_u32(ctx, slot, slot, e, scr)) || (rc = mcom_scan_u32(ctx, msz, msz, e, scr)) || (rc = mcom_scan_u32(ctx, rej, rej, e, scr)) ||
 	    (rc = mcom_scan64(ctx, rsz, rsz, e, scr64))) return rc;
 	uint32_t h32[3] = {0, 0, 0}; uint64_t chars = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&h32[0], slot + ng, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&h32[1], msz + ng, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&h32[2], rej + ng, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&chars, rsz + ng, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h32[0], slot + ng, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h32[1], msz + ng, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h32[2], rej + ng, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &chars, rsz + ng, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	h_counts[0] = h32[0]; h_counts[1] = chars; h_counts[2] = h32[1]; h_counts[3] = h32[2];
 	if (n_have + h32[0] + 1 > off_cap || chars_have + chars > seq_cap || members_have + h32[1] > mem_cap || h32[2] > rej_cap)
 		return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig set buffers too small for %u contigs, %llu chars, %u members, %u rejects", h32[0], (unsigned long long)chars, h32[1], h32[2]);
@@ -110,6 +110,6 @@ extern "C" int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, 
 	hipLaunchKernelGGL(k_group_emit, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_members, d_goff, ng, d_keep, d_nkept, d_sv, d_reflen,
 	                   d_refs, ref_stride, slot, msz, rsz, rej, n_have, chars_have, members_have, d_seq, d_soff, d_mem, d_moff, d_rej_rid, d_rej_group);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // the workspace arrays are in use until here
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));                      // the workspace arrays are in use until here
 	return MCOM_OK;
 }

@@ -35,6 +35,10 @@ struct mcom_ctx {
 	uint32_t bs_cap = 0;
 	// contig sketch: true = always the wave-per-string kernel (tests compare the two)
 	bool sketch_wave_only = false;
+	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
+	struct PinWait { void *dst; size_t off, bytes; };
+	unsigned char *pin = nullptr; size_t pin_off = 0;
+	std::vector<PinWait> pin_wait;
 };
 
 // brackets one kernel launch (or a short launch sequence) with events when the profiler is on
@@ -52,6 +56,12 @@ struct McomProfScope {
 };
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
+// A count or a flag back to the host costs a round trip; into pageable memory (a local variable) the runtime stages it and the
+// round trip takes 27 us instead of 15 (tools/ubench/d2h_latency.cpp), several hundred times per job.  mcom_d2h_async sends up to
+// 256 bytes through a pinned page of the context; mcom_stream_sync -- which replaces hipStreamSynchronize on the context's stream
+// everywhere in the library -- hands them to their destinations.  (mcom_fail drops what is still on its way.)
+hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes);
+hipError_t mcom_stream_sync(mcom_ctx *ctx);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
 // recycled device blocks for the library's own objects (api.hip)
 hipError_t mcom_dmalloc(void **out, size_t bytes);

@@ -109,8 +109,8 @@ extern "C" int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	hipLaunchKernelGGL(k_layout, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, d_coff_words, d_clen);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_coff_words, d_coff_words, n + 1, (uint64_t*)ctx->ws))) return rc;
-	MCOM_HIP(ctx, hipMemcpyAsync(h_total_words, d_coff_words + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_total_words, d_coff_words + n, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }
 
@@ -141,9 +141,9 @@ extern "C" int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_woff, d_woff, n + 1, (uint64_t*)ctx->ws))) return rc;
 	unsigned long long hm = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(h_n_windows, d_woff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&hm, mx, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_n_windows, d_woff + n, 8));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &hm, mx, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h_maxlen) *h_maxlen = hm;
 	return MCOM_OK;
 }
@@ -230,8 +230,8 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_jmoff, d_jmoff, nj + 1, (uint64_t*)ctx->ws))) return rc;
 	uint64_t total = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_jmoff + nj, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_jmoff + nj, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (total >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many members in one merge round");
 	const size_t rec_b = al256(total * sizeof(mcom_mm128));
 	if ((rc = mcom_ws_reserve(ctx, rec_b + mcom_sort_ws_bytes(total) + al256(scan64_scratch_elems(nj + 1) * 8) + al256(MCOM_GROUP_SCRATCH(total) * 4) + 1024))) return rc;
@@ -256,9 +256,9 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_jroff, d_jroff, nj + 1, scr))) return rc;
 	unsigned long long hm[2] = {0, 0}; uint64_t chars = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(hm, meta, 16, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&chars, d_jroff + nj, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 16));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &chars, d_jroff + nj, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (hm[1]) return mcom_fail(ctx, MCOM_E_ARG, "member offset beyond %d key bits", key_bits);
 	h_totals[0] = total; h_totals[1] = chars; h_totals[2] = hm[0];
 	return MCOM_OK;
@@ -354,9 +354,9 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	if ((rc = mcom_scan_u32(ctx, toff, toff, nj + 1, scr))) return rc;
 	if ((rc = mcom_scan_u32(ctx, uoff, uoff, nj + 1, scr))) return rc;
 	uint32_t nt = 0, nu = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&nt, toff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&nu, uoff + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nt, toff + nj, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nu, uoff + nj, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (nt > max_tiles || nu > max_units) return mcom_fail(ctx, MCOM_E_ARG, "tile count %u above its bound", nt);
 	if (nu) {
 		// units of 32 columns through the bit-sliced kernel; the tiles it hands back (a unit that more than 127 members reach) through
@@ -374,7 +374,7 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                        // the workspace arrays are in use until here
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));                        // the workspace arrays are in use until here
 	return MCOM_OK;
 }
 
@@ -408,8 +408,8 @@ extern "C" int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uin
 	hipLaunchKernelGGL(k_live_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, at, n, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t cnt = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&cnt, at + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &cnt, at + n, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_n_out = cnt;
 	return MCOM_OK;
 }
@@ -506,8 +506,8 @@ extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uin
 		MCOM_LAUNCH_CHECK(ctx);
 		if ((rc = mcom_scan_u32(ctx, kf, kf, n + 1, scr))) return rc;
 		uint32_t have = 0;
-		MCOM_HIP(ctx, hipMemcpyAsync(&have, kf + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &have, kf + n, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 		if (have != nkeep) return mcom_fail(ctx, MCOM_E_ARG, "%u contigs unflagged but %zu announced", have, nkeep);
 		hipLaunchKernelGGL(k_keep_index, dim3(nb), dim3(256), 0, ctx->stream, d_flag, kf, n, d_keepidx);
 		hipLaunchKernelGGL(k_keep_sizes, dim3(kb), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_soff, d_moff, ss, ms);
@@ -518,9 +518,9 @@ extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uin
 		                   d_seq2, d_soff2, d_mem2, d_moff2);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
-	MCOM_HIP(ctx, hipMemcpyAsync(&h_totals[0], d_soff2 + nj + nkeep, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&h_totals[1], d_moff2 + nj + nkeep, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[0], d_soff2 + nj + nkeep, 8));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[1], d_moff2 + nj + nkeep, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }
 
@@ -555,7 +555,7 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	*h_total = base;
 	if (!d_roff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if ((uint64_t)first_id + nkeep >= (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: record ids overflow");
-	if (nkeep == 0) { MCOM_HIP(ctx, hipMemcpyAsync(d_roff2 + first_id, &base, 4, hipMemcpyHostToDevice, ctx->stream)); MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MCOM_OK; }
+	if (nkeep == 0) { MCOM_HIP(ctx, hipMemcpyAsync(d_roff2 + first_id, &base, 4, hipMemcpyHostToDevice, ctx->stream)); MCOM_HIP(ctx, mcom_stream_sync(ctx)); return MCOM_OK; }
 	if (!d_rec || !d_roff || !d_keepidx || !d_rec2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_ws_reserve(ctx, al256((nkeep + 1) * 4) + al256(mcom_scan_scratch_elems(nkeep + 1) * 4 + 1024) + 256);
 	if (rc) return rc;
@@ -566,8 +566,8 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, sc, sc, nkeep + 1, scr))) return rc;
 	uint32_t kept = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&kept, sc + nkeep, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &kept, sc + nkeep, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = (uint64_t)base + kept;
 	if ((uint64_t)base + kept > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", (unsigned long long)base + kept, cap2);
 	hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,

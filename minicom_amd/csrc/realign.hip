@@ -140,7 +140,7 @@ __global__ void k_dict_ids(const mcom_mm128 *__restrict__ s, size_t n, uint32_t 
 extern "C" void mcom_dicts_free(mcom_ctx *ctx, mcom_dicts *d)
 {
 	if (!d) return;
-	if (ctx) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx) (void)mcom_stream_sync(ctx);
 	for (int j = 0; j < MAXDICT; ++j) { if (d->slots[j]) mcom_dfree(d->slots[j]); if (d->ids[j]) mcom_dfree(d->ids[j]); }
 	delete d;
 }
@@ -186,7 +186,7 @@ extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t 
 		d->slots[j] = t.slots; d->log2cap[j] = t.log2cap; d->numkeys[j] = t.numkeys; d->maxbin[j] = t.maxrun;
 		if (rc) { mcom_dicts_free(ctx, d); return rc; }
 	}
-	hipError_t e = hipStreamSynchronize(ctx->stream);
+	hipError_t e = mcom_stream_sync(ctx);
 	if (e != hipSuccess) { mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_HIP, "dict build: %s", hipGetErrorString(e)); }
 	*out = d;
 	return MCOM_OK;
@@ -678,8 +678,8 @@ extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, u
 		                          d_claim, d_stats, d_mark, (ulonglong2*)d_tuples, cap, d_count);
 		if (!rc) {
 			unsigned long long h = 0;
-			e = hipMemcpyAsync(&h, d_count, 8, hipMemcpyDeviceToHost, ctx->stream);
-			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			e = mcom_d2h_async(ctx, &h, d_count, 8);
+			if (e == hipSuccess) e = mcom_stream_sync(ctx);
 			*h_ntuples = h;
 		}
 	}
@@ -758,8 +758,8 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, f, f, n_sg + 1, scr))) return rc;
 	uint32_t nw = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&nw, f + n_sg, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nw, f + n_sg, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_nwon = nw;
 	if (nw == 0) return MCOM_OK;
 	// the records and the sort workspace live in their own block: the flags above stay where they are
@@ -771,7 +771,7 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	rc = mcom_sort_by_x(ctx, rec, nw, kb, blk + rec_b);
 	if (!rc) hipLaunchKernelGGL(k_claim_emit, dim3((nw + 255) / 256), dim3(256), 0, ctx->stream, rec, (size_t)nw, d_rids, d_flag, d_app_contig, d_app_member);
 	hipError_t e = hipGetLastError();
-	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess) e = mcom_stream_sync(ctx);
 	mcom_dfree(blk);
 	if (rc) return rc;
 	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "claim resolution: %s", hipGetErrorString(e));
@@ -821,8 +821,8 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 	hipLaunchKernelGGL(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned int hf = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&hf, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &hf, flag, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_may_exceed = hf ? 1 : 0;
 	return MCOM_OK;
 }

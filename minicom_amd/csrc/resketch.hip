@@ -144,8 +144,8 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	                   seg_end, d_chars);
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned long long seg_chars = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&seg_chars, d_chars, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &seg_chars, d_chars, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (seg_chars > merged_chars) return mcom_fail(ctx, MCOM_E_ARG, "segments of %llu bases in contigs of %llu", seg_chars, (unsigned long long)merged_chars);
 	if (h_sketched_chars) *h_sketched_chars = seg_chars;
 	uint64_t stotal = 0;
@@ -165,12 +165,12 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, d_roff2, d_roff2, nj + 1, (uint32_t*)ctx->ws))) return rc;
 	uint32_t total = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_roff2 + nj, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_roff2 + nj, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = total;
 	if (total > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap2);
 	hipLaunchKernelGGL(k_rs_write, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));                          // the temporaries go back to the pool
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));                          // the temporaries go back to the pool
 	return MCOM_OK;
 }

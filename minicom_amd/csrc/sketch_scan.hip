@@ -267,9 +267,9 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	hipLaunchKernelGGL(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
 	hipLaunchKernelGGL(k_ssc_order, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
 	uint32_t h2[2] = {0, 0};
-	MCOM_HIP(ctx, hipMemcpyAsync(&h2[0], misc, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipMemcpyAsync(&h2[1], base + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[0], misc, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[1], base + n, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h2[0] >= 32768u) return -1;
 	if (h2[1] > tmp_bound) return mcom_fail(ctx, MCOM_E_HIP, "sketch rooms %u above their bound", h2[1]);
 	const bool oddk = (k & 1) != 0;
@@ -284,22 +284,22 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
 	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;
 	uint32_t total = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&total, d_moff + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_moff + n, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h_total) *h_total = total;
 	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
 	if (total == 0) return MCOM_OK;
 	hipLaunchKernelGGL(k_ssc_gather, dim3((unsigned)(((size_t)nn * 4 + 255) / 256)), dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t n_over = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&n_over, misc + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_over, misc + 1, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (n_over) {                                                            // denser than their room: once more, into their final places
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
 		if (oddk) hipLaunchKernelGGL(k_sketch_scan<true>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
 		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
 		MCOM_LAUNCH_CHECK(ctx);
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
 	return MCOM_OK;
 }

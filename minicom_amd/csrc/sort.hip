@@ -451,8 +451,8 @@ extern "C" int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, s
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	std::vector<uint32_t> start((size_t)ranks + 1);
-	for (int q = 0; q <= ranks; ++q) MCOM_HIP(ctx, hipMemcpyAsync(&start[q], hist + (size_t)q * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int q = 0; q <= ranks; ++q) MCOM_HIP(ctx, mcom_d2h_async(ctx, &start[q], hist + (size_t)q * nblocks, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	for (int q = 0; q < ranks; ++q) h_counts[q] = start[q + 1] - start[q];
 	return MCOM_OK;
 }
@@ -508,8 +508,8 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t novf = 0;
-	MCOM_HIP(ctx, hipMemcpyAsync(&novf, ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &novf, ovf, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (!novf) return MCOM_OK;
 	// tiles that hold a group of thousands of records: gathered, sorted by the whole of x with the global passes (x ascends from
 	// group to group, so the tiles stay apart and their groups in place), put into the output
@@ -530,7 +530,7 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, compact, w2.tmp, m, ks, (bits + 7) / 8, w2.hist, w2.scratch, &res);
 	if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_out, res, ovf_list, ovf_dst, 1);
-	hipError_t e2 = hipStreamSynchronize(ctx->stream);
+	hipError_t e2 = mcom_stream_sync(ctx);
 	mcom_dfree(ws2);
 	if (rc) return rc;
 	if (e2 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "oversized groups: %s", hipGetErrorString(e2));
@@ -666,8 +666,8 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 			                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf_count, ovf_list);
 			MCOM_LAUNCH_CHECK(ctx);
 		}
-		MCOM_HIP(ctx, hipMemcpyAsync(&novf, ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-		MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &novf, ovf_count, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 		ctx->sort_overflow_segments += novf;
 		if (novf) {
 			// segments beyond the LDS arrays (one minimizer shared by thousands of reads): gathered, sorted by the whole key with the
@@ -687,7 +687,7 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 			mcom_mm128 *res = nullptr;
 			rc = radix_sort_records(ctx, w.tmp, w2.tmp, m, full, (2 * kmer + 9 + 7) / 8, w2.hist, w2.scratch, &res);
 			if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, res, ovf_list, ovf_dst, 1);
-			hipError_t e2 = hipStreamSynchronize(ctx->stream);
+			hipError_t e2 = mcom_stream_sync(ctx);
 			mcom_dfree(ws2);
 			if (rc) return rc;
 			if (e2 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "oversized segments: %s", hipGetErrorString(e2));
@@ -702,7 +702,7 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 	hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, d_sorted, n, d_counts);
 	hipLaunchKernelGGL(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_single_ord, d_members, d_group_off, d_counts);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_counts, d_counts, 4 * sizeof(uint64_t)));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	return MCOM_OK;
 }

@@ -84,8 +84,8 @@ int mcom_table_build_bucketed(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n,
 	hipLaunchKernelGGL(k_table_bucket, dim3(1u << bbits), dim3(256), lds, ctx->stream, sorted, bstart, bbits, lr, t->slots, meta);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t hm[2] = {0, 0};
-	MCOM_HIP(ctx, hipMemcpyAsync(hm, meta, 8, hipMemcpyDeviceToHost, ctx->stream));
-	MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	t->numkeys = hm[0]; t->maxrun = hm[1];
 	return MCOM_OK;
 }
@@ -104,7 +104,7 @@ int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t
 	hipError_t e = mcom_dmalloc(&t->slots, (size_t)16 << lg);
 	if (e != hipSuccess) { t->slots = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "hash table of %zu bytes: %s", (size_t)16 << lg, hipGetErrorString(e)); }
 	MCOM_HIP(ctx, hipMemsetAsync(t->slots, 0xFF, (size_t)16 << lg, ctx->stream));
-	if (n == 0) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); return MCOM_OK; }
+	if (n == 0) { MCOM_HIP(ctx, mcom_stream_sync(ctx)); return MCOM_OK; }
 	// own buffers (the caller's head / scr arrays are sized for n entries; the head list needs n + 1 and n + 2)
 	(void)head; (void)scr;
 	const size_t scr_elems = mcom_scan_scratch_elems(n + 1) + 256;
@@ -119,15 +119,15 @@ int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t
 	if (!rc) {
 		hipLaunchKernelGGL(k_table_head_list, dim3(blocks), dim3(256), 0, ctx->stream, sorted, n, hpre, hidx);
 		e3 = hipMemsetAsync(meta, 0, 8, ctx->stream);
-		if (e3 == hipSuccess) e3 = hipMemcpyAsync(&nh, hpre + n, 4, hipMemcpyDeviceToHost, ctx->stream);
-		if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+		if (e3 == hipSuccess) e3 = mcom_d2h_async(ctx, &nh, hpre + n, 4);
+		if (e3 == hipSuccess) e3 = mcom_stream_sync(ctx);
 	}
 	uint32_t hm[2] = {0, 0};
 	if (!rc && e3 == hipSuccess && nh) {
 		hipLaunchKernelGGL(k_table_insert, dim3((nh + 255) / 256), dim3(256), 0, ctx->stream, sorted, hidx, nh, t->slots, lg, meta);
 		e3 = hipGetLastError();
-		if (e3 == hipSuccess) e3 = hipMemcpyAsync(hm, meta, 8, hipMemcpyDeviceToHost, ctx->stream);
-		if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+		if (e3 == hipSuccess) e3 = mcom_d2h_async(ctx, hm, meta, 8);
+		if (e3 == hipSuccess) e3 = mcom_stream_sync(ctx);
 	}
 	mcom_dfree(buf);
 	if (rc) return rc;
