@@ -114,7 +114,7 @@ def _construct_ref(reads, members, L, k, e):
     return keep, new, sv, ACGT[second[sv:rend]].tobytes()
 
 
-@pytest.mark.parametrize("L,k,e", [(100, 31, 4), (150, 31, 4), (64, 17, 2)])
+@pytest.mark.parametrize("L,k,e", [(100, 31, 4), (150, 31, 4), (64, 17, 2), (250, 31, 4), (40, 17, 2), (33, 11, 1)])
 def test_group_consensus_and_groups_to_contigs(ctx, L, k, e):
     rng = np.random.default_rng(L + e)
     reads, packed, members, goff = _make_groups(rng, 400, L, k, e)
@@ -176,11 +176,11 @@ def _random_set(rng, n, L):
     return refs, mems, reads, pack_nt4(reads)
 
 
-def test_merge_round_pieces_against_numpy(ctx):
+@pytest.mark.parametrize("L", [100, 150, 250, 40])
+def test_merge_round_pieces_against_numpy(ctx, L):
     """One merge round on a random set: member merge, consensus (every column, and overlap only), carry of the rest."""
     import torch
-    L = 100
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + L)
     n = 300
     refs, mems, reads, packed = _random_set(rng, n, L)
     soff = np.concatenate([[0], np.cumsum([len(r) for r in refs])]).astype(np.int64)
