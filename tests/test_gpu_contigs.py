@@ -172,7 +172,7 @@ def test_radix_sort_ref_order_reproduces_the_reference_permutation(ctx, kat):
         assert [[int(p["x"]), int(p["y"])] for p in got] == t["out"]
 
 
-@pytest.mark.parametrize("n,nkeys,nbuckets", [(40000, 300, 7), (200000, 5000, 64), (30000, 30000, 16384)])
+@pytest.mark.parametrize("n,nkeys,nbuckets", [(40000, 300, 7), (200000, 5000, 64), (30000, 30000, 16384), (150000, 400, 2)])
 def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, nbuckets):
     """Index buckets far above 64 entries with many equal minimizers: mm_idx's order (kthread_idx.c:126,154) exactly."""
     import torch
