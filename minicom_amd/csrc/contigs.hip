@@ -674,13 +674,13 @@ extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, 
 	return MCOM_OK;
 }
 
-__global__ void k_idx_get(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t log2region, uint32_t bbits, const uint64_t *__restrict__ x, size_t n,
+__global__ void k_idx_get(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t region, uint32_t bbits, const uint64_t *__restrict__ x, size_t n,
                           uint32_t *__restrict__ start, uint32_t *__restrict__ count)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	uint32_t s = 0, c = 0;
-	if (x[i] != U64MAX) mcom_table_find_any(slots, log2cap, log2region, bbits, x[i], s, c);
+	if (x[i] != U64MAX) mcom_table_find_any(slots, log2cap, region, bbits, x[i], s, c);
 	start[i] = s; count[i] = c;
 }
 
@@ -689,7 +689,7 @@ extern "C" int mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d
 	if (!ctx || !mi) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_x || !d_start || !d_count) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.log2region, mi->tab.bbits, d_x, n, d_start, d_count);
+	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_x, n, d_start, d_count);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -755,13 +755,13 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 // The flags the reference also tests (:286) change while it merges, so they are left to the caller, who
 // walks each contig's candidates in this order and takes the first whose partner is still free.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t log2region, uint32_t bbits, const mcom_mm128 *__restrict__ q, size_t nq,
+__global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t region, uint32_t bbits, const mcom_mm128 *__restrict__ q, size_t nq,
                             uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
 	uint32_t s = 0, c = 0;
-	if (q[i].x != U64MAX) mcom_table_find_any(slots, log2cap, log2region, bbits, q[i].x, s, c);
+	if (q[i].x != U64MAX) mcom_table_find_any(slots, log2cap, region, bbits, q[i].x, s, c);
 	hits[i] = c; first[i] = s;                     // the later passes read these instead of probing the table again
 }
 // one thread per query: walks its hits, tests, writes a pass flag per (query, hit) pair at pair_off[q] + k
@@ -828,7 +828,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
-	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.log2region, mi->tab.bbits, d_query, n_query, hits, first);
+	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));

@@ -157,13 +157,14 @@ template <class F> __device__ __forceinline__ uint32_t mcom_block_search(uint32_
 // ---- exact key -> (run start, run length) map over a sorted record array (table.hip) ---------------------
 // Open addressing, linear probing, 16-byte slots {key, start | count << 32}, EMPTY key = ~0, load <= 0.5.
 // Bucketed form (the contig-minimizer index, whose records are sorted by bucket x & (2^bbits - 1) first): bucket v owns the
-// region of 2^log2region slots starting at v << log2region, a key probes inside its bucket's region only -- so the table is
-// BUILT bucket by bucket in LDS and written once, in order (table.hip), instead of by scattered atomicCAS.  log2region = 0:
+// region of `region` slots (any number, a multiple of four: 64-byte lines) starting at v * region, a key probes inside its bucket's
+// region only -- so the table is BUILT bucket by bucket in LDS and written once, in order (table.hip), instead of by scattered
+// atomicCAS, and it is as large as the fullest bucket asks for, not the next power of two.  region = 0:
 // one global table.
 struct McomTable {
 	uint64_t *slots; uint32_t log2cap;
 	uint32_t numkeys, maxrun;
-	uint32_t log2region, bbits;
+	uint32_t region, bbits;
 };
 // sorted: n records sorted by x (runs of equal x are the bins); head/scr: scratch of n and
 // mcom_scan_scratch_elems(n)+256 uint32; meta: 2 uint32 on the device.  Synchronous.
@@ -189,16 +190,19 @@ __device__ __forceinline__ bool mcom_table_find(const uint64_t *slots, uint32_t 
 		sl = (sl + 1) & capm;
 	}
 }
-__device__ __forceinline__ bool mcom_table_find_any(const uint64_t *slots, uint32_t log2cap, uint32_t log2region, uint32_t bbits, uint64_t key, uint32_t &start, uint32_t &count)
+__device__ __forceinline__ uint32_t mcom_region_slot(uint64_t key, uint32_t region)
 {
-	if (!log2region) return mcom_table_find(slots, log2cap, key, start, count);
-	const uint64_t base = (key & ((1ull << bbits) - 1)) << log2region;
-	const uint32_t rm = (1u << log2region) - 1u;
-	uint32_t sl = mcom_slot_of(key >> bbits, log2region);
+	return (uint32_t)((((key * 0x9E3779B97F4A7C15ull) >> 32) * (uint64_t)region) >> 32);
+}
+__device__ __forceinline__ bool mcom_table_find_any(const uint64_t *slots, uint32_t log2cap, uint32_t region, uint32_t bbits, uint64_t key, uint32_t &start, uint32_t &count)
+{
+	if (!region) return mcom_table_find(slots, log2cap, key, start, count);
+	const uint64_t base = (key & ((1ull << bbits) - 1)) * (uint64_t)region;
+	uint32_t sl = mcom_region_slot(key >> bbits, region);
 	for (;;) {
 		const uint64_t k = slots[2 * (base + sl)];
 		if (k == key) { const uint64_t v = slots[2 * (base + sl) + 1]; start = (uint32_t)v; count = (uint32_t)(v >> 32); return true; }
 		if (k == ~0ull) return false;
-		sl = (sl + 1) & rm;
+		sl = sl + 1 == region ? 0 : sl + 1;
 	}
 }

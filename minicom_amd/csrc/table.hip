@@ -39,11 +39,10 @@ __global__ void k_table_insert(const mcom_mm128 *__restrict__ s, const uint32_t 
 }
 
 // ---- bucketed build: one workgroup per bucket, the bucket's region of the table assembled in LDS and written in one piece ----
-__global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restrict__ s, const uint32_t *__restrict__ bstart, int bbits, uint32_t log2region,
+__global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restrict__ s, const uint32_t *__restrict__ bstart, int bbits, uint32_t R,
                                                       uint64_t *__restrict__ slots, uint32_t *__restrict__ meta /* [0] keys, [1] longest run */)
 {
-	extern __shared__ unsigned long long reg[];                               // [2^log2region][2]: key, start | count << 32
-	const uint32_t R = 1u << log2region, rm = R - 1u;
+	extern __shared__ unsigned long long reg[];                               // [R][2]: key, start | count << 32
 	const uint32_t v = blockIdx.x;
 	const uint32_t b0 = bstart[v], b1 = bstart[v + 1];
 	for (uint32_t q = threadIdx.x; q < 2 * R; q += 256) reg[q] = ~0ull;
@@ -54,34 +53,34 @@ __global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restri
 		if (i > b0 && s[i - 1].x == key) continue;                              // not the head of its run
 		uint32_t e = i + 1;
 		while (e < b1 && s[e].x == key) ++e;
-		uint32_t sl = mcom_slot_of(key >> bbits, log2region);
-		while (atomicCAS(&reg[2 * sl], ~0ull, (unsigned long long)key) != ~0ull) sl = (sl + 1) & rm;
+		uint32_t sl = mcom_region_slot(key >> bbits, R);
+		while (atomicCAS(&reg[2 * sl], ~0ull, (unsigned long long)key) != ~0ull) sl = sl + 1 == R ? 0 : sl + 1;
 		reg[2 * sl + 1] = (unsigned long long)i | ((unsigned long long)(e - i) << 32);
 		++heads; longest = e - i > longest ? e - i : longest;
 	}
 	for (int o = 32; o; o >>= 1) { heads += __shfl_xor(heads, o); const uint32_t t = __shfl_xor(longest, o); longest = t > longest ? t : longest; }
 	if ((threadIdx.x & 63) == 0) { if (heads) atomicAdd(&meta[0], heads); if (longest > meta[1]) atomicMax(&meta[1], longest); }
 	__syncthreads();
-	ulonglong2 *dst = (ulonglong2*)(slots + 2 * ((size_t)v << log2region));
+	ulonglong2 *dst = (ulonglong2*)(slots + 2 * ((size_t)v * R));
 	for (uint32_t q = threadIdx.x; q < R; q += 256) dst[q] = make_ulonglong2(reg[2 * q], reg[2 * q + 1]);
 }
 
 int mcom_table_build_bucketed(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, const uint32_t *bstart, int bbits, uint32_t max_bucket,
                               uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t)
 {
-	uint32_t lr = 4;
-	while ((1u << lr) < max_bucket + (max_bucket >> 2) + (max_bucket >> 3) + 16) ++lr;   // a region is at most 0.73 full if every record of the bucket were a key of its own
-	                                                                            // (about half of them are): half the LDS per workgroup and half the table to write and to
-	                                                                            // miss in, against a rare third probe
-	if (n == 0 || bbits < 1 || lr > 13 || ((size_t)16 << (lr + bbits)) > ((size_t)64 << 30))   // 2^13 slots = 128 KB of LDS; a larger bucket: the global table
+	// a region holds the fullest bucket at most 0.73 full if every record of it were a key of its own (about half of them are):
+	// as many slots as that asks for, a multiple of four -- not the next power of two, which wrote and cleared up to twice the table
+	const uint32_t R = (max_bucket + (max_bucket >> 2) + (max_bucket >> 3) + 16 + 3) & ~3u;
+	if (n == 0 || bbits < 1 || R > 8192 || ((size_t)16 * R << bbits) > ((size_t)64 << 30))   // 8192 slots = 128 KB of LDS; a larger bucket: the global table
 		return mcom_table_build(ctx, sorted, n, head, scr, meta, t);
-	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->log2region = lr; t->bbits = (uint32_t)bbits; t->log2cap = lr + (uint32_t)bbits;
-	hipError_t e = mcom_dmalloc(&t->slots, (size_t)16 << t->log2cap);
-	if (e != hipSuccess) { t->slots = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "hash table of %zu bytes: %s", (size_t)16 << t->log2cap, hipGetErrorString(e)); }
+	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->region = R; t->bbits = (uint32_t)bbits; t->log2cap = 0;
+	const size_t bytes = (size_t)16 * R << bbits;
+	hipError_t e = mcom_dmalloc(&t->slots, bytes);
+	if (e != hipSuccess) { t->slots = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "hash table of %zu bytes: %s", bytes, hipGetErrorString(e)); }
 	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 8, ctx->stream));
-	const size_t lds = (size_t)16 << lr;
+	const size_t lds = (size_t)16 * R;
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_table_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_table_bucket, dim3(1u << bbits), dim3(256), lds, ctx->stream, sorted, bstart, bbits, lr, t->slots, meta);
+	hipLaunchKernelGGL(k_table_bucket, dim3(1u << bbits), dim3(256), lds, ctx->stream, sorted, bstart, bbits, R, t->slots, meta);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t hm[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 8));
@@ -97,7 +96,7 @@ void mcom_table_free(McomTable *t)
 
 int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t)
 {
-	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->log2region = 0; t->bbits = 0;
+	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->region = 0; t->bbits = 0;
 	uint32_t lg = 4;
 	while ((1ull << lg) < 2 * n + 16) ++lg;
 	t->log2cap = lg;

@@ -25,6 +25,10 @@ print(f"step {step}: {len(rows)} launches, span {(t1 - t0) / 1e6:.1f} ms, kernel
 for k, v in busy.most_common(45):
     print(f"{v / 1e6:8.2f} ms {calls[k]:5d}  {k[:70]}")
 print("largest gaps (ms, before kernel):", [(round(g / 1e6, 2), k[:24]) for g, k in sorted(gaps, reverse=True)[:14]])
+byk = collections.Counter(); cnt = collections.Counter()
+for g, k in gaps:
+    byk[k] += g; cnt[k] += 1
+print("idle by the kernel that ended it (ms, count):", [(k[:22], round(v / 1e6, 2), cnt[k]) for k, v in byk.most_common(16)])
 hist = collections.Counter()
 for g, _ in gaps:
     hist[min(6, len(str(g // 1000)))] += g
