@@ -20,7 +20,7 @@ __global__ void k_claim_bid(const mcom_mm128 *__restrict__ pairs, size_t n, cons
 	if (matched[ci] || matched[cj]) { dead[e] = 1; return; }
 	atomicMin(&best[ci], (unsigned int)e);
 	atomicMin(&best[cj], (unsigned int)e);
-	*any_live = 1;
+	if (*(volatile unsigned int*)any_live == 0) *any_live = 1;            // filtered: millions of stores to one address would queue up on its L2 channel
 }
 __global__ void k_claim_take(const mcom_mm128 *__restrict__ pairs, size_t n, uint8_t *__restrict__ matched, uint8_t *__restrict__ dead,
                              const unsigned int *__restrict__ best, uint32_t *__restrict__ sel)
