@@ -280,6 +280,10 @@ int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sg
  * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
  * neither the dictionaries nor d_elig; 1 = build them and look.  Synchronous.                                */
 int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed);
+/* the same in two steps: _begin puts the counting on the context's stream and returns, _end waits and answers (so that a caller
+ * can run the screen on a second context / stream beside other work)                                                     */
+int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch);
+int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed);
 int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom,
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,

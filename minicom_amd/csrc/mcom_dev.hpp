@@ -35,6 +35,7 @@ struct mcom_ctx {
 	uint32_t bs_cap = 0;
 	// contig sketch: true = always the wave-per-string kernel (tests compare the two)
 	bool sketch_wave_only = false;
+	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
 	struct PinWait { void *dst; size_t off, bytes; };
 	unsigned char *pin = nullptr; size_t pin_off = 0;

@@ -798,10 +798,13 @@ __global__ void k_bin_screen_max(const unsigned int *__restrict__ table, size_t 
 	if (i < n && table[i] > maxsearch) *exceeded = 1;
 }
 
-extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)
+// begin: the counting kernels are put on the context's stream and the call returns; end: waits for them and reads the answer.
+// (mcom_dicts_screen is the two in one.  The pipeline runs the screen on a second stream beside the contig index build: the
+// two use different parts of the memory system -- atomics against streaming writes.)
+extern "C" int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch)
 {
-	if (!ctx || !h_may_exceed) return MCOM_E_ARG;
-	*h_may_exceed = 0;
+	if (!ctx) return MCOM_E_ARG;
+	ctx->screen_flag = nullptr;
 	if (n_sg == 0) return MCOM_OK;
 	CixGeom g;
 	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
@@ -820,9 +823,25 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag);
 	hipLaunchKernelGGL(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
 	MCOM_LAUNCH_CHECK(ctx);
+	ctx->screen_flag = flag;
+	return MCOM_OK;
+}
+extern "C" int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed)
+{
+	if (!ctx || !h_may_exceed) return MCOM_E_ARG;
+	*h_may_exceed = 0;
+	if (!ctx->screen_flag) return MCOM_OK;
 	unsigned int hf = 0;
-	MCOM_HIP(ctx, mcom_d2h_async(ctx, &hf, flag, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &hf, ctx->screen_flag, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	ctx->screen_flag = nullptr;
 	*h_may_exceed = hf ? 1 : 0;
 	return MCOM_OK;
+}
+extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)
+{
+	if (!ctx || !h_may_exceed) return MCOM_E_ARG;
+	*h_may_exceed = 0;
+	const int rc = mcom_dicts_screen_begin(ctx, d_sgbits, n_sg, L, ininumdict, maxsearch);
+	return rc ? rc : mcom_dicts_screen_end(ctx, h_may_exceed);
 }

@@ -208,6 +208,10 @@ struct mcomh_pipeline {
 	// second stream: transfers that nobody on the main stream waits for (the read classes going to the host, the singleton list
 	// coming up for Stage 2); in-stream they held the next kernels back for milliseconds
 	hipStream_t copy_stream = nullptr; hipEvent_t ev_main = nullptr, ev_sg = nullptr;
+	// a second library context on the copy stream: the first Stage-2 pass gathers the singletons' rows and runs the dictionary screen
+	// there, beside the contig index build on the main stream (atomics against streaming writes); what it leaves for the pass
+	mcom_ctx *ctx2 = nullptr; hipEvent_t ev_early = nullptr; int device = 0; bool prof_on = false;
+	struct Early { bool on = false; size_t n_sg = 0; DevBuf<uint32_t> sg; DevBuf<uint64_t> sgbits; } early;
 	PinVec<uint32_t> sg_pin; bool sg_uploaded = false;
 	ContigSet C, Cnext;                      // Cnext: the other half of a double buffer, kept to reuse its memory
 	// Stage 2 never reads the member lists, so the appends of the passes stay on the device (contig, member; in the
@@ -338,6 +342,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->stream = (hipStream_t)hip_stream;
 	int rc = mcom_create(&p->ctx, device, hip_stream);
 	if (rc) { delete p; return rc; }
+	p->device = device;
 	p->n = n; p->L = L; p->W = (2 * L + 63) / 64; p->NW = (L + 63) / 64;
 	p->k = pp->k > 0 ? pp->k : (L < 80 ? 17 : 31);                                  // minicommain.c:92-114
 	p->e = pp->e > 0 ? pp->e : 4;
@@ -438,6 +443,8 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (p->ev_main) (void)hipEventDestroy(p->ev_main);
 	if (p->ev_sg) (void)hipEventDestroy(p->ev_sg);
 	if (p->ev_cls) (void)hipEventDestroy(p->ev_cls);
+	if (p->ev_early) (void)hipEventDestroy(p->ev_early);
+	if (p->ctx2) mcom_destroy(p->ctx2);
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
 }
@@ -1324,6 +1331,21 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	{ const double tu = now_ms(); mcomh_update_single(p); p->stat["t_ra_update"] += now_ms() - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
+	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && p->sg_uploaded && !p->early.on) {
+		// singletons' rows and the dictionary screen on the copy stream (behind the upload of the singleton list, which went there),
+		// while this thread builds the contig index on the main stream
+		P::Early &E = p->early;
+		bool ok = true;
+		if (!p->ctx2) { ok = mcom_create(&p->ctx2, p->device, p->copy_stream) == MCOM_OK; if (ok && p->prof_on) (void)mcom_prof_enable(p->ctx2, 1); }
+		if (ok && !p->ev_early) ok = hipEventCreateWithFlags(&p->ev_early, hipEventDisableTiming) == hipSuccess;
+		if (ok && E.sgbits.reserve(n_sg * p->W)) {
+			E.sg.swap(p->d_sg_live); p->sg_live_valid = false;
+			if (mcom_gather_rows(p->ctx2, p->d_packed.p, E.sg.p, n_sg, p->L, E.sgbits.p) == MCOM_OK &&
+			    hipEventRecord(p->ev_early, p->copy_stream) == hipSuccess &&
+			    mcom_dicts_screen_begin(p->ctx2, E.sgbits.p, n_sg, p->L, p->numdict, p->maxsearch) == MCOM_OK) { E.on = true; E.n_sg = n_sg; }
+			else { (void)hipStreamSynchronize(p->copy_stream); p->d_sg_live.swap(E.sg); p->sg_live_valid = true; }   // as before
+		}
+	}
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
 		{                                                      // the set is on the device: lay it out and pack it there
 			uint64_t tw = 0;
@@ -1378,11 +1400,15 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		const double tg = now_ms();
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
 		if (!d_sg.reserve(n_sg) || !d_sgbits.reserve(n_sg * p->W) || !d_claim.reserve(n_sg) || !d_flag.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
-		if (p->sg_live_valid && p->n_sg_live == n_sg) {                                       // left by the pass before, or sent up beside the set-up
+		const bool early = p->early.on && p->early.n_sg == n_sg;
+		if (early) {                                                                         // gathered on the copy stream beside the index build
+			d_sg.swap(p->early.sg); d_sgbits.swap(p->early.sgbits);
+			if ((rc = p->hipc(hipStreamWaitEvent(p->stream, p->ev_early, 0), "wait"))) return rc;
+		} else if (p->sg_live_valid && p->n_sg_live == n_sg) {                                // left by the pass before, or sent up beside the set-up
 			d_sg.swap(p->d_sg_live); p->sg_live_valid = false;
 			if ((rc = p->hipc(hipStreamWaitEvent(p->stream, p->ev_sg, 0), "wait"))) return rc;
 		} else if ((rc = p->h2d(d_sg.p, p->sg.data(), n_sg, "upload singletons"))) return rc;
-		if ((rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;           // singleRead2bitset
+		if (!early && (rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_sg.p, n_sg, p->L, d_sgbits.p)))) return rc;   // singleRead2bitset
 		if ((rc = p->gpu(mcom_poly_filter(p->ctx, d_sgbits.p, p->d_nmask.p, d_sg.p, n_sg, p->L, thr, d_flag.p)))) return rc;
 		PinVec<uint8_t> &pf = p->raw_flags;
 		p->raw_flags_valid = false;
@@ -1397,7 +1423,10 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		int may_exceed = 1;
 		// (singletons only leave between the passes of one Stage 2, so a bin never grows: once the screen has proved that none
 		// exceeds maxsearch, it holds for the later passes too)
-		if (p->screen_clear) may_exceed = 0;
+		if (early) {
+			p->early.on = false;
+			if ((rc = mcom_dicts_screen_end(p->ctx2, &may_exceed))) return p->fail(rc, "%s", mcom_last_error(p->ctx2));
+		} else if (p->screen_clear) may_exceed = 0;
 		else if (!p->window_scan && (rc = p->gpu(mcom_dicts_screen(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, &may_exceed)))) return rc;
 		if (!may_exceed && !p->window_scan) p->screen_clear = true;
 		if (may_exceed) {
@@ -1685,10 +1714,22 @@ extern "C" int mcomh_result_digest(mcomh_pipeline *p, uint64_t out[8])
 	return MCOM_OK;
 }
 
-extern "C" int mcomh_prof_enable(mcomh_pipeline *p, int on) { return p ? mcom_prof_enable(p->ctx, on) : MCOM_E_ARG; }
+extern "C" int mcomh_prof_enable(mcomh_pipeline *p, int on)
+{
+	if (!p) return MCOM_E_ARG;
+	p->prof_on = on != 0;
+	if (p->ctx2) (void)mcom_prof_enable(p->ctx2, on);
+	return mcom_prof_enable(p->ctx, on);
+}
 extern "C" int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *total_ms, uint64_t *launches)
 {
-	return p ? p->gpu(mcom_prof_read(p->ctx, name, total_ms, launches)) : MCOM_E_ARG;
+	if (!p) return MCOM_E_ARG;
+	int rc = p->gpu(mcom_prof_read(p->ctx, name, total_ms, launches));
+	if (!rc && p->ctx2) {                                                    // what ran on the copy stream's context counts too
+		double ms2 = 0; uint64_t l2 = 0;
+		if (mcom_prof_read(p->ctx2, name, &ms2, &l2) == MCOM_OK) { if (total_ms) *total_ms += ms2; if (launches) *launches += l2; }
+	}
+	return rc;
 }
 extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 {
