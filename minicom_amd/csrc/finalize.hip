@@ -29,12 +29,12 @@ __global__ void k_mf_cnt(const uint32_t *__restrict__ ac, size_t n, unsigned lon
 __global__ __launch_bounds__(256) void k_mf_base(const uint64_t *__restrict__ mem, const uint64_t *__restrict__ moff, const uint64_t *__restrict__ moff2, size_t n, int kb,
                                                  mcom_mm128 *__restrict__ rec)
 {
-	const size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;     // sixteen lanes per contig
 	if (c >= n) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	const uint64_t a = moff[c], b = moff[c + 1], d = moff2[c];
 	const uint64_t hi = (uint64_t)c << kb;
-	for (uint64_t q = a + lane; q < b; q += 64) { const uint64_t y = mem[q]; mcom_mm128 r; r.x = hi | (uint64_t)(uint32_t)y; r.y = y; rec[d + (q - a)] = r; }
+	for (uint64_t q = a + lane; q < b; q += 16) { const uint64_t y = mem[q]; mcom_mm128 r; r.x = hi | (uint64_t)(uint32_t)y; r.y = y; rec[d + (q - a)] = r; }
 }
 // what one pass appended, behind what the contig holds so far: the pass's list ascends in the contig (the claim key starts with it,
 // realign.hip), so a member's place among its contig's appends is its distance from the first entry of that contig
@@ -104,7 +104,7 @@ extern "C" int mcom_members_finalize(mcom_ctx *ctx, const uint64_t *d_mem, const
 	if (e == hipSuccess) {
 		rc = mcom_scan64(ctx, (const uint64_t*)cnt, d_moff2, n_contigs + 1, (uint64_t*)scr);
 		if (!rc) {
-			hipLaunchKernelGGL(k_mf_base, dim3((unsigned)((n_contigs * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, d_moff2, n_contigs, key_bits, rec);
+			hipLaunchKernelGGL(k_mf_base, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, d_moff2, n_contigs, key_bits, rec);
 			for (int i = 0; i < n_passes; ++i) {
 				if (!h_app_n[i]) continue;
 				const unsigned blocks = (unsigned)((h_app_n[i] + 255) / 256);

@@ -92,21 +92,21 @@ __global__ void k_rs_count(const RsPlan *__restrict__ plan, size_t nj, const mco
 __global__ __launch_bounds__(256) void k_rs_write(const RsPlan *__restrict__ plan, const RsCut *__restrict__ cut, size_t nj, const mcom_mm128 *__restrict__ rec,
                                                   const mcom_mm128 *__restrict__ srec, const uint32_t *__restrict__ roff2, mcom_mm128 *__restrict__ out)
 {
-	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;     // sixteen lanes per job: a merged contig holds a few dozen records
 	if (j >= nj) return;
-	const int lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 15;
 	const RsPlan P = plan[j]; const RsCut C = cut[j];
 	const uint64_t id = (uint64_t)((uint32_t)j << 8) << 32;                  // (index<<8)+tid at tid 0, kthread_bucket.c:458
 	mcom_mm128 *dst = out + roff2[j];
-	for (uint32_t t = lane; t < C.nl; t += 64) { mcom_mm128 r = rec[C.l0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); dst[t] = r; }
+	for (uint32_t t = lane; t < C.nl; t += 16) { mcom_mm128 r = rec[C.l0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); dst[t] = r; }
 	dst += C.nl;
-	for (uint32_t t = lane; t < C.nm; t += 64) {
+	for (uint32_t t = lane; t < C.nm; t += 16) {
 		mcom_mm128 r = srec[C.m0 + t];
 		r.y = id | (uint64_t)((((uint32_t)r.y >> 1) + (uint32_t)P.s0) << 1) | (r.y & 1ull);
 		dst[t] = r;
 	}
 	dst += C.nm;
-	for (uint32_t t = lane; t < C.nt; t += 64) {
+	for (uint32_t t = lane; t < C.nt; t += 16) {
 		mcom_mm128 r = rec[C.t0 + t];
 		r.y = id | (uint64_t)((((uint32_t)r.y >> 1) + P.tail_off) << 1) | (r.y & 1ull);
 		dst[t] = r;
@@ -169,7 +169,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = total;
 	if (total > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap2);
-	hipLaunchKernelGGL(k_rs_write, dim3((unsigned)((nj * 64 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
+	hipLaunchKernelGGL(k_rs_write, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                          // the temporaries go back to the pool
 	return MCOM_OK;
