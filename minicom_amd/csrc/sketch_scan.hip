@@ -19,6 +19,7 @@
 // is scanned once more, straight into its final place.
 #include "mcom_dev.hpp"
 #include <algorithm>
+#include <type_traits>
 
 
 namespace {
@@ -153,26 +154,26 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	uint64_t ahead = issue8(0, ahead_sh);
 	uint64_t first8 = 0;
 	if (tiny) for (uint32_t q = 0; q < len; ++q) first8 |= (uint64_t)s[q] << (8 * q);
-	for (uint32_t i = 0; i < maxlen; ++i) {
-		if ((i & 7u) == 0) {                                                 // the next eight characters travel while these are scanned
-			chunk = ahead_sh < 64 ? ahead >> ahead_sh : (i == 0 ? first8 : 0ull);
-			ahead = issue8(i + 8, ahead_sh);
-		}
+	// One position of the scan.  FAST (k odd only): every lane of the wave is inside its string, past its first full window
+	// (run >= w + k) and reads A, C, G or T -- the steady state of nearly every iteration -- so the tests on all that, the run
+	// counter's cases and the first-window rule drop out of the body.
+	auto scan_step = [&](const uint32_t i, auto fast_tag) {
+		constexpr bool FAST = decltype(fast_tag)::value;
 		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
 		step = i;
 		const uint32_t u = ch & 0xDFu;                                       // fold case
-		const bool in = i < len;
-		const bool base = in && (u == 'A' || u == 'C' || u == 'G' || u == 'T');
+		const bool in = FAST || i < len;
+		const bool base = FAST || (in && (u == 'A' || u == 'C' || u == 'G' || u == 'T'));
 		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;                     // A0 C1 G2 T3
 		// Straight-line code with selects: a wave that is alone on its SIMD (the rings fill the LDS) pays for every taken branch with
 		// an instruction-fetch bubble, and this loop body used to hold nineteen of them.
 		const uint64_t nf = (fwd << 2 | c) & mask, nr = (rev >> 2) | ((3ull ^ c) << shift1);
 		fwd = base ? nf : fwd; rev = base ? nr : rev;
-		const bool pal = base && fwd == rev;                                 // a k-mer equal to its reverse complement stores nothing (:133)
+		const bool pal = !FAST && base && fwd == rev;                        // a k-mer equal to its reverse complement stores nothing (:133)
 		const bool stored = in && !pal;                                      // an ambiguous base stores an empty entry and resets the run
 		const uint32_t z = fwd < rev ? 0u : 1u;
-		run = base ? (pal ? run : run + 1) : (in ? 0 : run);
-		const bool real = base && !pal && run >= k;
+		run = FAST ? run + 1 : (base ? (pal ? run : run + 1) : (in ? 0 : run));
+		const bool real = FAST || (base && !pal && run >= k);
 		const uint64_t hx = mcom_hash64(z ? rev : fwd, mask);
 		const uint64_t cx = real ? hx : U64MAX;
 		const uint32_t cy = real ? ((i << 1) | z) : 0xFFFFFFFFu;
@@ -181,11 +182,13 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 			const bool lt = stored && (slot == 0 || cx < lap_x), eq = stored && !lt && cx == lap_x;
 			lap_x = lt ? cx : lap_x; lap_slot = (lt || eq) ? slot : lap_slot; lap_dup = lt ? false : (eq ? true : lap_dup);
 		}
-		const bool firstwin = stored && run == w + k - 1;
-		if (__builtin_expect(__ballot(firstwin) != 0, 0)) { if (firstwin) put_equals(false); }   // first full window: earlier copies of the minimum (:139-144)
+		if (!FAST) {
+			const bool firstwin = stored && run == w + k - 1;
+			if (__builtin_expect(__ballot(firstwin) != 0, 0)) { if (firstwin) put_equals(false); }   // first full window: earlier copies of the minimum (:139-144)
+		}
 		const bool newmin = stored && cx <= best_x;                          // '<=': the rightmost of equal hashes wins
 		const bool left = stored && !newmin && slot == best_slot;            // the minimum has just left the window
-		put_if((newmin && run >= w + k) || (left && run >= w + k - 1), best_x, best_y);
+		put_if(FAST ? (newmin || left) : ((newmin && run >= w + k) || (left && run >= w + k - 1)), best_x, best_y);
 		// the reference scans slot+1..w-1, then 0..slot, with '>=': the last smallest entry in that order = the better of the lap's
 		// minimum and the minimum of what is left of the lap before
 		uint64_t nx = lap_x; int ns = lap_slot; bool dup = lap_dup; uint32_t ny = 0xFFFFFFFFu;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 		best_x = newmin ? cx : (left ? nx : best_x);
 		best_y = newmin ? cy : (left ? ny : best_y);
 		best_slot = newmin ? slot : (left ? ns : best_slot);
-		const bool again = left && dup && run >= w + k - 1;
+		const bool again = left && dup && (FAST || run >= w + k - 1);
 		if (__builtin_expect(__ballot(again) != 0, 0)) { if (again) put_equals(true); }           // identical k-mers of the new minimum (:155-161)
 		const bool wrapped = stored && slot + 1 == w;
 		slot = stored ? (wrapped ? 0 : slot + 1) : slot;
@@ -217,6 +220,25 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 					SM[j * 64 + lane] = (uint8_t)ms;
 				}
 			}
+		}
+	};
+	// 0x80 in every byte of x that equals the byte of pat
+	auto eq8 = [](uint64_t x, uint64_t pat) -> uint64_t { const uint64_t zz = x ^ pat; return ~(((zz & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | zz | 0x7F7F7F7F7F7F7F7Full); };
+	for (uint32_t i0 = 0; i0 < maxlen; i0 += 8) {
+		chunk = ahead_sh < 64 ? ahead >> ahead_sh : (i0 == 0 ? first8 : 0ull);   // the next eight characters travel while these are scanned
+		ahead = issue8(i0 + 8, ahead_sh);
+		bool fast = false;
+		if (ODDK) {
+			const uint64_t uc = chunk & 0xDFDFDFDFDFDFDFDFull;
+			const uint64_t ok = eq8(uc, 0x4141414141414141ull) | eq8(uc, 0x4343434343434343ull) | eq8(uc, 0x4747474747474747ull) | eq8(uc, 0x5454545454545454ull);
+			fast = i0 + 8 <= len && run >= w + k && ok == 0x8080808080808080ull;
+		}
+		if (ODDK && __all(fast)) {
+#pragma unroll 1
+			for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::true_type{});
+		} else {
+#pragma unroll 1
+			for (uint32_t q = 0; q < 8 && i0 + q < maxlen; ++q) scan_step(i0 + q, std::false_type{});
 		}
 	}
 	if (best_x != U64MAX) put(best_x, best_y);                               // the minimum still held (:163-164)
