@@ -154,26 +154,28 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	uint64_t ahead = issue8(0, ahead_sh);
 	uint64_t first8 = 0;
 	if (tiny) for (uint32_t q = 0; q < len; ++q) first8 |= (uint64_t)s[q] << (8 * q);
-	// One position of the scan.  FAST (k odd only): every lane of the wave is inside its string, past its first full window
-	// (run >= w + k) and reads A, C, G or T -- the steady state of nearly every iteration -- so the tests on all that, the run
-	// counter's cases and the first-window rule drop out of the body.
-	auto scan_step = [&](const uint32_t i, auto fast_tag) {
-		constexpr bool FAST = decltype(fast_tag)::value;
+	// One position of the scan, in three strengths (k odd only for the upper two): 0 = as written; 1 = every lane of the wave is inside
+	// its string and reads A, C, G or T for the whole chunk of eight, so the tests on that and the run counter's cases drop out; 2 = the
+	// lanes are past their first full window as well (run >= w + k), so the thresholds on the run counter and the first-window rule
+	// drop out too -- the steady state of most iterations.
+	uint32_t lap_y = 0xFFFFFFFFu;                                              // pos<<1 | strand of the lap's minimum
+	auto scan_step = [&](const uint32_t i, auto level_tag) {
+		constexpr int LV = decltype(level_tag)::value;
 		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
 		step = i;
 		const uint32_t u = ch & 0xDFu;                                       // fold case
-		const bool in = FAST || i < len;
-		const bool base = FAST || (in && (u == 'A' || u == 'C' || u == 'G' || u == 'T'));
+		const bool in = LV >= 1 || i < len;
+		const bool base = LV >= 1 || (in && (u == 'A' || u == 'C' || u == 'G' || u == 'T'));
 		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;                     // A0 C1 G2 T3
 		// Straight-line code with selects: a wave that is alone on its SIMD (the rings fill the LDS) pays for every taken branch with
 		// an instruction-fetch bubble, and this loop body used to hold nineteen of them.
 		const uint64_t nf = (fwd << 2 | c) & mask, nr = (rev >> 2) | ((3ull ^ c) << shift1);
 		fwd = base ? nf : fwd; rev = base ? nr : rev;
-		const bool pal = !FAST && base && fwd == rev;                        // a k-mer equal to its reverse complement stores nothing (:133)
+		const bool pal = LV == 0 && base && fwd == rev;                      // a k-mer equal to its reverse complement stores nothing (:133)
 		const bool stored = in && !pal;                                      // an ambiguous base stores an empty entry and resets the run
 		const uint32_t z = fwd < rev ? 0u : 1u;
-		run = FAST ? run + 1 : (base ? (pal ? run : run + 1) : (in ? 0 : run));
-		const bool real = FAST || (base && !pal && run >= k);
+		run = LV >= 1 ? run + 1 : (base ? (pal ? run : run + 1) : (in ? 0 : run));
+		const bool real = LV == 2 || (base && !pal && run >= k);
 		const uint64_t hx = mcom_hash64(z ? rev : fwd, mask);
 		const uint64_t cx = real ? hx : U64MAX;
 		const uint32_t cy = real ? ((i << 1) | z) : 0xFFFFFFFFu;
@@ -181,32 +183,31 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 		{
 			const bool lt = stored && (slot == 0 || cx < lap_x), eq = stored && !lt && cx == lap_x;
 			lap_x = lt ? cx : lap_x; lap_slot = (lt || eq) ? slot : lap_slot; lap_dup = lt ? false : (eq ? true : lap_dup);
+			lap_y = (lt || eq) ? cy : lap_y;
 		}
-		if (!FAST) {
+		if (LV < 2) {
 			const bool firstwin = stored && run == w + k - 1;
 			if (__builtin_expect(__ballot(firstwin) != 0, 0)) { if (firstwin) put_equals(false); }   // first full window: earlier copies of the minimum (:139-144)
 		}
 		const bool newmin = stored && cx <= best_x;                          // '<=': the rightmost of equal hashes wins
 		const bool left = stored && !newmin && slot == best_slot;            // the minimum has just left the window
-		put_if(FAST ? (newmin || left) : ((newmin && run >= w + k) || (left && run >= w + k - 1)), best_x, best_y);
+		put_if(LV == 2 ? (newmin || left) : ((newmin && run >= w + k) || (left && run >= w + k - 1)), best_x, best_y);
 		// the reference scans slot+1..w-1, then 0..slot, with '>=': the last smallest entry in that order = the better of the lap's
 		// minimum and the minimum of what is left of the lap before
-		uint64_t nx = lap_x; int ns = lap_slot; bool dup = lap_dup; uint32_t ny = 0xFFFFFFFFu;
-		if (left) {
-			if (slot + 1 < w) {
-				const uint32_t sm = SM[(slot + 1) * 64 + lane];
-				const int sj = (int)(sm & 63u);
-				const uint64_t sx = ring_x(sj);
-				const bool older = sx < lap_x;
-				dup = older ? (sm & 0x80u) != 0 : (dup || sx == lap_x);
-				nx = older ? sx : nx; ns = older ? sj : ns;
-			}
-			ny = ring_y(ns, RX[ns * SSC_STRIDE + lane]);
+		uint64_t nx = lap_x; int ns = lap_slot; bool dup = lap_dup; uint32_t ny = lap_y;
+		if (left && slot + 1 < w) {
+			const uint32_t sm = SM[(slot + 1) * 64 + lane];
+			const int sj = (int)(sm & 63u);
+			const uint64_t sxw = RX[sj * SSC_STRIDE + lane];
+			const uint64_t sx = ODDK ? (sxw == U64MAX ? sxw : sxw & ~SSC_ZBIT) : sxw;
+			const bool older = sx < lap_x;
+			dup = older ? (sm & 0x80u) != 0 : (dup || sx == lap_x);
+			if (older) { nx = sx; ns = sj; ny = ring_y(sj, sxw); }
 		}
 		best_x = newmin ? cx : (left ? nx : best_x);
 		best_y = newmin ? cy : (left ? ny : best_y);
 		best_slot = newmin ? slot : (left ? ns : best_slot);
-		const bool again = left && dup && (FAST || run >= w + k - 1);
+		const bool again = left && dup && (LV == 2 || run >= w + k - 1);
 		if (__builtin_expect(__ballot(again) != 0, 0)) { if (again) put_equals(true); }           // identical k-mers of the new minimum (:155-161)
 		const bool wrapped = stored && slot + 1 == w;
 		slot = stored ? (wrapped ? 0 : slot + 1) : slot;
@@ -227,18 +228,23 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	for (uint32_t i0 = 0; i0 < maxlen; i0 += 8) {
 		chunk = ahead_sh < 64 ? ahead >> ahead_sh : (i0 == 0 ? first8 : 0ull);   // the next eight characters travel while these are scanned
 		ahead = issue8(i0 + 8, ahead_sh);
-		bool fast = false;
+		bool clean = false;
 		if (ODDK) {
 			const uint64_t uc = chunk & 0xDFDFDFDFDFDFDFDFull;
 			const uint64_t ok = eq8(uc, 0x4141414141414141ull) | eq8(uc, 0x4343434343434343ull) | eq8(uc, 0x4747474747474747ull) | eq8(uc, 0x5454545454545454ull);
-			fast = i0 + 8 <= len && run >= w + k && ok == 0x8080808080808080ull;
+			clean = i0 + 8 <= len && ok == 0x8080808080808080ull;
 		}
-		if (ODDK && __all(fast)) {
+		if (ODDK && __all(clean)) {
+			if (__all(run >= w + k)) {
 #pragma unroll 1
-			for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::true_type{});
+				for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::integral_constant<int, 2>{});
+			} else {
+#pragma unroll 1
+				for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::integral_constant<int, 1>{});
+			}
 		} else {
 #pragma unroll 1
-			for (uint32_t q = 0; q < 8 && i0 + q < maxlen; ++q) scan_step(i0 + q, std::false_type{});
+			for (uint32_t q = 0; q < 8 && i0 + q < maxlen; ++q) scan_step(i0 + q, std::integral_constant<int, 0>{});
 		}
 	}
 	if (best_x != U64MAX) put(best_x, best_y);                               // the minimum still held (:163-164)
