@@ -215,10 +215,15 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 			if (wrapped) {                                                   // the lap is complete: its suffix minima, newest (highest slot) first among equals
 				uint64_t mx = ring_x(w - 1); uint32_t ms = (uint32_t)(w - 1);
 				SM[(w - 1) * 64 + lane] = (uint8_t)ms;
-				for (int j = w - 2; j >= 0; --j) {
-					const uint64_t x = ring_x(j);
-					if (x < mx) { mx = x; ms = (uint32_t)j; } else if (x == mx) ms |= 0x80u;
-					SM[j * 64 + lane] = (uint8_t)ms;
+				for (int j = w - 2; j >= 0; j -= 4) {                           // four reads in flight: the wave has nobody to hide its LDS latency behind
+					uint64_t xs[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) xs[q] = j - q >= 0 ? ring_x(j - q) : U64MAX;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) if (j - q >= 0) {
+						if (xs[q] < mx) { mx = xs[q]; ms = (uint32_t)(j - q); } else if (xs[q] == mx) ms |= 0x80u;
+						SM[(j - q) * 64 + lane] = (uint8_t)ms;
+					}
 				}
 			}
 		}
