@@ -98,7 +98,7 @@ def cindex_bytes(st, model):
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan<true>", "k_sketch_scan<false>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false>"], "classify_pack": ["k_classify_pack16"],
-               "sketch_reads": ["k_sketch_reads<5, true>"],
+               "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true>"],
                "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
 

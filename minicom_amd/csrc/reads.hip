@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void k_classify_pack16(const uint8_t *__restri
 //   WIDE = true : 17 <= k <= 31, k-mers in a 64-bit register pair, mask low word is all ones
 //   WIDE = false: k <= 16, everything in 32-bit registers
 // ------------------------------------------------------------------------------------------------
-template <int W, bool WIDE>
+// ODDK: k is odd, so no k-mer (nor any of the partly filled registers at the start of a read) equals its reverse complement: every
+// base counts, the run counter is the position, and the two data-dependent branches of the loop body become one uniform test.
+template <int W, bool WIDE, bool ODDK>
 __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict__ packed, const uint32_t *__restrict__ rids,
                                                       size_t n, int L, int k, uint32_t rid0, mcom_mm128 *__restrict__ rec)
 {
@@ -219,7 +221,14 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 				const uint32_t c = (uint32_t)cur & 3u; cur >>= 2;
 				fwd = ((fwd << 2) | c) & mask;
 				rev = (rev >> 2) | ((uint64_t)((3u ^ c) << sh_hi) << 32);
-				if (fwd != rev) {
+				if (ODDK) {
+					if (i >= k - 1) {                                            // uniform
+						const uint32_t z = fwd < rev ? 0u : 1u;
+						const uint64_t h = mcom_hash64(z ? rev : fwd, mask);
+						const bool better = h < best_x;
+						best_x = better ? h : best_x; best_i = better ? (uint32_t)i : best_i; best_z = better ? z : best_z;
+					}
+				} else if (fwd != rev) {
 					++run;
 					if (run >= k) {
 						const uint32_t z = fwd < rev ? 0u : 1u;
@@ -242,7 +251,14 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 				const uint32_t c = (uint32_t)cur & 3u; cur >>= 2;
 				fwd = ((fwd << 2) | c) & mask;
 				rev = (rev >> 2) | ((3u ^ c) << sh);
-				if (fwd != rev) {
+				if (ODDK) {
+					if (i >= k - 1) {                                            // uniform
+						const uint32_t z = fwd < rev ? 0u : 1u;
+						const uint64_t h = mcom_hash64_lo(z ? rev : fwd, mask);
+						const bool better = h < best_x;
+						best_x = better ? h : best_x; best_i = better ? (uint32_t)i : best_i; best_z = better ? z : best_z;
+					}
+				} else if (fwd != rev) {
 					++run;
 					if (run >= k) {
 						const uint32_t z = fwd < rev ? 0u : 1u;
@@ -304,7 +320,8 @@ static int launch_sketch(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t
 {
 	const int W = mcom_words_per_read(L);
 	const unsigned blocks = (unsigned)((n + 255) / 256);
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_sketch_reads<WW, WIDE>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
+#define MCOM_CASE(WW) case WW: if (k & 1) hipLaunchKernelGGL((k_sketch_reads<WW, WIDE, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); \
+	else hipLaunchKernelGGL((k_sketch_reads<WW, WIDE, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
 	McomProfScope ps_(ctx, PROF_SKETCH_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported (1..256)", L); }
