@@ -13,6 +13,28 @@
 // k_classify_pack: G lanes cooperate on one read, 8 bases per lane (G = 16 for L <= 128, else 32), so a
 // 64-wide wave holds 64/G reads and every global access of a wave is one contiguous span.
 // ------------------------------------------------------------------------------------------------
+// Cross-lane exchanges inside a row of 16 lanes as DPP modifiers of ordinary VALU moves (no trip through the LDS crossbar, which is
+// what __shfl_xor compiles to: ds_bpermute_b32, ~100 cycles each, 18 of them per iteration of the classify kernel).  A sum or an
+// OR over the row only needs every step to pair disjoint halves: lane ^ 1, lane ^ 2 (quad permutes), then the mirror of the half
+// row and of the row (all lanes of a quad / of a half row already agree).
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_u64(uint64_t v)
+{
+	return (uint64_t)dpp_u32<CTRL>((uint32_t)v) | ((uint64_t)dpp_u32<CTRL>((uint32_t)(v >> 32)) << 32);
+}
+#define DPP_XOR1 0xB1        /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E        /* quad_perm [2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
+{
+	v += dpp_u32<DPP_XOR1>(v); v += dpp_u32<DPP_XOR2>(v); v += dpp_u32<DPP_HALF_MIRROR>(v); v += dpp_u32<DPP_MIRROR>(v);
+	return v;
+}
+
 __device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p)
 {
 	uint32_t v;
@@ -76,9 +98,10 @@ __global__ __launch_bounds__(256) void k_classify_pack(const uint8_t *__restrict
 		}
 		uint32_t cA = __popc(~lo & ~hi & ok), cC = __popc(lo & ~hi & ok), cG = __popc(~lo & hi & ok), cT = __popc(lo & hi & ok);
 		uint32_t acc0 = cA | (cT << 16), acc1 = cG | (cC << 16), accN = __popc(nb);
+		if (G == 16) { acc0 = row16_sum(acc0); acc1 = row16_sum(acc1); accN = row16_sum(accN); }   // one DPP row
+		else {
 #pragma unroll
-		for (int s = 1; s < G; s <<= 1) {
-			acc0 += __shfl_xor(acc0, s, 64); acc1 += __shfl_xor(acc1, s, 64); accN += __shfl_xor(accN, s, 64);
+			for (int s = 1; s < G; s <<= 1) { acc0 += __shfl_xor(acc0, s, 64); acc1 += __shfl_xor(acc1, s, 64); accN += __shfl_xor(accN, s, 64); }
 		}
 		const int nA = acc0 & 0xFFFF, nT = acc0 >> 16, nG = acc1 & 0xFFFF, nC = acc1 >> 16, nN = (int)accN;
 		int c;                                                               // kthread_reads.c:84-224
@@ -102,12 +125,12 @@ __global__ __launch_bounds__(256) void k_classify_pack(const uint8_t *__restrict
 		uint32_t out16 = (codes & keep) | fill;
 		// four lanes make one 64-bit word
 		uint64_t word = (uint64_t)out16 << (16 * (j & 3));
-		word |= __shfl_xor(word, 1, 64);
-		word |= __shfl_xor(word, 2, 64);
+		word |= dpp_u64<DPP_XOR1>(word);
+		word |= dpp_u64<DPP_XOR2>(word);
 		if (live && (j & 3) == 0 && (j >> 2) < W) packed[r * (size_t)W + (j >> 2)] = word;
 		if (nmask) {
 			uint64_t nw = (uint64_t)nb << (8 * (j & 7));
-			nw |= __shfl_xor(nw, 1, 64); nw |= __shfl_xor(nw, 2, 64); nw |= __shfl_xor(nw, 4, 64);
+			nw |= dpp_u64<DPP_XOR1>(nw); nw |= dpp_u64<DPP_XOR2>(nw); nw |= dpp_u64<DPP_HALF_MIRROR>(nw);   // (an OR over eight lanes: the quads already agree)
 			if (live && (j & 7) == 0 && (j >> 3) < NW) nmask[r * (size_t)NW + (j >> 3)] = nw;
 		}
 		if (live && j == 0) { cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN; }
@@ -151,8 +174,7 @@ __global__ __launch_bounds__(256) void k_classify_pack16(const uint8_t *__restri
 		const uint32_t ok = spread16(vmask & ~nb);
 		const uint32_t cA = __popc(~lo & ~hi & ok), cC = __popc(lo & ~hi & ok), cG = __popc(~lo & hi & ok), cT = __popc(lo & hi & ok);
 		uint32_t acc0 = cA | (cT << 16), acc1 = cG | (cC << 16), accN = __popc(nb);
-#pragma unroll
-		for (int s = 1; s < G; s <<= 1) { acc0 += __shfl_xor(acc0, s, 64); acc1 += __shfl_xor(acc1, s, 64); accN += __shfl_xor(accN, s, 64); }
+		acc0 = row16_sum(acc0); acc1 = row16_sum(acc1); accN = row16_sum(accN);   // G = 16 lanes = one DPP row
 		const int nA = acc0 & 0xFFFF, nT = acc0 >> 16, nG = acc1 & 0xFFFF, nC = acc1 >> 16, nN = (int)accN;
 		int c;                                                               // kthread_reads.c:84-224
 		if (nA == L) c = MCOM_CLS_ALLA;
@@ -173,11 +195,11 @@ __global__ __launch_bounds__(256) void k_classify_pack16(const uint8_t *__restri
 		const uint32_t fill = (rep & 1 ? nsp : 0u) | (rep & 2 ? (nsp << 1) : 0u);
 		const uint32_t out32 = (codes & keep) | fill;
 		uint64_t word = (uint64_t)out32 << (32 * (j & 1));                   // two lanes make one 64-bit word
-		word |= __shfl_xor(word, 1, 64);
+		word |= dpp_u64<DPP_XOR1>(word);
 		if (live && (j & 1) == 0 && (j >> 1) < W) packed[r * (size_t)W + (j >> 1)] = word;
 		if (nmask) {
 			uint64_t nw = (uint64_t)nb << (16 * (j & 3));                    // four lanes make one word of N flags
-			nw |= __shfl_xor(nw, 1, 64); nw |= __shfl_xor(nw, 2, 64);
+			nw |= dpp_u64<DPP_XOR1>(nw); nw |= dpp_u64<DPP_XOR2>(nw);
 			if (live && (j & 3) == 0 && (j >> 2) < NW) nmask[r * (size_t)NW + (j >> 2)] = nw;
 		}
 		if (live && j == 0) { cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN; }
