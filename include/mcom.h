@@ -11,6 +11,10 @@
  *   - return 0 on success, a negative mcom_status otherwise; mcom_last_error() gives the text.
  *     (the reference asserts / exit(1)s instead: sketch.c:122,248, bseq.c:54-57)
  *   - records are the reference's mm128_t: { x = hash, y = id<<32 | pos<<1 | strand } (minicom.h:17-19)
+ *   - contig ids: the reference packs (index in the thread's list << 8) + tid into the 32-bit id of a contig's records
+ *     (kthread_bucket.c:458, kthread_cb.c:232), which ends at 2^24 contigs per list; here the id IS the contig index
+ *     (32 bits: a 500 M-read job makes ~40 M first-round contigs).  A stage dump shifts by MCOM_REF_CONTIG_ID_SHIFT
+ *     when it prints records for comparison with the reference.
  *
  * Packed read format ("packed rows"): W = ceil(2L/64) little-endian 64-bit words per read, base i in
  * bits [2i, 2i+1], A=0 C=1 G=2 T=3 (sketch.c:8-25), unused high bits zero.  This is also the byte
@@ -28,6 +32,7 @@ extern "C" {
 #endif
 
 typedef struct { uint64_t x, y; } mcom_mm128;
+#define MCOM_REF_CONTIG_ID_SHIFT 8
 typedef struct mcom_ctx mcom_ctx;
 
 enum mcom_status {
@@ -100,6 +105,9 @@ int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d
  * as mm_sketch_two left it (sketch.c:271); x = UINT64_MAX (no minimizer) gives the all-ones record.                */
 int mcom_records_assemble(mcom_ctx *ctx, const uint64_t *d_x, const uint32_t *d_ylow, size_t n, uint32_t rid0, mcom_mm128 *d_rec);
 
+/* hash64 (sketch.c:27-37) of n k-mers (2k-bit values), batched: the invertible mix every sketch kernel applies.            */
+int mcom_hash64_batch(mcom_ctx *ctx, const uint64_t *d_kmer, size_t n, int k, uint64_t *d_hash);
+
 /* ---- a5 + a6: sort and group ------------------------------------------------------------------- */
 /* radix_sort_128x (misc.c:22, ksort.h:153): sorts n records in place by x ascending.  Stable: equal keys
  * keep their input order (the reference is stable only up to 64 elements, ksort.h:155).             */
@@ -124,7 +132,7 @@ int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int L, int
 /* ---- a3, a7..a9: contigs ------------------------------------------------------------------------- */
 /* Batched mm_sketch_lh_ori (sketch.c:116-165): the (w,k)-minimizers of n contigs.  Contig c is the ASCII
  * string d_seq[d_off[c] .. d_off[c+1]) (ACGT, anything else is an ambiguous base that resets the run);
- * its record id is d_ids[c] (NULL: c<<8, the reference's (index<<8)+tid at tid 0, kthread_bucket.c:458).
+ * its record id is d_ids[c] (NULL: c, the contig index -- see "contig ids" above).
  * max_per_contig > 0 keeps only the first that many (callers index the first m, kthread_bucket.c:463).
  * Out: d_moff[n+1] = start of each contig's minimizers in d_out (position order), *h_total = their
  * number.  MCOM_E_OVERFLOW (with *h_total = a capacity that is enough) when cap is too small.
@@ -172,7 +180,7 @@ int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_cof
  * every contig (mcom_sketch_contigs with max_per_contig 0), contig after contig.  For each query, in
  * order, and each index hit, in index order, the pair passes when the hit belongs to another contig,
  * has the same strand bit and match_pro <= cbthr.  d_out receives the passing pairs in that order as
- * { x = query y (contig<<8 in the id, pos_ori, dir), y = hit y (other contig, pos, dir) }.  The merge
+ * { x = query y (contig index in the id, pos_ori, dir), y = hit y (other contig, pos, dir) }.  The merge
  * flags (:286, :339) change while merging and stay with the caller.  h_counts = { pairs, passing }.
  * MCOM_E_OVERFLOW when cap is too small.  Synchronous.                                                */
 int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
@@ -247,7 +255,8 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
 /* The same pass driven from the singletons (results identical to mcom_realign_pass; it is the production path).
  * The klen-mers of the Stage-2 contigs (which do not change between passes, preprocess.c:197-232) are indexed ONCE.
  * The index (csrc/cindex.hip) is a multi-map of 64-byte lines -- word 0: entries in the line (| 0x100 when entries were
- * pushed past it), words 1-7: entries = 12-bit tag of the key | contig (24 bits) | position (28 bits) -- cut into
+ * pushed past it), words 1-7: entries = 12-bit tag of the key | contig | position (52 bits between them: 24 + 28 up to 2^24 contigs, more
+ * contigs take bits from the position; the build refuses a contig too long for its field) -- cut into
  * partitions of equal size; a key hashes to a partition and a home line, its entries lie in the home line and the lines
  * behind it; a key with more copies than a few lines hold (a repeat) keeps them in a run of lines of its own in the
  * extension area behind the partitions.  It is BUILT BY RADIX PARTITIONING: two streaming passes split
@@ -288,6 +297,13 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
+
+/* encode_byte (kthread_hash_realign.c:283-314), batched: d_ok[i] = 1 when the run-length mismatch text of read row i
+ * (d_rows [n][W], packed) against the L bases of contig d_contig[i] from base d_pos[i] on -- their reverse complement when
+ * d_dir[i] != 0, as :446-461 compare a reverse-strand read -- is at most 0.4 L characters long (the match-run counter is not
+ * reset after a short run, as in the reference).  d_cbits / d_coff: packed contigs as for mcom_realign_pass.                */
+int mcom_encode_byte(mcom_ctx *ctx, const uint64_t *d_rows, const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_contig,
+                     const uint32_t *d_pos, const uint8_t *d_dir, size_t n, int L, uint8_t *d_ok);
 
 /* Bins longer than maxsearch, exactly.  The reference walks the LIVE part of a bin from its end for at most
  * maxsearch entries (kthread_hash_realign.c:388, findpos at bbhashdict.c:33-49) and takes claimed reads out of every
@@ -398,7 +414,7 @@ int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_so
                        size_t n, const uint8_t *d_flag, size_t nj, size_t nkeep, uint8_t *d_seq2, uint64_t *d_soff2,
                        uint64_t *d_mem2, uint64_t *d_moff2, uint32_t *d_keepidx, uint64_t *h_totals);
 /* The minimizers of a carried contig do not change, only its index does: records of old contig d_keepidx[u]
- * are appended at d_rec2[base ...] with id (first_id+u)<<8, d_roff2[first_id .. first_id+nkeep] are written;
+ * are appended at d_rec2[base ...] with id first_id+u, d_roff2[first_id .. first_id+nkeep] are written;
  * *h_total = records in d_rec2 afterwards.  MCOM_E_OVERFLOW when cap2 is too small.                           */
 int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_keepidx, size_t nkeep,
                        uint32_t first_id, uint32_t base, mcom_mm128 *d_rec2, size_t cap2, uint32_t *d_roff2, uint64_t *h_total);
@@ -409,7 +425,7 @@ int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d
  * segment around the overlap is sketched.  Result identical to mcom_sketch_contigs on the merged contigs (k odd).
  *   d_jobs [nj][4] claimed pairs as in mcom_merge_members;  d_soff / d_rec / d_roff: string offsets, records and
  *   record offsets of the PARENT set;  d_seq2 / d_soff2: the merged contigs (jobs first, mcom_merge_consensus_jobs);
- *   out: d_roff2 [nj + 1], d_rec2 [<= cap2] with ids j<<8; *h_total records, *h_sketched_chars bases actually sketched.
+ *   out: d_roff2 [nj + 1], d_rec2 [<= cap2] with ids j; *h_total records, *h_sketched_chars bases actually sketched.
  * MCOM_E_OVERFLOW with *h_total = the room needed.  Synchronous.                                                  */
 int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
                          const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
@@ -428,7 +444,7 @@ int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
 int mcom_min_fold_u64(mcom_ctx *ctx, const uint64_t *d_parts, int n_parts, size_t stride, size_t n, uint64_t *d_out);
 /* *h_max = largest element (0 for n = 0).  Synchronous.                                                             */
 int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32_t *h_max);
-/* records sketched for contigs [first_contig, ...) of a set as if they were contigs 0, 1, ...: ids += first_contig << 8;
+/* records sketched for contigs [first_contig, ...) of a set as if they were contigs 0, 1, ...: ids += first_contig;
  * their n_off record offsets += first_record                                                                        */
 int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_rec, uint32_t first_contig, uint32_t *d_roff, size_t n_off, uint32_t first_record);
 

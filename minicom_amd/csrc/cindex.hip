@@ -4,7 +4,7 @@
 // singleton looks up its own 2*nd - 1 keys instead of every contig window asking every dictionary.
 //
 // Structure: a multi-map of lines of 8 words (64 bytes): word 0 = number of entries in the line (| 0x100 when entries
-// were pushed past it), words 1-7 = entries tag12 | contig24 | position28.  The table is cut into partitions of equal size
+// were pushed past it), words 1-7 = entries tag12 | contig | position (52 bits between them, cindex.hpp).  The table is cut into partitions of equal size
 // (a few thousand lines); a key hashes to a partition and to a HOME line inside it -- an address computed from the key
 // alone -- and its entries lie in the home line and, when that is full, in the lines behind it (wrapping inside the
 // partition): bucketed linear probing, placed exactly: entries in home order take consecutive slot positions,
@@ -38,7 +38,7 @@ __global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, u
 	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
 }
 
-struct CxSrc { const uint64_t *cbits, *coff, *woff; const uint32_t *first_contig; uint32_t c1; uint64_t pos0, n_pos; };
+struct CxSrc { const uint64_t *cbits, *coff, *woff; const uint32_t *first_contig; uint32_t c1; uint64_t pos0, n_pos; unsigned long long *head; };
 
 // the entry of position gi: false when the position holds none (a contig without windows, the end of the range)
 __device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint64_t gi, uint32_t &key32, uint64_t &slot)
@@ -48,6 +48,7 @@ __device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint6
 	while (c + 1 < s.c1 && s.woff[c + 1] + (uint64_t)g.maxoff * (c + 1) - s.pos0 <= gi) ++c;
 	if (s.woff[c + 1] == s.woff[c]) return false;
 	const uint64_t p = gi - (s.woff[c] + (uint64_t)g.maxoff * c - s.pos0);
+	if (p >> g.pbits) { if (*(volatile unsigned long long*)(s.head + 1) == 0) s.head[1] = 1; return false; }   // reported by the build
 	const uint64_t *src = s.cbits + s.coff[c] + ((2 * p) >> 6);
 	const int sh = (int)((2 * p) & 63);
 	uint64_t v = src[0] >> sh;
@@ -56,7 +57,7 @@ __device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint6
 	uint32_t part, h16;
 	cix_hash(key, g.n_parts, part, h16);
 	key32 = (part << 16) | h16;
-	slot = (cix_tag(key) << 52) | ((uint64_t)c << CIX_PBITS) | p;
+	slot = (cix_tag(key) << CIX_TAG_SHIFT) | ((uint64_t)c << g.pbits) | p;
 	return true;
 }
 
@@ -504,7 +505,7 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
 	if (!d_keys || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
 	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
-	if (n_contigs >= (1u << CIX_CBITS) - 1) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs for the index slots");
+	g.pbits = cix_pbits(n_contigs);
 	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
 	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
@@ -540,7 +541,7 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 		const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
 		hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
 		MCOM_LAUNCH_CHECK(ctx);
-		const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos};
+		const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos, (unsigned long long*)d_keys};
 		hipLaunchKernelGGL(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
@@ -569,9 +570,11 @@ extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, c
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_cx_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
 	MCOM_LAUNCH_CHECK(ctx);
-	uint64_t used = 0;
-	MCOM_HIP(ctx, mcom_d2h_async(ctx, &used, d_keys, 8));
+	uint64_t hd[2] = {0, 0};
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hd, d_keys, 16));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	const uint64_t used = hd[0];
+	if (hd[1]) return mcom_fail(ctx, MCOM_E_ARG, "contig index: a contig of this set of %u contigs is longer than 2^%d bases", n_contigs, g.pbits);
 	if (used > ext_cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index: %llu extension lines needed, room for %llu", (unsigned long long)used, (unsigned long long)ext_cap);
 	return MCOM_OK;
 }

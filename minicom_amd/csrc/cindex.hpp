@@ -24,11 +24,15 @@ __host__ __device__ static inline int dict_layout(int L, int ininumdict, int *st
 // extension area instead: bits 10-31 = lines of the run, bits 32-63 = its first line (counted from the extension's start)
 #define CIX_MORE 0x100ull
 #define CIX_HEAVY 0x200ull
-#define CIX_CBITS 24
-#define CIX_PBITS 28
+// an entry = tag (12 bits) | contig index | position in the contig.  The 52 bits below the tag are shared: up to 2^24 contigs
+// the position has 28 bits (the layout of rounds 1 and 2); a larger set (a 500 M-read job) takes the bits its contig indices
+// need from the position field.  Both sides derive the cut from the number of contigs of the set; the build refuses a
+// position that does not fit (header word 1).
+#define CIX_TAG_SHIFT 52
+__host__ __device__ static inline int cix_pbits(uint32_t n_contigs) { int cb = 24; while (cb < 32 && (1ull << cb) <= (uint64_t)n_contigs) ++cb; return CIX_TAG_SHIFT - cb; }
 #define CIX_MAX_PARTS 65535u
-#define CIX_HEAD_WORDS 8                    // d_keys[0] = lines of the extension area in use
-struct CixGeom { uint32_t n_parts, n_lines; int L, nd, klen, maxoff; int ds[MAXDICT]; };   // n_lines: lines per partition
+#define CIX_HEAD_WORDS 8                    // d_keys[0] = lines of the extension area in use, d_keys[1] != 0: a contig too long for the position field
+struct CixGeom { uint32_t n_parts, n_lines; int L, nd, klen, maxoff, pbits; int ds[MAXDICT]; };   // n_lines: lines per partition
 
 static inline int cix_geom(int L, int ininumdict, CixGeom &g)
 {
@@ -42,6 +46,7 @@ static inline int cix_geom(int L, int ininumdict, CixGeom &g)
 		if (g.ds[l] > 0 && L - g.ds[l] - g.klen > mo) mo = L - g.ds[l] - g.klen;
 	}
 	g.maxoff = mo;
+	g.pbits = 28;
 	return 0;
 }
 
@@ -55,5 +60,5 @@ __device__ __forceinline__ void cix_hash(uint64_t key, uint32_t n_parts, uint32_
 	part = (uint32_t)(((h >> 32) * (uint64_t)n_parts) >> 32);
 	h16 = (uint32_t)(h >> 16) & 0xFFFFu;
 }
-__device__ __forceinline__ uint64_t cix_tag(uint64_t key) { return (key * 0xD6E8FEB86659FD93ull) >> 52; }
+__device__ __forceinline__ uint64_t cix_tag(uint64_t key) { return (key * 0xD6E8FEB86659FD93ull) >> CIX_TAG_SHIFT; }
 __device__ __forceinline__ uint32_t cix_home(uint32_t h16, uint32_t n_lines) { return (h16 * n_lines) >> 16; }

@@ -16,7 +16,7 @@ __global__ void k_claim_bid(const mcom_mm128 *__restrict__ pairs, size_t n, cons
 	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= n || dead[e]) return;
 	const mcom_mm128 pr = pairs[e];
-	const uint32_t ci = (uint32_t)(pr.x >> 32) >> 8, cj = (uint32_t)(pr.y >> 32) >> 8;
+	const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
 	if (matched[ci] || matched[cj]) { dead[e] = 1; return; }
 	atomicMin(&best[ci], (unsigned int)e);
 	atomicMin(&best[cj], (unsigned int)e);
@@ -28,7 +28,7 @@ __global__ void k_claim_take(const mcom_mm128 *__restrict__ pairs, size_t n, uin
 	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= n || dead[e]) return;
 	const mcom_mm128 pr = pairs[e];
-	const uint32_t ci = (uint32_t)(pr.x >> 32) >> 8, cj = (uint32_t)(pr.y >> 32) >> 8;
+	const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
 	if (best[ci] == (unsigned int)e && best[cj] == (unsigned int)e) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; dead[e] = 1; }
 }
 __global__ void k_claim_jobs(const mcom_mm128 *__restrict__ pairs, size_t n, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ spre,
@@ -38,7 +38,7 @@ __global__ void k_claim_jobs(const mcom_mm128 *__restrict__ pairs, size_t n, con
 	if (e >= n || !sel[e]) return;
 	const mcom_mm128 pr = pairs[e];
 	uint32_t *j = jobs + 4 * (size_t)spre[e];
-	j[0] = (uint32_t)(pr.x >> 32) >> 8; j[1] = (uint32_t)(pr.y >> 32) >> 8; j[2] = (uint32_t)pr.x >> 1; j[3] = (uint32_t)pr.y >> 1;
+	j[0] = (uint32_t)(pr.x >> 32); j[1] = (uint32_t)(pr.y >> 32); j[2] = (uint32_t)pr.x >> 1; j[3] = (uint32_t)pr.y >> 1;
 }
 
 extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t n_pairs, size_t n_contigs, int max_rounds, uint32_t *d_jobs,

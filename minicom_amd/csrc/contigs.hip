@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 	const int lane = threadIdx.x;
 	const uint8_t *s = seq + off[t];
 	const int len = (int)((off_end ? off_end[t] : off[t + 1]) - off[t]);   // off_end: string t is [off[t], off_end[t]), a segment
-	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)(t << 8)) << 32;
+	const uint64_t idhi = (uint64_t)(ids ? ids[t] : (uint32_t)t) << 32;
 	const uint64_t mask = (1ull << (2 * k)) - 1;
 	SkChunk *my_chunks = chunks + piece_off[t];
 	// room in the temporary array comes from one of arena_mask+1 arenas, each with its own cursor: a single cursor would
@@ -405,7 +405,6 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	if (h_total) *h_total = 0;
 	if (k < 1 || k > 31 || w < 1 || w > MAXW) return mcom_fail(ctx, MCOM_E_ARG, "w=%d (1..%d) or k=%d (1..31) out of range", w, MAXW, k);
 	if (n >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contigs");
-	if (!d_ids && n > (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: the default record id (index<<8, kthread_bucket.c:458) overflows");
 	if (!d_moff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 4, ctx->stream)); return MCOM_OK; }
 	if (!d_seq || !d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
@@ -777,13 +776,13 @@ __global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *
 	const uint32_t s = first[i];
 	const mcom_mm128 m = q[i];
 	const uint32_t rid_ori = (uint32_t)(m.y >> 32), pos_ori = (uint32_t)m.y >> 1, dir_ori = (uint32_t)(m.y & 1);
-	const uint32_t ci = rid_ori >> 8;
+	const uint32_t ci = rid_ori;                          // the id IS the contig index here (include/mcom.h, "contig ids")
 	for (uint32_t u = 0; u < c; ++u) {
 		const uint64_t y = irec[s + u].y;
 		const uint32_t rid = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1, dir = (uint32_t)(y & 1);
 		uint32_t ok = 0;
 		if (rid != rid_ori && dir == dir_ori) {
-			const uint32_t cj = rid >> 8;
+			const uint32_t cj = rid;
 			const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
 			ok = mis <= (uint32_t)cbthr;
 		}

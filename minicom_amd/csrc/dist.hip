@@ -50,8 +50,8 @@ extern "C" int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32
 	return MCOM_OK;
 }
 
-// A rank sketches contigs [c0, c1) of the replicated set as if they were contigs 0 .. c1-c0-1: ids (index << 8 in the high
-// word of y, kthread_bucket.c:458) and record offsets are moved to their global values before the all-gather.
+// A rank sketches contigs [c0, c1) of the replicated set as if they were contigs 0 .. c1-c0-1: ids (the contig index in the high
+// word of y) and record offsets are moved to their global values before the all-gather.
 __global__ void k_records_rebase(mcom_mm128 *__restrict__ rec, size_t n, unsigned long long id_delta)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +67,7 @@ extern "C" int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_re
 	if (!ctx) return MCOM_E_ARG;
 	if (n_rec && first_contig) {
 		if (!d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-		hipLaunchKernelGGL(k_records_rebase, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n_rec, ((unsigned long long)first_contig << 8) << 32);
+		hipLaunchKernelGGL(k_records_rebase, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n_rec, (unsigned long long)first_contig << 32);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	if (n_off && first_record) {

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void k_carry_copy(const uint32_t *__restrict__
 	if (u == nkeep) return;
 	const uint32_t i = keepidx[u];
 	const uint32_t r0 = roff[i], cnt = roff[i + 1] - r0, d0 = base + sc[u];
-	const uint64_t id = (uint64_t)((first_id + (uint32_t)u) << 8) << 32;     // (index<<8)+tid at tid 0, kthread_bucket.c:458
+	const uint64_t id = (uint64_t)(first_id + (uint32_t)u) << 32;            // the contig index (include/mcom.h, "contig ids")
 	for (uint32_t t = lane; t < cnt; t += 16) { mcom_mm128 r = rec[r0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); rec2[d0 + t] = r; }
 }
 

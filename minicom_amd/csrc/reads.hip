@@ -364,6 +364,25 @@ extern "C" int mcom_sketch_reads(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	               : launch_sketch<false>(ctx, d_packed, d_rids, n, L, k, rid0, d_rec);
 }
 
+// a1 as a batched entry of its own: hash64 (sketch.c:27-37) of n k-mers with the two device forms the sketch kernels use
+__global__ void k_hash64(const uint64_t *__restrict__ kmer, size_t n, int k, uint64_t *__restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (k >= 17) out[i] = mcom_hash64(kmer[i], (1ull << (2 * k)) - 1);
+	else out[i] = mcom_hash64_lo((uint32_t)kmer[i], k == 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u));
+}
+extern "C" int mcom_hash64_batch(mcom_ctx *ctx, const uint64_t *d_kmer, size_t n, int k, uint64_t *d_hash)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
+	if (n == 0) return MCOM_OK;
+	if (!d_kmer || !d_hash) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_hash64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_kmer, n, k, d_hash);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
 extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
                                   uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
                                   uint64_t *d_nmask, mcom_mm128 *d_rec)

@@ -426,6 +426,29 @@ __device__ __forceinline__ bool encode_ok_sparse(const uint64_t (&mm)[W], int L,
 	return (double)len <= (double)L * 0.4;
 }
 
+// The L bases of a packed contig from base jj on, as a packed row; dir: their reverse complement (what the reference compares a
+// reverse-strand read with, kthread_hash_realign.c:446-461)
+template <int W>
+__device__ __forceinline__ void contig_window(const uint64_t *__restrict__ contig, uint64_t jj, int L, bool dir, uint64_t (&win)[W])
+{
+	const uint64_t *src = contig + ((2 * jj) >> 6);
+	const int sh = (int)((2 * jj) & 63);
+	uint64_t cur = src[0];
+#pragma unroll
+	for (int w = 0; w < W; ++w) { const uint64_t nxt = src[w + 1]; win[w] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur; cur = nxt; }
+	const int tail = 2 * L - 64 * (W - 1);
+	if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+	if (dir) {
+		uint64_t tt[W];
+#pragma unroll
+		for (int w = 0; w < W; ++w) tt[w] = ~rev_groups(win[W - 1 - w]);
+		const int drop = 64 * W - 2 * L;
+#pragma unroll
+		for (int w = 0; w < W; ++w) { const uint64_t a = tt[w], b = w + 1 < W ? tt[w + 1] : 0ull; win[w] = drop ? (a >> drop) | (b << (64 - drop)) : a; }
+		if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
+	}
+}
+
 // G lanes per singleton, lane q < 2*nd handles (dir = q / nd, dict = q % nd).  A lane first collects the contig
 // positions that carry its key (a few at most), then all lanes verify their i-th candidate together: the expensive
 // part runs converged instead of once per slot of the probe loop.
@@ -459,27 +482,12 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 
 	// what one candidate (contig, position of the key) amounts to
 	auto verify = [&](uint64_t v) {
-		const uint32_t c = (uint32_t)(v >> CIX_PBITS) & ((1u << CIX_CBITS) - 1u);
-		const int64_t jj = (int64_t)(v & ((1ull << CIX_PBITS) - 1)) - off;
+		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
+		const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
 		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
 		++n_cand;
 		uint64_t win[W], x[W];
-		const uint64_t *src = cbits + coff[c] + ((2 * (uint64_t)jj) >> 6);
-		const int sh = (int)((2 * (uint64_t)jj) & 63);
-		uint64_t cur = src[0];
-#pragma unroll
-		for (int w = 0; w < W; ++w) { const uint64_t nxt = src[w + 1]; win[w] = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur; cur = nxt; }
-		const int tail = 2 * L - 64 * (W - 1);
-		if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
-		if (dir) {
-			uint64_t tt[W];
-#pragma unroll
-			for (int w = 0; w < W; ++w) tt[w] = ~rev_groups(win[W - 1 - w]);
-			const int drop = 64 * W - 2 * L;
-#pragma unroll
-			for (int w = 0; w < W; ++w) { const uint64_t a = tt[w], b = w + 1 < W ? tt[w + 1] : 0ull; win[w] = drop ? (a >> drop) | (b << (64 - drop)) : a; }
-			if (tail < 64) win[W - 1] &= (1ull << tail) - 1;
-		}
+		contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
 		int dist = 0;
 #pragma unroll
 		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 #pragma unroll
 			for (int s = 1; s < 8; ++s) {
 				if ((unsigned long long)s > filled) break;
-				if ((ks[s] >> 52) != tag) continue;
+				if ((ks[s] >> CIX_TAG_SHIFT) != tag) continue;
 				const uint64_t v = ks[s];
 				if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
 				else verify(v);                                                                // a repeat: more copies than registers
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 #pragma unroll 1
 				for (uint32_t s = 1; s <= cn; ++s) {
 					const unsigned long long v = X[(size_t)j * 8 + s];
-					if ((v >> 52) != tag) continue;
+					if ((v >> CIX_TAG_SHIFT) != tag) continue;
 					if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
 					else verify(v);
 					++nc;
@@ -588,6 +596,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
 	g.n_parts = geom & 0xFFFFu; g.n_lines = geom >> 16;
+	g.pbits = cix_pbits(n_contigs);
 	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
 	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
 	if (n_contigs == 0 || n_sg == 0) return MCOM_OK;
@@ -627,6 +636,38 @@ extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, ui
 {
 	return realign_reads_launch(ctx, d_keys, n_parts, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, n_contigs, L, ininumdict, thr,
 	                            d_claim, d_stats, nullptr, nullptr, 0, nullptr);
+}
+
+// ---- a14 as a batched entry of its own: the cost test of kthread_hash_realign.c:283-314 for n (read, contig window) pairs, with the
+// device functions the pass itself uses (contig_window, encode_ok_sparse)
+template <int W>
+__global__ void k_encode_byte(const uint64_t *__restrict__ rows, const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
+                              const uint32_t *__restrict__ contig, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ dirs, size_t n, int L,
+                              uint8_t *__restrict__ ok)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint64_t win[W], mm[W];
+	const bool dir = dirs[i] != 0;
+	contig_window<W>(cbits + coff[contig[i]], (uint64_t)pos[i], L, dir, win);
+#pragma unroll
+	for (int w = 0; w < W; ++w) { const uint64_t x = win[w] ^ rows[i * (size_t)W + w]; mm[w] = (x | (x >> 1)) & 0x5555555555555555ull; }
+	ok[i] = encode_ok_sparse<W>(mm, L, dir) ? 1 : 0;
+}
+extern "C" int mcom_encode_byte(mcom_ctx *ctx, const uint64_t *d_rows, const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_contig,
+                                const uint32_t *d_pos, const uint8_t *d_dir, size_t n, int L, uint8_t *d_ok)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range", L);
+	if (n == 0) return MCOM_OK;
+	if (!d_rows || !d_cbits || !d_coff || !d_contig || !d_pos || !d_dir || !d_ok) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_encode_byte<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_rows, d_cbits, d_coff, d_contig, d_pos, d_dir, n, L, d_ok); break;
+	switch (mcom_words_per_read(L)) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_CASE
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
 }
 
 // ---- bins longer than maxsearch ---------------------------------------------------------------------------------

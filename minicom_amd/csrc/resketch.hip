@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_rs_write(const RsPlan *__restrict__ pla
 	if (j >= nj) return;
 	const int lane = threadIdx.x & 15;
 	const RsPlan P = plan[j]; const RsCut C = cut[j];
-	const uint64_t id = (uint64_t)((uint32_t)j << 8) << 32;                  // (index<<8)+tid at tid 0, kthread_bucket.c:458
+	const uint64_t id = (uint64_t)(uint32_t)j << 32;                        // the contig index (include/mcom.h, "contig ids")
 	mcom_mm128 *dst = out + roff2[j];
 	for (uint32_t t = lane; t < C.nl; t += 16) { mcom_mm128 r = rec[C.l0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); dst[t] = r; }
 	dst += C.nl;

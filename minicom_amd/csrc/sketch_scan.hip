@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	const uint32_t t = have ? (list ? list[li] : li) : 0u;
 	const uint32_t len = have ? ssc_len(off, off_end, t) : 0u;
 	const uint8_t *s = seq + (have ? off[t] : 0);
-	const uint64_t idhi = (uint64_t)(ids ? (have ? ids[t] : 0u) : (uint32_t)(t << 8)) << 32;
+	const uint64_t idhi = (uint64_t)(ids ? (have ? ids[t] : 0u) : (uint32_t)t) << 32;
 	const uint32_t mybase = have ? base[t] : 0u;
 	const uint32_t myroom = have ? (room_is_count ? cnt[t] : room[t]) : 0u;
 	uint32_t maxlen = len;

@@ -61,6 +61,8 @@ def load_library():
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32
     L.mcom_sketch_reads.argtypes = [vp, vp, vp, sz, i32, i32, u32, vp]
+    L.mcom_hash64_batch.restype = i32; L.mcom_hash64_batch.argtypes = [vp, vp, sz, i32, vp]
+    L.mcom_encode_byte.restype = i32; L.mcom_encode_byte.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]
     L.mcom_radix_sort_128x.restype = i32; L.mcom_radix_sort_128x.argtypes = [vp, vp, sz]
     L.mcom_sort_group.restype = i32
     L.mcom_sort_group.argtypes = [vp, vp, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -201,6 +203,22 @@ class Context:
                                                self._p(rids, torch.int32) if rids is not None else C.c_void_p(0),
                                                n, L, k, rid0, self._p(rec)))
         return rec
+
+    def hash64(self, kmers, k: int):
+        """mcom_hash64_batch: hash64 (sketch.c:27-37) of int64 k-mers."""
+        torch = _torch()
+        out = torch.empty_like(kmers)
+        self._check(self.lib.mcom_hash64_batch(self._h, self._p(kmers, torch.int64), int(kmers.shape[0]), k, self._p(out)))
+        return out
+
+    def encode_byte(self, rows, cg, contig, pos, dirs, L: int):
+        """mcom_encode_byte: the cost test of kthread_hash_realign.c:283-314 for (read row, contig window) pairs."""
+        torch = _torch()
+        n = int(rows.shape[0])
+        ok = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mcom_encode_byte(self._h, self._p(rows, torch.int64), self._p(cg["cbits"]), self._p(cg["coff"]), self._p(contig, torch.int32),
+                                              self._p(pos, torch.int32), self._p(dirs, torch.uint8), n, L, self._p(ok)))
+        return ok[:n]
 
     def radix_sort_128x(self, rec):
         """mcom_radix_sort_128x: in place, by x ascending, stable."""

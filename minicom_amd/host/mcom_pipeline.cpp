@@ -760,6 +760,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	if (n_sg_total <= 5000000) p->maxsearch = 2000;                                 // preprocess.c:169-172
 	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
 	p->stat["n_sg0"] = (double)n_sg_total;
+	p->stat["contigs_bucket"] = (double)p->dC.n;
 	p->stat["t_bucket"] += now_ms() - t0;
 	return MCOM_OK;
 }
@@ -1012,12 +1013,12 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		if (!flag.resize(n) || !jobs.resize(n / 2 + 1)) return p->fail(MCOM_E_NOMEM, "claim buffers");
 		if (n) memset(flag.data(), 0, n);
 		for (size_t q = 0; q < n_pass;) {
-			const uint32_t ci = (uint32_t)(pairs[q].x >> 32) >> 8;
+			const uint32_t ci = (uint32_t)(pairs[q].x >> 32);
 			size_t qe = q;
-			while (qe < n_pass && ((uint32_t)(pairs[qe].x >> 32) >> 8) == ci) ++qe;
+			while (qe < n_pass && (uint32_t)(pairs[qe].x >> 32) == ci) ++qe;
 			if (!flag[ci]) {
 				for (size_t u = q; u < qe; ++u) {
-					const uint32_t cj = (uint32_t)(pairs[u].y >> 32) >> 8;
+					const uint32_t cj = (uint32_t)(pairs[u].y >> 32);
 					if (flag[cj]) continue;
 					jobs[nj++] = Job{ci, cj, (uint32_t)pairs[u].x >> 1, (uint32_t)pairs[u].y >> 1};
 					flag[ci] = flag[cj] = 1;                                                // :339-343
@@ -1093,6 +1094,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	}
 	// the final set stays on the device, for Stage 2 and beyond; the host learns the offsets when Stage 2 asks for them
 	p->maxlen = maxlen;
+	p->stat["contigs_combine"] = (double)A.n;
 	p->dC.swap(A); p->dC_valid = true;
 	p->cbits_for_dC = packed_ready && p->dC.n != 0;                          // Stage 2 takes the packed set as it is
 	p->hostC_valid = false; p->host_off_valid = false;
@@ -1328,10 +1330,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	p->join_sg();
 	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
+	const bool sg_sent_up = p->sg_uploaded;                         // (mcomh_update_single clears the flag: it only vouches for the list of combine_cluster)
 	{ const double tu = now_ms(); mcomh_update_single(p); p->stat["t_ra_update"] += now_ms() - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
-	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && p->sg_uploaded && !p->early.on) {
+	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && sg_sent_up && !p->early.on) {
 		// singletons' rows and the dictionary screen on the copy stream (behind the upload of the singleton list, which went there),
 		// while this thread builds the contig index on the main stream
 		P::Early &E = p->early;
@@ -1342,7 +1345,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			E.sg.swap(p->d_sg_live); p->sg_live_valid = false;
 			if (mcom_gather_rows(p->ctx2, p->d_packed.p, E.sg.p, n_sg, p->L, E.sgbits.p) == MCOM_OK &&
 			    hipEventRecord(p->ev_early, p->copy_stream) == hipSuccess &&
-			    mcom_dicts_screen_begin(p->ctx2, E.sgbits.p, n_sg, p->L, p->numdict, p->maxsearch) == MCOM_OK) { E.on = true; E.n_sg = n_sg; }
+			    mcom_dicts_screen_begin(p->ctx2, E.sgbits.p, n_sg, p->L, p->numdict, p->maxsearch) == MCOM_OK) { E.on = true; E.n_sg = n_sg; p->stat["early_screen"] += 1; }
 			else { (void)hipStreamSynchronize(p->copy_stream); p->d_sg_live.swap(E.sg); p->sg_live_valid = true; }   // as before
 		}
 	}
@@ -1635,6 +1638,8 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, mo.p, mr.p, p->C.n(), (uint32_t)p->m, mo2.p, mr2.p, &tm)))) { fclose(f); return rc; }
 			rec.resize(tm);
 			if (tm) (void)hipMemcpy(rec.data(), mr2.p, tm * sizeof(mcom_mm128), hipMemcpyDeviceToHost);
+			// the reference's id is (index << 8) + tid (kthread_bucket.c:458); ours is the index
+			for (mcom_mm128 &r : rec) r.y = ((r.y >> 32) << (32 + MCOM_REF_CONTIG_ID_SHIFT)) | (r.y & 0xFFFFFFFFull);
 		}
 		dump_buckets(f, "MI0", rec);
 	}

@@ -93,6 +93,32 @@ def synth_reads(seed: int, n_reads: int, read_len: int, coverage: int = 30,
     return np.ascontiguousarray(out)
 
 
+def repeat_rich_reads(n: int, L: int, sub_rate: float = 0.004, seed: int = 97, genome: int = 200_000) -> np.ndarray:
+    """A repeat-rich read set: a short genome with a 2 kb segment in forty (partly mutated) copies, a tandem repeat of a
+    37-base unit, a poly-A and an (AT)n stretch, sampled at very high coverage -- groups of tens of thousands of reads, long
+    runs of equal minimizers in the contig index, contigs of 10^5 members, several Stage-2 passes at higher error rates."""
+    rng = np.random.default_rng(seed)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    G = genome
+    g = ACGT[rng.integers(0, 4, G)]
+    rep = ACGT[rng.integers(0, 4, 2000)]
+    for at in rng.integers(0, G - 2000, 40):
+        c = rep.copy()
+        for q in rng.integers(0, 2000, int(rng.integers(0, 6))):
+            c[q] = ACGT[rng.integers(0, 4)]
+        g[at:at + 2000] = c
+    unit = ACGT[rng.integers(0, 4, 37)]
+    g[50_000:50_000 + 37 * 60] = np.tile(unit, 60)
+    g[120_000:120_400] = ord("A"); g[130_000:130_300] = np.tile(np.frombuffer(b"AT", dtype=np.uint8), 150)
+    start = rng.integers(0, G - L + 1, n)
+    reads = g[start[:, None] + np.arange(L)[None, :]]
+    sub = rng.random((n, L)) < sub_rate
+    reads = np.where(sub, ACGT[rng.integers(0, 4, (n, L))], reads)
+    rc = rng.random(n) < 0.5
+    reads[rc] = comp[reads[rc]][:, ::-1]
+    return np.ascontiguousarray(reads)
+
+
 def write_fastq(path: str, reads: np.ndarray) -> None:
     n, L = reads.shape
     qual = b"I" * L

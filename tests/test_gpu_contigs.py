@@ -142,19 +142,19 @@ def test_find_next_candidates_on_reference_fixture_contigs(ctx, golden_dir, tag)
     # expectation with the oracle's functions
     table = {}
     for i, r in enumerate(refs):
-        mz = oracle.sketch_lh_ori(r, rw, k, i << 8)[:m]
+        mz = oracle.sketch_lh_ori(r, rw, k, i)[:m]
         for x, y in zip(mz["x"].tolist(), mz["y"].tolist()):
             table.setdefault(x, []).append(y)
     want = []
     tested = 0
     for i, r in enumerate(refs):
-        for x, y in zip(*[v.tolist() for v in (lambda a: (a["x"], a["y"]))(oracle.sketch_lh_ori(r, rw, k, i << 8))]):
+        for x, y in zip(*[v.tolist() for v in (lambda a: (a["x"], a["y"]))(oracle.sketch_lh_ori(r, rw, k, i))]):
             for hy in table.get(x, []):
                 tested += 1
                 rid = hy >> 32
-                if rid == (i << 8) or (hy & 1) != (y & 1):
+                if rid == i or (hy & 1) != (y & 1):
                     continue
-                if oracle.match_pro(r, refs[rid >> 8], (y & 0xFFFFFFFF) >> 1, (hy & 0xFFFFFFFF) >> 1) <= cbthr:
+                if oracle.match_pro(r, refs[rid], (y & 0xFFFFFFFF) >> 1, (hy & 0xFFFFFFFF) >> 1) <= cbthr:
                     want.append((y, hy))
     assert n_tested == tested
     assert list(zip(got["x"].tolist(), got["y"].tolist())) == want
@@ -234,7 +234,7 @@ def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, wave):
     moff = moff.cpu().numpy(); r = _recs(out)
     total = 0
     for i, ref in enumerate(refs):
-        want = oracle.sketch_lh_ori(ref, w, k, i << 8)
+        want = oracle.sketch_lh_ori(ref, w, k, i)
         seg = r[moff[i]:moff[i + 1]]
         assert np.array_equal(seg["x"], want["x"]) and np.array_equal(seg["y"], want["y"]), (w, k, i, len(ref))
         total += len(want)

@@ -257,7 +257,7 @@ def test_merge_round_pieces_against_numpy(ctx, L):
     at = base
     for u, i in enumerate(kept.tolist()):
         seg = r[ro[i]:ro[i + 1]].copy()
-        seg[:, 1] = (np.uint64((nj + u) << 8) << np.uint64(32)) | (seg[:, 1] & np.uint64(0xFFFFFFFF))
+        seg[:, 1] = (np.uint64(nj + u) << np.uint64(32)) | (seg[:, 1] & np.uint64(0xFFFFFFFF))
         assert ro2[nj + u] == at and np.array_equal(r2[at:at + len(seg)], seg), u
         at += len(seg)
     assert ro2[nn] == at == total

@@ -90,3 +90,63 @@ def test_pipeline_equals_the_sequential_oracle_on_8m_reads():
     for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
         assert np.array_equal(o.id_list(name), p.id_list(name)), name
     p.close(); o.close()
+
+
+def _oracle_with_heartbeat(reads, label):
+    import threading
+    import oracle
+    t0 = time.time()
+    stop = threading.Event()
+
+    def beat():
+        while not stop.wait(45):
+            print(f"... oracle ({label}) running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+    o = oracle.Pipeline(reads); o.run_all()
+    stop.set()
+    print(f"\noracle ({label}): {time.time() - t0:.0f} s", flush=True)
+    return o
+
+
+def _assert_equal_sets(o, p):
+    ref, roff, mem, moff = p.contig_set()
+    oc = o.contigs()
+    assert len(oc) == len(roff) - 1
+    assert b"".join(r for r, _ in oc) == ref.tobytes()
+    assert np.array_equal(np.cumsum([0] + [len(r) for r, _ in oc]).astype(np.uint64), roff)
+    assert np.array_equal(np.concatenate([m for _, m in oc]) if oc else np.zeros(0, np.uint64), mem)
+    assert np.array_equal(np.cumsum([0] + [len(m) for _, m in oc]).astype(np.uint64), moff)
+    for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        assert np.array_equal(o.id_list(name), p.id_list(name)), name
+
+
+def test_pipeline_equals_the_sequential_oracle_on_2m_reads_of_150_bases():
+    """The headline shape against the oracle above fixture size: 2 M x 150 bp with the plumbing extras (N, poly-A/T, N-heavy
+    reads): five-word rows, sixteen bases per lane in the classifier, eight Stage-2 dictionaries, index buckets beyond 64
+    entries -- contig strings, member lists and every list identical."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    n, L = 2_000_000, 150
+    reads = synth.synth_reads(5151, n, L, plumbing=True)
+    o = _oracle_with_heartbeat(reads, "2 M x 150")
+    p = Pipeline(reads, host_threads=8); p.pre_process()
+    assert len(o.contigs()) > 50_000 and p.stat("merge_rounds") >= 4 and p.stat("passes") >= 2
+    _assert_equal_sets(o, p)
+    assert p.stat("early_screen") >= 1                              # the first pass's singleton gather + screen ran beside the index build
+    p.close(); o.close()
+
+
+@pytest.mark.parametrize("n,L,sub_rate", [(3_000_000, 100, 0.004), (2_000_000, 100, 0.04), (1_000_000, 150, 0.02)])
+def test_pipeline_equals_the_sequential_oracle_on_repeat_rich_reads(n, L, sub_rate):
+    """A 200 kb genome with a 2 kb segment in forty copies, a tandem repeat, poly-A and (AT)n stretches at >= 750 x coverage:
+    groups beyond 65 535 members, contigs of 10^5 members, heavy runs of equal minimizers in the index, long Stage-2 bins and
+    up to five passes (tools/repeat_parity.py of round 1, now in the suite)."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = synth.repeat_rich_reads(n, L, sub_rate)
+    o = _oracle_with_heartbeat(reads, f"repeats {n} x {L} @ {sub_rate}")
+    p = Pipeline(reads, host_threads=8); p.pre_process()
+    print(f"repeat-rich {n} x {L}: {len(o.contigs())} contigs, largest {max((len(m) for _, m in o.contigs()), default=0)} members, "
+          f"big_bins {p.stat('big_bins')}, big_bin_reads {p.stat('big_bin_reads')}, passes {p.stat('passes')}", flush=True)
+    _assert_equal_sets(o, p)
+    p.close(); o.close()

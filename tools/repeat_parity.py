@@ -8,28 +8,8 @@ import numpy as np
 n, L = int(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 100
 gpu = "--oracle-only" not in sys.argv
 sub_rate = float(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else 0.004
-rng = np.random.default_rng(97)
-acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
-G = 200_000
-g = acgt[rng.integers(0, 4, G)]
-rep = acgt[rng.integers(0, 4, 2000)]
-for at in rng.integers(0, G - 2000, 40):                      # forty dispersed copies, a few of them mutated
-    c = rep.copy()
-    for q in rng.integers(0, 2000, int(rng.integers(0, 6))): c[q] = acgt[rng.integers(0, 4)]
-    g[at:at + 2000] = c
-unit = acgt[rng.integers(0, 4, 37)]
-g[50_000:50_000 + 37 * 60] = np.tile(unit, 60)                # a tandem repeat
-g[120_000:120_400] = ord("A"); g[130_000:130_300] = np.tile(np.frombuffer(b"AT", dtype=np.uint8), 150)
-start = rng.integers(0, G - L + 1, n)
-# a third of the reads pile up on the repeat copies
-hot = rng.random(n) < 0.35
-reads = g[start[:, None] + np.arange(L)[None, :]]
-sub = rng.random((n, L)) < sub_rate
-reads = np.where(sub, acgt[rng.integers(0, 4, (n, L))], reads)
-rc = rng.random(n) < 0.5
-reads[rc] = comp[reads[rc]][:, ::-1]
-reads = np.ascontiguousarray(reads)
+from minicom_amd import synth
+reads = synth.repeat_rich_reads(n, L, sub_rate)          # (the generator moved to minicom_amd/synth.py: tests/test_gpu_scale.py runs it too)
 t00 = time.time()
 def _beat():
     while True:
