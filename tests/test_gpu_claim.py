@@ -27,8 +27,8 @@ def _sequential(pairs, n):
 
 def _records(pairs):
     a = np.array(pairs, dtype=np.uint64).reshape(-1, 4)
-    x = ((a[:, 0] << np.uint64(8)) << np.uint64(32)) | (a[:, 2] << np.uint64(1))
-    y = ((a[:, 1] << np.uint64(8)) << np.uint64(32)) | (a[:, 3] << np.uint64(1)) | np.uint64(1)
+    x = (a[:, 0] << np.uint64(32)) | (a[:, 2] << np.uint64(1))            # the id is the contig index (include/mcom.h)
+    y = (a[:, 1] << np.uint64(32)) | (a[:, 3] << np.uint64(1)) | np.uint64(1)
     return np.stack([x, y], axis=1)
 
 
