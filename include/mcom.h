@@ -262,8 +262,8 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
  * extension area behind the partitions.  It is BUILT BY RADIX PARTITIONING: two streaming passes split
  * the entries by partition, then one workgroup per partition places its entries and writes its lines once (no scattered
  * insert, no memset, no atomics in HBM).
- *   mcom_cindex_plan   sizes it for a contig set: *geom (partitions | lines per partition << 16, handed to the build and
- *                      the lookups), *n_words = uint64 words of d_keys (header, partitions, extension area)
+ *   mcom_cindex_plan   sizes it for a contig set: *geom (partitions | lines per partition << 16 | shares | owner, handed to the build
+ *                      and the lookups), *n_words = uint64 words of d_keys (header, partitions, extension area)
  *   mcom_cindex_build  fills d_keys from the packed contigs (d_woff must hold n_contigs + 1 entries); temporaries of
  *                      24 bytes per entry come from the library's block pool.  MCOM_E_OVERFLOW: the extension area is
  *                      too small for this set's repeats -- build again with a larger n_words.  Synchronous.
@@ -276,14 +276,30 @@ int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbi
  *            maxsearch argument; both equal the reference only while no bin exceeds maxsearch -- for longer
  *            bins use mcom_dicts_bigbins / mcom_realign_pass_tuples below
  *   d_stats: optional [3] = { lookups, windows verified, tuples passing }                                */
-int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *geom, uint64_t *n_words);
+int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint64_t *geom, uint64_t *n_words);
 int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                      uint64_t n_windows, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words);
-/* mcom_cindex_build for contigs [c0, c1) of the set only: the multi-GPU path gives every rank a range of the replicated
- * contig set (size the index with mcom_cindex_plan(windows of the range, c1 - c0, ...)); entries carry the global
- * contig index, so that claim keys found against different ranks' parts are comparable.                        */
-int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                            uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words);
+                      uint64_t n_windows, int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words);
+/* Multi-GPU: the ONE index over all contigs shared out BY KEY.  The hash range is cut into `ranks` equal shares; rank q builds and
+ * holds share q (a table of its own, 1 / ranks of the entries) and looks up only the keys that hash into it -- every rank sees every
+ * singleton (rows replicated), does 1 / ranks of the lookups and verifications, and the claim keys are MIN-reduced.  The build is
+ * two calls with the caller's exchange between them:
+ *   mcom_cindex_plan_shared  geometry of every share (the same on all ranks but for the owner field): *n_entries = entries of the
+ *                            whole index (upper bound), *n_share = room a share needs for the entries it receives, *geom, *n_words
+ *   mcom_cindex_entries      the entries of contigs [c0, c1) of the set (a rank takes a range of the replicated set): d_key / d_slot
+ *                            [cap >= their positions], grouped by owning share in share order, h_counts[ranks] (HOST) = entries per
+ *                            share.  With one share they come grouped by the low byte of their partition (place: grouped = 1).
+ *                            Entries carry the global contig index.  MCOM_E_OVERFLOW when cap is too small.  Synchronous.
+ *   mcom_cindex_place        this share's table from the n_ent entries it received, in any order (grouped = 0): two radix passes by
+ *                            partition, then one workgroup per partition writes its lines.  d_key / d_slot are overwritten,
+ *                            d_key_tmp / d_slot_tmp are scratch of n_ent entries.  MCOM_E_OVERFLOW as for mcom_cindex_build.
+ * mcom_cindex_build = mcom_cindex_entries + mcom_cindex_place for one share.                                                */
+int mcom_cindex_plan_shared(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, int ranks, int rank, uint64_t *n_entries,
+                            uint64_t *n_share, uint64_t *geom, uint64_t *n_words);
+int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                        uint32_t c0, uint32_t c1, int L, int ininumdict, uint64_t geom, uint32_t *d_key, uint64_t *d_slot, uint64_t cap,
+                        uint64_t *h_counts);
+int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
+                      int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words);
 int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
 /* Screen before mcom_dicts_build: *h_may_exceed = 0 proves that no bin of any dictionary over these singletons
  * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
@@ -293,7 +309,7 @@ int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int 
  * can run the screen on a second context / stream beside other work)                                                     */
 int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch);
 int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed);
-int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom,
+int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t geom,
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
@@ -319,7 +335,7 @@ int mcom_encode_byte(mcom_ctx *ctx, const uint64_t *d_rows, const uint64_t *d_cb
  *   mcom_claims_patch        d_claim[d_idx[i]] = d_val[i]: the result of replaying the marked singletons
  * The replay itself (a few thousand reads, in visiting order) is host work: minicom_amd/host/mcom_pipeline.cpp.  */
 int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_binstart, uint8_t *d_mark);
-int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom,
+int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t geom,
                              const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg,
                              const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                              int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats,

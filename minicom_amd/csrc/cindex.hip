@@ -41,7 +41,8 @@ __global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, u
 struct CxSrc { const uint64_t *cbits, *coff, *woff; const uint32_t *first_contig; uint32_t c1; uint64_t pos0, n_pos; unsigned long long *head; };
 
 // the entry of position gi: false when the position holds none (a contig without windows, the end of the range)
-__device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint64_t gi, uint32_t &key32, uint64_t &slot)
+// digit: what pass 1 splits by -- the low byte of the partition, or (multi-GPU) the share that owns the key
+__device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint64_t gi, uint32_t &key32, uint64_t &slot, uint32_t &digit)
 {
 	if (gi >= s.n_pos) return false;
 	uint32_t c = s.first_contig[gi >> 8];
@@ -54,14 +55,15 @@ __device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint6
 	uint64_t v = src[0] >> sh;
 	if (sh + 2 * g.klen > 64) v |= src[1] << (64 - sh);
 	const uint64_t key = v & ((1ull << (2 * g.klen)) - 1);
-	uint32_t part, h16;
-	cix_hash(key, g.n_parts, part, h16);
+	uint32_t own, part, h16;
+	cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
 	key32 = (part << 16) | h16;
+	digit = g.n_owners > 1 ? own : (part & 255u);
 	slot = (cix_tag(key) << CIX_TAG_SHIFT) | ((uint64_t)c << g.pbits) | p;
 	return true;
 }
 
-// pass 1, histogram: digit = low byte of the partition
+// pass 1, histogram: digit = low byte of the partition (owner of the key when the index is shared out)
 __global__ __launch_bounds__(CX_THREADS) void k_cx_hist1(CixGeom g, CxSrc s, uint32_t *__restrict__ hist, uint32_t nblocks)
 {
 	__shared__ uint32_t h[256];
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_hist1(CixGeom g, CxSrc s, uin
 	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
 #pragma unroll 4
 	for (int it = 0; it < CX_ITEMS; ++it) {
-		uint32_t k32; uint64_t sl;
-		if (cx_entry(g, s, base + (uint64_t)it * CX_THREADS + threadIdx.x, k32, sl)) atomicAdd(&h[(k32 >> 16) & 255u], 1u);
+		uint32_t k32, dg; uint64_t sl;
+		if (cx_entry(g, s, base + (uint64_t)it * CX_THREADS + threadIdx.x, k32, sl, dg)) atomicAdd(&h[dg], 1u);
 	}
 	__syncthreads();
 	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -83,16 +85,19 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 {
 	__shared__ uint64_t st_slot[CX_TILE];
 	__shared__ uint32_t st_key[CX_TILE];
+	__shared__ uint8_t st_dig[CX_TILE];                     // (shared-out index only: the owner is not a function of the staged key)
 	__shared__ uint32_t cnt[256], start[256], gofs[256], wsum[CX_THREADS / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	cnt[tid] = 0;
 	__syncthreads();
 	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
-	uint32_t k32[CX_ITEMS], rank[CX_ITEMS]; uint64_t sl[CX_ITEMS]; bool ok[CX_ITEMS];
+	uint32_t k32[CX_ITEMS], rank[CX_ITEMS]; uint64_t sl[CX_ITEMS]; bool ok[CX_ITEMS]; uint8_t dg[CX_ITEMS];
 #pragma unroll
 	for (int it = 0; it < CX_ITEMS; ++it) {
-		ok[it] = cx_entry(g, s, base + (uint64_t)it * CX_THREADS + tid, k32[it], sl[it]);
-		rank[it] = ok[it] ? atomicAdd(&cnt[(k32[it] >> 16) & 255u], 1u) : 0u;
+		uint32_t d = 0;
+		ok[it] = cx_entry(g, s, base + (uint64_t)it * CX_THREADS + tid, k32[it], sl[it], d);
+		dg[it] = (uint8_t)d;
+		rank[it] = ok[it] ? atomicAdd(&cnt[d], 1u) : 0u;
 	}
 	__syncthreads();
 	{
@@ -110,20 +115,22 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 	__syncthreads();
 #pragma unroll
 	for (int it = 0; it < CX_ITEMS; ++it) if (ok[it]) {
-		const uint32_t at = start[(k32[it] >> 16) & 255u] + rank[it];
+		const uint32_t at = start[dg[it]] + rank[it];
 		st_key[at] = k32[it]; st_slot[at] = sl[it];
+		if (g.n_owners > 1) st_dig[at] = dg[it];
 	}
 	__syncthreads();
 	const uint32_t total = start[255] + cnt[255];
 	for (uint32_t q = tid; q < total; q += CX_THREADS) {
-		const uint32_t k = st_key[q], d = (k >> 16) & 255u;
+		const uint32_t d = g.n_owners > 1 ? (uint32_t)st_dig[q] : (st_key[q] >> 16) & 255u;
 		const size_t o = (size_t)gofs[d] + (q - start[d]);
-		out_key[o] = k; out_slot[o] = st_slot[q];
+		out_key[o] = st_key[q]; out_slot[o] = st_slot[q];
 	}
 }
 
-// pass 2 (digit = high byte of the partition), stable: the tile logic of sort.hip's k_radix_scatter on two arrays
-__global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t nblocks)
+// passes over the entry arrays (digit = byte of the partition at `shift`: 24 = its high byte, 16 = its low byte), stable: the tile
+// logic of sort.hip's k_radix_scatter on two arrays
+__global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t nblocks, int shift)
 {
 	__shared__ uint32_t h[256];
 	h[threadIdx.x] = 0;
@@ -132,13 +139,13 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restr
 #pragma unroll 4
 	for (int it = 0; it < CX_ITEMS; ++it) {
 		const size_t i = base + (size_t)it * CX_THREADS + threadIdx.x;
-		if (i < n) atomicAdd(&h[key[i] >> 24], 1u);
+		if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1u);
 	}
 	__syncthreads();
 	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__restrict__ in_key, const uint64_t *__restrict__ in_slot, size_t n,
-                                                            const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot)
+                                                            const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot, int shift)
 {
 	__shared__ uint64_t st_slot[CX_TILE];
 	__shared__ uint32_t st_key[CX_TILE];
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__re
 		const size_t i = base + (size_t)c * 64 + lane;
 		const bool valid = i < n;
 		uint32_t d = 0;
-		if (valid) { k32[c] = in_key[i]; sl[c] = in_slot[i]; d = k32[c] >> 24; }
+		if (valid) { k32[c] = in_key[i]; sl[c] = in_slot[i]; d = (k32[c] >> shift) & 255u; }
 		uint64_t peers = __ballot(valid);
 #pragma unroll
 		for (int bit = 0; bit < 8; ++bit) {
@@ -192,13 +199,13 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__re
 #pragma unroll
 	for (int c = 0; c < CX_ITEMS; ++c) {
 		const size_t i = base + (size_t)c * 64 + lane;
-		if (i < n) { const uint32_t at = wcnt[wv][k32[c] >> 24] + rank[c]; st_key[at] = k32[c]; st_slot[at] = sl[c]; }
+		if (i < n) { const uint32_t at = wcnt[wv][(k32[c] >> shift) & 255u] + rank[c]; st_key[at] = k32[c]; st_slot[at] = sl[c]; }
 	}
 	__syncthreads();
 	const size_t tile_base = (size_t)blockIdx.x * CX_TILE;
 	const uint32_t total = (uint32_t)((n - tile_base) < (size_t)CX_TILE ? (n - tile_base) : (size_t)CX_TILE);
 	for (uint32_t q = tid; q < total; q += CX_THREADS) {
-		const uint32_t k = st_key[q], d = k >> 24;
+		const uint32_t k = st_key[q], d = (k >> shift) & 255u;
 		const size_t o = (size_t)gofs[d] + (q - tstart[d]);
 		out_key[o] = k; out_slot[o] = st_slot[q];
 	}
@@ -473,115 +480,171 @@ __global__ __launch_bounds__(CS_THREADS) void k_cx_assemble_sorted(const uint32_
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------
-extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint32_t *geom, uint64_t *n_words)
+// sizes for `ranks` equal shares of the one index over a set with n_windows windows (ranks = 1: the whole index)
+extern "C" int mcom_cindex_plan_shared(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, int ranks, int rank, uint64_t *n_entries, uint64_t *n_share,
+                                       uint64_t *geom, uint64_t *n_words)
 {
 	CixGeom g;
-	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return MCOM_E_ARG;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g) || ranks < 1 || ranks > (int)CIX_MAX_OWNERS || rank < 0 || rank >= ranks) return MCOM_E_ARG;
 	const uint64_t ne = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff;          // an upper bound: contigs without windows hold no entry
-	if (ne >= (1ull << 32)) return MCOM_E_ARG;
-	uint64_t P = ne / 12288;                                                           // ~12 k entries = ~3500 lines = ~220 KB per partition
+	// a share receives the keys of 1 / ranks of the hash range: its expected number of entries, with room for the spread
+	const uint64_t share = ranks == 1 ? ne : ne / (uint64_t)ranks + ne / (uint64_t)ranks / 16 + 65536;
+	if (share >= (1ull << 32)) return MCOM_E_ARG;
+	uint64_t P = share / 12288;                                                        // ~12 k entries = ~3500 lines = ~220 KB per partition
 	if (P < 1) P = 1;
 	if (P > CIX_MAX_PARTS) P = CIX_MAX_PARTS;
-	uint64_t NL = (2 * ((ne + P - 1) / P) + 6) / 7;                                    // entries / 3.5: half full -- a lookup nearly always ends in its home line
+	uint64_t NL = (2 * ((share + P - 1) / P) + 6) / 7;                                 // entries / 3.5: half full -- a lookup nearly always ends in its home line
 	if (NL < 16) NL = 16;
-	if (NL > 12000) return MCOM_E_ARG;                                                 // the counters of a partition live in LDS
+	if (NL > CIX_MAX_LINES) return MCOM_E_ARG;                                         // the counters of a partition live in LDS (2.75 G entries per share)
 	const uint64_t ext = std::max<uint64_t>(1024, P * NL / 16);
 	if ((P * NL + ext) >= (1ull << 32)) return MCOM_E_ARG;
 	if (n_entries) *n_entries = ne;
-	if (geom) *geom = cix_pack((uint32_t)P, (uint32_t)NL);
+	if (n_share) *n_share = share;
+	if (geom) *geom = cix_pack((uint32_t)P, (uint32_t)NL, (uint32_t)ranks, (uint32_t)rank);
 	if (n_words) *n_words = CIX_HEAD_WORDS + 8 * (P * NL + ext);
 	return MCOM_OK;
 }
+extern "C" int mcom_cindex_plan(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, uint64_t *n_entries, uint64_t *geom, uint64_t *n_words)
+{
+	return mcom_cindex_plan_shared(n_windows, n_contigs, L, ininumdict, 1, 0, n_entries, nullptr, geom, n_words);
+}
 
-// contigs [c0, c1) of the set only (the whole set: 0, n_contigs): the multi-GPU path gives every rank a range of the
-// replicated contig set; entries carry the GLOBAL contig index, so claim keys of different ranks are comparable
-extern "C" int mcom_cindex_build_range(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                       uint32_t c0, uint32_t c1, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words)
+static inline size_t cx_al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Step 1 of the build: the entries of contigs [c0, c1) -- { partition << 16 | home bits } in d_key, slot words in d_slot, room for
+// `cap` each -- grouped by the share that owns their key (h_counts[q] entries for share q, in share order); with one share they
+// are grouped by the low byte of their partition instead, which is the first radix pass of mcom_cindex_place.
+extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
+                                   uint32_t c0, uint32_t c1, int L, int ininumdict, uint64_t geom, uint32_t *d_key, uint64_t *d_slot, uint64_t cap,
+                                   uint64_t *h_counts)
+{
+	if (!ctx || !h_counts) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	cix_unpack(geom, g);
+	for (uint32_t q = 0; q < g.n_owners; ++q) h_counts[q] = 0;
+	if (g.n_parts < 1 || g.n_lines < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index geometry");
+	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
+	g.pbits = cix_pbits(n_contigs);
+	if (c0 == c1) return MCOM_OK;
+	if (!d_cbits || !d_coff || !d_woff || !d_key || !d_slot) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
+	uint64_t w01[2] = {0, 0};
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[0], d_woff + c0, 8));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[1], d_woff + c1, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	const uint64_t n_pos = (w01[1] - w01[0]) ? (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff : 0;
+	if (n_pos >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions");
+	if (n_pos > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index entries: room for %llu, %llu positions", (unsigned long long)cap, (unsigned long long)n_pos);
+	if (!n_pos) return MCOM_OK;
+	const uint32_t nblocks = (uint32_t)((n_pos + CX_TILE - 1) / CX_TILE);
+	const uint64_t blocks256 = (n_pos + 255) / 256;
+	const size_t hist_b = cx_al((size_t)256 * nblocks * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nblocks + 2) * 4 + 1024), map_b = cx_al((size_t)blocks256 * 4 + 4);
+	char *tmp = nullptr;
+	if (mcom_dmalloc(&tmp, hist_b + scr_b + map_b + 2 * 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
+	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
+	uint32_t *hist = (uint32_t*)tmp, *scr = (uint32_t*)(tmp + hist_b), *first_contig = (uint32_t*)(tmp + hist_b + scr_b);
+	unsigned long long *head = (unsigned long long*)(tmp + hist_b + scr_b + map_b);   // word 1: a contig too long for the position field
+	MCOM_HIP(ctx, hipMemsetAsync(head, 0, 16, ctx->stream));
+	const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
+	hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
+	MCOM_LAUNCH_CHECK(ctx);
+	const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos, head};
+	hipLaunchKernelGGL(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
+	int rc;
+	if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;        // the extra element becomes the number of entries
+	hipLaunchKernelGGL(k_cx_scatter1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	MCOM_LAUNCH_CHECK(ctx);
+	// the first entry of every share = the scanned count of (digit q, block 0)
+	std::vector<uint32_t> st(g.n_owners + 1, 0);
+	if (g.n_owners > 1) { for (uint32_t q = 1; q < g.n_owners; ++q) MCOM_HIP(ctx, hipMemcpyAsync(&st[q], hist + (size_t)q * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream)); }
+	MCOM_HIP(ctx, hipMemcpyAsync(&st[g.n_owners], hist + (size_t)256 * nblocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+	uint64_t hd[2] = {0, 0};
+	MCOM_HIP(ctx, hipMemcpyAsync(hd, head, 16, hipMemcpyDeviceToHost, ctx->stream));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	if (hd[1]) return mcom_fail(ctx, MCOM_E_ARG, "contig index: a contig of this set of %u contigs is longer than 2^%d bases", n_contigs, g.pbits);
+	for (uint32_t q = 0; q < g.n_owners; ++q) h_counts[q] = (uint64_t)st[q + 1] - st[q];
+	return MCOM_OK;
+}
+
+// Step 2: this share's table from its n_ent entries (what mcom_cindex_entries made, or what the other ranks sent: any order),
+// sorted by partition in two radix passes (one when they arrive grouped by the partition's low byte: grouped != 0), then one
+// workgroup per partition.  d_key / d_slot are overwritten; d_key_tmp / d_slot_tmp: scratch of n_ent entries each.
+extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent64, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
+                                 int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words)
 {
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
-	g.n_parts = geom & 0xFFFFu; g.n_lines = geom >> 16;
+	cix_unpack(geom, g);
 	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
 	if (!d_keys || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
-	if (c0 > c1 || c1 > n_contigs) return mcom_fail(ctx, MCOM_E_ARG, "bad contig range");
-	g.pbits = cix_pbits(n_contigs);
+	if (n_ent64 >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig index entries for one share");
+	if (n_ent64 && (!d_key || !d_slot || !d_key_tmp || !d_slot_tmp)) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const uint32_t n_ent = (uint32_t)n_ent64;
 	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
 	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
-	uint64_t w01[2] = {0, 0};
-	if (c0 < c1) {
-		if (!d_cbits || !d_coff || !d_woff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-		MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[0], d_woff + c0, 8));
-		MCOM_HIP(ctx, mcom_d2h_async(ctx, &w01[1], d_woff + c1, 8));
-		MCOM_HIP(ctx, mcom_stream_sync(ctx));
-	}
-	const uint64_t n_pos = (w01[1] - w01[0]) ? (w01[1] - w01[0]) + (uint64_t)(c1 - c0) * (uint64_t)g.maxoff : 0;
-	if (n_pos >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions");
-	const uint32_t nblocks = (uint32_t)((n_pos + CX_TILE - 1) / CX_TILE);
-	const uint64_t blocks256 = (n_pos + 255) / 256;
-	// temporaries: two key / slot array pairs, histogram + scan scratch, block map, partition starts
-	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-	const size_t key_b = al((size_t)n_pos * 4 + 4), slot_b = al((size_t)n_pos * 8 + 8), hist_b = al((size_t)256 * std::max(1u, nblocks) * 4 + 64),
-	             scr_b = al(mcom_scan_scratch_elems((size_t)256 * std::max(1u, nblocks) + 2) * 4 + 1024), map_b = al((size_t)blocks256 * 4 + 4),
-	             tab_b = al(((size_t)g.n_parts + 2) * 4);
+	const uint32_t nb2 = std::max<uint32_t>(1, (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE));
+	const size_t hist_b = cx_al((size_t)256 * nb2 * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nb2 + 2) * 4 + 1024), tab_b = cx_al(((size_t)g.n_parts + 2) * 4);
 	char *tmp = nullptr;
-	if (mcom_dmalloc(&tmp, 2 * key_b + 2 * slot_b + hist_b + scr_b + map_b + 2 * tab_b + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: %zu bytes of temporaries", 2 * key_b + 2 * slot_b);
+	if (mcom_dmalloc(&tmp, hist_b + scr_b + 2 * tab_b + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
 	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
-	size_t o = 0;
-	auto take = [&](size_t b) { char *q = tmp + o; o += b; return q; };
-	uint32_t *keyA = (uint32_t*)take(key_b), *keyB = (uint32_t*)take(key_b);
-	uint64_t *slotA = (uint64_t*)take(slot_b), *slotB = (uint64_t*)take(slot_b);
-	uint32_t *hist = (uint32_t*)take(hist_b), *scr = (uint32_t*)take(scr_b), *first_contig = (uint32_t*)take(map_b);
-	uint32_t *pstart = (uint32_t*)take(tab_b);
-	uint8_t *redo = (uint8_t*)take(tab_b);
-	uint32_t n_ent = 0;
+	uint32_t *hist = (uint32_t*)tmp, *scr = (uint32_t*)(tmp + hist_b), *pstart = (uint32_t*)(tmp + hist_b + scr_b);
+	uint8_t *redo = (uint8_t*)(tmp + hist_b + scr_b + tab_b);
+	const uint32_t *skey = d_key; const uint64_t *sslot = d_slot;                         // the arrays that end up sorted by partition
 	int rc;
-	if (n_pos) {
-		const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
-		hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
-		MCOM_LAUNCH_CHECK(ctx);
-		const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos, (unsigned long long*)d_keys};
-		hipLaunchKernelGGL(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
-		MCOM_LAUNCH_CHECK(ctx);
-		MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
-		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;   // the extra element becomes the number of entries
-		MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_ent, hist + (size_t)256 * nblocks, 4));
-		hipLaunchKernelGGL(k_cx_scatter1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, keyA, slotA);
-		MCOM_LAUNCH_CHECK(ctx);
-		MCOM_HIP(ctx, mcom_stream_sync(ctx));
-	}
 	if (n_ent) {
-		const uint32_t nb2 = (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE);
-		hipLaunchKernelGGL(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, keyA, (size_t)n_ent, hist, nb2);
-		MCOM_LAUNCH_CHECK(ctx);
-		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nb2, scr))) return rc;
-		hipLaunchKernelGGL(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, keyA, slotA, (size_t)n_ent, hist, nb2, keyB, slotB);
-		MCOM_LAUNCH_CHECK(ctx);
+		uint32_t *ik = d_key, *ok = d_key_tmp; uint64_t *is = d_slot, *os = d_slot_tmp;
+		for (int shift = grouped ? 24 : 16; shift <= 24; shift += 8) {
+			hipLaunchKernelGGL(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, (size_t)n_ent, hist, nb2, shift);
+			MCOM_LAUNCH_CHECK(ctx);
+			if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nb2, scr))) return rc;
+			hipLaunchKernelGGL(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, is, (size_t)n_ent, hist, nb2, ok, os, shift);
+			MCOM_LAUNCH_CHECK(ctx);
+			std::swap(ik, ok); std::swap(is, os);
+		}
+		skey = ik; sslot = is;
 	}
-	hipLaunchKernelGGL(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, keyB, (size_t)n_ent, g.n_parts, pstart);
+	hipLaunchKernelGGL(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, skey, (size_t)n_ent, g.n_parts, pstart);
 	MCOM_LAUNCH_CHECK(ctx);
 	const size_t lds = (size_t)3 * g.n_lines * 4;
 	if (lds > 150 * 1024) return mcom_fail(ctx, MCOM_E_ARG, "contig index: partitions of %u lines", g.n_lines);
 	MCOM_HIP(ctx, hipMemsetAsync(redo, 0, g.n_parts, ctx->stream));
-	hipLaunchKernelGGL(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
+	hipLaunchKernelGGL(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
 	                   ctx->cix_cap_set ? std::min<uint32_t>(ctx->cix_cap, CS_CAP) : (uint32_t)CS_CAP);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_cx_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, keyB, slotB, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
+	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
 	MCOM_LAUNCH_CHECK(ctx);
-	uint64_t hd[2] = {0, 0};
-	MCOM_HIP(ctx, mcom_d2h_async(ctx, hd, d_keys, 16));
+	uint64_t used = 0;
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &used, d_keys, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
-	const uint64_t used = hd[0];
-	if (hd[1]) return mcom_fail(ctx, MCOM_E_ARG, "contig index: a contig of this set of %u contigs is longer than 2^%d bases", n_contigs, g.pbits);
 	if (used > ext_cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index: %llu extension lines needed, room for %llu", (unsigned long long)used, (unsigned long long)ext_cap);
 	return MCOM_OK;
 }
 
+// both steps for one GPU: 24 bytes per entry of temporaries from the library's block pool
 extern "C" int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
-                                 uint64_t n_windows, int L, int ininumdict, uint32_t geom, uint64_t *d_keys, uint64_t n_words)
+                                 uint64_t n_windows, int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words)
 {
-	(void)n_windows;                                                       // = d_woff[n_contigs]; read from the device
-	return mcom_cindex_build_range(ctx, d_cbits, d_coff, d_woff, n_contigs, 0, n_contigs, L, ininumdict, geom, d_keys, n_words);
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	cix_unpack(geom, g);
+	if (g.n_owners != 1) return mcom_fail(ctx, MCOM_E_ARG, "mcom_cindex_build makes the whole index: one share");
+	const uint64_t cap = n_windows + (uint64_t)n_contigs * (uint64_t)g.maxoff + 1;
+	if (cap >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig positions");
+	const size_t key_b = cx_al((size_t)cap * 4 + 4), slot_b = cx_al((size_t)cap * 8 + 8);
+	char *tmp = nullptr;
+	if (mcom_dmalloc(&tmp, 2 * key_b + 2 * slot_b) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: %zu bytes of temporaries", 2 * key_b + 2 * slot_b);
+	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
+	uint32_t *keyA = (uint32_t*)tmp, *keyB = (uint32_t*)(tmp + key_b);
+	uint64_t *slotA = (uint64_t*)(tmp + 2 * key_b), *slotB = (uint64_t*)(tmp + 2 * key_b + slot_b);
+	uint64_t cnt = 0;
+	int rc = mcom_cindex_entries(ctx, d_cbits, d_coff, d_woff, n_contigs, 0, n_contigs, L, ininumdict, geom, keyA, slotA, cap, &cnt);
+	if (rc) return rc;
+	return mcom_cindex_place(ctx, keyA, slotA, cnt, 1, keyB, slotB, L, ininumdict, geom, d_keys, n_words);
 }

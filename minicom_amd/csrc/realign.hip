@@ -518,18 +518,21 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		uint64_t key = bits_key(row, g.ds[l], g.klen);
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
 		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
-		uint32_t part, h16;
-		cix_hash(key, g.n_parts, part, h16);
+		uint32_t own, part, h16;
+		cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
 		const uint32_t nl = g.n_lines;
 		const unsigned long long *lines = keys + CIX_HEAD_WORDS;
 		const unsigned long long *L0 = lines + (size_t)part * nl * 8;
 		uint32_t line = cix_home(h16, nl);
 		const unsigned long long tag = cix_tag(key);
-		++n_look;
+		// (multi-GPU: the index is shared out by key; a key of another share is looked up on its owner's GPU, with this singleton's row
+		// replicated there, and the claim keys of all shares are MIN-reduced)
+		const bool mine = own == g.owner;
+		n_look += mine;
 		// the home line, then the lines behind it while entries were pushed on; when the home line says its keys are heavy (a repeat
 		// with more copies than a few lines hold) their entries are in a run of lines in the extension area, read afterwards
 		unsigned long long heavy = 0;
-		for (bool more = true, home = true; more; home = false) {
+		for (bool more = mine, home = true; more; home = false) {
 			const unsigned long long *kl = L0 + (size_t)line * 8;
 			unsigned long long ks[8];
 #pragma unroll
@@ -586,7 +589,7 @@ __global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsign
 	out[c] = s;
 }
 
-static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t geom, const uint64_t *d_sgbits,
+static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t geom, const uint64_t *d_sgbits,
                                 const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
                                 const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                 uint64_t *d_claim, uint64_t *d_stats, const uint8_t *d_mark, ulonglong2 *d_tuples, uint64_t cap,
@@ -595,7 +598,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 	if (!ctx) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
-	g.n_parts = geom & 0xFFFFu; g.n_lines = geom >> 16;
+	cix_unpack(geom, g);
 	g.pbits = cix_pbits(n_contigs);
 	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
 	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
@@ -629,7 +632,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t 
 	return MCOM_OK;
 }
 
-extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t n_parts, const uint64_t *d_sgbits,
+extern "C" int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t n_parts, const uint64_t *d_sgbits,
                                        const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg, const uint64_t *d_cbits,
                                        const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                        uint64_t *d_claim, uint64_t *d_stats)
@@ -702,7 +705,7 @@ extern "C" int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint
 	return MCOM_OK;
 }
 
-extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint32_t n_parts, const uint64_t *d_sgbits,
+extern "C" int mcom_realign_pass_tuples(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t n_parts, const uint64_t *d_sgbits,
                                         const uint8_t *d_sgflag, const uint8_t *d_mark, size_t n_sg, const uint64_t *d_cbits,
                                         const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr,
                                         uint64_t *d_claim, uint64_t *d_stats, uint64_t *d_tuples, uint64_t cap, uint64_t *h_ntuples)

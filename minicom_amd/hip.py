@@ -88,13 +88,13 @@ def load_library():
     L.mcom_realign_pass.restype = i32
     L.mcom_realign_pass.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, u64, i32, i32, vp, vp]
     L.mcom_cindex_plan.restype = i32
-    L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]
+    L.mcom_cindex_plan.argtypes = [u64, u32, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mcom_cindex_build.restype = i32
-    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u32, vp, u64]
+    L.mcom_cindex_build.argtypes = [vp, vp, vp, vp, u32, u64, i32, i32, u64, vp, u64]
     L.mcom_dicts_eligible.restype = i32
     L.mcom_dicts_eligible.argtypes = [vp, vp, vp, i32, vp]
     L.mcom_realign_pass_reads.restype = i32
-    L.mcom_realign_pass_reads.argtypes = [vp, vp, u32, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
+    L.mcom_realign_pass_reads.argtypes = [vp, vp, u64, vp, vp, vp, sz, vp, vp, vp, u32, i32, i32, i32, vp, vp]
     L.mcom_dicts_screen.restype = i32
     L.mcom_dicts_screen.argtypes = [vp, vp, sz, i32, i32, i32, C.POINTER(i32)]
     L.mcom_claims_resolve.restype = i32
@@ -363,7 +363,7 @@ class Context:
     def cindex_build(self, cbits, coff, woff, n_windows: int, L: int, ininumdict: int = 0):
         """mcom_cindex_plan + mcom_cindex_build.  Returns (index words int64, n_parts)."""
         torch = _torch()
-        ne, parts, nw = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        ne, parts, nw = C.c_uint64(), C.c_uint64(), C.c_uint64()
         n_contigs = int(coff.shape[0])
         self._check(self.lib.mcom_cindex_plan(int(n_windows), n_contigs, L, ininumdict, C.byref(ne), C.byref(parts), C.byref(nw)))
         words = int(nw.value)

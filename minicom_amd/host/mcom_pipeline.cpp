@@ -242,7 +242,7 @@ struct mcomh_pipeline {
 	bool cbits_for_dC = false;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
-	DevBuf<uint64_t> d_cix_keys; uint32_t cix_parts = 0;   // klen-mer index of the Stage-2 contigs (mcom_cindex_build)
+	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
@@ -1236,7 +1236,7 @@ static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgb
 	uint64_t cap = (1ull << 20) + 64ull * M.size(), nt = 0;
 	for (;;) {
 		if (!d_tup.reserve(2 * cap)) return p->fail(MCOM_E_NOMEM, "tuples");
-		if ((rc = p->gpu(mcom_realign_pass_tuples(p->ctx, p->d_cix_keys.p, p->cix_parts, d_sgbits, d_flag, d_mark.p, n_sg, p->d_cbits.p, p->d_coff_words.p,
+		if ((rc = p->gpu(mcom_realign_pass_tuples(p->ctx, p->d_cix_keys.p, p->cix_geom, d_sgbits, d_flag, d_mark.p, n_sg, p->d_cbits.p, p->d_coff_words.p,
 		                                          p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim, d_st, d_tup.p, cap, &nt)))) return rc;
 		if (nt <= cap) break;
 		cap = nt + (nt >> 3);
@@ -1367,9 +1367,11 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		if ((rc = p->gpu(mcom_window_layout(p->ctx, p->dC.soff.p, nc, p->L, p->d_woff.p, &nwin, &mlen)))) return rc;
 		p->n_windows = nwin; p->maxlen = std::max(p->maxlen, mlen);
 		if (!p->window_scan) {
-			// Multi-GPU: the index is sharded by contig range (equal shares of the windows), every rank probes ALL singletons
-			// against its part and the claim keys are MIN-reduced (dist_min_claims): the index -- the largest object of
-			// Stage 2 and its most expensive kernel -- is built once across the ranks, not once per rank.
+			// Multi-GPU: ONE index over all contigs, shared out BY KEY (include/mcom.h, mcom_cindex_plan_shared): a rank makes the entries of
+			// its range of the replicated contig set (equal shares of the windows), the entries travel to the owner of their key, and
+			// every rank places what it received into its share of the table.  A pass then looks every singleton up on every rank, but
+			// only the keys of the rank's share: 1 / R of the lookups and verifications each, claim keys MIN-reduced (dist_min_claims).
+			const int R = p->comm ? p->world : 1, me = p->comm ? p->rank : 0;
 			uint32_t c0 = 0, c1 = (uint32_t)nc; uint64_t nwin_mine = p->n_windows;
 			if (p->comm && nc) {
 				std::vector<uint64_t> hw(nc + 1);
@@ -1380,17 +1382,46 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				nwin_mine = hw[c1] - hw[c0];
 			}
 			p->cix_c0 = c0; p->cix_c1 = c1;
-			uint64_t ne = 0, nwords = 0;
-			if (mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &ne, &p->cix_parts, &nwords)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			uint64_t ne = 0, share = 0, nwords = 0, cap_mine = 0;
+			if (mcom_cindex_plan_shared(p->n_windows, (uint32_t)nc, p->L, p->numdict, R, me, &ne, &share, &p->cix_geom, &nwords) ||
+			    mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &cap_mine, nullptr, nullptr)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			DevBuf<uint32_t> keyA, keyB; DevBuf<uint64_t> slotA, slotB;
+			std::vector<uint64_t> cnt((size_t)R, 0);
 			for (int attempt = 0;; ++attempt) {                                 // a repeat-rich set may need a larger extension area for its heavy keys
-				if (!p->d_cix_keys.reserve(nwords)) return p->fail(MCOM_E_NOMEM, "contig index");
-				rc = mcom_cindex_build_range(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict, p->cix_parts, p->d_cix_keys.p, nwords);
-				if (rc != MCOM_E_OVERFLOW || attempt == 3) break;
-				nwords += std::max<uint64_t>(nwords / 4, 8 * (ne / 7 + 1024) / (attempt < 2 ? 4 : 1));
+				if (!p->d_cix_keys.reserve(nwords) || !keyA.reserve(cap_mine + 1) || !slotA.reserve(cap_mine + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
+				if ((rc = p->gpu(mcom_cindex_entries(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict, p->cix_geom,
+				                                     keyA.p, slotA.p, cap_mine + 1, cnt.data())))) return rc;
+				uint64_t n_ent = cnt[0];
+				if (R > 1) {
+					// the exchange: entries to the owner of their key (4 + 8 bytes each, two all-to-alls)
+					const double tx = now_ms();
+					std::vector<uint64_t> all, so(R), sb(R), ro(R), rb(R);
+					if ((rc = gather_host(p, cnt.data(), R, all))) return rc;
+					uint64_t a = 0, b = 0;
+					for (int q = 0; q < R; ++q) { so[q] = a; sb[q] = cnt[q]; a += cnt[q]; ro[q] = b; rb[q] = all[(size_t)q * R + me]; b += rb[q]; }
+					if (!keyB.reserve(std::max<uint64_t>(b, a) + 1) || !slotB.reserve(std::max<uint64_t>(b, a) + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
+					auto scaled = [&](const std::vector<uint64_t> &v, uint64_t m) { std::vector<uint64_t> o(v); for (auto &x : o) x *= m; return o; };
+					if ((rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, keyA.p, scaled(so, 4).data(), scaled(sb, 4).data(), keyB.p, scaled(ro, 4).data(), scaled(rb, 4).data(), 1, p->stream))) ||
+					    (rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, slotA.p, scaled(so, 8).data(), scaled(sb, 8).data(), slotB.p, scaled(ro, 8).data(), scaled(rb, 8).data(), 1, p->stream)))) return rc;
+					p->stat["t_x_cindex"] += now_ms() - tx; p->stat["x_cindex_entries"] += (double)(a - cnt[me]);
+					if (!keyA.reserve(b + 1) || !slotA.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
+					n_ent = b;
+					rc = mcom_cindex_place(p->ctx, keyB.p, slotB.p, n_ent, 0, keyA.p, slotA.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);
+				} else {
+					if (!keyB.reserve(n_ent + 1) || !slotB.reserve(n_ent + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
+					rc = mcom_cindex_place(p->ctx, keyA.p, slotA.p, n_ent, 1, keyB.p, slotB.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);
+				}
+				// (every rank must come to the same decision: a share that needs more room makes all of them build again)
+				uint64_t again = rc == MCOM_E_OVERFLOW ? 1 : 0;
+				if (R > 1 && (rc == MCOM_OK || rc == MCOM_E_OVERFLOW)) { int rc2 = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &again, 1, 2)); if (rc2) return rc2; }
+				if (rc != MCOM_OK && rc != MCOM_E_OVERFLOW) return p->gpu(rc);
+				p->stat["cix_entries"] += (double)n_ent;
+				if (!again) break;
+				if (attempt == 3) return p->fail(MCOM_E_OVERFLOW, "contig index: the extension area stays too small");
+				nwords += std::max<uint64_t>(nwords / 4, 8 * (share / 7 + 1024) / (attempt < 2 ? 4 : 1));
 				p->stat["cix_rebuilds"] += 1;
 			}
-			if (rc) return p->gpu(rc);
-			p->stat["cix_entries"] += (double)ne; p->stat["cix_slots"] += (double)nwords;
+			p->stat["cix_slots"] += (double)nwords;
 		}
 		p->stage2_uploaded = true;
 	}
@@ -1447,7 +1478,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			rc = MCOM_OK;
 			if (!d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
 			if (!rc && !big)
-				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_parts, d_sgbits.p, d_flag.p, nullptr,
+				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_geom, d_sgbits.p, d_flag.p, nullptr,
 				                                    n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
 			else if (!rc)
 				rc = realign_big_bins(p, dicts, d_sgbits.p, d_flag.p, n_sg, nc, thr, d_claim.p, d_st.p);
