@@ -163,6 +163,22 @@ int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
  * (count 0 = absent), which mcom_idx_records copies out.                                              */
 typedef struct mcom_idx mcom_idx;
 int  mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out);
+/* The same index in steps, for a caller that builds it by bucket range on several GPUs and all-gathers the parts (buckets are
+ * independent: kthread_idx.c:116-168 is a loop over them):
+ *   mcom_idx_create      an empty index for n records in all
+ *   mcom_idx_sort_part   the records of some buckets (in pushing order) sorted into their place rec[base_rec ..): bucket by bucket,
+ *                        each in radix_sort_128x's element order; *h_max_bucket = the fullest of them
+ *   mcom_idx_table_part  the table regions of buckets [bucket0, bucket1) -- those of the part -- sized for the fullest bucket of
+ *                        the WHOLE index (every builder passes the same max_bucket_all); MCOM_E_OVERFLOW: a bucket too large for a
+ *                        region (LDS) -- put all sorted records together and call mcom_idx_table_global instead
+ *   mcom_idx_buffers     where the parts of other builders are received: sorted records [n], table slots (16 bytes each, *region
+ *                        per bucket, bucket v at slot v * region)
+ * mcom_idx_build = create + sort_part(everything) + table_part(all buckets).                                              */
+int  mcom_idx_create(mcom_ctx *ctx, size_t n, int k, int b, mcom_idx **out);
+int  mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 *d_rec, size_t n, size_t base_rec, uint32_t *h_max_bucket);
+int  mcom_idx_table_part(mcom_ctx *ctx, mcom_idx *mi, uint32_t max_bucket_all, uint32_t bucket0, uint32_t bucket1);
+int  mcom_idx_table_global(mcom_ctx *ctx, mcom_idx *mi);
+int  mcom_idx_buffers(mcom_idx *mi, mcom_mm128 **d_rec, uint64_t **d_slots, uint32_t *region);
 /* radix_sort_128x with the reference's exact element order (sequential emulation, see mcom_radix_sort_128x
  * for the fast stable sort).                                                                          */
 int  mcom_radix_sort_128x_ref_order(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n);
@@ -463,6 +479,9 @@ int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32_t *h_max);
 /* records sketched for contigs [first_contig, ...) of a set as if they were contigs 0, 1, ...: ids += first_contig;
  * their n_off record offsets += first_record                                                                        */
 int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_rec, uint32_t first_contig, uint32_t *d_roff, size_t n_off, uint32_t first_record);
+
+/* d_off[i] += delta for n 64-bit offsets: a rank's share of a round's merged contigs moves to its place in the set            */
+int mcom_offsets_rebase(mcom_ctx *ctx, uint64_t *d_off, size_t n, uint64_t delta);
 
 /* Digest of a device array: h_sum_xor[0] = wrapping sum of its little-endian 64-bit words, each weighted by an odd
  * function of its index, h_sum_xor[1] = their xor (a tail of fewer than 8 bytes is zero-extended).  d_data 8-byte

@@ -594,6 +594,10 @@ struct mcom_idx {
 	size_t n;
 	mcom_mm128 *rec;     // sorted records
 	McomTable tab;
+	// a part being built (mcom_idx_sort_part .. mcom_idx_table_part): its place in rec, the starts of its buckets relative to it
+	int k = 0, b = 0;
+	size_t part_n = 0, part_base = 0;
+	uint32_t *part_bst = nullptr;
 };
 
 extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
@@ -601,6 +605,7 @@ extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 	if (!mi) return;
 	if (ctx) (void)mcom_stream_sync(ctx);
 	if (mi->rec) mcom_dfree(mi->rec);
+	if (mi->part_bst) mcom_dfree(mi->part_bst);
 	mcom_table_free(&mi->tab);
 	delete mi;
 }
@@ -610,64 +615,121 @@ int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bit
 int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_out, const uint32_t *d_bstart, uint32_t nr, int low_bits,
                            uint32_t max_range, uint32_t *d_overflow);
 
-extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out)
+// ---- the index in steps: a caller with several GPUs builds it by bucket range and all-gathers the parts (include/mcom.h) ----
+extern "C" int mcom_idx_create(mcom_ctx *ctx, size_t n, int k, int b, mcom_idx **out)
 {
 	if (!ctx || !out) return MCOM_E_ARG;
 	*out = nullptr;
 	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range", k);
 	if (b < 0 || b > 20 || b > 2 * k) return mcom_fail(ctx, MCOM_E_ARG, "bucket bits %d out of range", b);
 	if (n >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many records");
-	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	mcom_idx *mi = new mcom_idx();
-	mi->n = n; mi->rec = nullptr; mi->tab.slots = nullptr;
+	mi->n = n; mi->rec = nullptr; mi->tab.slots = nullptr; mi->tab.region = 0; mi->tab.bbits = 0; mi->tab.log2cap = 0; mi->tab.numkeys = 0; mi->tab.maxrun = 0;
+	mi->k = k; mi->b = b;
 	hipError_t e = mcom_dmalloc(&mi->rec, (n ? n : 1) * sizeof(mcom_mm128));
 	if (e != hipSuccess) { mi->rec = nullptr; mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_NOMEM, "index records: %s", hipGetErrorString(e)); }
-	const size_t sort_b = mcom_sort_ws_bytes(n);
-	const size_t head_b = ((n * 4) + 255) & ~(size_t)255;
-	const size_t scr_b = ((mcom_scan_scratch_elems(n) * 4 + 1024) + 255) & ~(size_t)255;
-	const size_t bst_b = ((((size_t)1 << b) + 2) * 4 + 255) & ~(size_t)255;
-	int rc = mcom_ws_reserve(ctx, sort_b + head_b + scr_b + 256 + bst_b);
-	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
-	char *base = (char*)ctx->ws;
-	bool have_bst = false; uint32_t max_bucket = 0;
-	if (n) {
-		hipError_t e1 = hipMemcpyAsync(mi->rec, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream);
-		if (e1 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e1)); }
-		if (b == 0) {
-			rc = mcom_sort_by_x(ctx, mi->rec, n, 2 * k, base);                 // stable: equal minimizers keep their input order
-			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
-		} else {
-			// the reference's order: records go to bucket x & (2^b-1) in input order (kthread_bucket.c:468-473), every bucket
-			// is then sorted by radix_sort_128x (kthread_idx.c:126), whose order of equal keys is reproduced exactly
-			uint32_t *bst = (uint32_t*)(base + sort_b + head_b + scr_b + 256);
-			const uint32_t nb = 1u << b;
-			rc = mcom_sort_by_low_bits(ctx, mi->rec, n, b, base);
-			if (!rc) rc = mcom_bucket_starts(ctx, mi->rec, n, b, bst);
-			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
-			std::vector<uint32_t> hb(nb + 1);
-			hipError_t e2 = mcom_d2h_async(ctx, hb.data(), bst, (nb + 1) * 4);
-			if (e2 == hipSuccess) e2 = mcom_stream_sync(ctx);
-			if (e2 != hipSuccess) { mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_HIP, "bucket bounds: %s", hipGetErrorString(e2)); }
-			uint32_t mx = 0;
-			for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
-			have_bst = true; max_bucket = mx;
-			uint32_t *ovf = (uint32_t*)(base + sort_b + head_b + scr_b);           // the 256-byte meta area, reused below
-			(void)hipMemsetAsync(ovf, 0, 4, ctx->stream);
-			if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
-				mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
-				rc = mcom_flag_sort_buckets(ctx, mi->rec, tmp, bst, nb, b, mx, ovf);
-				if (!rc) { e2 = hipMemcpyAsync(mi->rec, tmp, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "copy: %s", hipGetErrorString(e2)); }
-			} else rc = mcom_flag_sort_ranges(ctx, mi->rec, bst, nb, mx, ovf);
-			uint32_t ov = 0;
-			if (!rc) { e2 = mcom_d2h_async(ctx, &ov, ovf, 4); if (e2 == hipSuccess) e2 = mcom_stream_sync(ctx); if (e2 != hipSuccess) rc = mcom_fail(ctx, MCOM_E_HIP, "index sort: %s", hipGetErrorString(e2)); }
-			if (!rc && ov) rc = mcom_fail(ctx, MCOM_E_OVERFLOW, "index bucket sort ran out of range stack");
-			if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
-		}
+	if (b > 0) {
+		e = mcom_dmalloc(&mi->part_bst, (((size_t)1 << b) + 2) * 4);
+		if (e != hipSuccess) { mi->part_bst = nullptr; mcom_idx_destroy(ctx, mi); return mcom_fail(ctx, MCOM_E_NOMEM, "index bucket starts: %s", hipGetErrorString(e)); }
 	}
-	if (n && b > 0 && have_bst)                                               // records sorted by bucket first: the table is built bucket by bucket in LDS
-		rc = mcom_table_build_bucketed(ctx, mi->rec, n, (const uint32_t*)(base + sort_b + head_b + scr_b + 256), b, max_bucket,
-		                               (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
-	else rc = mcom_table_build(ctx, mi->rec, n, (uint32_t*)(base + sort_b), (uint32_t*)(base + sort_b + head_b), (uint32_t*)(base + sort_b + head_b + scr_b), &mi->tab);
+	*out = mi;
+	return MCOM_OK;
+}
+
+// the records of some buckets (all of them: the whole index), in the order the reference pushes them, sorted into rec[base ...):
+// bucket by bucket, every bucket in radix_sort_128x's exact element order (kthread_idx.c:126)
+extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 *d_rec, size_t n, size_t base_rec, uint32_t *h_max_bucket)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	if (h_max_bucket) *h_max_bucket = 0;
+	if (base_rec + n > mi->n) return mcom_fail(ctx, MCOM_E_ARG, "index part beyond the index");
+	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	mi->part_n = n; mi->part_base = base_rec;
+	const int b = mi->b, k = mi->k;
+	const size_t sort_b = mcom_sort_ws_bytes(n);
+	int rc = mcom_ws_reserve(ctx, sort_b + 256);
+	if (rc) return rc;
+	char *base = (char*)ctx->ws;
+	mcom_mm128 *part = mi->rec + base_rec;
+	if (n) MCOM_HIP(ctx, hipMemcpyAsync(part, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	if (b == 0) return n ? mcom_sort_by_x(ctx, part, n, 2 * k, base) : MCOM_OK;             // stable: equal minimizers keep their input order
+	const uint32_t nb = 1u << b;
+	if (!n) { MCOM_HIP(ctx, hipMemsetAsync(mi->part_bst, 0, ((size_t)nb + 1) * 4, ctx->stream)); return MCOM_OK; }
+	// records go to bucket x & (2^b-1) in input order (kthread_bucket.c:468-473), every bucket is then sorted by radix_sort_128x
+	rc = mcom_sort_by_low_bits(ctx, part, n, b, base);
+	if (!rc) rc = mcom_bucket_starts(ctx, part, n, b, mi->part_bst);
+	if (rc) return rc;
+	std::vector<uint32_t> hb(nb + 1);
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hb.data(), mi->part_bst, (nb + 1) * 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	uint32_t mx = 0;
+	for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
+	if (h_max_bucket) *h_max_bucket = mx;
+	uint32_t *ovf = (uint32_t*)(base + sort_b);
+	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
+	if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
+		mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
+		rc = mcom_flag_sort_buckets(ctx, part, tmp, mi->part_bst, nb, b, mx, ovf);
+		if (!rc) MCOM_HIP(ctx, hipMemcpyAsync(part, tmp, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+	} else rc = mcom_flag_sort_ranges(ctx, part, mi->part_bst, nb, mx, ovf);
+	if (rc) return rc;
+	uint32_t ov = 0;
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &ov, ovf, 4));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	if (ov) return mcom_fail(ctx, MCOM_E_OVERFLOW, "index bucket sort ran out of range stack");
+	return MCOM_OK;
+}
+
+int mcom_table_alloc_bucketed(mcom_ctx *ctx, int bbits, uint32_t max_bucket, McomTable *t);
+int mcom_table_fill_buckets(mcom_ctx *ctx, const mcom_mm128 *sorted, const uint32_t *bstart, uint32_t bucket0, uint32_t bucket1, uint32_t start_base, McomTable *t);
+
+// The table over the sorted part: the regions of buckets [bucket0, bucket1) (those the part holds), sized for the fullest bucket of
+// the WHOLE index (max_bucket_all; every builder passes the same).  MCOM_E_OVERFLOW: a bucket too large for a region in LDS -- the
+// caller puts all sorted records together and calls mcom_idx_table_global.
+extern "C" int mcom_idx_table_part(mcom_ctx *ctx, mcom_idx *mi, uint32_t max_bucket_all, uint32_t bucket0, uint32_t bucket1)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	if (mi->b < 1) return mcom_fail(ctx, MCOM_E_ARG, "an index without buckets has one global table");
+	if (bucket0 > bucket1 || bucket1 > (1u << mi->b)) return mcom_fail(ctx, MCOM_E_ARG, "bad bucket range");
+	if (!mi->tab.slots) { int rc = mcom_table_alloc_bucketed(ctx, mi->b, max_bucket_all, &mi->tab); if (rc) return rc; }
+	return mcom_table_fill_buckets(ctx, mi->rec + mi->part_base, mi->part_bst, bucket0, bucket1, (uint32_t)mi->part_base, &mi->tab);
+}
+extern "C" int mcom_idx_table_global(mcom_ctx *ctx, mcom_idx *mi)
+{
+	if (!ctx || !mi) return MCOM_E_ARG;
+	mcom_table_free(&mi->tab);
+	const size_t n = mi->n;
+	const size_t head_b = ((n * 4) + 255) & ~(size_t)255, scr_b = ((mcom_scan_scratch_elems(n) * 4 + 1024) + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, head_b + scr_b + 256);
+	if (rc) return rc;
+	char *base = (char*)ctx->ws;
+	return mcom_table_build(ctx, mi->rec, n, (uint32_t*)base, (uint32_t*)(base + head_b), (uint32_t*)(base + head_b + scr_b), &mi->tab);
+}
+// what the parts of other builders are received into: the sorted records [n], the table (slots of 16 bytes, *region per bucket;
+// *region = 0: one global table, nothing to exchange)
+extern "C" int mcom_idx_buffers(mcom_idx *mi, mcom_mm128 **d_rec, uint64_t **d_slots, uint32_t *region)
+{
+	if (!mi) return MCOM_E_ARG;
+	if (d_rec) *d_rec = mi->rec;
+	if (d_slots) *d_slots = mi->tab.slots;
+	if (region) *region = mi->tab.region;
+	return MCOM_OK;
+}
+
+extern "C" int mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int b, mcom_idx **out)
+{
+	if (!ctx || !out) return MCOM_E_ARG;
+	*out = nullptr;
+	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	mcom_idx *mi = nullptr;
+	int rc = mcom_idx_create(ctx, n, k, b, &mi);
+	if (rc) return rc;
+	uint32_t mx = 0;
+	rc = mcom_idx_sort_part(ctx, mi, d_rec, n, 0, &mx);
+	if (!rc) {
+		if (n && b > 0) { rc = mcom_idx_table_part(ctx, mi, mx, 0, 1u << b); if (rc == MCOM_E_OVERFLOW) rc = mcom_idx_table_global(ctx, mi); }
+		else rc = mcom_idx_table_global(ctx, mi);
+	}
 	if (rc) { mcom_idx_destroy(ctx, mi); return rc; }
 	*out = mi;
 	return MCOM_OK;

@@ -62,6 +62,20 @@ __global__ void k_add_u32(uint32_t *__restrict__ v, size_t n, uint32_t delta)
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) v[i] += delta;
 }
+__global__ void k_add_u64(unsigned long long *__restrict__ v, size_t n, unsigned long long delta)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] += delta;
+}
+extern "C" int mcom_offsets_rebase(mcom_ctx *ctx, uint64_t *d_off, size_t n, uint64_t delta)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!n || !delta) return MCOM_OK;
+	if (!d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	hipLaunchKernelGGL(k_add_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_off, n, (unsigned long long)delta);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
 extern "C" int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_rec, uint32_t first_contig, uint32_t *d_roff, size_t n_off, uint32_t first_record)
 {
 	if (!ctx) return MCOM_E_ARG;

@@ -170,10 +170,6 @@ struct McomTable {
 // sorted: n records sorted by x (runs of equal x are the bins); head/scr: scratch of n and
 // mcom_scan_scratch_elems(n)+256 uint32; meta: 2 uint32 on the device.  Synchronous.
 int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t);
-// bucketed: sorted by (x & (2^bbits - 1), x); bstart[2^bbits + 1] = first record of every bucket (device); max_bucket = its largest
-// bucket.  Falls back to mcom_table_build when a bucket is too large for an LDS region.
-int mcom_table_build_bucketed(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, const uint32_t *bstart, int bbits, uint32_t max_bucket,
-                              uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t);
 void mcom_table_free(McomTable *t);
 
 __device__ __forceinline__ uint32_t mcom_slot_of(uint64_t key, uint32_t log2cap)

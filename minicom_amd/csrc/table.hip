@@ -40,10 +40,11 @@ __global__ void k_table_insert(const mcom_mm128 *__restrict__ s, const uint32_t 
 
 // ---- bucketed build: one workgroup per bucket, the bucket's region of the table assembled in LDS and written in one piece ----
 __global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restrict__ s, const uint32_t *__restrict__ bstart, int bbits, uint32_t R,
-                                                      uint64_t *__restrict__ slots, uint32_t *__restrict__ meta /* [0] keys, [1] longest run */)
+                                                      uint64_t *__restrict__ slots, uint32_t *__restrict__ meta /* [0] keys, [1] longest run */,
+                                                      uint32_t bucket0, uint32_t start_base)
 {
 	extern __shared__ unsigned long long reg[];                               // [R][2]: key, start | count << 32
-	const uint32_t v = blockIdx.x;
+	const uint32_t v = bucket0 + blockIdx.x;
 	const uint32_t b0 = bstart[v], b1 = bstart[v + 1];
 	for (uint32_t q = threadIdx.x; q < 2 * R; q += 256) reg[q] = ~0ull;
 	__syncthreads();
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restri
 		while (e < b1 && s[e].x == key) ++e;
 		uint32_t sl = mcom_region_slot(key >> bbits, R);
 		while (atomicCAS(&reg[2 * sl], ~0ull, (unsigned long long)key) != ~0ull) sl = sl + 1 == R ? 0 : sl + 1;
-		reg[2 * sl + 1] = (unsigned long long)i | ((unsigned long long)(e - i) << 32);
+		reg[2 * sl + 1] = (unsigned long long)(start_base + i) | ((unsigned long long)(e - i) << 32);
 		++heads; longest = e - i > longest ? e - i : longest;
 	}
 	for (int o = 32; o; o >>= 1) { heads += __shfl_xor(heads, o); const uint32_t t = __shfl_xor(longest, o); longest = t > longest ? t : longest; }
@@ -65,27 +66,35 @@ __global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restri
 	for (uint32_t q = threadIdx.x; q < R; q += 256) dst[q] = make_ulonglong2(reg[2 * q], reg[2 * q + 1]);
 }
 
-int mcom_table_build_bucketed(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, const uint32_t *bstart, int bbits, uint32_t max_bucket,
-                              uint32_t *head, uint32_t *scr, uint32_t *meta, McomTable *t)
+// a region holds the fullest bucket at most 0.73 full if every record of it were a key of its own (about half of them are):
+// as many slots as that asks for, a multiple of four -- not the next power of two, which wrote and cleared up to twice the table.
+// MCOM_E_OVERFLOW: a bucket too large for a region in LDS (8192 slots = 128 KB) -- the global table (mcom_table_build) serves then.
+int mcom_table_alloc_bucketed(mcom_ctx *ctx, int bbits, uint32_t max_bucket, McomTable *t)
 {
-	// a region holds the fullest bucket at most 0.73 full if every record of it were a key of its own (about half of them are):
-	// as many slots as that asks for, a multiple of four -- not the next power of two, which wrote and cleared up to twice the table
 	const uint32_t R = (max_bucket + (max_bucket >> 2) + (max_bucket >> 3) + 16 + 3) & ~3u;
-	if (n == 0 || bbits < 1 || R > 8192 || ((size_t)16 * R << bbits) > ((size_t)64 << 30))   // 8192 slots = 128 KB of LDS; a larger bucket: the global table
-		return mcom_table_build(ctx, sorted, n, head, scr, meta, t);
+	if (bbits < 1 || R > 8192 || ((size_t)16 * R << bbits) > ((size_t)64 << 30)) return MCOM_E_OVERFLOW;
 	t->slots = nullptr; t->numkeys = 0; t->maxrun = 0; t->region = R; t->bbits = (uint32_t)bbits; t->log2cap = 0;
 	const size_t bytes = (size_t)16 * R << bbits;
 	hipError_t e = mcom_dmalloc(&t->slots, bytes);
 	if (e != hipSuccess) { t->slots = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "hash table of %zu bytes: %s", bytes, hipGetErrorString(e)); }
+	return MCOM_OK;
+}
+// the regions of buckets [bucket0, bucket1) from a sorted record array whose record 0 is record start_base of the index
+int mcom_table_fill_buckets(mcom_ctx *ctx, const mcom_mm128 *sorted, const uint32_t *bstart, uint32_t bucket0, uint32_t bucket1, uint32_t start_base, McomTable *t)
+{
+	if (bucket0 >= bucket1) return MCOM_OK;
+	int rc = mcom_ws_reserve(ctx, 256);
+	if (rc) return rc;
+	uint32_t *meta = (uint32_t*)ctx->ws;
 	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 8, ctx->stream));
-	const size_t lds = (size_t)16 * R;
+	const size_t lds = (size_t)16 * t->region;
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_table_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_table_bucket, dim3(1u << bbits), dim3(256), lds, ctx->stream, sorted, bstart, bbits, R, t->slots, meta);
+	hipLaunchKernelGGL(k_table_bucket, dim3(bucket1 - bucket0), dim3(256), lds, ctx->stream, sorted, bstart, (int)t->bbits, t->region, t->slots, meta, bucket0, start_base);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t hm[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
-	t->numkeys = hm[0]; t->maxrun = hm[1];
+	t->numkeys += hm[0]; t->maxrun = hm[1] > t->maxrun ? hm[1] : t->maxrun;
 	return MCOM_OK;
 }
 

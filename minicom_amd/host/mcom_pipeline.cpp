@@ -891,6 +891,48 @@ static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_fir
 	return MCOM_OK;
 }
 
+// Multi-GPU form of mm_idx_generation (kthread_idx.c:116-170 is a loop over independent buckets): a rank sorts the records of its
+// bucket range (ascending ranges in rank order, as in the bucket stage) and builds their table regions; sorted records and regions
+// are all-gathered into the replicated index, which every rank then queries for its share of the contigs.
+static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm, mcom_idx **out)
+{
+	const int R = p->world, me = p->rank;
+	*out = nullptr;
+	int rc;
+	DevBuf<mcom_mm128> part;
+	if (!part.reserve(tm + 1)) return p->fail(MCOM_E_NOMEM, "index records");
+	std::vector<uint64_t> cnt(R, 0), first(R, 0);
+	if ((rc = p->gpu(mcom_partition_by_owner(p->ctx, rec_m, tm, NB_BITS, R, part.p, cnt.data())))) return rc;
+	uint64_t tot = 0;
+	for (int q = 0; q < R; ++q) { first[q] = tot; tot += cnt[q]; }
+	if (tot != tm) return p->fail(MCOM_E_ARG, "index records without a minimizer");
+	mcom_idx *mi = nullptr;
+	if ((rc = p->gpu(mcom_idx_create(p->ctx, tm, p->k, NB_BITS, &mi)))) return rc;
+	uint32_t mx = 0;
+	rc = p->gpu(mcom_idx_sort_part(p->ctx, mi, part.p + first[me], cnt[me], first[me], &mx));
+	uint64_t mxa = mx;
+	if (!rc) rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mxa, 1, 2));
+	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
+	auto bucket0 = [&](int q) { return (uint32_t)((((uint64_t)q << NB_BITS) + R - 1) / R); };   // first bucket with (beta * R) >> b == q
+	rc = mcom_idx_table_part(p->ctx, mi, (uint32_t)mxa, bucket0(me), bucket0(me + 1));
+	if (rc && rc != MCOM_E_OVERFLOW) { p->gpu(rc); mcom_idx_destroy(p->ctx, mi); return rc; }
+	const bool global_table = rc == MCOM_E_OVERFLOW;                                  // the same on every rank: mxa is
+	mcom_mm128 *d_rec = nullptr; uint64_t *d_slots = nullptr; uint32_t region = 0;
+	mcom_idx_buffers(mi, &d_rec, &d_slots, &region);
+	const double tx = now_ms();
+	rc = gatherv(p, d_rec, first, cnt);
+	if (!rc && !global_table) {
+		std::vector<uint64_t> fs(R), cs(R);
+		for (int q = 0; q < R; ++q) { fs[q] = 2ull * bucket0(q) * region; cs[q] = 2ull * (bucket0(q + 1) - bucket0(q)) * region; }
+		rc = gatherv(p, d_slots, fs, cs);
+	}
+	p->stat["t_x_index"] += now_ms() - tx;
+	if (!rc && global_table) { rc = p->gpu(mcom_idx_table_global(p->ctx, mi)); p->stat["idx_global_tables"] += 1; }
+	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
+	*out = mi;
+	return MCOM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // combine_cluster: merge rounds                                                kthread_cb.c:570-630
 // The contig set (consensus strings, members, minimizers) lives on the device for the whole stage; per round only the
@@ -904,7 +946,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	long pre = 0;
 	int rc;
 	ContigSet &C = p->C;
-	DevSet A, B;
+	DevSet A, B, Tm;                                                         // Tm: a rank's share of a round's merged contigs (multi-GPU)
 	DevBuf<uint32_t> moff_m, d_jobs, d_keepidx; DevBuf<mcom_mm128> rec_m, d_pairs, d_pairs_loc; DevBuf<uint8_t> d_flag;
 	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
 	struct Job { uint32_t ci, cj, pos_ori, pos; };
@@ -953,7 +995,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, A.roff.p, A.rec.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
 			lap("t_cb_pack");
 			mcom_idx *mi = nullptr;
-			if ((rc = p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;           // mm_idx_generation (:580)
+			if ((rc = p->comm ? build_index_dist(p, rec_m.p, tm, &mi) : p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;   // mm_idx_generation (:580)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
 			if (!p->comm) {
@@ -1040,12 +1082,71 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			int kb = 2; while ((1ull << kb) < 4 * maxlen + 4) ++kb;
 			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);
 			uint64_t tot[3] = {0, 0, 0}, t2[2] = {0, 0};
+			uint64_t tn = 0;                                                             // minimizer records of the merged contigs
+			bool merged_sketched = false;
+			if (!p->comm) {
 			if ((rc = p->gpu(mcom_merge_members(p->ctx, A.mem.p, A.moff.p, d_jobs.p, nj, L, kb, B.mem.p, B.moff.p, B.soff.p, tot)))) return rc;
 			maxlen = std::max(maxlen, tot[2]);
 			lap("t_merge_members");
 			// construct_ref2 of every merged contig (:327)
 			if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, B.mem.p, B.moff.p, B.soff.p, nj, tot[1], L, B.seq.p, p->full_consensus ? nullptr : d_jobs.p, A.seq.p, A.soff.p)))) return rc;
 			lap("t_merge_cons");
+			} else {
+				// Multi-GPU: the merges of a round are independent (find_next :297-381 works on one claimed pair): a rank merges its share of
+				// the claimed pairs -- member lists, construct_ref2, the sketch around the overlap -- and the merged contigs are all-gathered
+				// into the head of the new set, in claiming order.
+				const int R = p->world, me = p->rank;
+				const size_t j0 = nj * (size_t)me / R, j1 = nj * (size_t)(me + 1) / R, njl = j1 - j0;
+				DevSet &T = Tm;
+				uint64_t tl[3] = {0, 0, 0}, tnl = 0, sk = 0;
+				const bool rs = p->resketch && (p->k & 1);
+				if (njl) {
+					if (!T.mem.reserve(A.members + 1) || !T.moff.reserve(njl + 2) || !T.soff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_merge_members(p->ctx, A.mem.p, A.moff.p, d_jobs.p + 4 * j0, njl, L, kb, T.mem.p, T.moff.p, T.soff.p, tl)))) return rc;
+					if (!T.seq.reserve(tl[1] + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, T.mem.p, T.moff.p, T.soff.p, njl, tl[1], L, T.seq.p, p->full_consensus ? nullptr : d_jobs.p + 4 * j0, A.seq.p, A.soff.p)))) return rc;
+					if (rs) {
+						if (!T.roff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+						size_t cap = std::max<size_t>(1024, tl[1] / 8 + njl);
+						for (int attempt = 0;; ++attempt) {
+							if (!T.rec.reserve(cap)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+							rc = mcom_resketch_merged(p->ctx, d_jobs.p + 4 * j0, njl, A.soff.p, A.rec.p, A.roff.p, T.seq.p, T.soff.p, tl[1], p->rw, p->k, T.roff.p, T.rec.p, cap, &tnl, &sk);
+							if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tnl; continue; }
+							if (rc) return p->gpu(rc);
+							break;
+						}
+						p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tnl; p->stat["resketch_saved_bases"] += (double)(tl[1] - sk);
+					}
+				}
+				lap("t_merge_local");
+				const uint64_t mine[4] = {tl[0], tl[1], tl[2], tnl};
+				std::vector<uint64_t> all, fj(R), cj(R), fm(R), cm(R), fc(R), cc(R), fr(R), cr(R);
+				if ((rc = gather_host(p, mine, 4, all))) return rc;
+				for (int q = 0; q < R; ++q) {
+					fj[q] = nj * (size_t)q / R; cj[q] = nj * (size_t)(q + 1) / R - fj[q];
+					fm[q] = tot[0]; cm[q] = all[4 * q]; tot[0] += cm[q]; fc[q] = tot[1]; cc[q] = all[4 * q + 1]; tot[1] += cc[q];
+					tot[2] = std::max(tot[2], all[4 * q + 2]); fr[q] = tn; cr[q] = all[4 * q + 3]; tn += cr[q];
+				}
+				maxlen = std::max(maxlen, tot[2]);
+				if (tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records");
+				// offsets and ids of the share move to their global values, then everything travels
+				if (njl && ((rc = p->gpu(mcom_offsets_rebase(p->ctx, T.moff.p, njl, fm[me]))) || (rc = p->gpu(mcom_offsets_rebase(p->ctx, T.soff.p, njl, fc[me]))))) return rc;
+				if (rs && njl && (rc = p->gpu(mcom_records_rebase(p->ctx, T.rec.p, tnl, (uint32_t)j0, T.roff.p, njl, (uint32_t)fr[me])))) return rc;
+				if (!B.seq.reserve(std::max<uint64_t>(A.chars, tot[1]) + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+				const double tx = now_ms();
+				if ((rc = gatherv(p, B.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, B.moff.p, fj, cj, T.moff.p)) || (rc = gatherv(p, B.seq.p, fc, cc, T.seq.p)) || (rc = gatherv(p, B.soff.p, fj, cj, T.soff.p))) return rc;
+				if ((rc = p->h2d(B.moff.p + nj, &tot[0], 1, "upload")) || (rc = p->h2d(B.soff.p + nj, &tot[1], 1, "upload"))) return rc;
+				if (rs) {
+					if (!B.roff.reserve(nn + 2) || !B.rec.reserve(tn + (size_t)A.nrec + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+					if ((rc = gatherv(p, B.rec.p, fr, cr, T.rec.p)) || (rc = gatherv(p, B.roff.p, fj, cj, T.roff.p))) return rc;
+					const uint32_t t32 = (uint32_t)tn;
+					if ((rc = p->h2d(B.roff.p + nj, &t32, 1, "upload"))) return rc;
+					merged_sketched = true;
+				}
+				if ((rc = p->sync("merged contigs"))) return rc;                             // (tot / t32 live on this stack frame)
+				p->stat["t_x_merged"] += now_ms() - tx;
+				lap("t_merge_gather");
+			}
 			// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
 			if ((rc = p->gpu(mcom_contigs_carry(p->ctx, A.seq.p, A.soff.p, A.mem.p, A.moff.p, n, d_flag.p, nj, nkeep, B.seq.p, B.soff.p, B.mem.p, B.moff.p,
 			                                    d_keepidx.p, t2)))) return rc;
@@ -1053,8 +1154,8 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if (B.members != A.members) return p->fail(MCOM_E_ARG, "merge round lost members: %llu of %llu", (unsigned long long)B.members, (unsigned long long)A.members);
 			lap("t_cb_copy");
 			// minimizers: merged contigs are sketched, the untouched ones keep theirs under their new index
-			uint64_t tn = 0;
-			if (p->resketch && (p->k & 1)) {
+			if (merged_sketched) { B.n = nn; }
+			else if (p->resketch && (p->k & 1)) {
 				// only around the overlaps; the parents' records carry the rest (csrc/resketch.hip)
 				B.n = nn;
 				if (!B.roff.reserve(nn + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
