@@ -324,6 +324,9 @@ int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int 
 /* the same in two steps: _begin puts the counting on the context's stream and returns, _end waits and answers (so that a caller
  * can run the screen on a second context / stream beside other work)                                                     */
 int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch);
+/* multi-GPU: the keys shared out as the contig index is (mcom_cindex_plan_shared): this call counts the keys of share `share` of
+ * n_shares only -- a bin is counted whole by one rank -- and the caller ORs the answers of all ranks                          */
+int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int n_shares, int share);
 int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed);
 int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t geom,
                             const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_elig, size_t n_sg,

@@ -69,6 +69,8 @@ int mcomh_combine_cluster(mcomh_pipeline *p);
 int mcomh_update_single(mcomh_pipeline *p);
 /* updateSingle + realign_hash at threshold thr; *cluster_reads = reads held by contigs afterwards */
 int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_reads);
+/* the Stage-2 loop alone (preprocess.c:197-232): passes at thr = e, e + S, ... until one adds too few reads        */
+int mcomh_stage2(mcomh_pipeline *p);
 /* the whole timed region of the reference: Stage 1 + Stage 2 with its loop control (preprocess.c:141-233) */
 int mcomh_pre_process(mcomh_pipeline *p);
 /* runs everything and writes the state after every stage in the text format of oracle/refdump.cpp */
@@ -146,6 +148,8 @@ int  mcomh_comm_allgatherv(mcomh_comm *c, const void *send, void *buf, const uin
 int  mcomh_comm_allreduce_u64(mcomh_comm *c, uint64_t *vals, size_t n, int op);
 /* bytes this rank has sent to OTHER ranks so far, and the number of all-to-alls                                     */
 void mcomh_comm_stats(const mcomh_comm *c, uint64_t *bytes_sent, uint64_t *calls);
+/* wall seconds this rank has spent inside all-to-all calls so far (staging copies and waiting for the peers included) */
+double mcomh_comm_seconds(const mcomh_comm *c);
 
 /* The distributed pipeline: this rank holds reads [rid0, rid0 + n_local) of n_total (shards are contiguous, in rank
  * order, and cover [0, n_total); paired end: the second file's reads follow the first file's, as in mcomh_create).

@@ -513,9 +513,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int nc = 0;
 	if (live) {
 		const uint64_t *rb = sgbits + sg * (size_t)W;
-#pragma unroll
-		for (int w = 0; w < W; ++w) row[w] = rb[w];
-		uint64_t key = bits_key(row, g.ds[l], g.klen);
+		uint64_t key = bits_key(rb, g.ds[l], g.klen);                                      // (the row itself is loaded once the key turns out to be this share's)
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
 		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
 		uint32_t own, part, h16;
@@ -529,6 +527,10 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		// replicated there, and the claim keys of all shares are MIN-reduced)
 		const bool mine = own == g.owner;
 		n_look += mine;
+		if (mine) {
+#pragma unroll
+			for (int w = 0; w < W; ++w) row[w] = rb[w];
+		}
 		// the home line, then the lines behind it while entries were pushed on; when the home line says its keys are heavy (a repeat
 		// with more copies than a few lines hold) their entries are in a run of lines in the extension area, read afterwards
 		unsigned long long heavy = 0;
@@ -826,13 +828,15 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 // The read-driven pass needs the dictionaries only to cut bins at maxsearch (:388), which almost never happens.  One
 // counter per hashed (dictionary, key) in a table of about one counter per key: a counter is an UPPER bound of its bin
 // (collisions only add), so "no counter above maxsearch" proves that no bin is.
+// (n_shares > 1: the keys are shared out as the index is, a rank counts the keys of its share only -- every bin is counted whole by one rank)
 __global__ void k_bin_screen(const uint64_t *__restrict__ sgbits, size_t n_sg, int W, int nd, CixGeom g, uint32_t log2t, uint32_t maxsearch,
-                             unsigned int *__restrict__ table, unsigned int *__restrict__ exceeded)
+                             unsigned int *__restrict__ table, unsigned int *__restrict__ exceeded, uint32_t n_shares, uint32_t share)
 {
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const size_t sg = t / (size_t)nd; const int l = (int)(t - sg * (size_t)nd);
 	if (sg >= n_sg) return;
 	const uint64_t key = bits_key(sgbits + sg * (size_t)W, g.ds[l], g.klen);
+	if (n_shares > 1) { uint32_t own, part, h16; cix_hash(key, n_shares, 1u, own, part, h16); if (own != share) return; }
 	const uint64_t h = (key * 8 + (uint64_t)l + 1) * 0x9E3779B97F4A7C15ull;
 	atomicAdd(&table[h >> (64 - log2t)], 1u);                                // nothing comes back: the counters are looked at afterwards (k_bin_screen_max)
 }
@@ -845,17 +849,19 @@ __global__ void k_bin_screen_max(const unsigned int *__restrict__ table, size_t 
 // begin: the counting kernels are put on the context's stream and the call returns; end: waits for them and reads the answer.
 // (mcom_dicts_screen is the two in one.  The pipeline runs the screen on a second stream beside the contig index build: the
 // two use different parts of the memory system -- atomics against streaming writes.)
-extern "C" int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch)
+extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int n_shares, int share)
 {
 	if (!ctx) return MCOM_E_ARG;
+	if (n_shares < 1 || share < 0 || share >= n_shares) return mcom_fail(ctx, MCOM_E_ARG, "bad share");
 	ctx->screen_flag = nullptr;
 	if (n_sg == 0) return MCOM_OK;
 	CixGeom g;
 	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
 	const uint64_t nkeys = (uint64_t)n_sg * (uint64_t)g.nd;
+	const uint64_t nmine = nkeys / (uint64_t)n_shares + 1;
 	// a counter per ~8 keys: collisions only add (the count stays an upper bound of every bin in it) and ~8 is far below any limit worth
 	// asking about, while the table (64 MB at 16 M singletons instead of 512) stays in the Infinity Cache, where the atomics are served
-	uint32_t lg = 10; while (lg < 30 && (8ull << lg) < nkeys) ++lg;
+	uint32_t lg = 10; while (lg < 30 && (8ull << lg) < nmine) ++lg;
 	int rc = mcom_ws_reserve(ctx, ((size_t)4 << lg) + 256);
 	if (rc) return rc;
 	unsigned int *table = (unsigned int*)ctx->ws;
@@ -864,11 +870,15 @@ extern "C" int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, 
 	const uint64_t blocks = (nkeys + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
-	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag);
+	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag, (uint32_t)n_shares, (uint32_t)share);
 	hipLaunchKernelGGL(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
 	MCOM_LAUNCH_CHECK(ctx);
 	ctx->screen_flag = flag;
 	return MCOM_OK;
+}
+extern "C" int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch)
+{
+	return mcom_dicts_screen_begin_shared(ctx, d_sgbits, n_sg, L, ininumdict, maxsearch, 1, 0);
 }
 extern "C" int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed)
 {

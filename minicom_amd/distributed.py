@@ -48,6 +48,7 @@ def _lib():
         L.mcomh_comm_allgatherv.restype = i32; L.mcomh_comm_allgatherv.argtypes = [vp, vp, vp, _u64p, _u64p, i32, vp]
         L.mcomh_comm_allreduce_u64.restype = i32; L.mcomh_comm_allreduce_u64.argtypes = [vp, _u64p, sz, i32]
         L.mcomh_comm_stats.restype = None; L.mcomh_comm_stats.argtypes = [vp, _u64p, _u64p]
+        L.mcomh_comm_seconds.restype = C.c_double; L.mcomh_comm_seconds.argtypes = [vp]
         L.mcomh_create_dist.restype = i32
         L.mcomh_create_dist.argtypes = [C.POINTER(vp), i32, vp, vp, vp, vp, sz, sz, C.c_uint64, C.c_uint64, i32, C.POINTER(Params)]
         _bound = True
@@ -57,6 +58,56 @@ def _lib():
 def _u64(a):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     return a, a.ctypes.data_as(_u64p)
+
+
+class _ThreadHub:
+    """The meeting point of Comm.threads: every rank publishes where its parts lie, all wait, every rank copies what is meant
+    for it, all wait again (the parts are the senders' own buffers)."""
+
+    def __init__(self, world: int, serialize: bool):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.lock = threading.Lock() if serialize else None
+        self.parts = [None] * world
+        self.bytes = np.zeros((world, world), dtype=np.uint64)            # [sender, receiver]
+
+    def enter(self):
+        """a rank starts computing (serialize: waits for its turn)"""
+        if self.lock:
+            self.lock.acquire()
+
+    def leave(self):
+        if self.lock:
+            self.lock.release()
+
+    def abort(self):
+        self.barrier.abort()
+
+    def make_callback(self, rank: int):
+        world = self.world
+
+        def alltoallv(_user, send, so, sb, recv, ro, rb):
+            try:
+                self.leave()
+                try:
+                    self.parts[rank] = [(send + int(so[q]) if sb[q] else 0, int(sb[q])) for q in range(world)]
+                    self.barrier.wait()
+                    for q in range(world):
+                        addr, nbytes = self.parts[q][rank]
+                        if nbytes != int(rb[q]):
+                            raise RuntimeError(f"rank {q} sends {nbytes} bytes to rank {rank}, which expects {int(rb[q])}")
+                        if nbytes:
+                            C.memmove(recv + int(ro[q]), addr, nbytes)
+                            self.bytes[q, rank] += nbytes
+                    self.barrier.wait()
+                finally:
+                    self.enter()
+                return 0
+            except Exception:                                                    # never let an exception cross the C boundary
+                traceback.print_exc()
+                return 1
+        return alltoallv
 
 
 class Comm:
@@ -110,6 +161,27 @@ class Comm:
         if _lib().mcomh_comm_create_ops(C.byref(h), rank, world, C.byref(ops), None):
             raise McomError("mcomh_comm_create_ops failed")
         return cls(h, rank, world, keep=(cb, ops))
+
+    @classmethod
+    def threads(cls, world: int, serialize: bool = False):
+        """`world` communicators for `world` threads of THIS process (one pipeline per thread): the all-to-all goes through
+        process memory.  For measurements and tests that want more ranks on one GPU than processes are allowed there.
+        serialize: a lock lets one rank compute at a time (it is given up while a rank waits in an exchange), so that kernel
+        and stage times of a rank are not disturbed by the others sharing the card.  Returns (comms, hub)."""
+        hub = _ThreadHub(world, serialize)
+        comms = []
+        for rank in range(world):
+            cb = _ALLTOALLV(hub.make_callback(rank))
+            ops = _Ops(cb)
+            h = C.c_void_p()
+            if _lib().mcomh_comm_create_ops(C.byref(h), rank, world, C.byref(ops), None):
+                raise McomError("mcomh_comm_create_ops failed")
+            comms.append(cls(h, rank, world, keep=(cb, ops, hub)))
+        return comms, hub
+
+    def seconds(self) -> float:
+        """wall seconds spent inside all-to-all calls so far"""
+        return float(_lib().mcomh_comm_seconds(self._h))
 
     def _check(self, rc):
         if rc:

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -65,6 +66,7 @@ struct mcomh_comm {
 	mcomh_comm_ops ops{}; void *user = nullptr;
 	std::string err;
 	uint64_t bytes_sent = 0, calls = 0;
+	double seconds = 0;                        // wall time inside all-to-all calls (staging copies and waiting for the peers included)
 	// staging: pinned host blocks (callbacks transport with device data), device blocks (RCCL with host data)
 	void *h_send = nullptr, *h_recv = nullptr; size_t h_send_cap = 0, h_recv_cap = 0;
 	void *d_send = nullptr, *d_recv = nullptr; size_t d_send_cap = 0, d_recv_cap = 0;
@@ -179,10 +181,24 @@ static int rccl_alltoallv(mcomh_comm *c, const char *send, const uint64_t *so, c
 	return MCOM_OK;
 }
 
+static int alltoallv_impl(mcomh_comm *c, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb,
+                          int on_device, void *hip_stream);
 extern "C" int mcomh_comm_alltoallv(mcomh_comm *c, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb,
                                     int on_device, void *hip_stream)
 {
 	if (!c || !so || !sb || !ro || !rb) return MCOM_E_ARG;
+	// the kernels that made the data are waited for BEFORE the clock starts: seconds = the exchange, not the work in front of it
+	if (on_device && hipStreamSynchronize((hipStream_t)hip_stream) != hipSuccess) return c->fail(MCOM_E_HIP, "all-to-all: the stream failed");
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = alltoallv_impl(c, send, so, sb, recv, ro, rb, on_device, hip_stream);
+	c->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return rc;
+}
+extern "C" double mcomh_comm_seconds(const mcomh_comm *c) { return c ? c->seconds : 0.0; }
+
+static int alltoallv_impl(mcomh_comm *c, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb,
+                          int on_device, void *hip_stream)
+{
 	const int R = c->world;
 	hipStream_t st = (hipStream_t)hip_stream;
 	uint64_t ts = 0, tr = 0;

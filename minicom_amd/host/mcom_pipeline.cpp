@@ -273,6 +273,9 @@ struct mcomh_pipeline {
 };
 
 using P = mcomh_pipeline;
+// the clock of the stage timers: wall time NOT spent inside exchanges (multi-GPU; mcomh_comm_seconds covers staging copies and the
+// wait for the peers), so that a stage's timers say what this rank itself was busy with.  One GPU: the wall clock.
+static double busy_now(const P *p) { return now_ms() - (p->comm ? 1e3 * mcomh_comm_seconds(p->comm) : 0.0); }
 static int materialize(P *p);
 static void ensure_sg_flag(P *p)
 {
@@ -457,7 +460,7 @@ extern "C" const char *mcomh_last_error(const mcomh_pipeline *p) { return p ? p-
 extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
-	const double t0 = now_ms();
+	const double t0 = busy_now(p);
 	const size_t n = p->n;                                              // all reads of the job
 	const bool dist = p->comm != nullptr;
 	const size_t nl = dist ? p->n_local : n;                            // ... and those this rank classifies and sketches
@@ -557,7 +560,7 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 			}
 		}
 	});
-	p->stat["t_reads"] += now_ms() - t0;
+	p->stat["t_reads"] += busy_now(p) - t0;
 	return MCOM_OK;
 }
 
@@ -567,7 +570,7 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
-	const double t0 = now_ms();
+	const double t0 = busy_now(p);
 	const int L = p->L;
 	const int RS = (2 * L + 15) & ~15;                       // stride of one group's consensus on the device
 	// Multi-GPU: the records of a round go to the owner of their bucket (bucket ranges in rank order); a rank then does what
@@ -629,7 +632,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			p->stat["t_x_records"] += now_ms() - tx;
 		}
 		size_t ns = 0, ng = 0, nm = 0, nrej = 0;
-		const double tg = now_ms();
+		const double tg = busy_now(p);
 		if (r == 1) p->stat["t_bk_pre"] += tg - t0;
 		const int set = r & 1;
 		DevBuf<uint32_t> &d_singles = d_singles_ab[set], &d_sord = d_sord_ab[set];
@@ -640,7 +643,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			uint64_t cnts[4];
 			if ((rc = p->gpu(mcom_sort_group(p->ctx, cur, n_cur, L, p->k, kmer_in, NB_BITS, d_sorted.p, d_singles.p, d_sord.p, d_members.p, d_goff.p, cnts)))) return rc;
 			ns = cnts[1]; ng = cnts[2]; nm = cnts[3];
-			p->stat["t_bk_sort"] += now_ms() - tg;
+			p->stat["t_bk_sort"] += busy_now(p) - tg;
 			if (!d_keep.reserve(nm + 1) || !d_nkept.reserve(ng + 1) || !d_sv.reserve(ng + 1) || !d_reflen.reserve(ng + 1) || !d_refs.reserve(ng * (size_t)RS + 16))
 				return p->fail(MCOM_E_NOMEM, "consensus buffers");
 			// construct_ref of every group on the device (:446)
@@ -707,8 +710,8 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				set_busy[set] = true;
 			}
 			if ((rc = p->d2h(Rd.rej.data(), d_rej.p, nrej, "copy")) || (rc = p->d2h(Rd.rejg.data(), d_rejg.p, nrej, "copy")) || (rc = p->sync("round copy"))) return rc;
-			p->stat["t_gpu"] += now_ms() - tg;
-			p->stat["t_bk_gpu"] += now_ms() - tg;
+			p->stat["t_gpu"] += busy_now(p) - tg;
+			p->stat["t_bk_gpu"] += busy_now(p) - tg;
 			// the next round only needs the rejects; where singles and rejects go in the singleton list is settled later
 			if (!last) resk.assign(Rd.rej.data(), Rd.rej.data() + nrej);
 			sg_rounds.push_back(std::move(Rd));
@@ -755,13 +758,13 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			p->sg_round_len[ri++] = p->sg.size() - before;
 		}
 		// a page-locked copy, so that the list goes up to the device beside the Stage-2 set-up instead of in front of the first pass
-		if (p->sg_gathered && p->sg_pin.resize(p->sg.size()) && !p->sg.empty()) memcpy(p->sg_pin.data(), p->sg.data(), p->sg.size() * 4);
+		if (p->sg_pin.resize(p->sg.size()) && !p->sg.empty()) memcpy(p->sg_pin.data(), p->sg.data(), p->sg.size() * 4);
 	}, std::move(sg_rounds));
 	if (n_sg_total <= 5000000) p->maxsearch = 2000;                                 // preprocess.c:169-172
 	if (p->maxsearch_forced > 0) p->maxsearch = p->maxsearch_forced;
 	p->stat["n_sg0"] = (double)n_sg_total;
 	p->stat["contigs_bucket"] = (double)p->dC.n;
-	p->stat["t_bucket"] += now_ms() - t0;
+	p->stat["t_bucket"] += busy_now(p) - t0;
 	return MCOM_OK;
 }
 
@@ -781,17 +784,25 @@ static int dist_gather_sg(P *p)
 	std::vector<uint64_t> first(R), tot(R, 0);
 	uint64_t total = 0;
 	for (int q = 0; q < R; ++q) { for (size_t r = 0; r < nr; ++r) tot[q] += all[(size_t)q * nr + r]; first[q] = total; total += tot[q]; }
-	if (tot[me] != p->sg.size()) return p->fail(MCOM_E_ARG, "singleton list: %zu entries, the rounds say %llu", p->sg.size(), (unsigned long long)tot[me]);
-	DevBuf<uint32_t> d;
-	if (!d.reserve(total + 1)) return p->fail(MCOM_E_NOMEM, "singleton list");
-	if ((rc = p->h2d(d.p + first[me], p->sg.data(), p->sg.size(), "upload singletons")) || (rc = p->sync("upload singletons")) || (rc = gatherv(p, d.p, first, tot))) return rc;
-	std::vector<uint32_t> flat(total), out;
-	if ((rc = p->d2h(flat.data(), d.p, total, "copy singletons")) || (rc = p->sync("copy singletons"))) return rc;
-	out.reserve(total);
+	if (tot[me] != p->sg.size() || p->sg_pin.size() != p->sg.size()) return p->fail(MCOM_E_ARG, "singleton list: %zu entries, the rounds say %llu", p->sg.size(), (unsigned long long)tot[me]);
+	// The parts meet on the device (this rank's goes up from its page-locked copy), are put into visiting order there -- one
+	// device-to-device copy per (round, rank) -- and the list comes back once, into page-locked memory: Stage 2 finds it in HBM
+	// already, the host keeps its copy for the accessors.
+	DevBuf<uint32_t> d_flat;
+	if (!d_flat.reserve(total + 1) || !p->d_sg_live.reserve(total + 1)) return p->fail(MCOM_E_NOMEM, "singleton list");
+	if ((rc = p->h2d(d_flat.p + first[me], p->sg_pin.data(), p->sg.size(), "upload singletons")) || (rc = gatherv(p, d_flat.p, first, tot))) return rc;
 	std::vector<uint64_t> cursor(first);
+	uint64_t at = 0;
 	for (size_t r = 0; r < nr; ++r)
-		for (int q = 0; q < R; ++q) { const uint64_t len = all[(size_t)q * nr + r]; out.insert(out.end(), flat.begin() + cursor[q], flat.begin() + cursor[q] + len); cursor[q] += len; }
-	p->sg.swap(out);
+		for (int q = 0; q < R; ++q) {
+			const uint64_t len = all[(size_t)q * nr + r];
+			if (len && (rc = p->hipc(hipMemcpyAsync(p->d_sg_live.p + at, d_flat.p + cursor[q], len * 4, hipMemcpyDeviceToDevice, p->stream), "order singletons"))) return rc;
+			cursor[q] += len; at += len;
+		}
+	if (!p->sg_pin.resize(total)) return p->fail(MCOM_E_NOMEM, "singleton list");
+	if ((rc = p->d2h(p->sg_pin.data(), p->d_sg_live.p, total, "copy singletons")) || (rc = p->sync("copy singletons"))) return rc;
+	p->sg.assign(p->sg_pin.data(), p->sg_pin.data() + total);
+	p->n_sg_live = total; p->sg_live_valid = total != 0;
 	p->sg_gathered = true;
 	return MCOM_OK;
 }
@@ -941,7 +952,7 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm, mcom_idx
 extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
-	const double t0 = now_ms();
+	const double t0 = busy_now(p);
 	const int L = p->L;
 	long pre = 0;
 	int rc;
@@ -951,8 +962,8 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
 	struct Job { uint32_t ci, cj, pos_ori, pos; };
 	PinVec<Job> jobs;
-	double tl = now_ms();
-	auto lap = [&](const char *nm) { const double t = now_ms(); p->stat[nm] += t - tl; tl = t; };
+	double tl = busy_now(p);
+	auto lap = [&](const char *nm) { const double t = busy_now(p); p->stat[nm] += t - tl; tl = t; };
 	// the set of the bucket stage is on the device already (kt_for_bucket); a set that only exists on the host is uploaded
 	uint64_t maxlen = 2 * (uint64_t)L;                                        // a group's consensus spans at most 2L columns
 	if (p->dC_valid) { A.swap(p->dC); p->dC_valid = false; }
@@ -967,11 +978,11 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		}
 	}
 	if (A.n) {
-		const double tg = now_ms();
+		const double tg = busy_now(p);
 		lap("t_cb_upload");
 		if ((rc = p->comm ? sketch_first_dist(p, A, A.n, A.chars, 0, A.nrec) : sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;   // find_next's own sketch (:234)
 		lap("t_cb_sketch");
-		p->stat["t_gpu"] += now_ms() - tg;
+		p->stat["t_gpu"] += busy_now(p) - tg;
 	}
 	bool packed_ready = false;                                                 // d_cbits & co. describe A (made at the end of the round before)
 	p->cbits_for_dC = false;
@@ -979,7 +990,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		const size_t n = A.n;
 		uint64_t n_pass = 0;
 		if (n) {
-			const double tg = now_ms();
+			const double tg = busy_now(p);
 			uint64_t tw = 0, tm = 0;
 			if (!packed_ready) {
 				if (!p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
@@ -1035,7 +1046,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 			if (rc) return p->gpu(rc);
 			lap("t_cb_findnext");
 			n_pass = hc[1];
-			p->stat["t_gpu"] += now_ms() - tg;
+			p->stat["t_gpu"] += busy_now(p) - tg;
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
 		// first-come claiming in contig order (find_next :267-343 at one thread) = the greedy matching over the pair list,
@@ -1074,7 +1085,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 		}
 		lap("t_claim");
 		if (nj) {
-			const double tg = now_ms();
+			const double tg = busy_now(p);
 			const size_t nkeep = n - 2 * nj, nn = nj + nkeep;
 			if (!d_keepidx.reserve(nkeep + 1) || !B.mem.reserve(A.members + 1) || !B.moff.reserve(nn + 1) ||
 			    !B.seq.reserve(A.chars + 16) || !B.soff.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
@@ -1186,7 +1197,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				lap("t_cb_pack");
 			}
 			A.swap(B);
-			p->stat["t_gpu"] += now_ms() - tg;
+			p->stat["t_gpu"] += busy_now(p) - tg;
 		} else packed_ready = packed_ready && n != 0;
 		p->stat["merge_rounds"] += 1;
 		const long tot = (long)A.n;
@@ -1201,13 +1212,16 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");
 	p->join_sg();
-	if (p->comm) {
-		if ((rc = dist_gather_sg(p))) return rc;
-		if (p->sg_pin.resize(p->sg.size()) && !p->sg.empty()) memcpy(p->sg_pin.data(), p->sg.data(), p->sg.size() * 4);
-	}
+	lap("t_cb_join");
+	const bool on_device = p->comm && !p->sg_gathered;                          // (multi-GPU: the ranks' parts meet on the device, the list is there already)
+	if (p->comm && (rc = dist_gather_sg(p))) return rc;
+	lap("t_cb_sg");
 	// the singleton list goes up on the copy stream while Stage 2 packs the contigs and builds its index
 	p->sg_uploaded = false;
-	if (!p->sg.empty() && p->sg_pin.size() == p->sg.size() && p->d_sg_live.reserve(p->sg.size())) {
+	if (on_device && p->sg_live_valid) {
+		if ((rc = p->hipc(hipEventRecord(p->ev_sg, p->stream), "event"))) return rc;
+		p->sg_uploaded = true;
+	} else if (!p->sg.empty() && p->sg_pin.size() == p->sg.size() && p->d_sg_live.reserve(p->sg.size())) {
 		if ((rc = p->hipc(hipMemcpyAsync(p->d_sg_live.p, p->sg_pin.data(), p->sg.size() * 4, hipMemcpyHostToDevice, p->copy_stream), "upload singletons")) ||
 		    (rc = p->hipc(hipEventRecord(p->ev_sg, p->copy_stream), "event"))) return rc;
 		p->n_sg_live = p->sg.size(); p->sg_live_valid = true; p->sg_uploaded = true;
@@ -1216,7 +1230,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->screen_clear = false;
-	p->stat["t_combine"] += now_ms() - t0;
+	p->stat["t_combine"] += busy_now(p) - t0;
 	return MCOM_OK;
 }
 
@@ -1290,7 +1304,7 @@ static int materialize(P *p)
 	const size_t m = p->pend.size();
 	if (!m) return MCOM_OK;
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set on the device");
-	const double t0 = now_ms();
+	const double t0 = busy_now(p);
 	DevSet &D = p->dC;
 	std::vector<const uint32_t*> ac(m); std::vector<const uint64_t*> am(m); std::vector<uint64_t> an(m);
 	for (size_t i = 0; i < m; ++i) { ac[i] = p->pend[i].contig.p; am[i] = p->pend[i].member.p; an[i] = p->pend[i].n; }
@@ -1303,7 +1317,7 @@ static int materialize(P *p)
 	D.members += p->n_pending;
 	p->pend.clear(); p->n_pending = 0;
 	p->hostC_valid = false; p->host_off_valid = false;
-	p->stat["t_ra_materialize"] += now_ms() - t0;
+	p->stat["t_ra_materialize"] += busy_now(p) - t0;
 	return MCOM_OK;
 }
 
@@ -1427,12 +1441,12 @@ static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgb
 extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_reads)
 {
 	if (!p) return MCOM_E_ARG;
-	const double t0 = now_ms();
+	const double t0 = busy_now(p);
 	p->join_sg();
 	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
 	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "Stage 2 needs the contig set of kt_for_bucket / combine_cluster on the device");
 	const bool sg_sent_up = p->sg_uploaded;                         // (mcomh_update_single clears the flag: it only vouches for the list of combine_cluster)
-	{ const double tu = now_ms(); mcomh_update_single(p); p->stat["t_ra_update"] += now_ms() - tu; }                // preprocess.c:203
+	{ const double tu = busy_now(p); mcomh_update_single(p); p->stat["t_ra_update"] += busy_now(p) - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
 	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && sg_sent_up && !p->early.on) {
@@ -1446,7 +1460,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			E.sg.swap(p->d_sg_live); p->sg_live_valid = false;
 			if (mcom_gather_rows(p->ctx2, p->d_packed.p, E.sg.p, n_sg, p->L, E.sgbits.p) == MCOM_OK &&
 			    hipEventRecord(p->ev_early, p->copy_stream) == hipSuccess &&
-			    mcom_dicts_screen_begin(p->ctx2, E.sgbits.p, n_sg, p->L, p->numdict, p->maxsearch) == MCOM_OK) { E.on = true; E.n_sg = n_sg; p->stat["early_screen"] += 1; }
+			    mcom_dicts_screen_begin_shared(p->ctx2, E.sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, p->comm ? p->world : 1, p->comm ? p->rank : 0) == MCOM_OK) { E.on = true; E.n_sg = n_sg; p->stat["early_screen"] += 1; }
 			else { (void)hipStreamSynchronize(p->copy_stream); p->d_sg_live.swap(E.sg); p->sg_live_valid = true; }   // as before
 		}
 	}
@@ -1526,13 +1540,13 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		}
 		p->stage2_uploaded = true;
 	}
-	p->stat["t_ra_setup"] += now_ms() - t0;
+	p->stat["t_ra_setup"] += busy_now(p) - t0;
 	p->stat["passes"] += 1;
 	p->stat["windows"] += (double)p->n_windows;
 	// every contig is re-sorted at the start of its scan (:318), but the scan itself never looks at the members: the sorts
 	// of all passes are folded into materialize()
 	if (n_sg) {
-		const double tg = now_ms();
+		const double tg = busy_now(p);
 		DevBuf<uint32_t> d_sg; DevBuf<uint64_t> d_sgbits, d_claim; DevBuf<uint8_t> d_flag;
 		if (!d_sg.reserve(n_sg) || !d_sgbits.reserve(n_sg * p->W) || !d_claim.reserve(n_sg) || !d_flag.reserve(n_sg)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
 		const bool early = p->early.on && p->early.n_sg == n_sg;
@@ -1562,7 +1576,13 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			p->early.on = false;
 			if ((rc = mcom_dicts_screen_end(p->ctx2, &may_exceed))) return p->fail(rc, "%s", mcom_last_error(p->ctx2));
 		} else if (p->screen_clear) may_exceed = 0;
-		else if (!p->window_scan && (rc = p->gpu(mcom_dicts_screen(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, &may_exceed)))) return rc;
+		else if (!p->window_scan && ((rc = p->gpu(mcom_dicts_screen_begin_shared(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, p->maxsearch, p->comm ? p->world : 1, p->comm ? p->rank : 0))) ||
+		                              (rc = p->gpu(mcom_dicts_screen_end(p->ctx, &may_exceed))))) return rc;
+		if (p->comm && !p->window_scan && !p->screen_clear) {                                  // a rank screened the keys of its share: any of them may say "look"
+			uint64_t any = (uint64_t)may_exceed;
+			if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &any, 1, 2)))) return rc;
+			may_exceed = any ? 1 : 0;
+		}
 		if (!may_exceed && !p->window_scan) p->screen_clear = true;
 		if (may_exceed) {
 			if ((rc = p->gpu(mcom_dicts_build(p->ctx, d_sgbits.p, n_sg, p->L, p->numdict, &dicts)))) return rc;
@@ -1611,9 +1631,9 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			p->n_sg_live = (size_t)n_next; p->sg_live_valid = true; p->sg_next_valid = true;
 		}
 		if ((rc = p->sync("realign pass"))) return rc;
-		p->stat["t_gpu"] += now_ms() - tg;
-		p->stat["t_ra_gpu"] += now_ms() - tg;
-		const double tw0 = now_ms();
+		p->stat["t_gpu"] += busy_now(p) - tg;
+		p->stat["t_ra_gpu"] += busy_now(p) - tg;
+		const double tw0 = busy_now(p);
 		{                                                                                    // bbhashdict.c:177-216, singleton order
 			// sg_flag is made from the raw flags when somebody looks (ensure_sg_flag); the near-poly-A / -T reads (flag 1 / 2) are rare
 			// and come as a list from the device, which only has to be put back into singleton order
@@ -1632,10 +1652,10 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		// a pass that appends nothing still counts: its scan sorts every contig first (:318), the appends of the pass before
 		// it included, and materialize() takes "the last pass" from the number of entries here
 		p->n_pending += nwon; p->pend.push_back(std::move(app));
-		p->stat["t_ra_append"] += now_ms() - tw0;
+		p->stat["t_ra_append"] += busy_now(p) - tw0;
 	} else p->pend.emplace_back();
 	if (cluster_reads) *cluster_reads = (long)(p->dC.members + p->n_pending);
-	p->stat["t_realign"] += now_ms() - t0;
+	p->stat["t_realign"] += busy_now(p) - t0;
 	return MCOM_OK;
 }
 
@@ -1643,6 +1663,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 // the reference's loop control around the stages                             preprocess.c:141-233
 // ----------------------------------------------------------------------------------------------------
 static int run_stage2(P *p, FILE *f);
+
+extern "C" int mcomh_stage2(mcomh_pipeline *p) { return p ? run_stage2(p, nullptr) : MCOM_E_ARG; }
 
 extern "C" int mcomh_pre_process(mcomh_pipeline *p)
 {

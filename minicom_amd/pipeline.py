@@ -74,7 +74,7 @@ def load_host_library():
 
 
 HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
-                    "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_pre_process",
+                    "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_stage2", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
                     "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order",
@@ -83,7 +83,7 @@ HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packe
                     # multi-GPU (bound in minicom_amd/distributed.py)
                     "mcomh_comm_unique_id", "mcomh_comm_create_rccl", "mcomh_comm_create_ops", "mcomh_comm_destroy", "mcomh_comm_rank",
                     "mcomh_comm_world", "mcomh_comm_last_error", "mcomh_comm_alltoallv", "mcomh_comm_allgatherv", "mcomh_comm_allreduce_u64",
-                    "mcomh_comm_stats", "mcomh_create_dist"]
+                    "mcomh_comm_stats", "mcomh_comm_seconds", "mcomh_create_dist"]
 
 
 def decompress(folder: str, out_path: str, order: bool = False) -> int:
@@ -225,6 +225,7 @@ class Pipeline:
     def combine_cluster(self): self._check(self.lib.mcomh_combine_cluster(self._h))
     def update_single(self): self._check(self.lib.mcomh_update_single(self._h))
     def pre_process(self): self._check(self.lib.mcomh_pre_process(self._h))
+    def stage2(self): self._check(self.lib.mcomh_stage2(self._h))
 
     def realign_hash(self, thr: int) -> int:
         cr = C.c_long()

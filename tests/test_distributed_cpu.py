@@ -74,6 +74,46 @@ def test_library_collectives_between_processes_over_gloo(world):
     mp.spawn(_worker, args=(world, _free_port()), nprocs=world, join=True)
 
 
+def _collective_checks(c, rank, world):
+    send = [_part(rank, q, world) for q in range(world)]
+    want = [_part(q, rank, world) for q in range(world)]
+    got = c.alltoallv(np.concatenate(send), [len(s) for s in send], [len(w) for w in want])
+    assert np.array_equal(got, np.concatenate(want))
+    got = c.allgatherv(_part(rank, rank, world), [len(_part(q, q, world)) for q in range(world)])
+    assert np.array_equal(got, np.concatenate([_part(q, q, world) for q in range(world)]))
+    v = np.array([rank + 1, 2 ** 40 + rank], dtype=np.uint64)
+    assert c.allreduce(v, "sum").tolist() == [world * (world + 1) // 2, world * 2 ** 40 + world * (world - 1) // 2]
+    assert c.allreduce(v, "max").tolist() == [world, 2 ** 40 + world - 1]
+
+
+@pytest.mark.parametrize("world,serialize", [(4, False), (8, True)])
+def test_library_collectives_between_threads_of_one_process(world, serialize):
+    """Comm.threads: the transport of tools/dist_work.py (more ranks on one card than processes are allowed there); with
+    serialize a rank computes only while it holds the hub's lock and gives it up inside an exchange."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from minicom_amd.distributed import Comm
+    comms, hub = Comm.threads(world, serialize=serialize)
+    errors = []
+
+    def run(rank):
+        hub.enter()
+        try:
+            _collective_checks(comms[rank], rank, world)
+        except Exception as e:                                                  # noqa: BLE001
+            errors.append((rank, repr(e))); hub.abort()
+        finally:
+            hub.leave()
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join(timeout=60) for t in ts]
+    assert not errors, errors
+    want = sum(len(_part(s, d, world)) for s in range(world) for d in range(world) if s != d)
+    assert int(hub.bytes.sum()) - int(np.trace(hub.bytes)) >= want
+    assert all(c.seconds() > 0 for c in comms)
+    for c in comms:
+        c.close()
+
+
 def test_communicator_rejects_bad_arguments():
     """No GPU, no peers: argument checks of the C entry points."""
     import ctypes as C
