@@ -14,13 +14,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_checked(n, L, seed):
+def _run_checked(n, L, seed, coverage=30, stats=None):
     import torch
     import minicom_amd
     from minicom_amd.check import check_result
     from minicom_amd.pipeline import Pipeline
     ctx = minicom_amd.Context(0)
-    reads = ctx.synth_reads(seed, n, L)
+    reads = ctx.synth_reads(seed, n, L, coverage=coverage)
     ctx.sync()
     t = time.time()
     p = Pipeline(reads, L=L, host_threads=8)
@@ -30,6 +30,8 @@ def _run_checked(n, L, seed):
     t = time.time()
     res = check_result(p, reads, L)
     print(f"[{n} x {L}] checked in {time.time() - t:.1f} s: {res}", flush=True)
+    if stats is not None:
+        stats.update({k: p.stat(k) for k in ("contigs_bucket", "contigs_combine", "cix_entries", "rounds", "merge_rounds", "passes")})
     p.close()
     p = Pipeline(reads, L=L, host_threads=8)
     p.pre_process()
@@ -49,6 +51,22 @@ def test_config1_100m_reads_of_150_bases():
     assert res["members"] > 0.8 * n and res["n_contigs"] > 1_000_000       # 30x coverage: most reads end up in contigs
     assert res["max_mismatch"] <= L // 2 and res["mean_mismatch"] < 0.02 * L
     assert res["members_checked"] == res["members"]
+
+
+def test_more_than_2_pow_24_contigs_on_one_card():
+    """The reference packs (contig index << 8) + thread into 32 bits (kthread_bucket.c:458): 2^24 contigs per list, which a 500 M-read
+    job (BASELINE configs[3], ~39 M first-round contigs) exceeds.  Here the id is the 32-bit index and the Stage-2 index entries take
+    the bits they need from the position field: 80 M x 100 bp at 5 x coverage leaves > 2^24 contigs after the bucket stage on one
+    card -- every read accounted for, every member on its contig, two runs bit-identical."""
+    n, L = 80_000_000, 100
+    st = {}
+    res, d1, d2 = _run_checked(n, L, 1005, coverage=5, stats=st)
+    print(f"contigs after the bucket stage {st['contigs_bucket']:.0f}, after merging {st['contigs_combine']:.0f}, index entries {st['cix_entries']:.0f}", flush=True)
+    assert st["contigs_bucket"] > 2 ** 24 and st["merge_rounds"] >= 3 and st["passes"] >= 2
+    assert d1 == d2
+    assert res["n_reads"] == n and res["members"] + res["n_sg"] + sum(res["n_" + k] for k in ("allA", "allT", "allN", "fpA", "fpT", "fpN", "Nfile")) == n
+    assert res["members"] > 0.5 * n and res["members_checked"] == res["members"]
+    assert res["max_mismatch"] <= L // 2
 
 
 def test_config2_67m_reads_of_100_bases():
