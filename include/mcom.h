@@ -67,6 +67,12 @@ int mcom_prof_enable(mcom_ctx *ctx, int on);
 int mcom_prof_reset(mcom_ctx *ctx);
 int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
 
+/* The library keeps freed device blocks of its own objects for reuse.  mcom_pool_trim gives the free ones back to the runtime;
+ * mcom_set_oom_hook names a function the library calls when it cannot get a block even so (a caller with a pool of its own frees
+ * it there), before it gives up with MCOM_E_NOMEM.                                                                          */
+void mcom_pool_trim(void);
+void mcom_set_oom_hook(void (*hook)(void));
+
 /* Diagnostics.  mcom_counter: "sort_overflow_segments" = segments of mcom_sort_group that did not fit its in-LDS sort and
  * went through the nine-pass sort instead (a minimizer shared by thousands of reads); "sketch_strings" = strings sketched by the
  * lane-per-string kernel of mcom_sketch_contigs so far (64 per wave).  mcom_set_segment_capacity lowers

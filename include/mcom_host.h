@@ -61,6 +61,9 @@ int  mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, con
  * assembles the records instead of sketching the rows again.  The arrays must stay valid until kt_for_reads returns. */
 int  mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow);
 void mcomh_destroy(mcomh_pipeline *p);
+/* Device blocks of destroyed pipelines are kept for the next one of the process (a steady-state step allocates nothing); this gives
+ * the free ones -- the driver's and the library's -- back to the runtime.  Both pools do so by themselves when memory runs out.    */
+void mcomh_pool_trim(void);
 const char *mcomh_last_error(const mcomh_pipeline *p);
 
 int mcomh_kt_for_reads(mcomh_pipeline *p);

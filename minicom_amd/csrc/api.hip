@@ -52,6 +52,18 @@ static std::mutex g_blk_mu;
 static std::multimap<std::pair<int, size_t>, void*> g_blk_free;       // (device, bytes) -> block
 static std::map<void*, std::pair<int, size_t>> g_blk_live;
 
+static void (*g_oom_hook)(void) = nullptr;
+// the free blocks of the pool go back to the runtime (a caller that keeps a pool of its own asks for this when IT runs out of memory)
+extern "C" void mcom_pool_trim(void)
+{
+	std::vector<void*> drop;
+	{ std::lock_guard<std::mutex> g(g_blk_mu); for (auto &kv : g_blk_free) drop.push_back(kv.second); g_blk_free.clear(); }
+	for (void *q : drop) (void)hipFree(q);
+	(void)hipGetLastError();
+}
+// ... and the other way round: called when a block cannot be had even after the pool's own free blocks are gone
+extern "C" void mcom_set_oom_hook(void (*hook)(void)) { g_oom_hook = hook; }
+
 hipError_t mcom_dmalloc(void **out, size_t bytes)
 {
 	int dev = 0; (void)hipGetDevice(&dev);
@@ -72,7 +84,8 @@ hipError_t mcom_dmalloc(void **out, size_t bytes)
 		for (void *q : drop) (void)hipFree(q);
 		(void)hipGetLastError();
 		e = hipMalloc(&p, cap);
-		if (e != hipSuccess) { *out = nullptr; return e; }
+		if (e != hipSuccess && g_oom_hook) { (void)hipGetLastError(); g_oom_hook(); e = hipMalloc(&p, cap); }
+		if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return e; }
 	}
 	std::lock_guard<std::mutex> g(g_blk_mu);
 	g_blk_live[p] = std::make_pair(dev, cap);
@@ -104,7 +117,8 @@ int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
 	}
 	size_t want = bytes + bytes / 8 + (1 << 20);
 	hipError_t e = hipMalloc(&ctx->ws, want);
-	if (e != hipSuccess) { ctx->ws = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "workspace of %zu bytes: %s", want, hipGetErrorString(e)); }
+	if (e != hipSuccess) { (void)hipGetLastError(); mcom_pool_trim(); if (g_oom_hook) g_oom_hook(); e = hipMalloc(&ctx->ws, want); }
+	if (e != hipSuccess) { (void)hipGetLastError(); ctx->ws = nullptr; return mcom_fail(ctx, MCOM_E_NOMEM, "workspace of %zu bytes: %s", want, hipGetErrorString(e)); }
 	ctx->ws_bytes = want;
 	return MCOM_OK;
 }

@@ -49,7 +49,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	if (n_contigs && !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n_contigs) MCOM_HIP(ctx, hipMemsetAsync(d_flag, 0, n_contigs, ctx->stream));
 	if (n_pairs == 0) return MCOM_OK;
-	if (!d_pairs || !d_jobs || n_pairs >= (1ull << 32) - 1 || n_contigs >= (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "bad claim arguments");
+	if (!d_pairs || !d_jobs || n_pairs >= (1ull << 32) - 1 || n_contigs >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "bad claim arguments");
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
 	const size_t best_b = al(n_contigs * 4), dead_b = al(n_pairs), sel_b = al((n_pairs + 1) * 4), scr_b = al(mcom_scan_scratch_elems(n_pairs + 1) * 4 + 1024);
 	int rc = mcom_ws_reserve(ctx, best_b + dead_b + 2 * sel_b + scr_b + 256);

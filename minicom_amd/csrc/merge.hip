@@ -554,7 +554,7 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	if (!ctx || !h_total) return MCOM_E_ARG;
 	*h_total = base;
 	if (!d_roff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	if ((uint64_t)first_id + nkeep >= (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: record ids overflow");
+	if ((uint64_t)first_id + nkeep >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32 - 2 contigs: record ids overflow");
 	if (nkeep == 0) { MCOM_HIP(ctx, hipMemcpyAsync(d_roff2 + first_id, &base, 4, hipMemcpyHostToDevice, ctx->stream)); MCOM_HIP(ctx, mcom_stream_sync(ctx)); return MCOM_OK; }
 	if (!d_rec || !d_roff || !d_keepidx || !d_rec2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_ws_reserve(ctx, al256((nkeep + 1) * 4) + al256(mcom_scan_scratch_elems(nkeep + 1) * 4 + 1024) + 256);

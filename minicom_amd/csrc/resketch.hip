@@ -130,7 +130,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	if (k < 1 || k > 31 || !(k & 1) || w < 1 || w > 128) return mcom_fail(ctx, MCOM_E_ARG, "w=%d (1..128) or k=%d (odd, 1..31) out of range", w, k);
 	if (!d_roff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (nj == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_roff2, 0, 4, ctx->stream)); return MCOM_OK; }
-	if (nj >= (1ull << 24)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^24 contigs: record ids overflow");
+	if (nj >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32 - 2 contigs: record ids overflow");
 	if (!d_jobs || !d_soff || !d_rec || !d_roff || !d_seq2 || !d_soff2 || !d_rec2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	DevBlock b_plan, b_s0, b_s1, b_cnt, b_moff, b_srec, b_cut;
 	RsPlan *plan = b_plan.get<RsPlan>(nj);

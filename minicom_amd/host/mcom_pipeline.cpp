@@ -105,17 +105,25 @@ public:
 		}
 		void *p = nullptr;
 		if (hipMalloc(&p, cap) != hipSuccess) {
-			// out of memory: give the pooled blocks of this device back and try once more
-			std::vector<void*> drop;
-			{ std::lock_guard<std::mutex> g(mu); for (auto it = free_.begin(); it != free_.end();) { if (it->first.first == dev) { drop.push_back(it->second); it = free_.erase(it); } else ++it; } }
-			for (void *q : drop) (void)hipFree(q);
-			if (hipMalloc(&p, cap) != hipSuccess) p = nullptr;
+			// out of memory: give the pooled blocks back -- this pool's, then the library's -- and try once more.  (The failed call's error is
+			// taken off the runtime's books: left there, the next kernel-launch check would report an out-of-memory that was recovered from.)
+			(void)hipGetLastError();
+			trim();
+			if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); mcom_pool_trim(); if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
 		}
 		return p;
 	}
+	void trim() {
+		std::vector<void*> drop;
+		{ std::lock_guard<std::mutex> g(mu); for (auto &kv : free_) drop.push_back(kv.second); free_.clear(); }
+		for (void *q : drop) (void)hipFree(q);
+		(void)hipGetLastError();
+	}
 	void put(void *p, size_t cap) { if (!p) return; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(mu); free_.emplace(std::make_pair(dev, cap), p); }
 };
-DevicePool &device_pool() { static DevicePool *pool = new DevicePool(); return *pool; }
+static void host_pool_trim_hook();
+DevicePool &device_pool() { static DevicePool *pool = [] { mcom_set_oom_hook(&host_pool_trim_hook); return new DevicePool(); }(); return *pool; }
+static void host_pool_trim_hook() { device_pool().trim(); }
 
 template <class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;            // cap in elements
@@ -451,6 +459,8 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (p->ctx) mcom_destroy(p->ctx);
 	delete p;
 }
+
+extern "C" void mcomh_pool_trim(void) { device_pool().trim(); mcom_pool_trim(); }
 
 extern "C" const char *mcomh_last_error(const mcomh_pipeline *p) { return p ? p->err.c_str() : "null pipeline"; }
 

@@ -83,7 +83,7 @@ HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packe
                     # multi-GPU (bound in minicom_amd/distributed.py)
                     "mcomh_comm_unique_id", "mcomh_comm_create_rccl", "mcomh_comm_create_ops", "mcomh_comm_destroy", "mcomh_comm_rank",
                     "mcomh_comm_world", "mcomh_comm_last_error", "mcomh_comm_alltoallv", "mcomh_comm_allgatherv", "mcomh_comm_allreduce_u64",
-                    "mcomh_comm_stats", "mcomh_comm_seconds", "mcomh_create_dist"]
+                    "mcomh_comm_stats", "mcomh_comm_seconds", "mcomh_create_dist", "mcomh_pool_trim"]
 
 
 def decompress(folder: str, out_path: str, order: bool = False) -> int:
@@ -95,6 +95,11 @@ def decompress(folder: str, out_path: str, order: bool = False) -> int:
     if rc:
         raise McomError(f"cannot decode the stream files in {folder}")
     return int(n.value)
+
+
+def pool_trim():
+    """mcomh_pool_trim: pooled device blocks of closed pipelines go back to the runtime."""
+    load_host_library().mcomh_pool_trim()
 
 
 def decompress_pe(folder: str, out_path1: str, out_path2: str) -> int:

@@ -67,6 +67,45 @@ def test_more_than_2_pow_24_contigs_on_one_card():
     assert res["n_reads"] == n and res["members"] + res["n_sg"] + sum(res["n_" + k] for k in ("allA", "allT", "allN", "fpA", "fpT", "fpN", "Nfile")) == n
     assert res["members"] > 0.5 * n and res["members_checked"] == res["members"]
     assert res["max_mismatch"] <= L // 2
+    # ... and the multi-GPU path on the same input: 2 and 4 ranks (threads of this process on the one card, Comm.threads) end with
+    # the single-GPU digest on every rank
+    from minicom_amd.pipeline import pool_trim
+    for world in (2, 4):
+        pool_trim()                                                        # (the blocks the runs before left in the process's pools)
+        assert _thread_ranks_digests(n, L, 1005, 5, world) == [d1] * world, world
+    pool_trim()
+
+
+def _thread_ranks_digests(n, L, seed, coverage, world):
+    import threading
+    import torch
+    import minicom_amd
+    from minicom_amd.distributed import Comm, DistPipeline
+    ctx = minicom_amd.Context(0)
+    reads = ctx.synth_reads(seed, n, L, coverage=coverage)
+    ctx.sync()
+    comms, hub = Comm.threads(world)
+    out, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            p = DistPipeline(reads[lo:hi], lo, n, comms[rank], L=L, device=0, host_threads=4)
+            p.pre_process()
+            out[rank] = p.result_digest()
+            p.close()
+        except Exception as e:                                                  # noqa: BLE001
+            errors.append((rank, repr(e))); hub.abort()
+    t0 = time.time()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors
+    print(f"[{n} x {L}] {world} ranks: {time.time() - t0:.1f} s", flush=True)
+    for c in comms:
+        c.close()
+    del reads
+    torch.cuda.empty_cache()
+    return out
 
 
 def test_config2_67m_reads_of_100_bases():
