@@ -472,6 +472,24 @@ int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const
                          const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
                          uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars);
 
+/* ---- the stream files of cluster_dump, made where the data is (kthread_dump.c:142-236, :364-417) ---- */
+/* print_encode for every member of every contig: d_mem / d_moff = the member lists in dump order (cmpcluster2 inside a contig,
+ * kthread_dump.c:143: mcom_members_finalize with one empty pass sorts them so), d_cbits / d_coff the packed contigs
+ * (mcom_pack_contigs), d_packed / d_nmask (may be NULL: no read holds an N) the reads.  Out, as file images:
+ *   d_pos  [4 n_contigs + 2 n_members] beg_pos.bin: per contig its member count (u32), then the 16-bit position deltas (:167, :224)
+ *   d_dir  [(n_members + 7) / 8]       dir.bin: one direction bit per member, least significant first (breads.h:241-248)
+ *   d_text [*h_text_bytes]             dif_char.txt: per member the run-length mismatch text of :198-221 and a newline
+ * MCOM_E_OVERFLOW (with *h_text_bytes = the room needed; d_pos / d_dir are complete) when text_cap is too small.  Synchronous. */
+int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_nmask, int L, const uint64_t *d_cbits, const uint64_t *d_coff,
+                      const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint8_t *d_pos, uint8_t *d_dir,
+                      uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes);
+/* ref.bin: the contig strings back to back, four bases per byte (breads.h:232-239): d_out [(chars + 3) / 4]                      */
+int mcom_dump_refbin(mcom_ctx *ctx, const uint8_t *d_seq, uint64_t chars, uint8_t *d_out);
+/* single.seq: reads d_rids[0 .. n) back to back, four bases per byte (kthread_dump.c:390-417): d_out [(n L + 3) / 4]            */
+int mcom_dump_singles(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, uint64_t n, int L, uint8_t *d_out);
+/* d_flag[i] = 1 when read d_rids[i] holds an N (such unclustered reads go to single_N.seq as text, kthread_dump.c:400-407)       */
+int mcom_rows_have_n(mcom_ctx *ctx, const uint64_t *d_nmask, const uint32_t *d_rids, size_t n, int L, uint8_t *d_flag);
+
 /* ---- multi-GPU helpers (no reference counterpart: the reference is a shared-memory program) ---- */
 /* Stable partition of n records by the rank that owns their minimizer bucket: bucket beta = x & (2^b - 1) belongs to
  * rank (beta * ranks) >> b -- contiguous bucket ranges in rank order, so that rank-major order is the reference's

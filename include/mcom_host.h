@@ -38,6 +38,8 @@ typedef struct {
 	int full_consensus; /* 1 = count every column of a merged contig (construct_ref2 as written) instead of only the
 	                       parents' overlap; same strings (A/B switch for measurements)                             */
 	int full_sketch;    /* 1 = sketch merged contigs whole instead of around the overlap; same records (A/B switch) */
+	int host_dump;      /* 1 = mcomh_cluster_dump writes its streams with the host loop of the -p / paired-end modes instead of the
+	                       device encoder (csrc/streams.hip); same files (A/B switch, the cross-check of tests/test_streams.py)   */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

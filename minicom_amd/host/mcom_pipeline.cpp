@@ -252,6 +252,7 @@ struct mcomh_pipeline {
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
+	bool host_dump = false;                                           // true: cluster_dump's default mode on the host, as the -p / paired-end modes (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
 	bool screen_clear = false;                                             // a pass of this Stage 2 proved that no dictionary bin exceeds maxsearch
@@ -285,6 +286,7 @@ using P = mcomh_pipeline;
 // wait for the peers), so that a stage's timers say what this rank itself was busy with.  One GPU: the wall clock.
 static double busy_now(const P *p) { return now_ms() - (p->comm ? 1e3 * mcomh_comm_seconds(p->comm) : 0.0); }
 static int materialize(P *p);
+static int ensure_packed_contigs(P *p);
 static void ensure_sg_flag(P *p)
 {
 	if (!p->raw_flags_valid) return;
@@ -368,6 +370,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->window_scan = pp->window_scan == 1;
 	p->full_consensus = pp->full_consensus == 1;
 	p->resketch = pp->full_sketch != 1;
+	p->host_dump = pp->host_dump == 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
@@ -1445,6 +1448,23 @@ static int realign_big_bins(P *p, const mcom_dicts *dicts, const uint64_t *d_sgb
 	return p->sync("claims of long bins");
 }
 
+// the packed form of the contig set in dC (combine_cluster leaves the packed form of its last set behind)
+static int ensure_packed_contigs(P *p)
+{
+	if (p->cbits_for_dC) return MCOM_OK;
+	const size_t nc = p->dC.n;
+	uint64_t tw = 0;
+	int rc;
+	if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+	if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+	p->total_words = tw;
+	if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+	if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
+	           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
+	p->cbits_for_dC = true;
+	return MCOM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // realign_hash: one Stage-2 pass                                    kthread_hash_realign.c:569-594
 // ----------------------------------------------------------------------------------------------------
@@ -1475,18 +1495,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		}
 	}
 	if (!p->stage2_uploaded) {                      // contig consensus strings do not change during Stage 2
-		{                                                      // the set is on the device: lay it out and pack it there
-			uint64_t tw = 0;
-			if (!p->cbits_for_dC) {                                // (combine_cluster leaves the packed form of its last set behind)
-				if (!p->d_coff_words.reserve(nc + 1) || !p->d_clen.reserve(nc + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
-				if ((rc = p->gpu(mcom_contig_layout(p->ctx, p->dC.soff.p, nc, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
-				p->total_words = tw;
-				if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-				if (nc && ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear")) ||
-				           (rc = p->gpu(mcom_pack_contigs(p->ctx, p->dC.seq.p, p->dC.soff.p, p->d_coff_words.p, (uint32_t)nc, tw, p->d_cbits.p))))) return rc;
-				p->cbits_for_dC = true;
-			}
-		}
+		if ((rc = ensure_packed_contigs(p))) return rc;            // the set is on the device: laid out and packed there
 		if (!p->d_woff.reserve(nc + 2)) return p->fail(MCOM_E_NOMEM, "window offsets");
 		uint64_t nwin = 0, mlen = 0;
 		if ((rc = p->gpu(mcom_window_layout(p->ctx, p->dC.soff.p, nc, p->L, p->d_woff.p, &nwin, &mlen)))) return rc;
@@ -1956,10 +1965,124 @@ static bool write_ids(const std::string &path, const std::vector<uint32_t> &ids)
 	return true;
 }
 
+// The default mode with the streams made on the device (csrc/streams.hip): the member lists are put into dump order there
+// (cmpcluster2, kthread_dump.c:143), one thread per member writes its mismatch text, position delta and direction bit, the
+// bit-packed files are one thread per output byte; what crosses PCIe are the finished file images (about 10 bytes per read
+// instead of the 64 of packed rows + N masks), and the host writes them with one fwrite each.
+static bool write_file(const std::string &path, const void *data, size_t bytes)
+{
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f) return false;
+	const bool ok = bytes == 0 || fwrite(data, 1, bytes, f) == bytes;
+	return fclose(f) == 0 && ok;
+}
+// the reads of a (short) list as strings with their N put back (kthread_dump.c:178-186): rows and masks gathered on the device
+static int fetch_read_strings(P *p, const std::vector<uint32_t> &rids, std::vector<char> &out)
+{
+	const int L = p->L, W = p->W, NW = p->NW;
+	const size_t n = rids.size();
+	out.assign(n * ((size_t)L + 1), 0);
+	if (!n) return MCOM_OK;
+	DevBuf<uint32_t> d_r; DevBuf<uint64_t> d_rows, d_nm;
+	if (!d_r.reserve(n) || !d_rows.reserve(n * W) || !d_nm.reserve(n * NW)) return p->fail(MCOM_E_NOMEM, "list rows");
+	std::vector<uint64_t> rows(n * (size_t)W), nm(n * (size_t)NW);
+	int rc;
+	if ((rc = p->h2d(d_r.p, rids.data(), n, "upload list")) || (rc = p->gpu(mcom_gather_rows(p->ctx, p->d_packed.p, d_r.p, n, L, d_rows.p))) ||
+	    (rc = p->gpu(mcom_gather_rows(p->ctx, p->d_nmask.p, d_r.p, n, 32 * NW, d_nm.p))) ||               // (a mask row = NW words = the packed row of 32 NW bases)
+	    (rc = p->d2h(rows.data(), d_rows.p, n * W, "copy rows")) || (rc = p->d2h(nm.data(), d_nm.p, n * NW, "copy masks")) || (rc = p->sync("list rows"))) return rc;
+	for (size_t r = 0; r < n; ++r) {
+		char *o = out.data() + r * ((size_t)L + 1);
+		for (int i = 0; i < L; ++i) o[i] = ((nm[r * NW + (i >> 6)] >> (i & 63)) & 1) ? 'N' : ACGT[(rows[r * W + (i >> 5)] >> (2 * (i & 31))) & 3];
+	}
+	return MCOM_OK;
+}
+static int cluster_dump_device(mcomh_pipeline *p, const char *folder)
+{
+	p->join_sg();
+	ensure_sg_flag(p);
+	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
+	int rc = materialize(p);
+	if (rc) return rc;
+	if (!p->dC_valid) return p->fail(MCOM_E_ARG, "no contig set on the device");
+	const double t0 = now_ms();
+	DevSet &D = p->dC;
+	const int L = p->L;
+	const std::string dir(folder);
+	PinVec<uint8_t> h_pos, h_dir, h_text, h_ref, h_single;
+	uint64_t text_bytes = 0;
+	const size_t pos_bytes = 4 * D.n + 2 * (size_t)D.members, dir_bytes = ((size_t)D.members + 7) / 8, ref_bytes = ((size_t)D.chars + 3) / 4;
+	if (D.n) {
+		if ((rc = ensure_packed_contigs(p))) return rc;
+		// members in dump order: stable by (offset, direction) inside every contig -- the fold of mcom_members_finalize with one empty pass
+		DevBuf<uint64_t> mem2, moff2;
+		if (!mem2.reserve(D.members + 1) || !moff2.reserve(D.n + 2)) return p->fail(MCOM_E_NOMEM, "member lists");
+		int kb = 2; while ((1ull << kb) < 4 * std::max<uint64_t>(p->maxlen, 2 * (uint64_t)L) + 4) ++kb;
+		const uint32_t *ac[1] = {nullptr}; const uint64_t *am[1] = {nullptr}; const uint64_t an[1] = {0};
+		if ((rc = p->gpu(mcom_members_finalize(p->ctx, D.mem.p, D.moff.p, D.n, D.members, ac, am, an, 1, kb, mem2.p, moff2.p)))) return rc;
+		DevBuf<uint8_t> d_pos, d_dir, d_text, d_ref;
+		if (!d_pos.reserve(pos_bytes + 16) || !d_dir.reserve(dir_bytes + 16) || !d_ref.reserve(ref_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
+		rc = mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, moff2.p, D.n, D.members, d_pos.p, d_dir.p, nullptr, 0, &text_bytes);
+		if (rc != MCOM_E_OVERFLOW && rc != MCOM_OK) return p->gpu(rc);
+		if (!d_text.reserve(text_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
+		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, moff2.p, D.n, D.members, d_pos.p, d_dir.p, d_text.p,
+		                                   text_bytes + 16, &text_bytes))) || (rc = p->gpu(mcom_dump_refbin(p->ctx, D.seq.p, D.chars, d_ref.p)))) return rc;
+		if (!h_pos.resize(pos_bytes) || !h_dir.resize(dir_bytes) || !h_text.resize(text_bytes) || !h_ref.resize(ref_bytes)) return p->fail(MCOM_E_NOMEM, "stream images");
+		if ((rc = p->d2h(h_pos.data(), d_pos.p, pos_bytes, "copy streams")) || (rc = p->d2h(h_dir.data(), d_dir.p, dir_bytes, "copy streams")) ||
+		    (rc = p->d2h(h_text.data(), d_text.p, (size_t)text_bytes, "copy streams")) || (rc = p->d2h(h_ref.data(), d_ref.p, ref_bytes, "copy streams")) || (rc = p->sync("copy streams"))) return rc;
+	}
+	p->stat["t_dump_members"] += now_ms() - t0;
+	// unclustered reads: those with an N join the N file as text, the others are packed four per byte in singleton order (:390-417)
+	std::vector<uint32_t> live, single_ids, nfile = p->Nfile;
+	live.reserve(p->sg.size());
+	for (size_t i = 0; i < p->sg.size(); ++i) if (!p->sg_flag[i]) live.push_back(p->sg[i]);
+	if (!live.empty()) {
+		DevBuf<uint32_t> d_ids; DevBuf<uint8_t> d_f, d_single;
+		std::vector<uint8_t> hasn(live.size());
+		if (!d_ids.reserve(live.size()) || !d_f.reserve(live.size())) return p->fail(MCOM_E_NOMEM, "singleton buffers");
+		if ((rc = p->h2d(d_ids.p, live.data(), live.size(), "upload singletons")) || (rc = p->gpu(mcom_rows_have_n(p->ctx, p->d_nmask.p, d_ids.p, live.size(), L, d_f.p))) ||
+		    (rc = p->d2h(hasn.data(), d_f.p, live.size(), "copy flags")) || (rc = p->sync("singleton flags"))) return rc;
+		single_ids.reserve(live.size());
+		for (size_t i = 0; i < live.size(); ++i) (hasn[i] ? nfile : single_ids).push_back(live[i]);
+		const size_t sbytes = (single_ids.size() * (size_t)L + 3) / 4;
+		if (!single_ids.empty()) {
+			if (!d_single.reserve(sbytes + 16) || !h_single.resize(sbytes)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
+			if ((rc = p->h2d(d_ids.p, single_ids.data(), single_ids.size(), "upload singletons")) || (rc = p->gpu(mcom_dump_singles(p->ctx, p->d_packed.p, d_ids.p, single_ids.size(), L, d_single.p))) ||
+			    (rc = p->d2h(h_single.data(), d_single.p, sbytes, "copy singletons")) || (rc = p->sync("singleton stream"))) return rc;
+		}
+	}
+	p->stat["t_dump_gpu"] += now_ms() - t0;
+	const double tw = now_ms();
+	if (!write_file(dir + "/ref.bin.0", h_ref.data(), D.n ? ref_bytes : 0) || !write_file(dir + "/beg_pos.bin.0", h_pos.data(), D.n ? pos_bytes : 0) ||
+	    !write_file(dir + "/dir.bin.0", h_dir.data(), D.n ? dir_bytes : 0) || !write_file(dir + "/dif_char.txt.0", h_text.data(), D.n ? (size_t)text_bytes : 0) ||
+	    !write_file(dir + "/single.seq", h_single.data(), h_single.size())) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	FILE *finfo = fopen((dir + "/info.txt").c_str(), "w");
+	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
+	fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	fclose(finfo);
+	// the short lists as text (:566-671)
+	struct TextList { const char *name; const std::vector<uint32_t> *ids; char base; };
+	const TextList lists[4] = {{"AA.txt", &p->fpA, 'A'}, {"TT.txt", &p->fpT, 'T'}, {"NN.txt", &p->fpN, 'N'}, {"single_N.seq", &nfile, 0}};
+	for (const TextList &tl : lists) {
+		std::vector<char> strs;
+		if ((rc = fetch_read_strings(p, *tl.ids, strs))) return rc;
+		FILE *f = fopen((dir + "/" + tl.name).c_str(), "w");
+		if (!f) return p->fail(MCOM_E_ARG, "cannot write text streams");
+		for (size_t r = 0; r < tl.ids->size(); ++r) {
+			const char *t = strs.data() + r * ((size_t)L + 1);
+			if (tl.base) fprintf(f, "%s\n", const_base_text(t, L, tl.base).c_str()); else fprintf(f, "%s\n", t);
+		}
+		fclose(f);
+	}
+	p->stat["t_dump_write"] += now_ms() - tw;
+	p->stat["dump_bytes"] += (double)(pos_bytes + dir_bytes + ref_bytes + text_bytes + h_single.size());
+	return MCOM_OK;
+}
+
 // mode 0: default; 1: order-preserving (-p, ORDER); 2: paired end (_PE: reads [0, n/2) are the first file, the rest their mates)
 static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 {
 	if (!p || !folder) return MCOM_E_ARG;
+	if (mode == 0 && !p->host_dump) return cluster_dump_device(p, folder);
 	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70

@@ -76,6 +76,31 @@ def test_round_trip_at_a_size_no_fixture_covers():
     p.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [64, 100, 150, 250])
+def test_device_stream_encoder_equals_the_host_loop(tmp_path, L):
+    """cluster_dump's default mode is made on the device (csrc/streams.hip: one thread per member writes print_encode's text,
+    kthread_dump.c:198-221); the host loop of the -p / paired-end modes writes the same files (host_dump = 1).  200 k reads plus
+    20 k with N, poly-A/T and N-heavy reads: every file byte-identical."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = np.concatenate([synth.synth_reads(3030 + L, 200000, L), synth.synth_reads(3031 + L, 20000, L, plumbing=True)])
+    files = {}
+    for how in (0, 1):
+        p = Pipeline(reads, host_threads=8, host_dump=how)
+        p.pre_process()
+        d = tmp_path / f"streams{how}"; d.mkdir()
+        p.cluster_dump(str(d))
+        if how == 0:
+            assert p.stat("dump_bytes") > 0                              # the device encoder ran
+        p.close()
+        files[how] = {f: (d / f).read_bytes() for f in sorted(os.listdir(d))}
+    assert sorted(files[0]) == sorted(files[1])
+    for name in files[1]:
+        assert files[0][name] == files[1][name], name
+    assert len(files[0]["dif_char.txt.0"]) > 100000 and b"N" in files[0]["dif_char.txt.0"]
+
+
 # ---- order-preserving mode (minicom -p, the reference compiled with ORDER): SURVEY section 8f rank 4, single-end part
 def _golden_order_streams(golden_dir, tag):
     with gzip.open(os.path.join(golden_dir, "streams_order_" + tag + ".tar.gz"), "rb") as g:
