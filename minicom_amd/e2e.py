@@ -1,0 +1,161 @@
+"""File -> stream files, timed stage by stage (bench.py's `value_file_to_streams`, tools/e2e_bench.py).
+
+The hot path's number (bench.py `value`) starts with the reads resident in HBM and ends with the contig set there.  What a user of
+the `minicom` command waits for starts with a FASTQ file on disk and ends with the pre-entropy-coder stream files on disk
+(ref.bin / beg_pos.bin / dir.bin / dif_char.txt / single.seq ...: the contents of the .minicom container before bsc / 7z / xz):
+    parse + upload   mcomh_fastq_to_device   (mapped file, all cores, page-locked blocks straight to the rows' place in HBM)
+    hot path         mcomh_pre_process       (Stage 1 + Stage 2)
+    encode + write   mcomh_cluster_dump      (streams made on the device, csrc/streams.hip; file images copied back and written)
+The reference binary (oracle/_ref, when present) runs the same way on a prefix of the same file: its whole process, file to
+stream files, by the wall clock."""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads: int = 1_000_000, workdir: str | None = None, keep: bool = False):
+    import numpy as np
+    import torch
+    import minicom_amd
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    td = tempfile.mkdtemp(prefix="mcom_e2e_", dir=workdir)
+    try:
+        ctx = minicom_amd.Context(0)
+        fq = os.path.join(td, "reads.fastq")
+        t = time.perf_counter()
+        # the file is written in blocks of 4 M reads generated on the device (the generator of the benchmark)
+        with open(fq, "wb"):
+            pass
+        block = 4_000_000
+        tmp = os.path.join(td, "part.fastq")
+        with open(fq, "ab") as out:
+            for lo in range(0, n, block):
+                cnt = min(block, n - lo)
+                part = ctx.synth_reads(seed, n, L, first=lo, count=cnt).cpu().numpy()
+                _append_fastq(out, part, lo)
+                del part
+        ctx.close()
+        t_write_input = time.perf_counter() - t
+        size = os.path.getsize(fq)
+        out_dir = os.path.join(td, "streams"); os.makedirs(out_dir)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p = Pipeline.from_fastq(fq, host_threads=host_threads)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        p.pre_process()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        p.cluster_dump(out_dir)
+        t3 = time.perf_counter()
+        assert p.n == n and p.L == L
+        stream_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+        res = {"reads": n, "read_len": L, "fastq_bytes": size, "stream_bytes": stream_bytes,
+               "seconds": {"parse_and_upload": round(t1 - t0, 3), "hot_path": round(t2 - t1, 3), "encode_copy_write": round(t3 - t2, 3),
+                           "of_which_device_encode_and_copy": round(p.stat("t_dump_gpu") / 1e3, 3), "of_which_file_writes": round(p.stat("t_dump_write") / 1e3, 3),
+                           "total": round(t3 - t0, 3)},
+               "value": round(n / (t3 - t0) / 1e6, 3), "unit": "Mreads/s",
+               "fastq_GB_per_s": round(size / (t1 - t0) / 1e9, 2),
+               "note": "FASTQ file (page cache) -> parse -> HBM -> Stage 1 + Stage 2 -> stream files written; the entropy coder (bsc / 7z / xz, external) is not part of it",
+               "input_written_in_s": round(t_write_input, 1)}
+        p.close()
+        res["reference"] = _reference_on_prefix(fq, td, n, L, ref_reads)
+        return res
+    finally:
+        if not keep:
+            shutil.rmtree(td, ignore_errors=True)
+
+
+def host_cores() -> int:
+    """cores this process may run on (the GPU box gives a job a share of the host)"""
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:                                                           # noqa: BLE001
+        return os.cpu_count() or 1
+
+
+def reference_binary(L: int):
+    """(path, variant, threads) of the reference build with the most threads the box has cores for (oracle/build_ref.sh compiles the
+    thread count in, as the reference's own script does: minicom:56-91), or None"""
+    cores = host_cores()
+    best = None
+    for t in (64, 32, 16, 8, 1):
+        variant = f"L{L}_t{t}" if t > 1 else f"L{L}"
+        exe = os.path.join(ROOT, "oracle", "_ref", variant, "minicom_bin")
+        if os.path.exists(exe) and (t <= cores or best is None):
+            best = (exe, variant, t)
+            if t <= cores:
+                break
+    return best
+
+
+def _append_fastq(out, reads, first_id):
+    """four-line records @r<id>, quality 'I' (synth.write_fastq_fast's layout, appended block by block)"""
+    import numpy as np
+    m, L = reads.shape
+    lo = first_id
+    end = first_id + m
+    while lo < end:
+        digits = len(str(lo))
+        hi = min(end, 10 ** digits)
+        k = hi - lo
+        rec = np.empty((k, 2 + digits + 1 + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+        ids = np.arange(lo, hi, dtype=np.int64)
+        for d in range(digits):
+            rec[:, 2 + digits - 1 - d] = ord("0") + (ids // 10 ** d) % 10
+        o = 2 + digits
+        rec[:, o] = 10
+        rec[:, o + 1:o + 1 + L] = reads[lo - first_id:hi - first_id]
+        rec[:, o + 1 + L] = 10; rec[:, o + 2 + L] = ord("+"); rec[:, o + 3 + L] = 10
+        rec[:, o + 4 + L:o + 4 + 2 * L] = ord("I")
+        rec[:, o + 4 + 2 * L] = 10
+        out.write(rec.tobytes())
+        lo = hi
+
+
+def _reference_on_prefix(fq, td, n, L, ref_reads):
+    """the reference's own binary (built by oracle/build_ref.sh in the build container; it travels as a built file), whole process"""
+    found = reference_binary(L)
+    if not found:
+        return None
+    exe, variant, threads = found
+    m = min(n, ref_reads)
+    pre = os.path.join(td, "prefix.fastq")
+    with open(fq, "rb") as f, open(pre, "wb") as g:                            # the first m records
+        need = 4 * m
+        buf = b""
+        while need > 0:
+            chunk = f.read(64 << 20)
+            if not chunk:
+                break
+            lines = chunk.count(b"\n")
+            if lines <= need:
+                g.write(chunk); need -= lines
+            else:
+                pos = -1
+                for _ in range(need):
+                    pos = chunk.index(b"\n", pos + 1)
+                g.write(chunk[:pos + 1]); need = 0
+    out = os.path.join(td, "ref_out"); os.makedirs(out)
+    cwd = os.path.join(td, "ref_cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
+    t = time.perf_counter()
+    try:
+        pr = subprocess.run([exe, pre, out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "note": f"the reference did not finish {m} reads in 900 s"}
+    dt = time.perf_counter() - t
+    if pr.returncode != 0:
+        return {"value": None, "note": f"the reference binary failed ({pr.returncode})"}
+    st = [float(x) for x in re.findall(r"\[Stage \d\] Real time: ([\d.]+)", pr.stdout.decode())]
+    return {"value": round(m / dt / 1e6, 4), "unit": "Mreads/s", "reads": m, "threads": threads, "seconds_total": round(dt, 2),
+            "seconds_stage1_plus_stage2": round(sum(st), 2) if len(st) == 2 else None,
+            "note": f"oracle/_ref/{variant}/minicom_bin on the first {m} reads of the same file, whole process (load + Stage 1 + Stage 2 + cluster_dump), wall clock"}

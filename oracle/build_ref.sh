@@ -64,3 +64,7 @@ build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE
 # multi-threaded builds, used only as the CPU baseline of bench.py (their output is not reproducible run to run)
 NUM_THR=16 build_variant L150_t16 150
+# ... at other core counts: bench.py takes the largest one the box has cores for (north_star: "-t <host cores>")
+NUM_THR=8 build_variant L150_t8 150
+NUM_THR=32 build_variant L150_t32 150
+NUM_THR=64 build_variant L150_t64 150

@@ -125,3 +125,32 @@ def test_from_fastq_reports_unequal_lengths(tmp_path):
     _write(p, b"@r1\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n@r2\nACGT\n+\nIIII\n")
     with pytest.raises(McomError, match="Length of reads are different"):
         Pipeline.from_fastq(p)
+
+
+@pytest.mark.gpu
+def test_parallel_parser_of_four_line_fastq_equals_the_sequential_reader(tmp_path):
+    """A plain four-line FASTQ file is mapped and parsed by all cores at once (mcom_fastq.cpp: record boundaries found by their
+    shape); 400 k reads of 150 bases = 130 MB, record sizes varying with the name, quality lines that start with '@' and '+':
+    the rows in HBM equal the array the file was written from, and the sequential reader's result."""
+    import torch
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, read_fastq
+    reads = np.concatenate([synth.synth_reads(71, 399000, 150), synth.synth_reads(72, 1000, 150, plumbing=True)])
+    fq = str(tmp_path / "big.fastq")
+    synth.write_fastq_fast(fq, reads)
+    assert os.path.getsize(fq) > 100 << 20
+    p = Pipeline.from_fastq(fq)
+    assert (p.n, p.L) == reads.shape
+    p.pre_process()
+    q = Pipeline(reads); q.pre_process()
+    assert p.result_digest() == q.result_digest()
+    p.close(); q.close()
+    assert np.array_equal(read_fastq(fq)[::997], reads[::997])
+    # not the four-line shape (a blank line in the middle): the sequential reader takes over, same result
+    with open(fq, "rb") as f:
+        data = f.read()
+    cut = data.index(b"\n@r200000\n") + 1
+    open(fq, "wb").write(data[:cut] + b"\n" + data[cut:])
+    p = Pipeline.from_fastq(fq)
+    assert p.n == reads.shape[0]
+    p.close()
