@@ -38,6 +38,10 @@ typedef struct {
 	int full_consensus; /* 1 = count every column of a merged contig (construct_ref2 as written) instead of only the
 	                       parents' overlap; same strings (A/B switch for measurements)                             */
 	int full_sketch;    /* 1 = sketch merged contigs whole instead of around the overlap; same records (A/B switch) */
+	int overlap_screen; /* 1 = the first Stage-2 pass gathers the singletons' rows and screens the dictionaries on the copy stream, beside
+	                       the contig index build, instead of behind it in the main stream; same result.  Measured on MI355X (100 M
+	                       reads): the two kernels slow each other down by what the overlap saves (243.7 vs 245-249 ms per step), so
+	                       it is off by default                                                                                 */
 	int host_dump;      /* 1 = mcomh_cluster_dump writes its streams with the host loop of the -p / paired-end modes instead of the
 	                       device encoder (csrc/streams.hip); same files (A/B switch, the cross-check of tests/test_streams.py)   */
 } mcomh_params;

@@ -80,12 +80,15 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_hist1(CixGeom g, CxSrc s, uin
 }
 
 // pass 1, scatter: the tile's entries grouped by digit in LDS (order inside a digit is free), every digit's run written in one piece
+// OWNERS: the index is shared out (digit = owner, kept beside the staged entry: it is not a function of the staged key; the extra
+// LDS would cost the one-share kernel its second workgroup per CU)
+template <bool OWNERS>
 __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, const uint32_t *__restrict__ offs, uint32_t nblocks,
                                                             uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot)
 {
 	__shared__ uint64_t st_slot[CX_TILE];
 	__shared__ uint32_t st_key[CX_TILE];
-	__shared__ uint8_t st_dig[CX_TILE];                     // (shared-out index only: the owner is not a function of the staged key)
+	__shared__ uint8_t st_dig[OWNERS ? CX_TILE : 4];
 	__shared__ uint32_t cnt[256], start[256], gofs[256], wsum[CX_THREADS / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	cnt[tid] = 0;
@@ -117,12 +120,12 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 	for (int it = 0; it < CX_ITEMS; ++it) if (ok[it]) {
 		const uint32_t at = start[dg[it]] + rank[it];
 		st_key[at] = k32[it]; st_slot[at] = sl[it];
-		if (g.n_owners > 1) st_dig[at] = dg[it];
+		if (OWNERS) st_dig[at] = dg[it];
 	}
 	__syncthreads();
 	const uint32_t total = start[255] + cnt[255];
 	for (uint32_t q = tid; q < total; q += CX_THREADS) {
-		const uint32_t d = g.n_owners > 1 ? (uint32_t)st_dig[q] : (st_key[q] >> 16) & 255u;
+		const uint32_t d = OWNERS ? (uint32_t)st_dig[q] : (st_key[q] >> 16) & 255u;
 		const size_t o = (size_t)gofs[d] + (q - start[d]);
 		out_key[o] = st_key[q]; out_slot[o] = st_slot[q];
 	}
@@ -555,7 +558,8 @@ extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const
 	MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
 	int rc;
 	if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;        // the extra element becomes the number of entries
-	hipLaunchKernelGGL(k_cx_scatter1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	if (g.n_owners > 1) hipLaunchKernelGGL(k_cx_scatter1<true>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	else hipLaunchKernelGGL(k_cx_scatter1<false>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
 	MCOM_LAUNCH_CHECK(ctx);
 	// the first entry of every share = the scanned count of (digit q, block 0)
 	std::vector<uint32_t> st(g.n_owners + 1, 0);

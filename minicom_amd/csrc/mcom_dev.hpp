@@ -111,6 +111,29 @@ __device__ __forceinline__ uint64_t mcom_hash64(uint64_t key, uint64_t mask)
 	return key;
 }
 
+// The same mix for 17 <= k <= 31 written for the machine: the low word of the mask is all ones, so only the high word is masked
+// (mhi = the mask's high word), and the two multiplications by small constants (x265, x21 -- the reference writes them as shifts
+// and adds, the compiler folds them into 64 x 32-bit multiply-adds, six v_mad_u64_u32 per k-mer) are chains of v_lshl_add_u64
+// (gfx940+: (a << s) + c, s <= 4, one instruction): 265 = 9 + 16 * 16, 21 = 5 + 16.
+template <int S> __device__ __forceinline__ uint64_t mcom_lshl_add64(uint64_t a, uint64_t c)
+{
+	uint64_t d;
+	asm("v_lshl_add_u64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(S), "v"(c));
+	return d;
+}
+__device__ __forceinline__ uint64_t mcom_mask_hi(uint64_t v, uint32_t mhi) { return (v & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(v >> 32) & mhi) << 32); }
+__device__ __forceinline__ uint64_t mcom_hash64_wide(uint64_t key, uint32_t mhi)
+{
+	key = mcom_mask_hi(~key + (key << 21), mhi);
+	key ^= key >> 24;
+	{ const uint64_t k9 = mcom_lshl_add64<3>(key, key), k16 = key << 4; key = mcom_mask_hi(mcom_lshl_add64<4>(k16, k9), mhi); }   // key + (key << 3) + (key << 8)
+	key ^= key >> 14;
+	{ const uint64_t k5 = mcom_lshl_add64<2>(key, key); key = mcom_mask_hi(mcom_lshl_add64<4>(key, k5), mhi); }                    // key + (key << 2) + (key << 4)
+	key ^= key >> 28;
+	key = mcom_mask_hi(key + (key << 31), mhi);
+	return key;
+}
+
 // 32-bit form of the same mix for 2k <= 32 (mask fits in one register)
 __device__ __forceinline__ uint32_t mcom_hash64_lo(uint32_t key, uint32_t mask)
 {

@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 	int run = 0;
 	if (WIDE) {
 		const uint32_t mhi = (uint32_t)((1ull << (2 * k - 32)) - 1);
-		const uint64_t mask = ((uint64_t)mhi << 32) | 0xFFFFFFFFull;
 		const int sh_hi = 2 * (k - 1) - 32;                 // top base of the reverse k-mer, inside the high word
 		uint64_t fwd = 0, rev = 0;
 		int i = 0;
@@ -241,20 +240,20 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 			const int lim = (L - 32 * q) < 32 ? (L - 32 * q) : 32;
 			for (int b = 0; b < lim; ++b, ++i) {
 				const uint32_t c = (uint32_t)cur & 3u; cur >>= 2;
-				fwd = ((fwd << 2) | c) & mask;
+				fwd = mcom_mask_hi((fwd << 2) | c, mhi);
 				rev = (rev >> 2) | ((uint64_t)((3u ^ c) << sh_hi) << 32);
 				if (ODDK) {
 					if (i >= k - 1) {                                            // uniform
-						const uint32_t z = fwd < rev ? 0u : 1u;
-						const uint64_t h = mcom_hash64(z ? rev : fwd, mask);
+						const bool lt = fwd < rev;                                  // one comparison serves the strand and the choice
+						const uint64_t h = mcom_hash64_wide(lt ? fwd : rev, mhi);
 						const bool better = h < best_x;
-						best_x = better ? h : best_x; best_i = better ? (uint32_t)i : best_i; best_z = better ? z : best_z;
+						best_x = better ? h : best_x; best_i = better ? ((uint32_t)i << 1 | (lt ? 0u : 1u)) : best_i;
 					}
 				} else if (fwd != rev) {
 					++run;
 					if (run >= k) {
 						const uint32_t z = fwd < rev ? 0u : 1u;
-						const uint64_t h = mcom_hash64(z ? rev : fwd, mask);
+						const uint64_t h = mcom_hash64_wide(z ? rev : fwd, mhi);
 						if (h < best_x) { best_x = h; best_i = (uint32_t)i; best_z = z; }
 					}
 				}
@@ -293,7 +292,8 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 	}
 	mcom_mm128 o;
 	o.x = best_x;
-	o.y = best_x == U64MAX ? U64MAX : ((uint64_t)rid << 32 | (uint64_t)(best_i << 1) | best_z);
+	const uint32_t ylow = (WIDE && ODDK) ? best_i : ((best_i << 1) | best_z);       // (that loop keeps position and strand in one register)
+	o.y = best_x == U64MAX ? U64MAX : ((uint64_t)rid << 32 | (uint64_t)ylow);
 	rec[t] = o;
 }
 
@@ -369,7 +369,7 @@ __global__ void k_hash64(const uint64_t *__restrict__ kmer, size_t n, int k, uin
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	if (k >= 17) out[i] = mcom_hash64(kmer[i], (1ull << (2 * k)) - 1);
+	if (k >= 17) out[i] = mcom_hash64_wide(kmer[i], (uint32_t)((1ull << (2 * k - 32)) - 1));
 	else out[i] = mcom_hash64_lo((uint32_t)kmer[i], k == 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u));
 }
 extern "C" int mcom_hash64_batch(mcom_ctx *ctx, const uint64_t *d_kmer, size_t n, int k, uint64_t *d_hash)

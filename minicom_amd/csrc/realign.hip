@@ -455,7 +455,9 @@ __device__ __forceinline__ void contig_window(const uint64_t *__restrict__ conti
 #define RR_CAND 4
 // TUP: singletons with mark[sg] set (members of a bin longer than maxsearch) do not take part in the minimum: every
 // tuple they pass is appended to `tuples` {claim key, singleton} for the replay of those bins on the host
-template <int W, int G, bool TUP>
+// SHARED: the index is shared out by key over several GPUs (its own instantiation: the one-GPU kernel sits at 94 registers, five
+// waves per SIMD, and the ownership test's few more would leave it four -- 19 -> 21.5 ms)
+template <int W, int G, bool TUP, bool SHARED>
 __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys,
                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
                                                        const uint32_t *__restrict__ elig, size_t n_sg, const uint64_t *__restrict__ cbits,
@@ -513,11 +515,16 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int nc = 0;
 	if (live) {
 		const uint64_t *rb = sgbits + sg * (size_t)W;
-		uint64_t key = bits_key(rb, g.ds[l], g.klen);                                      // (the row itself is loaded once the key turns out to be this share's)
+		constexpr bool shared = SHARED;                                                    // the index is shared out by key: most keys are another rank's,
+		if (!shared) {                                                                     // and the row is loaded only once the key turns out to be this share's
+#pragma unroll
+			for (int w = 0; w < W; ++w) row[w] = rb[w];
+		}
+		uint64_t key = shared ? bits_key(rb, g.ds[l], g.klen) : bits_key(row, g.ds[l], g.klen);
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
 		if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
 		uint32_t own, part, h16;
-		cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
+		cix_hash(key, SHARED ? g.n_owners : 1u, g.n_parts, own, part, h16);
 		const uint32_t nl = g.n_lines;
 		const unsigned long long *lines = keys + CIX_HEAD_WORDS;
 		const unsigned long long *L0 = lines + (size_t)part * nl * 8;
@@ -525,9 +532,9 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		const unsigned long long tag = cix_tag(key);
 		// (multi-GPU: the index is shared out by key; a key of another share is looked up on its owner's GPU, with this singleton's row
 		// replicated there, and the claim keys of all shares are MIN-reduced)
-		const bool mine = own == g.owner;
+		const bool mine = !SHARED || own == g.owner;
 		n_look += mine;
-		if (mine) {
+		if (shared && mine) {
 #pragma unroll
 			for (int w = 0; w < W; ++w) row[w] = rb[w];
 		}
@@ -619,15 +626,16 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t 
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 #define MCOM_ARGS g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count
+#define MCOM_LAUNCH(WW, GG, TT) do { if (g.n_owners > 1) hipLaunchKernelGGL((k_realign_reads<WW, GG, TT, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else hipLaunchKernelGGL((k_realign_reads<WW, GG, TT, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)
 #define MCOM_CASE(WW) case WW: \
-	if (d_mark) { if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
-	              else hipLaunchKernelGGL((k_realign_reads<WW, 32, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } \
-	else if (G == 16) hipLaunchKernelGGL((k_realign_reads<WW, 16, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
-	else hipLaunchKernelGGL((k_realign_reads<WW, 32, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); break;
+	if (d_mark) { if (G == 16) MCOM_LAUNCH(WW, 16, true); else MCOM_LAUNCH(WW, 32, true); } \
+	else if (G == 16) MCOM_LAUNCH(WW, 16, false); else MCOM_LAUNCH(WW, 32, false); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
+#undef MCOM_LAUNCH
 #undef MCOM_ARGS
 	MCOM_LAUNCH_CHECK(ctx);
 	if (d_stats) hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void k_ssc_order(const uint64_t *__restrict__ 
 // position of a ring entry follows from its slot, its strand bit rides in bit 62 of the hash word (hashes have 2k <= 62 bits),
 // and the ring of positions (a sixth of the LDS, i.e. one more wave per CU) is not needed.
 #define SSC_ZBIT (1ull << 62)
-template <bool ODDK>
+// WIDE: k >= 17, the hash in its form for 64-bit k-mers (mcom_hash64_wide: high-word mask, shift-add chains)
+template <bool ODDK, bool WIDE>
 __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end,
                                                     const uint32_t *__restrict__ ids, const uint32_t *__restrict__ list, uint32_t nlist,
                                                     int w, int k, uint32_t limit, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
@@ -173,10 +174,11 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 		fwd = base ? nf : fwd; rev = base ? nr : rev;
 		const bool pal = LV == 0 && base && fwd == rev;                      // a k-mer equal to its reverse complement stores nothing (:133)
 		const bool stored = in && !pal;                                      // an ambiguous base stores an empty entry and resets the run
-		const uint32_t z = fwd < rev ? 0u : 1u;
+		const bool fwd_lt = fwd < rev;
+		const uint32_t z = fwd_lt ? 0u : 1u;
 		run = LV >= 1 ? run + 1 : (base ? (pal ? run : run + 1) : (in ? 0 : run));
 		const bool real = LV == 2 || (base && !pal && run >= k);
-		const uint64_t hx = mcom_hash64(z ? rev : fwd, mask);
+		const uint64_t hx = WIDE ? mcom_hash64_wide(fwd_lt ? fwd : rev, (uint32_t)(mask >> 32)) : mcom_hash64(fwd_lt ? fwd : rev, mask);
 		const uint64_t cx = real ? hx : U64MAX;
 		const uint32_t cy = real ? ((i << 1) | z) : 0xFFFFFFFFu;
 		if (stored) { RX[slot * SSC_STRIDE + lane] = (ODDK && real) ? (cx | (z ? SSC_ZBIT : 0ull)) : cx; if (!ODDK) RY[slot * 64 + lane] = (uint16_t)cy; }
@@ -305,12 +307,16 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h2[0] >= 32768u) return -1;
 	if (h2[1] > tmp_bound) return mcom_fail(ctx, MCOM_E_HIP, "sketch rooms %u above their bound", h2[1]);
-	const bool oddk = (k & 1) != 0;
+	const bool oddk = (k & 1) != 0, wide = k >= 17;
+#define SSC_LAUNCH(blocks, ...) do { \
+	if (oddk && wide) hipLaunchKernelGGL((k_sketch_scan<true, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else if (oddk) hipLaunchKernelGGL((k_sketch_scan<true, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else if (wide) hipLaunchKernelGGL((k_sketch_scan<false, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else hipLaunchKernelGGL((k_sketch_scan<false, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); } while (0)
 	const size_t lds = (size_t)w * SSC_STRIDE * 8 + (oddk ? 0 : (size_t)w * 64 * 2) + (size_t)w * 64;
 	{
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-		if (oddk) hipLaunchKernelGGL(k_sketch_scan<true>, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
-		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((nn + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
+		SSC_LAUNCH((nn + 63) / 64, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	ctx->sketch_strings += n;
@@ -329,8 +335,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (n_over) {                                                            // denser than their room: once more, into their final places
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-		if (oddk) hipLaunchKernelGGL(k_sketch_scan<true>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
-		else hipLaunchKernelGGL(k_sketch_scan<false>, dim3((n_over + 63) / 64), dim3(64), lds, ctx->stream, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
+		SSC_LAUNCH((n_over + 63) / 64, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}

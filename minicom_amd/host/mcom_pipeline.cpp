@@ -252,6 +252,7 @@ struct mcomh_pipeline {
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
+	bool overlap_screen = false;                                      // true: the first Stage-2 pass's row gather + screen on the copy stream (A/B switch)
 	bool host_dump = false;                                           // true: cluster_dump's default mode on the host, as the -p / paired-end modes (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
@@ -371,6 +372,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->full_consensus = pp->full_consensus == 1;
 	p->resketch = pp->full_sketch != 1;
 	p->host_dump = pp->host_dump == 1;
+	p->overlap_screen = pp->overlap_screen == 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
@@ -1479,7 +1481,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 	{ const double tu = busy_now(p); mcomh_update_single(p); p->stat["t_ra_update"] += busy_now(p) - tu; }                // preprocess.c:203
 	const size_t nc = p->dC.n, n_sg = p->sg.size();
 	int rc;
-	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && sg_sent_up && !p->early.on) {
+	if (!p->stage2_uploaded && !p->window_scan && !p->screen_clear && n_sg && p->sg_live_valid && p->n_sg_live == n_sg && sg_sent_up && !p->early.on && p->overlap_screen) {
 		// singletons' rows and the dictionary screen on the copy stream (behind the upload of the singleton list, which went there),
 		// while this thread builds the contig index on the main stream
 		P::Early &E = p->early;

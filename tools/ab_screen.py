@@ -1,0 +1,15 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import torch, minicom_amd
+from minicom_amd.pipeline import Pipeline
+ctx = minicom_amd.Context(0)
+n, L = 100_000_000, 150
+reads = ctx.synth_reads(1002, n, L); ctx.sync()
+for label, prm in (("overlap", {"overlap_screen": 1}), ("serial", {}), ("overlap", {"overlap_screen": 1}), ("serial", {})):
+    ts = []
+    for it in range(3):
+        p = Pipeline(reads, L=L, host_threads=16, **prm); p.prof_enable(True)
+        torch.cuda.synchronize(); t = time.perf_counter(); p.pre_process(); d = p.result_digest(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+        info = (p.stat("t_realign"), p.prof_read("cindex_build")[0], p.prof_read("realign_reads")[0], p.prof_read("dict_build")[0], p.stat("early_screen"))
+        p.close()
+    print(label, ["%.1f" % x for x in ts], "t_realign %.1f cindex %.1f realign_reads %.1f screen %.1f early %d" % info, flush=True)
