@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- Mreads/s of minicom's sketch + index + overlap hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--genome uniform|repeats]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
 One step = one full pass of the hot path (the reference's timed region, Stage 1 + Stage 2, preprocess.c:137-234) over one
-batch of synthetic reads that are already resident in HBM: BASELINE.json configs[1], 100 M x 150 bp, k = 31, default
-parameters, per GPU.  The step ends with the result digest read back (mcomh_result_digest), which every timed step must
-share with an untimed run whose result was CHECKED (minicom_amd/check.py: every read in exactly one place, every member on
-and like its contig).
-N > 1: one process per GPU; the distributed pipeline of libmcom_host.so (mcomh_create_dist): reads sharded, minimizer
-records exchanged to bucket owners every bucket round over RCCL (ncclSend/ncclRecv groups), contig set replicated by
-all-gather, Stage-2 claims MIN-reduced; every rank ends with the complete result, identical to the single-GPU result over all
-N x reads ("weak" scaling: reads per GPU fixed).  Prints ONE JSON line on rank 0.
+batch of synthetic reads that are already resident in HBM.  The step ends with the result digest read back
+(mcomh_result_digest), which every timed step must share with an untimed run whose result was CHECKED (minicom_amd/check.py:
+every read in exactly one place, every member on and like its contig).
+
+Workload.  N = 1: BASELINE.json configs[1], 100 M x 150 bp, k = 31, default parameters.  N > 1: configs[3]'s shape, ONE job of
+62.5 M x N reads (500 M at N = 8) sharded over the GPUs -- reads per GPU fixed, "scaling": "weak" -- and, beside it,
+`value_strong_100m`: configs[1]'s 100 M-read job sharded over the same N GPUs.  One process per GPU; the distributed pipeline of
+libmcom_host.so (mcomh_create_dist): reads sharded, minimizer records exchanged to bucket owners every bucket round over RCCL
+(ncclSend / ncclRecv groups), merge-round index built by bucket range, merges by claimed-pair range, the Stage-2 contig index
+shared out by key, claims MIN-reduced; every rank ends with the complete result, identical to the single-GPU result over all reads.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -27,50 +30,55 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SEED = 1002            # seed = 1000 + config number
+SEED = 1002            # seed = 1000 + config number (configs[1]); the N > 1 job uses 1004 (configs[3])
 CLOCK_HZ = 2.4e9       # MI355X engine clock; 256 CUs x 4 SIMDs; a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 VALU_PEAK = 1024 * CLOCK_HZ / 2
+HBM_PEAK = 8000.0      # GB/s (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable)
+READS_PER_GPU_WEAK = 62_500_000
 
 
 def cpu_baseline(L, sample):
-    """The reference itself (oracle/_ref, built from /root/reference in the build container) on the host cores,
-    on a bounded sample of the same workload; falls back to the C restatement (oracle/) when the binary is absent."""
+    """The reference itself (oracle/_ref, built from /root/reference in the build container, compiled for the most threads the box
+    has cores for: the thread count is a compile-time constant of the reference, minicom:56-91) on the host cores, on a bounded
+    sample of the same workload, by its own Stage 1 + Stage 2 timers; falls back to the C restatement (oracle/) when absent."""
     from minicom_amd import synth
+    from minicom_amd.e2e import host_cores, reference_binary
     reads = synth.synth_reads(SEED, sample, L)
     tag = f"{sample} reads x {L} bp, same generator (seed {SEED}, 30x coverage, 0.5% substitutions)"
-    for variant, cores in (("L150_t16", 16), ("L150", 1)):
-        exe = os.path.join(ROOT, "oracle", "_ref", variant, "minicom_bin")
-        if L != 150 or not os.path.exists(exe):
-            continue
+    found = reference_binary(L)
+    if found:
+        exe, variant, threads = found
         try:
             with tempfile.TemporaryDirectory() as td:
                 fq = os.path.join(td, "s.fastq")
-                synth.write_fastq(fq, reads)
+                synth.write_fastq_fast(fq, reads, tricky_quality=False)
                 out = os.path.join(td, "out"); os.makedirs(out)
                 cwd = os.path.join(td, "cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
-                p = subprocess.run([exe, fq, out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+                t0 = time.perf_counter()
+                p = subprocess.run([exe, fq, out], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                wall = time.perf_counter() - t0
                 t = [float(x) for x in re.findall(r"\[Stage \d\] Real time: ([\d.]+)", p.stdout.decode())]
                 if p.returncode == 0 and len(t) == 2:
-                    return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": cores, "kind": "reference", "sample_reads": sample,
-                            "sample": tag + f"; reference's own Stage 1 + Stage 2 timers, -t {cores} (the reference slows down with size: "
-                                            "0.056 Mreads/s on 8 M reads, DESIGN.md section 6)", "seconds": round(sum(t), 3)}
-        except Exception:
+                    return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": threads, "kind": "reference", "sample_reads": sample,
+                            "sample": tag + f"; oracle/_ref/{variant}/minicom_bin (-t {threads}; the box offers {host_cores()} cores), its own Stage 1 + Stage 2 timers, measured in this run",
+                            "seconds": round(sum(t), 3), "seconds_whole_process": round(wall, 3)}
+        except Exception:                                                      # noqa: BLE001
             pass
     import oracle
-    p = oracle.Pipeline(reads)
+    sample = min(sample, 1_000_000)
+    p = oracle.Pipeline(reads[:sample])
     t0 = time.perf_counter(); p.run_all(); dt = time.perf_counter() - t0
     p.close()
     return {"value": round(sample / dt / 1e6, 6), "unit": "Mreads/s", "cores": 1, "kind": "port", "sample_reads": sample,
-            "sample": tag + "; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
+            "sample": f"{sample} reads x {L} bp, same generator; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
 
 
 KERNELS = ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows", "consensus",
            "cindex_build", "realign_reads")
 
 
-def algorithmic_bytes(name, st, L, nd, model="word"):
-    """Algorithmic bytes of every launch of a timed kernel class over the timed steps.
-    model "word": the words an entry touches, as section 8d counts them; "sector": the 64-byte lines a random access moves."""
+def algorithmic_bytes(name, st, L, nd):
+    """Algorithmic bytes of every launch of a timed kernel class over the timed steps."""
     W = (2 * L + 63) // 64
     if name == "realign_windows":      # per (window, dir, dict): 8 key + 8 table word + 8 rank + 8 startpos + 4 id + 8W verify
         return (36 + 8 * W) * (2 * nd - 1) * st["windows"]
@@ -81,57 +89,66 @@ def algorithmic_bytes(name, st, L, nd, model="word"):
     if name == "realign_reads":        # per lookup one 64-B line of keys; per verified window value + offsets + packed window; per singleton row, flag, claim
         return 64 * st["ra_lookups"] + (8 + 24 + 8 * (W + 1)) * st["ra_verified"] + (8 * W + 9) * st["ra_singletons"]
     if name == "cindex_build":
-        return cindex_bytes(st, model)
+        return cindex_bytes(st)
     if name == "sketch_contigs":       # every contig base (1 byte) in, 16 B per minimizer out, one launch per call
         return (st.get("sketch_bases", 0) + 16 * st.get("sketch_records", 0)) or None
     return None                        # radix_pass / dict_build / find_next: launches of many sizes, no single byte model
 
 
-def cindex_bytes(st, model):
-    """The contig 17-mer index of Stage 2 (csrc/cindex.hip), per build: radix-partitioned, everything streams, so words and
-    sectors coincide.  Per entry (12 bytes: 4 of partition + home bits, 8 of slot): written by pass 1, read twice (histogram: the
-    4-byte half only) and written by pass 2, read by the placement (its second read comes from L2); plus the table, written once."""
+def cindex_bytes(st):
+    """The contig 17-mer index of Stage 2 (csrc/cindex.hip), model "passes": what THIS build moves by design.  Per entry (12 bytes:
+    4 of partition + home bits, 8 of slot): written by pass 1, read twice (histogram: the 4-byte half only) and written by pass 2,
+    read by the placement (its second read comes from L2); plus the table, written once."""
     return (12 + 4 + 12 + 12 + 12) * st.get("cix_entries", 0) + 8 * st.get("cix_slots", 0)
 
 
 # HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan<true>", "k_sketch_scan<false>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false>"], "classify_pack": ["k_classify_pack16"],
-               "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true>"],
-               "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
+PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan<true, true>", "k_sketch_scan<false, true>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false, false>"],
+               "classify_pack": ["k_classify_pack16"], "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true, false>"],
+               "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1<false>", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
 
-def pmc(cls, field):
-    """A PMC figure of a kernel class (summed over the kernels of the class that were counted), or None."""
+def pmc_load():
     try:
         with open(PMC_FILE) as f:
-            d = json.load(f)
-        vals = [d["kernels"][k][field] for k in PMC_KERNELS[cls] if k in d["kernels"] and field in d["kernels"][k]]
-        return sum(vals) if vals else None
-    except Exception:
+            return json.load(f)
+    except Exception:                                                          # noqa: BLE001
         return None
+
+
+def pmc(d, cls, field):
+    """A PMC figure of a kernel class (summed over the kernels of the class that were counted), or None."""
+    if not d:
+        return None
+    vals = [d["kernels"][k][field] for k in PMC_KERNELS[cls] if k in d["kernels"] and field in d["kernels"][k]]
+    return sum(vals) if vals else None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads of the job (sharded over the GPUs)")
+    ap.add_argument("--reads", type=int, default=0, help="reads of the job (sharded over the GPUs); 0 = 100 M on one GPU, 62.5 M per GPU on several")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", choices=("uniform", "repeats"), default="uniform", help="repeats: the repeat-rich device genome (forty-copy segments, tandem repeats, poly-A, (AT)n)")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the file -> stream files measurement (0 = skip)")
     ap.add_argument("--force-exchange", action="store_true", help="run the distributed pipeline (one-rank RCCL communicator) even with one GPU (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the checked run (the digest comparison between steps stays)")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling 100 M-read figure")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import minicom_amd
-    from minicom_amd.pipeline import Pipeline
+    from minicom_amd.hip import McomError
+    from minicom_amd.pipeline import Pipeline, pool_trim
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -152,88 +169,132 @@ def main():
         if world > 1:
             dist.broadcast_object_list(box, src=0)
         comm = Comm.rccl(rank, world, box[0], local_rank)
-    dev = torch.device("cuda", local_rank)
-    # One JOB of a.reads reads, sharded: the scaling series is STRONG (total work fixed).  A job is bounded by the format the
-    # reference and this implementation share -- contig ids are index << 8 in 32 bits (kthread_bucket.c:458): 2^24 contigs, about
-    # 200 M reads of this generator -- so "100 M reads per GPU" cannot exist as one job on 4 or 8 GPUs, for the reference either.
     L = a.read_len
-    n_local = a.reads // world
-    n_total = n_local * world
     threads = a.host_threads or max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
     ctx = minicom_amd.Context(local_rank)
-
-    # synthetic input, resident in HBM before any timed region: this rank's shard of one n_total-read set
-    reads = ctx.synth_reads(SEED, n_total, L, first=rank * n_local, count=n_local)
-    ctx.sync()
-
-    def make():
-        if not distributed:
-            return Pipeline(reads, L=L, device=local_rank, host_threads=threads)
-        return DistPipeline(reads, rank * n_local, n_total, comm, L=L, device=local_rank, host_threads=threads)
-
-    agg, digests = {}, []
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    STATS = ("windows", "passes", "rounds", "merge_rounds", "resketch", "n_sg0", "big_bins", "sketch_bases", "sort_records", "sketch_strings", "t_reads", "t_bucket", "t_combine",
-             "t_realign", "t_gpu", "ra_lookups", "ra_verified", "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "t_x_reads",
-             "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_pairs")
+    def agree(ok):
+        """all ranks must take the same branch"""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
-    def step(timed):
-        p = make()
-        p.prof_enable(True)
-        p.pre_process()
-        dg = p.result_digest()
-        if timed:
-            digests.append(dg)
-            for k in STATS:
-                agg[k] = agg.get(k, 0.0) + p.stat(k)
-            agg["n"] = agg.get("n", 0.0) + (n_local if distributed else p.n)
-            for name in KERNELS:
-                ms, calls = p.prof_read(name)
-                agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
-                agg["calls_" + name] = agg.get("calls_" + name, 0) + calls
-        p.close()
+    STATS = ("windows", "passes", "rounds", "merge_rounds", "claim_rounds", "resketch", "n_sg0", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
+             "sort_overflow_segments", "sketch_bases", "sort_records", "sketch_strings", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "ra_lookups", "ra_verified",
+             "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "x_cindex_entries", "contigs_bucket", "contigs_combine",
+             "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")
 
-    for _ in range(a.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def measure(n_total, seed, steps, warmup, check):
+        """K timed steps of one job of n_total reads; returns (seconds, aggregate stats, digests, reads, make)."""
+        n_local = n_total // world
+        n_total = n_local * world
+        # synthetic input, resident in HBM before any timed region: this rank's shard of one n_total-read set
+        reads = ctx.synth_reads(seed, n_total, L, first=rank * n_local, count=n_local, genome=a.genome)
+        ctx.sync()
 
-    # ---- the checked run (untimed): the result the timed steps must reproduce
-    checked = None
-    if not a.no_check:
-        from minicom_amd.check import check_result
-        p = make()
-        p.pre_process()
-        ref_digest = p.result_digest()
-        checked = check_result(p, reads, L, rid0=rank * n_local)
-        p.close()
-        for i, dg in enumerate(digests):
-            assert dg == ref_digest, f"timed step {i} gave another result than the checked run: {dg} vs {ref_digest}"
-    else:
-        ref_digest = digests[0]
-        assert all(dg == ref_digest for dg in digests), "the timed steps disagree with each other"
-    if world > 1:
-        every = [None] * world
-        dist.all_gather_object(every, ref_digest)
-        assert all(dg == every[0] for dg in every), f"the ranks hold different results: {every}"
+        def make():
+            if not distributed:
+                return Pipeline(reads, L=L, device=local_rank, host_threads=threads)
+            return DistPipeline(reads, rank * n_local, n_total, comm, L=L, device=local_rank, host_threads=threads)
+        agg, digests = {}, []
+
+        def step(timed):
+            p = make()
+            # HIP events around the hot kernel classes, on the launch stream, inside the timed steps (the contract's live kernel times):
+            # about a hundred event pairs per step out of a process-wide pool -- 0.1 % of a step
+            p.prof_enable(True)
+            p.pre_process()
+            dg = p.result_digest()
+            if timed:
+                digests.append(dg)
+                for k in STATS:
+                    agg[k] = agg.get(k, 0.0) + p.stat(k)
+                agg["n"] = agg.get("n", 0.0) + (n_local if distributed else p.n)
+                for name in KERNELS:
+                    ms, calls = p.prof_read(name)
+                    agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
+                    agg["calls_" + name] = agg.get("calls_" + name, 0) + calls
+            p.close()
+        for _ in range(warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        checked = None
+        if check:
+            from minicom_amd.check import check_result
+            p = make()
+            p.pre_process()
+            ref_digest = p.result_digest()
+            checked = check_result(p, reads, L, rid0=rank * n_local)
+            p.close()
+            for i, dg in enumerate(digests):
+                if dg != ref_digest:
+                    raise SystemExit(f"timed step {i} gave another result than the checked run: {dg} vs {ref_digest}")
+        else:
+            ref_digest = digests[0]
+            if any(dg != ref_digest for dg in digests):
+                raise SystemExit("the timed steps disagree with each other")
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, ref_digest)
+            if any(dg != every[0] for dg in every):
+                raise SystemExit(f"the ranks hold different results: {every}")
+        return dt, agg, ref_digest, checked, reads, n_total, n_local
+
+    # ---- the job: configs[1] on one GPU, configs[3]'s shape on several (62.5 M reads per GPU)
+    weak = world > 1 and a.reads == 0
+    n_job = a.reads or (READS_PER_GPU_WEAK * world if world > 1 else 100_000_000)
+    seed = 1004 if weak else SEED
+    fell_back = None
+    try:
+        ok, err = True, None
+        try:
+            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check)
+        except (McomError, RuntimeError) as e:                                  # e.g. out of memory at a size no single card could rehearse
+            ok, err = False, f"{type(e).__name__}: {e}"
+        if not agree(ok):
+            if not weak:
+                raise SystemExit(f"the job failed: {err}")
+            fell_back = f"the {n_job // 1_000_000} M-read job failed on some rank ({err}); this line is the 100 M-read job sharded over the GPUs instead"
+            pool_trim(); torch.cuda.empty_cache()
+            weak, n_job, seed = False, 100_000_000, SEED
+            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check)
+    finally:
+        pass
+
+    # ---- N > 1: the strong-scaling figure beside the weak one -- configs[1]'s 100 M-read job over the same GPUs
+    strong = None
+    if world > 1 and weak and not a.no_strong:
+        del reads
+        pool_trim(); torch.cuda.empty_cache()
+        try:
+            sdt, sagg, sdig, _, sreads, sn_total, sn_local = measure(100_000_000, SEED, max(1, a.steps // 2), 1, False)
+            strong = {"value": round(sn_total * max(1, a.steps // 2) / sdt / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(sdt / max(1, a.steps // 2) * 1e3, 2),
+                      "workload": f"{sn_total // 1_000_000}M x {L}bp (BASELINE configs[1]) as one job sharded over {world} GPUs", "digest": [str(v) for v in sdig]}
+            del sreads
+        except (McomError, RuntimeError) as e:
+            strong = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
+        reads = None
 
     # ---- host to host (one GPU): reads in page-locked host memory, uploaded in chunks beside classify / pack / sketch, and the
     # whole result copied back, all inside the timed region -- what a caller pays who hands over host buffers (never `value`)
     h2h = None
-    if world == 1 and not distributed and not a.no_host_to_host and rank == 0:
+    if world == 1 and not distributed and not a.no_host_to_host and rank == 0 and a.genome == "uniform":
         try:
             import psutil
             need = n_local * L
@@ -252,102 +313,145 @@ def main():
                     p.close()
                     return nc, dg
                 h_step()
+                hs = max(1, a.steps // 2)
                 t1 = time.perf_counter()
-                for _ in range(a.steps):
+                for _ in range(hs):
                     nc, dg = h_step()
-                    assert dg == ref_digest, "the host-to-host run gave another result"
+                    if dg != ref_digest:
+                        raise SystemExit("the host-to-host run gave another result")
                 dth = time.perf_counter() - t1
-                h2h = {"value": round(n_local * a.steps / dth / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dth / a.steps * 1e3, 2),
+                h2h = {"value": round(n_local * hs / dth / 1e6, 3), "unit": "Mreads/s", "ms_per_step": round(dth / hs * 1e3, 2),
                        "h2d_bytes": need, "d2h": "contig strings + member lists + offsets", "n_contigs": nc,
                        "note": "reads in page-locked host memory, chunked upload overlapped with classify/pack/sketch; results copied to the host inside the timed region"}
                 del host
-        except Exception as e:                                                   # never lose the bench line to the extra measurement
+        except SystemExit:
+            raise
+        except Exception as e:                                                   # noqa: BLE001  never lose the bench line to the extra measurement
             h2h = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
+
+    # ---- file -> stream files (one GPU): what the `minicom` command's user waits for, before the external entropy coder
+    e2e = None
+    if world == 1 and not distributed and rank == 0 and a.e2e_reads > 0 and a.genome == "uniform":
+        reads = None
+        pool_trim(); torch.cuda.empty_cache()
+        try:
+            from minicom_amd.e2e import file_to_streams
+            e2e = file_to_streams(a.e2e_reads, L, SEED, host_threads=threads, ref_reads=1_000_000)
+        except Exception as e:                                                   # noqa: BLE001
+            e2e = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
 
     if rank == 0:
         nd = len(minicom_amd.hip.dict_layout(L)[0])
         st = dict(agg)
-        default_workload = n_local == 100_000_000 and L == 150 and not distributed
+        P = pmc_load()
+        default_workload = n_local == 100_000_000 and L == 150 and not distributed and a.genome == "uniform"
         per_step = {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in KERNELS}
 
-        def hbm_line(cls, model="word"):
-            b = algorithmic_bytes(cls, st, L, nd, model)
+        def hbm_line(cls, model):
+            b = algorithmic_bytes(cls, st, L, nd)
             ms, calls = agg.get("ms_" + cls, 0.0), agg.get("calls_" + cls, 0)
             if not b or ms <= 0 or not calls:
                 return None
             ach = (b / calls) / (ms / calls * 1e-3) / 1e9
-            return {"kernel": cls, "bound": "hbm", "model": model, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "launches": int(calls), "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
-                    "traffic": pmc(cls, "traffic_bytes_per_launch") if default_workload else None}
+            line = {"kernel": cls, "bound": "hbm", "model": model, "achieved": round(ach, 2), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                    "launches": int(calls), "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls)}
+            # PMC traffic: raw counters, and with the guide's x2 for FETCH_SIZE on the kernels whose loads are wide coalesced streams
+            raw, cor = (pmc(P, cls, "traffic_bytes_per_launch"), pmc(P, cls, "traffic_corrected_bytes_per_launch")) if default_workload else (None, None)
+            line["traffic"] = cor if cor is not None else raw
+            line["traffic_raw"] = raw
+            line["traffic_corrected"] = cor
+            return line
 
         def issue_line(cls, waves):
-            """Integer-issue roofline of an ALU-bound kernel: VALU wave-instructions per second against 1024 SIMDs x clock / 2."""
-            v = pmc(cls, "valu_per_wave")
+            """Integer-issue roofline of an ALU-bound kernel: VALU wave-instructions per second against 1024 SIMDs x clock / 2 (an upper
+            bound of the peak: 64-bit shifts, adds and multiplies take more than one issue slot)."""
+            v = pmc(P, cls, "valu_per_wave")
             ms = agg.get("ms_" + cls, 0.0)
             if not v or ms <= 0:
                 return None
             rate = v * waves / (ms * 1e-3)
             return {"bound": "valu_issue", "valu_insts_per_wave": v, "waves": int(waves), "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK / 1e9, 1),
-                    "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK, 4), "source": "profiles/pmc_constants.json (SQ_INSTS_VALU / SQ_WAVES, PMC pass)"}
+                    "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK, 4), "source": "profiles/pmc_constants.json (SQ_INSTS_VALU / SQ_WAVES, PMC pass)",
+                    "note": "the peak counts every VALU instruction as one 2-cycle issue; 64-bit shift / add instructions take more, so the true fraction is higher"}
 
         roof = None
         for cand in sorted(KERNELS, key=lambda q: -agg.get("ms_" + q, 0.0)):      # the dominant class that has a byte model
-            roof = hbm_line(cand)
+            roof = hbm_line(cand, "passes" if cand == "cindex_build" else "word")
             if roof:
                 break
         if roof:
-            roof["traffic_source"] = "profiles/pmc_constants.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command)" if default_workload else None
+            roof["traffic_source"] = ("profiles/pmc_constants.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command; corrected = FETCH x 2 for the kernels "
+                                      "flagged as wide streaming readers, MI355X_MICROARCH.md 'HBM')") if default_workload else None
             roof["device_ms_per_step_by_kernel"] = per_step
-            if roof["kernel"] == "sketch_contigs":
-                roof["note"] = "integer-issue bound (see issue_roofline): 1 byte in and 0.07 records out per position; the HBM fraction is small by construction"
-            # the per-read sketch kernel alone (SURVEY section 8d asks for it): ALU bound, so both rooflines
-            sk = hbm_line("sketch_reads")
+            if roof["kernel"] == "cindex_build":
+                # what the build MUST touch, whatever its passes: the packed contigs in, the table out
+                minimal = (2 * st.get("cix_entries", 0) / 8 + 8 * st.get("cix_slots", 0)) / max(1, agg.get("calls_cindex_build", 1))
+                roof["algorithmic_minimal"] = {"bytes_per_launch": int(minimal), "achieved": round(minimal / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                               "frac": round(minimal / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK, 4), "what": "packed contigs read once + index table written once"}
+                roof["note"] = ("model 'passes': the bytes this radix-partitioned build moves by design (two streaming passes over 12-byte entries + one placement pass per "
+                                "partition); two launches per build since round 3 (entries, placement: the multi-GPU exchange sits between them)")
+            sk = hbm_line("sketch_reads", "word")
             if sk:
                 sk["ms_per_step"] = round(agg["ms_sketch_reads"] / a.steps, 3)
                 sk["mreads_per_s"] = round((st["n"] + st["resketch"]) / (agg["ms_sketch_reads"] * 1e-3) / 1e6, 1)
                 sk["algorithmic_bytes_per_read"] = 8 * ((2 * L + 63) // 64) + 16
                 sk["issue_roofline"] = issue_line("sketch_reads", (st["n"] + st["resketch"]) / 64)
-                sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers (48 VALU instructions per base, PMC); the HBM fraction cannot be high"
+                sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers; the HBM fraction cannot be high (SURVEY section 7)"
                 roof["sketch_kernel"] = sk
-            sc = hbm_line("sketch_contigs")
+            sc = hbm_line("sketch_contigs", "word")
             if sc:
-                # one lane per string: 64 strings per wave; the kernel is neither byte- nor issue-bound (5-6 waves per CU: latency),
-                # both fractions are given so that this can be seen
                 sc["issue_roofline"] = issue_line("sketch_contigs", st.get("sketch_strings", 0.0) / 64)
-                sc["note"] = "one lane per string, LDS rings allow 5-6 waves per CU: bound by latency (PMC: SQ_WAIT_ANY 55 % of wave cycles), neither by bytes nor by issue"
+                sc["note"] = "one lane per string, LDS rings allow 5-6 waves per CU: bound by latency, neither by bytes nor by issue"
                 if roof["kernel"] != "sketch_contigs":
                     roof["sketch_contigs"] = sc
                 else:
                     roof["issue_roofline"] = sc["issue_roofline"]
-            # the heaviest kernel that IS bound by HBM, both byte models
             if roof["kernel"] != "cindex_build":
-                hb = hbm_line("cindex_build")
+                hb = hbm_line("cindex_build", "passes")
                 if hb:
-                    hb["note"] = "radix-partitioned build (two streaming passes + one placement pass per partition): word and sector models coincide"
                     roof["hbm_bound_kernel"] = hb
+        whole = None
+        if P and default_workload and "_whole_step" in P:
+            w = P["_whole_step"]
+            ms = dt / a.steps * 1e3
+            whole = {"traffic_GB": round(w["traffic_corrected_bytes"] / 1e9, 1), "traffic_raw_GB": round(w["traffic_raw_bytes"] / 1e9, 1),
+                     "hbm_frac": round(w["traffic_corrected_bytes"] / 1e9 / (ms * 1e-3) / HBM_PEAK, 4), "launches": w.get("launches"),
+                     "source": "profiles/pmc_constants.json: FETCH_SIZE + WRITE_SIZE summed over every kernel of one step (PMC passes of this command), over this run's ms_per_step"}
+        ppp = a.steps
         res = {
             "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",
             "value": round(n_total * a.steps / dt / 1e6, 4), "unit": "Mreads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{n_total // 1_000_000}M x {L}bp synthetic reads, k=31 default params (BASELINE configs[1]), one job"
-                                   + (f" sharded over {world} GPUs ({n_local // 1_000_000}M reads each)" if world > 1 else "") + "; full Stage 1 + Stage 2 per step",
-                       "reads_total": n_total, "reads_per_gpu": n_local, "read_len": L, "k": 31,
-                       "parallelism": "1 GPU" if not distributed else f"{world} GPU(s): reads sharded, per-round minimizer-record exchange to bucket owners + all-gathers over RCCL "
-                                                                     "send/recv groups, result replicated and identical to the single-GPU result",
-                       "host_threads": threads,
-                       "per_step": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("rounds", "merge_rounds", "passes", "windows", "resketch", "n_sg0", "big_bins", "x_records")},
-                       "stage_ms_rank0": {q: round(agg.get(q, 0.0) / a.steps, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
-                                                                                           "t_x_contigs", "t_x_sketch", "t_x_pairs")},
+            "config": {"workload": (f"{n_total // 1_000_000}M x {L}bp synthetic reads, k=31 default params, "
+                                    + ("BASELINE configs[1], one GPU" if world == 1 else
+                                       (f"BASELINE configs[3]'s shape: one job of {READS_PER_GPU_WEAK / 1e6:g} M reads per GPU" if weak else "BASELINE configs[1] as one job") + f" sharded over {world} GPUs")
+                                    + ("" if a.genome == "uniform" else "; REPEAT-RICH genome (forty-copy 2 kb segments, tandem repeats, poly-A, (AT)n)") + "; full Stage 1 + Stage 2 per step"),
+                       "genome": a.genome, "reads_total": n_total, "reads_per_gpu": n_local, "read_len": L, "k": 31,
+                       "parallelism": "1 GPU" if not distributed else f"{world} GPU(s): reads sharded; per bucket round minimizer records to bucket owners; merge-round index by bucket range, merges by "
+                                                                     "claimed-pair range, Stage-2 index shared out by key -- all over RCCL send/recv groups; result replicated, identical to the "
+                                                                     "single-GPU result",
+                       "scaling_note": ("reads per GPU: 100 M at N = 1 (configs[1]), 62.5 M at N > 1 (configs[3] = 500 M at N = 8); value_strong_100m = configs[1]'s job over the same GPUs. "
+                                        "No multi-GPU node was available to this build: the N > 1 path is exact (tests), its scaling unmeasured (profiles/r03_dist_work.json: per-rank work on one card)"),
+                       "fell_back": fell_back, "host_threads": threads,
+                       "per_step": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("rounds", "merge_rounds", "claim_rounds", "passes", "windows", "resketch", "n_sg0", "contigs_bucket",
+                                                                                  "contigs_combine", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
+                                                                                  "sort_overflow_segments", "x_records", "x_cindex_entries")},
+                       "stage_ms_rank0": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
+                                                                                        "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")},
+                       "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step)",
                        "results": "contig set (strings + member lists) complete in HBM at the end of a step, its digest read back inside the step; host copy on demand"},
             "result": {"digest": [str(v) for v in ref_digest], "digest_fields": "contigs, chars, members, unclustered, strings, member words, offsets, lists",
                        "every_timed_step_equal": True, "checked_run": checked},
             "value_host_to_host": h2h,
+            "value_file_to_streams": e2e,
+            "value_strong_100m": strong,
+            "whole_step": whole,
             "roofline": roof,
         }
         if comm is not None:
             sent, calls = comm.stats()
-            res["config"]["rccl_bytes_sent_rank0_per_step"] = int(sent / (a.steps + a.warmup + (0 if a.no_check else 1)))
+            res["config"]["rccl_bytes_sent_rank0_total"] = int(sent)
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(L, a.cpu_sample)
         elif not a.no_cpu_baseline:

@@ -518,6 +518,11 @@ int mcom_digest(mcom_ctx *ctx, const void *d_data, size_t bytes, uint64_t *h_sum
 /* ---- synthetic input (bench / tests): same generator as minicom_amd/synth.py ------------------ */
 int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                      uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);
+/* genome_kind 0: the uniform genome of mcom_synth_reads; 1: a repeat-rich genome (blocks of 25 kb: a 2 kb segment out of families of
+ * forty copies in every block, tandem repeats, poly-A and (AT)n stretches -- csrc/reads.hip), the hard case for buckets, index runs
+ * and Stage-2 bins.  Device generator only (bench.py --genome repeats; no host twin).                                          */
+int mcom_synth_reads_genome(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate, int genome_kind,
+                            uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,17 @@ extern "C" const char *mcom_last_error(const mcom_ctx *ctx) { return ctx ? ctx->
 static const char *PROF_NAMES[PROF_COUNT] = { "classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next",
                                               "dict_build", "realign_windows", "consensus", "cindex_build", "realign_reads" };
 
+static std::mutex g_ev_mu;
+static std::vector<hipEvent_t> g_ev_free;
+hipEvent_t mcom_prof_event_get()
+{
+	{ std::lock_guard<std::mutex> g(g_ev_mu); if (!g_ev_free.empty()) { hipEvent_t e = g_ev_free.back(); g_ev_free.pop_back(); return e; } }
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return e;
+}
+void mcom_prof_event_put(hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(g_ev_mu); g_ev_free.push_back(e); } }
+
 static void prof_collect(mcom_ctx *ctx)
 {
 	if (ctx->prof_open.empty()) return;
@@ -187,7 +198,7 @@ static void prof_collect(mcom_ctx *ctx)
 	for (McomProfSpan &s : ctx->prof_open) {
 		float ms = 0;
 		if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { ctx->prof_ms[s.id] += ms; ctx->prof_calls[s.id] += 1; }
-		(void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
+		mcom_prof_event_put(s.a); mcom_prof_event_put(s.b);
 	}
 	ctx->prof_open.clear();
 }

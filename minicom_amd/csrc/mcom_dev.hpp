@@ -42,14 +42,17 @@ struct mcom_ctx {
 	std::vector<PinWait> pin_wait;
 };
 
+// events of the profiler come from a process-wide free list (creating and destroying a pair per launch cost more than recording them)
+hipEvent_t mcom_prof_event_get();
+void mcom_prof_event_put(hipEvent_t e);
 // brackets one kernel launch (or a short launch sequence) with events when the profiler is on
 struct McomProfScope {
 	mcom_ctx *ctx; int idx;
 	McomProfScope(mcom_ctx *c, int id) : ctx(c), idx(-1) {
 		if (!c->prof_on) return;
 		McomProfSpan s; s.id = id;
-		if (hipEventCreate(&s.a) != hipSuccess) return;
-		if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
+		if (!(s.a = mcom_prof_event_get())) return;
+		if (!(s.b = mcom_prof_event_get())) { mcom_prof_event_put(s.a); return; }
 		(void)hipEventRecord(s.a, c->stream);
 		c->prof_open.push_back(s); idx = (int)c->prof_open.size() - 1;
 	}

@@ -315,8 +315,33 @@ __device__ __forceinline__ uint64_t sm64(uint64_t z)
 	return z ^ (z >> 31);
 }
 
+// The repeat-rich genome (kind 1): blocks of 25 kb.  The first 2 kb of every block is a copy of one of n_blocks / 40 family
+// sequences (forty copies each, a copy carrying up to five substitutions of its own); one block in 200 holds a tandem repeat of a
+// 37-base unit (60 times), one in 400 a poly-A stretch of 400 bases, one in 400 an (AT)150 stretch; everything else is the uniform
+// genome.  What a uniform genome never produces: minimizer groups of a thousand reads, long runs of equal minimizers in the contig
+// index, 17-mers with forty copies in the Stage-2 index (heavy home lines), long Stage-2 bins.
+#define SYN_BLOCK 25000ull
+__device__ __forceinline__ unsigned synth_base(uint64_t b0, uint64_t g, int kind, uint64_t n_blocks)
+{
+	if (kind == 1) {
+		const uint64_t blk = g / SYN_BLOCK, off = g - blk * SYN_BLOCK;
+		if (off < 2000) {
+			const uint64_t fams = n_blocks / 40 ? n_blocks / 40 : 1, fam = blk % fams;
+			unsigned b = (unsigned)(sm64(b0 ^ 0x5eedfa11ull ^ (fam * 2000 + off)) & 3);
+			const uint64_t m = sm64(b0 + 77 + blk) % 6;                              // this copy's substitutions
+			const uint64_t h = sm64(b0 + 99 + g);
+			if ((h % 2000) < m) b = (b + 1 + (unsigned)((h >> 20) % 3)) & 3;
+			return b;
+		}
+		if (blk % 200 == 7 && off >= 5000 && off < 5000 + 37 * 60) return (unsigned)(sm64(b0 + 1234 + blk * 64 + (off - 5000) % 37) & 3);
+		if (blk % 400 == 11 && off >= 9000 && off < 9400) return 0u;                 // A
+		if (blk % 400 == 13 && off >= 12000 && off < 12300) return (off & 1) ? 3u : 0u;   // (AT)n
+	}
+	return (unsigned)(sm64(b0 + g) & 3);
+}
+
 __global__ void k_synth_reads(uint64_t seed, uint64_t G, int L, uint64_t thr, uint64_t first, uint64_t count,
-                              uint8_t *__restrict__ out, size_t pitch)
+                              uint8_t *__restrict__ out, size_t pitch, int kind)
 {
 	const uint64_t b0 = sm64(seed + 0), b1 = sm64(seed + 1), b2 = sm64(seed + 2), b3 = sm64(seed + 3);
 	const uint64_t total = count * (uint64_t)L;
@@ -326,7 +351,7 @@ __global__ void k_synth_reads(uint64_t seed, uint64_t G, int L, uint64_t thr, ui
 		const uint64_t start = sm64(b1 + r) % (G - (uint64_t)L + 1);
 		const int strand = (int)(sm64(b2 + r) & 1);
 		const int i = strand ? L - 1 - o : o;                                              // forward coordinate
-		unsigned b = (unsigned)(sm64(b0 + start + (uint64_t)i) & 3);
+		unsigned b = synth_base(b0, start + (uint64_t)i, kind, G / SYN_BLOCK);
 		const uint64_t u = sm64(b3 + r * (uint64_t)L + (uint64_t)i);
 		if ((u & 0xFFFFFF) < thr) b = (b + 1 + (unsigned)((u >> 24) % 3)) & 3;
 		out[q * pitch + o] = "ACGT"[strand ? 3 - b : b];
@@ -413,8 +438,13 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 extern "C" int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                                 uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch)
 {
+	return mcom_synth_reads_genome(ctx, seed, n_reads, L, coverage, sub_rate, 0, first, count, d_ascii, pitch);
+}
+extern "C" int mcom_synth_reads_genome(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate, int genome_kind,
+                                       uint64_t first, uint64_t count, uint8_t *d_ascii, size_t pitch)
+{
 	if (!ctx) return MCOM_E_ARG;
-	if (L < 1 || L > 256 || coverage < 1 || pitch < (size_t)L) return mcom_fail(ctx, MCOM_E_ARG, "bad synth arguments");
+	if (L < 1 || L > 256 || coverage < 1 || pitch < (size_t)L || genome_kind < 0 || genome_kind > 1) return mcom_fail(ctx, MCOM_E_ARG, "bad synth arguments");
 	if (count == 0) return MCOM_OK;
 	if (!d_ascii) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	uint64_t G = n_reads * (uint64_t)L / (uint64_t)coverage;
@@ -423,7 +453,7 @@ extern "C" int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, 
 	uint64_t blocks = (count * (uint64_t)L + 255) / 256;
 	const uint64_t cap = (uint64_t)ctx->n_cu * 32;
 	if (blocks > cap) blocks = cap;
-	hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, G, L, thr, first, count, d_ascii, pitch);
+	hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, G, L, thr, first, count, d_ascii, pitch, genome_kind);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

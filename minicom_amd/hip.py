@@ -118,6 +118,8 @@ def load_library():
     L.mcom_claim_pairs.argtypes = [vp, vp, sz, sz, i32, vp, vp, C.POINTER(u64), C.POINTER(i32)]
     L.mcom_synth_reads.restype = i32
     L.mcom_synth_reads.argtypes = [vp, u64, u64, i32, i32, C.c_double, u64, u64, vp, sz]
+    L.mcom_synth_reads_genome.restype = i32
+    L.mcom_synth_reads_genome.argtypes = [vp, u64, u64, i32, i32, C.c_double, i32, u64, u64, vp, sz]
     _lib = L
     return L
 
@@ -565,13 +567,14 @@ class Context:
         return ac[:nw.value], am[:nw.value]
 
     def synth_reads(self, seed: int, n_reads: int, L: int, coverage: int = 30, sub_rate: float = 0.005,
-                    first: int = 0, count: int | None = None, pitch: int | None = None):
+                    first: int = 0, count: int | None = None, pitch: int | None = None, genome: str = "uniform"):
+        """mcom_synth_reads_genome; genome: "uniform" or "repeats" (device generator only)."""
         torch = _torch()
         if count is None:
             count = n_reads - first
         pitch = pitch or L
         out = torch.empty((count, pitch), dtype=torch.uint8, device=self.device)
-        self._check(self.lib.mcom_synth_reads(self._h, seed, n_reads, L, coverage, sub_rate, first, count, self._p(out), pitch))
+        self._check(self.lib.mcom_synth_reads_genome(self._h, seed, n_reads, L, coverage, sub_rate, {"uniform": 0, "repeats": 1}[genome], first, count, self._p(out), pitch))
         return out
 
 

@@ -77,6 +77,41 @@ public:
 	void swap(PinVec &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
 };
 
+// Large host arrays that every pipeline makes anew (the singleton list and its flags: 4 + 1 bytes per unclustered read) come from a
+// process-wide pool of malloc'ed blocks too: a fresh 64 MB vector costs its page faults when it is first written and the unmapping
+// of its pages when it is freed -- 8 ms per step at 100 M reads, most of it in the pipeline's destructor.
+class HostPool {
+	std::mutex mu;
+	std::multimap<size_t, void*> free_;
+public:
+	void *get(size_t bytes) {                                              // the block carries its capacity in the 64 bytes before it
+		const size_t unit = (size_t)1 << 20, cap = ((bytes + bytes / 8 + unit - 1) / unit) * unit;
+		{
+			std::lock_guard<std::mutex> g(mu);
+			auto it = free_.lower_bound(cap);
+			if (it != free_.end() && it->first <= 2 * cap + unit) { void *p = it->second; free_.erase(it); return p; }
+		}
+		char *raw = (char*)malloc(cap + 64);
+		if (!raw) throw std::bad_alloc();
+		*(size_t*)raw = cap;
+		return raw + 64;
+	}
+	void put(void *p) { if (!p) return; const size_t cap = *(size_t*)((char*)p - 64); std::lock_guard<std::mutex> g(mu); free_.emplace(cap, p); }
+};
+HostPool &host_pool() { static HostPool *pool = new HostPool(); return *pool; }
+template <class T> struct PoolAlloc {
+	using value_type = T;
+	PoolAlloc() = default;
+	template <class U> PoolAlloc(const PoolAlloc<U>&) {}
+	static constexpr size_t SMALL = (size_t)1 << 20;
+	T *allocate(size_t n) { const size_t b = n * sizeof(T); if (b < SMALL) { void *q = malloc(b ? b : 1); if (!q) throw std::bad_alloc(); return (T*)q; } return (T*)host_pool().get(b); }
+	void deallocate(T *q, size_t n) { if (n * sizeof(T) < SMALL) free(q); else host_pool().put(q); }
+	template <class U> bool operator==(const PoolAlloc<U>&) const { return true; }
+	template <class U> bool operator!=(const PoolAlloc<U>&) const { return false; }
+};
+using U32Pooled = std::vector<uint32_t, PoolAlloc<uint32_t>>;
+using U8Pooled = std::vector<uint8_t, PoolAlloc<uint8_t>>;
+
 // all contigs of one stage: members (rid<<32 | offset<<1 | dir, breads.h:49-58) and consensus strings, flat
 struct ContigSet {
 	PinVec<uint64_t> mem; std::vector<uint64_t> moff{0};
@@ -208,8 +243,9 @@ struct mcomh_pipeline {
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
 	PinVec<uint8_t> h_cls;
-	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile, sg;
-	std::vector<uint8_t> sg_flag;
+	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile;
+	U32Pooled sg;
+	U8Pooled sg_flag;
 	// the flags of the last Stage-2 pass as they came from the device (0 live, 1 / 2 near-poly, 3 claimed); sg_flag (1 = gone) is
 	// made from them only when somebody looks (ensure_sg_flag): a pass does not wait for a 16 M-entry host loop
 	PinVec<uint8_t> raw_flags; bool raw_flags_valid = false;
@@ -236,7 +272,7 @@ struct mcomh_pipeline {
 	// updateSingle (preprocess.c:243-255) happens on the device at the end of a pass: the next pass finds its singleton ids
 	// in d_sg_live, the host its compacted list in sg_next
 	DevBuf<uint32_t> d_sg_live; size_t n_sg_live = 0; bool sg_live_valid = false;
-	std::vector<uint32_t> sg_next; bool sg_next_valid = false;
+	U32Pooled sg_next; bool sg_next_valid = false;
 	// the singleton list of the bucket stage is put together by a host thread beside combine_cluster's GPU work
 	std::thread sg_thread, cls_thread;       // (and the class lists of kt_for_reads beside the bucket stage)
 	hipEvent_t ev_cls = nullptr; bool cls_failed = false;
@@ -1279,7 +1315,7 @@ extern "C" int mcomh_update_single(mcomh_pipeline *p)
 	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { size_t c = 0; for (size_t q = head + b; q < head + e; ++q) c += !f[q]; cnt[(size_t)t + 1] = c; });
 	for (int t = 0; t < nt; ++t) cnt[(size_t)t + 1] += cnt[(size_t)t];
 	const size_t nn = head + cnt[(size_t)nt];
-	std::vector<uint32_t> out(nn);
+	U32Pooled out(nn);
 	memcpy(out.data(), p->sg.data(), head * 4);
 	const uint32_t *src = p->sg.data();
 	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { uint32_t *dst = out.data() + head + cnt[(size_t)t]; for (size_t q = head + b; q < head + e; ++q) if (!f[q]) *dst++ = src[q]; });
@@ -1698,7 +1734,7 @@ extern "C" int mcomh_pre_process(mcomh_pipeline *p)
 }
 
 // ---- dump in the text format of oracle/refdump.cpp ---------------------------------------------------
-static void dump_list(FILE *f, const char *name, const std::vector<uint32_t> &v)
+template <class V> static void dump_list(FILE *f, const char *name, const V &v)
 {
 	fprintf(f, "LIST %s %zu", name, v.size());
 	for (uint32_t x : v) fprintf(f, " %u", x);
@@ -1847,7 +1883,8 @@ extern "C" const uint32_t *mcomh_list(const mcomh_pipeline *p, const char *name,
 	const std::vector<uint32_t> *v = nullptr;
 	if (!strcmp(name, "allA")) v = &p->allA; else if (!strcmp(name, "allT")) v = &p->allT; else if (!strcmp(name, "allN")) v = &p->allN;
 	else if (!strcmp(name, "fpA")) v = &p->fpA; else if (!strcmp(name, "fpT")) v = &p->fpT; else if (!strcmp(name, "fpN")) v = &p->fpN;
-	else if (!strcmp(name, "Nfile")) v = &p->Nfile; else if (!strcmp(name, "sg")) v = &p->sg;
+	else if (!strcmp(name, "Nfile")) v = &p->Nfile;
+	else if (!strcmp(name, "sg")) { if (n) *n = p->sg.size(); return p->sg.data(); }
 	if (!v) { if (n) *n = 0; return nullptr; }
 	if (n) *n = v->size();
 	return v->data();
@@ -1921,6 +1958,7 @@ extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 	if (!strcmp(name, "rw")) return p->rw;
 	if (!strcmp(name, "maxsearch")) return p->maxsearch;
 	if (!strcmp(name, "sketch_strings")) return (double)mcom_counter(p->ctx, "sketch_strings");
+	if (!strcmp(name, "sort_overflow_segments")) return (double)mcom_counter(p->ctx, "sort_overflow_segments");
 	auto it = p->stat.find(name);
 	return it == p->stat.end() ? 0.0 : it->second;
 }
