@@ -187,7 +187,7 @@ def test_pipeline_equals_the_sequential_oracle_on_2m_reads_of_150_bases():
     reads = synth.synth_reads(5151, n, L, plumbing=True)
     o = _oracle_with_heartbeat(reads, "2 M x 150")
     p = Pipeline(reads, host_threads=8, overlap_screen=1); p.pre_process()
-    assert len(o.contigs()) > 50_000 and p.stat("merge_rounds") >= 4 and p.stat("passes") >= 2
+    assert len(o.contigs()) > 30_000 and p.stat("merge_rounds") >= 4 and p.stat("passes") >= 2
     _assert_equal_sets(o, p)
     assert p.stat("early_screen") >= 1                              # (the variant with the first pass's singleton gather + screen beside the index build)
     d_overlap = p.result_digest()
