@@ -10,6 +10,7 @@
 #include "../../include/mcom_host.h"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cinttypes>
 #include <cstdarg>
@@ -275,7 +276,7 @@ struct mcomh_pipeline {
 	U32Pooled sg_next; bool sg_next_valid = false;
 	// the singleton list of the bucket stage is put together by a host thread beside combine_cluster's GPU work
 	std::thread sg_thread, cls_thread;       // (and the class lists of kt_for_reads beside the bucket stage)
-	hipEvent_t ev_cls = nullptr; bool cls_failed = false;
+	hipEvent_t ev_cls = nullptr; std::atomic<bool> cls_failed{false};        // (written by the class-list thread)
 	void join_cls() { if (cls_thread.joinable()) cls_thread.join(); }
 	void join_sg() { join_cls(); if (sg_thread.joinable()) sg_thread.join(); }
 	// contigs of the current stage on the device
@@ -411,14 +412,14 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->overlap_screen = pp->overlap_screen == 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
-	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcom_destroy(p->ctx); delete p; return MCOM_E_ARG; }
+	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcomh_destroy(p); return MCOM_E_ARG; }
 	if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&p->ev_sg, hipEventDisableTiming) != hipSuccess) { mcom_destroy(p->ctx); delete p; return MCOM_E_HIP; }
+	    hipEventCreateWithFlags(&p->ev_sg, hipEventDisableTiming) != hipSuccess) { mcomh_destroy(p); return MCOM_E_HIP; }   // (every failure exit releases what exists)
 	if (host_reads) {
 		p->pitch = (size_t)L;
 		p->h_ascii.assign(host_reads, host_reads + n * (size_t)L);
-		if (!p->d_ascii_own.reserve(n * (size_t)L + 16)) { mcom_destroy(p->ctx); delete p; return MCOM_E_NOMEM; }
-		if (n && hipMemcpyAsync(p->d_ascii_own.p, host_reads, n * (size_t)L, hipMemcpyHostToDevice, p->stream) != hipSuccess) { mcom_destroy(p->ctx); delete p; return MCOM_E_HIP; }
+		if (!p->d_ascii_own.reserve(n * (size_t)L + 16)) { mcomh_destroy(p); return MCOM_E_NOMEM; }
+		if (n && hipMemcpyAsync(p->d_ascii_own.p, host_reads, n * (size_t)L, hipMemcpyHostToDevice, p->stream) != hipSuccess) { mcomh_destroy(p); return MCOM_E_HIP; }
 		p->d_ascii = p->d_ascii_own.p;
 	} else { p->d_ascii = d_reads; p->pitch = pitch; }
 	*out = p;
@@ -1556,7 +1557,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 			p->cix_c0 = c0; p->cix_c1 = c1;
 			uint64_t ne = 0, share = 0, nwords = 0, cap_mine = 0;
 			if (mcom_cindex_plan_shared(p->n_windows, (uint32_t)nc, p->L, p->numdict, R, me, &ne, &share, &p->cix_geom, &nwords) ||
-			    mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &cap_mine, nullptr, nullptr)) return p->fail(MCOM_E_ARG, "contig index: too many positions");
+			    mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &cap_mine, nullptr, nullptr)) return p->fail(MCOM_E_ARG, "contig index: %llu windows are more than one share of %d holds (2^32 positions, or 65 535 partitions of 12 000 lines = 2.75 G entries)", (unsigned long long)p->n_windows, R);
 			DevBuf<uint32_t> keyA, keyB; DevBuf<uint64_t> slotA, slotB;
 			std::vector<uint64_t> cnt((size_t)R, 0);
 			for (int attempt = 0;; ++attempt) {                                 // a repeat-rich set may need a larger extension area for its heavy keys

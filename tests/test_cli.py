@@ -103,7 +103,7 @@ def test_minicom_script_writes_the_reference_streams_and_reads_them_back(golden_
     if mode == "pe":
         _write_fastq(tmp_path / "s_1.fastq", rows[:half]); _write_fastq(tmp_path / "s_2.fastq", rows[half:2 * half])
         out = _run(["bash", os.path.join(BIN, "minicom"), "-1", "s_1.fastq", "-2", "s_2.fastq", "-t", "4"], tmp_path)
-        arch = tmp_path / ("s_1" + suffix + ".minicom")
+        arch = tmp_path / ("s" + suffix + ".minicom")               # file_1.fastq -> file_comp_pe.minicom, as the reference (minicom:179)
     else:
         _write_fastq(tmp_path / "s.fastq", rows)
         out = _run(["bash", os.path.join(BIN, "minicom"), "-r", "s.fastq", "-t", "4"] + (["-p"] if mode == "p" else []), tmp_path)
