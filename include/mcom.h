@@ -86,9 +86,13 @@ int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
 /* Likewise for the merge consensus: a unit of 32 columns that more than `members` members reach sends its tile to the
  * wave-per-tile kernel (0 = default, the 127 the bit-sliced counters hold).  Same consensus either way.              */
 int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
-/* mcom_sketch_contigs has two kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) and one
- * wave per string; wave_per_string != 0 forces the second.  Same sketch either way.                                    */
+/* mcom_sketch_contigs has three kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) with a ring of
+ * 32-bit hash prefixes (k odd: ties are settled by recomputing the hashes from the string) or of 64-bit hashes, and one wave per
+ * string; wave_per_string = 1 forces the last, 2 the 64-bit ring, 0 = the default choice.  Same sketch every way.
+ * mcom_set_sketch_prefix_bits (1..30; default 14: prefixes of up to 14 bits live in 16-bit ring words, wider ones in 32-bit words)
+ * sets the prefix width of the first: a few bits make ties the rule (tests); wave_per_string = 3 keeps 32-bit words at any width.    */
 int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
+int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
 
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:

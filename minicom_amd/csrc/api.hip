@@ -254,7 +254,15 @@ extern "C" int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members)
 extern "C" int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string)
 {
 	if (!ctx) return MCOM_E_ARG;
-	ctx->sketch_wave_only = wave_per_string != 0;
+	ctx->sketch_wave_only = wave_per_string == 1;
+	ctx->sketch_ring64 = wave_per_string == 2;
+	ctx->sketch_ring32_only = wave_per_string == 3;
+	return MCOM_OK;
+}
+extern "C" int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits)
+{
+	if (!ctx || bits < 1 || bits > 30) return MCOM_E_ARG;
+	ctx->sketch_prefix_bits = bits;
 	return MCOM_OK;
 }
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)

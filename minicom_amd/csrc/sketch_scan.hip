@@ -258,10 +258,274 @@ __global__ __launch_bounds__(64) void k_sketch_scan(const uint8_t *__restrict__ 
 	if (have) cnt[t] = ne;
 }
 
+// ---- the same scan with a ring of 32-bit hash PREFIXES (k odd) ---------------------------------------------------------------
+// The ring of 8-byte hashes is what fills the LDS: w x 64 x 8 bytes per wave, six waves per CU, 1.5 per SIMD -- and a wave that
+// is nearly alone on its SIMD pays every latency in full (PMC: 35 % of its cycles waiting, VALU pipe a quarter busy).  What the
+// scan does with a ring entry is compare it: with the minimum of the lap, with another entry when the suffix minima are made,
+// with the minimum when equal k-mers are looked for.  The top PB bits of the hash (and the strand bit) decide nearly every
+// comparison; when two prefixes are equal the hashes are RECOMPUTED from the strings (the position of a ring entry follows from
+// its slot, the k characters ending there give the k-mer: hash64 is a bijection, equal hashes are equal k-mers), so every
+// decision is the one the 64-bit ring makes.  Ties are one comparison in 2^30 between different k-mers, and every comparison
+// between equal ones (repeats inside a window: rare, and costing a hundred instructions each).  The minimum itself is kept as
+// (prefix, position) too, so what is emitted is the position: the hash of an emitted record is made afterwards from the string
+// (in k_ssc_gather) -- 0.07 records per position.  Default: 14-bit prefixes in 16-bit words, a quarter of the LDS (19 waves per CU
+// by LDS, 6 per SIMD by registers); measured on 8 M strings of 200: 64-bit ring 11.8 ms, 30-bit prefixes 9.3, 14-bit 8.0, 12-bit 9.4.
+// RT: the ring word, uint32_t (prefixes of up to 30 bits) or uint16_t (up to 14: a tie every 16 384 comparisons, still next to nothing,
+// for a ring of a quarter of the 64-bit one's size)
+template <bool WIDE, class RT>
+__global__ __launch_bounds__(64) void k_sketch_scan32(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end,
+                                                      const uint32_t *__restrict__ ids, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                      int w, int k, uint32_t limit, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
+                                                      int room_is_count, mcom_mm128 *__restrict__ dst, uint32_t *__restrict__ cnt, int pb)
+{
+	extern __shared__ __align__(8) unsigned char ssc_lds[];
+	RT *RP = (RT*)ssc_lds;                                                 // [w][64]: prefix << 1 | strand, all ones when empty
+	constexpr uint32_t EW = (uint32_t)(RT)~(RT)0, SSC_EMPTY32 = EW >> 1;     // the empty ring word and its key (above every prefix)
+	uint8_t *SM = (uint8_t*)(RP + (size_t)w * 64);                         // [w][64]: newest smallest slot of the last lap's slots j..w-1; bit 7: its hash occurs again there
+	const int lane = threadIdx.x;
+	const uint32_t li = blockIdx.x * 64u + (uint32_t)lane;
+	const bool have = li < nlist;
+	const uint32_t t = have ? (list ? list[li] : li) : 0u;
+	const uint32_t len = have ? ssc_len(off, off_end, t) : 0u;
+	const uint8_t *s = seq + (have ? off[t] : 0);
+	const uint64_t idhi = (uint64_t)(ids ? (have ? ids[t] : 0u) : (uint32_t)t) << 32;
+	const uint32_t mybase = have ? base[t] : 0u;
+	const uint32_t myroom = have ? (room_is_count ? cnt[t] : room[t]) : 0u;
+	uint32_t maxlen = len;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxlen, d, 64); maxlen = o > maxlen ? o : maxlen; }
+	for (int j = 0; j < w; ++j) { RP[j * 64 + lane] = (RT)EW; SM[j * 64 + lane] = (uint8_t)((w - 1) | 0x80); }
+	const uint64_t mask = (1ull << (2 * k)) - 1;
+	const int shift1 = 2 * (k - 1);
+	const int psh = 2 * k > pb ? 2 * k - pb : 0;                           // the prefix: the top pb bits of the 2k-bit hash
+	uint64_t fwd = 0, rev = 0;
+	int run = 0, slot = 0, best_slot = 0;
+	uint32_t best_p = SSC_EMPTY32, best_y = 0xFFFFFFFFu;
+	uint32_t lap_p = SSC_EMPTY32; int lap_slot = 0; bool lap_dup = false; uint32_t lap_y = 0xFFFFFFFFu;
+	uint32_t ne = 0, step = 0;
+	// the hash of the k-mer that ends at position pos (all of its k characters are bases: only such entries are real)
+	auto full_at = [&](uint32_t pos) -> uint64_t {
+		uint64_t f = 0, r = 0;
+		for (int q = k - 1; q >= 0; --q) {
+			const uint32_t ch = s[pos - (uint32_t)q];
+			const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;
+			f = (f << 2 | c) & mask; r = (r >> 2) | ((3ull ^ c) << shift1);
+		}
+		const uint64_t canon = f < r ? f : r;
+		return WIDE ? mcom_hash64_wide(canon, (uint32_t)(mask >> 32)) : mcom_hash64(canon, mask);
+	};
+	// position of the entry in slot j, seen at a storing step whose entry went into slot `cur`
+	auto pos_of = [&](int j, int cur) -> uint32_t { const int age = cur - j < 0 ? cur - j + w : cur - j; return step - (uint32_t)age; };
+	// exact order of two entries given as (prefix, pos<<1|strand): -1 / 0 / +1 as the first hash is smaller / equal / larger
+	auto cmp_entries = [&](uint32_t pa, uint32_t ya, uint32_t pb_, uint32_t yb) -> int {
+		if (pa != pb_) return pa < pb_ ? -1 : 1;
+		if (pa == SSC_EMPTY32) return 0;
+		const uint64_t xa = full_at(ya >> 1), xb = full_at(yb >> 1);
+		return xa < xb ? -1 : (xa == xb ? 0 : 1);
+	};
+	auto put_y = [&](uint32_t y) {
+		if (ne < limit) {
+			if (ne < myroom) { mcom_mm128 v; v.x = y == 0xFFFFFFFFu ? U64MAX : 0ull; v.y = y == 0xFFFFFFFFu ? U64MAX : (idhi | y); dst[(size_t)mybase + ne] = v; }
+			++ne;
+		}
+	};
+	auto put_if = [&](bool cond, uint32_t y) {
+		const bool counted = cond && ne < limit;
+		if (counted && ne < myroom) { mcom_mm128 v; v.x = y == 0xFFFFFFFFu ? U64MAX : 0ull; v.y = y == 0xFFFFFFFFu ? U64MAX : (idhi | y); dst[(size_t)mybase + ne] = v; }
+		ne += counted ? 1u : 0u;
+	};
+	// every other entry of the ring, oldest first, that has the minimum's hash but is not the minimum itself (sketch.c:140-143, :156-160);
+	// cur: the slot of the newest entry
+	auto put_equals = [&](bool with_current) {
+		if (best_p == SSC_EMPTY32) return;                                   // (empty entries carry y = all ones, as the minimum then does: never put)
+		const uint64_t bx = full_at(best_y >> 1);
+		auto one = [&](int j) {
+			const uint32_t e = RP[j * 64 + lane];
+			if ((e >> 1) != best_p || e == EW) return;
+			const uint32_t y = (pos_of(j, slot) << 1) | (e & 1u);
+			if (y != best_y && full_at(y >> 1) == bx) put_y(y);
+		};
+		for (int j = slot + 1; j < w; ++j) one(j);
+		const int e = with_current ? slot + 1 : slot;
+		for (int j = 0; j < e; ++j) one(j);
+	};
+	const bool tiny = len < 8;
+	auto issue8 = [&](uint32_t p, uint32_t &sh) -> uint64_t {
+		const uint32_t a = tiny ? 0u : (p + 8 <= len ? p : len - 8);
+		const uint8_t *src = tiny ? (const uint8_t*)off : s + a;
+		uint64_t v; __builtin_memcpy(&v, src, 8);
+		sh = tiny ? 64u : 8 * (p - a);
+		return v;
+	};
+	uint64_t chunk = 0;
+	uint32_t ahead_sh = 0;
+	uint64_t ahead = issue8(0, ahead_sh);
+	uint64_t first8 = 0;
+	if (tiny) for (uint32_t q = 0; q < len; ++q) first8 |= (uint64_t)s[q] << (8 * q);
+	auto scan_step = [&](const uint32_t i, auto level_tag) {
+		constexpr int LV = decltype(level_tag)::value;
+		const uint32_t ch = (uint32_t)chunk & 0xFFu; chunk >>= 8;
+		step = i;
+		const uint32_t u = ch & 0xDFu;
+		const bool in = LV >= 1 || i < len;
+		const bool base_ = LV >= 1 || (in && (u == 'A' || u == 'C' || u == 'G' || u == 'T'));
+		const uint64_t c = ((ch >> 1) ^ (ch >> 2)) & 3u;
+		const uint64_t nf = (fwd << 2 | c) & mask, nr = (rev >> 2) | ((3ull ^ c) << shift1);
+		fwd = base_ ? nf : fwd; rev = base_ ? nr : rev;
+		const bool stored = in;                                              // (k odd: no k-mer is its own reverse complement)
+		const bool fwd_lt = fwd < rev;
+		const uint32_t z = fwd_lt ? 0u : 1u;
+		run = LV >= 1 ? run + 1 : (base_ ? run + 1 : (in ? 0 : run));
+		const bool real = LV == 2 || (base_ && run >= k);
+		const uint64_t hx = WIDE ? mcom_hash64_wide(fwd_lt ? fwd : rev, (uint32_t)(mask >> 32)) : mcom_hash64(fwd_lt ? fwd : rev, mask);
+		const uint32_t cp = real ? (uint32_t)(hx >> psh) : SSC_EMPTY32;
+		const uint32_t cy = real ? ((i << 1) | z) : 0xFFFFFFFFu;
+		if (stored) RP[slot * 64 + lane] = (RT)(real ? ((cp << 1) | z) : EW);
+		{
+			// the lap's minimum: '<' replaces, '==' marks a duplicate and moves to the newer entry
+			bool lt = stored && (slot == 0 || cp < lap_p), eq = false;
+			const bool tie = stored && slot != 0 && cp == lap_p;
+			if (__builtin_expect(__ballot(tie) != 0, 0)) {
+				if (tie) { if (cp == SSC_EMPTY32) eq = true; else { const uint64_t lx = full_at(lap_y >> 1); lt = hx < lx; eq = hx == lx; } }
+			}
+			lap_p = lt ? cp : lap_p; lap_slot = (lt || eq) ? slot : lap_slot; lap_dup = lt ? false : (eq ? true : lap_dup);
+			lap_y = (lt || eq) ? cy : lap_y;
+		}
+		if (LV < 2) {
+			const bool firstwin = stored && run == w + k - 1;
+			if (__builtin_expect(__ballot(firstwin) != 0, 0)) { if (firstwin) put_equals(false); }
+		}
+		bool newmin = stored && cp < best_p;                                  // '<=': the rightmost of equal hashes wins
+		{
+			const bool tie = stored && cp == best_p;
+			if (__builtin_expect(__ballot(tie) != 0, 0)) {
+				if (tie) newmin = cp == SSC_EMPTY32 ? true : hx <= full_at(best_y >> 1);
+			}
+		}
+		const bool left = stored && !newmin && slot == best_slot;            // the minimum has just left the window
+		put_if(LV == 2 ? (newmin || left) : ((newmin && run >= w + k) || (left && run >= w + k - 1)), best_y);
+		uint32_t np = lap_p; int ns = lap_slot; bool dup = lap_dup; uint32_t ny = lap_y;
+		if (left && slot + 1 < w) {
+			const uint32_t sm = SM[(slot + 1) * 64 + lane];
+			const int sj = (int)(sm & 63u);
+			const uint32_t e = RP[sj * 64 + lane];
+			const uint32_t sp = e >> 1;                                        // (the empty word's key is SSC_EMPTY32)
+			const uint32_t sy = e == EW ? 0xFFFFFFFFu : ((pos_of(sj, slot) << 1) | (e & 1u));
+			const int c3 = cmp_entries(sp, sy, lap_p, lap_y);
+			const bool older = c3 < 0;
+			dup = older ? (sm & 0x80u) != 0 : (dup || c3 == 0);
+			if (older) { np = sp; ns = sj; ny = sy; }
+		}
+		best_p = newmin ? cp : (left ? np : best_p);
+		best_y = newmin ? cy : (left ? ny : best_y);
+		best_slot = newmin ? slot : (left ? ns : best_slot);
+		const bool again = left && dup && (LV == 2 || run >= w + k - 1);
+		if (__builtin_expect(__ballot(again) != 0, 0)) { if (again) put_equals(true); }
+		const bool wrapped = stored && slot + 1 == w;
+		const int cur = slot;                                                // the slot this step's entry went into
+		slot = stored ? (wrapped ? 0 : slot + 1) : slot;
+		if (__builtin_expect(__ballot(wrapped) != 0, 0)) {
+			if (wrapped) {                                                   // the lap is complete: its suffix minima, newest (highest slot) first among equals
+				auto key = [&](int j) -> uint32_t { return (uint32_t)RP[j * 64 + lane] >> 1; };
+				auto yof = [&](int j) -> uint32_t { const uint32_t e = RP[j * 64 + lane]; return e == EW ? 0xFFFFFFFFu : ((pos_of(j, cur) << 1) | (e & 1u)); };
+				uint32_t mx = key(w - 1); uint32_t ms = (uint32_t)(w - 1);
+				SM[(w - 1) * 64 + lane] = (uint8_t)ms;
+				for (int j = w - 2; j >= 0; j -= 4) {
+					uint32_t xs[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) xs[q] = j - q >= 0 ? key(j - q) : SSC_EMPTY32;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) if (j - q >= 0) {
+						if (xs[q] < mx) { mx = xs[q]; ms = (uint32_t)(j - q); }
+						else if (xs[q] == mx) {
+							const int c3 = xs[q] == SSC_EMPTY32 ? 0 : cmp_entries(xs[q], yof(j - q), mx, yof((int)(ms & 63u)));
+							if (c3 < 0) ms = (uint32_t)(j - q); else if (c3 == 0) ms |= 0x80u;
+						}
+						SM[(j - q) * 64 + lane] = (uint8_t)ms;
+					}
+				}
+			}
+		}
+	};
+	auto eq8 = [](uint64_t x, uint64_t pat) -> uint64_t { const uint64_t zz = x ^ pat; return ~(((zz & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | zz | 0x7F7F7F7F7F7F7F7Full); };
+	for (uint32_t i0 = 0; i0 < maxlen; i0 += 8) {
+		chunk = ahead_sh < 64 ? ahead >> ahead_sh : (i0 == 0 ? first8 : 0ull);
+		ahead = issue8(i0 + 8, ahead_sh);
+		const uint64_t uc = chunk & 0xDFDFDFDFDFDFDFDFull;
+		const uint64_t ok = eq8(uc, 0x4141414141414141ull) | eq8(uc, 0x4343434343434343ull) | eq8(uc, 0x4747474747474747ull) | eq8(uc, 0x5454545454545454ull);
+		const bool clean = i0 + 8 <= len && ok == 0x8080808080808080ull;
+		if (__all(clean)) {
+			if (__all(run >= w + k)) {
+#pragma unroll 1
+				for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::integral_constant<int, 2>{});
+			} else {
+#pragma unroll 1
+				for (uint32_t q = 0; q < 8; ++q) scan_step(i0 + q, std::integral_constant<int, 1>{});
+			}
+		} else {
+#pragma unroll 1
+			for (uint32_t q = 0; q < 8 && i0 + q < maxlen; ++q) scan_step(i0 + q, std::integral_constant<int, 0>{});
+		}
+	}
+	if (best_p != SSC_EMPTY32) put_y(best_y);                                // the minimum still held (:163-164)
+	if (have) cnt[t] = ne;
+}
+
+// the hashes of the records k_sketch_scan32 emitted (x = 0 placeholders): from the string, four lanes per string.  The k characters
+// that end at the record's position come as four unaligned 8-byte loads; eight characters pack into sixteen bits with three
+// shift-or-mask steps, the forward k-mer is the group-reversed little-endian word and the reverse complement its complement.
+__device__ __forceinline__ uint64_t ssc_pack8(uint64_t x)
+{
+	uint64_t c = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ull;          // A0 C1 G2 T3 in the low two bits of every byte
+	c = (c | (c >> 6)) & 0x000F000F000F000Full;
+	c = (c | (c >> 12)) & 0x000000FF000000FFull;
+	return (c | (c >> 24)) & 0xFFFFull;                                  // character j of the eight at bits 2j
+}
+template <bool WIDE>
+__device__ __forceinline__ uint64_t ssc_hash_at(const uint8_t *__restrict__ s, uint32_t pos, int k, uint64_t mask)
+{
+		// the 32 characters that end at pos (k <= 31 of them count; a string shorter than 32 is read from its start and shifted)
+		uint64_t le;
+		if (pos >= 31) {
+			uint64_t w4[4];
+			__builtin_memcpy(w4, s + (pos - 31), 32);
+			le = ssc_pack8(w4[0]) | (ssc_pack8(w4[1]) << 16) | (ssc_pack8(w4[2]) << 32) | (ssc_pack8(w4[3]) << 48);   // character pos - 31 + j at bits 2j
+			le >>= 2 * (32 - k);                                          // character pos - k + 1 + j at bits 2j
+		} else {
+			le = 0;
+			for (int j = 0; j < k; ++j) { const uint32_t ch = s[pos + 1 - (uint32_t)k + (uint32_t)j]; le |= (uint64_t)(((ch >> 1) ^ (ch >> 2)) & 3u) << (2 * j); }
+		}
+		le &= mask;
+		const uint64_t r = ~le & mask;                                   // reverse complement as the scan rolls it: the newest character on top, complemented
+		uint64_t f = __brevll(le);                                       // forward k-mer: the oldest character on top
+		f = ((f >> 1) & 0x5555555555555555ull) | ((f & 0x5555555555555555ull) << 1);
+		f >>= 64 - 2 * k;
+		const uint64_t canon = f < r ? f : r;
+		return WIDE ? mcom_hash64_wide(canon, (uint32_t)(mask >> 32)) : mcom_hash64(canon, mask);
+}
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_ssc_fill_x(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                    const uint32_t *__restrict__ moff, int k, mcom_mm128 *__restrict__ out)
+{
+	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t li = g >> 2, q = g & 3u;
+	if (li >= nlist) return;
+	const uint32_t t = list ? list[li] : li;
+	const uint8_t *s = seq + off[t];
+	const uint64_t mask = (1ull << (2 * k)) - 1;
+	for (uint32_t i = moff[t] + q; i < moff[t + 1]; i += 4) {
+		const uint64_t y = out[i].y;
+		if (y != U64MAX) out[i].x = ssc_hash_at<WIDE>(s, (uint32_t)y >> 1, k, mask);
+	}
+}
+
 // the records of every string from its room to its place; strings that emitted more than their room are listed
+// FILL: the records come from k_sketch_scan32 with their hashes still to be made (1: k < 17, 2: k >= 17)
+template <int FILL>
 __global__ __launch_bounds__(256) void k_ssc_gather(const mcom_mm128 *__restrict__ tmp, const uint32_t *__restrict__ base, const uint32_t *__restrict__ room,
                                                     const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ moff, uint32_t n,
-                                                    mcom_mm128 *__restrict__ out, uint32_t *__restrict__ over_list, uint32_t *__restrict__ n_over)
+                                                    mcom_mm128 *__restrict__ out, uint32_t *__restrict__ over_list, uint32_t *__restrict__ n_over,
+                                                    const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off, int k)
 {
 	// four lanes per string
 	const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -271,7 +535,14 @@ __global__ __launch_bounds__(256) void k_ssc_gather(const mcom_mm128 *__restrict
 	if (c > r) { if (q == 0) over_list[atomicAdd(n_over, 1u)] = t; return; }
 	const mcom_mm128 *src = tmp + base[t];
 	mcom_mm128 *dstp = out + moff[t];
-	for (uint32_t i = q; i < c; i += 4) dstp[i] = src[i];
+	if (FILL == 0) { for (uint32_t i = q; i < c; i += 4) dstp[i] = src[i]; return; }
+	const uint8_t *s = seq + off[t];
+	const uint64_t mask = (1ull << (2 * k)) - 1;
+	for (uint32_t i = q; i < c; i += 4) {
+		mcom_mm128 v = src[i];
+		if (v.y != U64MAX) v.x = ssc_hash_at<FILL == 2>(s, (uint32_t)v.y >> 1, k, mask);
+		dstp[i] = v;
+	}
 }
 }  // namespace
 
@@ -308,12 +579,19 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	if (h2[0] >= 32768u) return -1;
 	if (h2[1] > tmp_bound) return mcom_fail(ctx, MCOM_E_HIP, "sketch rooms %u above their bound", h2[1]);
 	const bool oddk = (k & 1) != 0, wide = k >= 17;
+	const bool ring32 = oddk && !ctx->sketch_ring64;                         // the ring of hash prefixes: a half or a quarter of the LDS
+	const bool ring16 = ring32 && ctx->sketch_prefix_bits <= 14 && !ctx->sketch_ring32_only;             // 16-bit ring words hold prefixes of up to 14 bits
+	const int pb = ctx->sketch_prefix_bits;
 #define SSC_LAUNCH(blocks, ...) do { \
-	if (oddk && wide) hipLaunchKernelGGL((k_sketch_scan<true, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	if (ring16 && wide) hipLaunchKernelGGL((k_sketch_scan32<true, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring16) hipLaunchKernelGGL((k_sketch_scan32<false, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring32 && wide) hipLaunchKernelGGL((k_sketch_scan32<true, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring32) hipLaunchKernelGGL((k_sketch_scan32<false, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (oddk && wide) hipLaunchKernelGGL((k_sketch_scan<true, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
 	else if (oddk) hipLaunchKernelGGL((k_sketch_scan<true, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
 	else if (wide) hipLaunchKernelGGL((k_sketch_scan<false, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
 	else hipLaunchKernelGGL((k_sketch_scan<false, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); } while (0)
-	const size_t lds = (size_t)w * SSC_STRIDE * 8 + (oddk ? 0 : (size_t)w * 64 * 2) + (size_t)w * 64;
+	const size_t lds = ring16 ? (size_t)w * 64 * 2 + (size_t)w * 64 : ring32 ? (size_t)w * 64 * 4 + (size_t)w * 64 : (size_t)w * SSC_STRIDE * 8 + (oddk ? 0 : (size_t)w * 64 * 2) + (size_t)w * 64;
 	{
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
 		SSC_LAUNCH((nn + 63) / 64, d_seq, d_off, d_off_end, d_ids, perm, nn, w, k, limit, base, room, 0, tmp, cnt);
@@ -328,7 +606,12 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	if (h_total) *h_total = total;
 	if (total > cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap);
 	if (total == 0) return MCOM_OK;
-	hipLaunchKernelGGL(k_ssc_gather, dim3((unsigned)(((size_t)nn * 4 + 255) / 256)), dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1);
+	{
+		const dim3 gb((unsigned)(((size_t)nn * 4 + 255) / 256));
+		if (!ring32) hipLaunchKernelGGL(k_ssc_gather<0>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+		else if (wide) hipLaunchKernelGGL(k_ssc_gather<2>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+		else hipLaunchKernelGGL(k_ssc_gather<1>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+	}
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t n_over = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_over, misc + 1, 4));
@@ -337,6 +620,12 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
 		SSC_LAUNCH((n_over + 63) / 64, d_seq, d_off, d_off_end, d_ids, over, n_over, w, k, limit, d_moff, room, 1, d_out, cnt);
 		MCOM_LAUNCH_CHECK(ctx);
+		if (ring32) {                                                        // (the gather made the hashes of the others; these went straight into place)
+			const unsigned fb = (unsigned)(((size_t)n_over * 4 + 255) / 256);
+			if (wide) hipLaunchKernelGGL(k_ssc_fill_x<true>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
+			else hipLaunchKernelGGL(k_ssc_fill_x<false>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
+			MCOM_LAUNCH_CHECK(ctx);
+		}
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
 	return MCOM_OK;

@@ -242,10 +242,16 @@ class Context:
         self.lib.mcom_set_index_capacity.restype = C.c_int; self.lib.mcom_set_index_capacity.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.mcom_set_index_capacity(self._h, entries))
 
-    def set_sketch_kernel(self, wave_per_string: bool):
-        """Test hook of mcom_sketch_contigs: force the wave-per-string kernel (the default picks the lane-per-string one where it applies)."""
+    def set_sketch_kernel(self, wave_per_string):
+        """Test hook of mcom_sketch_contigs: 1 / True = the wave-per-string kernel, 2 = the lane-per-string kernel with the 64-bit ring,
+        0 / False = the default choice (the ring of 32-bit prefixes for odd k)."""
         self.lib.mcom_set_sketch_kernel.restype = C.c_int; self.lib.mcom_set_sketch_kernel.argtypes = [C.c_void_p, C.c_int]
-        self._check(self.lib.mcom_set_sketch_kernel(self._h, 1 if wave_per_string else 0))
+        self._check(self.lib.mcom_set_sketch_kernel(self._h, int(wave_per_string)))
+
+    def set_sketch_prefix_bits(self, bits: int):
+        """Test hook: the prefix width of the prefix ring (14 by default, in 16-bit words; above 14 in 32-bit words); a few bits make prefix ties the rule."""
+        self.lib.mcom_set_sketch_prefix_bits.restype = C.c_int; self.lib.mcom_set_sketch_prefix_bits.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_sketch_prefix_bits(self._h, bits))
 
     def set_consensus_capacity(self, members: int):
         """Test hook of the merge consensus: units that more than `members` members reach use the wave-per-tile kernel (0 = default 127)."""

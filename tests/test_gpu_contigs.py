@@ -201,17 +201,21 @@ def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, n
     idx.close()
 
 
-@pytest.mark.parametrize("wave", [False, True])
-@pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24), (64, 31)])
-def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, wave):
+@pytest.mark.parametrize("kernel", ["default", "wave", "ring64", "prefix3", "prefix9", "prefix30", "ring32prefix5"])
+@pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24), (64, 31), (20, 13), (33, 25)])
+def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, kernel):
     """Tie-rich strings (short-period repeats, homopolymers, copied blocks, ambiguous bases): equal hashes inside a
     window exercise the duplicate rules of sketch.c:138-161 and the exact fallback of the prefix window scan.
-    Both kernels: one lane per string (windows up to 64; homopolymers overflow their room and are scanned again) and
-    one wave per string."""
+    All kernels: one lane per string with the ring of 32-bit hash prefixes (k odd: the default; a tie between prefixes is settled by
+    recomputing the hashes from the string -- with the prefix narrowed to 3 or 9 bits that is most comparisons) or of 64-bit
+    hashes (windows up to 64; homopolymers overflow their room and are scanned again), and one wave per string."""
     import oracle
-    if wave and w == 128:
+    if kernel != "default" and w == 128:
         pytest.skip("w = 128 takes the wave-per-string kernel anyway")
-    ctx.set_sketch_kernel(wave)
+    if "prefix" in kernel and k % 2 == 0:
+        pytest.skip("the prefix ring is for odd k")
+    ctx.set_sketch_kernel({"default": 0, "wave": 1, "ring64": 2, "ring32prefix5": 3}.get(kernel, 0))        # 3: 32-bit ring words whatever the prefix width
+    ctx.set_sketch_prefix_bits(5 if kernel == "ring32prefix5" else int(kernel[6:]) if kernel.startswith("prefix") else 14)
     from test_gpu_resketch import _string
     rng = np.random.default_rng(100 * w + k)
     refs = []
@@ -230,7 +234,7 @@ def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, wave):
         moff, out = ctx.sketch_contigs(cg["seq"], cg["off"], len(refs), w, k)
         ctx.sync()
     finally:
-        ctx.set_sketch_kernel(False)
+        ctx.set_sketch_kernel(0); ctx.set_sketch_prefix_bits(14)
     moff = moff.cpu().numpy(); r = _recs(out)
     total = 0
     for i, ref in enumerate(refs):

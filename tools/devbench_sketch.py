@@ -13,7 +13,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 ln = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 44
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 31
+mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0        # 0 default (prefix ring for odd k), 1 wave per string, 2 the 64-bit ring
 ctx = Context(0)
+ctx.set_sketch_kernel(mode)
+if len(sys.argv) > 6:
+    ctx.set_sketch_prefix_bits(int(sys.argv[6]))
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 lens = torch.randint(ln - 40, ln + 60, (n,), device="cuda", generator=g, dtype=torch.int64)
 off = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); off[1:] = torch.cumsum(lens, 0)
