@@ -207,6 +207,119 @@ __global__ __launch_bounds__(256) void k_classify_pack16(const uint8_t *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_classify_flat (round 3): the same result for reads that lie back to back (pitch == L), as a byte stream.
+// The kernels above give a read sixteen lanes: at L = 150 ten of them have bases, every load is an unaligned dword at pitch 150,
+// and the counts and the words are put together across lanes -- 37 wave instructions per read, issue-bound at 2.1 TB/s.  Here a
+// wave takes 64 consecutive reads = 64 L bytes (a multiple of 16 whatever L is): phase A loads them as aligned 16-byte units,
+// lane after lane, turns every unit into 32 bits of codes and 16 N flags and lays them down in LDS as two flat bit streams;
+// phase B gives every lane one read: its W words are cut out of the code stream at bit 2 L r (and its N words out of the flag
+// stream at bit L r), counted with popcounts, classified, the N positions filled with the majority base, and written -- no
+// cross-lane step at all, every lane busy in both phases: ~9 wave instructions per read, which leaves the kernel to HBM.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread32_64(uint64_t x)             // bit i of the low 32 bits -> bit 2i
+{
+	x &= 0xFFFFFFFFull;
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x << 2)) & 0x3333333333333333ull;
+	x = (x | (x << 1)) & 0x5555555555555555ull;
+	return x;
+}
+// 64 bits of a flat stream of 32-bit words from bit `bit` on (the stream has two words of padding behind its end)
+__device__ __forceinline__ uint64_t stream64(const uint32_t *w, uint32_t bit)
+{
+	const uint32_t i = bit >> 5, sh = bit & 31u;
+	const uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
+	return sh ? (lo >> sh) | ((uint64_t)w[i + 2] << (64 - sh)) : lo;
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_classify_flat(const uint8_t *__restrict__ ascii, size_t n, int L, int e, uint64_t *__restrict__ packed,
+                                                       uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt, uint64_t *__restrict__ nmask)
+{
+	constexpr int NW = (W + 1) / 2;
+	extern __shared__ uint32_t cf_lds[];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t units = 4u * (uint32_t)L;                               // 16-byte units of 64 reads
+	uint32_t *codes = cf_lds + (size_t)wv * (units + units / 2 + 8);       // [units + 2]: 32 bits of codes per unit
+	uint32_t *nbw = codes + units + 4;                                     // [units / 2 + 2]: 16 N flags per unit, two units per word
+	uint16_t *nbh = (uint16_t*)nbw;
+	const size_t total = n * (size_t)L;
+	const size_t nchunks = (n + 63) / 64;
+	const size_t wave0 = (size_t)blockIdx.x * (blockDim.x >> 6) + wv, nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+	if (lane < 4) { codes[units + lane] = 0; if (lane < 2) nbw[units / 2 + lane] = 0; }
+	for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
+		const size_t byte0 = ch * 64 * (size_t)L;
+		// phase A: units of 16 bases
+		for (uint32_t u = lane; u < units; u += 64) {
+			const size_t off = byte0 + 16 * (size_t)u;
+			uint4 d = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);   // 'A's behind the end of the data
+			if (off + 16 <= total) d = *(const uint4*)(ascii + off);
+			else if (off < total) { uint32_t t[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u}; for (size_t q = off; q < total; ++q) { const int b = (int)(q - off); t[b >> 2] = (t[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | ((uint32_t)ascii[q] << (8 * (b & 3))); } d = make_uint4(t[0], t[1], t[2], t[3]); }
+			codes[u] = ascii4_to_codes(d.x) | (ascii4_to_codes(d.y) << 8) | (ascii4_to_codes(d.z) << 16) | (ascii4_to_codes(d.w) << 24);
+			nbh[u] = (uint16_t)(ascii4_nbits(d.x) | (ascii4_nbits(d.y) << 4) | (ascii4_nbits(d.z) << 8) | (ascii4_nbits(d.w) << 12));
+		}
+		__builtin_amdgcn_s_waitcnt(0);                                       // (one wave: its LDS writes are in order; make them visible to the other lanes)
+		__builtin_amdgcn_wave_barrier();
+		// phase B: one read per lane
+		const size_t r = ch * 64 + (size_t)lane;
+		if (r < n) {
+			uint64_t cw[W], nw[NW];
+#pragma unroll
+			for (int w = 0; w < W; ++w) cw[w] = stream64(codes, 2u * (uint32_t)L * (uint32_t)lane + 64u * w);
+#pragma unroll
+			for (int w = 0; w < NW; ++w) {
+				nw[w] = stream64(nbw, (uint32_t)L * (uint32_t)lane + 64u * w);
+				const int left = L - 64 * w;
+				if (left < 64) nw[w] &= left > 0 ? ((1ull << left) - 1) : 0ull;
+			}
+			int nA = 0, nC = 0, nG = 0, nT = 0, nN = 0;
+			uint64_t okm[W];
+#pragma unroll
+			for (int w = 0; w < W; ++w) {
+				const int left = 2 * L - 64 * w;                              // code bits of this word
+				const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
+				const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1)));
+				okm[w] = ~nsp & 0x5555555555555555ull & valid;
+				const uint64_t lo = cw[w] & 0x5555555555555555ull, hi = (cw[w] >> 1) & 0x5555555555555555ull;
+				nA += __popcll(~lo & ~hi & okm[w]); nC += __popcll(lo & ~hi & okm[w]); nG += __popcll(~lo & hi & okm[w]); nT += __popcll(lo & hi & okm[w]);
+			}
+#pragma unroll
+			for (int w = 0; w < NW; ++w) nN += __popcll(nw[w]);
+			int c;                                                           // kthread_reads.c:84-224
+			if (nA == L) c = MCOM_CLS_ALLA;
+			else if (nT == L) c = MCOM_CLS_ALLT;
+			else if (nN == L) c = MCOM_CLS_ALLN;
+			else if (nT + nG + nC + nN <= e) c = MCOM_CLS_NEARA;
+			else if (nA + nG + nC + nN <= e) c = MCOM_CLS_NEART;
+			else if (nA + nT + nG + nC <= e) c = MCOM_CLS_NEARN;
+			else if (!((double)nN <= 0.4 * (double)L)) c = MCOM_CLS_NHEAVY;
+			else c = MCOM_CLS_SKETCH;
+			uint32_t rep = 0;                                                // majority base, ties A,T,G,C (:185-201)
+			if (c == MCOM_CLS_SKETCH && nN > 0) {
+				int mx = nA; if (nT > mx) mx = nT; if (nG > mx) mx = nG; if (nC > mx) mx = nC;
+				rep = (mx == nA) ? 0u : (mx == nT) ? 3u : (mx == nG) ? 2u : 1u;
+			}
+#pragma unroll
+			for (int w = 0; w < W; ++w) {
+				const int left = 2 * L - 64 * w;
+				const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
+				const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1))) & valid;
+				const uint64_t keep = okm[w] | (okm[w] << 1);
+				const uint64_t fill = ((rep & 1) ? nsp : 0ull) | ((rep & 2) ? (nsp << 1) : 0ull);
+				packed[r * (size_t)W + w] = (cw[w] & keep) | fill;
+			}
+			if (nmask) {
+#pragma unroll
+				for (int w = 0; w < NW; ++w) nmask[r * (size_t)NW + w] = nw[w];
+			}
+			cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN;
+		}
+		__builtin_amdgcn_wave_barrier();                                     // the next chunk's phase A overwrites the streams
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_sketch_reads: one thread per read, rolling forward / reverse-complement k-mers out of the packed
 // row held in registers; 64 reads of a wave run the same control flow (the only divergent branch is the
 // rare k-mer that equals its own reverse complement).
@@ -424,6 +537,17 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 	size_t blocks = (waves + 3) / 4;
 	const size_t cap = (size_t)ctx->n_cu * 16;
 	if (blocks > cap) blocks = cap;
+	const bool flat = pitch == (size_t)L && ((uintptr_t)d_ascii & 15) == 0;      // reads back to back, 16-byte aligned: the byte-stream kernel
+	if (flat) {
+		McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
+		const size_t chunks = (n + 63) / 64;
+		size_t fb = (chunks + 3) / 4;
+		if (fb > (size_t)ctx->n_cu * 8) fb = (size_t)ctx->n_cu * 8;
+		const size_t lds = 4 * (size_t)(4 * L + 2 * L + 8) * 4;
+#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_classify_flat<WW>), dim3((unsigned)fb), dim3(256), lds, ctx->stream, d_ascii, n, L, e, d_packed, d_cls, d_ncnt, d_nmask); break;
+		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported", L); }
+#undef MCOM_CASE
+	} else
 	{ McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
 	if (L <= 128) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
 	else          hipLaunchKernelGGL(k_classify_pack16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
