@@ -105,8 +105,8 @@ def cindex_bytes(st):
 # HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
 # this same command; kernels cannot be counted while bench.py itself is timing them)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan<true, true>", "k_sketch_scan<false, true>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false, false>"],
-               "classify_pack": ["k_classify_pack16"], "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true, false>"],
+PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan32<true, unsigned short>", "k_sketch_scan32<true, unsigned int>", "k_sketch_scan<true, true>", "k_sketch_scan<false, true>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false, false>"],
+               "classify_pack": ["k_classify_flat<5>", "k_classify_pack16"], "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true, false>"],
                "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1<false>", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
 

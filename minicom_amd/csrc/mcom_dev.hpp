@@ -128,11 +128,20 @@ template <int S> __device__ __forceinline__ uint64_t mcom_lshl_add64(uint64_t a,
 	return d;
 }
 __device__ __forceinline__ uint64_t mcom_mask_hi(uint64_t v, uint32_t mhi) { return (v & 0xFFFFFFFFull) | ((uint64_t)((uint32_t)(v >> 32) & mhi) << 32); }
+// key * C + add (mod 2^64) for a 32-bit constant: one 32 x 32 -> 64 multiply-add for the low word, one 32-bit multiply and an add
+// for the high word.  (tools/ubench/valu_rates.hip: v_mad_u64_u32 and v_mul_lo_u32 issue like every other three-operand or 64-bit
+// instruction on gfx950, 4.4 cycles per wave, two-operand 32-bit instructions in 2.4.)
+__device__ __forceinline__ uint64_t mcom_mul64_c32(uint64_t key, uint32_t C, uint64_t add)
+{
+	const uint64_t p = (uint64_t)(uint32_t)key * C + add;
+	const uint32_t hi = (uint32_t)(key >> 32) * C + (uint32_t)(p >> 32);
+	return ((uint64_t)hi << 32) | (uint32_t)p;
+}
 __device__ __forceinline__ uint64_t mcom_hash64_wide(uint64_t key, uint32_t mhi)
 {
-	key = mcom_mask_hi(~key + (key << 21), mhi);
+	key = mcom_mask_hi(mcom_mul64_c32(key, 0x1FFFFFu, ~0ull), mhi);                 // ~key + (key << 21) = key * (2^21 - 1) - 1
 	key ^= key >> 24;
-	{ const uint64_t k9 = mcom_lshl_add64<3>(key, key), k16 = key << 4; key = mcom_mask_hi(mcom_lshl_add64<4>(k16, k9), mhi); }   // key + (key << 3) + (key << 8)
+	key = mcom_mask_hi(mcom_mul64_c32(key, 265u, 0), mhi);                          // key + (key << 3) + (key << 8)
 	key ^= key >> 14;
 	{ const uint64_t k5 = mcom_lshl_add64<2>(key, key); key = mcom_mask_hi(mcom_lshl_add64<4>(key, k5), mhi); }                    // key + (key << 2) + (key << 4)
 	key ^= key >> 28;

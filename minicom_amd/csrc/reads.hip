@@ -346,6 +346,8 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 		const uint32_t mhi = (uint32_t)((1ull << (2 * k - 32)) - 1);
 		const int sh_hi = 2 * (k - 1) - 32;                 // top base of the reverse k-mer, inside the high word
 		uint64_t fwd = 0, rev = 0;
+		uint32_t vzero = 0, vone = 1;
+		asm volatile("" : "+v"(vzero), "+v"(vone));                            // constants that live in registers (operands of the strand select)
 		int i = 0;
 #pragma unroll
 		for (int q = 0; q < W; ++q) {
@@ -358,9 +360,11 @@ __global__ __launch_bounds__(256) void k_sketch_reads(const uint64_t *__restrict
 				if (ODDK) {
 					if (i >= k - 1) {                                            // uniform
 						const bool lt = fwd < rev;                                  // one comparison serves the strand and the choice
+						uint32_t z = lt ? vzero : vone;                             // (from registers: a two-operand select on the same vcc,
+						asm volatile("" : "+v"(z));                                 // made here and now: the compiler would compare again after the hash)
 						const uint64_t h = mcom_hash64_wide(lt ? fwd : rev, mhi);
 						const bool better = h < best_x;
-						best_x = better ? h : best_x; best_i = better ? ((uint32_t)i << 1 | (lt ? 0u : 1u)) : best_i;
+						best_x = better ? h : best_x; best_i = better ? ((uint32_t)i << 1 | z) : best_i;
 					}
 				} else if (fwd != rev) {
 					++run;

@@ -790,7 +790,11 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 	// visited before group g.  Nobody needs the list before Stage 2: a thread builds it beside combine_cluster.
 	// (multi-GPU: this rank's part, round by round; combine_cluster puts the ranks' parts together, dist_gather_sg)
 	p->join_sg();
-	if ((rc = p->hipc(hipStreamSynchronize(p->copy_stream), "round lists"))) return rc;
+	{
+		const double tw = now_ms();
+		if ((rc = p->hipc(hipStreamSynchronize(p->copy_stream), "round lists"))) return rc;
+		p->stat["t_bk_lists_wait"] += now_ms() - tw;
+	}
 	p->sg_round_len.assign(sg_rounds.size(), 0);
 	p->sg_gathered = !dist;
 	p->sg_thread = std::thread([p, n_sg_total](std::vector<SgRound> rounds) {

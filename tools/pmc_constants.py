@@ -10,7 +10,7 @@ traffic, sq, out, tag = sys.argv[1:5]
 # for `traffic_corrected`.  Calibration in this code base: k_classify_pack16 reads 15.0 GB of ASCII and FETCH_SIZE says 8.1; k_cx_scatter2
 # reads 12 bytes x 0.88 G entries = 10.6 GB and FETCH_SIZE says 5.4.  Kernels that gather (table lookups, row gathers, per-object
 # kernels) keep their raw count.
-STREAMING = ("k_classify_pack16", "k_classify_pack", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_radix_hist", "k_radix_scatter", "k_scan_tile", "k_scan_add",
+STREAMING = ("k_classify_flat", "k_classify_pack16", "k_classify_pack", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_radix_hist", "k_radix_scatter", "k_scan_tile", "k_scan_add",
              "k_scan64_tile", "k_scan64_add", "k_digest", "k_mask_records", "k_st_refbin", "k_table_heads", "k_bucket_starts", "k_live_flags", "k_prefix_copy", "k_min_fold")
 res = {"_source": {"traffic": f"profiles/{tag}_pmc_traffic_100m.json (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes of `bench.py --steps 1 --warmup 0`, 100 M x 150 bp; "
                               "raw = counters x 1024; corrected = FETCH x 2 for the wide streaming readers listed in tools/pmc_constants.py)",

@@ -6,7 +6,7 @@ import sys
 db, pat, top = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25
 con = sqlite3.connect(db)
 rows = list(con.execute("select name, start, end, grid_x from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if "k_classify_pack" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_classify_" in r[0]]
 rows = rows[starts[-1]:]
 short = lambda s: s.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:28]
 hits = [(r[2] - r[1], i) for i, r in enumerate(rows) if pat in r[0]]

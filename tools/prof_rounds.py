@@ -6,7 +6,7 @@ import sys
 db, marker = sys.argv[1], sys.argv[2]
 con = sqlite3.connect(db)
 rows = list(con.execute("select name, start, end from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if "k_classify_pack" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_classify_" in r[0]]
 rows = rows[starts[-1]:]
 t0 = rows[0][1]
 marks = [(r[1] - t0) / 1e6 for r in rows if marker in r[0]]

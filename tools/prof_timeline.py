@@ -1,13 +1,17 @@
 """Timeline of ONE step of bench.py from a rocprofv3 rocpd database: busy time per kernel, idle gaps, launches.
-   prof_timeline.py RESULTS.db [STEP]   (a step starts at a k_classify_pack* dispatch; default: the last one)"""
+   prof_timeline.py RESULTS.db [STEP]   (a step starts at a k_classify_* dispatch; default: the last one)"""
 import collections
 import sqlite3
 import sys
 
 db = sys.argv[1]
-con = sqlite3.connect(db)
-rows = list(con.execute("select name, start, end from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if r[0].startswith("k_classify_pack") or r[0].startswith("void k_classify_pack")]
+if db.endswith(".csv"):                                                        # rocprofv3 --output-format csv: *_kernel_trace.csv
+    import csv
+    rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(db))), key=lambda r: r[1])
+else:
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select name, start, end from kernels order by start"))
+starts = [i for i, r in enumerate(rows) if r[0].replace("void ", "").replace("(anonymous namespace)::", "").startswith("k_classify_")]
 step = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 1
 a = starts[step]; b = starts[step + 1] if step + 1 < len(starts) else len(rows)
 rows = rows[a:b]
@@ -33,3 +37,6 @@ hist = collections.Counter()
 for g, _ in gaps:
     hist[min(6, len(str(g // 1000)))] += g
 print("idle by gap size (digits of us):", {k: round(v / 1e6, 1) for k, v in sorted(hist.items())})
+big = sorted(((e - s, i) for i, (n, s, e) in enumerate(rows) if "copyBuffer" in n or "fillBuffer" in n), reverse=True)[:16]
+short = lambda n: n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:28]
+print("largest copies / fills (ms, kind, kernel before, kernel after):", [(round(d / 1e6, 2), "copy" if "copy" in rows[i][0] else "fill", short(rows[i - 1][0]) if i else "", short(rows[i + 1][0]) if i + 1 < len(rows) else "") for d, i in big])
