@@ -42,7 +42,7 @@ def cpu_baseline(L, sample):
     has cores for: the thread count is a compile-time constant of the reference, minicom:56-91) on the host cores, on a bounded
     sample of the same workload, by its own Stage 1 + Stage 2 timers; falls back to the C restatement (oracle/) when absent."""
     from minicom_amd import synth
-    from minicom_amd.e2e import host_cores, reference_binary
+    from tools.e2e import host_cores, reference_binary
     reads = synth.synth_reads(SEED, sample, L)
     tag = f"{sample} reads x {L} bp, same generator (seed {SEED}, 30x coverage, 0.5% substitutions)"
     found = reference_binary(L)
@@ -335,7 +335,7 @@ def main():
         reads = None
         pool_trim(); torch.cuda.empty_cache()
         try:
-            from minicom_amd.e2e import file_to_streams
+            from tools.e2e import file_to_streams
             e2e = file_to_streams(a.e2e_reads, L, SEED, host_threads=threads, ref_reads=1_000_000)
         except Exception as e:                                                   # noqa: BLE001
             e2e = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}

@@ -66,6 +66,11 @@ const char *mcom_version(void);
 int mcom_prof_enable(mcom_ctx *ctx, int on);
 int mcom_prof_reset(mcom_ctx *ctx);
 int mcom_prof_read(mcom_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
+/* The kernels launched while the profiler was on, as text: one line "kernel name<TAB>launches" per kernel instantiation (the
+ * compiler's spelling, which is the name rocprofv3 prints), for the class `name`; "*" = every kernel of the library, inside a
+ * timed class or not; "-" = those outside every class.  A caller that attaches counter figures to a class's time (bench.py) can
+ * so ask which kernels that time belongs to.  *need = bytes of the full text with its NUL; the text is cut at cap.        */
+int mcom_prof_kernels(mcom_ctx *ctx, const char *name, char *buf, size_t cap, size_t *need);
 
 /* The library keeps freed device blocks of its own objects for reuse.  mcom_pool_trim gives the free ones back to the runtime;
  * mcom_set_oom_hook names a function the library calls when it cannot get a block even so (a caller with a pool of its own frees
@@ -75,24 +80,9 @@ void mcom_set_oom_hook(void (*hook)(void));
 
 /* Diagnostics.  mcom_counter: "sort_overflow_segments" = segments of mcom_sort_group that did not fit its in-LDS sort and
  * went through the nine-pass sort instead (a minimizer shared by thousands of reads); "sketch_strings" = strings sketched by the
- * lane-per-string kernel of mcom_sketch_contigs so far (64 per wave).  mcom_set_segment_capacity lowers
- * the size above which a segment takes that route (0 = default, at most 4096): lets a small test input exercise it;
- * results never depend on it.                                                                                        */
+ * lane-per-string kernel of mcom_sketch_contigs so far (64 per wave).  (The knobs that force the rare code paths on small
+ * inputs are test hooks and live in include/mcom_test.h, not here.)                                                    */
 uint64_t mcom_counter(const mcom_ctx *ctx, const char *name);
-int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records);
-/* Likewise for mcom_cindex_build: partitions with more than `entries` entries are placed by the scattered kernel instead of
- * the sorted one (0 = all of them; negative = default).  Same index either way.                                       */
-int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
-/* Likewise for the merge consensus: a unit of 32 columns that more than `members` members reach sends its tile to the
- * wave-per-tile kernel (0 = default, the 127 the bit-sliced counters hold).  Same consensus either way.              */
-int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
-/* mcom_sketch_contigs has three kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) with a ring of
- * 32-bit hash prefixes (k odd: ties are settled by recomputing the hashes from the string) or of 64-bit hashes, and one wave per
- * string; wave_per_string = 1 forces the last, 2 the 64-bit ring, 0 = the default choice.  Same sketch every way.
- * mcom_set_sketch_prefix_bits (1..30; default 14: prefixes of up to 14 bits live in 16-bit ring words, wider ones in 32-bit words)
- * sets the prefix width of the first: a few bits make ties the rule (tests); wave_per_string = 3 keeps 32-bit words at any width.    */
-int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
-int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
 
 /* ---- a4 + a2: reads --------------------------------------------------------------------------- */
 /* Replaces kt_for_reads / process_reads (kthread_reads.c:247, :40-230) for a batch of n reads:

@@ -198,6 +198,8 @@ double mcomh_stat(const mcomh_pipeline *p, const char *name);
 /* kernel timing of the pipeline's own mcom_ctx (mcom_prof_enable / mcom_prof_read of include/mcom.h) */
 int mcomh_prof_enable(mcomh_pipeline *p, int on);
 int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *total_ms, uint64_t *launches);
+/* mcom_prof_kernels of include/mcom.h over the pipeline's contexts: "kernel<TAB>launches" lines of class `name` ("*" = all) */
+int mcomh_prof_kernels(mcomh_pipeline *p, const char *name, char *buf, size_t cap, size_t *need);
 
 #ifdef __cplusplus
 }

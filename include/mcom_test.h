@@ -1,0 +1,31 @@
+/* mcom_test.h -- TEST HOOKS of libmcom_hip.so.  Not part of the drop-in boundary (include/mcom.h): nothing a caller of the
+ * reference's functions needs is declared here.  Each hook forces a code path that real inputs reach only at sizes a unit test
+ * cannot afford (a sort segment beyond the LDS, an index partition beyond the sorted placement, a consensus unit beyond the
+ * bit-sliced counters) or selects between kernels that compute the same result.  Results never depend on any of them.  */
+#ifndef MCOM_TEST_H
+#define MCOM_TEST_H
+#include "mcom.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mcom_sort_group: the size above which a segment takes the nine-pass route instead of the in-LDS sort (0 = default, at most 4096). */
+int mcom_set_segment_capacity(mcom_ctx *ctx, uint32_t records);
+/* mcom_cindex_build: partitions with more than `entries` entries are placed by the scattered kernel instead of
+ * the sorted one (0 = all of them; negative = default).  Same index either way.                                       */
+int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
+/* Merge consensus: a unit of 32 columns that more than `members` members reach sends its tile to the
+ * wave-per-tile kernel (0 = default, the 127 the bit-sliced counters hold).  Same consensus either way.              */
+int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
+/* mcom_sketch_contigs has three kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) with a ring of
+ * 32-bit hash prefixes (k odd: ties are settled by recomputing the hashes from the string) or of 64-bit hashes, and one wave per
+ * string; wave_per_string = 1 forces the last, 2 the 64-bit ring, 0 = the default choice.  Same sketch every way.
+ * mcom_set_sketch_prefix_bits (1..30; default 14: prefixes of up to 14 bits live in 16-bit ring words, wider ones in 32-bit words)
+ * sets the prefix width of the first: a few bits make ties the rule (tests); wave_per_string = 3 keeps 32-bit words at any width.    */
+int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
+int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

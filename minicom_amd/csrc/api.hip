@@ -1,5 +1,6 @@
 // minicom_amd/csrc/api.hip -- context, error text and workspace of libmcom_hip.so
 #include "mcom_dev.hpp"
+#include "../../include/mcom_test.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -216,6 +217,36 @@ extern "C" int mcom_prof_reset(mcom_ctx *ctx)
 	if (!ctx) return MCOM_E_ARG;
 	prof_collect(ctx);
 	for (int i = 0; i < PROF_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_calls[i] = 0; }
+	ctx->prof_kernels.clear();
+	return MCOM_OK;
+}
+
+// "const char *mcom_kernel_name() [K = &(anonymous namespace)::k_x<5, true>]" -> "k_x<5, true>"
+static std::string prof_kernel_text(const char *pretty)
+{
+	std::string t(pretty);
+	size_t a = t.find("K = &");
+	if (a != std::string::npos) t = t.substr(a + 5);
+	if (!t.empty() && t.back() == ']') t.pop_back();
+	const char *anon = "(anonymous namespace)::";
+	for (size_t q; (q = t.find(anon)) != std::string::npos; ) t.erase(q, strlen(anon));
+	return t;
+}
+
+extern "C" int mcom_prof_kernels(mcom_ctx *ctx, const char *name, char *buf, size_t cap, size_t *need)
+{
+	if (!ctx || !name) return MCOM_E_ARG;
+	int cls = -1;
+	if (!strcmp(name, "*")) cls = -2;
+	else if (!strcmp(name, "-")) cls = PROF_COUNT;
+	else for (int i = 0; i < PROF_COUNT; ++i) if (!strcmp(name, PROF_NAMES[i])) cls = i;
+	if (cls == -1) return mcom_fail(ctx, MCOM_E_ARG, "unknown profiler name %s", name);
+	std::map<std::string, uint64_t> out;
+	for (const auto &kv : ctx->prof_kernels) if (cls == -2 || kv.first.first == cls) out[prof_kernel_text(kv.first.second)] += kv.second;
+	std::string txt;
+	for (const auto &kv : out) { txt += kv.first; txt += '\t'; txt += std::to_string(kv.second); txt += '\n'; }
+	if (need) *need = txt.size() + 1;
+	if (buf && cap) { size_t m = txt.size() < cap - 1 ? txt.size() : cap - 1; memcpy(buf, txt.data(), m); buf[m] = 0; }
 	return MCOM_OK;
 }
 

@@ -550,16 +550,16 @@ extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const
 	unsigned long long *head = (unsigned long long*)(tmp + hist_b + scr_b + map_b);   // word 1: a contig too long for the position field
 	MCOM_HIP(ctx, hipMemsetAsync(head, 0, 16, ctx->stream));
 	const uint64_t pos0 = w01[0] + (uint64_t)g.maxoff * c0;
-	hipLaunchKernelGGL(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
+	MCOM_LAUNCH(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
 	MCOM_LAUNCH_CHECK(ctx);
 	const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos, head};
-	hipLaunchKernelGGL(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
+	MCOM_LAUNCH(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
 	int rc;
 	if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;        // the extra element becomes the number of entries
-	if (g.n_owners > 1) hipLaunchKernelGGL(k_cx_scatter1<true>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
-	else hipLaunchKernelGGL(k_cx_scatter1<false>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	if (g.n_owners > 1) MCOM_LAUNCH(k_cx_scatter1<true>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	else MCOM_LAUNCH(k_cx_scatter1<false>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
 	MCOM_LAUNCH_CHECK(ctx);
 	// the first entry of every share = the scanned count of (digit q, block 0)
 	std::vector<uint32_t> st(g.n_owners + 1, 0);
@@ -603,25 +603,25 @@ extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slo
 	if (n_ent) {
 		uint32_t *ik = d_key, *ok = d_key_tmp; uint64_t *is = d_slot, *os = d_slot_tmp;
 		for (int shift = grouped ? 24 : 16; shift <= 24; shift += 8) {
-			hipLaunchKernelGGL(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, (size_t)n_ent, hist, nb2, shift);
+			MCOM_LAUNCH(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, (size_t)n_ent, hist, nb2, shift);
 			MCOM_LAUNCH_CHECK(ctx);
 			if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nb2, scr))) return rc;
-			hipLaunchKernelGGL(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, is, (size_t)n_ent, hist, nb2, ok, os, shift);
+			MCOM_LAUNCH(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, is, (size_t)n_ent, hist, nb2, ok, os, shift);
 			MCOM_LAUNCH_CHECK(ctx);
 			std::swap(ik, ok); std::swap(is, os);
 		}
 		skey = ik; sslot = is;
 	}
-	hipLaunchKernelGGL(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, skey, (size_t)n_ent, g.n_parts, pstart);
+	MCOM_LAUNCH(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, skey, (size_t)n_ent, g.n_parts, pstart);
 	MCOM_LAUNCH_CHECK(ctx);
 	const size_t lds = (size_t)3 * g.n_lines * 4;
 	if (lds > 150 * 1024) return mcom_fail(ctx, MCOM_E_ARG, "contig index: partitions of %u lines", g.n_lines);
 	MCOM_HIP(ctx, hipMemsetAsync(redo, 0, g.n_parts, ctx->stream));
-	hipLaunchKernelGGL(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
+	MCOM_LAUNCH(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
 	                   ctx->cix_cap_set ? std::min<uint32_t>(ctx->cix_cap, CS_CAP) : (uint32_t)CS_CAP);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_cx_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
+	MCOM_LAUNCH(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint64_t used = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &used, d_keys, 8));

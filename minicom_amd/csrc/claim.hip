@@ -68,8 +68,8 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 		if (rounds >= max_rounds) return mcom_fail(ctx, MCOM_E_OVERFLOW, "claiming did not settle in %d rounds", max_rounds);
 		MCOM_HIP(ctx, hipMemsetAsync(best, 0xFF, best_b, ctx->stream));
 		MCOM_HIP(ctx, hipMemsetAsync(live, 0, 4, ctx->stream));
-		hipLaunchKernelGGL(k_claim_bid, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_flag, dead, best, live);
-		hipLaunchKernelGGL(k_claim_take, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_flag, dead, best, sel);
+		MCOM_LAUNCH(k_claim_bid, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_flag, dead, best, live);
+		MCOM_LAUNCH(k_claim_take, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_flag, dead, best, sel);
 		MCOM_LAUNCH_CHECK(ctx);
 		unsigned int hl = 0;
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, &hl, live, 4));
@@ -84,7 +84,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nj, spre + n_pairs, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_nj = nj;
-	if (nj) hipLaunchKernelGGL(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs);
+	if (nj) MCOM_LAUNCH(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                                // the workspace is in use until here
 	return MCOM_OK;

@@ -333,7 +333,7 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	hipError_t er = hipMemsetAsync(big, 0, 4, ctx->stream);
 	if (er == hipSuccess) {
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-#define MCOM_GC(NU) case NU: hipLaunchKernelGGL((k_group_consensus_reg<NU>), dim3(n_rest), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
+#define MCOM_GC(NU) case NU: MCOM_LAUNCH((k_group_consensus_reg<NU>), dim3(n_rest), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
 	                   d_group_off, n_rest, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big, glist); break;
 		switch ((2 * L + 63) / 64) { MCOM_GC(1) MCOM_GC(2) MCOM_GC(3) MCOM_GC(4) MCOM_GC(5) MCOM_GC(6) MCOM_GC(7) MCOM_GC(8) default: er = hipErrorInvalidValue; }
 #undef MCOM_GC
@@ -344,7 +344,7 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	if (er == hipSuccess) er = mcom_stream_sync(ctx);
 	if (er == hipSuccess && hb) {                                            // groups of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-		hipLaunchKernelGGL((k_group_consensus<false>), dim3(n_rest), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
+		MCOM_LAUNCH((k_group_consensus<false>), dim3(n_rest), dim3(64), (size_t)(8 * 2 * L * 4 + 2 * L + 16), ctx->stream, d_packed, mcom_words_per_read(L), d_members,
 		                   d_group_off, n_rest, L, k_orig, e, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride, big, glist);
 		er = hipGetLastError();
 		if (er == hipSuccess) er = mcom_stream_sync(ctx);
@@ -502,14 +502,14 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	MCOM_HIP(ctx, mcom_dmalloc((void**)&big, 256));
 	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
 	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
-	hipLaunchKernelGGL(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+	MCOM_LAUNCH(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist); }
 	unsigned int hb = 0;
 	hipError_t e1 = mcom_d2h_async(ctx, &hb, big, 4);
 	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
 	if (e1 == hipSuccess && hb) {                                            // a job of 65535 members or more: 32-bit counters
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-		hipLaunchKernelGGL((k_merge_consensus<false>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+		MCOM_LAUNCH((k_merge_consensus<false>), dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist);
 		e1 = mcom_stream_sync(ctx);
 	}
@@ -549,12 +549,12 @@ extern "C" int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, cons
 	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
 	int rc = mcom_ws_reserve(ctx, scr_b);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_prefix_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n, m, d_out_moff);
+	MCOM_LAUNCH(k_prefix_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n, m, d_out_moff);
 	MCOM_LAUNCH_CHECK(ctx);
 	rc = mcom_scan_u32(ctx, d_out_moff, d_out_moff, n + 1, (uint32_t*)ctx->ws);
 	if (rc) return rc;
 	const size_t tot = n * (size_t)m;
-	hipLaunchKernelGGL(k_prefix_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_rec, n, m, d_out_moff, d_out);
+	MCOM_LAUNCH(k_prefix_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_rec, n, m, d_out_moff, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	if (h_total) {
 		uint32_t total = 0;

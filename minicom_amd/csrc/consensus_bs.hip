@@ -359,8 +359,8 @@ int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t
 	hipError_t er = hipMemsetAsync(bins, 0, 80 * 4, ctx->stream);
 	const unsigned blocks = (n_groups + 255) / 256;
 	if (er == hipSuccess) {
-		hipLaunchKernelGGL(k_bs_sizes, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins);
-		hipLaunchKernelGGL(k_bs_order, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins, cursor, perm);
+		MCOM_LAUNCH(k_bs_sizes, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins);
+		MCOM_LAUNCH(k_bs_order, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins, cursor, perm);
 		er = hipGetLastError();
 	}
 	uint32_t nbig = 0;
@@ -371,7 +371,7 @@ int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t
 	const int LG = (2 * L + 31) / 32, GPW = 64 / LG;
 	if (nsmall) {
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-		hipLaunchKernelGGL(k_group_consensus_bs, dim3((nsmall + GPW - 1) / GPW), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off, perm,
+		MCOM_LAUNCH(k_group_consensus_bs, dim3((nsmall + GPW - 1) / GPW), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_group_off, perm,
 		                   nsmall, L, k_orig, e, LG, GPW, d_keep, d_nkept, d_sv, d_reflen, d_refs, ref_stride);
 	}
 	er = hipGetLastError();
@@ -393,7 +393,7 @@ int mcom_merge_consensus_units(mcom_ctx *ctx, const uint64_t *d_packed, const ui
 	MCOM_HIP(ctx, hipMemsetAsync(d_tflag, 0, ((size_t)n_tiles + 1) * 4, ctx->stream));
 	{
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
-		hipLaunchKernelGGL(k_merge_consensus_bs, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
+		MCOM_LAUNCH(k_merge_consensus_bs, dim3((n_units + 63) / 64), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 		                   d_ujob, d_uoff, n_units, L, d_refs, d_reg_lo, d_reg_hi, d_toff, d_tflag, d_tlist, tcount,
 		                   ctx->bs_cap && ctx->bs_cap < (1u << BS_KM) ? ctx->bs_cap : (1u << BS_KM) - 1u);
 	}

@@ -435,12 +435,12 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	SkChunk *chunks = (SkChunk*)(base + slot_b + scr_b);
 	unsigned long long *cursor = (unsigned long long*)(base + slot_b + scr_b + chunk_b);
 	mcom_mm128 *tmp = (mcom_mm128*)(base + slot_b + scr_b + chunk_b + cur_b);
-	hipLaunchKernelGGL(k_sketch_slots, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_off_end, n, piece_off);
+	MCOM_LAUNCH(k_sketch_slots, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_off, d_off_end, n, piece_off);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, piece_off, piece_off, n + 1, scr))) return rc;
 	MCOM_HIP(ctx, hipMemsetAsync(chunks, 0, chunk_b + cur_b, ctx->stream));             // chunk table and the cursors behind it
 	{ McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
-	hipLaunchKernelGGL(k_sketch_contigs, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_seq, d_off, d_off_end, d_ids, n, w, k, limit, piece_off, chunks, tmp,
+	MCOM_LAUNCH(k_sketch_contigs, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_seq, d_off, d_off_end, d_ids, n, w, k, limit, piece_off, chunks, tmp,
 	                   arena_cap, arenas - 1, cursor, d_moff); }
 	MCOM_LAUNCH_CHECK(ctx);
 	// counts are in d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
@@ -458,7 +458,7 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 		return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", total, cap);
 	}
 	if (total == 0) return MCOM_OK;
-	hipLaunchKernelGGL(k_sketch_gather, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, ctx->stream, piece_off, chunks, tmp, n, d_moff, d_out);
+	MCOM_LAUNCH(k_sketch_gather, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, ctx->stream, piece_off, chunks, tmp, n, d_moff, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -548,7 +548,7 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 	const uint64_t blocks = (total_words + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
 	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
-	hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n);
+	MCOM_LAUNCH(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -578,9 +578,9 @@ extern "C" int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, con
 	const uint64_t blocks = (total_words + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
 	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
-	if (n_first) hipLaunchKernelGGL(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n_first);
+	if (n_first) MCOM_LAUNCH(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n_first);
 	const size_t nkeep = n - n_first;
-	if (nkeep) hipLaunchKernelGGL(k_packed_carry, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits_old, d_coff_old, d_keepidx, nkeep,
+	if (nkeep) MCOM_LAUNCH(k_packed_carry, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits_old, d_coff_old, d_keepidx, nkeep,
 	                              (size_t)n_first, d_coff, d_cbits);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -750,7 +750,7 @@ extern "C" int mcom_idx_get(mcom_ctx *ctx, const mcom_idx *mi, const uint64_t *d
 	if (!ctx || !mi) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_x || !d_start || !d_count) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_x, n, d_start, d_count);
+	MCOM_LAUNCH(k_idx_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_x, n, d_start, d_count);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -805,7 +805,7 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 	if (!ctx) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_cbits || !d_coff || !d_clen || !d_a || !d_pos_a || !d_b || !d_pos_b || !d_mismatch) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_match_pro, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits, d_coff, d_clen, d_a, d_pos_a, d_b, d_pos_b, n, d_mismatch);
+	MCOM_LAUNCH(k_match_pro, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits, d_coff, d_clen, d_a, d_pos_a, d_b, d_pos_b, n, d_mismatch);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -889,7 +889,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
-	hipLaunchKernelGGL(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, hits, first);
+	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
@@ -912,7 +912,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	rc = mcom_ws_reserve(ctx, scr2_b);
 	if (rc) { cleanup(); return rc; }
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
-	hipLaunchKernelGGL(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
+	MCOM_LAUNCH(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
 	uint32_t last_flag = 0, n_pass = 0;
 	e1 = mcom_d2h_async(ctx, &last_flag, pass + (n_pairs - 1), 4);
 	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
@@ -927,7 +927,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
-		hipLaunchKernelGGL(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
+		MCOM_LAUNCH(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
 		e1 = mcom_stream_sync(ctx);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}

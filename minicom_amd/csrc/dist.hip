@@ -19,7 +19,7 @@ extern "C" int mcom_min_fold_u64(mcom_ctx *ctx, const uint64_t *d_parts, int n_p
 	if (!ctx || n_parts < 1) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_parts || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_min_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)d_parts, n_parts, stride, n, (unsigned long long*)d_out);
+	MCOM_LAUNCH(k_min_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)d_parts, n_parts, stride, n, (unsigned long long*)d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -43,7 +43,7 @@ extern "C" int mcom_max_u16(mcom_ctx *ctx, const uint16_t *d_v, size_t n, uint32
 	uint32_t *d = (uint32_t*)ctx->ws;
 	MCOM_HIP(ctx, hipMemsetAsync(d, 0, 4, ctx->stream));
 	const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-	hipLaunchKernelGGL(k_max_u16, dim3(blocks), dim3(256), 0, ctx->stream, d_v, n, d);
+	MCOM_LAUNCH(k_max_u16, dim3(blocks), dim3(256), 0, ctx->stream, d_v, n, d);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_max, d, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
@@ -72,7 +72,7 @@ extern "C" int mcom_offsets_rebase(mcom_ctx *ctx, uint64_t *d_off, size_t n, uin
 	if (!ctx) return MCOM_E_ARG;
 	if (!n || !delta) return MCOM_OK;
 	if (!d_off) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_add_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_off, n, (unsigned long long)delta);
+	MCOM_LAUNCH(k_add_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_off, n, (unsigned long long)delta);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -81,12 +81,12 @@ extern "C" int mcom_records_rebase(mcom_ctx *ctx, mcom_mm128 *d_rec, size_t n_re
 	if (!ctx) return MCOM_E_ARG;
 	if (n_rec && first_contig) {
 		if (!d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-		hipLaunchKernelGGL(k_records_rebase, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n_rec, (unsigned long long)first_contig << 32);
+		MCOM_LAUNCH(k_records_rebase, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n_rec, (unsigned long long)first_contig << 32);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	if (n_off && first_record) {
 		if (!d_roff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-		hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, ctx->stream, d_roff, n_off, first_record);
+		MCOM_LAUNCH(k_add_u32, dim3((unsigned)((n_off + 255) / 256)), dim3(256), 0, ctx->stream, d_roff, n_off, first_record);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	return MCOM_OK;
@@ -130,8 +130,8 @@ extern "C" int mcom_digest(mcom_ctx *ctx, const void *d_data, size_t bytes, uint
 	MCOM_HIP(ctx, hipMemsetAsync(d, 0, 514 * 8, ctx->stream));
 	const size_t nw = bytes >> 3;
 	const unsigned blocks = (unsigned)(nw / 256 + 1 < 4096 ? nw / 256 + 1 : 4096);
-	hipLaunchKernelGGL(k_digest, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_data, bytes, d);
-	hipLaunchKernelGGL(k_digest_fold, dim3(1), dim3(1), 0, ctx->stream, d);
+	MCOM_LAUNCH(k_digest, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_data, bytes, d);
+	MCOM_LAUNCH(k_digest_fold, dim3(1), dim3(1), 0, ctx->stream, d);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_sum_xor, d + 512, 16));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));

@@ -97,20 +97,20 @@ extern "C" int mcom_members_finalize(mcom_ctx *ctx, const uint64_t *d_mem, const
 	int rc = mcom_ws_reserve(ctx, mcom_sort_ws_bytes(total));
 	if (rc) { mcom_dfree(rec); mcom_dfree(cnt); return rc;	}
 	const unsigned cblocks = (unsigned)((n_contigs + 1 + 255) / 256);
-	hipLaunchKernelGGL(k_mf_cnt0, dim3(cblocks), dim3(256), 0, ctx->stream, d_moff, n_contigs, cnt, cursor);
+	MCOM_LAUNCH(k_mf_cnt0, dim3(cblocks), dim3(256), 0, ctx->stream, d_moff, n_contigs, cnt, cursor);
 	for (int i = 0; i < n_passes; ++i)
-		if (h_app_n[i]) hipLaunchKernelGGL(k_mf_cnt, dim3((unsigned)((h_app_n[i] + 255) / 256)), dim3(256), 0, ctx->stream, d_app_contig[i], (size_t)h_app_n[i], cnt);
+		if (h_app_n[i]) MCOM_LAUNCH(k_mf_cnt, dim3((unsigned)((h_app_n[i] + 255) / 256)), dim3(256), 0, ctx->stream, d_app_contig[i], (size_t)h_app_n[i], cnt);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) {
 		rc = mcom_scan64(ctx, (const uint64_t*)cnt, d_moff2, n_contigs + 1, (uint64_t*)scr);
 		if (!rc) {
-			hipLaunchKernelGGL(k_mf_base, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, d_moff2, n_contigs, key_bits, rec);
+			MCOM_LAUNCH(k_mf_base, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, d_moff2, n_contigs, key_bits, rec);
 			for (int i = 0; i < n_passes; ++i) {
 				if (!h_app_n[i]) continue;
 				const unsigned blocks = (unsigned)((h_app_n[i] + 255) / 256);
-				hipLaunchKernelGGL(k_mf_app, dim3(blocks), dim3(256), 0, ctx->stream, d_app_contig[i], d_app_member[i], (size_t)h_app_n[i], key_bits,
+				MCOM_LAUNCH(k_mf_app, dim3(blocks), dim3(256), 0, ctx->stream, d_app_contig[i], d_app_member[i], (size_t)h_app_n[i], key_bits,
 				                   i == n_passes - 1 ? 1 : 0, d_moff2, cursor, rec);
-				hipLaunchKernelGGL(k_mf_advance, dim3(blocks), dim3(256), 0, ctx->stream, d_app_contig[i], (size_t)h_app_n[i], cursor);
+				MCOM_LAUNCH(k_mf_advance, dim3(blocks), dim3(256), 0, ctx->stream, d_app_contig[i], (size_t)h_app_n[i], cursor);
 			}
 			e = hipGetLastError();
 		}
@@ -118,7 +118,7 @@ extern "C" int mcom_members_finalize(mcom_ctx *ctx, const uint64_t *d_mem, const
 			const mcom_mm128 *sorted = (const mcom_mm128*)ctx->ws;
 			rc = mcom_sort_groups_by_x(ctx, rec, (mcom_mm128*)ctx->ws, (size_t)total, d_moff2, n_contigs, key_bits + cb, tiles);
 			if (!rc) {
-				hipLaunchKernelGGL(k_mf_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, sorted, (size_t)total, d_mem2);
+				MCOM_LAUNCH(k_mf_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, sorted, (size_t)total, d_mem2);
 				e = hipGetLastError();
 			}
 		}

@@ -253,7 +253,7 @@ int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_
 	if (fixed + cap * 3 > lds_max) cap = ((lds_max - fixed) / 3) & ~(size_t)7;
 	const size_t lds = fixed + cap * 3;
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort_tokens, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_flag_sort_tokens, dim3(nr), dim3(64), lds, ctx->stream, d_in, d_out, d_bstart, nr, (uint32_t)cap, d_overflow);
+	MCOM_LAUNCH(k_flag_sort_tokens, dim3(nr), dim3(64), lds, ctx->stream, d_in, d_out, d_bstart, nr, (uint32_t)cap, d_overflow);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -278,7 +278,7 @@ int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bs
 	if (fixed + cap * sizeof(mcom_mm128) > lds_max) cap = (lds_max - fixed) / sizeof(mcom_mm128);
 	const size_t lds = fixed + cap * sizeof(mcom_mm128);
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_flag_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_flag_sort, dim3(nr), dim3(64), lds, ctx->stream, d_rec, d_bstart, nr, (uint32_t)cap, d_overflow);
+	MCOM_LAUNCH(k_flag_sort, dim3(nr), dim3(64), lds, ctx->stream, d_rec, d_bstart, nr, (uint32_t)cap, d_overflow);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -286,7 +286,7 @@ int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bs
 int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bits, uint32_t *d_bstart)
 {
 	const uint32_t nb = 1u << bits;
-	hipLaunchKernelGGL(k_bucket_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n, (uint64_t)nb - 1, nb, d_bstart);
+	MCOM_LAUNCH(k_bucket_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n, (uint64_t)nb - 1, nb, d_bstart);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

@@ -92,7 +92,7 @@ extern "C" int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, 
 	uint32_t *scr = (uint32_t*)take(mcom_scan_scratch_elems(e) * 4 + 1024);
 	uint64_t *scr64 = (uint64_t*)take(mcom_scan64_scratch_elems(e) * 8);
 	const unsigned gb = (unsigned)((e + 255) / 256);
-	hipLaunchKernelGGL(k_group_sizes, dim3(gb), dim3(256), 0, ctx->stream, d_goff, d_nkept, d_reflen, ng, slot, msz, rsz, rej);
+	MCOM_LAUNCH(k_group_sizes, dim3(gb), dim3(256), 0, ctx->stream, d_goff, d_nkept, d_reflen, ng, slot, msz, rsz, rej);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, slot, slot, e, scr)) || (rc = mcom_scan_u32(ctx, msz, msz, e, scr)) || (rc = mcom_scan_u32(ctx, rej, rej, e, scr)) ||
 	    (rc = mcom_scan64(ctx, rsz, rsz, e, scr64))) return rc;
@@ -107,7 +107,7 @@ extern "C" int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, 
 		return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig set buffers too small for %u contigs, %llu chars, %u members, %u rejects", h32[0], (unsigned long long)chars, h32[1], h32[2]);
 	if (!d_seq || !d_soff || !d_mem || !d_moff || (h32[2] && (!d_rej_rid || !d_rej_group))) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (n_have == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_soff, 0, 8, ctx->stream)); MCOM_HIP(ctx, hipMemsetAsync(d_moff, 0, 8, ctx->stream)); }
-	hipLaunchKernelGGL(k_group_emit, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_members, d_goff, ng, d_keep, d_nkept, d_sv, d_reflen,
+	MCOM_LAUNCH(k_group_emit, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_members, d_goff, ng, d_keep, d_nkept, d_sv, d_reflen,
 	                   d_refs, ref_stride, slot, msz, rsz, rej, n_have, chars_have, members_have, d_seq, d_soff, d_mem, d_moff, d_rej_rid, d_rej_group);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                      // the workspace arrays are in use until here

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/mcom.h"
@@ -24,6 +25,10 @@ struct mcom_ctx {
 	std::vector<McomProfSpan> prof_open;
 	double prof_ms[PROF_COUNT] = {0};
 	uint64_t prof_calls[PROF_COUNT] = {0};
+	// which kernels were launched, how often, and inside which timed class (PROF_COUNT = outside any): keyed by the address of the
+	// instantiation's name string (MCOM_LAUNCH), so that a caller can ask for the EXACT kernels a class's time belongs to
+	int prof_cur = PROF_COUNT;
+	std::map<std::pair<int, const char *>, uint64_t> prof_kernels;
 	// bucket sort: capacity of an in-LDS segment (0 = the kernel's own 4096; tests lower it to reach the fallback on small
 	// inputs) and how many segments went through the fallback so far
 	uint32_t seg_cap = 0; uint64_t sort_overflow_segments = 0;
@@ -58,9 +63,18 @@ struct McomProfScope {
 		if (!(s.b = mcom_prof_event_get())) { mcom_prof_event_put(s.a); return; }
 		(void)hipEventRecord(s.a, c->stream);
 		c->prof_open.push_back(s); idx = (int)c->prof_open.size() - 1;
+		prev = c->prof_cur; c->prof_cur = id;
 	}
-	~McomProfScope() { if (idx >= 0) (void)hipEventRecord(ctx->prof_open[idx].b, ctx->stream); }
+	~McomProfScope() { if (idx >= 0) { (void)hipEventRecord(ctx->prof_open[idx].b, ctx->stream); ctx->prof_cur = prev; } }
+	int prev = PROF_COUNT;
 };
+// Every kernel launch of the library goes through MCOM_LAUNCH: hipLaunchKernelGGL, plus -- while the profiler is on -- a tally of
+// the kernel's name under the class whose scope is open.  The name is the compiler's own spelling of the instantiation
+// ("... [K = &k_sketch_reads<5, true, true>]"), which is what rocprofv3 prints for the same kernel.
+template <auto K> const char *mcom_kernel_name() { return __PRETTY_FUNCTION__; }
+#define MCOM_LAUNCH(kernel, grid, block, lds, stream, ...) do { \
+	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, mcom_kernel_name<&kernel>())]; \
+	hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
 // A count or a flag back to the host costs a round trip; into pageable memory (a local variable) the runtime stages it and the

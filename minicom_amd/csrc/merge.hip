@@ -54,12 +54,12 @@ static int scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, ui
 {
 	if (n == 0) return MCOM_OK;
 	const size_t nb = (n + S64_TILE - 1) / S64_TILE;
-	hipLaunchKernelGGL(k_scan64_tile, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
+	MCOM_LAUNCH(k_scan64_tile, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
 	MCOM_LAUNCH_CHECK(ctx);
 	if (nb > 1) {
 		int rc = scan64(ctx, scratch, scratch, nb, scratch + nb);
 		if (rc) return rc;
-		hipLaunchKernelGGL(k_scan64_add, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, out, n, scratch);
+		MCOM_LAUNCH(k_scan64_add, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, out, n, scratch);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	return MCOM_OK;
@@ -106,7 +106,7 @@ extern "C" int mcom_contig_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	if (!d_soff || !d_clen) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(n + 1) * 8) + 256);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_layout, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, d_coff_words, d_clen);
+	MCOM_LAUNCH(k_layout, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, d_coff_words, d_clen);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_coff_words, d_coff_words, n + 1, (uint64_t*)ctx->ws))) return rc;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_total_words, d_coff_words + n, 8));
@@ -137,7 +137,7 @@ extern "C" int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	if (rc) return rc;
 	unsigned long long *mx = (unsigned long long*)((char*)ctx->ws + al256(scan64_scratch_elems(n + 1) * 8));
 	MCOM_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
-	hipLaunchKernelGGL(k_window_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, L, d_woff, mx);
+	MCOM_LAUNCH(k_window_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, L, d_woff, mx);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_woff, d_woff, n + 1, (uint64_t*)ctx->ws))) return rc;
 	unsigned long long hm = 0;
@@ -226,7 +226,7 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(nj + 1) * 8) + 1024);
 	if (rc) return rc;
 	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
-	hipLaunchKernelGGL(k_job_counts, dim3(jblocks), dim3(256), 0, ctx->stream, jobs, nj, d_moff, d_jmoff);
+	MCOM_LAUNCH(k_job_counts, dim3(jblocks), dim3(256), 0, ctx->stream, jobs, nj, d_moff, d_jmoff);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_jmoff, d_jmoff, nj + 1, (uint64_t*)ctx->ws))) return rc;
 	uint64_t total = 0;
@@ -242,7 +242,7 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	uint32_t *tiles = w.take<uint32_t>(MCOM_GROUP_SCRATCH(total));
 	unsigned long long *meta = w.take<unsigned long long>(4);               // [0] maxlen, [1] error flag
 	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 32, ctx->stream));
-	hipLaunchKernelGGL(k_job_fill, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
+	MCOM_LAUNCH(k_job_fill, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
 	                   (unsigned int*)(meta + 1));
 	MCOM_LAUNCH_CHECK(ctx);
 	{
@@ -251,8 +251,8 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 		if ((rc = mcom_sort_groups_by_x(ctx, rec, sorted, total, d_jmoff, nj, key_bits + jb, tiles))) return rc;
 		rec = sorted;
 	}
-	hipLaunchKernelGGL(k_job_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rec, (size_t)total, d_jm);
-	hipLaunchKernelGGL(k_job_len, dim3(jblocks), dim3(256), 0, ctx->stream, rec, d_jmoff, nj, L, d_jroff, meta);
+	MCOM_LAUNCH(k_job_emit, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rec, (size_t)total, d_jm);
+	MCOM_LAUNCH(k_job_len, dim3(jblocks), dim3(256), 0, ctx->stream, rec, d_jmoff, nj, L, d_jroff, meta);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_jroff, d_jroff, nj + 1, scr))) return rc;
 	unsigned long long hm[2] = {0, 0}; uint64_t chars = 0;
@@ -348,8 +348,8 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	uint32_t *tjob = w.take<uint32_t>(max_tiles + 1), *tidx = w.take<uint32_t>(max_tiles + 1), *tflag = w.take<uint32_t>(max_tiles + 1), *tlist = w.take<uint32_t>(max_tiles + 1);
 	uint32_t *ujob = w.take<uint32_t>(max_units);
 	const unsigned jblocks = (unsigned)((nj + 1 + 255) / 256);
-	if (regions) hipLaunchKernelGGL(k_job_regions, dim3(jblocks), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, olo, ohi, toff, uoff);
-	else hipLaunchKernelGGL(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff, uoff);
+	if (regions) MCOM_LAUNCH(k_job_regions, dim3(jblocks), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, olo, ohi, toff, uoff);
+	else MCOM_LAUNCH(k_tile_counts, dim3(jblocks), dim3(256), 0, ctx->stream, d_jroff, nj, toff, uoff);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, toff, toff, nj + 1, scr))) return rc;
 	if ((rc = mcom_scan_u32(ctx, uoff, uoff, nj + 1, scr))) return rc;
@@ -361,8 +361,8 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 	if (nu) {
 		// units of 32 columns through the bit-sliced kernel; the tiles it hands back (a unit that more than 127 members reach) through
 		// the wave-per-tile kernel
-		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, uoff, nj, ujob, (uint32_t*)nullptr);
-		hipLaunchKernelGGL(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
+		MCOM_LAUNCH(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, uoff, nj, ujob, (uint32_t*)nullptr);
+		MCOM_LAUNCH(k_tile_fill, dim3(jblocks), dim3(256), 0, ctx->stream, toff, nj, tjob, tidx);
 		MCOM_LAUNCH_CHECK(ctx);
 		uint32_t nlist = 0;
 		if ((rc = mcom_merge_consensus_units(ctx, d_packed, d_jm, d_jmoff, d_jroff, ujob, uoff, nu, L, d_refs, regions ? olo : nullptr, regions ? ohi : nullptr,
@@ -371,7 +371,7 @@ extern "C" int mcom_merge_consensus_jobs(mcom_ctx *ctx, const uint64_t *d_packed
 			return rc;
 	}
 	if (regions) {
-		hipLaunchKernelGGL(k_merge_copy, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
+		MCOM_LAUNCH(k_merge_copy, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_seq, d_soff, d_jroff, olo, ohi, d_refs);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                        // the workspace arrays are in use until here
@@ -402,10 +402,10 @@ extern "C" int mcom_compact_live(mcom_ctx *ctx, const uint32_t *d_ids, const uin
 	WsCut w{(char*)ctx->ws, 0};
 	uint32_t *at = w.take<uint32_t>(n + 1);
 	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(n + 1) + 256);
-	hipLaunchKernelGGL(k_live_flags, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_flag, n, at);
+	MCOM_LAUNCH(k_live_flags, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_flag, n, at);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, at, at, n + 1, scr))) return rc;
-	hipLaunchKernelGGL(k_live_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, at, n, d_out);
+	MCOM_LAUNCH(k_live_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, at, n, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t cnt = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &cnt, at + n, 4));
@@ -431,7 +431,7 @@ extern "C" int mcom_list_flagged(mcom_ctx *ctx, const uint32_t *d_ids, const uin
 	MCOM_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
 	if (n == 0) return MCOM_OK;
 	if (!d_ids || !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_list_flagged, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, n, d_out, cap, d_count);
+	MCOM_LAUNCH(k_list_flagged, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ids, d_flag, n, d_out, cap, d_count);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -502,19 +502,19 @@ extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uin
 		uint64_t *ss = w.take<uint64_t>(nkeep + 1), *ms = w.take<uint64_t>(nkeep + 1);
 		uint64_t *scr64 = w.take<uint64_t>(scan64_scratch_elems(nkeep + 1));
 		const unsigned nb = (unsigned)((n + 1 + 255) / 256), kb = (unsigned)((nkeep + 1 + 255) / 256);
-		hipLaunchKernelGGL(k_keep_flags, dim3(nb), dim3(256), 0, ctx->stream, d_flag, n, kf);
+		MCOM_LAUNCH(k_keep_flags, dim3(nb), dim3(256), 0, ctx->stream, d_flag, n, kf);
 		MCOM_LAUNCH_CHECK(ctx);
 		if ((rc = mcom_scan_u32(ctx, kf, kf, n + 1, scr))) return rc;
 		uint32_t have = 0;
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, &have, kf + n, 4));
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 		if (have != nkeep) return mcom_fail(ctx, MCOM_E_ARG, "%u contigs unflagged but %zu announced", have, nkeep);
-		hipLaunchKernelGGL(k_keep_index, dim3(nb), dim3(256), 0, ctx->stream, d_flag, kf, n, d_keepidx);
-		hipLaunchKernelGGL(k_keep_sizes, dim3(kb), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_soff, d_moff, ss, ms);
+		MCOM_LAUNCH(k_keep_index, dim3(nb), dim3(256), 0, ctx->stream, d_flag, kf, n, d_keepidx);
+		MCOM_LAUNCH(k_keep_sizes, dim3(kb), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_soff, d_moff, ss, ms);
 		MCOM_LAUNCH_CHECK(ctx);
 		if ((rc = scan64(ctx, ss, ss, nkeep + 1, scr64)) || (rc = scan64(ctx, ms, ms, nkeep + 1, scr64))) return rc;
-		hipLaunchKernelGGL(k_keep_offsets, dim3(kb), dim3(256), 0, ctx->stream, ss, ms, nkeep, nj, d_soff2, d_moff2);
-		hipLaunchKernelGGL(k_keep_copy, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, nj, d_seq, d_soff, d_mem, d_moff,
+		MCOM_LAUNCH(k_keep_offsets, dim3(kb), dim3(256), 0, ctx->stream, ss, ms, nkeep, nj, d_soff2, d_moff2);
+		MCOM_LAUNCH(k_keep_copy, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, nj, d_seq, d_soff, d_mem, d_moff,
 		                   d_seq2, d_soff2, d_mem2, d_moff2);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
@@ -562,7 +562,7 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	WsCut w{(char*)ctx->ws, 0};
 	uint32_t *sc = w.take<uint32_t>(nkeep + 1);
 	uint32_t *scr = w.take<uint32_t>(mcom_scan_scratch_elems(nkeep + 1) + 256);
-	hipLaunchKernelGGL(k_carry_counts, dim3((unsigned)((nkeep + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_roff, sc);
+	MCOM_LAUNCH(k_carry_counts, dim3((unsigned)((nkeep + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_roff, sc);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, sc, sc, nkeep + 1, scr))) return rc;
 	uint32_t kept = 0;
@@ -570,7 +570,7 @@ extern "C" int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const 
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = (uint64_t)base + kept;
 	if ((uint64_t)base + kept > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu minimizers but room for %zu", (unsigned long long)base + kept, cap2);
-	hipLaunchKernelGGL(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,
+	MCOM_LAUNCH(k_carry_copy, dim3((unsigned)(((nkeep + 1) * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_keepidx, nkeep, d_rec, d_roff, sc, first_id, base,
 	                   d_rec2, d_roff2);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;

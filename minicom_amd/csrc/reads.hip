@@ -484,8 +484,8 @@ static int launch_sketch(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t
 {
 	const int W = mcom_words_per_read(L);
 	const unsigned blocks = (unsigned)((n + 255) / 256);
-#define MCOM_CASE(WW) case WW: if (k & 1) hipLaunchKernelGGL((k_sketch_reads<WW, WIDE, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); \
-	else hipLaunchKernelGGL((k_sketch_reads<WW, WIDE, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
+#define MCOM_CASE(WW) case WW: if (k & 1) MCOM_LAUNCH((k_sketch_reads<WW, WIDE, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); \
+	else MCOM_LAUNCH((k_sketch_reads<WW, WIDE, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_rids, n, L, k, rid0, d_rec); break;
 	McomProfScope ps_(ctx, PROF_SKETCH_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported (1..256)", L); }
@@ -520,7 +520,7 @@ extern "C" int mcom_hash64_batch(mcom_ctx *ctx, const uint64_t *d_kmer, size_t n
 	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
 	if (n == 0) return MCOM_OK;
 	if (!d_kmer || !d_hash) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_hash64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_kmer, n, k, d_hash);
+	MCOM_LAUNCH(k_hash64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_kmer, n, k, d_hash);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -548,17 +548,17 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 		size_t fb = (chunks + 3) / 4;
 		if (fb > (size_t)ctx->n_cu * 8) fb = (size_t)ctx->n_cu * 8;
 		const size_t lds = 4 * (size_t)(4 * L + 2 * L + 8) * 4;
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_classify_flat<WW>), dim3((unsigned)fb), dim3(256), lds, ctx->stream, d_ascii, n, L, e, d_packed, d_cls, d_ncnt, d_nmask); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_classify_flat<WW>), dim3((unsigned)fb), dim3(256), lds, ctx->stream, d_ascii, n, L, e, d_packed, d_cls, d_ncnt, d_nmask); break;
 		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported", L); }
 #undef MCOM_CASE
 	} else
 	{ McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
-	if (L <= 128) hipLaunchKernelGGL((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
-	else          hipLaunchKernelGGL(k_classify_pack16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
+	if (L <= 128) MCOM_LAUNCH((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
+	else          MCOM_LAUNCH(k_classify_pack16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
 	MCOM_LAUNCH_CHECK(ctx);
 	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_mask_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_rec);
+	MCOM_LAUNCH(k_mask_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_rec);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -581,7 +581,7 @@ extern "C" int mcom_synth_reads_genome(mcom_ctx *ctx, uint64_t seed, uint64_t n_
 	uint64_t blocks = (count * (uint64_t)L + 255) / 256;
 	const uint64_t cap = (uint64_t)ctx->n_cu * 32;
 	if (blocks > cap) blocks = cap;
-	hipLaunchKernelGGL(k_synth_reads, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, G, L, thr, first, count, d_ascii, pitch, genome_kind);
+	MCOM_LAUNCH(k_synth_reads, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, G, L, thr, first, count, d_ascii, pitch, genome_kind);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -606,7 +606,7 @@ extern "C" int mcom_records_assemble(mcom_ctx *ctx, const uint64_t *d_x, const u
 	if (n == 0) return MCOM_OK;
 	if (!d_x || !d_ylow || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if ((uint64_t)rid0 + n > (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "read ids exceed 32 bits");
-	hipLaunchKernelGGL(k_records_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x, d_ylow, n, rid0, d_rec);
+	MCOM_LAUNCH(k_records_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x, d_ylow, n, rid0, d_rec);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

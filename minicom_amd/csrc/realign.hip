@@ -71,7 +71,7 @@ extern "C" int mcom_gather_rows(mcom_ctx *ctx, const uint64_t *d_packed, const u
 	if (!d_packed || !d_rids || !d_out || L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "bad gather arguments");
 	const int W = mcom_words_per_read(L);
 	const size_t tot = n * (size_t)W;
-	hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d_rids, n, W, d_out);
+	MCOM_LAUNCH(k_gather_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d_rids, n, W, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -117,7 +117,7 @@ extern "C" int mcom_poly_filter(mcom_ctx *ctx, const uint64_t *d_sgbits, const u
 	if (!ctx) return MCOM_E_ARG;
 	if (n_sg == 0) return MCOM_OK;
 	if (!d_sgbits || !d_flag || L < 1 || L > 256 || (d_nmask && !d_rids)) return mcom_fail(ctx, MCOM_E_ARG, "bad poly filter arguments");
-	hipLaunchKernelGGL(k_poly_filter, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d_nmask, d_rids, n_sg, L,
+	MCOM_LAUNCH(k_poly_filter, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d_nmask, d_rids, n_sg, L,
 	                   mcom_words_per_read(L), (L + 63) / 64, thr, d_flag);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -176,10 +176,10 @@ extern "C" int mcom_dicts_build(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t 
 		hipError_t e2 = mcom_dmalloc(&d->ids[j], (n ? n : 1) * 4);
 		if (e2 != hipSuccess) { d->ids[j] = nullptr; mcom_dicts_free(ctx, d); return mcom_fail(ctx, MCOM_E_NOMEM, "dictionary %d: out of device memory", j); }
 		if (n) {
-			hipLaunchKernelGGL(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
+			MCOM_LAUNCH(k_dict_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_sgbits, n, d->W, d->ds[j], d->kl[j], rec);
 			rc = mcom_sort_by_x(ctx, rec, n, 2 * d->kl[j], sortws);
 			if (rc) { mcom_dicts_free(ctx, d); return rc; }
-			hipLaunchKernelGGL(k_dict_ids, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, d->ids[j]);
+			MCOM_LAUNCH(k_dict_ids, dim3(blocks), dim3(256), 0, ctx->stream, rec, n, d->ids[j]);
 		}
 		McomTable t;
 		rc = mcom_table_build(ctx, rec, n, head, scr, meta, &t);
@@ -217,7 +217,7 @@ extern "C" int mcom_dicts_lookup(mcom_ctx *ctx, const mcom_dicts *d, int dict, c
 	if (!ctx || !d) return MCOM_E_ARG;
 	if (dict < 0 || dict >= d->nd) return mcom_fail(ctx, MCOM_E_ARG, "dictionary %d out of range", dict);
 	if (n == 0) return MCOM_OK;
-	hipLaunchKernelGGL(k_dict_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d->slots[dict], d->log2cap[dict], d_keys, n, d_start, d_count);
+	MCOM_LAUNCH(k_dict_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d->slots[dict], d->log2cap[dict], d_keys, n, d_start, d_count);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -349,7 +349,7 @@ extern "C" int mcom_realign_pass(mcom_ctx *ctx, const mcom_dicts *d, const uint6
 	for (int j = 0; j < d->nd; ++j) { dd.ds[j] = d->ds[j]; dd.kl[j] = d->kl[j]; dd.slots[j] = d->slots[j]; dd.log2cap[j] = d->log2cap[j]; dd.ids[j] = d->ids[j]; }
 	const uint64_t blocks = (n_windows + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many windows for one launch");
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_realign_windows<WW>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dd, d_sgbits, d_sgflag, d_cbits, d_coff, d_woff, n_contigs, n_windows, thr, maxsearch, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_realign_windows<WW>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dd, d_sgbits, d_sgflag, d_cbits, d_coff, d_woff, n_contigs, n_windows, thr, maxsearch, (unsigned long long*)d_claim, (unsigned long long*)d_stats); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_WINDOWS);
 	switch (d->W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
@@ -397,7 +397,7 @@ extern "C" int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uin
 	if (!d_sgbits || !d_elig || maxsearch < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad eligibility arguments");
 	MCOM_HIP(ctx, hipMemsetAsync(d_elig, 0, d->n_sg * 4, ctx->stream));
 	for (int l = 0; l < d->nd; ++l)
-		hipLaunchKernelGGL(k_dict_eligible, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
+		MCOM_LAUNCH(k_dict_eligible, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
 		                   d->slots[l], d->log2cap[l], d->ds[l], d->kl[l], l, (uint32_t)maxsearch, d_elig);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -626,19 +626,19 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t 
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 #define MCOM_ARGS g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count
-#define MCOM_LAUNCH(WW, GG, TT) do { if (g.n_owners > 1) hipLaunchKernelGGL((k_realign_reads<WW, GG, TT, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
-	else hipLaunchKernelGGL((k_realign_reads<WW, GG, TT, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)
+#define MCOM_RA_LAUNCH(WW, GG, TT) do { if (g.n_owners > 1) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else MCOM_LAUNCH((k_realign_reads<WW, GG, TT, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)
 #define MCOM_CASE(WW) case WW: \
-	if (d_mark) { if (G == 16) MCOM_LAUNCH(WW, 16, true); else MCOM_LAUNCH(WW, 32, true); } \
-	else if (G == 16) MCOM_LAUNCH(WW, 16, false); else MCOM_LAUNCH(WW, 32, false); break;
+	if (d_mark) { if (G == 16) MCOM_RA_LAUNCH(WW, 16, true); else MCOM_RA_LAUNCH(WW, 32, true); } \
+	else if (G == 16) MCOM_RA_LAUNCH(WW, 16, false); else MCOM_RA_LAUNCH(WW, 32, false); break;
 	McomProfScope ps_(ctx, PROF_REALIGN_READS);
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
-#undef MCOM_LAUNCH
+#undef MCOM_RA_LAUNCH
 #undef MCOM_ARGS
 	MCOM_LAUNCH_CHECK(ctx);
-	if (d_stats) hipLaunchKernelGGL(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
+	if (d_stats) MCOM_LAUNCH(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
 	return MCOM_OK;
 }
 
@@ -675,7 +675,7 @@ extern "C" int mcom_encode_byte(mcom_ctx *ctx, const uint64_t *d_rows, const uin
 	if (n == 0) return MCOM_OK;
 	if (!d_rows || !d_cbits || !d_coff || !d_contig || !d_pos || !d_dir || !d_ok) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const unsigned blocks = (unsigned)((n + 255) / 256);
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_encode_byte<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_rows, d_cbits, d_coff, d_contig, d_pos, d_dir, n, L, d_ok); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_encode_byte<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_rows, d_cbits, d_coff, d_contig, d_pos, d_dir, n, L, d_ok); break;
 	switch (mcom_words_per_read(L)) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 	default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
@@ -709,7 +709,7 @@ extern "C" int mcom_dicts_bigbins(mcom_ctx *ctx, const mcom_dicts *d, const uint
 	if (!d_sgbits || !d_binstart || !d_mark || maxsearch < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad arguments");
 	MCOM_HIP(ctx, hipMemsetAsync(d_mark, 0, d->n_sg, ctx->stream));
 	for (int l = 0; l < d->nd; ++l)
-		hipLaunchKernelGGL(k_dict_bigbins, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
+		MCOM_LAUNCH(k_dict_bigbins, dim3((unsigned)((d->n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgbits, d->W, d->ids[l], d->n_sg,
 		                   d->slots[l], d->log2cap[l], d->ds[l], d->kl[l], (uint32_t)maxsearch, d_binstart + (size_t)l * d->n_sg, d_mark);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -753,7 +753,7 @@ extern "C" int mcom_claims_patch(mcom_ctx *ctx, uint64_t *d_claim, const uint32_
 	if (!ctx) return MCOM_E_ARG;
 	if (n == 0) return MCOM_OK;
 	if (!d_claim || !d_idx || !d_val) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_claims_patch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_claim, d_idx,
+	MCOM_LAUNCH(k_claims_patch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (unsigned long long*)d_claim, d_idx,
 	                   (const unsigned long long*)d_val, n);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
@@ -808,7 +808,7 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	if (rc) return rc;
 	uint32_t *f = (uint32_t*)ctx->ws, *scr = (uint32_t*)((char*)ctx->ws + f_b);
 	const unsigned blocks = (unsigned)((n_sg + 1 + 255) / 256);
-	hipLaunchKernelGGL(k_claim_flags, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f);
+	MCOM_LAUNCH(k_claim_flags, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, f, f, n_sg + 1, scr))) return rc;
 	uint32_t nw = 0;
@@ -821,9 +821,9 @@ extern "C" int mcom_claims_resolve(mcom_ctx *ctx, const uint64_t *d_claim, const
 	char *blk = nullptr;
 	if (mcom_dmalloc(&blk, rec_b + mcom_sort_ws_bytes(nw)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "claim records");
 	mcom_mm128 *rec = (mcom_mm128*)blk;
-	hipLaunchKernelGGL(k_claim_records, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f, rec);
+	MCOM_LAUNCH(k_claim_records, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)d_claim, n_sg, f, rec);
 	rc = mcom_sort_by_x(ctx, rec, nw, kb, blk + rec_b);
-	if (!rc) hipLaunchKernelGGL(k_claim_emit, dim3((nw + 255) / 256), dim3(256), 0, ctx->stream, rec, (size_t)nw, d_rids, d_flag, d_app_contig, d_app_member);
+	if (!rc) MCOM_LAUNCH(k_claim_emit, dim3((nw + 255) / 256), dim3(256), 0, ctx->stream, rec, (size_t)nw, d_rids, d_flag, d_app_contig, d_app_member);
 	hipError_t e = hipGetLastError();
 	if (e == hipSuccess) e = mcom_stream_sync(ctx);
 	mcom_dfree(blk);
@@ -878,8 +878,8 @@ extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_s
 	const uint64_t blocks = (nkeys + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
-	hipLaunchKernelGGL(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag, (uint32_t)n_shares, (uint32_t)share);
-	hipLaunchKernelGGL(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
+	MCOM_LAUNCH(k_bin_screen, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, (uint32_t)maxsearch, table, flag, (uint32_t)n_shares, (uint32_t)share);
+	MCOM_LAUNCH(k_bin_screen_max, dim3((unsigned)((((size_t)1 << lg) + 255) / 256)), dim3(256), 0, ctx->stream, table, (size_t)1 << lg, (uint32_t)maxsearch, flag); }
 	MCOM_LAUNCH_CHECK(ctx);
 	ctx->screen_flag = flag;
 	return MCOM_OK;

@@ -140,7 +140,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	RsCut *cut = b_cut.get<RsCut>(nj);
 	if (!plan || !seg_start || !seg_end || !d_chars || !smoff || !cut) return mcom_fail(ctx, MCOM_E_NOMEM, "resketch buffers");
 	MCOM_HIP(ctx, hipMemsetAsync(d_chars, 0, 8, ctx->stream));
-	hipLaunchKernelGGL(k_rs_plan, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, d_soff2, w, k, plan, seg_start,
+	MCOM_LAUNCH(k_rs_plan, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, d_soff2, w, k, plan, seg_start,
 	                   seg_end, d_chars);
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned long long seg_chars = 0;
@@ -161,7 +161,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	}
 	int rc = mcom_ws_reserve(ctx, (mcom_scan_scratch_elems(nj + 1) + 256) * 4 + 1024);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_rs_count, dim3((unsigned)((nj + 1 + 255) / 256)), dim3(256), 0, ctx->stream, plan, nj, d_rec, d_roff, srec, smoff, cut, d_roff2);
+	MCOM_LAUNCH(k_rs_count, dim3((unsigned)((nj + 1 + 255) / 256)), dim3(256), 0, ctx->stream, plan, nj, d_rec, d_roff, srec, smoff, cut, d_roff2);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, d_roff2, d_roff2, nj + 1, (uint32_t*)ctx->ws))) return rc;
 	uint32_t total = 0;
@@ -169,7 +169,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = total;
 	if (total > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap2);
-	hipLaunchKernelGGL(k_rs_write, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
+	MCOM_LAUNCH(k_rs_write, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                          // the temporaries go back to the pool
 	return MCOM_OK;

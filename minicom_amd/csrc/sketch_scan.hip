@@ -567,11 +567,11 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	uint32_t *bins = (uint32_t*)(b0 + 5 * n4 + scr_b), *cursor = bins + SSC_BINS, *start = cursor + SSC_BINS, *misc = start + SSC_BINS;   // misc[0] longest, [1] overflowed strings
 	mcom_mm128 *tmp = (mcom_mm128*)(b0 + head);
 	MCOM_HIP(ctx, hipMemsetAsync(bins, 0, (3 * SSC_BINS + 16) * 4, ctx->stream));
-	hipLaunchKernelGGL(k_ssc_prepare, dim3((nn + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
+	MCOM_LAUNCH(k_ssc_prepare, dim3((nn + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, room, base, n + 1, scr))) return rc;
-	hipLaunchKernelGGL(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
-	hipLaunchKernelGGL(k_ssc_order, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
+	MCOM_LAUNCH(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
+	MCOM_LAUNCH(k_ssc_order, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
 	uint32_t h2[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[0], misc, 4));
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[1], base + n, 4));
@@ -583,14 +583,14 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	const bool ring16 = ring32 && ctx->sketch_prefix_bits <= 14 && !ctx->sketch_ring32_only;             // 16-bit ring words hold prefixes of up to 14 bits
 	const int pb = ctx->sketch_prefix_bits;
 #define SSC_LAUNCH(blocks, ...) do { \
-	if (ring16 && wide) hipLaunchKernelGGL((k_sketch_scan32<true, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
-	else if (ring16) hipLaunchKernelGGL((k_sketch_scan32<false, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
-	else if (ring32 && wide) hipLaunchKernelGGL((k_sketch_scan32<true, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
-	else if (ring32) hipLaunchKernelGGL((k_sketch_scan32<false, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
-	else if (oddk && wide) hipLaunchKernelGGL((k_sketch_scan<true, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
-	else if (oddk) hipLaunchKernelGGL((k_sketch_scan<true, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
-	else if (wide) hipLaunchKernelGGL((k_sketch_scan<false, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
-	else hipLaunchKernelGGL((k_sketch_scan<false, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); } while (0)
+	if (ring16 && wide) MCOM_LAUNCH((k_sketch_scan32<true, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring16) MCOM_LAUNCH((k_sketch_scan32<false, uint16_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring32 && wide) MCOM_LAUNCH((k_sketch_scan32<true, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (ring32) MCOM_LAUNCH((k_sketch_scan32<false, uint32_t>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__, pb); \
+	else if (oddk && wide) MCOM_LAUNCH((k_sketch_scan<true, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else if (oddk) MCOM_LAUNCH((k_sketch_scan<true, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else if (wide) MCOM_LAUNCH((k_sketch_scan<false, true>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); \
+	else MCOM_LAUNCH((k_sketch_scan<false, false>), dim3(blocks), dim3(64), lds, ctx->stream, __VA_ARGS__); } while (0)
 	const size_t lds = ring16 ? (size_t)w * 64 * 2 + (size_t)w * 64 : ring32 ? (size_t)w * 64 * 4 + (size_t)w * 64 : (size_t)w * SSC_STRIDE * 8 + (oddk ? 0 : (size_t)w * 64 * 2) + (size_t)w * 64;
 	{
 		McomProfScope ps_(ctx, PROF_SKETCH_CONTIGS);
@@ -608,9 +608,9 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	if (total == 0) return MCOM_OK;
 	{
 		const dim3 gb((unsigned)(((size_t)nn * 4 + 255) / 256));
-		if (!ring32) hipLaunchKernelGGL(k_ssc_gather<0>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
-		else if (wide) hipLaunchKernelGGL(k_ssc_gather<2>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
-		else hipLaunchKernelGGL(k_ssc_gather<1>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+		if (!ring32) MCOM_LAUNCH(k_ssc_gather<0>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+		else if (wide) MCOM_LAUNCH(k_ssc_gather<2>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
+		else MCOM_LAUNCH(k_ssc_gather<1>, gb, dim3(256), 0, ctx->stream, tmp, base, room, cnt, d_moff, nn, d_out, over, misc + 1, d_seq, d_off, k);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t n_over = 0;
@@ -622,8 +622,8 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 		MCOM_LAUNCH_CHECK(ctx);
 		if (ring32) {                                                        // (the gather made the hashes of the others; these went straight into place)
 			const unsigned fb = (unsigned)(((size_t)n_over * 4 + 255) / 256);
-			if (wide) hipLaunchKernelGGL(k_ssc_fill_x<true>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
-			else hipLaunchKernelGGL(k_ssc_fill_x<false>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
+			if (wide) MCOM_LAUNCH(k_ssc_fill_x<true>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
+			else MCOM_LAUNCH(k_ssc_fill_x<false>, dim3(fb), dim3(256), 0, ctx->stream, d_seq, d_off, over, n_over, d_moff, k, d_out);
 			MCOM_LAUNCH_CHECK(ctx);
 		}
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));

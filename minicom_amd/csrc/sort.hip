@@ -349,12 +349,12 @@ static int scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, 
 {
 	if (n == 0) return MCOM_OK;
 	const size_t nb = (n + SC_TILE - 1) / SC_TILE;
-	hipLaunchKernelGGL(k_scan_tile, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
+	MCOM_LAUNCH(k_scan_tile, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
 	MCOM_LAUNCH_CHECK(ctx);
 	if (nb > 1) {
 		int rc = scan_u32(ctx, scratch, scratch, nb, scratch + nb);
 		if (rc) return rc;
-		hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, out, n, scratch);
+		MCOM_LAUNCH(k_scan_add, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, out, n, scratch);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	return MCOM_OK;
@@ -373,11 +373,11 @@ static int radix_sort_records(mcom_ctx *ctx, mcom_mm128 *a, mcom_mm128 *tmp, siz
 	mcom_mm128 *src = a, *dst = tmp;
 	for (int p = 0; p < passes; ++p) {
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
-		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, ks, p, hist, nblocks);
+		MCOM_LAUNCH(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, ks, p, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 		int rc = scan_u32(ctx, hist, hist, (size_t)256 * nblocks, scratch);
 		if (rc) return rc;
-		hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, ks, p, hist, nblocks);
+		MCOM_LAUNCH(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, ks, p, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 		mcom_mm128 *t = src; src = dst; dst = t;
 	}
@@ -444,10 +444,10 @@ extern "C" int mcom_partition_by_owner(mcom_ctx *ctx, const mcom_mm128 *d_rec, s
 	KeySpec ks{3, b, ranks, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
-		hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, n, ks, 0, hist, nblocks);
+		MCOM_LAUNCH(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, n, ks, 0, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 		if ((rc = scan_u32(ctx, hist, hist, (size_t)256 * nblocks, scratch))) return rc;
-		hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, d_out, n, ks, 0, hist, nblocks);
+		MCOM_LAUNCH(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, d_rec, d_out, n, ks, 0, hist, nblocks);
 		MCOM_LAUNCH_CHECK(ctx);
 	}
 	std::vector<uint32_t> start((size_t)ranks + 1);
@@ -498,12 +498,12 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	uint32_t *start = d_scratch, *ovf = d_scratch + ((ntiles + 3) & ~1u);     // [count, pad, list of ntiles pairs, ntiles offsets]
 	uint2 *ovf_list = (uint2*)(ovf + 2);
 	uint32_t *ovf_dst = ovf + 2 + 2 * (size_t)ntiles;
-	hipLaunchKernelGGL(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
+	MCOM_LAUNCH(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
 	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
 	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
-		hipLaunchKernelGGL(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64,
+		MCOM_LAUNCH(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64,
 		                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf, ovf_list);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
@@ -526,10 +526,10 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	if (mcom_dmalloc(&ws2, rec_b + sort_ws_layout(m, nullptr, nullptr)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "workspace for %zu records of oversized groups", m);
 	mcom_mm128 *compact = (mcom_mm128*)ws2;
 	SortWs w2; sort_ws_layout(m, &w2, (char*)ws2 + rec_b);
-	hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_in, compact, ovf_list, ovf_dst, 0);
+	MCOM_LAUNCH(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_in, compact, ovf_list, ovf_dst, 0);
 	mcom_mm128 *res = nullptr;
 	int rc = radix_sort_records(ctx, compact, w2.tmp, m, ks, (bits + 7) / 8, w2.hist, w2.scratch, &res);
-	if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_out, res, ovf_list, ovf_dst, 1);
+	if (!rc) MCOM_LAUNCH(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_out, res, ovf_list, ovf_dst, 1);
 	hipError_t e2 = mcom_stream_sync(ctx);
 	mcom_dfree(ws2);
 	if (rc) return rc;
@@ -650,19 +650,19 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 		mcom_mm128 *dst = (passes & 1) ? w.tmp : d_sorted;
 		for (int p = 0; p < passes; ++p) {
 			McomProfScope ps_(ctx, PROF_RADIX_PASS);
-			hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, msd, p, w.hist, nblocks);
+			MCOM_LAUNCH(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, msd, p, w.hist, nblocks);
 			MCOM_LAUNCH_CHECK(ctx);
 			if ((rc = scan_u32(ctx, w.hist, w.hist, (size_t)256 * nblocks, w.scratch))) return rc;
-			hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, msd, p, w.hist, nblocks);
+			MCOM_LAUNCH(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, msd, p, w.hist, nblocks);
 			MCOM_LAUNCH_CHECK(ctx);
 			src = dst; dst = dst == w.tmp ? d_sorted : w.tmp;
 		}
 		uint32_t novf = 0;
 		{
 			McomProfScope ps_(ctx, PROF_RADIX_PASS);
-			hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
+			MCOM_LAUNCH(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
 			MCOM_HIP(ctx, hipMemsetAsync(ovf_count, 0, 4, ctx->stream));
-			hipLaunchKernelGGL(k_segment_sort, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits,
+			MCOM_LAUNCH(k_segment_sort, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits,
 			                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf_count, ovf_list);
 			MCOM_LAUNCH_CHECK(ctx);
 		}
@@ -683,10 +683,10 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 			void *ws2 = nullptr;
 			if (mcom_dmalloc(&ws2, sort_ws_layout(m, nullptr, nullptr)) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "workspace for %zu records of oversized segments", m);
 			SortWs w2; sort_ws_layout(m, &w2, (char*)ws2);
-			hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, w.tmp, ovf_list, ovf_dst, 0);
+			MCOM_LAUNCH(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, w.tmp, ovf_list, ovf_dst, 0);
 			mcom_mm128 *res = nullptr;
 			rc = radix_sort_records(ctx, w.tmp, w2.tmp, m, full, (2 * kmer + 9 + 7) / 8, w2.hist, w2.scratch, &res);
-			if (!rc) hipLaunchKernelGGL(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, res, ovf_list, ovf_dst, 1);
+			if (!rc) MCOM_LAUNCH(k_seg_move, dim3(novf), dim3(256), 0, ctx->stream, d_sorted, res, ovf_list, ovf_dst, 1);
 			hipError_t e2 = mcom_stream_sync(ctx);
 			mcom_dfree(ws2);
 			if (rc) return rc;
@@ -694,13 +694,13 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 		}
 	}
 	const unsigned blocks = (unsigned)((n + 255) / 256);
-	hipLaunchKernelGGL(k_group_flags, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2);
+	MCOM_LAUNCH(k_group_flags, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan_u32(ctx, f0, f0, n, scr))) return rc;
 	if ((rc = scan_u32(ctx, f1, f1, n, scr))) return rc;
 	if ((rc = scan_u32(ctx, f2, f2, n, scr))) return rc;
-	hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, d_sorted, n, d_counts);
-	hipLaunchKernelGGL(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_single_ord, d_members, d_group_off, d_counts);
+	MCOM_LAUNCH(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, d_sorted, n, d_counts);
+	MCOM_LAUNCH(k_group_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted, n, f0, f1, f2, d_singles, d_single_ord, d_members, d_group_off, d_counts);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, h_counts, d_counts, 4 * sizeof(uint64_t)));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));

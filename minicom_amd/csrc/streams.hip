@@ -212,15 +212,15 @@ extern "C" int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	if (mcom_dmalloc(&tmp, cid_b + len_b + scr_b) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "stream encoder: %zu bytes of scratch", cid_b + len_b + scr_b);
 	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
 	uint32_t *cid = (uint32_t*)tmp; uint64_t *tlen = (uint64_t*)(tmp + cid_b), *scr = (uint64_t*)(tmp + cid_b + len_b);
-	hipLaunchKernelGGL(k_st_contigs, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n_contigs, cid, (uint16_t*)d_pos);
+	MCOM_LAUNCH(k_st_contigs, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n_contigs, cid, (uint16_t*)d_pos);
 	MCOM_LAUNCH_CHECK(ctx);
 	const unsigned blocks = (unsigned)((n_members + 255) / 256);
 	MCOM_HIP(ctx, hipMemsetAsync(tlen + n_members, 0, 8, ctx->stream));
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_st_len<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_nmask, NW, L, d_mem, d_moff, cid, (size_t)n_members, d_cbits, d_coff, (uint16_t*)d_pos, tlen); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_st_len<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_nmask, NW, L, d_mem, d_moff, cid, (size_t)n_members, d_cbits, d_coff, (uint16_t*)d_pos, tlen); break;
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
 	MCOM_LAUNCH_CHECK(ctx);
-	hipLaunchKernelGGL(k_st_dirs, dim3((unsigned)(((n_members + 7) / 8 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, (size_t)n_members, d_dir);
+	MCOM_LAUNCH(k_st_dirs, dim3((unsigned)(((n_members + 7) / 8 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, (size_t)n_members, d_dir);
 	MCOM_LAUNCH_CHECK(ctx);
 	int rc = mcom_scan64(ctx, tlen, tlen, n_members + 1, scr);
 	if (rc) return rc;
@@ -229,7 +229,7 @@ extern "C" int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
 	if (total > text_cap || !d_text) return mcom_fail(ctx, MCOM_E_OVERFLOW, "mismatch text: %llu bytes, room for %llu", (unsigned long long)total, (unsigned long long)text_cap);
-#define MCOM_CASE(WW) case WW: hipLaunchKernelGGL((k_st_emit<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_nmask, NW, L, d_mem, cid, (size_t)n_members, d_cbits, d_coff, tlen, d_text); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_st_emit<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_nmask, NW, L, d_mem, cid, (size_t)n_members, d_cbits, d_coff, tlen, d_text); break;
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: break; }
 #undef MCOM_CASE
 	MCOM_LAUNCH_CHECK(ctx);
@@ -243,7 +243,7 @@ extern "C" int mcom_dump_refbin(mcom_ctx *ctx, const uint8_t *d_seq, uint64_t ch
 	if (!d_seq || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const uint64_t bytes = (chars + 3) / 4;
 	if ((bytes + 255) / 256 >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig bases for one launch");
-	hipLaunchKernelGGL(k_st_refbin, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, d_seq, chars, d_out);
+	MCOM_LAUNCH(k_st_refbin, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, d_seq, chars, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -256,7 +256,7 @@ extern "C" int mcom_dump_singles(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	if (!d_packed || !d_rids || !d_out) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const uint64_t bytes = (n * (uint64_t)L + 3) / 4;
 	if ((bytes + 255) / 256 >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many unclustered reads for one launch");
-	hipLaunchKernelGGL(k_st_singles, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, mcom_words_per_read(L), L, d_rids, n, d_out);
+	MCOM_LAUNCH(k_st_singles, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, mcom_words_per_read(L), L, d_rids, n, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -267,7 +267,7 @@ extern "C" int mcom_rows_have_n(mcom_ctx *ctx, const uint64_t *d_nmask, const ui
 	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range", L);
 	if (!n) return MCOM_OK;
 	if (!d_nmask || !d_rids || !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	hipLaunchKernelGGL(k_st_has_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_nmask, (L + 63) / 64, d_rids, n, d_flag);
+	MCOM_LAUNCH(k_st_has_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_nmask, (L + 63) / 64, d_rids, n, d_flag);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

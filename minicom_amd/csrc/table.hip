@@ -89,7 +89,7 @@ int mcom_table_fill_buckets(mcom_ctx *ctx, const mcom_mm128 *sorted, const uint3
 	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 8, ctx->stream));
 	const size_t lds = (size_t)16 * t->region;
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_table_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_table_bucket, dim3(bucket1 - bucket0), dim3(256), lds, ctx->stream, sorted, bstart, (int)t->bbits, t->region, t->slots, meta, bucket0, start_base);
+	MCOM_LAUNCH(k_table_bucket, dim3(bucket1 - bucket0), dim3(256), lds, ctx->stream, sorted, bstart, (int)t->bbits, t->region, t->slots, meta, bucket0, start_base);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t hm[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 8));
@@ -120,19 +120,19 @@ int mcom_table_build(mcom_ctx *ctx, const mcom_mm128 *sorted, size_t n, uint32_t
 	if (mcom_dmalloc(&buf, ((n + 1) + (n + 2) + scr_elems) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "run heads");
 	uint32_t *hpre = buf, *hidx = buf + (n + 1), *scr2 = hidx + (n + 2);
 	const unsigned blocks = (unsigned)((n + 1 + 255) / 256);
-	hipLaunchKernelGGL(k_table_heads, dim3(blocks), dim3(256), 0, ctx->stream, sorted, n, hpre);
+	MCOM_LAUNCH(k_table_heads, dim3(blocks), dim3(256), 0, ctx->stream, sorted, n, hpre);
 	int rc = mcom_scan_u32(ctx, hpre, hpre, n + 1, scr2);
 	uint32_t nh = 0;
 	hipError_t e3 = hipSuccess;
 	if (!rc) {
-		hipLaunchKernelGGL(k_table_head_list, dim3(blocks), dim3(256), 0, ctx->stream, sorted, n, hpre, hidx);
+		MCOM_LAUNCH(k_table_head_list, dim3(blocks), dim3(256), 0, ctx->stream, sorted, n, hpre, hidx);
 		e3 = hipMemsetAsync(meta, 0, 8, ctx->stream);
 		if (e3 == hipSuccess) e3 = mcom_d2h_async(ctx, &nh, hpre + n, 4);
 		if (e3 == hipSuccess) e3 = mcom_stream_sync(ctx);
 	}
 	uint32_t hm[2] = {0, 0};
 	if (!rc && e3 == hipSuccess && nh) {
-		hipLaunchKernelGGL(k_table_insert, dim3((nh + 255) / 256), dim3(256), 0, ctx->stream, sorted, hidx, nh, t->slots, lg, meta);
+		MCOM_LAUNCH(k_table_insert, dim3((nh + 255) / 256), dim3(256), 0, ctx->stream, sorted, hidx, nh, t->slots, lg, meta);
 		e3 = hipGetLastError();
 		if (e3 == hipSuccess) e3 = mcom_d2h_async(ctx, hm, meta, 8);
 		if (e3 == hipSuccess) e3 = mcom_stream_sync(ctx);

@@ -24,9 +24,12 @@ def header_path() -> str:
 
 
 def _declared_symbols() -> list[str]:
-    txt = open(header_path()).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mcom_[a-z0-9_]+)\s*\(", txt)))
+    """every entry point include/mcom.h (the boundary) and include/mcom_test.h (test hooks) declare"""
+    names = set()
+    for h in (header_path(), os.path.join(os.path.dirname(header_path()), "mcom_test.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(mcom_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
 
 
 ABI_SYMBOLS = _declared_symbols()
@@ -57,6 +60,7 @@ def load_library():
     L.mcom_prof_enable.restype = i32; L.mcom_prof_enable.argtypes = [vp, i32]
     L.mcom_prof_reset.restype = i32; L.mcom_prof_reset.argtypes = [vp]
     L.mcom_prof_read.restype = i32; L.mcom_prof_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64)]
+    L.mcom_prof_kernels.restype = i32; L.mcom_prof_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
     L.mcom_process_reads.restype = i32
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32

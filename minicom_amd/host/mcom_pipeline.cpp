@@ -1738,7 +1738,7 @@ extern "C" int mcomh_pre_process(mcomh_pipeline *p)
 	return run_stage2(p, nullptr);
 }
 
-// ---- dump in the text format of oracle/refdump.cpp ---------------------------------------------------
+// ---- dump in the text format of the golden-fixture stage dumps (tests/golden/) ---------------------------------------------------
 template <class V> static void dump_list(FILE *f, const char *name, const V &v)
 {
 	fprintf(f, "LIST %s %zu", name, v.size());
@@ -1952,6 +1952,33 @@ extern "C" int mcomh_prof_read(mcomh_pipeline *p, const char *name, double *tota
 		if (mcom_prof_read(p->ctx2, name, &ms2, &l2) == MCOM_OK) { if (total_ms) *total_ms += ms2; if (launches) *launches += l2; }
 	}
 	return rc;
+}
+extern "C" int mcomh_prof_kernels(mcomh_pipeline *p, const char *name, char *buf, size_t cap, size_t *need)
+{
+	if (!p) return MCOM_E_ARG;
+	// both contexts' tallies, merged line by line (the copy stream's context launches a few of the same kernels)
+	std::map<std::string, uint64_t> all;
+	mcom_ctx *cs[2] = { p->ctx, p->ctx2 };
+	for (mcom_ctx *c : cs) {
+		if (!c) continue;
+		size_t nb = 0;
+		int rc = p->gpu(mcom_prof_kernels(c, name, nullptr, 0, &nb));
+		if (rc) return rc;
+		std::string t(nb, '\0');
+		(void)mcom_prof_kernels(c, name, &t[0], nb, nullptr);
+		size_t a = 0;
+		while (a < t.size()) {
+			size_t e = t.find('\n', a); if (e == std::string::npos) break;
+			size_t tab = t.find('\t', a);
+			if (tab != std::string::npos && tab < e) all[t.substr(a, tab - a)] += strtoull(t.c_str() + tab + 1, nullptr, 10);
+			a = e + 1;
+		}
+	}
+	std::string txt;
+	for (const auto &kv : all) { txt += kv.first; txt += '\t'; txt += std::to_string(kv.second); txt += '\n'; }
+	if (need) *need = txt.size() + 1;
+	if (buf && cap) { size_t m = txt.size() < cap - 1 ? txt.size() : cap - 1; memcpy(buf, txt.data(), m); buf[m] = 0; }
+	return MCOM_OK;
 }
 extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 {

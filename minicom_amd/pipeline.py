@@ -65,6 +65,7 @@ def load_host_library():
     L.mcomh_stat.restype = C.c_double; L.mcomh_stat.argtypes = [vp, cp]
     L.mcomh_prof_enable.restype = i32; L.mcomh_prof_enable.argtypes = [vp, i32]
     L.mcomh_prof_read.restype = i32; L.mcomh_prof_read.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.mcomh_prof_kernels.restype = i32; L.mcomh_prof_kernels.argtypes = [vp, cp, C.c_char_p, sz, C.POINTER(sz)]
     L.mcomh_fastq_read.restype = i32; L.mcomh_fastq_read.argtypes = [cp, C.POINTER(i32), vp, sz, C.POINTER(sz)]
     L.mcomh_fastq_to_device.restype = i32
     L.mcomh_fastq_to_device.argtypes = [cp, i32, C.POINTER(i32), sz, C.POINTER(vp), C.POINTER(sz), C.c_char_p, sz]
@@ -76,7 +77,7 @@ def load_host_library():
 HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_stage2", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
-                    "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_fastq_read", "mcomh_fastq_to_device",
+                    "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_prof_kernels", "mcomh_fastq_read", "mcomh_fastq_to_device",
                     "mcomh_device_free", "mcomh_cluster_dump_order", "mcomh_decompress_order",
                     "mcomh_cluster_dump_pe", "mcomh_decompress_pe", "mcomh_fastq_pair_to_device",
                     "mcomh_contig_set", "mcomh_result_digest",
@@ -253,6 +254,19 @@ class Pipeline:
         ms = C.c_double(); n = C.c_uint64()
         self._check(self.lib.mcomh_prof_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def prof_kernels(self, name: str = "*") -> dict:
+        """{kernel name: launches} of one kernel class ("*": every kernel of the library) while the profiler was on -- the
+        compiler's spelling of each instantiation, which is the name rocprofv3 prints"""
+        need = C.c_size_t()
+        self._check(self.lib.mcomh_prof_kernels(self._h, name.encode(), None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        self._check(self.lib.mcomh_prof_kernels(self._h, name.encode(), buf, need.value + 1, None))
+        out = {}
+        for ln in buf.value.decode().splitlines():
+            k, _, c = ln.rpartition("\t")
+            out[k] = int(c)
+        return out
 
     def stat(self, name: str) -> float:
         return float(self.lib.mcomh_stat(self._h, name.encode()))

@@ -11,13 +11,19 @@ OUT=$HERE/_ref
 [ -d "$REF" ] || { echo "reference sources not present at $REF: skipping oracle/_ref build"; exit 0; }
 mkdir -p "$OUT"
 CXX=${CXX:-g++}
-CXXFLAGS="-O3 -Wno-unused-function -std=c++11 -w -march=x86-64-v2 -fopenmp"
+# -march: the golden-fixture variants are built for x86-64-v2 (any box can run them; their outputs do not depend on it); the
+# CPU-baseline variants (_t*) for x86-64-v3 -- the reference's own Makefile:2 says -march=native, which cannot travel to another
+# box; v3 (AVX2, BMI2, POPCNT) is what every current server CPU offers and is what bench.py names in cpu_baseline.sample
+base_flags() { echo "-O3 -Wno-unused-function -std=c++11 -w -march=${MARCH:-x86-64-v2} -fopenmp"; }
 LIB_SRCS="bseq misc preprocess sketch bbhashdict kthread_reads kthread_bucket kthread_idx kthread_cb kthread_hash_realign kthread_dump "
 
 build_variant() {   # name readlen extra_defines...
   local name=$1 L=$2; shift 2
   local d=$OUT/$name
+  local CXXFLAGS; CXXFLAGS=$(base_flags)
   mkdir -p "$d/output_ref"
+  if [ -f "$d/.march" ] && [ "$(cat "$d/.march")" != "${MARCH:-x86-64-v2}" ]; then rm -f "$d"/*.o; fi
+  echo "${MARCH:-x86-64-v2}" > "$d/.march"
   {
     echo "#pragma once"
     for x in "$@"; do
@@ -63,8 +69,10 @@ ININUMDICT=4 build_variant L100_s4 100
 build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE
 # multi-threaded builds, used only as the CPU baseline of bench.py (their output is not reproducible run to run)
-NUM_THR=16 build_variant L150_t16 150
+MARCH=x86-64-v3 NUM_THR=16 build_variant L150_t16 150
 # ... at other core counts: bench.py takes the largest one the box has cores for (north_star: "-t <host cores>")
-NUM_THR=8 build_variant L150_t8 150
-NUM_THR=32 build_variant L150_t32 150
-NUM_THR=64 build_variant L150_t64 150
+MARCH=x86-64-v3 NUM_THR=8 build_variant L150_t8 150
+MARCH=x86-64-v3 NUM_THR=32 build_variant L150_t32 150
+MARCH=x86-64-v3 NUM_THR=64 build_variant L150_t64 150
+# the same at x86-64-v2, should a box lack AVX2 (bench.py falls back to it and says so)
+NUM_THR=64 build_variant L150_t64_v2 150

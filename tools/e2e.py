@@ -17,7 +17,7 @@ import subprocess
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repo root
 
 
 def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads: int = 1_000_000, workdir: str | None = None, keep: bool = False):
