@@ -42,12 +42,11 @@ def cpu_baseline(L, sample):
     has cores for: the thread count is a compile-time constant of the reference, minicom:56-91) on the host cores, on a bounded
     sample of the same workload, by its own Stage 1 + Stage 2 timers; falls back to the C restatement (oracle/) when absent."""
     from minicom_amd import synth
-    from tools.e2e import host_cores, reference_binary
+    from tools.e2e import host_cores, reference_binaries
     reads = synth.synth_reads(SEED, sample, L)
     tag = f"{sample} reads x {L} bp, same generator (seed {SEED}, 30x coverage, 0.5% substitutions)"
-    found = reference_binary(L)
-    if found:
-        exe, variant, threads = found
+    tried = []
+    for exe, variant, threads, march in reference_binaries(L):
         try:
             with tempfile.TemporaryDirectory() as td:
                 fq = os.path.join(td, "s.fastq")
@@ -60,19 +59,23 @@ def cpu_baseline(L, sample):
                 t = [float(x) for x in re.findall(r"\[Stage \d\] Real time: ([\d.]+)", p.stdout.decode())]
                 if p.returncode == 0 and len(t) == 2:
                     return {"value": round(sample / sum(t) / 1e6, 6), "unit": "Mreads/s", "cores": threads, "kind": "reference", "sample_reads": sample,
-                            "sample": tag + f"; oracle/_ref/{variant}/minicom_bin (-t {threads}; the box offers {host_cores()} cores), its own Stage 1 + Stage 2 timers, measured in this run",
-                            "seconds": round(sum(t), 3), "seconds_whole_process": round(wall, 3)}
-        except Exception:                                                      # noqa: BLE001
-            pass
+                            "sample": tag + f"; oracle/_ref/{variant}/minicom_bin (-t {threads}; the box offers {host_cores()} cores; g++ -O3 -march={march} -- the reference's Makefile says "
+                                            "-march=native, which cannot travel between boxes), its own Stage 1 + Stage 2 timers, measured in this run",
+                            "march": march, "seconds": round(sum(t), 3), "seconds_whole_process": round(wall, 3), "variants_that_failed": tried or None}
+                tried.append(f"{variant}: exit {p.returncode}")
+        except Exception as e:                                                 # noqa: BLE001
+            tried.append(f"{variant}: {type(e).__name__}")
     import oracle
     sample = min(sample, 1_000_000)
     p = oracle.Pipeline(reads[:sample])
     t0 = time.perf_counter(); p.run_all(); dt = time.perf_counter() - t0
     p.close()
     return {"value": round(sample / dt / 1e6, 6), "unit": "Mreads/s", "cores": 1, "kind": "port", "sample_reads": sample,
-            "sample": f"{sample} reads x {L} bp, same generator; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3)}
+            "sample": f"{sample} reads x {L} bp, same generator; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3), "variants_that_failed": tried or None}
 
 
+CINDEX_NOTE = ("model 'passes': the bytes this radix-partitioned build moves by design (streaming passes over the entries + one placement pass per partition: "
+               "cindex_bytes() in this file, DESIGN.md section 3); two launches per build (entries, placement: the multi-GPU exchange sits between them)")
 KERNELS = ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows", "consensus",
            "cindex_build", "realign_reads")
 
@@ -102,28 +105,53 @@ def cindex_bytes(st):
     return (12 + 4 + 12 + 12 + 12) * st.get("cix_entries", 0) + 8 * st.get("cix_slots", 0)
 
 
-# HBM traffic and SQ instruction counts per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of
-# this same command; kernels cannot be counted while bench.py itself is timing them)
+# HBM traffic and SQ figures per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of this same command,
+# tools/profile_round.sh; kernels cannot be counted while bench.py itself is timing them).  A figure is quoted ONLY for the exact
+# kernel instantiations this run launched inside the class (the library's own tally, mcom_prof_kernels) and only while the source
+# file the kernel was compiled from -- and the shared headers -- are the ones that were profiled (tools/source_sha.py); otherwise
+# the figure is null and the line says which kernel was not covered.
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_KERNELS = {"sketch_contigs": ["k_sketch_scan32<true, unsigned short>", "k_sketch_scan32<true, unsigned int>", "k_sketch_scan<true, true>", "k_sketch_scan<false, true>", "k_sketch_contigs"], "realign_reads": ["k_realign_reads<5, 16, false, false>"],
-               "classify_pack": ["k_classify_flat<5>", "k_classify_pack16"], "sketch_reads": ["k_sketch_reads<5, true, true>", "k_sketch_reads<5, true, false>"],
-               "cindex_build": ["k_cindex_blocks", "k_cx_hist1", "k_cx_scatter1<false>", "k_cx_hist2", "k_cx_scatter2", "k_cx_bounds", "k_cx_assemble_sorted", "k_cx_assemble"]}
 
 
 def pmc_load():
     try:
         with open(PMC_FILE) as f:
-            return json.load(f)
+            d = json.load(f)
+        from tools import source_sha
+        d["_by_norm"] = {source_sha.norm(k): v for k, v in d["kernels"].items()}
+        d["_shas"], d["_kfiles"] = source_sha.file_shas(), source_sha.kernel_files()
+        return d
     except Exception:                                                          # noqa: BLE001
         return None
 
 
-def pmc(d, cls, field):
-    """A PMC figure of a kernel class (summed over the kernels of the class that were counted), or None."""
+def pmc_entry(d, name):
+    """(entry, None) of one observed kernel name, or (None, why not)"""
+    from tools import source_sha
+    e = d["_by_norm"].get(source_sha.norm(name))
+    if e is None:
+        return None, f"{name}: not in profiles/pmc_constants.json"
+    if e.get("source_sha") != source_sha.kernel_sha(name, d["_shas"], d["_kfiles"]):
+        return None, f"{name}: {e.get('source_file')} or a shared header changed since commit {d['_meta']['commit'][:8]} was profiled"
+    return e, None
+
+
+def pmc_class(d, observed, field):
+    """sum over the kernels observed in a class of field x launches; (value, []) or (None, [reasons])"""
     if not d:
-        return None
-    vals = [d["kernels"][k][field] for k in PMC_KERNELS[cls] if k in d["kernels"] and field in d["kernels"][k]]
-    return sum(vals) if vals else None
+        return None, ["profiles/pmc_constants.json missing"]
+    if not observed:
+        return None, ["no kernel observed in this class"]
+    tot, why = 0.0, []
+    for name, cnt in observed.items():
+        e, w = pmc_entry(d, name)
+        if e is None:
+            why.append(w)
+        elif field not in e:
+            why.append(f"{name}: no {field}")
+        else:
+            tot += e[field] * cnt
+    return (None, why) if why else (tot, [])
 
 
 def main():
@@ -141,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the checked run (the digest comparison between steps stays)")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-event-ab", action="store_true", help="skip the K extra steps without profiler events (the A/B of what the events cost)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling 100 M-read figure")
     a = ap.parse_args()
 
@@ -191,7 +220,7 @@ def main():
              "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "x_cindex_entries", "contigs_bucket", "contigs_combine",
              "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")
 
-    def measure(n_total, seed, steps, warmup, check):
+    def measure(n_total, seed, steps, warmup, check, ab_events=False):
         """K timed steps of one job of n_total reads; returns (seconds, aggregate stats, digests, reads, make)."""
         n_local = n_total // world
         n_total = n_local * world
@@ -203,13 +232,13 @@ def main():
             if not distributed:
                 return Pipeline(reads, L=L, device=local_rank, host_threads=threads)
             return DistPipeline(reads, rank * n_local, n_total, comm, L=L, device=local_rank, host_threads=threads)
-        agg, digests = {}, []
+        agg, digests, observed = {}, [], {}
 
-        def step(timed):
+        def step(timed, events=True):
             p = make()
             # HIP events around the hot kernel classes, on the launch stream, inside the timed steps (the contract's live kernel times):
-            # about a hundred event pairs per step out of a process-wide pool -- 0.1 % of a step
-            p.prof_enable(True)
+            # about a hundred event pairs per step out of a process-wide pool; what they cost is measured below (`event_overhead`)
+            p.prof_enable(events)
             p.pre_process()
             dg = p.result_digest()
             if timed:
@@ -221,7 +250,14 @@ def main():
                     ms, calls = p.prof_read(name)
                     agg["ms_" + name] = agg.get("ms_" + name, 0.0) + ms
                     agg["calls_" + name] = agg.get("calls_" + name, 0) + calls
+                    o = observed.setdefault(name, {})
+                    for kn, c in p.prof_kernels(name).items():                   # the exact kernels the class's time belongs to
+                        o[kn] = o.get(kn, 0) + c
+                o = observed.setdefault("*", {})
+                for kn, c in p.prof_kernels("*").items():
+                    o[kn] = o.get(kn, 0) + c
             p.close()
+            return dg
         for _ in range(warmup):
             step(False)
         barrier()
@@ -234,6 +270,17 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # A/B of the event profiler: the same K steps again with the events off (untimed for `value`; reported beside it)
+        agg["_events_off_s"] = None
+        if ab_events:
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                if step(False, events=False) != digests[0]:
+                    raise SystemExit("a step without events gave another result")
+            barrier()
+            agg["_events_off_s"] = time.perf_counter() - t1
+        agg["_observed"] = observed
         checked = None
         if check:
             from minicom_amd.check import check_result
@@ -264,7 +311,7 @@ def main():
     try:
         ok, err = True, None
         try:
-            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check)
+            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check, ab_events=not a.no_event_ab)
         except (McomError, RuntimeError) as e:                                  # e.g. out of memory at a size no single card could rehearse
             ok, err = False, f"{type(e).__name__}: {e}"
         if not agree(ok):
@@ -347,6 +394,8 @@ def main():
         default_workload = n_local == 100_000_000 and L == 150 and not distributed and a.genome == "uniform"
         per_step = {q: round(agg.get("ms_" + q, 0.0) / a.steps, 2) for q in KERNELS}
 
+        observed = agg.get("_observed", {})
+
         def hbm_line(cls, model):
             b = algorithmic_bytes(cls, st, L, nd)
             ms, calls = agg.get("ms_" + cls, 0.0), agg.get("calls_" + cls, 0)
@@ -354,25 +403,40 @@ def main():
                 return None
             ach = (b / calls) / (ms / calls * 1e-3) / 1e9
             line = {"kernel": cls, "bound": "hbm", "model": model, "achieved": round(ach, 2), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
-                    "launches": int(calls), "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls)}
-            # PMC traffic: raw counters, and with the guide's x2 for FETCH_SIZE on the kernels whose loads are wide coalesced streams
-            raw, cor = (pmc(P, cls, "traffic_bytes_per_launch"), pmc(P, cls, "traffic_corrected_bytes_per_launch")) if default_workload else (None, None)
-            line["traffic"] = cor if cor is not None else raw
-            line["traffic_raw"] = raw
-            line["traffic_corrected"] = cor
+                    "launches": int(calls), "avg_launch_ms": round(ms / calls, 4), "algorithmic_bytes_per_launch": int(b / calls),
+                    "kernels_observed": {k: round(v / a.steps, 1) for k, v in sorted(observed.get(cls, {}).items())}}
+            # PMC traffic of exactly these kernels: raw counters, and with the guide's x2 for FETCH_SIZE on the kernels whose loads are wide coalesced streams
+            if default_workload:
+                raw, why = pmc_class(P, observed.get(cls, {}), "traffic_bytes_per_launch")
+                cor, _ = pmc_class(P, observed.get(cls, {}), "traffic_corrected_bytes_per_launch")
+            else:
+                raw, cor, why = None, None, ["PMC passes were taken at the default workload only"]
+            line["traffic"] = int(cor / calls) if cor is not None else None
+            line["traffic_raw"] = int(raw / calls) if raw is not None else None
+            line["traffic_corrected"] = line["traffic"]
+            if why:
+                line["traffic_stale"] = why
             return line
 
-        def issue_line(cls, waves):
-            """Integer-issue roofline of an ALU-bound kernel: VALU wave-instructions per second against 1024 SIMDs x clock / 2 (an upper
-            bound of the peak: 64-bit shifts, adds and multiplies take more than one issue slot)."""
-            v = pmc(P, cls, "valu_per_wave")
-            ms = agg.get("ms_" + cls, 0.0)
-            if not v or ms <= 0:
+        def issue_line(cls):
+            """ALU roofline of a kernel class from the SQ pass of its dominant kernel: the share of the SIMDs' cycles in which a VALU instruction was
+            executing (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel time x 2.4 GHz)), with the wave-side split beside it"""
+            obs = observed.get(cls, {})
+            if not P or not obs:
                 return None
-            rate = v * waves / (ms * 1e-3)
-            return {"bound": "valu_issue", "valu_insts_per_wave": v, "waves": int(waves), "achieved": round(rate / 1e9, 1), "peak": round(VALU_PEAK / 1e9, 1),
-                    "unit": "G wave-instructions/s", "frac": round(rate / VALU_PEAK, 4), "source": "profiles/pmc_constants.json (SQ_INSTS_VALU / SQ_WAVES, PMC pass)",
-                    "note": "the peak counts every VALU instruction as one 2-cycle issue; 64-bit shift / add instructions take more, so the true fraction is higher"}
+            best, why = None, []
+            for name in obs:
+                e, w = pmc_entry(P, name)
+                if e is None:
+                    why.append(w)
+                elif "valu_busy" in e and (best is None or e.get("sq_pass_ms", 0) > best[1].get("sq_pass_ms", 0)):
+                    best = (name, e)
+            if why or best is None:
+                return {"bound": "valu", "frac": None, "stale": why or ["no SQ pass for this class"]}
+            name, e = best
+            return {"bound": "valu", "kernel": name, "frac": e["valu_busy"], "valu_busy": e["valu_busy"], "valu_active_of_wave_cycles": e.get("valu_active_of_wave_cycles"),
+                    "wait_any_of_wave_cycles": e.get("wait_any"), "issue_stall_of_wave_cycles": e.get("wait_inst"), "waves_per_simd_avg": e.get("waves_per_simd_avg"),
+                    "valu_insts_per_wave": e.get("valu_per_wave"), "source": f"profiles/pmc_constants.json (commit {P['_meta']['commit'][:8]}, SQ pass at {e.get('sq_pass_reads')} reads): " + P["_meta"]["valu_busy"]}
 
         roof = None
         for cand in sorted(KERNELS, key=lambda q: -agg.get("ms_" + q, 0.0)):      # the dominant class that has a byte model
@@ -380,28 +444,27 @@ def main():
             if roof:
                 break
         if roof:
-            roof["traffic_source"] = ("profiles/pmc_constants.json (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command; corrected = FETCH x 2 for the kernels "
-                                      "flagged as wide streaming readers, MI355X_MICROARCH.md 'HBM')") if default_workload else None
+            roof["traffic_source"] = (f"profiles/pmc_constants.json, commit {P['_meta']['commit'][:8]} (FETCH_SIZE + WRITE_SIZE, separate PMC passes of this command; corrected = FETCH x 2 for the "
+                                      "kernels flagged as wide streaming readers, MI355X_MICROARCH.md 'HBM'); quoted for the kernels this run observed, null when one is not covered") if P and default_workload else None
             roof["device_ms_per_step_by_kernel"] = per_step
             if roof["kernel"] == "cindex_build":
                 # what the build MUST touch, whatever its passes: the packed contigs in, the table out
                 minimal = (2 * st.get("cix_entries", 0) / 8 + 8 * st.get("cix_slots", 0)) / max(1, agg.get("calls_cindex_build", 1))
                 roof["algorithmic_minimal"] = {"bytes_per_launch": int(minimal), "achieved": round(minimal / (roof["avg_launch_ms"] * 1e-3) / 1e9, 2), "unit": "GB/s",
                                                "frac": round(minimal / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK, 4), "what": "packed contigs read once + index table written once"}
-                roof["note"] = ("model 'passes': the bytes this radix-partitioned build moves by design (two streaming passes over 12-byte entries + one placement pass per "
-                                "partition); two launches per build since round 3 (entries, placement: the multi-GPU exchange sits between them)")
+                roof["note"] = CINDEX_NOTE
             sk = hbm_line("sketch_reads", "word")
             if sk:
                 sk["ms_per_step"] = round(agg["ms_sketch_reads"] / a.steps, 3)
                 sk["mreads_per_s"] = round((st["n"] + st["resketch"]) / (agg["ms_sketch_reads"] * 1e-3) / 1e6, 1)
                 sk["algorithmic_bytes_per_read"] = 8 * ((2 * L + 63) // 64) + 16
-                sk["issue_roofline"] = issue_line("sketch_reads", (st["n"] + st["resketch"]) / 64)
+                sk["issue_roofline"] = issue_line("sketch_reads")
                 sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers; the HBM fraction cannot be high (SURVEY section 7)"
                 roof["sketch_kernel"] = sk
             sc = hbm_line("sketch_contigs", "word")
             if sc:
-                sc["issue_roofline"] = issue_line("sketch_contigs", st.get("sketch_strings", 0.0) / 64)
-                sc["note"] = "one lane per string, LDS rings allow 5-6 waves per CU: bound by latency, neither by bytes nor by issue"
+                sc["issue_roofline"] = issue_line("sketch_contigs")
+                sc["note"] = "one lane per string with an LDS ring per lane: bound by latency and issue at few waves per SIMD, not by bytes"
                 if roof["kernel"] != "sketch_contigs":
                     roof["sketch_contigs"] = sc
                 else:
@@ -409,14 +472,26 @@ def main():
             if roof["kernel"] != "cindex_build":
                 hb = hbm_line("cindex_build", "passes")
                 if hb:
+                    hb["note"] = CINDEX_NOTE
                     roof["hbm_bound_kernel"] = hb
         whole = None
+        launches_live = sum(observed.get("*", {}).values()) / a.steps if observed.get("*") else None
         if P and default_workload and "_whole_step" in P:
             w = P["_whole_step"]
             ms = dt / a.steps * 1e3
-            whole = {"traffic_GB": round(w["traffic_corrected_bytes"] / 1e9, 1), "traffic_raw_GB": round(w["traffic_raw_bytes"] / 1e9, 1),
-                     "hbm_frac": round(w["traffic_corrected_bytes"] / 1e9 / (ms * 1e-3) / HBM_PEAK, 4), "launches": w.get("launches"),
-                     "source": "profiles/pmc_constants.json: FETCH_SIZE + WRITE_SIZE summed over every kernel of one step (PMC passes of this command), over this run's ms_per_step"}
+            # the whole-step counter total stands only while every kernel this run launched is one that was counted, from unchanged source
+            why = [x for x in (pmc_entry(P, k)[1] for k in observed.get("*", {})) if x]
+            whole = {"traffic_GB": round(w["traffic_corrected_bytes"] / 1e9, 1) if not why else None, "traffic_raw_GB": round(w["traffic_raw_bytes"] / 1e9, 1) if not why else None,
+                     "hbm_frac": round(w["traffic_corrected_bytes"] / 1e9 / (ms * 1e-3) / HBM_PEAK, 4) if not why else None, "launches_in_pmc_pass": w.get("launches"),
+                     "kernel_launches_per_step": launches_live, "stale": why or None,
+                     "source": f"profiles/pmc_constants.json (commit {P['_meta']['commit'][:8]}): FETCH_SIZE + WRITE_SIZE summed over every kernel of one step (PMC passes of this command), over this run's "
+                               "ms_per_step; kernel_launches_per_step = the library's own tally in the timed steps (memsets and copies not included)"}
+        elif launches_live is not None:
+            whole = {"kernel_launches_per_step": launches_live}
+        ev_ab = None
+        if agg.get("_events_off_s"):
+            ev_ab = {"ms_per_step_with_events": round(dt / a.steps * 1e3, 2), "ms_per_step_without_events": round(agg["_events_off_s"] / a.steps * 1e3, 2), "steps_each": a.steps,
+                     "note": "the timed steps carry the HIP events of the kernel timing (the contract's live measurement); the same K steps repeated without them, same process, same inputs"}
         ppp = a.steps
         res = {
             "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",
@@ -439,7 +514,7 @@ def main():
                                                                                   "sort_overflow_segments", "x_records", "x_cindex_entries")},
                        "stage_ms_rank0": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
                                                                                         "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")},
-                       "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step)",
+                       "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step; cost: event_overhead)",
                        "results": "contig set (strings + member lists) complete in HBM at the end of a step, its digest read back inside the step; host copy on demand"},
             "result": {"digest": [str(v) for v in ref_digest], "digest_fields": "contigs, chars, members, unclustered, strings, member words, offsets, lists",
                        "every_timed_step_equal": True, "checked_run": checked},
@@ -447,6 +522,7 @@ def main():
             "value_file_to_streams": e2e,
             "value_strong_100m": strong,
             "whole_step": whole,
+            "event_overhead": ev_ab,
             "roofline": roof,
         }
         if comm is not None:

@@ -82,19 +82,27 @@ def host_cores() -> int:
         return os.cpu_count() or 1
 
 
-def reference_binary(L: int):
-    """(path, variant, threads) of the reference build with the most threads the box has cores for (oracle/build_ref.sh compiles the
-    thread count in, as the reference's own script does: minicom:56-91), or None"""
+def reference_binaries(L: int):
+    """[(path, variant, threads, march)] of the reference builds to try, best first: the most threads the box has cores for
+    (oracle/build_ref.sh compiles the thread count in, as the reference's own script does: minicom:56-91), then the x86-64-v2
+    build of the same should the box lack AVX2"""
     cores = host_cores()
-    best = None
+    out = []
     for t in (64, 32, 16, 8, 1):
-        variant = f"L{L}_t{t}" if t > 1 else f"L{L}"
-        exe = os.path.join(ROOT, "oracle", "_ref", variant, "minicom_bin")
-        if os.path.exists(exe) and (t <= cores or best is None):
-            best = (exe, variant, t)
-            if t <= cores:
-                break
-    return best
+        for suffix in ("", "_v2"):
+            variant = (f"L{L}_t{t}" if t > 1 else f"L{L}") + suffix
+            d = os.path.join(ROOT, "oracle", "_ref", variant)
+            exe = os.path.join(d, "minicom_bin")
+            if os.path.exists(exe) and t <= cores:
+                march = open(os.path.join(d, ".march")).read().strip() if os.path.exists(os.path.join(d, ".march")) else "x86-64-v2"
+                out.append((exe, variant, t, march))
+    return out
+
+
+def reference_binary(L: int):
+    """(path, variant, threads) of the first of reference_binaries, or None"""
+    c = reference_binaries(L)
+    return c[0][:3] if c else None
 
 
 def _append_fastq(out, reads, first_id):

@@ -2,6 +2,7 @@
 
   prof_export.py top  RESULTS.db OUT.csv          the top_kernels view of a rocpd database (durations in us)
   prof_export.py pmc  FETCH.csv WRITE.csv OUT.json  per kernel: launches, FETCH_SIZE and WRITE_SIZE in bytes (KB counters x 1024)
+  prof_export.py trace RESULTS.db OUT.csv [STEP]   every launch of one bench step (a step starts at a k_classify_* dispatch): name, start (us from the step's start), duration (us)
 """
 import collections
 import csv
@@ -41,8 +42,32 @@ def pmc(fetch_csv, write_csv, out):
         json.dump({k: res[k] for k in order}, f, indent=1)
 
 
+def trace(db, out, step=None):
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select name, start, end from kernels order by start"))
+    short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")
+    starts = [i for i, r in enumerate(rows) if short(r[0]).startswith("k_classify_")]
+    step = len(starts) - 1 if step is None else step
+    a = starts[step]; b = starts[step + 1] if step + 1 < len(starts) else len(rows)
+    t0 = rows[a][1]
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "start_us", "duration_us"])
+        for n, s, e in rows[a:b]:
+            n = short(n)
+            depth = 0
+            for i, ch in enumerate(n):
+                if ch == "<": depth += 1
+                elif ch == ">": depth -= 1
+                elif ch == "(" and depth == 0:
+                    n = n[:i]; break
+            w.writerow([n, round((s - t0) / 1e3, 2), round((e - s) / 1e3, 2)])
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "top":
         top(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
