@@ -120,6 +120,8 @@ def pmc_load():
         from tools import source_sha
         d["_by_norm"] = {source_sha.norm(k): v for k, v in d["kernels"].items()}
         d["_shas"], d["_kfiles"] = source_sha.file_shas(), source_sha.kernel_files()
+        d.setdefault("_meta", {}).setdefault("commit", "unknown (made before round 4)")
+        d["_meta"].setdefault("valu_busy", "")
         return d
     except Exception:                                                          # noqa: BLE001
         return None
