@@ -153,7 +153,12 @@ def pmc_class(d, observed, field):
             why.append(f"{name}: no {field}")
         else:
             tot += e[field] * cnt
-    return (None, why) if why else (tot, [])
+    return (None, brief(why)) if why else (tot, [])
+
+
+def brief(why, keep=6):
+    """a long list of reasons cut to its first few and a count"""
+    return why if len(why) <= keep else why[:keep] + [f"... and {len(why) - keep} more"]
 
 
 def main():
@@ -434,7 +439,7 @@ def main():
                 elif "valu_busy" in e and (best is None or e.get("sq_pass_ms", 0) > best[1].get("sq_pass_ms", 0)):
                     best = (name, e)
             if why or best is None:
-                return {"bound": "valu", "frac": None, "stale": why or ["no SQ pass for this class"]}
+                return {"bound": "valu", "frac": None, "stale": brief(why) or ["no SQ pass for this class"]}
             name, e = best
             return {"bound": "valu", "kernel": name, "frac": e["valu_busy"], "valu_busy": e["valu_busy"], "valu_active_of_wave_cycles": e.get("valu_active_of_wave_cycles"),
                     "wait_any_of_wave_cycles": e.get("wait_any"), "issue_stall_of_wave_cycles": e.get("wait_inst"), "waves_per_simd_avg": e.get("waves_per_simd_avg"),
@@ -485,7 +490,7 @@ def main():
             why = [x for x in (pmc_entry(P, k)[1] for k in observed.get("*", {})) if x]
             whole = {"traffic_GB": round(w["traffic_corrected_bytes"] / 1e9, 1) if not why else None, "traffic_raw_GB": round(w["traffic_raw_bytes"] / 1e9, 1) if not why else None,
                      "hbm_frac": round(w["traffic_corrected_bytes"] / 1e9 / (ms * 1e-3) / HBM_PEAK, 4) if not why else None, "launches_in_pmc_pass": w.get("launches"),
-                     "kernel_launches_per_step": launches_live, "stale": why or None,
+                     "kernel_launches_per_step": launches_live, "stale": brief(why) or None,
                      "source": f"profiles/pmc_constants.json (commit {P['_meta']['commit'][:8]}): FETCH_SIZE + WRITE_SIZE summed over every kernel of one step (PMC passes of this command), over this run's "
                                "ms_per_step; kernel_launches_per_step = the library's own tally in the timed steps (memsets and copies not included)"}
         elif launches_live is not None:

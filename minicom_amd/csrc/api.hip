@@ -2,6 +2,8 @@
 #include "mcom_dev.hpp"
 #include "../../include/mcom_test.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#include <cxxabi.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -221,15 +223,23 @@ extern "C" int mcom_prof_reset(mcom_ctx *ctx)
 	return MCOM_OK;
 }
 
-// "const char *mcom_kernel_name() [K = &(anonymous namespace)::k_x<5, true>]" -> "k_x<5, true>"
-static std::string prof_kernel_text(const char *pretty)
+// host address of a kernel -> "k_x<5, true>": the runtime's (mangled) name, demangled, without return type and argument list
+static std::string prof_kernel_text(mcom_ctx *ctx, const void *fn)
 {
-	std::string t(pretty);
-	size_t a = t.find("K = &");
-	if (a != std::string::npos) t = t.substr(a + 5);
-	if (!t.empty() && t.back() == ']') t.pop_back();
+	const char *m = hipKernelNameRefByPtr(fn, ctx->stream);
+	if (!m) { (void)hipGetLastError(); char b[32]; snprintf(b, sizeof b, "kernel@%p", fn); return b; }
+	int st = 0;
+	char *d = abi::__cxa_demangle(m, nullptr, nullptr, &st);
+	std::string t = (st == 0 && d) ? d : m;
+	free(d);
+	if (t.compare(0, 5, "void ") == 0) t.erase(0, 5);
 	const char *anon = "(anonymous namespace)::";
 	for (size_t q; (q = t.find(anon)) != std::string::npos; ) t.erase(q, strlen(anon));
+	int depth = 0;
+	for (size_t i = 0; i < t.size(); ++i) {                                     // cut at the argument list: the first '(' outside template brackets
+		if (t[i] == '<') ++depth; else if (t[i] == '>') --depth;
+		else if (t[i] == '(' && depth == 0) { t.erase(i); break; }
+	}
 	return t;
 }
 
@@ -242,7 +252,7 @@ extern "C" int mcom_prof_kernels(mcom_ctx *ctx, const char *name, char *buf, siz
 	else for (int i = 0; i < PROF_COUNT; ++i) if (!strcmp(name, PROF_NAMES[i])) cls = i;
 	if (cls == -1) return mcom_fail(ctx, MCOM_E_ARG, "unknown profiler name %s", name);
 	std::map<std::string, uint64_t> out;
-	for (const auto &kv : ctx->prof_kernels) if (cls == -2 || kv.first.first == cls) out[prof_kernel_text(kv.first.second)] += kv.second;
+	for (const auto &kv : ctx->prof_kernels) if (cls == -2 || kv.first.first == cls) out[prof_kernel_text(ctx, kv.first.second)] += kv.second;
 	std::string txt;
 	for (const auto &kv : out) { txt += kv.first; txt += '\t'; txt += std::to_string(kv.second); txt += '\n'; }
 	if (need) *need = txt.size() + 1;

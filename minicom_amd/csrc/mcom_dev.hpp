@@ -25,10 +25,10 @@ struct mcom_ctx {
 	std::vector<McomProfSpan> prof_open;
 	double prof_ms[PROF_COUNT] = {0};
 	uint64_t prof_calls[PROF_COUNT] = {0};
-	// which kernels were launched, how often, and inside which timed class (PROF_COUNT = outside any): keyed by the address of the
-	// instantiation's name string (MCOM_LAUNCH), so that a caller can ask for the EXACT kernels a class's time belongs to
+	// which kernels were launched, how often, and inside which timed class (PROF_COUNT = outside any): keyed by the host address of
+	// the instantiation (MCOM_LAUNCH), so that a caller can ask for the EXACT kernels a class's time belongs to
 	int prof_cur = PROF_COUNT;
-	std::map<std::pair<int, const char *>, uint64_t> prof_kernels;
+	std::map<std::pair<int, const void *>, uint64_t> prof_kernels;
 	// bucket sort: capacity of an in-LDS segment (0 = the kernel's own 4096; tests lower it to reach the fallback on small
 	// inputs) and how many segments went through the fallback so far
 	uint32_t seg_cap = 0; uint64_t sort_overflow_segments = 0;
@@ -69,11 +69,10 @@ struct McomProfScope {
 	int prev = PROF_COUNT;
 };
 // Every kernel launch of the library goes through MCOM_LAUNCH: hipLaunchKernelGGL, plus -- while the profiler is on -- a tally of
-// the kernel's name under the class whose scope is open.  The name is the compiler's own spelling of the instantiation
-// ("... [K = &k_sketch_reads<5, true, true>]"), which is what rocprofv3 prints for the same kernel.
-template <auto K> const char *mcom_kernel_name() { return __PRETTY_FUNCTION__; }
+// the instantiation under the class whose scope is open.  mcom_prof_kernels turns the addresses into names with the runtime's own
+// table (hipKernelNameRefByPtr, demangled): the spelling rocprofv3 prints for the same kernel, template arguments included.
 #define MCOM_LAUNCH(kernel, grid, block, lds, stream, ...) do { \
-	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, mcom_kernel_name<&kernel>())]; \
+	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, (const void*)&kernel)]; \
 	hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
 
 int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);

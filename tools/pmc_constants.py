@@ -120,8 +120,9 @@ def main():
                                 "--no-cpu-baseline --no-host-to-host --no-check --e2e-reads 0` (100 M x 150 bp); raw = counters x 1024; corrected = FETCH x 2 for the wide streaming readers "
                                 "listed in tools/pmc_constants.py (MI355X_MICROARCH.md, HBM)",
                      "sq": f"profiles/{tag}_pmc_sq.json: two SQ passes of the same command at --reads {sq_reads}; per-wave figures do not depend on the size",
-                     "valu_busy": "SQ_ACTIVE_INST_VALU (quad-cycles summed over waves) x 4 / (1024 SIMDs x kernel time in that pass x 2.4 GHz): the share of the SIMDs' cycles in which a VALU "
-                                  "instruction of some wave was executing"},
+                     "valu_busy": "rocprofv3's VALUBusy: SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE (per XCD) -- on gfx950 SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU (one quad-cycle per "
+                                  "instruction), so it is 4 / simd_cycles_per_valu_inst and exceeds 1 when the SIMDs issue cheaper-than-4-cycle instructions back to back: >= 1 means saturated; "
+                                  "simd_cycles_per_valu_inst = 1024 SIMDs x GRBM_GUI_ACTIVE / 8 / SQ_INSTS_VALU, at the clock the chip held (clock_ghz)"},
            "kernels": {}}
     whole = {"traffic_raw_bytes": 0, "traffic_corrected_bytes": 0, "launches": 0}
     then_shas = sha_then["files"]
@@ -149,12 +150,17 @@ def main():
             continue
         e = res["kernels"].setdefault(k, {})
         secs = d["ms_in_pass"] * 1e-3
+        gui = d.get("GRBM_GUI_ACTIVE", 0)                                            # summed over the 8 XCDs: / 8 = cycles the kernel was on the chip
         e.update({"valu_per_wave": int(d.get("SQ_INSTS_VALU", 0) / w), "salu_per_wave": int(d.get("SQ_INSTS_SALU", 0) / w), "lds_per_wave": int(d.get("SQ_INSTS_LDS", 0) / w),
                   "vmem_rd_per_wave": round(d.get("SQ_INSTS_VMEM_RD", 0) / w, 1), "vmem_wr_per_wave": round(d.get("SQ_INSTS_VMEM_WR", 0) / w, 1),
                   "wait_any": round(d.get("SQ_WAIT_ANY", 0) / cyc, 3), "wait_inst": round(d.get("SQ_WAIT_INST_ANY", 0) / cyc, 3), "active": round(d.get("SQ_ACTIVE_INST_ANY", 0) / cyc, 3),
                   "valu_active_of_wave_cycles": round(d.get("SQ_ACTIVE_INST_VALU", 0) / cyc, 3),
-                  "valu_busy": round(d.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (N_SIMD * secs * CLOCK_HZ), 4) if secs > 0 else None,
-                  "waves_per_simd_avg": round(cyc * 4 / (N_SIMD * secs * CLOCK_HZ), 2) if secs > 0 else None,
+                  "valu_busy": round(d.get("SQ_ACTIVE_INST_VALU", 0) / 256.0 / (gui / 8.0), 4) if gui else None,
+                  "clock_ghz": round(gui / 8.0 / secs / 1e9, 3) if gui and secs > 0 else None,
+                  "simd_cycles_per_valu_inst": round(N_SIMD * (gui / 8.0) / d["SQ_INSTS_VALU"], 3) if gui and d.get("SQ_INSTS_VALU") else None,
+                  "ns_per_valu_inst_per_simd": round(secs * N_SIMD / d["SQ_INSTS_VALU"] * 1e9, 4) if secs > 0 and d.get("SQ_INSTS_VALU") else None,
+                  "int64_share_of_valu": round(d.get("SQ_INSTS_VALU_INT64", 0) / d["SQ_INSTS_VALU"], 3) if d.get("SQ_INSTS_VALU") and "SQ_INSTS_VALU_INT64" in d else None,
+                  "waves_per_simd_avg": round(cyc * 4 / (N_SIMD * (gui / 8.0)), 2) if gui else None,
                   "sq_busy_cycles": d.get("SQ_BUSY_CYCLES"), "grbm_gui_active": d.get("GRBM_GUI_ACTIVE"), "sq_pass_ms": d["ms_in_pass"], "sq_pass_reads": sq_reads})
     for k, e in res["kernels"].items():
         e["source_file"] = kfiles.get(k.split("<")[0])

@@ -14,8 +14,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 python3 tools/source_sha.py > "$O/source_sha.json"
-PROFILED="--steps 2 --warmup 1 --no-cpu-baseline --no-host-to-host --e2e-reads 0"
-COUNTED="--steps 1 --warmup 0 --no-cpu-baseline --no-host-to-host --no-check --e2e-reads 0"
+PROFILED="--steps 2 --warmup 1 --no-event-ab --no-cpu-baseline --no-host-to-host --e2e-reads 0"
+COUNTED="--steps 1 --warmup 0 --no-event-ab --no-cpu-baseline --no-host-to-host --no-check --e2e-reads 0"
 echo "[1/6] kernel trace + stats: bench.py $PROFILED"
 rocprofv3 --kernel-trace --stats -d "$O/kt" -o kt -- python3 bench.py $PROFILED > "$O/line_profiled.json" 2> "$O/kt.err"
 DB=$(find "$O/kt" -name '*.db' | head -1)
@@ -31,7 +31,7 @@ echo "[4/6] SQ pass A (issue / busy) at $SQ_READS reads"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$O/sqa" -o s -- python3 bench.py $COUNTED --reads "$SQ_READS" > "$O/sqa.out" 2> "$O/sqa.err"
 echo "[5/6] SQ pass B (instruction mix)"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_LDS_BANK_CONFLICT \
     --output-format csv -d "$O/sqb" -o s -- python3 bench.py $COUNTED --reads "$SQ_READS" > "$O/sqb.out" 2> "$O/sqb.err"
 echo "[6/6] the unprofiled line: python3 bench.py (defaults)"
 python3 bench.py > "$O/line_default.json" 2> "$O/default.err"
