@@ -303,10 +303,10 @@ int mcom_cindex_build(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_
  *                            whole index (upper bound), *n_share = room a share needs for the entries it receives, *geom, *n_words
  *   mcom_cindex_entries      the entries of contigs [c0, c1) of the set (a rank takes a range of the replicated set): d_key / d_slot
  *                            [cap >= their positions], grouped by owning share in share order, h_counts[ranks] (HOST) = entries per
- *                            share.  With one share they come grouped by the low byte of their partition (place: grouped = 1).
+ *                            share.  With one share they come grouped by the high byte of their partition (place: grouped = 1).
  *                            Entries carry the global contig index.  MCOM_E_OVERFLOW when cap is too small.  Synchronous.
  *   mcom_cindex_place        this share's table from the n_ent entries it received, in any order (grouped = 0): two radix passes by
- *                            partition, then one workgroup per partition writes its lines.  d_key / d_slot are overwritten,
+ *                            partition (high byte, then low byte inside each high-byte region), then one workgroup per partition writes its lines.  d_key / d_slot are overwritten,
  *                            d_key_tmp / d_slot_tmp are scratch of n_ent entries.  MCOM_E_OVERFLOW as for mcom_cindex_build.
  * mcom_cindex_build = mcom_cindex_entries + mcom_cindex_place for one share.                                                */
 int mcom_cindex_plan_shared(uint64_t n_windows, uint32_t n_contigs, int L, int ininumdict, int ranks, int rank, uint64_t *n_entries,

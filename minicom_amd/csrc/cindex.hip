@@ -38,45 +38,81 @@ __global__ void k_cindex_blocks(int maxoff, const uint64_t *__restrict__ woff, u
 	for (uint64_t blk = (a + 255) >> 8; (blk << 8) < b && blk < n_blocks; ++blk) first_contig[blk] = c;
 }
 
+// Workgroups are dealt to the 8 XCDs round robin, and every XCD has an L2 of its own.  Tiles that follow each other write runs that
+// follow each other (the same digit's region), and a run of ~24 entries ends inside a 128-byte line: with tile = block, the two
+// halves of such a line are written through two different L2s.  So XCD x takes a contiguous eighth of the tiles: the halves meet
+// in one L2 and leave it as whole lines.  t >= n_tiles: a spare workgroup (the eighths are rounded up).
+__device__ __forceinline__ uint32_t cx_tile(uint32_t b, uint32_t n_tiles) { const uint32_t per = (n_tiles + 7u) >> 3; return (b & 7u) * per + (b >> 3); }
+static inline uint32_t cx_grid(uint32_t n_tiles) { return ((n_tiles + 7u) >> 3) << 3; }
+
 struct CxSrc { const uint64_t *cbits, *coff, *woff; const uint32_t *first_contig; uint32_t c1; uint64_t pos0, n_pos; unsigned long long *head; };
 
-// the entry of position gi: false when the position holds none (a contig without windows, the end of the range)
-// digit: what pass 1 splits by -- the low byte of the partition, or (multi-GPU) the share that owns the key
-__device__ __forceinline__ bool cx_entry(const CixGeom &g, const CxSrc &s, uint64_t gi, uint32_t &key32, uint64_t &slot, uint32_t &digit)
+// ---- walking the position space.  A thread owns CX_ITEMS CONSECUTIVE positions: it finds its contig once, loads three words of
+// the packed string and then rolls the klen-mer two bits per position (round 3 looked every position up on its own: contig search,
+// offsets and two word loads per position, twice -- histogram and scatter; the round-4 profile gave 3.6 + 9.9 ms for the two).
+struct CxWalk { uint32_t c; bool has; uint64_t p, np, lo, hi; };
+__device__ __forceinline__ uint64_t cx_first(const CixGeom &g, const CxSrc &s, uint32_t c) { return s.woff[c] + (uint64_t)g.maxoff * c - s.pos0; }
+__device__ __forceinline__ void cx_load(const CixGeom &g, const CxSrc &s, CxWalk &w)
 {
-	if (gi >= s.n_pos) return false;
+	w.has = s.woff[w.c + 1] != s.woff[w.c];
+	if (!w.has || w.p >= w.np) return;
+	const uint64_t len = (s.woff[w.c + 1] - s.woff[w.c]) + (uint64_t)g.L - 1;     // the contig's length: its words are ceil(2 len / 64) + 1
+	const uint64_t q = (2 * len + 63) >> 6, i = (2 * w.p) >> 6;
+	const uint64_t *src = s.cbits + s.coff[w.c] + i;
+	const int sh = (int)((2 * w.p) & 63);
+	const uint64_t w0 = src[0], w1 = src[1], w2 = i + 2 <= q ? src[2] : 0ull;      // (bits past the contig's own words are never part of a key)
+	w.lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+	w.hi = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+}
+__device__ __forceinline__ void cx_seek(const CixGeom &g, const CxSrc &s, uint64_t gi, CxWalk &w)
+{
 	uint32_t c = s.first_contig[gi >> 8];
-	while (c + 1 < s.c1 && s.woff[c + 1] + (uint64_t)g.maxoff * (c + 1) - s.pos0 <= gi) ++c;
-	if (s.woff[c + 1] == s.woff[c]) return false;
-	const uint64_t p = gi - (s.woff[c] + (uint64_t)g.maxoff * c - s.pos0);
-	if (p >> g.pbits) { if (*(volatile unsigned long long*)(s.head + 1) == 0) s.head[1] = 1; return false; }   // reported by the build
-	const uint64_t *src = s.cbits + s.coff[c] + ((2 * p) >> 6);
-	const int sh = (int)((2 * p) & 63);
-	uint64_t v = src[0] >> sh;
-	if (sh + 2 * g.klen > 64) v |= src[1] << (64 - sh);
-	const uint64_t key = v & ((1ull << (2 * g.klen)) - 1);
-	uint32_t own, part, h16;
-	cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
-	key32 = (part << 16) | h16;
-	digit = g.n_owners > 1 ? own : (part & 255u);
-	slot = (cix_tag(key) << CIX_TAG_SHIFT) | ((uint64_t)c << g.pbits) | p;
-	return true;
+	while (c + 1 < s.c1 && cx_first(g, s, c + 1) <= gi) ++c;
+	const uint64_t a = cx_first(g, s, c);
+	w.c = c; w.p = gi - a; w.np = cx_first(g, s, c + 1) - a;
+	cx_load(g, s, w);
+}
+// the entry of the walk's position (false: a contig without windows), then one position on
+// digit: what pass 1 splits by -- the HIGH byte of the partition, or (multi-GPU) the share that owns the key
+__device__ __forceinline__ bool cx_step(const CixGeom &g, const CxSrc &s, CxWalk &w, uint32_t &key32, uint64_t &slot, uint32_t &digit)
+{
+	while (w.p >= w.np) {                                                           // next contig (rare: a contig holds hundreds of positions)
+		++w.c; w.p = 0; w.np = cx_first(g, s, w.c + 1) - cx_first(g, s, w.c);
+		cx_load(g, s, w);
+	}
+	bool ok = w.has;
+	if (ok && (w.p >> g.pbits)) { if (*(volatile unsigned long long*)(s.head + 1) == 0) s.head[1] = 1; ok = false; }   // reported by the build
+	if (ok) {
+		const uint64_t key = w.lo & ((1ull << (2 * g.klen)) - 1);
+		uint32_t own, part, h16;
+		cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
+		key32 = (part << 16) | h16;
+		digit = g.n_owners > 1 ? own : (part >> 8);
+		slot = (cix_tag(key) << CIX_TAG_SHIFT) | ((uint64_t)w.c << g.pbits) | w.p;
+	}
+	w.lo = (w.lo >> 2) | (w.hi << 62); w.hi >>= 2; ++w.p;
+	return ok;
 }
 
-// pass 1, histogram: digit = low byte of the partition (owner of the key when the index is shared out)
+// pass 1, histogram: digit = high byte of the partition (owner of the key when the index is shared out)
 __global__ __launch_bounds__(CX_THREADS) void k_cx_hist1(CixGeom g, CxSrc s, uint32_t *__restrict__ hist, uint32_t nblocks)
 {
 	__shared__ uint32_t h[256];
+	const uint32_t tile = cx_tile(blockIdx.x, nblocks);
+	if (tile >= nblocks) return;
 	h[threadIdx.x] = 0;
 	__syncthreads();
-	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
+	uint64_t gi = (uint64_t)tile * CX_TILE + (uint64_t)threadIdx.x * CX_ITEMS;
+	if (gi < s.n_pos) {
+		CxWalk w; cx_seek(g, s, gi, w);
 #pragma unroll 4
-	for (int it = 0; it < CX_ITEMS; ++it) {
-		uint32_t k32, dg; uint64_t sl;
-		if (cx_entry(g, s, base + (uint64_t)it * CX_THREADS + threadIdx.x, k32, sl, dg)) atomicAdd(&h[dg], 1u);
+		for (int it = 0; it < CX_ITEMS && gi < s.n_pos; ++it, ++gi) {
+			uint32_t k32, dg; uint64_t sl;
+			if (cx_step(g, s, w, k32, sl, dg)) atomicAdd(&h[dg], 1u);
+		}
 	}
 	__syncthreads();
-	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+	hist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
 }
 
 // pass 1, scatter: the tile's entries grouped by digit in LDS (order inside a digit is free), every digit's run written in one piece
@@ -91,16 +127,22 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 	__shared__ uint8_t st_dig[OWNERS ? CX_TILE : 4];
 	__shared__ uint32_t cnt[256], start[256], gofs[256], wsum[CX_THREADS / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t tile = cx_tile(blockIdx.x, nblocks);
+	if (tile >= nblocks) return;
 	cnt[tid] = 0;
 	__syncthreads();
-	const uint64_t base = (uint64_t)blockIdx.x * CX_TILE;
+	uint64_t gi = (uint64_t)tile * CX_TILE + (uint64_t)tid * CX_ITEMS;
 	uint32_t k32[CX_ITEMS], rank[CX_ITEMS]; uint64_t sl[CX_ITEMS]; bool ok[CX_ITEMS]; uint8_t dg[CX_ITEMS];
+	{
+		CxWalk w; w.c = 0; w.has = false; w.p = w.np = w.lo = w.hi = 0;
+		if (gi < s.n_pos) cx_seek(g, s, gi, w);
 #pragma unroll
-	for (int it = 0; it < CX_ITEMS; ++it) {
-		uint32_t d = 0;
-		ok[it] = cx_entry(g, s, base + (uint64_t)it * CX_THREADS + tid, k32[it], sl[it], d);
-		dg[it] = (uint8_t)d;
-		rank[it] = ok[it] ? atomicAdd(&cnt[d], 1u) : 0u;
+		for (int it = 0; it < CX_ITEMS; ++it, ++gi) {
+			uint32_t d = 0;
+			ok[it] = gi < s.n_pos && cx_step(g, s, w, k32[it], sl[it], d);
+			dg[it] = (uint8_t)d;
+			rank[it] = ok[it] ? atomicAdd(&cnt[d], 1u) : 0u;
+		}
 	}
 	__syncthreads();
 	{
@@ -113,7 +155,7 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 		uint32_t add = 0;
 		for (int q = 0; q < wv; ++q) add += wsum[q];
 		start[tid] = v + add - tot;
-		gofs[tid] = offs[(size_t)tid * nblocks + blockIdx.x];
+		gofs[tid] = offs[(size_t)tid * nblocks + tile];
 	}
 	__syncthreads();
 #pragma unroll
@@ -125,103 +167,147 @@ __global__ __launch_bounds__(CX_THREADS) void k_cx_scatter1(CixGeom g, CxSrc s, 
 	__syncthreads();
 	const uint32_t total = start[255] + cnt[255];
 	for (uint32_t q = tid; q < total; q += CX_THREADS) {
-		const uint32_t d = OWNERS ? (uint32_t)st_dig[q] : (st_key[q] >> 16) & 255u;
+		const uint32_t d = OWNERS ? (uint32_t)st_dig[q] : st_key[q] >> 24;
 		const size_t o = (size_t)gofs[d] + (q - start[d]);
 		out_key[o] = st_key[q]; out_slot[o] = st_slot[q];
 	}
 }
 
-// passes over the entry arrays (digit = byte of the partition at `shift`: 24 = its high byte, 16 = its low byte), stable: the tile
-// logic of sort.hip's k_radix_scatter on two arrays
-__global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restrict__ key, size_t n, uint32_t *__restrict__ hist, uint32_t nblocks, int shift)
+// ---- passes over the entry arrays.  MSD order (round 4): first by the high byte of the partition (pass 1 above, or -- for entries
+// that arrive in any order -- the flat pass REGION = false here), then INSIDE each of those 256 regions by the low byte (REGION =
+// true: tiles never straddle two regions).  No pass needs to be stable (the order inside a partition is free), so ranks come from
+// LDS atomics as in pass 1 (round 3's second pass was the LSD-stable one: eight ballots per entry), and the starts of the
+// partitions fall out of the second pass's scanned histogram (no search pass).
+// rs[257]: first entry of every region; tp[257]: first tile of every region (tiles of CX_TILE entries, the last of a region short)
+struct CxTiles { uint32_t rs[257], tp[257]; };
+__global__ void k_cx_regions(const uint32_t *__restrict__ key, uint32_t n, CxTiles *__restrict__ T)
 {
-	__shared__ uint32_t h[256];
-	h[threadIdx.x] = 0;
+	__shared__ uint32_t tl[257];
+	const uint32_t v = threadIdx.x;                                                    // 0 .. 256: first index whose high byte is >= v
+	uint32_t lo = 0, hi = n;
+	if (v >= 256) lo = n;
+	else while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((key[mid] >> 24) < v) lo = mid + 1; else hi = mid; }
+	T->rs[v] = lo; tl[v] = lo;
 	__syncthreads();
-	const size_t base = (size_t)blockIdx.x * CX_TILE;
+	if (v == 0) {
+		uint32_t run = 0;
+		for (int r = 0; r < 256; ++r) { T->tp[r] = run; run += (tl[r + 1] - tl[r] + CX_TILE - 1) / CX_TILE; }
+		T->tp[256] = run;
+	}
+}
+// where a block of the region passes works: region r, tile t of it, entries [first, first + count); false: a spare block
+struct CxWhere { uint32_t r, t, nt, first, count; };
+__device__ __forceinline__ bool cx_where(const CxTiles *__restrict__ T, uint32_t b, uint32_t *sh_tp, CxWhere &w)
+{
+	for (uint32_t q = threadIdx.x; q < 257; q += blockDim.x) sh_tp[q] = T->tp[q];
+	__syncthreads();
+	if (b >= sh_tp[256]) return false;
+	uint32_t lo = 0, hi = 255;                                                         // the last region whose first tile is <= b (empty regions share a first tile with the next)
+	while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (sh_tp[mid] <= b) lo = mid; else hi = mid - 1; }
+	// (tp[lo + 1] > b >= tp[lo]: the region is not empty)
+	w.r = lo; w.t = b - sh_tp[lo]; w.nt = sh_tp[lo + 1] - sh_tp[lo];
+	const uint32_t a = T->rs[lo], e = T->rs[lo + 1];
+	w.first = a + w.t * CX_TILE;
+	w.count = e - w.first < (uint32_t)CX_TILE ? e - w.first : (uint32_t)CX_TILE;
+	return true;
+}
+template <bool REGION>
+__global__ __launch_bounds__(CX_THREADS) void k_cx_hist2(const uint32_t *__restrict__ key, uint32_t n, const CxTiles *__restrict__ T, uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+	__shared__ uint32_t h[256], sh_tp[257];
+	const uint32_t b = cx_tile(blockIdx.x, nblocks);
+	if (b >= nblocks) return;
+	h[threadIdx.x] = 0;
+	uint32_t first, count; size_t at;
+	if (REGION) {
+		CxWhere w;
+		if (!cx_where(T, b, sh_tp, w)) { hist[(size_t)256 * b + threadIdx.x] = 0; return; }   // spare tiles clear the spare slots
+		first = w.first; count = w.count; at = (size_t)256 * sh_tp[w.r] + (size_t)threadIdx.x * w.nt + w.t;
+	} else {
+		__syncthreads();
+		first = b * (uint32_t)CX_TILE; count = n - first < (uint32_t)CX_TILE ? n - first : (uint32_t)CX_TILE;
+		at = (size_t)threadIdx.x * nblocks + b;
+	}
 #pragma unroll 4
 	for (int it = 0; it < CX_ITEMS; ++it) {
-		const size_t i = base + (size_t)it * CX_THREADS + threadIdx.x;
-		if (i < n) atomicAdd(&h[(key[i] >> shift) & 255u], 1u);
+		const uint32_t i = (uint32_t)it * CX_THREADS + threadIdx.x;
+		if (i < count) atomicAdd(&h[(key[first + i] >> (REGION ? 16 : 24)) & 255u], 1u);
 	}
 	__syncthreads();
-	hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+	hist[at] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__restrict__ in_key, const uint64_t *__restrict__ in_slot, size_t n,
-                                                            const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot, int shift)
+template <bool REGION>
+__global__ __launch_bounds__(CX_THREADS) void k_cx_scatter2(const uint32_t *__restrict__ in_key, const uint64_t *__restrict__ in_slot, uint32_t n, const CxTiles *__restrict__ T,
+                                                            const uint32_t *__restrict__ offs, uint32_t nblocks, uint32_t *__restrict__ out_key, uint64_t *__restrict__ out_slot)
 {
 	__shared__ uint64_t st_slot[CX_TILE];
 	__shared__ uint32_t st_key[CX_TILE];
-	__shared__ uint32_t wcnt[CX_THREADS / 64][256];
-	__shared__ uint32_t tstart[256], gofs[256], wsum[CX_THREADS / 64];
+	__shared__ uint32_t cnt[256], start[256], gofs[256], wsum[CX_THREADS / 64], sh_tp[257];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	for (int q = tid; q < (CX_THREADS / 64) * 256; q += CX_THREADS) (&wcnt[0][0])[q] = 0;
-	__syncthreads();
-	const size_t base = (size_t)blockIdx.x * CX_TILE + (size_t)wv * (CX_TILE / (CX_THREADS / 64));
-	uint32_t k32[CX_ITEMS]; uint64_t sl[CX_ITEMS]; uint16_t rank[CX_ITEMS];
-	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+	constexpr int SHIFT = REGION ? 16 : 24;
+	const uint32_t b = cx_tile(blockIdx.x, nblocks);
+	if (b >= nblocks) return;
+	cnt[tid] = 0;
+	uint32_t first, count; size_t at;
+	if (REGION) {
+		CxWhere w;
+		if (!cx_where(T, b, sh_tp, w)) return;
+		first = w.first; count = w.count; at = (size_t)256 * sh_tp[w.r] + (size_t)tid * w.nt + w.t;
+	} else {
+		__syncthreads();
+		first = b * (uint32_t)CX_TILE; count = n - first < (uint32_t)CX_TILE ? n - first : (uint32_t)CX_TILE;
+		at = (size_t)tid * nblocks + b;
+	}
+	uint32_t k32[CX_ITEMS], rank[CX_ITEMS]; uint64_t sl[CX_ITEMS];
 #pragma unroll
-	for (int c = 0; c < CX_ITEMS; ++c) {
-		const size_t i = base + (size_t)c * 64 + lane;
-		const bool valid = i < n;
-		uint32_t d = 0;
-		if (valid) { k32[c] = in_key[i]; sl[c] = in_slot[i]; d = (k32[c] >> shift) & 255u; }
-		uint64_t peers = __ballot(valid);
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		const uint32_t i = (uint32_t)it * CX_THREADS + tid;
+		if (i < count) { k32[it] = in_key[first + i]; sl[it] = in_slot[first + i]; }
+	}
 #pragma unroll
-		for (int bit = 0; bit < 8; ++bit) {
-			const bool one = (d >> bit) & 1;
-			const uint64_t bl = __ballot(one);
-			peers &= one ? bl : ~bl;
-		}
-		uint32_t old = 0;
-		const int leader = __ffsll((unsigned long long)peers) - 1;
-		if (valid && lane == leader) { old = wcnt[wv][d]; wcnt[wv][d] = old + (uint32_t)__popcll(peers); }
-		old = __shfl(old, leader < 0 ? 0 : leader, 64);
-		rank[c] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		const uint32_t i = (uint32_t)it * CX_THREADS + tid;
+		rank[it] = i < count ? atomicAdd(&cnt[(k32[it] >> SHIFT) & 255u], 1u) : 0u;
 	}
 	__syncthreads();
 	{
-		const int d = tid;
-		uint32_t c[CX_THREADS / 64], tot = 0;
-#pragma unroll
-		for (int w = 0; w < CX_THREADS / 64; ++w) { c[w] = wcnt[w][d]; tot += c[w]; }
+		const uint32_t tot = cnt[tid];
 		uint32_t v = tot;
 #pragma unroll
-		for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = __shfl_up(v, sft, 64); if (lane >= sft) v += t; }
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
 		if (lane == 63) wsum[wv] = v;
 		__syncthreads();
 		uint32_t add = 0;
 		for (int q = 0; q < wv; ++q) add += wsum[q];
-		uint32_t run = v + add - tot;
-		tstart[d] = run;
-#pragma unroll
-		for (int w = 0; w < CX_THREADS / 64; ++w) { wcnt[w][d] = run; run += c[w]; }
-		gofs[d] = offs[(size_t)d * nblocks + blockIdx.x];
+		start[tid] = v + add - tot;
+		gofs[tid] = offs[at];
 	}
 	__syncthreads();
 #pragma unroll
-	for (int c = 0; c < CX_ITEMS; ++c) {
-		const size_t i = base + (size_t)c * 64 + lane;
-		if (i < n) { const uint32_t at = wcnt[wv][(k32[c] >> shift) & 255u] + rank[c]; st_key[at] = k32[c]; st_slot[at] = sl[c]; }
+	for (int it = 0; it < CX_ITEMS; ++it) {
+		const uint32_t i = (uint32_t)it * CX_THREADS + tid;
+		if (i < count) { const uint32_t p = start[(k32[it] >> SHIFT) & 255u] + rank[it]; st_key[p] = k32[it]; st_slot[p] = sl[it]; }
 	}
 	__syncthreads();
-	const size_t tile_base = (size_t)blockIdx.x * CX_TILE;
-	const uint32_t total = (uint32_t)((n - tile_base) < (size_t)CX_TILE ? (n - tile_base) : (size_t)CX_TILE);
-	for (uint32_t q = tid; q < total; q += CX_THREADS) {
-		const uint32_t k = st_key[q], d = (k >> shift) & 255u;
-		const size_t o = (size_t)gofs[d] + (q - tstart[d]);
+	for (uint32_t q = tid; q < count; q += CX_THREADS) {
+		const uint32_t k = st_key[q], d = (k >> SHIFT) & 255u;
+		const size_t o = (size_t)gofs[d] + (q - start[d]);
 		out_key[o] = k; out_slot[o] = st_slot[q];
 	}
 }
 
-// first entry of every partition in the sorted key array: pstart[v] = first index whose partition is >= v
-__global__ void k_cx_bounds(const uint32_t *__restrict__ key, size_t n, uint32_t n_parts, uint32_t *__restrict__ pstart)
+// first entry of every partition, from the scanned histogram of the region pass: partition v = region v >> 8, digit v & 255
+__global__ void k_cx_pstart(const CxTiles *__restrict__ T, const uint32_t *__restrict__ offs, uint32_t n, uint32_t n_parts, uint32_t *__restrict__ pstart)
 {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	const uint32_t cur = i < n ? key[i] >> 16 : n_parts;
-	const uint32_t first = i > 0 ? (key[i - 1] >> 16) + 1 : 0;
-	for (uint32_t v = first; v <= cur && v <= n_parts; ++v) pstart[v] = (uint32_t)i;
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > n_parts) return;
+	const uint32_t r = v >> 8, d = v & 255u;
+	uint32_t at = n;
+	if (v < n_parts && r < 256) {
+		const uint32_t nt = T->tp[r + 1] - T->tp[r];
+		at = nt ? offs[(size_t)256 * T->tp[r] + (size_t)d * nt] : T->rs[r];
+	}
+	pstart[v] = at;
 }
 // ---- placement: one workgroup per partition ------------------------------------------------------------------------------
 #define CA_THREADS 512
@@ -377,10 +463,20 @@ __global__ __launch_bounds__(CS_THREADS) void k_cx_assemble_sorted(const uint32_
 	unsigned long long *lines = head + CIX_HEAD_WORDS;
 	unsigned long long *L0 = lines + (size_t)part * NL * 8;
 	unsigned long long *X0 = lines + (size_t)n_parts * NL * 8;
+	// every entry of the partition is loaded NOW: 14 keys and 14 slot words per thread, all in flight at once; the keys are used
+	// twice (counts, sort) and the slot words only after the scans, so their latency hides behind everything in between (round 3
+	// loaded key by key and slot by slot inside the two loops, and the keys twice)
+	constexpr int CS_PER = CS_CAP / CS_THREADS;
+	uint32_t kk[CS_PER]; uint64_t ss[CS_PER];
+#pragma unroll
+	for (int q = 0; q < CS_PER; ++q) { const uint32_t i = (uint32_t)q * CS_THREADS + tid; kk[q] = i < n ? key[s0 + i] : 0u; }
+#pragma unroll
+	for (int q = 0; q < CS_PER; ++q) { const uint32_t i = (uint32_t)q * CS_THREADS + tid; ss[q] = i < n ? slot[s0 + i] : 0ull; }
 	for (uint32_t l = tid; l < NL; l += CS_THREADS) cnt[l] = 0;
 	if (tid == 0) n_heavy = 0;
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += CS_THREADS) atomicAdd(&cnt[cix_home(key[s0 + i] & 0xFFFFu, NL)], 1u);
+#pragma unroll
+	for (int q = 0; q < CS_PER; ++q) { if ((uint32_t)q * CS_THREADS + tid < n) { kk[q] = cix_home(kk[q] & 0xFFFFu, NL); atomicAdd(&cnt[kk[q]], 1u); } }   // (kk = home line from here on)
 	__syncthreads();
 	uint32_t T = 8 * CIX_WAYS;
 	const uint32_t room = (uint32_t)(((uint64_t)CIX_WAYS * NL * 15) / 16);
@@ -451,34 +547,41 @@ __global__ __launch_bounds__(CS_THREADS) void k_cx_assemble_sorted(const uint32_
 	for (uint32_t l = tid; l < NL; l += CS_THREADS) cnt[l] = 0;
 	__syncthreads();
 	// the counting sort of the slot words; a heavy home's entries go straight to their run
-	for (uint32_t i = tid; i < n; i += CS_THREADS) {
-		const uint32_t h = cix_home(key[s0 + i] & 0xFFFFu, NL);
+#pragma unroll
+	for (int u = 0; u < CS_PER; ++u) if ((uint32_t)u * CS_THREADS + tid < n) {
+		const uint32_t h = kk[u];
 		const uint32_t k = atomicAdd(&cnt[h], 1u);
 		uint32_t hq = CS_HEAVY;
 		for (uint32_t q = 0; q < n_heavy; ++q) if (hv_line[q] == h) hq = q;
-		if (hq == CS_HEAVY) sorted[first[h] + k] = slot[s0 + i];
-		else if (hv_base[hq] != 0xFFFFFFFEu) X0[((size_t)hv_base[hq] + k / CIX_WAYS) * 8 + 1 + k % CIX_WAYS] = slot[s0 + i];
+		if (hq == CS_HEAVY) sorted[first[h] + k] = ss[u];
+		else if (hv_base[hq] != 0xFFFFFFFEu) X0[((size_t)hv_base[hq] + k / CIX_WAYS) * 8 + 1 + k % CIX_WAYS] = ss[u];
 	}
 	__syncthreads();
-	// one thread per line: its 64 bytes in one piece
+	// four lanes per line, sixteen bytes each: a wave's store is one run of 1 KB (round 3 let one thread write its line's four
+	// quarters one after the other -- 64 lanes, 64 lines, four partial-line stores each)
 	const uint32_t nlight = first[NL];
-	for (uint32_t l = tid; l < NL; l += CS_THREADS) {
+	const uint32_t j2 = (uint32_t)(tid & 3) * 2;                                   // this lane's two words of the line: j2, j2 + 1
+	for (uint32_t l = (uint32_t)tid >> 2; l < NL; l += CS_THREADS / 4) {
 		const uint32_t cl = (uint32_t)first[l + 1] - first[l];
 		const uint32_t have = (uint32_t)carry[l] + cl, occ = std::min(have, CIX_WAYS);
-		unsigned long long w[8];
-		w[0] = (unsigned long long)occ | (have > CIX_WAYS ? CIX_MORE : 0ull);
-		for (uint32_t q = 0; q < n_heavy; ++q) if (hv_line[q] == l && hv_base[q] != 0xFFFFFFFEu)
-			w[0] |= CIX_HEAVY | ((unsigned long long)((hv_cnt[q] + CIX_WAYS - 1) / CIX_WAYS) << 10) | ((unsigned long long)hv_base[q] << 32);
 		int32_t f = (int32_t)first[l] - (int32_t)carry[l];
 		if (f < 0) f += (int32_t)nlight;                                          // entries carried round the end of the partition
+		unsigned long long w[2];
 #pragma unroll
-		for (uint32_t j = 0; j < CIX_WAYS; ++j) {
-			uint32_t at = (uint32_t)f + j;
-			if (at >= nlight) at -= nlight;
-			w[1 + j] = j < occ ? sorted[at] : 0ull;
+		for (uint32_t e = 0; e < 2; ++e) {
+			const uint32_t word = j2 + e;
+			if (word == 0) {
+				w[e] = (unsigned long long)occ | (have > CIX_WAYS ? CIX_MORE : 0ull);
+				for (uint32_t q = 0; q < n_heavy; ++q) if (hv_line[q] == l && hv_base[q] != 0xFFFFFFFEu)
+					w[e] |= CIX_HEAVY | ((unsigned long long)((hv_cnt[q] + CIX_WAYS - 1) / CIX_WAYS) << 10) | ((unsigned long long)hv_base[q] << 32);
+			} else {
+				const uint32_t j = word - 1;
+				uint32_t at = (uint32_t)f + j;
+				if (at >= nlight) at -= nlight;
+				w[e] = j < occ ? sorted[at] : 0ull;
+			}
 		}
-		ulonglong2 *dst = (ulonglong2*)(L0 + (size_t)l * 8);
-		dst[0] = make_ulonglong2(w[0], w[1]); dst[1] = make_ulonglong2(w[2], w[3]); dst[2] = make_ulonglong2(w[4], w[5]); dst[3] = make_ulonglong2(w[6], w[7]);
+		*(ulonglong2*)(L0 + (size_t)l * 8 + j2) = make_ulonglong2(w[0], w[1]);
 	}
 }
 
@@ -516,7 +619,7 @@ static inline size_t cx_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // Step 1 of the build: the entries of contigs [c0, c1) -- { partition << 16 | home bits } in d_key, slot words in d_slot, room for
 // `cap` each -- grouped by the share that owns their key (h_counts[q] entries for share q, in share order); with one share they
-// are grouped by the low byte of their partition instead, which is the first radix pass of mcom_cindex_place.
+// are grouped by the HIGH byte of their partition instead, which is the first radix pass of mcom_cindex_place.
 extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                                    uint32_t c0, uint32_t c1, int L, int ininumdict, uint64_t geom, uint32_t *d_key, uint64_t *d_slot, uint64_t cap,
                                    uint64_t *h_counts)
@@ -553,13 +656,13 @@ extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const
 	MCOM_LAUNCH(k_cindex_blocks, dim3((c1 - c0 + 255) / 256), dim3(256), 0, ctx->stream, g.maxoff, d_woff, c0, c1, pos0, blocks256, first_contig);
 	MCOM_LAUNCH_CHECK(ctx);
 	const CxSrc src{d_cbits, d_coff, d_woff, first_contig, c1, pos0, n_pos, head};
-	MCOM_LAUNCH(k_cx_hist1, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
+	MCOM_LAUNCH(k_cx_hist1, dim3(cx_grid(nblocks)), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hist + (size_t)256 * nblocks, 0, 4, ctx->stream));
 	int rc;
 	if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nblocks + 1, scr))) return rc;        // the extra element becomes the number of entries
-	if (g.n_owners > 1) MCOM_LAUNCH(k_cx_scatter1<true>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
-	else MCOM_LAUNCH(k_cx_scatter1<false>, dim3(nblocks), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	if (g.n_owners > 1) MCOM_LAUNCH(k_cx_scatter1<true>, dim3(cx_grid(nblocks)), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
+	else MCOM_LAUNCH(k_cx_scatter1<false>, dim3(cx_grid(nblocks)), dim3(CX_THREADS), 0, ctx->stream, g, src, hist, nblocks, d_key, d_slot);
 	MCOM_LAUNCH_CHECK(ctx);
 	// the first entry of every share = the scanned count of (digit q, block 0)
 	std::vector<uint32_t> st(g.n_owners + 1, 0);
@@ -574,7 +677,7 @@ extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const
 }
 
 // Step 2: this share's table from its n_ent entries (what mcom_cindex_entries made, or what the other ranks sent: any order),
-// sorted by partition in two radix passes (one when they arrive grouped by the partition's low byte: grouped != 0), then one
+// sorted by partition in two passes (one when they arrive grouped by the partition's HIGH byte: grouped != 0), then one
 // workgroup per partition.  d_key / d_slot are overwritten; d_key_tmp / d_slot_tmp: scratch of n_ent entries each.
 extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent64, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
                                  int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words)
@@ -591,28 +694,39 @@ extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slo
 	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
 	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
-	const uint32_t nb2 = std::max<uint32_t>(1, (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE));
-	const size_t hist_b = cx_al((size_t)256 * nb2 * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nb2 + 2) * 4 + 1024), tab_b = cx_al(((size_t)g.n_parts + 2) * 4);
+	const uint32_t nbA = std::max<uint32_t>(1, (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE));   // tiles of the flat pass
+	const uint32_t nbR = nbA + 256;                                                                       // at most: every region ends in a short tile
+	const size_t hist_b = cx_al((size_t)256 * nbR * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nbR + 2) * 4 + 1024), tab_b = cx_al(((size_t)g.n_parts + 2) * 4);
 	char *tmp = nullptr;
-	if (mcom_dmalloc(&tmp, hist_b + scr_b + 2 * tab_b + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
+	if (mcom_dmalloc(&tmp, hist_b + scr_b + 2 * tab_b + cx_al(sizeof(CxTiles)) + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
 	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
 	uint32_t *hist = (uint32_t*)tmp, *scr = (uint32_t*)(tmp + hist_b), *pstart = (uint32_t*)(tmp + hist_b + scr_b);
 	uint8_t *redo = (uint8_t*)(tmp + hist_b + scr_b + tab_b);
+	CxTiles *tiles = (CxTiles*)(tmp + hist_b + scr_b + 2 * tab_b);
 	const uint32_t *skey = d_key; const uint64_t *sslot = d_slot;                         // the arrays that end up sorted by partition
 	int rc;
+	uint32_t *ik = d_key, *ok = d_key_tmp; uint64_t *is = d_slot, *os = d_slot_tmp;
+	if (n_ent && !grouped) {                                                              // any order -> by the partition's high byte
+		MCOM_LAUNCH(k_cx_hist2<false>, dim3(cx_grid(nbA)), dim3(CX_THREADS), 0, ctx->stream, ik, n_ent, (const CxTiles*)nullptr, hist, nbA);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nbA, scr))) return rc;
+		MCOM_LAUNCH(k_cx_scatter2<false>, dim3(cx_grid(nbA)), dim3(CX_THREADS), 0, ctx->stream, ik, is, n_ent, (const CxTiles*)nullptr, hist, nbA, ok, os);
+		MCOM_LAUNCH_CHECK(ctx);
+		std::swap(ik, ok); std::swap(is, os);
+	}
+	// inside every region by the partition's low byte
+	MCOM_LAUNCH(k_cx_regions, dim3(1), dim3(257), 0, ctx->stream, ik, n_ent, tiles);
+	MCOM_LAUNCH_CHECK(ctx);
 	if (n_ent) {
-		uint32_t *ik = d_key, *ok = d_key_tmp; uint64_t *is = d_slot, *os = d_slot_tmp;
-		for (int shift = grouped ? 24 : 16; shift <= 24; shift += 8) {
-			MCOM_LAUNCH(k_cx_hist2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, (size_t)n_ent, hist, nb2, shift);
-			MCOM_LAUNCH_CHECK(ctx);
-			if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nb2, scr))) return rc;
-			MCOM_LAUNCH(k_cx_scatter2, dim3(nb2), dim3(CX_THREADS), 0, ctx->stream, ik, is, (size_t)n_ent, hist, nb2, ok, os, shift);
-			MCOM_LAUNCH_CHECK(ctx);
-			std::swap(ik, ok); std::swap(is, os);
-		}
+		MCOM_LAUNCH(k_cx_hist2<true>, dim3(cx_grid(nbR)), dim3(CX_THREADS), 0, ctx->stream, ik, n_ent, (const CxTiles*)tiles, hist, nbR);
+		MCOM_LAUNCH_CHECK(ctx);
+		if ((rc = mcom_scan_u32(ctx, hist, hist, (size_t)256 * nbR, scr))) return rc;
+		MCOM_LAUNCH(k_cx_scatter2<true>, dim3(cx_grid(nbR)), dim3(CX_THREADS), 0, ctx->stream, ik, is, n_ent, (const CxTiles*)tiles, hist, nbR, ok, os);
+		MCOM_LAUNCH_CHECK(ctx);
+		std::swap(ik, ok); std::swap(is, os);
 		skey = ik; sslot = is;
 	}
-	MCOM_LAUNCH(k_cx_bounds, dim3((unsigned)(((size_t)n_ent + 1 + 255) / 256)), dim3(256), 0, ctx->stream, skey, (size_t)n_ent, g.n_parts, pstart);
+	MCOM_LAUNCH(k_cx_pstart, dim3((g.n_parts + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const CxTiles*)tiles, hist, n_ent, g.n_parts, pstart);
 	MCOM_LAUNCH_CHECK(ctx);
 	const size_t lds = (size_t)3 * g.n_lines * 4;
 	if (lds > 150 * 1024) return mcom_fail(ctx, MCOM_E_ARG, "contig index: partitions of %u lines", g.n_lines);
