@@ -202,6 +202,14 @@ int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_cof
 int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
                               const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
                               mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
+/* The same for a merge round after the first (kthread_cb.c:570-627): contigs [0, n_new) are the ones the round before made (they
+ * head the new list, cp_cluster order :397-434), the others came through it unmerged.  A pair of two of those others was a candidate
+ * in the round before, with the same strings at the same positions, and did not pass then (a passing pair of two contigs that both
+ * stay unclaimed does not exist: the first of the two to be visited takes the other, :286-343) -- so it is not evaluated again.
+ * Same output as mcom_find_next_candidates; n_new = 0 evaluates every pair.                                                    */
+int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
+                                  const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
+                                  mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
 
 /* ---- contig consensus on the device ------------------------------------- */
 /* construct_ref (kthread_bucket.c:69-377) for all n_groups groups of mcom_sort_group's output at once.

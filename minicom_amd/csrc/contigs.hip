@@ -825,53 +825,63 @@ __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap
 	if (q[i].x != U64MAX) mcom_table_find_any(slots, log2cap, region, bbits, q[i].x, s, c);
 	hits[i] = c; first[i] = s;                     // the later passes read these instead of probing the table again
 }
-// one thread per query: walks its hits, tests, writes a pass flag per (query, hit) pair at pair_off[q] + k
-__global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
-                          const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
-                          const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
-                          int cbthr, uint32_t *__restrict__ pass)
+// Round 4: the evaluation runs one thread per (query, hit) PAIR.  Three queries in four have no hit, and the others between one
+// and thousands: with a thread per query (rounds 1-3) a wave ran as long as its busiest lane while most lanes had nothing to do, and
+// every lane walked its hits one dependent gather after the other.  k_fn_expand names the query of every pair (the only loop over a
+// query's hits left: plain stores), then every lane of k_fn_eval has one pair to test and k_fn_emit one to write.
+__global__ void k_fn_expand(const uint32_t *__restrict__ pair_off, size_t nq, uint32_t *__restrict__ pair_q)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
-	const uint32_t p0 = pair_off[i], c = pair_off[i + 1] - p0;
-	if (!c) return;
-	const uint32_t s = first[i];
-	const mcom_mm128 m = q[i];
-	const uint32_t rid_ori = (uint32_t)(m.y >> 32), pos_ori = (uint32_t)m.y >> 1, dir_ori = (uint32_t)(m.y & 1);
-	const uint32_t ci = rid_ori;                          // the id IS the contig index here (include/mcom.h, "contig ids")
-	for (uint32_t u = 0; u < c; ++u) {
-		const uint64_t y = irec[s + u].y;
-		const uint32_t rid = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1, dir = (uint32_t)(y & 1);
-		uint32_t ok = 0;
-		if (rid != rid_ori && dir == dir_ori) {
-			const uint32_t cj = rid;
-			const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
-			ok = mis <= (uint32_t)cbthr;
-		}
-		pass[p0 + u] = ok;
+	const uint32_t p0 = pair_off[i], p1 = pair_off[i + 1];
+	for (uint32_t p = p0; p < p1; ++p) pair_q[p] = (uint32_t)i;
+}
+// n_new: contigs [0, n_new) are new in this merge round (the merged ones head the list, cp_cluster order); 0 = all of them.  A pair of
+// two contigs that both came through the round before unmerged cannot pass: it was a candidate then, with the same strings and the
+// same positions, and a passing pair of two contigs that both stay unclaimed does not exist (the first of the two to be visited would
+// have taken the other, kthread_cb.c:286-343) -- so it failed match_pro then and fails it now.
+__global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
+                          const mcom_mm128 *__restrict__ q, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q, uint32_t n_pairs,
+                          const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
+                          int cbthr, uint32_t n_new, uint32_t *__restrict__ pass)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pairs) return;
+	const uint32_t i = pair_q[p];
+	const uint32_t u = p - pair_off[i], s = first[i];
+	const uint64_t my = q[i].y, y = irec[s + u].y;
+	const uint32_t ci = (uint32_t)(my >> 32), pos_ori = (uint32_t)my >> 1;   // the id IS the contig index here (include/mcom.h, "contig ids")
+	const uint32_t cj = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1;
+	uint32_t ok = 0;
+	if (cj != ci && ((my ^ y) & 1) == 0 && (n_new == 0 || ci < n_new || cj < n_new)) {
+		const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
+		ok = mis <= (uint32_t)cbthr;
 	}
+	pass[p] = ok;
 }
 __global__ void k_fn_emit(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
-                          const mcom_mm128 *__restrict__ q, size_t nq, const uint32_t *__restrict__ pair_off,
+                          const mcom_mm128 *__restrict__ q, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q,
                           const uint32_t *__restrict__ pass_pre, uint32_t n_pairs, uint32_t last_flag,
                           mcom_mm128 *__restrict__ out)
 {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nq) return;
-	const uint32_t p0 = pair_off[i], c = pair_off[i + 1] - p0;
-	if (!c) return;
-	const uint32_t s = first[i];
-	const uint64_t my = q[i].y;
-	for (uint32_t u = 0; u < c; ++u) {
-		const uint32_t p = p0 + u;
-		const uint32_t here = pass_pre[p], nxt = (p + 1 < n_pairs) ? pass_pre[p + 1] : pass_pre[p] + last_flag;
-		if (nxt != here) { mcom_mm128 v; v.x = my; v.y = irec[s + u].y; out[here] = v; }   // x = query y (contig i, pos_ori, dir), y = hit y
-	}
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pairs) return;
+	const uint32_t here = pass_pre[p], nxt = (p + 1 < n_pairs) ? pass_pre[p + 1] : pass_pre[p] + last_flag;
+	if (nxt == here) return;
+	const uint32_t i = pair_q[p];
+	mcom_mm128 v; v.x = q[i].y; v.y = irec[first[i] + (p - pair_off[i])].y;        // x = query y (contig i, pos_ori, dir), y = hit y
+	out[here] = v;
 }
 
 extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
                                          const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
                                          mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
+{
+	return mcom_find_next_candidates_new(ctx, mi, d_query, n_query, d_cbits, d_coff, d_clen, cbthr, 0, d_out, cap, h_counts);
+}
+extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
+                                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
+                                             mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
 {
 	if (!ctx || !mi) return MCOM_E_ARG;
 	if (h_counts) { h_counts[0] = h_counts[1] = 0; }
@@ -900,19 +910,21 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (h_counts) h_counts[0] = n_pairs;
 	if (n_pairs == 0) return MCOM_OK;
 	// pass 2: evaluate pairs; the workspace may move, so the offsets are kept in a fresh allocation
-	uint32_t *pair_off = nullptr, *pass = nullptr;
+	uint32_t *pair_off = nullptr, *pass = nullptr, *pair_q = nullptr;
 	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
 	hipError_t e = mcom_dmalloc(&pair_off, nq1 * 4);
 	if (e == hipSuccess) e = mcom_dmalloc(&pass, (size_t)n_pairs * 4);
-	if (e != hipSuccess) { if (pair_off) mcom_dfree(pair_off); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
-	auto cleanup = [&]() { mcom_dfree(pair_off); mcom_dfree(pass); };
+	if (e == hipSuccess) e = mcom_dmalloc(&pair_q, (size_t)n_pairs * 4);
+	auto cleanup = [&]() { if (pair_off) mcom_dfree(pair_off); if (pass) mcom_dfree(pass); if (pair_q) mcom_dfree(pair_q); };
+	if (e != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
 	hipError_t e1 = hipMemcpyAsync(pair_off, hits, nq1 * 4, hipMemcpyDeviceToDevice, ctx->stream);
-	if (e1 == hipSuccess) e1 = hipMemsetAsync(pass, 0, (size_t)n_pairs * 4, ctx->stream);
 	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate buffers: %s", hipGetErrorString(e1)); }
 	rc = mcom_ws_reserve(ctx, scr2_b);
 	if (rc) { cleanup(); return rc; }
+	const unsigned pb = (unsigned)(((size_t)n_pairs + 255) / 256);
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
-	MCOM_LAUNCH(k_fn_eval, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, d_cbits, d_coff, d_clen, cbthr, pass); }
+	MCOM_LAUNCH(k_fn_expand, dim3(qb), dim3(256), 0, ctx->stream, pair_off, n_query, pair_q);
+	MCOM_LAUNCH(k_fn_eval, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, n_pairs, d_cbits, d_coff, d_clen, cbthr, n_new, pass); }
 	uint32_t last_flag = 0, n_pass = 0;
 	e1 = mcom_d2h_async(ctx, &last_flag, pass + (n_pairs - 1), 4);
 	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
@@ -927,7 +939,7 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
-		MCOM_LAUNCH(k_fn_emit, dim3(qb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, n_query, pair_off, pass, n_pairs, last_flag, d_out);
+		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, pass, n_pairs, last_flag, d_out);
 		e1 = mcom_stream_sync(ctx);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}

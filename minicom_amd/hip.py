@@ -81,6 +81,8 @@ def load_library():
     L.mcom_match_pro.restype = i32; L.mcom_match_pro.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.mcom_find_next_candidates.restype = i32
     L.mcom_find_next_candidates.argtypes = [vp, vp, vp, sz, vp, vp, vp, i32, vp, sz, vp]
+    L.mcom_find_next_candidates_new.restype = i32
+    L.mcom_find_next_candidates_new.argtypes = [vp, vp, vp, sz, vp, vp, vp, i32, u32, vp, sz, vp]
     L.mcom_dict_layout.restype = i32; L.mcom_dict_layout.argtypes = [i32, i32, vp, vp]
     L.mcom_gather_rows.restype = i32; L.mcom_gather_rows.argtypes = [vp, vp, vp, sz, i32, vp]
     L.mcom_poly_filter.restype = i32; L.mcom_poly_filter.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp]

@@ -1042,6 +1042,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 	}
 	bool packed_ready = false;                                                 // d_cbits & co. describe A (made at the end of the round before)
 	p->cbits_for_dC = false;
+	uint32_t n_new = 0;                                                        // contigs [0, n_new) of A were made by the round before (0: the first round)
 	for (;;) {
 		const size_t n = A.n;
 		uint64_t n_pass = 0;
@@ -1069,7 +1070,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				size_t cap = std::max<size_t>(1024, A.nrec);
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-					rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs.p, d_pairs.cap, hc);
+					rc = mcom_find_next_candidates_new(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, n_new, d_pairs.p, d_pairs.cap, hc);
 					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 					break;
 				}
@@ -1083,7 +1084,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				size_t cap = std::max<size_t>(1024, (size_t)(qr[1] - qr[0]));
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs_loc.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-					rc = mcom_find_next_candidates(p->ctx, mi, A.rec.p + qr[0], qr[1] - qr[0], p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, d_pairs_loc.p, d_pairs_loc.cap, hc);
+					rc = mcom_find_next_candidates_new(p->ctx, mi, A.rec.p + qr[0], qr[1] - qr[0], p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, n_new, d_pairs_loc.p, d_pairs_loc.cap, hc);
 					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 					break;
 				}
@@ -1253,6 +1254,7 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				lap("t_cb_pack");
 			}
 			A.swap(B);
+			n_new = (uint32_t)nj;
 			p->stat["t_gpu"] += busy_now(p) - tg;
 		} else packed_ready = packed_ready && n != 0;
 		p->stat["merge_rounds"] += 1;
