@@ -34,7 +34,12 @@ hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t byte
 }
 hipError_t mcom_stream_sync(mcom_ctx *ctx)
 {
-	const hipError_t e = hipStreamSynchronize(ctx->stream);
+	hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (e == hipSuccess && ctx->poison && *ctx->poison) {                        // a kernel's bounded wait ran out (scan.hip): its results are wrong
+		*ctx->poison = 0;
+		ctx->err = "a device-side wait ran out (one-launch scan): results of this stream are invalid";
+		e = hipErrorLaunchFailure;
+	}
 	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, ctx->pin + w.off, w.bytes);
 	ctx->pin_wait.clear(); ctx->pin_off = 0;
 	return e;
@@ -160,6 +165,8 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 		if (drop) (void)hipFree(drop);
 	}
 	if (ctx->pin) (void)hipHostFree(ctx->pin);
+	if (ctx->scan_parts) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scan_parts); }
+	if (ctx->poison) (void)hipHostFree((void*)ctx->poison);
 	delete ctx;
 }
 

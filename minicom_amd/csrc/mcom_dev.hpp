@@ -43,6 +43,9 @@ struct mcom_ctx {
 	// ... 2 = the lane-per-string kernel with the ring of 64-bit hashes even where the ring of 32-bit prefixes applies (k odd); and the
 	// prefix width of the latter (tests narrow it to a few bits so that prefix ties, one in 2^30 otherwise, happen all the time)
 	bool sketch_ring64 = false, sketch_ring32_only = false; int sketch_prefix_bits = 14;   // (measured: 14 bits in 16-bit words 8.0 ms, 30 bits in 32-bit words 9.3, 12 bits 9.4, 64-bit ring 11.8)
+	// one-launch scans (scan.hip): published chunk sums, the launch counter that validates them, and the poison flag a kernel raises
+	// when a bounded wait ran out (pinned host word; mcom_stream_sync turns it into an error)
+	unsigned long long *scan_parts = nullptr; uint32_t scan_epoch = 0; volatile unsigned int *poison = nullptr; unsigned int *d_poison = nullptr;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
 	struct PinWait { void *dst; size_t off, bytes; };
@@ -91,6 +94,7 @@ template <class T> static inline hipError_t mcom_dmalloc(T **out, size_t bytes) 
 // internal helpers shared between translation units (sort.hip)
 int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch);
 size_t mcom_scan_scratch_elems(size_t n);
+int mcom_scan_prepare(mcom_ctx *ctx);                    // the scratch of the one-launch scans and the poison flag (scan.hip)
 size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);

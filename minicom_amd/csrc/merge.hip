@@ -11,63 +11,9 @@
 //   mcom_records_carry      their minimizers re-labelled for the next round instead of sketched again
 #include "mcom_dev.hpp"
 
-// ---- 64-bit exclusive scan -------------------------------------------------------------------------------------
-#define S64_THREADS 256
-#define S64_PER 4
-#define S64_TILE (S64_THREADS * S64_PER)
-
-__global__ __launch_bounds__(S64_THREADS) void k_scan64_tile(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, size_t n,
-                                                            uint64_t *__restrict__ sums)
-{
-	__shared__ uint64_t wsum[S64_THREADS / 64];
-	const size_t base = (size_t)blockIdx.x * S64_TILE + (size_t)threadIdx.x * S64_PER;
-	uint64_t v[S64_PER], tot = 0;
-#pragma unroll
-	for (int q = 0; q < S64_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0ull; tot += v[q]; }
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	uint64_t inc = tot;
-#pragma unroll
-	for (int s = 1; s < 64; s <<= 1) { const uint64_t t = __shfl_up(inc, s, 64); if (lane >= s) inc += t; }
-	if (lane == 63) wsum[wv] = inc;
-	__syncthreads();
-	uint64_t add = 0, all = 0;
-	for (int q = 0; q < S64_THREADS / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
-	uint64_t run = inc + add - tot;
-#pragma unroll
-	for (int q = 0; q < S64_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
-	if (sums && threadIdx.x == 0) sums[blockIdx.x] = all;
-}
-__global__ __launch_bounds__(S64_THREADS) void k_scan64_add(uint64_t *__restrict__ out, size_t n, const uint64_t *__restrict__ sums)
-{
-	const size_t i = (size_t)blockIdx.x * S64_TILE + threadIdx.x;
-	const uint64_t a = sums[blockIdx.x];
-#pragma unroll
-	for (int q = 0; q < S64_PER; ++q) { const size_t j = i + (size_t)q * S64_THREADS; if (j < n) out[j] += a; }
-}
-static size_t scan64_scratch_elems(size_t n)
-{
-	size_t tot = 0;
-	while (n > S64_TILE) { n = (n + S64_TILE - 1) / S64_TILE; tot += n; }
-	return tot + 1;
-}
-static int scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch)
-{
-	if (n == 0) return MCOM_OK;
-	const size_t nb = (n + S64_TILE - 1) / S64_TILE;
-	MCOM_LAUNCH(k_scan64_tile, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
-	MCOM_LAUNCH_CHECK(ctx);
-	if (nb > 1) {
-		int rc = scan64(ctx, scratch, scratch, nb, scratch + nb);
-		if (rc) return rc;
-		MCOM_LAUNCH(k_scan64_add, dim3((unsigned)nb), dim3(S64_THREADS), 0, ctx->stream, out, n, scratch);
-		MCOM_LAUNCH_CHECK(ctx);
-	}
-	return MCOM_OK;
-}
-
-// exported to the other translation units of the library
-size_t mcom_scan64_scratch_elems(size_t n) { return scan64_scratch_elems(n); }
-int mcom_scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch) { return scan64(ctx, in, out, n, scratch); }
+// (the exclusive scans live in scan.hip: one launch each)
+static inline int scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint64_t *scratch) { return mcom_scan64(ctx, in, out, n, scratch); }
+static inline size_t scan64_scratch_elems(size_t n) { return mcom_scan64_scratch_elems(n); }
 
 // bump allocator over the context workspace
 struct WsCut {

@@ -289,80 +289,9 @@ __global__ void k_seg_move(mcom_mm128 *__restrict__ arr, mcom_mm128 *__restrict_
 	for (uint32_t i = threadIdx.x; i < sg.y - sg.x; i += blockDim.x) { if (back) arr[sg.x + i] = compact[d0 + i]; else compact[d0 + i] = arr[sg.x + i]; }
 }
 
-// ---- generic exclusive scan of uint32 (2048 elements per block, recursive on the block sums) -------
-#define SC_THREADS 256
-#define SC_PER 8                             // (k_scan_tile's vector path assumes eight)
-#define SC_TILE (SC_THREADS * SC_PER)
-__global__ __launch_bounds__(SC_THREADS) void k_scan_tile(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
-                                                          uint32_t *__restrict__ sums)
-{
-	__shared__ uint32_t wsum[SC_THREADS / 64];
-	const size_t base = (size_t)blockIdx.x * SC_TILE + (size_t)threadIdx.x * SC_PER;
-	uint32_t v[SC_PER], tot = 0;
-	const bool vec = base + SC_PER <= n && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;   // eight elements as two 16-byte accesses
-	if (vec) {
-		const uint4 a = *(const uint4*)(in + base), b = *(const uint4*)(in + base + 4);
-		v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-#pragma unroll
-		for (int q = 0; q < SC_PER; ++q) tot += v[q];
-	} else {
-#pragma unroll
-		for (int q = 0; q < SC_PER; ++q) { v[q] = (base + q < n) ? in[base + q] : 0u; tot += v[q]; }
-	}
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	uint32_t inc = tot;
-#pragma unroll
-	for (int s = 1; s < 64; s <<= 1) { uint32_t t = __shfl_up(inc, s, 64); if (lane >= s) inc += t; }
-	if (lane == 63) wsum[wv] = inc;
-	__syncthreads();
-	uint32_t add = 0, all = 0;
-	for (int q = 0; q < SC_THREADS / 64; ++q) { if (q < wv) add += wsum[q]; all += wsum[q]; }
-	uint32_t run = inc + add - tot;
-	if (vec) {
-		uint32_t o[SC_PER];
-#pragma unroll
-		for (int q = 0; q < SC_PER; ++q) { o[q] = run; run += v[q]; }
-		*(uint4*)(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
-		*(uint4*)(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
-	} else {
-#pragma unroll
-		for (int q = 0; q < SC_PER; ++q) { if (base + q < n) out[base + q] = run; run += v[q]; }
-	}
-	if (sums && threadIdx.x == 0) sums[blockIdx.x] = all;
-}
-__global__ void k_scan_add(uint32_t *__restrict__ out, size_t n, const uint32_t *__restrict__ sums)
-{
-	const size_t i = (size_t)blockIdx.x * SC_TILE + threadIdx.x;
-	const uint32_t a = sums[blockIdx.x];
-#pragma unroll
-	for (int q = 0; q < SC_PER; ++q) { const size_t j = i + (size_t)q * SC_THREADS; if (j < n) out[j] += a; }
-}
-
-// scratch: needs room for the block sums of every level; returns bytes needed for n elements
-static size_t scan_scratch_elems(size_t n)
-{
-	size_t tot = 0;
-	while (n > SC_TILE) { n = (n + SC_TILE - 1) / SC_TILE; tot += n; }
-	return tot + 1;
-}
-static int scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch)
-{
-	if (n == 0) return MCOM_OK;
-	const size_t nb = (n + SC_TILE - 1) / SC_TILE;
-	MCOM_LAUNCH(k_scan_tile, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, in, out, n, nb > 1 ? scratch : nullptr);
-	MCOM_LAUNCH_CHECK(ctx);
-	if (nb > 1) {
-		int rc = scan_u32(ctx, scratch, scratch, nb, scratch + nb);
-		if (rc) return rc;
-		MCOM_LAUNCH(k_scan_add, dim3((unsigned)nb), dim3(SC_THREADS), 0, ctx->stream, out, n, scratch);
-		MCOM_LAUNCH_CHECK(ctx);
-	}
-	return MCOM_OK;
-}
-
-// exported to the other translation units of the library
-int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch) { return scan_u32(ctx, in, out, n, scratch); }
-size_t mcom_scan_scratch_elems(size_t n) { return scan_scratch_elems(n); }
+// (the exclusive scans live in scan.hip: one launch each)
+static inline int scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch) { return mcom_scan_u32(ctx, in, out, n, scratch); }
+static inline size_t scan_scratch_elems(size_t n) { return mcom_scan_scratch_elems(n); }
 
 // ---- the sort driver -------------------------------------------------------------------------------
 // a and tmp are ping-pong buffers of n records; on return *sorted points at the one holding the result
