@@ -21,6 +21,8 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 #define MCOM_PIN_BYTES 4096
 hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
+	for (const mcom_ctx::ScanTotal &t : ctx->scan_last)                            // the total of a scan that is on its way: already in pinned memory
+		if (t.last && t.last == src && t.bytes == bytes && t.gen == ctx->launch_gen) { mcom_ctx::PinWait w{dst, 0, bytes}; w.from = ctx->scan_tot + t.slot; ctx->pin_wait.push_back(w); return hipSuccess; }
 	if (bytes <= 256) {
 		if (!ctx->pin && hipHostMalloc((void**)&ctx->pin, MCOM_PIN_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; (void)hipGetLastError(); }
 		const size_t need = (bytes + 7) & ~(size_t)7;
@@ -35,12 +37,13 @@ hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t byte
 hipError_t mcom_stream_sync(mcom_ctx *ctx)
 {
 	hipError_t e = hipStreamSynchronize(ctx->stream);
+	++ctx->launch_gen;                                                             // (what a scan left in pinned memory is consumed below)
 	if (e == hipSuccess && ctx->poison && *ctx->poison) {                        // a kernel's bounded wait ran out (scan.hip): its results are wrong
 		*ctx->poison = 0;
 		ctx->err = "a device-side wait ran out (one-launch scan): results of this stream are invalid";
 		e = hipErrorLaunchFailure;
 	}
-	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, ctx->pin + w.off, w.bytes);
+	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, w.from ? w.from : (const void*)(ctx->pin + w.off), w.bytes);
 	ctx->pin_wait.clear(); ctx->pin_off = 0;
 	return e;
 }

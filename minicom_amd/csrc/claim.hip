@@ -21,27 +21,37 @@ __global__ void k_claim_jobs(const mcom_mm128 *__restrict__ pairs, size_t n, con
 
 // ---- round 4: all rounds in ONE launch ------------------------------------------------------------------------------------------
 // The loop above cost two launches, two clears and a host round trip per round (25 rounds in the benchmark's first merge round, a
-// handful in the others: ~150 launches and ~40 round trips per step).  k_claim_all runs the same rounds inside one cooperative launch:
-// 4 workgroups per CU (a CU holds 8 of these: every one is resident, which a grid barrier needs), every workgroup owning a fixed
-// stripe of the edge list, two grid barriers per round.  A bid is { round << 32 | ~edge } under atomicMax, so the bids of a later
+// handful in the others: ~150 launches and ~40 round trips per step).  k_claim_all runs the same rounds inside one launch:
+// one workgroup of 1024 threads per CU (every one is resident, which a grid barrier needs), every workgroup owning a fixed
+// stripe of the edge list, one grid barrier per round.  A bid is { round << 32 | ~edge } under atomicMax, so the bids of a later
 // round override those of an earlier one and `best` needs no clear between rounds.  The barrier is the guide's recipe (each wave's
 // stores drained by __syncthreads, one lane's agent-scope release, a counter, that lane's agent-scope acquire, __syncthreads) and its
 // wait is bounded: a workgroup that gives up raises the context's poison flag and leaves -- the others leave at their next barrier
 // for the same reason -- and the host falls back to the launch-per-round loop.
-#define CL_THREADS 256
-__device__ __forceinline__ bool cl_barrier(unsigned int *bar, unsigned int G, unsigned int &gen, unsigned int *poison)
+#define CL_THREADS 1024
+#define CL_REL_LINES 16                     // copies of the release word, one cache line each: 16 pollers per line instead of 256 on one
+#define CL_STATE_WORDS (64 + CL_REL_LINES * 32)
+// One workgroup of 1024 threads per CU: a barrier of 256 arrivals (the first form had 1024 workgroups of 256 threads polling ONE word
+// with agent-scope loads while the late arrivals' atomics queued behind the polls on that word's L2 channel: ~50 us per barrier,
+// 13 ms per step against 6.2 ms for the launch-per-round loop).  The last to arrive releases everybody through CL_REL_LINES words.
+__device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, unsigned int &gen, unsigned int *poison)
 {
 	__shared__ int ok_s;
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		__threadfence();
 		++gen;
-		atomicAdd(bar, 1u);
-		const unsigned int want = gen * G;
-		unsigned int polls = 0; int ok = 1;
-		while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-			if (++polls > (1u << 24) || ((polls & 4095u) == 0 && *(volatile unsigned int*)poison)) { *poison = 1u; ok = 0; break; }   // (the flag lives in host memory: looked at rarely)
-			__builtin_amdgcn_s_sleep(2);
+		unsigned int *rel = state + 64;
+		int ok = 1;
+		if (atomicAdd(state, 1u) == gen * G - 1u) {
+			for (int j = 0; j < CL_REL_LINES; ++j) __hip_atomic_store(rel + 32 * j, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			unsigned int *mine = rel + 32 * (blockIdx.x % CL_REL_LINES);
+			unsigned int polls = 0;
+			while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+				if (++polls > (1u << 23) || ((polls & 4095u) == 0 && *(volatile unsigned int*)poison)) { *poison = 1u; ok = 0; break; }   // (the flag lives in host memory: looked at rarely)
+				__builtin_amdgcn_s_sleep(8);
+			}
 		}
 		__threadfence();
 		ok_s = ok;
@@ -49,38 +59,63 @@ __device__ __forceinline__ bool cl_barrier(unsigned int *bar, unsigned int G, un
 	__syncthreads();
 	return ok_s != 0;
 }
+// ONE barrier per round: a phase takes the winners of the round before and places the bids of its own round.  Bids of odd and even
+// rounds go to two arrays, so a take never meets a bid of the next round.  What the missing barrier between "take" and "bid" allows
+// is a stale bid: an edge bids although one of its ends was matched in this very phase.  It cannot be taken (a take looks at the
+// matched flags again, a barrier later) and it cannot change the result: an edge that IS taken was the smallest bidder at both ends
+// among bids that include every edge still truly alive there, and its ends were free -- the greedy matching's own rule.  A stale bid
+// can only make a live edge wait one more round (every edge is stale at most once).
 __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__restrict__ pairs, uint32_t n, uint8_t *matched, uint8_t *dead,
-                                                         unsigned long long *best, uint32_t *__restrict__ sel, unsigned int *state, int max_rounds, unsigned int *poison)
+                                                         unsigned long long *best, uint32_t n_contigs, uint32_t *__restrict__ sel, unsigned int *state, int max_rounds,
+                                                         unsigned int *poison)
 {
-	// state[0] = barrier counter, state[1 + (round & 1)] = "some edge is live in this round", state[3] = rounds done, state[4] = did not settle
+	// state[0] = barrier counter; on a line of their own: state[32 + round % 3] = "some edge bid in this round", state[36] = rounds with bids,
+	// state[37] = did not settle; state[64 ...] = the release words
 	const unsigned int G = gridDim.x;
-	const uint32_t stride = G * CL_THREADS;
+	const uint32_t stride = G * CL_THREADS, chunks = (n + 15u) >> 4;
 	unsigned int gen = 0;
 	for (int round = 1; ; ++round) {
-		const unsigned long long rkey = (unsigned long long)round << 32;
+		if (round > 1) {
+			const bool any = *(volatile unsigned int*)(state + 32 + (round - 1) % 3) != 0;
+			if (!any || round - 1 >= max_rounds) {
+				if (blockIdx.x == 0 && threadIdx.x == 0) { state[36] = (unsigned int)(any ? round - 1 : round - 2); state[37] = any ? 1u : 0u; }
+				return;
+			}
+		}
+		const unsigned long long rkey = (unsigned long long)round << 32, pkey = (unsigned long long)(round - 1) << 32;
+		unsigned long long *bestC = best + (size_t)(round & 1) * n_contigs;
+		const unsigned long long *bestP = best + (size_t)((round - 1) & 1) * n_contigs;
 		bool live = false;
-		for (uint32_t e = blockIdx.x * CL_THREADS + threadIdx.x; e < n; e += stride) {
-			if (dead[e]) continue;
-			const mcom_mm128 pr = pairs[e];
-			const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
-			if (matched[ci] || matched[cj]) { dead[e] = 1; continue; }
-			const unsigned long long key = rkey | (unsigned long long)(0xFFFFFFFFu - e);
-			atomicMax(&best[ci], key);
-			atomicMax(&best[cj], key);
-			live = true;
+		// sixteen edges per step: one 16-byte load of their dead flags (most edges are dead after the first rounds, and a loop of
+		// dependent one-byte loads -- 114 per thread and phase -- was what the first form of this kernel spent its time on)
+		for (uint32_t c = blockIdx.x * CL_THREADS + threadIdx.x; c < chunks; c += stride) {
+			const uint4 d16 = ((const uint4*)dead)[c];
+			const uint32_t dw[4] = {d16.x, d16.y, d16.z, d16.w};
+#pragma unroll
+			for (int w = 0; w < 4; ++w) {
+				if (dw[w] == 0x01010101u) continue;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					const uint32_t e = c * 16 + w * 4 + b;
+					if (((dw[w] >> (8 * b)) & 0xFFu) || e >= n) continue;
+					const mcom_mm128 pr = pairs[e];
+					const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
+					const unsigned long long inv = (unsigned long long)(0xFFFFFFFFu - e);
+					const bool mi = matched[ci] != 0, mj = matched[cj] != 0;
+					if (round > 1 && bestP[ci] == (pkey | inv) && bestP[cj] == (pkey | inv)) {   // the winner of the round before at both ends
+						if (!mi && !mj) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; }          // (a stale bid: an end was matched meanwhile)
+						dead[e] = 1;
+						continue;
+					}
+					if (mi || mj) { dead[e] = 1; continue; }
+					atomicMax(&bestC[ci], rkey | inv);
+					atomicMax(&bestC[cj], rkey | inv);
+					live = true;
+				}
+			}
 		}
-		if (__any(live) && (threadIdx.x & 63) == 0 && *(volatile unsigned int*)(state + 1 + (round & 1)) == 0) state[1 + (round & 1)] = 1;
-		if (!cl_barrier(state, G, gen, poison)) return;
-		const bool any = *(volatile unsigned int*)(state + 1 + (round & 1)) != 0;
-		if (!any || round > max_rounds) { if (blockIdx.x == 0 && threadIdx.x == 0) { state[3] = (unsigned int)(round - 1); state[4] = any ? 1u : 0u; } return; }
-		for (uint32_t e = blockIdx.x * CL_THREADS + threadIdx.x; e < n; e += stride) {
-			if (dead[e]) continue;
-			const mcom_mm128 pr = pairs[e];
-			const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
-			const unsigned long long key = rkey | (unsigned long long)(0xFFFFFFFFu - e);
-			if (best[ci] == key && best[cj] == key) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; dead[e] = 1; }
-		}
-		if (blockIdx.x == 0 && threadIdx.x == 0) state[1 + ((round + 1) & 1)] = 0;           // the next round's flag (nobody reads or writes it before the barrier below)
+		if (__any(live) && (threadIdx.x & 63) == 0 && *(volatile unsigned int*)(state + 32 + round % 3) == 0) state[32 + round % 3] = 1;
+		if (blockIdx.x == 0 && threadIdx.x == 0) state[32 + (round + 1) % 3] = 0;                // the next round's flag (nobody else touches it in this phase)
 		if (!cl_barrier(state, G, gen, poison)) return;
 	}
 }
@@ -97,32 +132,32 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	int rc = mcom_scan_prepare(ctx);                                               // (the poison flag)
 	if (rc) return rc;
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-	const size_t best_b = al(n_contigs * 8), dead_b = al(n_pairs), sel_b = al((n_pairs + 1) * 4);
-	rc = mcom_ws_reserve(ctx, best_b + dead_b + 2 * sel_b + 512);
+	const size_t best_b = al(2 * n_contigs * 8), dead_b = al(n_pairs + 16), sel_b = al((n_pairs + 1) * 4);
+	rc = mcom_ws_reserve(ctx, best_b + dead_b + 2 * sel_b + al(CL_STATE_WORDS * 4) + 256);
 	if (rc) return rc;
 	char *base = (char*)ctx->ws;
 	unsigned long long *best = (unsigned long long*)base;
 	uint8_t *dead = (uint8_t*)(base + best_b);
 	uint32_t *sel = (uint32_t*)(base + best_b + dead_b);
-	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b);
-	unsigned int *state = (unsigned int*)(base + best_b + dead_b + 2 * sel_b);
-	MCOM_HIP(ctx, hipMemsetAsync(base, 0, best_b + dead_b + sel_b, ctx->stream));   // best = 0: below every bid; dead, sel = 0
-	MCOM_HIP(ctx, hipMemsetAsync(state, 0, 64, ctx->stream));
+	unsigned int *state = (unsigned int*)(base + best_b + dead_b + sel_b);
+	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4));
+	MCOM_HIP(ctx, hipMemsetAsync(base, 0, best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4), ctx->stream));   // best = 0: below every bid; dead, sel, state = 0
 	const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
-	unsigned int hs[5] = {0, 0, 0, 0, 0};
+	unsigned int hs[2] = {0, 0};
 	{
-		unsigned grid = (unsigned)ctx->n_cu * 4;
-		if (grid > blocks) grid = blocks;
+		unsigned grid = (unsigned)ctx->n_cu;
+		const unsigned need = (unsigned)((n_pairs + 16 * CL_THREADS - 1) / (16 * CL_THREADS));
+		if (grid > need) grid = need;
 		uint32_t n32 = (uint32_t)n_pairs;
-		void *args[] = { (void*)&d_pairs, (void*)&n32, (void*)&d_flag, (void*)&dead, (void*)&best, (void*)&sel, (void*)&state, (void*)&max_rounds, (void*)&ctx->d_poison };
-		if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, (const void*)&k_claim_all)];
-		const hipError_t e = hipLaunchCooperativeKernel((const void*)k_claim_all, dim3(grid), dim3(CL_THREADS), args, 0, ctx->stream);
-		if (e != hipSuccess) { (void)hipGetLastError(); return mcom_fail(ctx, MCOM_E_HIP, "claiming: cooperative launch: %s", hipGetErrorString(e)); }
-		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state, 20));
+		// a plain launch: what a grid barrier needs is that every workgroup is resident, which the grid's size guarantees (one workgroup
+		// per CU) and a cooperative launch would only check (rocprofv3's kernel trace crashed on the cooperative one)
+		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, max_rounds, ctx->d_poison);
+		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state + 36, 8));
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
-	if (hs[4]) return mcom_fail(ctx, MCOM_E_OVERFLOW, "claiming did not settle in %d rounds", max_rounds);
-	if (h_rounds) *h_rounds = (int)hs[3];
+	if (hs[1]) return mcom_fail(ctx, MCOM_E_OVERFLOW, "claiming did not settle in %d rounds", max_rounds);
+	if (h_rounds) *h_rounds = (int)hs[0];
 	// the taken edges in list order = the reference's claiming order
 	if ((rc = mcom_scan_u32(ctx, sel, spre, n_pairs + 1, nullptr))) return rc;      // sel[n_pairs] = 0 from the memset
 	uint32_t nj = 0;

@@ -46,9 +46,16 @@ struct mcom_ctx {
 	// one-launch scans (scan.hip): published chunk sums, the launch counter that validates them, and the poison flag a kernel raises
 	// when a bounded wait ran out (pinned host word; mcom_stream_sync turns it into an error)
 	unsigned long long *scan_parts = nullptr; uint32_t scan_epoch = 0; volatile unsigned int *poison = nullptr; unsigned int *d_poison = nullptr;
+	// ... and the LAST element of every scan's output, which its kernel also stores into a ring of pinned host words: a caller that reads
+	// that element back (the total: nearly every scan is followed by exactly that) finds it there after the next synchronisation --
+	// mcom_d2h_async recognises the address and issues no copy (127 of a step's 308 device-to-host copies in round 3's profile)
+	enum { SCAN_TOTALS = 64 };
+	unsigned long long *scan_tot = nullptr, *d_scan_tot = nullptr;               // host / device view of the ring (after the poison word)
+	// (an entry stands only while no other kernel has been launched and the stream has not been synchronised since its scan: launch_gen)
+	struct ScanTotal { const void *last; uint32_t bytes, slot, gen; } scan_last[8] = {}; uint32_t scan_last_at = 0, launch_gen = 1;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
-	struct PinWait { void *dst; size_t off, bytes; };
+	struct PinWait { void *dst; size_t off, bytes; const void *from = nullptr; };   // from != nullptr: the value waits there (a scan's total), not in the page
 	unsigned char *pin = nullptr; size_t pin_off = 0;
 	std::vector<PinWait> pin_wait;
 };
@@ -75,6 +82,7 @@ struct McomProfScope {
 // the instantiation under the class whose scope is open.  mcom_prof_kernels turns the addresses into names with the runtime's own
 // table (hipKernelNameRefByPtr, demangled): the spelling rocprofv3 prints for the same kernel, template arguments included.
 #define MCOM_LAUNCH(kernel, grid, block, lds, stream, ...) do { \
+	++ctx->launch_gen; \
 	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, (const void*)&kernel)]; \
 	hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
 

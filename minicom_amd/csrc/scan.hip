@@ -56,7 +56,8 @@ __device__ __forceinline__ void so_store(T *out, size_t base, size_t n, const T 
 
 template <class T>
 __global__ __launch_bounds__(SO_THREADS) void k_scan_one(const T *in, T *out, size_t n, uint32_t tiles_per_wg,
-                                                         unsigned long long *__restrict__ parts, uint32_t epoch, unsigned int *__restrict__ poison)
+                                                         unsigned long long *__restrict__ parts, uint32_t epoch, unsigned int *__restrict__ poison,
+                                                         unsigned long long *__restrict__ total_slot)
 {
 	constexpr int PER = SoCfg<T>::PER;
 	constexpr size_t TILE = (size_t)SO_THREADS * PER;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(SO_THREADS) void k_scan_one(const T *in, T *out, si
 #pragma unroll
 		for (int u = 0; u < PER; ++u) { o[u] = run; run += v[u]; }
 		so_store<T>(out, at, last, o);
+		if (n - 1 >= at && n - 1 < at + PER) *total_slot = (unsigned long long)o[n - 1 - at];   // the last element, for the host (mcom_d2h_async)
 		base += all;
 		__syncthreads();
 	}
@@ -140,9 +142,10 @@ __global__ __launch_bounds__(SO_THREADS) void k_scan_one(const T *in, T *out, si
 int mcom_scan_prepare(mcom_ctx *ctx)
 {
 	if (ctx->scan_parts) return MCOM_OK;
-	MCOM_HIP(ctx, hipHostMalloc((void**)&ctx->poison, 64, hipHostMallocMapped));
+	MCOM_HIP(ctx, hipHostMalloc((void**)&ctx->poison, 64 + 8 * mcom_ctx::SCAN_TOTALS, hipHostMallocMapped));
 	*ctx->poison = 0;
 	MCOM_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_poison, (void*)ctx->poison, 0));
+	ctx->scan_tot = (unsigned long long*)((char*)ctx->poison + 64); ctx->d_scan_tot = (unsigned long long*)((char*)ctx->d_poison + 64);
 	MCOM_HIP(ctx, hipMalloc((void**)&ctx->scan_parts, (size_t)2 * SO_MAX_WG * 8));
 	MCOM_HIP(ctx, hipMemsetAsync(ctx->scan_parts, 0, (size_t)2 * SO_MAX_WG * 8, ctx->stream));
 	ctx->scan_epoch = 0;
@@ -162,8 +165,14 @@ static int scan_one(mcom_ctx *ctx, const T *in, T *out, size_t n)
 	const size_t G = (tiles + per - 1) / per;
 	if (per >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "scan of %zu elements", n);
 	if (++ctx->scan_epoch == 0) ctx->scan_epoch = 1;                               // (0 = what the cleared scratch holds)
-	MCOM_LAUNCH(k_scan_one<T>, dim3((unsigned)G), dim3(SO_THREADS), 0, ctx->stream, in, out, n, (uint32_t)per, ctx->scan_parts, ctx->scan_epoch, ctx->d_poison);
+	const uint32_t slot = ctx->scan_epoch % mcom_ctx::SCAN_TOTALS, gen_before = ctx->launch_gen;
+	MCOM_LAUNCH(k_scan_one<T>, dim3((unsigned)G), dim3(SO_THREADS), 0, ctx->stream, in, out, n, (uint32_t)per, ctx->scan_parts, ctx->scan_epoch, ctx->d_poison, ctx->d_scan_tot + slot);
 	MCOM_LAUNCH_CHECK(ctx);
+	for (mcom_ctx::ScanTotal &t : ctx->scan_last) {
+		if (t.slot == slot) t.last = nullptr;                                      // (the ring came round: that total is gone)
+		if (t.gen == gen_before) t.gen = ctx->launch_gen;                          // scans in a row: the earlier ones' totals still stand
+	}
+	ctx->scan_last[ctx->scan_last_at++ % 8] = mcom_ctx::ScanTotal{(const void*)(out + n - 1), (uint32_t)sizeof(T), slot, ctx->launch_gen};
 	return MCOM_OK;
 }
 
