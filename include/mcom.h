@@ -489,6 +489,23 @@ int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d
 int mcom_dump_refbin(mcom_ctx *ctx, const uint8_t *d_seq, uint64_t chars, uint8_t *d_out);
 /* single.seq: reads d_rids[0 .. n) back to back, four bases per byte (kthread_dump.c:390-417): d_out [(n L + 3) / 4]            */
 int mcom_dump_singles(mcom_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_rids, uint64_t n, int L, uint8_t *d_out);
+/* The order-preserving (`minicom -p`, ORDER) and paired-end (_PE) file sets differ from the default one in the member order inside a contig
+ * and in their id streams (kthread_dump.c:33-138, kthread_dump_pe.c:35-120, :218-619):
+ *   mcom_members_order3  the member lists in cmpcluster3 order (offset, then read id: kthread_cb.c:72-84, the qsort of kthread_dump.c:34):
+ *                        d_mem2 [n_members]; key_bits as for mcom_members_finalize.  mcom_dump_members then runs on them unchanged
+ *   mcom_dump_ids_order  ids.bin: per member its read id, or the difference to the id before it when the 16-bit position delta is 0 (:116-127)
+ *   mcom_dump_ids_text   ids.txt of the paired-end mode: "%d %u\n" = file of the read (id >= half: 1), read id (kthread_dump_pe.c:70-74);
+ *                        d_text NULL and text_cap 0: a sizing call (*h_text_bytes)
+ *   mcom_dump_pairing    peids.bin.sp / file.bin.sp over the reads of the eight lists (d_lists: their ids in the decoder's order) and
+ *                        peids.bin.0 / file.bin.0 over the members: a first-file read is numbered in the decoder's order among first-file
+ *                        reads, a second-file read (id >= half) writes the number of its mate id - half; file.bin: one bit per read
+ *                        (kthread_dump_pe.c:270-470, :583-612).  d_ids_sp [<= n_list], d_file_sp [(n_list + 7) / 8], d_ids_0 [<= n_members],
+ *                        d_file_0 [(n_members + 7) / 8]; h_counts = { entries of d_ids_sp, of d_ids_0 }.  All synchronous.                 */
+int mcom_members_order3(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, int key_bits, uint64_t *d_mem2);
+int mcom_dump_ids_order(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint32_t *d_ids);
+int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes);
+int mcom_dump_pairing(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
+                      uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts);
 /* d_flag[i] = 1 when read d_rids[i] holds an N (such unclustered reads go to single_N.seq as text, kthread_dump.c:400-407)       */
 int mcom_rows_have_n(mcom_ctx *ctx, const uint64_t *d_nmask, const uint32_t *d_rids, size_t n, int L, uint8_t *d_flag);
 

@@ -42,8 +42,9 @@ typedef struct {
 	                       the contig index build, instead of behind it in the main stream; same result.  Measured on MI355X (100 M
 	                       reads): the two kernels slow each other down by what the overlap saves (243.7 vs 245-249 ms per step), so
 	                       it is off by default                                                                                 */
-	int host_dump;      /* 1 = mcomh_cluster_dump writes its streams with the host loop of the -p / paired-end modes instead of the
-	                       device encoder (csrc/streams.hip); same files (A/B switch, the cross-check of tests/test_streams.py)   */
+	int host_dump;      /* 1 = mcomh_cluster_dump, _order and _pe write their streams with the host loop (every base of every member, as the
+	                       reference's print_encode does) instead of the device encoders (csrc/streams.hip); same files (A/B switch, the
+	                       cross-check of tests/test_streams.py)                                                                      */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

@@ -228,6 +228,7 @@ extern "C" int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, tlen + n_members, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
+	if (!d_text && !text_cap) return MCOM_OK;                                   // a sizing call: d_pos and d_dir are complete, the text's length known
 	if (total > text_cap || !d_text) return mcom_fail(ctx, MCOM_E_OVERFLOW, "mismatch text: %llu bytes, room for %llu", (unsigned long long)total, (unsigned long long)text_cap);
 #define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_st_emit<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_packed, d_nmask, NW, L, d_mem, cid, (size_t)n_members, d_cbits, d_coff, tlen, d_text); break;
 	switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: break; }
@@ -269,5 +270,224 @@ extern "C" int mcom_rows_have_n(mcom_ctx *ctx, const uint64_t *d_nmask, const ui
 	if (!d_nmask || !d_rids || !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	MCOM_LAUNCH(k_st_has_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_nmask, (L + 63) / 64, d_rids, n, d_flag);
 	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// ---- the order-preserving and the paired-end file sets (kthread_dump.c:33-138, kthread_dump_pe.c:35-120, :218-619) ----
+// Round 3 wrote these two modes with a host loop over every base of every member (~260 s per 100 M reads).  They differ from the
+// default mode in the member order inside a contig (cmpcluster3: offset, then read id, kthread_cb.c:72-84), in one more stream per
+// member (the ids), and in the pairing streams of the paired-end mode; mismatch text, positions, directions, contigs and singles are
+// the default mode's kernels above.
+namespace {
+__global__ __launch_bounds__(256) void k_o3_fill(const uint64_t *__restrict__ mem, const uint64_t *__restrict__ moff, size_t n_contigs, mcom_mm128 *__restrict__ rec)
+{
+	const size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;         // sixteen lanes per contig
+	if (c >= n_contigs) return;
+	const int lane = threadIdx.x & 15;
+	const uint64_t hi = (uint64_t)c << 32;
+	for (uint64_t q = moff[c] + lane; q < moff[c + 1]; q += 16) { const uint64_t y = mem[q]; mcom_mm128 r; r.x = hi | (y >> 32); r.y = y; rec[q] = r; }
+}
+__global__ void k_o3_rekey(const mcom_mm128 *__restrict__ in, size_t n, int kb, mcom_mm128 *__restrict__ out)
+{
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n) return;
+	const mcom_mm128 r = in[q];
+	mcom_mm128 o; o.x = ((r.x >> 32) << kb) | (uint64_t)((uint32_t)r.y >> 1); o.y = r.y;
+	out[q] = o;
+}
+__global__ void k_o3_out(const mcom_mm128 *__restrict__ rec, size_t n, uint64_t *__restrict__ mem2)
+{
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n) mem2[q] = rec[q].y;
+}
+__global__ __launch_bounds__(256) void k_st_cid(const uint64_t *__restrict__ moff, size_t n_contigs, uint32_t *__restrict__ cid)
+{
+	const size_t c = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+	if (c >= n_contigs) return;
+	for (uint64_t q = moff[c] + (threadIdx.x & 15); q < moff[c + 1]; q += 16) cid[q] = (uint32_t)c;
+}
+// ids.bin of the order-preserving mode (kthread_dump.c:116-127): the read id, or -- at the position of the member before -- its
+// difference to that member's id (the 16-bit position delta of the stream decides what "the same position" is)
+__global__ void k_st_ids_order(const uint64_t *__restrict__ mem, const uint64_t *__restrict__ moff, const uint32_t *__restrict__ cid, size_t n_members, uint32_t *__restrict__ out)
+{
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_members) return;
+	const uint64_t y = mem[q];
+	const uint32_t rid = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1;
+	uint32_t v = rid;
+	if (q > moff[cid[q]]) {
+		const uint64_t yp = mem[q - 1];
+		if ((uint16_t)(pos - ((uint32_t)yp >> 1)) == 0) v = rid - (uint32_t)(yp >> 32);
+	}
+	out[q] = v;
+}
+// ids.txt of the paired-end mode (kthread_dump_pe.c:70-74): "%d %u\n" = which file the member came from, its read id
+__device__ __forceinline__ int st_digits(uint32_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+__global__ void k_st_idtext_len(const uint64_t *__restrict__ mem, size_t n, uint64_t *__restrict__ len)
+{
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n) len[q] = 3 + (uint64_t)st_digits((uint32_t)(mem[q] >> 32));
+}
+__global__ void k_st_idtext_emit(const uint64_t *__restrict__ mem, size_t n, uint32_t half, const uint64_t *__restrict__ off, uint8_t *__restrict__ text)
+{
+	const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n) return;
+	uint32_t rid = (uint32_t)(mem[q] >> 32);
+	uint8_t *o = text + off[q];
+	const int d = st_digits(rid);
+	o[0] = rid < half ? (uint8_t)'0' : (uint8_t)'1'; o[1] = (uint8_t)' ';
+	for (int i = d - 1; i >= 0; --i) { o[2 + i] = (uint8_t)('0' + rid % 10); rid /= 10; }
+	o[2 + d] = (uint8_t)'\n';
+}
+// pairing (kthread_dump_pe.c:270-470, :583-612).  seq = the reads in the order the decoder writes them: the eight lists, then the
+// members.  A read of the first file gets its number in that order among first-file reads (mpv); a read of the second file writes the
+// number of its mate; a file bit per read says which it is.
+__global__ void k_pe_rid(const uint32_t *__restrict__ lists, size_t n_list, const uint64_t *__restrict__ mem, size_t n_members, uint32_t half, uint32_t *__restrict__ first)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n_list + n_members) return;
+	if (i == n_list + n_members) { first[i] = 0; return; }
+	const uint32_t rid = i < n_list ? lists[i] : (uint32_t)(mem[i - n_list] >> 32);
+	first[i] = rid < half ? 1u : 0u;
+}
+__global__ void k_pe_mpv(const uint32_t *__restrict__ lists, size_t n_list, const uint64_t *__restrict__ mem, size_t n_members, uint32_t half, const uint32_t *__restrict__ pre,
+                         uint32_t *__restrict__ mpv)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_list + n_members) return;
+	const uint32_t rid = i < n_list ? lists[i] : (uint32_t)(mem[i - n_list] >> 32);
+	if (rid < half) mpv[rid] = pre[i];
+}
+__global__ void k_pe_ids(const uint32_t *__restrict__ lists, size_t n_list, const uint64_t *__restrict__ mem, size_t n_members, uint32_t half, const uint32_t *__restrict__ pre,
+                         const uint32_t *__restrict__ mpv, uint32_t *__restrict__ ids_sp, uint32_t *__restrict__ ids_0)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_list + n_members) return;
+	const uint32_t rid = i < n_list ? lists[i] : (uint32_t)(mem[i - n_list] >> 32);
+	if (rid < half) return;
+	const uint32_t second_before = (uint32_t)i - pre[i];                          // reads of the second file in front of this one
+	if (i < n_list) ids_sp[second_before] = mpv[rid - half];
+	else ids_0[second_before - ((uint32_t)n_list - pre[n_list])] = mpv[rid - half];
+}
+// file.bin: one bit per read of a range of seq (1 = second file), least significant first (bit_push, breads.h:241-248)
+__global__ void k_pe_bits(const uint32_t *__restrict__ first, size_t lo, size_t n, uint8_t *__restrict__ out)
+{
+	const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (8 * b >= n) return;
+	unsigned v = 0;
+	for (int j = 0; j < 8; ++j) { const size_t q = 8 * b + j; if (q < n && !first[lo + q]) v |= 1u << j; }
+	out[b] = (uint8_t)v;
+}
+}  // namespace
+
+extern "C" int mcom_members_order3(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, int key_bits, uint64_t *d_mem2)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (key_bits < 1 || key_bits > 32) return mcom_fail(ctx, MCOM_E_ARG, "bad key bits");
+	if (n_contigs == 0 || n_members == 0) return MCOM_OK;
+	if (!d_mem || !d_moff || !d_mem2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n_members >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-1 members");
+	int cb = 1; while ((1ull << cb) < n_contigs) ++cb;
+	if (key_bits + cb > 64) return mcom_fail(ctx, MCOM_E_ARG, "contig index and member offset need %d bits", key_bits + cb);
+	mcom_mm128 *a = nullptr, *b = nullptr; uint32_t *tiles = nullptr;
+	const size_t rec_b = (n_members + 1) * sizeof(mcom_mm128);
+	if (mcom_dmalloc(&a, rec_b) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "member records");
+	if (mcom_dmalloc(&b, rec_b) != hipSuccess) { mcom_dfree(a); return mcom_fail(ctx, MCOM_E_NOMEM, "member records"); }
+	if (mcom_dmalloc(&tiles, (MCOM_GROUP_SCRATCH(n_members) + 16) * 4) != hipSuccess) { mcom_dfree(a); mcom_dfree(b); return mcom_fail(ctx, MCOM_E_NOMEM, "member records"); }
+	int rc = mcom_ws_reserve(ctx, mcom_sort_ws_bytes(n_members));                  // (the oversized-group route of the grouped sort)
+	const unsigned blocks = (unsigned)((n_members + 255) / 256);
+	if (!rc) {
+		MCOM_LAUNCH(k_o3_fill, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, n_contigs, a);
+		rc = mcom_sort_groups_by_x(ctx, a, b, (size_t)n_members, d_moff, n_contigs, 32 + cb, tiles);                 // by read id inside every contig
+	}
+	if (!rc) {
+		MCOM_LAUNCH(k_o3_rekey, dim3(blocks), dim3(256), 0, ctx->stream, (const mcom_mm128*)b, (size_t)n_members, key_bits, a);
+		rc = mcom_sort_groups_by_x(ctx, a, b, (size_t)n_members, d_moff, n_contigs, key_bits + cb, tiles);           // then, stable, by offset
+	}
+	if (!rc) MCOM_LAUNCH(k_o3_out, dim3(blocks), dim3(256), 0, ctx->stream, (const mcom_mm128*)b, (size_t)n_members, d_mem2);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = mcom_stream_sync(ctx);
+	mcom_dfree(a); mcom_dfree(b); mcom_dfree(tiles);
+	if (rc) return rc;
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "%s", hipGetErrorString(e));
+	return MCOM_OK;
+}
+
+extern "C" int mcom_dump_ids_order(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint32_t *d_ids)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_contigs == 0 || n_members == 0) return MCOM_OK;
+	if (!d_mem || !d_moff || !d_ids) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	uint32_t *cid = nullptr;
+	if (mcom_dmalloc(&cid, n_members * 4 + 16) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "id stream scratch");
+	MCOM_LAUNCH(k_st_cid, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n_contigs, cid);
+	MCOM_LAUNCH(k_st_ids_order, dim3((unsigned)((n_members + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, d_moff, (const uint32_t*)cid, (size_t)n_members, d_ids);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = mcom_stream_sync(ctx);
+	mcom_dfree(cid);
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "%s", hipGetErrorString(e));
+	return MCOM_OK;
+}
+
+extern "C" int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes)
+{
+	if (!ctx || !h_text_bytes) return MCOM_E_ARG;
+	*h_text_bytes = 0;
+	if (n_members == 0) return MCOM_OK;
+	if (!d_mem) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	uint64_t *len = nullptr;
+	if (mcom_dmalloc(&len, (n_members + 1) * 8) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "id text scratch");
+	struct Guard { mcom_ctx *c; uint64_t *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, len};
+	const unsigned blocks = (unsigned)((n_members + 255) / 256);
+	MCOM_HIP(ctx, hipMemsetAsync(len + n_members, 0, 8, ctx->stream));
+	MCOM_LAUNCH(k_st_idtext_len, dim3(blocks), dim3(256), 0, ctx->stream, d_mem, (size_t)n_members, len);
+	MCOM_LAUNCH_CHECK(ctx);
+	int rc = mcom_scan64(ctx, len, len, n_members + 1, nullptr);
+	if (rc) return rc;
+	uint64_t total = 0;
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, len + n_members, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	*h_text_bytes = total;
+	if (!d_text && !text_cap) return MCOM_OK;                                    // a sizing call
+	if (total > text_cap || !d_text) return mcom_fail(ctx, MCOM_E_OVERFLOW, "id text: %llu bytes, room for %llu", (unsigned long long)total, (unsigned long long)text_cap);
+	MCOM_LAUNCH(k_st_idtext_emit, dim3(blocks), dim3(256), 0, ctx->stream, d_mem, (size_t)n_members, half, (const uint64_t*)len, d_text);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+extern "C" int mcom_dump_pairing(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
+                                 uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts)
+{
+	if (!ctx || !h_counts) return MCOM_E_ARG;
+	h_counts[0] = h_counts[1] = 0;
+	const uint64_t N = n_list + n_members;
+	if (N == 0) return MCOM_OK;
+	if (N >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-2 reads");
+	if ((n_list && !d_lists) || (n_members && !d_mem) || !d_ids_sp || !d_file_sp || !d_ids_0 || !d_file_0) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	uint32_t *first = nullptr, *pre = nullptr, *mpv = nullptr;
+	auto drop = [&]() { if (first) mcom_dfree(first); if (pre) mcom_dfree(pre); if (mpv) mcom_dfree(mpv); };
+	if (mcom_dmalloc(&first, (N + 1) * 4) != hipSuccess || mcom_dmalloc(&pre, (N + 1) * 4) != hipSuccess || mcom_dmalloc(&mpv, ((size_t)half + 1) * 4) != hipSuccess) {
+		drop(); return mcom_fail(ctx, MCOM_E_NOMEM, "pairing scratch");
+	}
+	const unsigned blocks = (unsigned)((N + 1 + 255) / 256);
+	MCOM_LAUNCH(k_pe_rid, dim3(blocks), dim3(256), 0, ctx->stream, d_lists, (size_t)n_list, d_mem, (size_t)n_members, half, first);
+	int rc = mcom_scan_u32(ctx, first, pre, N + 1, nullptr);
+	uint32_t cnt[2] = {0, 0};                                                    // first-file reads among the lists, among everything
+	hipError_t e = hipSuccess;
+	if (!rc) {
+		MCOM_LAUNCH(k_pe_mpv, dim3(blocks), dim3(256), 0, ctx->stream, d_lists, (size_t)n_list, d_mem, (size_t)n_members, half, (const uint32_t*)pre, mpv);
+		MCOM_LAUNCH(k_pe_ids, dim3(blocks), dim3(256), 0, ctx->stream, d_lists, (size_t)n_list, d_mem, (size_t)n_members, half, (const uint32_t*)pre, (const uint32_t*)mpv, d_ids_sp, d_ids_0);
+		if (n_list) MCOM_LAUNCH(k_pe_bits, dim3((unsigned)(((n_list + 7) / 8 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)first, (size_t)0, (size_t)n_list, d_file_sp);
+		if (n_members) MCOM_LAUNCH(k_pe_bits, dim3((unsigned)(((n_members + 7) / 8 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)first, (size_t)n_list, (size_t)n_members, d_file_0);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpyAsync(&cnt[0], pre + n_list, 4, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(&cnt[1], pre + N, 4, hipMemcpyDeviceToHost, ctx->stream);
+	}
+	if (e == hipSuccess) e = mcom_stream_sync(ctx);
+	drop();
+	if (rc) return rc;
+	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "%s", hipGetErrorString(e));
+	h_counts[0] = n_list - cnt[0];                                               // second-file reads among the lists: entries of d_ids_sp
+	h_counts[1] = n_members - (cnt[1] - cnt[0]);                                 // ... among the members: entries of d_ids_0
 	return MCOM_OK;
 }

@@ -2070,8 +2070,14 @@ static int fetch_read_strings(P *p, const std::vector<uint32_t> &rids, std::vect
 	}
 	return MCOM_OK;
 }
-static int cluster_dump_device(mcomh_pipeline *p, const char *folder)
+// mode 0: default; 1: order-preserving (-p, ORDER); 2: paired end (_PE: reads [0, n/2) are the first file, the rest their mates).
+// Round 4: all three modes are made here; the host loop below (cluster_dump_impl) is what mcomh_params.host_dump asks for and what
+// the tests compare this with.
+static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 {
+	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
+	const uint32_t half = (uint32_t)(p->n / 2);
+	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70
 	p->join_sg();
 	ensure_sg_flag(p);
 	if (p->cls_failed) return p->fail(MCOM_E_HIP, "the read classes did not arrive from the device: the class lists are incomplete");
@@ -2082,60 +2088,103 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder)
 	DevSet &D = p->dC;
 	const int L = p->L;
 	const std::string dir(folder);
-	PinVec<uint8_t> h_pos, h_dir, h_text, h_ref, h_single;
-	uint64_t text_bytes = 0;
+	PinVec<uint8_t> h_pos, h_dir, h_text, h_ref, h_single, h_ids;
+	uint64_t text_bytes = 0, ids_bytes = 0;
 	const size_t pos_bytes = 4 * D.n + 2 * (size_t)D.members, dir_bytes = ((size_t)D.members + 7) / 8, ref_bytes = ((size_t)D.chars + 3) / 4;
+	DevBuf<uint64_t> mem2, moff2;                                                 // the members in dump order (kept for the pairing streams)
+	const uint64_t *d_mem_dump = nullptr;
 	if (D.n) {
 		if ((rc = ensure_packed_contigs(p))) return rc;
-		// members in dump order: stable by (offset, direction) inside every contig -- the fold of mcom_members_finalize with one empty pass
-		DevBuf<uint64_t> mem2, moff2;
 		if (!mem2.reserve(D.members + 1) || !moff2.reserve(D.n + 2)) return p->fail(MCOM_E_NOMEM, "member lists");
 		int kb = 2; while ((1ull << kb) < 4 * std::max<uint64_t>(p->maxlen, 2 * (uint64_t)L) + 4) ++kb;
-		const uint32_t *ac[1] = {nullptr}; const uint64_t *am[1] = {nullptr}; const uint64_t an[1] = {0};
-		if ((rc = p->gpu(mcom_members_finalize(p->ctx, D.mem.p, D.moff.p, D.n, D.members, ac, am, an, 1, kb, mem2.p, moff2.p)))) return rc;
-		DevBuf<uint8_t> d_pos, d_dir, d_text, d_ref;
+		const uint64_t *d_moff_dump = D.moff.p;
+		if (!sorted) {
+			// members in dump order: stable by (offset, direction) inside every contig -- the fold of mcom_members_finalize with one empty pass
+			const uint32_t *ac[1] = {nullptr}; const uint64_t *am[1] = {nullptr}; const uint64_t an[1] = {0};
+			if ((rc = p->gpu(mcom_members_finalize(p->ctx, D.mem.p, D.moff.p, D.n, D.members, ac, am, an, 1, kb, mem2.p, moff2.p)))) return rc;
+			d_moff_dump = moff2.p;
+		} else if ((rc = p->gpu(mcom_members_order3(p->ctx, D.mem.p, D.moff.p, D.n, D.members, kb, mem2.p)))) return rc;   // cmpcluster3 (kthread_dump.c:34): the pipeline keeps its own order
+		d_mem_dump = mem2.p;
+		DevBuf<uint8_t> d_pos, d_dir, d_text, d_ref, d_ids;
 		if (!d_pos.reserve(pos_bytes + 16) || !d_dir.reserve(dir_bytes + 16) || !d_ref.reserve(ref_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
-		rc = mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, moff2.p, D.n, D.members, d_pos.p, d_dir.p, nullptr, 0, &text_bytes);
-		if (rc != MCOM_E_OVERFLOW && rc != MCOM_OK) return p->gpu(rc);
+		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, d_moff_dump, D.n, D.members, d_pos.p, d_dir.p, nullptr, 0, &text_bytes)))) return rc;
 		if (!d_text.reserve(text_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
-		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, moff2.p, D.n, D.members, d_pos.p, d_dir.p, d_text.p,
+		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, d_moff_dump, D.n, D.members, d_pos.p, d_dir.p, d_text.p,
 		                                   text_bytes + 16, &text_bytes))) || (rc = p->gpu(mcom_dump_refbin(p->ctx, D.seq.p, D.chars, d_ref.p)))) return rc;
-		if (!h_pos.resize(pos_bytes) || !h_dir.resize(dir_bytes) || !h_text.resize(text_bytes) || !h_ref.resize(ref_bytes)) return p->fail(MCOM_E_NOMEM, "stream images");
+		if (order) {                                                               // ids.bin.0 (kthread_dump.c:116-127)
+			ids_bytes = 4 * (uint64_t)D.members;
+			if (!d_ids.reserve(ids_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
+			if ((rc = p->gpu(mcom_dump_ids_order(p->ctx, mem2.p, D.moff.p, D.n, D.members, (uint32_t*)d_ids.p)))) return rc;
+		} else if (pe) {                                                           // ids.txt.0 (kthread_dump_pe.c:70-74)
+			if ((rc = p->gpu(mcom_dump_ids_text(p->ctx, mem2.p, D.members, half, nullptr, 0, &ids_bytes)))) return rc;
+			if (!d_ids.reserve(ids_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
+			if ((rc = p->gpu(mcom_dump_ids_text(p->ctx, mem2.p, D.members, half, d_ids.p, ids_bytes + 16, &ids_bytes)))) return rc;
+		}
+		if (!h_pos.resize(pos_bytes) || !h_dir.resize(dir_bytes) || !h_text.resize(text_bytes) || !h_ref.resize(ref_bytes) || !h_ids.resize(ids_bytes)) return p->fail(MCOM_E_NOMEM, "stream images");
 		if ((rc = p->d2h(h_pos.data(), d_pos.p, pos_bytes, "copy streams")) || (rc = p->d2h(h_dir.data(), d_dir.p, dir_bytes, "copy streams")) ||
-		    (rc = p->d2h(h_text.data(), d_text.p, (size_t)text_bytes, "copy streams")) || (rc = p->d2h(h_ref.data(), d_ref.p, ref_bytes, "copy streams")) || (rc = p->sync("copy streams"))) return rc;
+		    (rc = p->d2h(h_text.data(), d_text.p, (size_t)text_bytes, "copy streams")) || (rc = p->d2h(h_ref.data(), d_ref.p, ref_bytes, "copy streams")) ||
+		    (ids_bytes && (rc = p->d2h(h_ids.data(), d_ids.p, (size_t)ids_bytes, "copy streams"))) || (rc = p->sync("copy streams"))) return rc;
 	}
 	p->stat["t_dump_members"] += now_ms() - t0;
-	// unclustered reads: those with an N join the N file as text, the others are packed four per byte in singleton order (:390-417)
+	// unclustered reads: those with an N join the N file as text, the others are packed four per byte in singleton order (:390-417);
+	// the two other modes write every list in read-id order (:420-427) and the singles after their sorted ids
 	std::vector<uint32_t> live, single_ids, nfile = p->Nfile;
 	live.reserve(p->sg.size());
 	for (size_t i = 0; i < p->sg.size(); ++i) if (!p->sg_flag[i]) live.push_back(p->sg[i]);
 	if (!live.empty()) {
-		DevBuf<uint32_t> d_ids; DevBuf<uint8_t> d_f, d_single;
+		DevBuf<uint32_t> d_ids; DevBuf<uint8_t> d_f;
 		std::vector<uint8_t> hasn(live.size());
 		if (!d_ids.reserve(live.size()) || !d_f.reserve(live.size())) return p->fail(MCOM_E_NOMEM, "singleton buffers");
 		if ((rc = p->h2d(d_ids.p, live.data(), live.size(), "upload singletons")) || (rc = p->gpu(mcom_rows_have_n(p->ctx, p->d_nmask.p, d_ids.p, live.size(), L, d_f.p))) ||
 		    (rc = p->d2h(hasn.data(), d_f.p, live.size(), "copy flags")) || (rc = p->sync("singleton flags"))) return rc;
 		single_ids.reserve(live.size());
 		for (size_t i = 0; i < live.size(); ++i) (hasn[i] ? nfile : single_ids).push_back(live[i]);
+	}
+	std::vector<uint32_t> fpA = p->fpA, fpT = p->fpT, fpN = p->fpN, allA = p->allA, allT = p->allT, allN = p->allN;
+	if (sorted) for (std::vector<uint32_t> *v : {&fpA, &fpT, &fpN, &nfile, &single_ids, &allA, &allT, &allN}) std::sort(v->begin(), v->end());
+	if (!single_ids.empty()) {
+		DevBuf<uint32_t> d_ids; DevBuf<uint8_t> d_single;
 		const size_t sbytes = (single_ids.size() * (size_t)L + 3) / 4;
-		if (!single_ids.empty()) {
-			if (!d_single.reserve(sbytes + 16) || !h_single.resize(sbytes)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
-			if ((rc = p->h2d(d_ids.p, single_ids.data(), single_ids.size(), "upload singletons")) || (rc = p->gpu(mcom_dump_singles(p->ctx, p->d_packed.p, d_ids.p, single_ids.size(), L, d_single.p))) ||
-			    (rc = p->d2h(h_single.data(), d_single.p, sbytes, "copy singletons")) || (rc = p->sync("singleton stream"))) return rc;
-		}
+		if (!d_ids.reserve(single_ids.size()) || !d_single.reserve(sbytes + 16) || !h_single.resize(sbytes)) return p->fail(MCOM_E_NOMEM, "singleton buffers");
+		if ((rc = p->h2d(d_ids.p, single_ids.data(), single_ids.size(), "upload singletons")) || (rc = p->gpu(mcom_dump_singles(p->ctx, p->d_packed.p, d_ids.p, single_ids.size(), L, d_single.p))) ||
+		    (rc = p->d2h(h_single.data(), d_single.p, sbytes, "copy singletons")) || (rc = p->sync("singleton stream"))) return rc;
+	}
+	// paired end: the pairing streams (kthread_dump_pe.c:270-470, :583-612) over the eight lists and over the members
+	PinVec<uint8_t> h_pe_sp, h_pe_0, h_fb_sp, h_fb_0;
+	if (pe) {
+		std::vector<uint32_t> lists;
+		for (const std::vector<uint32_t> *v : {&allA, &allT, &allN, &fpA, &fpT, &fpN, &nfile, &single_ids}) lists.insert(lists.end(), v->begin(), v->end());
+		const size_t nl = lists.size(), nm = D.n ? (size_t)D.members : 0;
+		DevBuf<uint32_t> d_lists, d_isp, d_i0; DevBuf<uint8_t> d_fsp, d_f0;
+		if (!d_lists.reserve(nl + 1) || !d_isp.reserve(nl + 1) || !d_i0.reserve(nm + 1) || !d_fsp.reserve((nl + 7) / 8 + 16) || !d_f0.reserve((nm + 7) / 8 + 16)) return p->fail(MCOM_E_NOMEM, "pairing buffers");
+		uint64_t cnt[2] = {0, 0};
+		if ((nl && (rc = p->h2d(d_lists.p, lists.data(), nl, "upload lists"))) ||
+		    (rc = p->gpu(mcom_dump_pairing(p->ctx, d_lists.p, nl, d_mem_dump, nm, half, d_isp.p, d_fsp.p, d_i0.p, d_f0.p, cnt)))) return rc;
+		if (!h_pe_sp.resize(4 * cnt[0]) || !h_pe_0.resize(4 * cnt[1]) || !h_fb_sp.resize((nl + 7) / 8) || !h_fb_0.resize((nm + 7) / 8)) return p->fail(MCOM_E_NOMEM, "pairing images");
+		if ((cnt[0] && (rc = p->d2h(h_pe_sp.data(), (const uint8_t*)d_isp.p, 4 * cnt[0], "copy pairing"))) || (cnt[1] && (rc = p->d2h(h_pe_0.data(), (const uint8_t*)d_i0.p, 4 * cnt[1], "copy pairing"))) ||
+		    (nl && (rc = p->d2h(h_fb_sp.data(), d_fsp.p, (nl + 7) / 8, "copy pairing"))) || (nm && (rc = p->d2h(h_fb_0.data(), d_f0.p, (nm + 7) / 8, "copy pairing"))) || (rc = p->sync("pairing streams"))) return rc;
 	}
 	p->stat["t_dump_gpu"] += now_ms() - t0;
 	const double tw = now_ms();
 	if (!write_file(dir + "/ref.bin.0", h_ref.data(), D.n ? ref_bytes : 0) || !write_file(dir + "/beg_pos.bin.0", h_pos.data(), D.n ? pos_bytes : 0) ||
 	    !write_file(dir + "/dir.bin.0", h_dir.data(), D.n ? dir_bytes : 0) || !write_file(dir + "/dif_char.txt.0", h_text.data(), D.n ? (size_t)text_bytes : 0) ||
 	    !write_file(dir + "/single.seq", h_single.data(), h_single.size())) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	if (order && !write_file(dir + "/ids.bin.0", h_ids.data(), D.n ? (size_t)ids_bytes : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);   // kthread_dump.c:266-269
+	if (pe && (!write_file(dir + "/ids.txt.0", h_ids.data(), D.n ? (size_t)ids_bytes : 0) || !write_file(dir + "/peids.bin.sp", h_pe_sp.data(), h_pe_sp.size()) ||
+	           !write_file(dir + "/file.bin.sp", h_fb_sp.data(), h_fb_sp.size()) || !write_file(dir + "/peids.bin.0", h_pe_0.data(), h_pe_0.size()) ||
+	           !write_file(dir + "/file.bin.0", h_fb_0.data(), h_fb_0.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+	if (order && (!write_ids(dir + "/allA.ids.bin", allA) || !write_ids(dir + "/allT.ids.bin", allT) || !write_ids(dir + "/allN.ids.bin", allN) ||
+	              !write_ids(dir + "/AA.ids.bin", fpA) || !write_ids(dir + "/TT.ids.bin", fpT) || !write_ids(dir + "/NN.ids.bin", fpN) ||
+	              !write_ids(dir + "/Nfile.ids.bin", nfile) || !write_ids(dir + "/singleFile.ids.bin", single_ids))) return p->fail(MCOM_E_ARG, "cannot write id streams");
 	FILE *finfo = fopen((dir + "/info.txt").c_str(), "w");
 	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
-	fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	if (pe) fprintf(finfo, "%d %d\n%u\n%zu %zu %zu\n", L, 1, half, p->allA.size(), p->allT.size(), p->allN.size());   // kthread_dump_pe.c:222-234
+	else fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	if (order) fprintf(finfo, "%u\n", (unsigned)p->n);                                               // :377-379
 	fclose(finfo);
 	// the short lists as text (:566-671)
 	struct TextList { const char *name; const std::vector<uint32_t> *ids; char base; };
-	const TextList lists[4] = {{"AA.txt", &p->fpA, 'A'}, {"TT.txt", &p->fpT, 'T'}, {"NN.txt", &p->fpN, 'N'}, {"single_N.seq", &nfile, 0}};
+	const TextList lists[4] = {{"AA.txt", &fpA, 'A'}, {"TT.txt", &fpT, 'T'}, {"NN.txt", &fpN, 'N'}, {"single_N.seq", &nfile, 0}};
 	for (const TextList &tl : lists) {
 		std::vector<char> strs;
 		if ((rc = fetch_read_strings(p, *tl.ids, strs))) return rc;
@@ -2148,7 +2197,7 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder)
 		fclose(f);
 	}
 	p->stat["t_dump_write"] += now_ms() - tw;
-	p->stat["dump_bytes"] += (double)(pos_bytes + dir_bytes + ref_bytes + text_bytes + h_single.size());
+	p->stat["dump_bytes"] += (double)(pos_bytes + dir_bytes + ref_bytes + text_bytes + ids_bytes + h_single.size());
 	return MCOM_OK;
 }
 
@@ -2156,7 +2205,7 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder)
 static int cluster_dump_impl(mcomh_pipeline *p, const char *folder, int mode)
 {
 	if (!p || !folder) return MCOM_E_ARG;
-	if (mode == 0 && !p->host_dump) return cluster_dump_device(p, folder);
+	if (!p->host_dump) return cluster_dump_device(p, folder, mode);
 	const bool order = mode == 1, pe = mode == 2, sorted = mode != 0;
 	const uint32_t half = (uint32_t)(p->n / 2);
 	if (pe && (p->n & 1)) return p->fail(MCOM_E_ARG, "paired-end mode needs as many reads in the second file as in the first");   // preprocess.c:70

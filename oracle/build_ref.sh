@@ -68,6 +68,8 @@ build_variant L75 75
 ININUMDICT=4 build_variant L100_s4 100
 build_variant L100_order 100 ORDER
 build_variant L100_pe 100 _PE
+build_variant L150_order 150 ORDER
+build_variant L150_pe 150 _PE
 # multi-threaded builds, used only as the CPU baseline of bench.py (their output is not reproducible run to run)
 MARCH=x86-64-v3 NUM_THR=16 build_variant L150_t16 150
 # ... at other core counts: bench.py takes the largest one the box has cores for (north_star: "-t <host cores>")

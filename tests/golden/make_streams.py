@@ -50,6 +50,10 @@ def make(tag, variant, prefix="streams_", paired=False):
 
 
 if __name__ == "__main__":
+    if "--only-L150-modes" in sys.argv:
+        make("stages_L150", "L150_order", prefix="streams_order_")
+        make("stages_L150", "L150_pe", prefix="streams_pe_", paired=True)
+        sys.exit(0)
     if "--only-L40" in sys.argv:
         make("stages_L40", "L40")                                     # short reads: k = 17, w = 3
         sys.exit(0)
@@ -57,4 +61,6 @@ if __name__ == "__main__":
     make("stages_L150", "L150")
     make("stages_L100", "L100_order", prefix="streams_order_")       # -p: the order-preserving file set (ids streams)
     make("stages_L100", "L100_pe", prefix="streams_pe_", paired=True)  # paired end: pairing streams
+    make("stages_L150", "L150_order", prefix="streams_order_")       # ... and at L = 150 (BASELINE configs[4] is 150 bp)
+    make("stages_L150", "L150_pe", prefix="streams_pe_", paired=True)
     make("stages_L40", "L40")

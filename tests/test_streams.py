@@ -108,10 +108,10 @@ def _golden_order_streams(golden_dir, tag):
         return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
 
 
-def test_our_decoder_restores_the_original_order_from_the_reference_order_streams(golden_dir, tmp_path):
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_our_decoder_restores_the_original_order_from_the_reference_order_streams(golden_dir, tmp_path, tag):
     """CPU: mcomh_decompress_order applied to the -p file set written by the reference itself."""
     from minicom_amd.pipeline import decompress
-    tag = "stages_L100"
     d = tmp_path / "streams"; d.mkdir()
     for name, data in _golden_order_streams(golden_dir, tag).items():
         (d / name).write_bytes(data)
@@ -123,9 +123,9 @@ def test_our_decoder_restores_the_original_order_from_the_reference_order_stream
 
 
 @pytest.mark.gpu
-def test_order_stream_files_byte_identical_to_reference_and_exact(golden_dir, tmp_path):
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_order_stream_files_byte_identical_to_reference_and_exact(golden_dir, tmp_path, tag):
     from minicom_amd.pipeline import Pipeline, decompress
-    tag = "stages_L100"
     rows = _golden_reads(golden_dir, tag)
     reads = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
     p = Pipeline(reads, host_threads=4)
@@ -170,11 +170,11 @@ def _golden_pe_streams(golden_dir, tag):
         return {m.name: tf.extractfile(m).read() for m in tf.getmembers()}
 
 
-def test_our_decoder_pairs_the_mates_from_the_reference_pe_streams(golden_dir, tmp_path):
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_our_decoder_pairs_the_mates_from_the_reference_pe_streams(golden_dir, tmp_path, tag):
     """CPU: mcomh_decompress_pe applied to the paired-end file set written by the reference itself (file 1 = the first half
     of the fixture reads, file 2 = the second half)."""
     from minicom_amd.pipeline import decompress_pe
-    tag = "stages_L100"
     d = tmp_path / "streams"; d.mkdir()
     for name, data in _golden_pe_streams(golden_dir, tag).items():
         (d / name).write_bytes(data)
@@ -187,10 +187,10 @@ def test_our_decoder_pairs_the_mates_from_the_reference_pe_streams(golden_dir, t
 
 
 @pytest.mark.gpu
-def test_pe_stream_files_byte_identical_to_reference_and_pairs_kept(golden_dir, tmp_path):
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_pe_stream_files_byte_identical_to_reference_and_pairs_kept(golden_dir, tmp_path, tag):
     from minicom_amd import synth
     from minicom_amd.pipeline import Pipeline, decompress_pe
-    tag = "stages_L100"
     rows = _golden_reads(golden_dir, tag)
     half = len(rows) // 2
     reads = np.frombuffer(b"".join(rows[:2 * half]), dtype=np.uint8).reshape(2 * half, len(rows[0])).copy()
@@ -231,3 +231,30 @@ def test_pe_round_trip_at_a_size_no_fixture_covers(tmp_path):
     got = np.sort(np.concatenate([a, b], axis=1).view("S300").ravel())
     want = np.sort(np.ascontiguousarray(np.concatenate([reads[:half], reads[half:]], axis=1)).view("S300").ravel())
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["order", "paired"])
+@pytest.mark.parametrize("L", [100, 150])
+def test_device_encoders_of_the_order_and_paired_end_modes_equal_the_host_loop(tmp_path, mode, L):
+    """Round 4: the -p and paired-end file sets are made on the device too (csrc/streams.hip: cmpcluster3 member order by two
+    grouped sorts, ids.bin / ids.txt one thread per member, the pairing streams by scans; kthread_dump.c:33-138,
+    kthread_dump_pe.c:35-120, :218-619).  The host loop (host_dump = 1) walks every base of every member as the reference does:
+    every file of the two must be byte-identical on 200 k reads + 20 k with N, poly-A/T and N-heavy reads."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = np.concatenate([synth.synth_reads(5050 + L, 200000, L), synth.synth_reads(5051 + L, 20000, L, plumbing=True)])
+    files = {}
+    for how in (0, 1):
+        p = Pipeline(reads, host_threads=8, host_dump=how)
+        p.pre_process()
+        d = tmp_path / f"streams{how}"; d.mkdir()
+        p.cluster_dump(str(d), order=mode == "order", paired=mode == "paired")
+        if how == 0:
+            assert p.stat("dump_bytes") > 0                              # the device encoder ran
+        p.close()
+        files[how] = {f: (d / f).read_bytes() for f in sorted(os.listdir(d))}
+    assert sorted(files[0]) == sorted(files[1])
+    for name in files[1]:
+        assert files[0][name] == files[1][name], name
+    assert len(files[0]["ids.bin.0" if mode == "order" else "peids.bin.0"]) > 100000
