@@ -384,7 +384,7 @@ def main():
             h2h = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
 
     # ---- file -> stream files (one GPU): what the `minicom` command's user waits for, before the external entropy coder
-    e2e = None
+    e2e, e2e_modes = None, {}
     if world == 1 and not distributed and rank == 0 and a.e2e_reads > 0 and a.genome == "uniform":
         reads = None
         pool_trim(); torch.cuda.empty_cache()
@@ -393,6 +393,14 @@ def main():
             e2e = file_to_streams(a.e2e_reads, L, SEED, host_threads=threads, ref_reads=1_000_000)
         except Exception as e:                                                   # noqa: BLE001
             e2e = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
+        # the same for the two other file sets of the command line: `minicom -p` (order-preserving) and `minicom -1 -2` (paired end)
+        for mode in ("order", "paired"):
+            try:
+                pool_trim(); torch.cuda.empty_cache()
+                r = file_to_streams(a.e2e_reads, L, SEED, host_threads=threads, ref_reads=0, mode=mode)
+                e2e_modes[mode] = {k: r[k] for k in ("mode", "reads", "value", "unit", "seconds", "stream_bytes")}
+            except Exception as e:                                               # noqa: BLE001
+                e2e_modes[mode] = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
 
     if rank == 0:
         nd = len(minicom_amd.hip.dict_layout(L)[0])
@@ -527,6 +535,8 @@ def main():
                        "every_timed_step_equal": True, "checked_run": checked},
             "value_host_to_host": h2h,
             "value_file_to_streams": e2e,
+            "value_file_to_streams_order_preserving": e2e_modes.get("order"),
+            "value_file_to_streams_paired_end": e2e_modes.get("paired"),
             "value_strong_100m": strong,
             "whole_step": whole,
             "event_overhead": ev_ab,

@@ -95,6 +95,12 @@ int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size
                        uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
                        uint64_t *d_nmask, mcom_mm128 *d_rec);
 
+/* The same for reads the caller has packed already (round 4: a FASTQ parser that packs on the host sends 2 bits per base and one N
+ * flag per base over PCIe instead of a byte per base): d_in_packed [n][W] codes A0 C1 G2 T3 with 0 at an N, d_in_nmask [n][ceil(L/64)].
+ * Same outputs; d_packed / d_nmask may be the input arrays themselves (d_nmask NULL: the masks are not kept).                        */
+int mcom_process_reads_packed(mcom_ctx *ctx, const uint64_t *d_in_packed, const uint64_t *d_in_nmask, size_t n, int L, int k, int e,
+                              uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt, uint64_t *d_nmask, mcom_mm128 *d_rec);
+
 /* Batched mm_sketch_two (sketch.c:238-289) on packed rows.  d_rids (optional): sketch rows
  * d_rids[i] of d_packed and stamp that rid (the re-sketch of rejected reads with k-1, k-2, ...,
  * kthread_bucket.c:205, :489); NULL: rows rid0+i... i.e. row i with rid rid0+i.                 */

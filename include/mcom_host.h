@@ -66,6 +66,13 @@ int  mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_stream, con
 /* Optional, between mcomh_create_packed and mcomh_kt_for_reads: the minimizers of the packed rows are known (sketched
  * with the pipeline's k by the rank that sent them); d_x [n] hashes, d_ylow [n] position<<1 | strand.  kt_for_reads then
  * assembles the records instead of sketching the rows again.  The arrays must stay valid until kt_for_reads returns. */
+/* File(s) -> pipeline (round 4; replaces bseq_open / bseq_read / bseq_read_second, bseq.c:19-66, preprocess.c:52-75).  A plain
+ * four-line FASTQ file is parsed by up to 64 threads, packed by them (2 bits per base + one N flag per base: 64 bytes per read over
+ * PCIe at L = 150 instead of 150) and sent straight into the pipeline's row arrays; classes, N counts and the majority-base
+ * substitution are made on the device.  gzip, FASTA and multi-line records go through the sequential reader.  path2 (may be NULL):
+ * the mates' file, whose reads follow those of the first.  err [err_cap]: the message of a failure.                              */
+int  mcomh_create_from_fastq(mcomh_pipeline **out, int device, void *hip_stream, const char *path1, const char *path2, const mcomh_params *pp,
+                             char *err, size_t err_cap);
 int  mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow);
 void mcomh_destroy(mcomh_pipeline *p);
 /* Device blocks of destroyed pipelines are kept for the next one of the process (a steady-state step allocates nothing); this gives

@@ -233,6 +233,55 @@ __device__ __forceinline__ uint64_t stream64(const uint32_t *w, uint32_t bit)
 	const uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
 	return sh ? (lo >> sh) | ((uint64_t)w[i + 2] << (64 - sh)) : lo;
 }
+// one read as W words of codes and NW words of N flags: counts, class, N positions filled with the majority base, written
+// (kthread_reads.c:55-224) -- the second phase of k_classify_flat, and all of k_classify_packed
+template <int W>
+__device__ __forceinline__ void cf_classify_words(const uint64_t (&cw)[W], const uint64_t (&nw)[(W + 1) / 2], int L, int e, size_t r, uint64_t *packed,
+                                                  uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt, uint64_t *nmask)
+{
+	constexpr int NW = (W + 1) / 2;
+	int nA = 0, nC = 0, nG = 0, nT = 0, nN = 0;
+	uint64_t okm[W];
+#pragma unroll
+	for (int w = 0; w < W; ++w) {
+		const int left = 2 * L - 64 * w;                              // code bits of this word
+		const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
+		const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1)));
+		okm[w] = ~nsp & 0x5555555555555555ull & valid;
+		const uint64_t lo = cw[w] & 0x5555555555555555ull, hi = (cw[w] >> 1) & 0x5555555555555555ull;
+		nA += __popcll(~lo & ~hi & okm[w]); nC += __popcll(lo & ~hi & okm[w]); nG += __popcll(~lo & hi & okm[w]); nT += __popcll(lo & hi & okm[w]);
+	}
+#pragma unroll
+	for (int w = 0; w < NW; ++w) nN += __popcll(nw[w]);
+	int c;                                                           // kthread_reads.c:84-224
+	if (nA == L) c = MCOM_CLS_ALLA;
+	else if (nT == L) c = MCOM_CLS_ALLT;
+	else if (nN == L) c = MCOM_CLS_ALLN;
+	else if (nT + nG + nC + nN <= e) c = MCOM_CLS_NEARA;
+	else if (nA + nG + nC + nN <= e) c = MCOM_CLS_NEART;
+	else if (nA + nT + nG + nC <= e) c = MCOM_CLS_NEARN;
+	else if (!((double)nN <= 0.4 * (double)L)) c = MCOM_CLS_NHEAVY;
+	else c = MCOM_CLS_SKETCH;
+	uint32_t rep = 0;                                                // majority base, ties A,T,G,C (:185-201)
+	if (c == MCOM_CLS_SKETCH && nN > 0) {
+		int mx = nA; if (nT > mx) mx = nT; if (nG > mx) mx = nG; if (nC > mx) mx = nC;
+		rep = (mx == nA) ? 0u : (mx == nT) ? 3u : (mx == nG) ? 2u : 1u;
+	}
+#pragma unroll
+	for (int w = 0; w < W; ++w) {
+		const int left = 2 * L - 64 * w;
+		const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
+		const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1))) & valid;
+		const uint64_t keep = okm[w] | (okm[w] << 1);
+		const uint64_t fill = ((rep & 1) ? nsp : 0ull) | ((rep & 2) ? (nsp << 1) : 0ull);
+		packed[r * (size_t)W + w] = (cw[w] & keep) | fill;
+	}
+	if (nmask) {
+#pragma unroll
+		for (int w = 0; w < NW; ++w) nmask[r * (size_t)NW + w] = nw[w];
+	}
+	cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN;
+}
 template <int W>
 __global__ __launch_bounds__(256) void k_classify_flat(const uint8_t *__restrict__ ascii, size_t n, int L, int e, uint64_t *__restrict__ packed,
                                                        uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt, uint64_t *__restrict__ nmask)
@@ -273,50 +322,32 @@ __global__ __launch_bounds__(256) void k_classify_flat(const uint8_t *__restrict
 				const int left = L - 64 * w;
 				if (left < 64) nw[w] &= left > 0 ? ((1ull << left) - 1) : 0ull;
 			}
-			int nA = 0, nC = 0, nG = 0, nT = 0, nN = 0;
-			uint64_t okm[W];
-#pragma unroll
-			for (int w = 0; w < W; ++w) {
-				const int left = 2 * L - 64 * w;                              // code bits of this word
-				const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
-				const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1)));
-				okm[w] = ~nsp & 0x5555555555555555ull & valid;
-				const uint64_t lo = cw[w] & 0x5555555555555555ull, hi = (cw[w] >> 1) & 0x5555555555555555ull;
-				nA += __popcll(~lo & ~hi & okm[w]); nC += __popcll(lo & ~hi & okm[w]); nG += __popcll(~lo & hi & okm[w]); nT += __popcll(lo & hi & okm[w]);
-			}
-#pragma unroll
-			for (int w = 0; w < NW; ++w) nN += __popcll(nw[w]);
-			int c;                                                           // kthread_reads.c:84-224
-			if (nA == L) c = MCOM_CLS_ALLA;
-			else if (nT == L) c = MCOM_CLS_ALLT;
-			else if (nN == L) c = MCOM_CLS_ALLN;
-			else if (nT + nG + nC + nN <= e) c = MCOM_CLS_NEARA;
-			else if (nA + nG + nC + nN <= e) c = MCOM_CLS_NEART;
-			else if (nA + nT + nG + nC <= e) c = MCOM_CLS_NEARN;
-			else if (!((double)nN <= 0.4 * (double)L)) c = MCOM_CLS_NHEAVY;
-			else c = MCOM_CLS_SKETCH;
-			uint32_t rep = 0;                                                // majority base, ties A,T,G,C (:185-201)
-			if (c == MCOM_CLS_SKETCH && nN > 0) {
-				int mx = nA; if (nT > mx) mx = nT; if (nG > mx) mx = nG; if (nC > mx) mx = nC;
-				rep = (mx == nA) ? 0u : (mx == nT) ? 3u : (mx == nG) ? 2u : 1u;
-			}
-#pragma unroll
-			for (int w = 0; w < W; ++w) {
-				const int left = 2 * L - 64 * w;
-				const uint64_t valid = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1 : 0ull);
-				const uint64_t nsp = spread32_64(nw[w >> 1] >> (32 * (w & 1))) & valid;
-				const uint64_t keep = okm[w] | (okm[w] << 1);
-				const uint64_t fill = ((rep & 1) ? nsp : 0ull) | ((rep & 2) ? (nsp << 1) : 0ull);
-				packed[r * (size_t)W + w] = (cw[w] & keep) | fill;
-			}
-			if (nmask) {
-#pragma unroll
-				for (int w = 0; w < NW; ++w) nmask[r * (size_t)NW + w] = nw[w];
-			}
-			cls[r] = (uint8_t)c; ncnt[r] = (uint16_t)nN;
+			cf_classify_words<W>(cw, nw, L, e, r, packed, cls, ncnt, nmask);
 		}
 		__builtin_amdgcn_wave_barrier();                                     // the next chunk's phase A overwrites the streams
 	}
+}
+
+// The same for reads that arrive PACKED: W words of 2-bit codes (an N holds code 0) and NW words of N flags per read, as a parser that
+// packs on the host sends them (round 4: 64 bytes per read over PCIe instead of 150).  One read per lane; in and out may be the same arrays.
+template <int W>
+__global__ __launch_bounds__(256) void k_classify_packed(const uint64_t *in_packed, const uint64_t *in_nmask, size_t n, int L, int e, uint64_t *packed,
+                                                         uint8_t *__restrict__ cls, uint16_t *__restrict__ ncnt, uint64_t *nmask)
+{
+	constexpr int NW = (W + 1) / 2;
+	const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const int nwr = (L + 63) / 64;                                               // words of flags a read really has
+	uint64_t cw[W], nw[NW];
+#pragma unroll
+	for (int w = 0; w < W; ++w) cw[w] = in_packed[r * (size_t)W + w];
+#pragma unroll
+	for (int w = 0; w < NW; ++w) {
+		nw[w] = w < nwr ? in_nmask[r * (size_t)nwr + w] : 0ull;
+		const int left = L - 64 * w;
+		if (left < 64) nw[w] &= left > 0 ? ((1ull << left) - 1) : 0ull;
+	}
+	cf_classify_words<W>(cw, nw, L, e, r, packed, cls, ncnt, nmask);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,6 +552,33 @@ extern "C" int mcom_hash64_batch(mcom_ctx *ctx, const uint64_t *d_kmer, size_t n
 	if (n == 0) return MCOM_OK;
 	if (!d_kmer || !d_hash) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	MCOM_LAUNCH(k_hash64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_kmer, n, k, d_hash);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
+// kt_for_reads for reads that were packed by the caller (a FASTQ parser that packs on the host: 2 bits per base + one N flag per base
+// cross PCIe instead of a byte per base).  d_in_packed [n][W]: codes A0 C1 G2 T3, an N holds 0; d_in_nmask [n][ceil(L/64)]: bit i = base
+// i is an N.  Outputs as mcom_process_reads; d_packed / d_nmask may be the input arrays themselves.
+extern "C" int mcom_process_reads_packed(mcom_ctx *ctx, const uint64_t *d_in_packed, const uint64_t *d_in_nmask, size_t n, int L, int k, int e,
+                                         uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt, uint64_t *d_nmask, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range 1..256", L);
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
+	if (n == 0) return MCOM_OK;
+	if (!d_in_packed || !d_in_nmask || !d_packed || !d_cls || !d_ncnt || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const int W = mcom_words_per_read(L);
+	const unsigned blocks = (unsigned)((n + 255) / 256);
+	{
+		McomProfScope ps_(ctx, PROF_CLASSIFY_PACK);
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_classify_packed<WW>), dim3(blocks), dim3(256), 0, ctx->stream, d_in_packed, d_in_nmask, n, L, e, d_packed, d_cls, d_ncnt, d_nmask); break;
+		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8) default: return mcom_fail(ctx, MCOM_E_ARG, "read length %d not supported", L); }
+#undef MCOM_CASE
+	}
+	MCOM_LAUNCH_CHECK(ctx);
+	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
+	if (rc) return rc;
+	MCOM_LAUNCH(k_mask_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_rec);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

@@ -63,6 +63,8 @@ def load_library():
     L.mcom_prof_kernels.restype = i32; L.mcom_prof_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
     L.mcom_process_reads.restype = i32
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
+    L.mcom_process_reads_packed.restype = i32
+    L.mcom_process_reads_packed.argtypes = [vp, vp, vp, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32
     L.mcom_sketch_reads.argtypes = [vp, vp, vp, sz, i32, i32, u32, vp]
     L.mcom_hash64_batch.restype = i32; L.mcom_hash64_batch.argtypes = [vp, vp, sz, i32, vp]
@@ -200,6 +202,19 @@ class Context:
         rec = self.empty_records(n)
         self._check(self.lib.mcom_process_reads(self._h, self._p(ascii_, torch.uint8), pitch, n, L, k, e, rid0,
                                                 self._p(packed), self._p(cls), self._p(ncnt), self._p(nmask), self._p(rec)))
+        return {"packed": packed, "cls": cls, "ncnt": ncnt, "nmask": nmask, "rec": rec}
+
+    def process_reads_packed(self, in_packed, in_nmask, L: int, k: int, e: int = 4, rid0: int = 0, in_place: bool = False):
+        """mcom_process_reads_packed: reads as a packing parser sends them (int64 [n, W] codes with 0 at an N, int64 [n, ceil(L/64)] N flags)."""
+        torch = _torch()
+        n = int(in_packed.shape[0])
+        packed = in_packed if in_place else torch.empty_like(in_packed)
+        nmask = in_nmask if in_place else torch.empty_like(in_nmask)
+        cls = torch.empty(n, dtype=torch.uint8, device=self.device)
+        ncnt = torch.empty(n, dtype=torch.int16, device=self.device)
+        rec = self.empty_records(n)
+        self._check(self.lib.mcom_process_reads_packed(self._h, self._p(in_packed, torch.int64), self._p(in_nmask, torch.int64), n, L, k, e, rid0,
+                                                       self._p(packed), self._p(cls), self._p(ncnt), self._p(nmask), self._p(rec)))
         return {"packed": packed, "cls": cls, "ncnt": ncnt, "nmask": nmask, "rec": rec}
 
     def sketch_reads(self, packed, L: int, k: int, rids=None, rid0: int = 0, out=None):

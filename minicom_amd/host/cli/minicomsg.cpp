@@ -7,13 +7,12 @@ int main(int argc, char **argv)
 {
 	CliOptions o;
 	if (argc < 3 || !cli_parse(argc, argv, 3, o)) { fprintf(stderr, "usage: minicomsg IN.fastq OUTDIR [-k K -e E -m M -w W -s S -S STEP -E MAXTHR -g CBTHR -R ROUNDS -t THREADS -p -D GPU]\n"); return 1; }
-	int L = 0; size_t n = 0; uint8_t *d_reads = nullptr; char err[256] = "";
-	int rc = mcomh_fastq_to_device(argv[1], o.device, &L, 0, &d_reads, &n, err, sizeof err);
-	if (rc) { fprintf(stderr, "%s: %s\n", argv[1], err[0] ? err : "cannot read"); return 1; }
+	char err[256] = "";
 	mcomh_pipeline *mp = nullptr;
-	if ((rc = mcomh_create(&mp, o.device, nullptr, nullptr, d_reads, (size_t)L, n, L, &o.prm))) { fprintf(stderr, "mcomh_create failed (%d): no usable GPU or bad parameters\n", rc); return 1; }
+	int rc = mcomh_create_from_fastq(&mp, o.device, nullptr, argv[1], nullptr, &o.prm, err, sizeof err);
+	if (rc) { fprintf(stderr, "%s: %s\n", argv[1], err[0] ? err : "cannot read the file, no usable GPU or bad parameters"); return 1; }
+	const size_t n = (size_t)mcomh_stat(mp, "n"); const int L = (int)mcomh_stat(mp, "L");
 	if ((rc = cli_run(mp, n, L)) || (rc = o.order ? mcomh_cluster_dump_order(mp, argv[2]) : mcomh_cluster_dump(mp, argv[2]))) { fprintf(stderr, "%s\n", mcomh_last_error(mp)); return 1; }
 	mcomh_destroy(mp);
-	mcomh_device_free(d_reads);
 	return 0;
 }

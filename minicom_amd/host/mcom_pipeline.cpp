@@ -8,6 +8,7 @@
 // back to back + offsets), so no stage allocates per contig.  Citations are file:line into yuansliu/minicom src/.
 #include "../../include/mcom.h"
 #include "../../include/mcom_host.h"
+#include "mcom_fastq.hpp"
 #include <hip/hip_runtime_api.h>
 #include <algorithm>
 #include <atomic>
@@ -239,6 +240,8 @@ struct mcomh_pipeline {
 	DevBuf<uint8_t> d_ascii_own; const uint8_t *d_ascii = nullptr; size_t pitch = 0;
 	const uint8_t *stream_host = nullptr;    // reads in caller-owned host memory, uploaded chunk by chunk (mcomh_create_streamed)
 	const uint64_t *ext_packed = nullptr;    // packed-row input (mcomh_create_packed): no classification stage
+	uint8_t *d_ascii_adopted = nullptr;                                // a character matrix made by mcomh_create_from_fastq: freed with the pipeline
+	bool packed_in_place = false;                                      // d_packed / d_nmask hold the reads as a packing parser sent them (codes + N flags): kt_for_reads classifies them in place
 	const uint64_t *ext_x = nullptr; const uint32_t *ext_ylow = nullptr;   // ... whose minimizers came along (mcomh_set_records)
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
@@ -478,6 +481,79 @@ extern "C" int mcomh_create_packed(mcomh_pipeline **out, int device, void *hip_s
 	return MCOM_OK;
 }
 
+// File(s) -> pipeline (round 4).  A plain four-line FASTQ file is parsed by all cores at once, PACKED by the parser threads and sent
+// straight into the pipeline's own row arrays: 2 bits per base + one N flag per base over PCIe (64 bytes per read at L = 150 instead
+// of 150), no character matrix in HBM at all; classes, N counts and the majority-base substitution are made on the device
+// (mcom_process_reads_packed).  Anything else (gzip, FASTA, sequences over several lines) goes through the sequential reader and the
+// character matrix as before.  path2: the mates' file (bseq_read_second, preprocess.c:52-75: read n/2 + i is the mate of read i).
+extern "C" int mcomh_create_from_fastq(mcomh_pipeline **out, int device, void *hip_stream, const char *path1, const char *path2, const mcomh_params *pp,
+                                       char *err, size_t err_cap)
+{
+	auto fail = [&](int code, const char *msg) { if (err && err_cap) snprintf(err, err_cap, "%s", msg); return code; };
+	if (!out || !path1) return MCOM_E_ARG;
+	*out = nullptr;
+	if (hipSetDevice(device) != hipSuccess) return fail(MCOM_E_HIP, "no usable GPU");
+	{
+		int L = 0;
+		const double t_ix = now_ms();
+		const size_t cap1 = mcom_fastq_stream_cap(path1, &L), cap2 = path2 && cap1 ? mcom_fastq_stream_cap(path2, &L) : 0;
+		if (cap1 && (!path2 || cap2)) {
+			static const uint8_t dummy = 0;
+			int rc = mcomh_create(out, device, hip_stream, nullptr, &dummy, (size_t)L, 0, L, pp);    // parameter resolution; the number of reads follows
+			if (rc) return fail(rc, "cannot create the pipeline");
+			P *p = *out;
+			p->d_ascii = nullptr;
+			auto giveup = [&](int code, const char *msg) { mcomh_destroy(p); *out = nullptr; return fail(code, msg); };
+			DevBuf<uint64_t> tp, tn;                                                 // the rows at their provisional places
+			const size_t cap = cap1 + cap2;
+			if (!tp.reserve(cap * p->W + 1) || !tn.reserve(cap * p->NW + 1)) return giveup(MCOM_E_NOMEM, "read buffers");
+			McomFastqStream *s1 = nullptr, *s2 = nullptr;
+			struct Drop { McomFastqStream *&a, *&b; ~Drop() { mcom_fastq_stream_free(a); mcom_fastq_stream_free(b); } } drop{s1, s2};
+			int st = mcom_fastq_stream_packed(path1, L, device, p->copy_stream, tp.p, tn.p, cap1, &s1);
+			if (st == 1 && path2) st = mcom_fastq_stream_packed(path2, L, device, p->copy_stream, tp.p + cap1 * p->W, tn.p + cap1 * p->NW, cap2, &s2);
+			if (st < 0) return giveup(st, st == MCOM_E_NOMEM ? "out of memory" : "upload failed");
+			if (st == 1) {
+				const size_t n1 = mcom_fastq_stream_total(s1), n2 = path2 ? mcom_fastq_stream_total(s2) : 0;
+				if (path2 && n1 != n2) { if (err && err_cap) snprintf(err, err_cap, "the two files hold %zu and %zu reads", n1, n2); mcomh_destroy(p); *out = nullptr; return MCOM_E_ARG; }
+				const size_t n = n1 + n2;
+				const double t_up = now_ms();
+				p->n = n;
+				if (!p->d_packed.reserve(n * p->W + 1) || !p->d_nmask.reserve(n * p->NW + 1)) return giveup(MCOM_E_NOMEM, "read buffers");
+				// the gaps between the pieces close: one device-to-device copy per piece and array
+				size_t row = 0;
+				bool ok = true;
+				for (int f = 0; f < (path2 ? 2 : 1) && ok; ++f) {
+					const McomFastqStream *s = f ? s2 : s1;
+					const size_t np = mcom_fastq_stream_pieces(s, nullptr, nullptr), base = f ? cap1 : 0;
+					std::vector<size_t> prov(np), cnt(np);
+					(void)mcom_fastq_stream_pieces(s, prov.data(), cnt.data());
+					for (size_t q = 0; q < np && ok; ++q) {
+						if (!cnt[q]) continue;
+						ok = hipMemcpyAsync(p->d_packed.p + row * p->W, tp.p + (base + prov[q]) * p->W, cnt[q] * (size_t)p->W * 8, hipMemcpyDeviceToDevice, p->stream) == hipSuccess &&
+						     hipMemcpyAsync(p->d_nmask.p + row * p->NW, tn.p + (base + prov[q]) * p->NW, cnt[q] * (size_t)p->NW * 8, hipMemcpyDeviceToDevice, p->stream) == hipSuccess;
+						row += cnt[q];
+					}
+				}
+				if (ok) ok = hipStreamSynchronize(p->stream) == hipSuccess;           // (the provisional arrays go back to the pool below)
+				if (!ok || row != n) return giveup(MCOM_E_HIP, "upload failed");
+				p->packed_in_place = true;
+				extern double g_fastq_ms[3];
+				p->stat["t_fastq_index"] = 0; p->stat["t_fastq_upload"] = t_up - t_ix; p->stat["t_fastq_close_gaps"] = now_ms() - t_up;
+				p->stat["t_fastq_setup_max"] = g_fastq_ms[0]; p->stat["t_fastq_pack_max"] = g_fastq_ms[1]; p->stat["t_fastq_wait_max"] = g_fastq_ms[2];
+				return MCOM_OK;
+			}
+			mcomh_destroy(p); *out = nullptr;                                        // not this layout after all, or a character outside ACGTN: the sequential reader words the message
+		}
+	}
+	uint8_t *d = nullptr; size_t n = 0; int L = 0;
+	int rc = path2 ? mcomh_fastq_pair_to_device(path1, path2, device, &L, 0, &d, &n, err, err_cap) : mcomh_fastq_to_device(path1, device, &L, 0, &d, &n, err, err_cap);
+	if (rc) return rc;
+	rc = mcomh_create(out, device, hip_stream, nullptr, d, (size_t)L, n, L, pp);
+	if (rc) { mcomh_device_free(d); return fail(rc, "cannot create the pipeline"); }
+	(*out)->d_ascii_adopted = d;                                                  // released with the pipeline
+	return MCOM_OK;
+}
+
 extern "C" int mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow)
 {
 	if (!p) return MCOM_E_ARG;
@@ -492,6 +568,7 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	if (!p) return;
 	p->join_sg();
 	(void)hipStreamSynchronize(p->stream);
+	if (p->d_ascii_adopted) { (void)hipFree(p->d_ascii_adopted); p->d_ascii_adopted = nullptr; }
 	if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
 	if (p->ev_main) (void)hipEventDestroy(p->ev_main);
 	if (p->ev_sg) (void)hipEventDestroy(p->ev_sg);
@@ -517,11 +594,14 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 	const bool dist = p->comm != nullptr;
 	const size_t nl = dist ? p->n_local : n;                            // ... and those this rank classifies and sketches
 	const uint64_t r0 = dist ? p->rid0 : 0;
-	if (dist && p->ext_packed) return p->fail(MCOM_E_ARG, "packed-row input is a single-GPU entry");
+	if (dist && (p->ext_packed || p->packed_in_place)) return p->fail(MCOM_E_ARG, "packed-row input is a single-GPU entry");
 	if (!p->d_packed.reserve(n * p->W + 1) || !p->d_nmask.reserve(n * p->NW + 1) || !p->d_cls.reserve(n + 1) ||
 	    !p->d_ncnt.reserve(nl + 1) || !p->d_rec.reserve(nl + 1)) return p->fail(MCOM_E_NOMEM, "read buffers");
 	int rc;
-	if (p->ext_packed) {
+	if (p->packed_in_place) {
+		// the parser packed on the host (mcomh_create_from_fastq): codes and N flags are in place, the device does what is left of process_reads
+		rc = p->gpu(mcom_process_reads_packed(p->ctx, p->d_packed.p, p->d_nmask.p, n, p->L, p->k, p->e, 0, p->d_packed.p, p->d_cls.p, p->d_ncnt.p, p->d_nmask.p, p->d_rec.p));
+	} else if (p->ext_packed) {
 		// packed rows handed over by the caller: every read is a kept read (class 0) without N
 		if (n && ((rc = p->hipc(hipMemcpyAsync(p->d_packed.p, p->ext_packed, n * (size_t)p->W * 8, hipMemcpyDeviceToDevice, p->stream), "copy packed rows")) ||
 		          (rc = p->hipc(hipMemsetAsync(p->d_cls.p, 0, n, p->stream), "clear")) ||
@@ -1986,6 +2066,8 @@ extern "C" double mcomh_stat(const mcomh_pipeline *p, const char *name)
 {
 	if (!p) return 0;
 	if (!strcmp(name, "k")) return p->k;
+	if (!strcmp(name, "n")) return (double)p->n;
+	if (!strcmp(name, "L")) return p->L;
 	if (!strcmp(name, "e")) return p->e;
 	if (!strcmp(name, "step")) return p->step;
 	if (!strcmp(name, "maxthr")) return p->maxthr;

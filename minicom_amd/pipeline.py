@@ -66,6 +66,7 @@ def load_host_library():
     L.mcomh_prof_enable.restype = i32; L.mcomh_prof_enable.argtypes = [vp, i32]
     L.mcomh_prof_read.restype = i32; L.mcomh_prof_read.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.mcomh_prof_kernels.restype = i32; L.mcomh_prof_kernels.argtypes = [vp, cp, C.c_char_p, sz, C.POINTER(sz)]
+    L.mcomh_create_from_fastq.restype = i32; L.mcomh_create_from_fastq.argtypes = [C.POINTER(vp), i32, vp, cp, cp, C.POINTER(Params), C.c_char_p, sz]
     L.mcomh_fastq_read.restype = i32; L.mcomh_fastq_read.argtypes = [cp, C.POINTER(i32), vp, sz, C.POINTER(sz)]
     L.mcomh_fastq_to_device.restype = i32
     L.mcomh_fastq_to_device.argtypes = [cp, i32, C.POINTER(i32), sz, C.POINTER(vp), C.POINTER(sz), C.c_char_p, sz]
@@ -74,7 +75,7 @@ def load_host_library():
     return L
 
 
-HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packed", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
+HOST_ABI_SYMBOLS = ["mcomh_create", "mcomh_create_streamed", "mcomh_create_packed", "mcomh_create_from_fastq", "mcomh_set_records", "mcomh_destroy", "mcomh_last_error", "mcomh_kt_for_reads", "mcomh_kt_for_bucket",
                     "mcomh_combine_cluster", "mcomh_update_single", "mcomh_realign_hash", "mcomh_stage2", "mcomh_pre_process",
                     "mcomh_dump_stages", "mcomh_cluster_dump", "mcomh_decompress", "mcomh_n_contigs", "mcomh_contig_ref", "mcomh_contig_n", "mcomh_contig_members",
                     "mcomh_list", "mcomh_stat", "mcomh_prof_enable", "mcomh_prof_read", "mcomh_prof_kernels", "mcomh_fastq_read", "mcomh_fastq_to_device",
@@ -188,24 +189,19 @@ class Pipeline:
         """FASTQ/FASTA (plain or .gz) -> HBM through two pinned chunks (mcomh_fastq_to_device) -> pipeline.
         path2: the mates' file (paired end): its reads follow those of the first file."""
         lib = load_host_library()
-        Lc, n, d = C.c_int(L), C.c_size_t(), C.c_void_p()
         err = C.create_string_buffer(256)
-        if path2 is None:
-            rc = lib.mcomh_fastq_to_device(path.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
-        else:
-            rc = lib.mcomh_fastq_pair_to_device(path.encode(), path2.encode(), device, C.byref(Lc), chunk_reads, C.byref(d), C.byref(n), err, 256)
-        if rc:
-            raise McomError(f"{path}: {err.value.decode() or rc}")
         self = cls.__new__(cls)
         self.lib = lib
         p = Params(**{k: int(v) for k, v in params.items()})
         h = C.c_void_p()
-        rc = lib.mcomh_create(C.byref(h), device, C.c_void_p(0), None, d, Lc.value, n.value, Lc.value, C.byref(p))
+        rc = lib.mcomh_create_from_fastq(C.byref(h), device, C.c_void_p(0), path.encode(), path2.encode() if path2 else None, C.byref(p), err, 256)
         if rc:
-            lib.mcomh_device_free(d)
-            raise McomError(f"mcomh_create failed ({rc})")
-        self._h, self._dev_reads, self._keep = h, d, None
-        self.n, self.L = n.value, Lc.value
+            raise McomError(f"{path}: {err.value.decode() or rc}")
+        self._h, self._dev_reads, self._keep = h, None, None
+        self.n, self.L = int(lib.mcomh_stat(h, b"n")), int(lib.mcomh_stat(h, b"L"))
+        if L and L != self.L:
+            self.close()
+            raise McomError(f"{path}: reads of {self.L} bases, {L} expected")
         return self
 
     def _check(self, rc):

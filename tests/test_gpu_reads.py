@@ -156,3 +156,33 @@ def test_full_size_property_sketch_is_permutation_invariant(ctx):
     assert torch.equal(r1[:, 1], rec2[:, 1])
     x = records_to_numpy(out["rec"][:1000])
     assert np.all(x["x"] < (1 << 62))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [37, 64, 100, 150, 200, 256])
+def test_reads_packed_on_the_host_give_what_the_character_matrix_gives(L):
+    """Round 4: the FASTQ parser packs on the host (2 bits per base, an N as code 0 plus a flag) and mcom_process_reads_packed does what
+    is left of process_reads (kthread_reads.c:55-224) on the device: classes, N counts, majority-base substitution, records -- all equal
+    to mcom_process_reads on the characters; in place as well."""
+    import torch
+    import minicom_amd
+    from minicom_amd import synth
+    reads = np.concatenate([synth.synth_reads(77 + L, 20000, L), synth.synth_reads(78 + L, 20000, L, plumbing=True)])
+    n = reads.shape[0]
+    code = np.zeros(256, dtype=np.uint64); code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
+    W, NW = (2 * L + 63) // 64, (L + 63) // 64
+    packed = np.zeros((n, W), dtype=np.uint64); nmask = np.zeros((n, NW), dtype=np.uint64)
+    c = code[reads]; isn = (reads == ord("N")).astype(np.uint64)
+    for i in range(L):
+        packed[:, i // 32] |= c[:, i] << np.uint64(2 * (i % 32))
+        nmask[:, i // 64] |= isn[:, i] << np.uint64(i % 64)
+    ctx = minicom_amd.Context(0)
+    k = 31 if L >= 80 else 17
+    want = ctx.process_reads(torch.from_numpy(reads).cuda(), L, k, want_nmask=True)
+    dp, dn = torch.from_numpy(packed.view(np.int64)).cuda(), torch.from_numpy(nmask.view(np.int64)).cuda()
+    for in_place in (False, True):
+        got = ctx.process_reads_packed(dp.clone(), dn.clone(), L, k, in_place=in_place)
+        ctx.sync()
+        for name in ("packed", "cls", "ncnt", "nmask"):
+            assert torch.equal(got[name], want[name]), (name, in_place)
+        assert torch.equal(got["rec"], want["rec"]), in_place

@@ -20,7 +20,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repo root
 
 
-def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads: int = 1_000_000, workdir: str | None = None, keep: bool = False):
+def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads: int = 1_000_000, workdir: str | None = None, keep: bool = False, mode: str = "default"):
+    """mode: "default" (multiset of reads), "order" (minicom -p), "paired" (minicompe: the first n / 2 reads are file 1, the others their
+    mates in file 2)"""
     import numpy as np
     import torch
     import minicom_amd
@@ -30,36 +32,40 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
     try:
         ctx = minicom_amd.Context(0)
         fq = os.path.join(td, "reads.fastq")
+        fq2 = os.path.join(td, "reads_2.fastq") if mode == "paired" else None
+        if mode == "paired":
+            n -= n & 1
         t = time.perf_counter()
         # the file is written in blocks of 4 M reads generated on the device (the generator of the benchmark)
-        with open(fq, "wb"):
-            pass
         block = 4_000_000
-        tmp = os.path.join(td, "part.fastq")
-        with open(fq, "ab") as out:
-            for lo in range(0, n, block):
-                cnt = min(block, n - lo)
-                part = ctx.synth_reads(seed, n, L, first=lo, count=cnt).cpu().numpy()
-                _append_fastq(out, part, lo)
-                del part
+        for path, a, b in ((fq, 0, n // 2 if fq2 else n), (fq2, n // 2, n)):
+            if path is None:
+                continue
+            with open(path, "wb") as out:
+                for lo in range(a, b, block):
+                    cnt = min(block, b - lo)
+                    part = ctx.synth_reads(seed, n, L, first=lo, count=cnt).cpu().numpy()
+                    _append_fastq(out, part, lo - a)
+                    del part
         ctx.close()
         t_write_input = time.perf_counter() - t
-        size = os.path.getsize(fq)
+        size = os.path.getsize(fq) + (os.path.getsize(fq2) if fq2 else 0)
         out_dir = os.path.join(td, "streams"); os.makedirs(out_dir)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        p = Pipeline.from_fastq(fq, host_threads=host_threads)
+        p = Pipeline.from_fastq(fq, path2=fq2, host_threads=host_threads)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         p.pre_process()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        p.cluster_dump(out_dir)
+        p.cluster_dump(out_dir, order=mode == "order", paired=mode == "paired")
         t3 = time.perf_counter()
         assert p.n == n and p.L == L
         stream_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
-        res = {"reads": n, "read_len": L, "fastq_bytes": size, "stream_bytes": stream_bytes,
-               "seconds": {"parse_and_upload": round(t1 - t0, 3), "hot_path": round(t2 - t1, 3), "encode_copy_write": round(t3 - t2, 3),
+        res = {"mode": mode, "reads": n, "read_len": L, "fastq_bytes": size, "stream_bytes": stream_bytes,
+               "seconds": {"parse_and_upload": round(t1 - t0, 3), "of_which_read_pack_upload": round(p.stat("t_fastq_upload") / 1e3, 3), "of_which_closing_the_gaps": round(p.stat("t_fastq_close_gaps") / 1e3, 3),
+                           "pass_2_slowest_thread": {"setup": round(p.stat("t_fastq_setup_max") / 1e3, 3), "pack": round(p.stat("t_fastq_pack_max") / 1e3, 3), "wait_for_copies": round(p.stat("t_fastq_wait_max") / 1e3, 3)}, "hot_path": round(t2 - t1, 3), "encode_copy_write": round(t3 - t2, 3),
                            "of_which_device_encode_and_copy": round(p.stat("t_dump_gpu") / 1e3, 3), "of_which_file_writes": round(p.stat("t_dump_write") / 1e3, 3),
                            "total": round(t3 - t0, 3)},
                "value": round(n / (t3 - t0) / 1e6, 3), "unit": "Mreads/s",
@@ -67,7 +73,7 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
                "note": "FASTQ file (page cache) -> parse -> HBM -> Stage 1 + Stage 2 -> stream files written; the entropy coder (bsc / 7z / xz, external) is not part of it",
                "input_written_in_s": round(t_write_input, 1)}
         p.close()
-        res["reference"] = _reference_on_prefix(fq, td, n, L, ref_reads)
+        res["reference"] = _reference_on_prefix(fq, td, n, L, ref_reads) if mode == "default" and ref_reads else None
         return res
     finally:
         if not keep:
@@ -75,11 +81,19 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
 
 
 def host_cores() -> int:
-    """cores this process may run on (the GPU box gives a job a share of the host)"""
+    """CPUs this process may really use: the affinity mask cut by the cgroup's CPU quota (the GPU box gives a job a share of the host:
+    256 cores visible, cpu.max = 16 CPUs)"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:                                                           # noqa: BLE001
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:                                                           # noqa: BLE001
+        pass
+    return n
 
 
 def reference_binaries(L: int):
