@@ -231,9 +231,17 @@ def main():
         """K timed steps of one job of n_total reads; returns (seconds, aggregate stats, digests, reads, make)."""
         n_local = n_total // world
         n_total = n_local * world
-        # synthetic input, resident in HBM before any timed region: this rank's shard of one n_total-read set
-        reads = ctx.synth_reads(seed, n_total, L, first=rank * n_local, count=n_local, genome=a.genome)
-        ctx.sync()
+        # synthetic input, resident in HBM before any timed region: this rank's shard of one n_total-read set.  (The ranks agree that
+        # everybody holds its shard before anybody enters the pipeline: from there on a failing rank takes the others with it -- the
+        # library's failure protocol -- but an allocation that fails HERE on one rank would leave the others waiting in an exchange.)
+        reads, alloc_err = None, None
+        try:
+            reads = ctx.synth_reads(seed, n_total, L, first=rank * n_local, count=n_local, genome=a.genome)
+            ctx.sync()
+        except (McomError, RuntimeError) as e:
+            alloc_err = e
+        if not agree(alloc_err is None):
+            raise alloc_err if alloc_err is not None else McomError("another rank could not allocate its shard of the reads")
 
         def make():
             if not distributed:

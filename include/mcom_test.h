@@ -25,6 +25,17 @@ int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
 int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
 int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
 
+
+/* ---- libmcom_host.so ---- */
+struct mcomh_pipeline;
+/* Multi-GPU failure protocol (minicom_amd/host/mcom_pipeline.cpp, "Failure protocol"): rank-local errors travel with a flag exchange in
+ * front of every collective so that no rank is left waiting for one that has returned.  mcomh_test_inject_failure makes this rank fail
+ * right before its k-th flag exchange (k = 1 ...), as if the local work in front of it had failed; mcomh_test_flag_exchanges says how
+ * many a finished run made.  tests/test_gpu_distributed.py lets one rank of three fail at points spread over every stage: all three must
+ * return an error, none may hang.                                                                                                   */
+int  mcomh_test_inject_failure(struct mcomh_pipeline *p, long k);
+long mcomh_test_flag_exchanges(const struct mcomh_pipeline *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -305,6 +305,8 @@ struct mcomh_pipeline {
 	std::vector<uint64_t> shard_lo;                                        // [world + 1] first read of every rank
 	std::vector<uint64_t> sg_round_len;                                    // this rank's singles + rejects per bucket round
 	bool sg_gathered = true;
+	long inject_at = -1, flag_exchanges = 0;                             // test hook: fail right before the inject_at-th flag exchange (mcomh_test_inject_failure)
+	bool peers_know = false;                                          // multi-GPU: a failure has been announced to (or learnt from) the other ranks
 	uint32_t cix_c0 = 0, cix_c1 = 0;                                       // contigs whose 17-mers this rank indexes in Stage 2
 
 	int fail(int code, const char *fmt, ...) {
@@ -342,23 +344,82 @@ static const char ACGT[] = "ACGT";
 
 // ---- multi-GPU plumbing: everything goes through the one all-to-all of host/mcom_comm.cpp ---------------------------
 static int comm_rc(P *p, int rc) { if (rc) p->err = std::string("communicator: ") + mcomh_comm_last_error(p->comm); return rc; }
+// Failure protocol.  A rank that hits an error between two collectives and simply returned would leave the others waiting in the
+// next one for ever (round 3's advisor finding: contig index build, merge-round index, merge shares ...).  So every exchange of the
+// pipeline starts with one flag word per rank, exchanged on its own (always the same size, so that any two such exchanges pair): "I have failed".  A rank that fails
+// in its local work announces it with ONE such flag exchange when its stage function returns (stage_exit below); that exchange pairs
+// with the flag exchange at the head of the collective the others are about to enter, they see the flag, skip the collective and
+// return too.  Every rank issues the same sequence of flag exchanges up to the failure, so they always pair.
+// the flag exchange: one word per rank, always the same size, so that any two of them pair -- a rank's announcement with whatever
+// collective the others are about to enter.  fail_flag: this rank has failed.
+static int flags(P *p, bool fail_flag)
+{
+	const int R = p->world;
+	if (!fail_flag && ++p->flag_exchanges == p->inject_at) return p->fail(MCOM_E_ARG, "injected failure in front of flag exchange %ld (test hook)", p->inject_at);
+	std::vector<uint64_t> buf((size_t)R, 0), off(R), bytes(R);
+	for (int q = 0; q < R; ++q) { off[q] = (uint64_t)q * 8; bytes[q] = 8; }
+	buf[(size_t)p->rank] = fail_flag ? 1 : 0;
+	int rc = comm_rc(p, mcomh_comm_allgatherv(p->comm, nullptr, buf.data(), off.data(), bytes.data(), 0, p->stream));
+	if (rc) { p->peers_know = true; return rc; }                              // (a broken transport: nothing more can be said to anybody)
+	int failed = -1;
+	for (int q = 0; q < R; ++q) if (buf[(size_t)q] && failed < 0) failed = q;
+	if (failed >= 0) {
+		p->peers_know = true;
+		if (!fail_flag) return p->fail(MCOM_E_HIP, "rank %d failed in its part of this stage", failed);
+	}
+	return MCOM_OK;
+}
 // k values of every rank, rank-major: all[q * k + i]
 static int gather_host(P *p, const uint64_t *mine, size_t k, std::vector<uint64_t> &all)
 {
 	const int R = p->world;
+	int rc = flags(p, false);
+	if (rc) return rc;
 	all.assign((size_t)R * k, 0);
+	if (!k) return MCOM_OK;
 	std::vector<uint64_t> off(R), bytes(R);
 	for (int q = 0; q < R; ++q) { off[q] = (uint64_t)q * k * 8; bytes[q] = k * 8; }
-	if (k) memcpy(all.data() + (size_t)p->rank * k, mine, k * 8);
+	memcpy(all.data() + (size_t)p->rank * k, mine, k * 8);
 	return comm_rc(p, mcomh_comm_allgatherv(p->comm, nullptr, all.data(), off.data(), bytes.data(), 0, p->stream));
 }
-// all-gather of a device array: rank q's part is elements [first[q], first[q] + cnt[q]); send = NULL: mine is in place
-template <class T> static int gatherv(P *p, T *buf, const std::vector<uint64_t> &first, const std::vector<uint64_t> &cnt, const T *send = nullptr)
+// the flag exchange alone: in front of a collective that moves device data
+static int guard(P *p) { return flags(p, false); }
+// what a stage function of a multi-GPU pipeline returns through: a rank that failed on its own tells the others
+static int stage_exit(P *p, int rc)
+{
+	if (rc && p->comm && !p->peers_know) { const std::string e = p->err; (void)flags(p, true); p->err = e; p->peers_know = true; }
+	return rc;
+}
+// sums / minima / maxima of a few counters (op 0 / 1 / 2), on the flag-carrying exchange
+static int allreduce_host(P *p, uint64_t *vals, size_t n, int op)
+{
+	std::vector<uint64_t> all;
+	int rc = gather_host(p, vals, n, all);
+	if (rc) return rc;
+	for (size_t i = 0; i < n; ++i) {
+		uint64_t v = all[i];
+		for (int q = 1; q < p->world; ++q) { const uint64_t x = all[(size_t)q * n + i]; v = op == 0 ? v + x : op == 1 ? std::min(v, x) : std::max(v, x); }
+		vals[i] = v;
+	}
+	return MCOM_OK;
+}
+// all-gather of a device array: rank q's part is elements [first[q], first[q] + cnt[q]); send = NULL: mine is in place.
+// guarded = false: the exchange directly follows another one, with nothing in between that can fail
+template <class T> static int gatherv(P *p, T *buf, const std::vector<uint64_t> &first, const std::vector<uint64_t> &cnt, const T *send = nullptr, bool guarded = true)
 {
 	const int R = p->world;
+	int rc;
+	if (guarded && (rc = guard(p))) return rc;
 	std::vector<uint64_t> off(R), bytes(R);
 	for (int q = 0; q < R; ++q) { off[q] = first[q] * sizeof(T); bytes[q] = cnt[q] * sizeof(T); }
 	return comm_rc(p, mcomh_comm_allgatherv(p->comm, send, buf, off.data(), bytes.data(), 1, p->stream));
+}
+// all-to-all of device data (offsets and sizes in bytes)
+static int alltoallv_dev(P *p, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *rb, bool guarded = true)
+{
+	int rc;
+	if (guarded && (rc = guard(p))) return rc;
+	return comm_rc(p, mcomh_comm_alltoallv(p->comm, send, so, sb, recv, ro, rb, 1, p->stream));
 }
 // Stage-2 claim keys: every rank holds the minimum over ITS contigs; the claim is the minimum over all.
 // Reduce-scatter by all-to-all (rank q folds slice q of everybody), then all-gather of the folded slices: direct
@@ -373,7 +434,7 @@ static int dist_min_claims(P *p, uint64_t *d_claim, size_t n)
 	DevBuf<uint64_t> parts;
 	if (!parts.reserve((size_t)R * len + 1)) return p->fail(MCOM_E_NOMEM, "claim shares");
 	for (int q = 0; q < R; ++q) { so[q] = lo[q] * 8; sb[q] = (lo[q + 1] - lo[q]) * 8; ro[q] = (uint64_t)q * len * 8; rb[q] = len * 8; first[q] = lo[q]; cnt[q] = lo[q + 1] - lo[q]; }
-	int rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, d_claim, so.data(), sb.data(), parts.p, ro.data(), rb.data(), 1, p->stream));
+	int rc = alltoallv_dev(p, d_claim, so.data(), sb.data(), parts.p, ro.data(), rb.data());
 	if (rc) return rc;
 	if ((rc = p->gpu(mcom_min_fold_u64(p->ctx, parts.p, R, (size_t)len, (size_t)len, d_claim + lo[me])))) return rc;
 	if ((rc = gatherv(p, d_claim, first, cnt))) return rc;
@@ -554,6 +615,10 @@ extern "C" int mcomh_create_from_fastq(mcomh_pipeline **out, int device, void *h
 	return MCOM_OK;
 }
 
+// test hook (include/mcom_test.h): this rank fails, as if its local work had, right before its k-th flag exchange
+extern "C" int mcomh_test_inject_failure(mcomh_pipeline *p, long k) { if (!p) return MCOM_E_ARG; p->inject_at = k; return MCOM_OK; }
+extern "C" long mcomh_test_flag_exchanges(const mcomh_pipeline *p) { return p ? p->flag_exchanges : 0; }
+
 extern "C" int mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow)
 {
 	if (!p) return MCOM_E_ARG;
@@ -586,7 +651,9 @@ extern "C" const char *mcomh_last_error(const mcomh_pipeline *p) { return p ? p-
 // ----------------------------------------------------------------------------------------------------
 // kt_for_reads                                                             kthread_reads.c:247, :40-230
 // ----------------------------------------------------------------------------------------------------
-extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
+static int kt_for_reads_impl(mcomh_pipeline *p);
+extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p) { return p ? stage_exit(p, kt_for_reads_impl(p)) : MCOM_E_ARG; }
+static int kt_for_reads_impl(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = busy_now(p);
@@ -648,11 +715,11 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 		std::vector<uint64_t> first(R), cnt(R), fW(R), cW(R), fN(R), cN(R);
 		for (int q = 0; q < R; ++q) { first[q] = p->shard_lo[q]; cnt[q] = p->shard_lo[q + 1] - p->shard_lo[q]; fW[q] = first[q] * p->W; cW[q] = cnt[q] * p->W; fN[q] = first[q] * p->NW; cN[q] = cnt[q] * p->NW; }
 		const double tx = now_ms();
-		if ((rc = gatherv(p, p->d_packed.p, fW, cW)) || (rc = gatherv(p, p->d_cls.p, first, cnt))) return rc;
+		if ((rc = gatherv(p, p->d_packed.p, fW, cW)) || (rc = gatherv(p, p->d_cls.p, first, cnt, (const uint8_t*)nullptr, false))) return rc;
 		uint32_t mx = 0;
 		if ((rc = p->gpu(mcom_max_u16(p->ctx, p->d_ncnt.p, nl, &mx)))) return rc;
 		uint64_t any = mx;
-		if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &any, 1, 2)))) return rc;
+		if ((rc = allreduce_host(p, &any, 1, 2))) return rc;
 		if (any) { if ((rc = gatherv(p, p->d_nmask.p, fN, cN))) return rc; }
 		else {
 			if (r0 && (rc = p->hipc(hipMemsetAsync(p->d_nmask.p, 0, r0 * p->NW * 8, p->stream), "clear"))) return rc;
@@ -699,7 +766,9 @@ extern "C" int mcomh_kt_for_reads(mcomh_pipeline *p)
 // ----------------------------------------------------------------------------------------------------
 // kt_for_bucket: Stage-1 rounds                                               kthread_bucket.c:562-629
 // ----------------------------------------------------------------------------------------------------
-extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
+static int kt_for_bucket_impl(mcomh_pipeline *p);
+extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p) { return p ? stage_exit(p, kt_for_bucket_impl(p)) : MCOM_E_ARG; }
+static int kt_for_bucket_impl(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = busy_now(p);
@@ -755,7 +824,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 			uint64_t a = 0, b = 0;
 			for (int q = 0; q < R; ++q) { so[q] = a * 16; sb[q] = cnt[q] * 16; a += cnt[q]; ro[q] = b * 16; rb[q] = all[(size_t)q * R + me] * 16; b += all[(size_t)q * R + me]; }
 			if (!d_recv.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "exchange buffers");
-			if ((rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, d_part.p, so.data(), sb.data(), d_recv.p, ro.data(), rb.data(), 1, p->stream)))) return rc;
+			if ((rc = alltoallv_dev(p, d_part.p, so.data(), sb.data(), d_recv.p, ro.data(), rb.data()))) return rc;
 			// what arrives is ordered by sender, each part by rid.  Round 1: shards are rid ranges in rank order, so this is
 			// rid order already; later rounds: one stable sort by rid restores what mcom_sort_group's tie rule expects
 			if (r > 1 && (rc = p->gpu(mcom_sort_by_rid(p->ctx, d_recv.p, (size_t)b)))) return rc;
@@ -826,7 +895,7 @@ extern "C" int mcomh_kt_for_bucket(mcomh_pipeline *p)
 				if (gc2[0] != gc[0] || gc2[1] != gc[1] || gc2[2] != gc[2] || gc2[3] != gc[3]) return p->fail(MCOM_E_ARG, "contig counts changed between the two calls");
 			}
 			const double tx = now_ms();
-			if ((rc = gatherv(p, D.seq.p, fc, cc)) || (rc = gatherv(p, D.soff.p, fn, cn)) || (rc = gatherv(p, D.mem.p, fm, cm)) || (rc = gatherv(p, D.moff.p, fn, cn))) return rc;
+			if ((rc = gatherv(p, D.seq.p, fc, cc)) || (rc = gatherv(p, D.soff.p, fn, cn, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.mem.p, fm, cm, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.moff.p, fn, cn, (const uint64_t*)nullptr, false))) return rc;
 			p->stat["t_x_contigs"] += now_ms() - tx;
 			D.n += tn; D.chars += tc; D.members += tm;
 			nrej = gc[3];
@@ -913,7 +982,7 @@ static int dist_gather_sg(P *p)
 	const size_t nr = p->sg_round_len.size();
 	int rc;
 	uint64_t mn = nr, mx = nr;
-	if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mn, 1, 1))) || (rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mx, 1, 2)))) return rc;
+	if ((rc = allreduce_host(p, &mn, 1, 1)) || (rc = allreduce_host(p, &mx, 1, 2))) return rc;
 	if (mn != mx) return p->fail(MCOM_E_ARG, "the ranks ran different numbers of bucket rounds");
 	std::vector<uint64_t> all;
 	if ((rc = gather_host(p, p->sg_round_len.data(), nr, all))) return rc;
@@ -1031,7 +1100,7 @@ static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_fir
 	if (!S.rec.reserve(total + room + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
 	if ((rc = p->gpu(mcom_records_rebase(p->ctx, tmp.p, tl, (uint32_t)c0, toff.p, nloc, (uint32_t)first[me])))) return rc;
 	const double tx = now_ms();
-	if ((rc = gatherv(p, S.rec.p, first, cnt, tmp.p)) || (rc = gatherv(p, S.roff.p, fo, co, toff.p))) return rc;
+	if ((rc = gatherv(p, S.rec.p, first, cnt, tmp.p)) || (rc = gatherv(p, S.roff.p, fo, co, toff.p, false))) return rc;
 	p->stat["t_x_sketch"] += now_ms() - tx;
 	const uint32_t t32 = (uint32_t)total;
 	if ((rc = p->h2d(S.roff.p + n_first, &t32, 1, "upload")) || (rc = p->sync("upload"))) return rc;
@@ -1058,7 +1127,7 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm, mcom_idx
 	uint32_t mx = 0;
 	rc = p->gpu(mcom_idx_sort_part(p->ctx, mi, part.p + first[me], cnt[me], first[me], &mx));
 	uint64_t mxa = mx;
-	if (!rc) rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &mxa, 1, 2));
+	if (!rc) rc = allreduce_host(p, &mxa, 1, 2);
 	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
 	auto bucket0 = [&](int q) { return (uint32_t)((((uint64_t)q << NB_BITS) + R - 1) / R); };   // first bucket with (beta * R) >> b == q
 	rc = mcom_idx_table_part(p->ctx, mi, (uint32_t)mxa, bucket0(me), bucket0(me + 1));
@@ -1085,7 +1154,9 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm, mcom_idx
 // The contig set (consensus strings, members, minimizers) lives on the device for the whole stage; per round only the
 // passing candidate pairs come to the host, for the first-come claiming, and the claimed pairs go back.
 // ----------------------------------------------------------------------------------------------------
-extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
+static int combine_cluster_impl(mcomh_pipeline *p);
+extern "C" int mcomh_combine_cluster(mcomh_pipeline *p) { return p ? stage_exit(p, combine_cluster_impl(p)) : MCOM_E_ARG; }
+static int combine_cluster_impl(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = busy_now(p);
@@ -1282,11 +1353,11 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 				if (rs && njl && (rc = p->gpu(mcom_records_rebase(p->ctx, T.rec.p, tnl, (uint32_t)j0, T.roff.p, njl, (uint32_t)fr[me])))) return rc;
 				if (!B.seq.reserve(std::max<uint64_t>(A.chars, tot[1]) + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
 				const double tx = now_ms();
-				if ((rc = gatherv(p, B.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, B.moff.p, fj, cj, T.moff.p)) || (rc = gatherv(p, B.seq.p, fc, cc, T.seq.p)) || (rc = gatherv(p, B.soff.p, fj, cj, T.soff.p))) return rc;
+				if ((rc = gatherv(p, B.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, B.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, B.seq.p, fc, cc, T.seq.p, false)) || (rc = gatherv(p, B.soff.p, fj, cj, T.soff.p, false))) return rc;
 				if ((rc = p->h2d(B.moff.p + nj, &tot[0], 1, "upload")) || (rc = p->h2d(B.soff.p + nj, &tot[1], 1, "upload"))) return rc;
 				if (rs) {
 					if (!B.roff.reserve(nn + 2) || !B.rec.reserve(tn + (size_t)A.nrec + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-					if ((rc = gatherv(p, B.rec.p, fr, cr, T.rec.p)) || (rc = gatherv(p, B.roff.p, fj, cj, T.roff.p))) return rc;
+					if ((rc = gatherv(p, B.rec.p, fr, cr, T.rec.p)) || (rc = gatherv(p, B.roff.p, fj, cj, T.roff.p, false))) return rc;
 					const uint32_t t32 = (uint32_t)tn;
 					if ((rc = p->h2d(B.roff.p + nj, &t32, 1, "upload"))) return rc;
 					merged_sketched = true;
@@ -1375,7 +1446,9 @@ extern "C" int mcomh_combine_cluster(mcomh_pipeline *p)
 // ----------------------------------------------------------------------------------------------------
 // updateSingle                                                                 preprocess.c:243-255
 // ----------------------------------------------------------------------------------------------------
-extern "C" int mcomh_update_single(mcomh_pipeline *p)
+static int update_single_impl(mcomh_pipeline *p);
+extern "C" int mcomh_update_single(mcomh_pipeline *p) { return p ? stage_exit(p, update_single_impl(p)) : MCOM_E_ARG; }
+static int update_single_impl(mcomh_pipeline *p)
 {
 	if (!p) return MCOM_E_ARG;
 	p->join_sg();
@@ -1593,7 +1666,9 @@ static int ensure_packed_contigs(P *p)
 // ----------------------------------------------------------------------------------------------------
 // realign_hash: one Stage-2 pass                                    kthread_hash_realign.c:569-594
 // ----------------------------------------------------------------------------------------------------
-extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_reads)
+static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads);
+extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_reads) { return p ? stage_exit(p, realign_hash_impl(p, thr, cluster_reads)) : MCOM_E_ARG; }
+static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 {
 	if (!p) return MCOM_E_ARG;
 	const double t0 = busy_now(p);
@@ -1660,8 +1735,8 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 					for (int q = 0; q < R; ++q) { so[q] = a; sb[q] = cnt[q]; a += cnt[q]; ro[q] = b; rb[q] = all[(size_t)q * R + me]; b += rb[q]; }
 					if (!keyB.reserve(std::max<uint64_t>(b, a) + 1) || !slotB.reserve(std::max<uint64_t>(b, a) + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 					auto scaled = [&](const std::vector<uint64_t> &v, uint64_t m) { std::vector<uint64_t> o(v); for (auto &x : o) x *= m; return o; };
-					if ((rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, keyA.p, scaled(so, 4).data(), scaled(sb, 4).data(), keyB.p, scaled(ro, 4).data(), scaled(rb, 4).data(), 1, p->stream))) ||
-					    (rc = comm_rc(p, mcomh_comm_alltoallv(p->comm, slotA.p, scaled(so, 8).data(), scaled(sb, 8).data(), slotB.p, scaled(ro, 8).data(), scaled(rb, 8).data(), 1, p->stream)))) return rc;
+					if ((rc = alltoallv_dev(p, keyA.p, scaled(so, 4).data(), scaled(sb, 4).data(), keyB.p, scaled(ro, 4).data(), scaled(rb, 4).data())) ||
+					    (rc = alltoallv_dev(p, slotA.p, scaled(so, 8).data(), scaled(sb, 8).data(), slotB.p, scaled(ro, 8).data(), scaled(rb, 8).data(), false))) return rc;
 					p->stat["t_x_cindex"] += now_ms() - tx; p->stat["x_cindex_entries"] += (double)(a - cnt[me]);
 					if (!keyA.reserve(b + 1) || !slotA.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 					n_ent = b;
@@ -1672,7 +1747,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 				}
 				// (every rank must come to the same decision: a share that needs more room makes all of them build again)
 				uint64_t again = rc == MCOM_E_OVERFLOW ? 1 : 0;
-				if (R > 1 && (rc == MCOM_OK || rc == MCOM_E_OVERFLOW)) { int rc2 = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &again, 1, 2)); if (rc2) return rc2; }
+				if (R > 1 && (rc == MCOM_OK || rc == MCOM_E_OVERFLOW)) { int rc2 = allreduce_host(p, &again, 1, 2); if (rc2) return rc2; }
 				if (rc != MCOM_OK && rc != MCOM_E_OVERFLOW) return p->gpu(rc);
 				p->stat["cix_entries"] += (double)n_ent;
 				if (!again) break;
@@ -1724,7 +1799,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 		                              (rc = p->gpu(mcom_dicts_screen_end(p->ctx, &may_exceed))))) return rc;
 		if (p->comm && !p->window_scan && !p->screen_clear) {                                  // a rank screened the keys of its share: any of them may say "look"
 			uint64_t any = (uint64_t)may_exceed;
-			if ((rc = comm_rc(p, mcomh_comm_allreduce_u64(p->comm, &any, 1, 2)))) return rc;
+			if ((rc = allreduce_host(p, &any, 1, 2))) return rc;
 			may_exceed = any ? 1 : 0;
 		}
 		if (!may_exceed && !p->window_scan) p->screen_clear = true;
@@ -1808,7 +1883,7 @@ extern "C" int mcomh_realign_hash(mcomh_pipeline *p, int thr, long *cluster_read
 // ----------------------------------------------------------------------------------------------------
 static int run_stage2(P *p, FILE *f);
 
-extern "C" int mcomh_stage2(mcomh_pipeline *p) { return p ? run_stage2(p, nullptr) : MCOM_E_ARG; }
+extern "C" int mcomh_stage2(mcomh_pipeline *p) { return p ? stage_exit(p, run_stage2(p, nullptr)) : MCOM_E_ARG; }
 
 extern "C" int mcomh_pre_process(mcomh_pipeline *p)
 {

@@ -150,3 +150,55 @@ def test_one_rank_rccl_communicator(golden_dir):
     assert calls > 10 and sent == 0                                           # one rank: everything it "sends" stays with it
     p.close(); comm.close()
     _assert_same(want, got, "rccl, one rank")
+
+
+def test_a_rank_that_fails_takes_the_others_with_it_instead_of_leaving_them_waiting():
+    """Round 3's advisor finding: a rank that returned from a rank-local error before a collective left the others waiting in it.
+    Now every collective starts with (or carries) a flag exchange and a failing rank announces itself with one when its stage
+    function returns (mcom_pipeline.cpp, "Failure protocol").  Three ranks as threads of this process on 60 k reads; rank 1 is made
+    to fail right before its k-th flag exchange (include/mcom_test.h) for k spread over every stage of the run: every rank must
+    come back with an error -- the failing one with its own, the others naming it -- and none may hang."""
+    import ctypes as C
+    import threading
+    from minicom_amd.distributed import Comm, DistPipeline
+    from minicom_amd.hip import McomError
+    reads = _synthetic(60000, 100, seed=77)
+    n, L = reads.shape
+    world = 3
+
+    def run(inject_at):
+        comms, hub = Comm.threads(world)
+        res, total = [None] * world, [0] * world
+
+        def rank_main(rank):
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            p = DistPipeline(reads[lo:hi], lo, n, comms[rank], L=L, device=0, host_threads=2)
+            p.lib.mcomh_test_inject_failure.argtypes = [C.c_void_p, C.c_long]
+            p.lib.mcomh_test_flag_exchanges.restype = C.c_long; p.lib.mcomh_test_flag_exchanges.argtypes = [C.c_void_p]
+            made = p.lib.mcomh_test_flag_exchanges(p._h)                   # (creating the pipeline exchanged the shard bounds already)
+            if rank == 1 and inject_at > 0:
+                p.lib.mcomh_test_inject_failure(p._h, made + inject_at)
+            try:
+                p.pre_process()
+                res[rank] = "ok"
+            except McomError as e:
+                res[rank] = str(e)
+            total[rank] = p.lib.mcomh_test_flag_exchanges(p._h) - made
+            p.close()
+        th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=180)
+        assert not any(t.is_alive() for t in th), f"a rank hangs after an injected failure at exchange {inject_at}: {res}"
+        for c in comms:
+            c.close()
+        return res, total
+
+    res, total = run(0)
+    assert res == ["ok"] * world and total[0] == total[1] == total[2] and total[1] > 40, (res, total)
+    points = sorted({1, 2, 3, 5, 8, 13, 21, 34, total[1] // 2, total[1] - 8, total[1] - 1, total[1]})
+    for k in points:
+        res, _ = run(k)
+        assert "injected failure" in res[1], (k, res)
+        assert all(r != "ok" and "rank 1 failed" in r for i, r in enumerate(res) if i != 1), (k, res)
