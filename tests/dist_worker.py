@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--rank", type=int); ap.add_argument("--world", type=int); ap.add_argument("--port", type=int)
     ap.add_argument("--reads"); ap.add_argument("--out"); ap.add_argument("--bounds", default="")
     ap.add_argument("--params", default="{}"); ap.add_argument("--dump", default="")
+    ap.add_argument("--transport", default="gloo", help="gloo: the library's all-to-all through torch.distributed, every rank on GPU 0; rccl: ncclSend / ncclRecv, rank r on GPU r")
     a = ap.parse_args()
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(a.port)
     import torch.distributed as dist
@@ -37,8 +38,17 @@ def main():
     n, L = reads.shape
     bounds = [int(x) for x in a.bounds.split(",")] if a.bounds else [n * q // a.world for q in range(a.world + 1)]
     lo, hi = bounds[a.rank], bounds[a.rank + 1]
-    comm = Comm.torch()
-    p = DistPipeline(reads[lo:hi], lo, n, comm, L=L, device=0, host_threads=2, **json.loads(a.params))
+    device = 0
+    if a.transport == "rccl":                                   # the production transport between real peers: one GPU per rank
+        import torch
+        device = a.rank
+        torch.cuda.set_device(device)
+        box = [Comm.unique_id() if a.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = Comm.rccl(a.rank, a.world, box[0], device)
+    else:
+        comm = Comm.torch()
+    p = DistPipeline(reads[lo:hi], lo, n, comm, L=L, device=device, host_threads=2, **json.loads(a.params))
     p.pre_process()
     res = result_arrays(p)
     res["stats"] = np.array([p.stat("rounds"), p.stat("merge_rounds"), p.stat("passes"), p.stat("big_bins"), p.stat("x_records")])
