@@ -530,7 +530,7 @@ def main():
                                                                      "claimed-pair range, Stage-2 index shared out by key -- all over RCCL send/recv groups; result replicated, identical to the "
                                                                      "single-GPU result",
                        "scaling_note": ("reads per GPU: 100 M at N = 1 (configs[1]), 62.5 M at N > 1 (configs[3] = 500 M at N = 8); value_strong_100m = configs[1]'s job over the same GPUs. "
-                                        "No multi-GPU node was available to this build: the N > 1 path is exact (tests), its scaling unmeasured (profiles/r03_dist_work.json: per-rank work on one card)"),
+                                        "No multi-GPU node was available to this build: the N > 1 path is exact (tests), its scaling unmeasured (profiles/r04_dist_work.json: per-rank work on one card)"),
                        "fell_back": fell_back, "host_threads": threads,
                        "per_step": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("rounds", "merge_rounds", "claim_rounds", "passes", "windows", "resketch", "n_sg0", "contigs_bucket",
                                                                                   "contigs_combine", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",

@@ -444,7 +444,7 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	                   arena_cap, arenas - 1, cursor, d_moff); }
 	MCOM_LAUNCH_CHECK(ctx);
 	// counts are in d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
-	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
+	MCOM_HIP(ctx, mcom_clear_later(ctx, d_moff + n, 4));
 	if ((rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, scr))) return rc;
 	std::vector<unsigned long long> fill(arenas);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, fill.data(), cursor, arenas * 8));
@@ -666,7 +666,7 @@ extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 
 	for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
 	if (h_max_bucket) *h_max_bucket = mx;
 	uint32_t *ovf = (uint32_t*)(base + sort_b);
-	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
+	MCOM_HIP(ctx, mcom_clear_later(ctx, ovf, 4));
 	if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
 		mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
 		rc = mcom_flag_sort_buckets(ctx, part, tmp, mi->part_bst, nb, b, mx, ovf);
@@ -858,15 +858,16 @@ __global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *
 		ok = mis <= (uint32_t)cbthr;
 	}
 	pass[p] = ok;
+	if (p == 0) pass[n_pairs] = 0;                                               // the scan over n_pairs + 1 flags leaves the number of passing pairs here
 }
 __global__ void k_fn_emit(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
                           const mcom_mm128 *__restrict__ q, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q,
-                          const uint32_t *__restrict__ pass_pre, uint32_t n_pairs, uint32_t last_flag,
+                          const uint32_t *__restrict__ pass_pre, uint32_t n_pairs,
                           mcom_mm128 *__restrict__ out)
 {
 	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n_pairs) return;
-	const uint32_t here = pass_pre[p], nxt = (p + 1 < n_pairs) ? pass_pre[p + 1] : pass_pre[p] + last_flag;
+	const uint32_t here = pass_pre[p], nxt = pass_pre[p + 1];                       // (n_pairs + 1 scanned flags)
 	if (nxt == here) return;
 	const uint32_t i = pair_q[p];
 	mcom_mm128 v; v.x = q[i].y; v.y = irec[first[i] + (p - pair_off[i])].y;        // x = query y (contig i, pos_ori, dir), y = hit y
@@ -901,7 +902,7 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
 	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
+	MCOM_HIP(ctx, mcom_clear_later(ctx, hits + n_query, 4));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
 	uint32_t n_pairs = 0;
@@ -913,7 +914,7 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	uint32_t *pair_off = nullptr, *pass = nullptr, *pair_q = nullptr;
 	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
 	hipError_t e = mcom_dmalloc(&pair_off, nq1 * 4);
-	if (e == hipSuccess) e = mcom_dmalloc(&pass, (size_t)n_pairs * 4);
+	if (e == hipSuccess) e = mcom_dmalloc(&pass, ((size_t)n_pairs + 1) * 4);
 	if (e == hipSuccess) e = mcom_dmalloc(&pair_q, (size_t)n_pairs * 4);
 	auto cleanup = [&]() { if (pair_off) mcom_dfree(pair_off); if (pass) mcom_dfree(pass); if (pair_q) mcom_dfree(pair_q); };
 	if (e != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
@@ -925,21 +926,17 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
 	MCOM_LAUNCH(k_fn_expand, dim3(qb), dim3(256), 0, ctx->stream, pair_off, n_query, pair_q);
 	MCOM_LAUNCH(k_fn_eval, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, n_pairs, d_cbits, d_coff, d_clen, cbthr, n_new, pass); }
-	uint32_t last_flag = 0, n_pass = 0;
-	e1 = mcom_d2h_async(ctx, &last_flag, pass + (n_pairs - 1), 4);
-	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
-	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate evaluation: %s", hipGetErrorString(e1)); }
-	rc = mcom_scan_u32(ctx, pass, pass, n_pairs, (uint32_t*)ctx->ws);
+	uint32_t n_pass = 0;
+	rc = mcom_scan_u32(ctx, pass, pass, (size_t)n_pairs + 1, (uint32_t*)ctx->ws);
 	if (rc) { cleanup(); return rc; }
-	e1 = mcom_d2h_async(ctx, &n_pass, pass + (n_pairs - 1), 4);
-	if (e1 == hipSuccess) e1 = mcom_stream_sync(ctx);
-	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate scan: %s", hipGetErrorString(e1)); }
-	n_pass += last_flag;
+	hipError_t e1b = mcom_d2h_async(ctx, &n_pass, pass + n_pairs, 4);               // (the scan's own total: no copy, scan.hip)
+	if (e1b == hipSuccess) e1b = mcom_stream_sync(ctx);
+	if (e1b != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate scan: %s", hipGetErrorString(e1b)); }
 	if (h_counts) h_counts[1] = n_pass;
 	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
-		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, pass, n_pairs, last_flag, d_out);
+		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, pass, n_pairs, d_out);
 		e1 = mcom_stream_sync(ctx);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}

@@ -99,6 +99,8 @@ public:
 		return raw + 64;
 	}
 	void put(void *p) { if (!p) return; const size_t cap = *(size_t*)((char*)p - 64); std::lock_guard<std::mutex> g(mu); free_.emplace(cap, p); }
+	// the free blocks go back to the C library (mcomh_pool_trim: a process that has run jobs of many sizes keeps a block of every size otherwise)
+	void trim() { std::lock_guard<std::mutex> g(mu); for (auto &kv : free_) free((char*)kv.second - 64); free_.clear(); }
 };
 HostPool &host_pool() { static HostPool *pool = new HostPool(); return *pool; }
 template <class T> struct PoolAlloc {
@@ -158,9 +160,9 @@ public:
 	}
 	void put(void *p, size_t cap) { if (!p) return; int dev = 0; (void)hipGetDevice(&dev); std::lock_guard<std::mutex> g(mu); free_.emplace(std::make_pair(dev, cap), p); }
 };
-static void host_pool_trim_hook();
-DevicePool &device_pool() { static DevicePool *pool = [] { mcom_set_oom_hook(&host_pool_trim_hook); return new DevicePool(); }(); return *pool; }
-static void host_pool_trim_hook() { device_pool().trim(); }
+static void device_pool_trim_hook();
+DevicePool &device_pool() { static DevicePool *pool = [] { mcom_set_oom_hook(&device_pool_trim_hook); return new DevicePool(); }(); return *pool; }
+static void device_pool_trim_hook() { device_pool().trim(); }                    // (what the library calls when IT runs out of device memory)
 
 template <class T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;            // cap in elements
@@ -644,7 +646,7 @@ extern "C" void mcomh_destroy(mcomh_pipeline *p)
 	delete p;
 }
 
-extern "C" void mcomh_pool_trim(void) { device_pool().trim(); mcom_pool_trim(); }
+extern "C" void mcomh_pool_trim(void) { device_pool().trim(); mcom_pool_trim(); host_pool().trim(); }
 
 extern "C" const char *mcomh_last_error(const mcomh_pipeline *p) { return p ? p->err.c_str() : "null pipeline"; }
 
