@@ -512,6 +512,20 @@ int mcom_dump_ids_order(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_
 int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes);
 int mcom_dump_pairing(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
                       uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts);
+/* One stream set per thread (kthread_dump.c:370-379, minicom:110-146: the number of stream files is part of the format, info.txt says it):
+ * the sets are cut at contig boundaries out of the images above.  The _at forms also say where in a text image the lines of given members
+ * start (h_text_at[q] for member index h_at_members[q]) and how many second-file reads lie among the members in front of a given one
+ * (h_second_at: where a set's peids.bin starts); mcom_dump_member_bits packs dir.bin (which = 0) or file.bin (which = 1: read id >= half)
+ * of the members of one set from bit 0, as the reference's per-thread bit writer does.                                                  */
+int mcom_dump_members_at(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_nmask, int L, const uint64_t *d_cbits, const uint64_t *d_coff,
+                         const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint8_t *d_pos, uint8_t *d_dir,
+                         uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes, const uint64_t *h_at_members, int n_at, uint64_t *h_text_at);
+int mcom_dump_ids_text_at(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes,
+                          const uint64_t *h_at_members, int n_at, uint64_t *h_text_at);
+int mcom_dump_pairing_at(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
+                         uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts,
+                         const uint64_t *h_at_members, int n_at, uint64_t *h_second_at);
+int mcom_dump_member_bits(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, int which, uint32_t half, uint8_t *d_out);
 /* d_flag[i] = 1 when read d_rids[i] holds an N (such unclustered reads go to single_N.seq as text, kthread_dump.c:400-407)       */
 int mcom_rows_have_n(mcom_ctx *ctx, const uint64_t *d_nmask, const uint32_t *d_rids, size_t n, int L, uint8_t *d_flag);
 

@@ -45,6 +45,10 @@ typedef struct {
 	int host_dump;      /* 1 = mcomh_cluster_dump, _order and _pe write their streams with the host loop (every base of every member, as the
 	                       reference's print_encode does) instead of the device encoders (csrc/streams.hip); same files (A/B switch, the
 	                       cross-check of tests/test_streams.py)                                                                      */
+	int stream_sets;    /* number of stream sets mcomh_cluster_dump* writes (0 or 1: one).  The reference writes one set per thread -- ref.bin.T,
+	                       beg_pos.bin.T, dir.bin.T, dif_char.txt.T [, ids.bin.T | ids.txt.T, peids.bin.T, file.bin.T], info.txt = "L n_threads"
+	                       (kthread_dump.c:370-379) -- and its decoder takes them in parallel (decompress.c:1248-1300); here the contigs are cut
+	                       into that many runs of about equal member counts.  The `minicom -t N` command line passes N (device encoders only)   */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

@@ -199,6 +199,12 @@ extern "C" int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const 
                                  const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint8_t *d_pos, uint8_t *d_dir,
                                  uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes)
 {
+	return mcom_dump_members_at(ctx, d_packed, d_nmask, L, d_cbits, d_coff, d_mem, d_moff, n_contigs, n_members, d_pos, d_dir, d_text, text_cap, h_text_bytes, nullptr, 0, nullptr);
+}
+extern "C" int mcom_dump_members_at(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_nmask, int L, const uint64_t *d_cbits, const uint64_t *d_coff,
+                                    const uint64_t *d_mem, const uint64_t *d_moff, size_t n_contigs, uint64_t n_members, uint8_t *d_pos, uint8_t *d_dir,
+                                    uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes, const uint64_t *h_at_members, int n_at, uint64_t *h_text_at)
+{
 	if (!ctx || !h_text_bytes) return MCOM_E_ARG;
 	*h_text_bytes = 0;
 	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range", L);
@@ -226,6 +232,10 @@ extern "C" int mcom_dump_members(mcom_ctx *ctx, const uint64_t *d_packed, const 
 	if (rc) return rc;
 	uint64_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, tlen + n_members, 8));
+	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q) {                 // where the text of given members starts (stream sets cut at contig boundaries)
+		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
+		MCOM_HIP(ctx, hipMemcpyAsync(&h_text_at[q], tlen + h_at_members[q], 8, hipMemcpyDeviceToHost, ctx->stream));
+	}
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
 	if (!d_text && !text_cap) return MCOM_OK;                                   // a sizing call: d_pos and d_dir are complete, the text's length known
@@ -431,6 +441,11 @@ extern "C" int mcom_dump_ids_order(mcom_ctx *ctx, const uint64_t *d_mem, const u
 
 extern "C" int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes)
 {
+	return mcom_dump_ids_text_at(ctx, d_mem, n_members, half, d_text, text_cap, h_text_bytes, nullptr, 0, nullptr);
+}
+extern "C" int mcom_dump_ids_text_at(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, uint32_t half, uint8_t *d_text, uint64_t text_cap, uint64_t *h_text_bytes,
+                                     const uint64_t *h_at_members, int n_at, uint64_t *h_text_at)
+{
 	if (!ctx || !h_text_bytes) return MCOM_E_ARG;
 	*h_text_bytes = 0;
 	if (n_members == 0) return MCOM_OK;
@@ -446,6 +461,10 @@ extern "C" int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t
 	if (rc) return rc;
 	uint64_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, len + n_members, 8));
+	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q) {
+		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
+		MCOM_HIP(ctx, hipMemcpyAsync(&h_text_at[q], len + h_at_members[q], 8, hipMemcpyDeviceToHost, ctx->stream));
+	}
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
 	if (!d_text && !text_cap) return MCOM_OK;                                    // a sizing call
@@ -457,6 +476,12 @@ extern "C" int mcom_dump_ids_text(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t
 
 extern "C" int mcom_dump_pairing(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
                                  uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts)
+{
+	return mcom_dump_pairing_at(ctx, d_lists, n_list, d_mem, n_members, half, d_ids_sp, d_file_sp, d_ids_0, d_file_0, h_counts, nullptr, 0, nullptr);
+}
+extern "C" int mcom_dump_pairing_at(mcom_ctx *ctx, const uint32_t *d_lists, uint64_t n_list, const uint64_t *d_mem, uint64_t n_members, uint32_t half,
+                                    uint32_t *d_ids_sp, uint8_t *d_file_sp, uint32_t *d_ids_0, uint8_t *d_file_0, uint64_t *h_counts,
+                                    const uint64_t *h_at_members, int n_at, uint64_t *h_second_at)
 {
 	if (!ctx || !h_counts) return MCOM_E_ARG;
 	h_counts[0] = h_counts[1] = 0;
@@ -482,12 +507,40 @@ extern "C" int mcom_dump_pairing(mcom_ctx *ctx, const uint32_t *d_lists, uint64_
 		e = hipGetLastError();
 		if (e == hipSuccess) e = hipMemcpyAsync(&cnt[0], pre + n_list, 4, hipMemcpyDeviceToHost, ctx->stream);
 		if (e == hipSuccess) e = hipMemcpyAsync(&cnt[1], pre + N, 4, hipMemcpyDeviceToHost, ctx->stream);
+		for (int q = 0; q < n_at && h_at_members && h_second_at && e == hipSuccess; ++q) {   // (first-file reads in front of member m, turned into second-file ones below)
+			h_second_at[q] = 0;
+			if (h_at_members[q] <= n_members) e = hipMemcpyAsync(&h_second_at[q], pre + n_list + h_at_members[q], 4, hipMemcpyDeviceToHost, ctx->stream);
+		}
 	}
 	if (e == hipSuccess) e = mcom_stream_sync(ctx);
 	drop();
 	if (rc) return rc;
 	if (e != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "%s", hipGetErrorString(e));
+	for (int q = 0; q < n_at && h_at_members && h_second_at; ++q)                // second-file reads among the members in front of member m: where a set's peids start
+		h_second_at[q] = h_at_members[q] - (h_second_at[q] - cnt[0]);
 	h_counts[0] = n_list - cnt[0];                                               // second-file reads among the lists: entries of d_ids_sp
 	h_counts[1] = n_members - (cnt[1] - cnt[0]);                                 // ... among the members: entries of d_ids_0
+	return MCOM_OK;
+}
+
+// dir.bin / file.bin of ONE stream set: the bits of members [0, n) of d_mem packed from bit 0 (the reference starts a fresh bit writer per
+// thread, kthread_dump.c:370-379; breads.h:241-248).  which = 0: the direction bit; 1: the file bit of the paired-end mode (read id >= half)
+namespace {
+__global__ void k_st_member_bits(const uint64_t *__restrict__ mem, size_t n, int which, uint32_t half, uint8_t *__restrict__ out)
+{
+	const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (8 * b >= n) return;
+	unsigned v = 0;
+	for (int j = 0; j < 8; ++j) { const size_t q = 8 * b + j; if (q < n) { const uint64_t y = mem[q]; v |= (unsigned)(which ? ((uint32_t)(y >> 32) >= half) : (unsigned)(y & 1ull)) << j; } }
+	out[b] = (uint8_t)v;
+}
+}
+extern "C" int mcom_dump_member_bits(mcom_ctx *ctx, const uint64_t *d_mem, uint64_t n_members, int which, uint32_t half, uint8_t *d_out)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!n_members) return MCOM_OK;
+	if (!d_mem || !d_out || which < 0 || which > 1) return mcom_fail(ctx, MCOM_E_ARG, "bad arguments");
+	MCOM_LAUNCH(k_st_member_bits, dim3((unsigned)(((n_members + 7) / 8 + 255) / 256)), dim3(256), 0, ctx->stream, d_mem, (size_t)n_members, which, half, d_out);
+	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

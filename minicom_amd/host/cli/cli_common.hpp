@@ -26,7 +26,8 @@ static inline bool cli_parse(int argc, char **argv, int first, CliOptions &o)
 		case 'k': o.prm.k = v; break;          case 'e': o.prm.e = v; break;       case 'm': o.prm.m = v; break;
 		case 'w': o.prm.w = v; break;          case 's': o.prm.numdict = v; break; case 'S': o.prm.step = v; break;
 		case 'E': o.prm.maxthr = v; break;     case 'g': o.prm.cbthr = v; break;   case 'R': o.prm.max_rounds = v; break;
-		case 't': o.prm.host_threads = v; break; case 'D': o.device = v; break;
+		case 't': o.prm.host_threads = v; o.prm.stream_sets = v; break;   // (the reference writes one stream set per thread: the count is part of the format)
+		case 'D': o.device = v; break;
 		default: return false;
 		}
 	}

@@ -295,6 +295,7 @@ struct mcomh_pipeline {
 	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
 	bool overlap_screen = false;                                      // true: the first Stage-2 pass's row gather + screen on the copy stream (A/B switch)
+	int stream_sets = 1;                                              // stream sets cluster_dump writes (the reference: one per thread)
 	bool host_dump = false;                                           // true: cluster_dump's default mode on the host, as the -p / paired-end modes (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
@@ -475,6 +476,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->full_consensus = pp->full_consensus == 1;
 	p->resketch = pp->full_sketch != 1;
 	p->host_dump = pp->host_dump == 1;
+	p->stream_sets = pp->stream_sets > 1 ? std::min(pp->stream_sets, 4096) : 1;
 	p->overlap_screen = pp->overlap_screen == 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
@@ -2249,9 +2251,14 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 	const std::string dir(folder);
 	PinVec<uint8_t> h_pos, h_dir, h_text, h_ref, h_single, h_ids;
 	uint64_t text_bytes = 0, ids_bytes = 0;
-	const size_t pos_bytes = 4 * D.n + 2 * (size_t)D.members, dir_bytes = ((size_t)D.members + 7) / 8, ref_bytes = ((size_t)D.chars + 3) / 4;
+	const size_t pos_bytes = 4 * D.n + 2 * (size_t)D.members;
 	DevBuf<uint64_t> mem2, moff2;                                                 // the members in dump order (kept for the pairing streams)
 	const uint64_t *d_mem_dump = nullptr;
+	// Stream sets (the reference: one per thread, kthread_dump.c:370-379): set t holds contigs [sc[t], sc[t + 1]) -- runs of about equal member
+	// counts.  The member streams are encoded ONCE for all contigs; a set's beg_pos / dif_char / ids file is a slice of the image (cut at a contig
+	// boundary), its bit-packed files (ref.bin, dir.bin, file.bin) are packed per set, from bit 0, as the reference's per-thread writers do.
+	const int T = D.n ? (int)std::min<size_t>((size_t)p->stream_sets, D.n) : 1;
+	std::vector<uint64_t> sc(T + 1, 0), sm(T + 1, 0), schars(T + 1, 0), stext(T + 1, 0), sids(T + 1, 0), ssecond(T + 1, 0), sdir(T + 1, 0), sref(T + 1, 0);
 	if (D.n) {
 		if ((rc = ensure_packed_contigs(p))) return rc;
 		if (!mem2.reserve(D.members + 1) || !moff2.reserve(D.n + 2)) return p->fail(MCOM_E_NOMEM, "member lists");
@@ -2264,20 +2271,39 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 			d_moff_dump = moff2.p;
 		} else if ((rc = p->gpu(mcom_members_order3(p->ctx, D.mem.p, D.moff.p, D.n, D.members, kb, mem2.p)))) return rc;   // cmpcluster3 (kthread_dump.c:34): the pipeline keeps its own order
 		d_mem_dump = mem2.p;
+		// where the sets are cut
+		sc[T] = D.n; sm[T] = D.members; schars[T] = D.chars;
+		if (T > 1) {
+			std::vector<uint64_t> hm(D.n + 1), hs(D.n + 1);
+			if ((rc = p->d2h(hm.data(), d_moff_dump, D.n + 1, "copy member offsets")) || (rc = p->d2h(hs.data(), D.soff.p, D.n + 1, "copy string offsets")) || (rc = p->sync("copy offsets"))) return rc;
+			for (int t = 1; t < T; ++t) {
+				size_t c = (size_t)(std::lower_bound(hm.begin(), hm.begin() + D.n, (uint64_t)D.members * (uint64_t)t / (uint64_t)T) - hm.begin());
+				c = std::max<size_t>(c, (size_t)sc[t - 1] + 1); c = std::min<size_t>(c, D.n - (size_t)(T - t));   // every set holds a contig
+				sc[t] = c; sm[t] = hm[c]; schars[t] = hs[c];
+			}
+		}
+		for (int t = 0; t <= T; ++t) { sdir[t] = t ? sdir[t - 1] + (sm[t] - sm[t - 1] + 7) / 8 : 0; sref[t] = t ? sref[t - 1] + (schars[t] - schars[t - 1] + 3) / 4 : 0; }
+		const size_t dir_bytes = (size_t)sdir[T], ref_bytes = (size_t)sref[T];
 		DevBuf<uint8_t> d_pos, d_dir, d_text, d_ref, d_ids;
-		if (!d_pos.reserve(pos_bytes + 16) || !d_dir.reserve(dir_bytes + 16) || !d_ref.reserve(ref_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
+		if (!d_pos.reserve(pos_bytes + 16) || !d_dir.reserve(std::max(dir_bytes, ((size_t)D.members + 7) / 8) + 16) || !d_ref.reserve(ref_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
 		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, d_moff_dump, D.n, D.members, d_pos.p, d_dir.p, nullptr, 0, &text_bytes)))) return rc;
 		if (!d_text.reserve(text_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
-		if ((rc = p->gpu(mcom_dump_members(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, d_moff_dump, D.n, D.members, d_pos.p, d_dir.p, d_text.p,
-		                                   text_bytes + 16, &text_bytes))) || (rc = p->gpu(mcom_dump_refbin(p->ctx, D.seq.p, D.chars, d_ref.p)))) return rc;
-		if (order) {                                                               // ids.bin.0 (kthread_dump.c:116-127)
+		if ((rc = p->gpu(mcom_dump_members_at(p->ctx, p->d_packed.p, p->d_nmask.p, L, p->d_cbits.p, p->d_coff_words.p, mem2.p, d_moff_dump, D.n, D.members, d_pos.p, d_dir.p, d_text.p,
+		                                      text_bytes + 16, &text_bytes, sm.data(), T + 1, stext.data())))) return rc;
+		// the bit-packed files, set by set (one set: dir.bin is what mcom_dump_members made already)
+		for (int t = 0; t < T; ++t) {
+			if (T > 1 && (rc = p->gpu(mcom_dump_member_bits(p->ctx, mem2.p + sm[t], sm[t + 1] - sm[t], 0, 0, d_dir.p + sdir[t])))) return rc;
+			if ((rc = p->gpu(mcom_dump_refbin(p->ctx, D.seq.p + schars[t], schars[t + 1] - schars[t], d_ref.p + sref[t])))) return rc;
+		}
+		if (order) {                                                               // ids.bin.T (kthread_dump.c:116-127)
 			ids_bytes = 4 * (uint64_t)D.members;
 			if (!d_ids.reserve(ids_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
 			if ((rc = p->gpu(mcom_dump_ids_order(p->ctx, mem2.p, D.moff.p, D.n, D.members, (uint32_t*)d_ids.p)))) return rc;
-		} else if (pe) {                                                           // ids.txt.0 (kthread_dump_pe.c:70-74)
+			for (int t = 0; t <= T; ++t) sids[t] = 4 * sm[t];
+		} else if (pe) {                                                           // ids.txt.T (kthread_dump_pe.c:70-74)
 			if ((rc = p->gpu(mcom_dump_ids_text(p->ctx, mem2.p, D.members, half, nullptr, 0, &ids_bytes)))) return rc;
 			if (!d_ids.reserve(ids_bytes + 16)) return p->fail(MCOM_E_NOMEM, "stream buffers");
-			if ((rc = p->gpu(mcom_dump_ids_text(p->ctx, mem2.p, D.members, half, d_ids.p, ids_bytes + 16, &ids_bytes)))) return rc;
+			if ((rc = p->gpu(mcom_dump_ids_text_at(p->ctx, mem2.p, D.members, half, d_ids.p, ids_bytes + 16, &ids_bytes, sm.data(), T + 1, sids.data())))) return rc;
 		}
 		if (!h_pos.resize(pos_bytes) || !h_dir.resize(dir_bytes) || !h_text.resize(text_bytes) || !h_ref.resize(ref_bytes) || !h_ids.resize(ids_bytes)) return p->fail(MCOM_E_NOMEM, "stream images");
 		if ((rc = p->d2h(h_pos.data(), d_pos.p, pos_bytes, "copy streams")) || (rc = p->d2h(h_dir.data(), d_dir.p, dir_bytes, "copy streams")) ||
@@ -2318,27 +2344,38 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 		if (!d_lists.reserve(nl + 1) || !d_isp.reserve(nl + 1) || !d_i0.reserve(nm + 1) || !d_fsp.reserve((nl + 7) / 8 + 16) || !d_f0.reserve((nm + 7) / 8 + 16)) return p->fail(MCOM_E_NOMEM, "pairing buffers");
 		uint64_t cnt[2] = {0, 0};
 		if ((nl && (rc = p->h2d(d_lists.p, lists.data(), nl, "upload lists"))) ||
-		    (rc = p->gpu(mcom_dump_pairing(p->ctx, d_lists.p, nl, d_mem_dump, nm, half, d_isp.p, d_fsp.p, d_i0.p, d_f0.p, cnt)))) return rc;
-		if (!h_pe_sp.resize(4 * cnt[0]) || !h_pe_0.resize(4 * cnt[1]) || !h_fb_sp.resize((nl + 7) / 8) || !h_fb_0.resize((nm + 7) / 8)) return p->fail(MCOM_E_NOMEM, "pairing images");
+		    (rc = p->gpu(mcom_dump_pairing_at(p->ctx, d_lists.p, nl, d_mem_dump, nm, half, d_isp.p, d_fsp.p, d_i0.p, d_f0.p, cnt, sm.data(), T + 1, ssecond.data())))) return rc;
+		// file.bin.T: a set's file bits packed from bit 0 (the byte ranges of dir.bin.T: one bit per member either way)
+		if (T > 1) { if (!d_f0.reserve((size_t)sdir[T] + 16)) return p->fail(MCOM_E_NOMEM, "pairing buffers");
+			for (int t = 0; t < T; ++t) if ((rc = p->gpu(mcom_dump_member_bits(p->ctx, d_mem_dump + sm[t], sm[t + 1] - sm[t], 1, half, d_f0.p + sdir[t])))) return rc; }
+		const size_t f0_bytes = T > 1 ? (size_t)sdir[T] : (nm + 7) / 8;
+		if (!h_pe_sp.resize(4 * cnt[0]) || !h_pe_0.resize(4 * cnt[1]) || !h_fb_sp.resize((nl + 7) / 8) || !h_fb_0.resize(f0_bytes)) return p->fail(MCOM_E_NOMEM, "pairing images");
 		if ((cnt[0] && (rc = p->d2h(h_pe_sp.data(), (const uint8_t*)d_isp.p, 4 * cnt[0], "copy pairing"))) || (cnt[1] && (rc = p->d2h(h_pe_0.data(), (const uint8_t*)d_i0.p, 4 * cnt[1], "copy pairing"))) ||
-		    (nl && (rc = p->d2h(h_fb_sp.data(), d_fsp.p, (nl + 7) / 8, "copy pairing"))) || (nm && (rc = p->d2h(h_fb_0.data(), d_f0.p, (nm + 7) / 8, "copy pairing"))) || (rc = p->sync("pairing streams"))) return rc;
+		    (nl && (rc = p->d2h(h_fb_sp.data(), d_fsp.p, (nl + 7) / 8, "copy pairing"))) || (f0_bytes && (rc = p->d2h(h_fb_0.data(), d_f0.p, f0_bytes, "copy pairing"))) || (rc = p->sync("pairing streams"))) return rc;
 	}
 	p->stat["t_dump_gpu"] += now_ms() - t0;
 	const double tw = now_ms();
-	if (!write_file(dir + "/ref.bin.0", h_ref.data(), D.n ? ref_bytes : 0) || !write_file(dir + "/beg_pos.bin.0", h_pos.data(), D.n ? pos_bytes : 0) ||
-	    !write_file(dir + "/dir.bin.0", h_dir.data(), D.n ? dir_bytes : 0) || !write_file(dir + "/dif_char.txt.0", h_text.data(), D.n ? (size_t)text_bytes : 0) ||
-	    !write_file(dir + "/single.seq", h_single.data(), h_single.size())) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
-	if (order && !write_file(dir + "/ids.bin.0", h_ids.data(), D.n ? (size_t)ids_bytes : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);   // kthread_dump.c:266-269
-	if (pe && (!write_file(dir + "/ids.txt.0", h_ids.data(), D.n ? (size_t)ids_bytes : 0) || !write_file(dir + "/peids.bin.sp", h_pe_sp.data(), h_pe_sp.size()) ||
-	           !write_file(dir + "/file.bin.sp", h_fb_sp.data(), h_fb_sp.size()) || !write_file(dir + "/peids.bin.0", h_pe_0.data(), h_pe_0.size()) ||
-	           !write_file(dir + "/file.bin.0", h_fb_0.data(), h_fb_0.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+	for (int t = 0; t < T; ++t) {
+		const std::string sfx = "." + std::to_string(t);
+		const size_t pos_a = D.n ? 4 * (size_t)sc[t] + 2 * (size_t)sm[t] : 0, pos_b = D.n ? 4 * (size_t)sc[t + 1] + 2 * (size_t)sm[t + 1] : 0;
+		if (!write_file(dir + "/ref.bin" + sfx, h_ref.data() + sref[t], D.n ? (size_t)(sref[t + 1] - sref[t]) : 0) ||
+		    !write_file(dir + "/beg_pos.bin" + sfx, h_pos.data() + pos_a, pos_b - pos_a) ||
+		    !write_file(dir + "/dir.bin" + sfx, h_dir.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : 0) ||
+		    !write_file(dir + "/dif_char.txt" + sfx, h_text.data() + stext[t], D.n ? (size_t)(stext[t + 1] - stext[t]) : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+		if (order && !write_file(dir + "/ids.bin" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);   // kthread_dump.c:266-269
+		if (pe && (!write_file(dir + "/ids.txt" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0) ||
+		           !write_file(dir + "/peids.bin" + sfx, h_pe_0.data() + 4 * ssecond[t], D.n ? (size_t)(4 * (ssecond[t + 1] - ssecond[t])) : 0) ||
+		           !write_file(dir + "/file.bin" + sfx, h_fb_0.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : h_fb_0.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+	}
+	if (!write_file(dir + "/single.seq", h_single.data(), h_single.size())) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	if (pe && (!write_file(dir + "/peids.bin.sp", h_pe_sp.data(), h_pe_sp.size()) || !write_file(dir + "/file.bin.sp", h_fb_sp.data(), h_fb_sp.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
 	if (order && (!write_ids(dir + "/allA.ids.bin", allA) || !write_ids(dir + "/allT.ids.bin", allT) || !write_ids(dir + "/allN.ids.bin", allN) ||
 	              !write_ids(dir + "/AA.ids.bin", fpA) || !write_ids(dir + "/TT.ids.bin", fpT) || !write_ids(dir + "/NN.ids.bin", fpN) ||
 	              !write_ids(dir + "/Nfile.ids.bin", nfile) || !write_ids(dir + "/singleFile.ids.bin", single_ids))) return p->fail(MCOM_E_ARG, "cannot write id streams");
 	FILE *finfo = fopen((dir + "/info.txt").c_str(), "w");
 	if (!finfo) return p->fail(MCOM_E_ARG, "cannot write info.txt");
-	if (pe) fprintf(finfo, "%d %d\n%u\n%zu %zu %zu\n", L, 1, half, p->allA.size(), p->allT.size(), p->allN.size());   // kthread_dump_pe.c:222-234
-	else fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, 1, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
+	if (pe) fprintf(finfo, "%d %d\n%u\n%zu %zu %zu\n", L, T, half, p->allA.size(), p->allT.size(), p->allN.size());   // kthread_dump_pe.c:222-234
+	else fprintf(finfo, "%d %d\n%zu %zu %zu\n", L, T, p->allA.size(), p->allT.size(), p->allN.size());   // :375-376
 	if (order) fprintf(finfo, "%u\n", (unsigned)p->n);                                               // :377-379
 	fclose(finfo);
 	// the short lists as text (:566-671)
@@ -2356,7 +2393,7 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 		fclose(f);
 	}
 	p->stat["t_dump_write"] += now_ms() - tw;
-	p->stat["dump_bytes"] += (double)(pos_bytes + dir_bytes + ref_bytes + text_bytes + ids_bytes + h_single.size());
+	p->stat["dump_bytes"] += (double)(pos_bytes + h_dir.size() + h_ref.size() + text_bytes + ids_bytes + h_single.size());
 	return MCOM_OK;
 }
 

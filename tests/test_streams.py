@@ -258,3 +258,72 @@ def test_device_encoders_of_the_order_and_paired_end_modes_equal_the_host_loop(t
     for name in files[1]:
         assert files[0][name] == files[1][name], name
     assert len(files[0]["ids.bin.0" if mode == "order" else "peids.bin.0"]) > 100000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "order", "paired"])
+def test_one_stream_set_per_thread_as_the_reference_writes_them(tmp_path, mode):
+    """The number of stream files is part of the format (info.txt = "L n_threads"; kthread_dump.c:370-379, minicom:110-146): the reference
+    writes one set per thread and its decoder takes them in parallel (decompress.c:1248-1300).  stream_sets = 5 cuts the contigs into five
+    runs: the per-member files of the five sets concatenate to the one-set files, info.txt says 5, our decoder gives the reads back, and so
+    does THE REFERENCE'S OWN decoder (oracle/_ref/L150*/decompress, built from /root/reference/src by oracle/build_ref.sh: test
+    infrastructure) -- in the reads' original order for -p, mate beside mate for the paired-end mode."""
+    import subprocess
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress, decompress_pe
+    L = 150
+    reads = np.concatenate([synth.synth_reads(909, 120000, L), synth.synth_reads(910, 6000, L, plumbing=True)])
+    n = reads.shape[0]
+    half = n // 2
+    kw = {"order": mode == "order", "paired": mode == "paired"}
+    dirs = {}
+    for T in (1, 5):
+        p = Pipeline(reads, host_threads=8, stream_sets=T)
+        p.pre_process()
+        d = tmp_path / f"sets{T}"; d.mkdir()
+        p.cluster_dump(str(d), **kw)
+        p.close()
+        dirs[T] = d
+    one, five = dirs[1], dirs[5]
+    assert (five / "info.txt").read_text().split()[:2] == [str(L), "5"]
+    per_member = ["beg_pos.bin", "dif_char.txt"] + (["ids.bin"] if mode == "order" else ["ids.txt", "peids.bin"] if mode == "paired" else [])
+    for name in per_member:
+        assert b"".join((five / f"{name}.{t}").read_bytes() for t in range(5)) == (one / f"{name}.0").read_bytes(), name
+    for name in ("single.seq", "AA.txt", "TT.txt", "NN.txt", "single_N.seq"):
+        assert (five / name).read_bytes() == (one / name).read_bytes(), name
+    assert all((five / f"ref.bin.{t}").stat().st_size > 0 for t in range(5))
+
+    def check(rows1, rows2=None):
+        if mode == "order":
+            assert rows1 == [r.tobytes() for r in reads]
+        elif mode == "paired":
+            assert sorted(zip(rows1, rows2)) == sorted((reads[i].tobytes(), reads[half + i].tobytes()) for i in range(half))
+        else:
+            assert sorted(rows1) == sorted(r.tobytes() for r in reads)
+    # our decoder
+    o1, o2 = tmp_path / "o1.txt", tmp_path / "o2.txt"
+    if mode == "paired":
+        assert decompress_pe(str(five), str(o1), str(o2)) == half
+        check(o1.read_bytes().split(b"\n")[:-1], o2.read_bytes().split(b"\n")[:-1])
+    else:
+        assert decompress(str(five), str(o1), order=mode == "order") == n
+        check(o1.read_bytes().split(b"\n")[:-1])
+    # the reference's decoder, when its build travelled with the repo
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = {"default": "L150", "order": "L150_order", "paired": "L150_pe"}[mode]
+    exe = os.path.join(root, "oracle", "_ref", variant, "decompress")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref is not built here")
+    r1, r2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    subprocess.run([exe, str(five), str(r1), "true" if mode == "paired" else "false", "true" if mode == "order" else "false", "4", str(r2)], check=True, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL)
+    if mode == "order":
+        check(r1.read_bytes().split(b"\n")[:-1])
+    else:
+        # the default and paired-end decoders leave their pieces in the folder; the reference's script concatenates them (minicom:386-396: with single_N.seq in the default mode; decompress.c:1296-1308)
+        parts = [five / "aatt.fasta"] + ([five / "single_N.seq"] if mode == "default" else []) + [five / "single_dec.fasta"] + [five / f"result_{t}.seq" for t in range(5)]
+        rows = b"".join(q.read_bytes() for q in parts if q.exists()).split(b"\n")[:-1]
+        if mode == "paired":
+            check(rows, r2.read_bytes().split(b"\n")[:-1])
+        else:
+            check(rows)
