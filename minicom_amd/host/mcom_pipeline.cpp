@@ -513,6 +513,7 @@ extern "C" int mcomh_create_dist(mcomh_pipeline **out, int device, void *hip_str
 	if (!out) return MCOM_E_ARG;
 	*out = nullptr;
 	if (!comm || n_total >= (1ull << 32) || rid0 + n_local > n_total) return MCOM_E_ARG;
+	if (mcomh_comm_world(comm) > 256) { fprintf(stderr, "mcomh_create_dist: %d ranks; the Stage-2 index is shared out among at most 256 owners\n", mcomh_comm_world(comm)); return MCOM_E_ARG; }
 	int rc = mcomh_create(out, device, hip_stream, host_reads, d_reads, pitch, n_local, L, pp);
 	if (rc) return rc;
 	P *p = *out;
