@@ -14,44 +14,13 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	if (ctx) { ctx->err = buf; ctx->pin_wait.clear(); ctx->pin_off = 0; mcom_clear_flush(ctx); }
+	if (ctx) { ctx->err = buf; ctx->pin_wait.clear(); ctx->pin_off = 0; }
 	return code;
-}
-
-// ---- batched small clears (mcom_dev.hpp) ----------------------------------------------------------------------------------------
-struct ClearList { unsigned int *p[8]; uint32_t words[8], value[8]; };
-__global__ void k_clear_list(ClearList L)
-{
-	unsigned int *p = L.p[blockIdx.y];
-	const uint32_t n = L.words[blockIdx.y], v = L.value[blockIdx.y];
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
-}
-void mcom_clear_flush(mcom_ctx *ctx)
-{
-	if (!ctx->n_clears) return;
-	ClearList L;
-	uint32_t mx = 0;
-	const int n = ctx->n_clears;
-	ctx->n_clears = 0;                                                           // (first: the launch below goes through no macro, but stay re-entrant)
-	for (int i = 0; i < 8; ++i) { L.p[i] = i < n ? (unsigned int*)ctx->clears[i].p : nullptr; L.words[i] = i < n ? ctx->clears[i].words : 0; L.value[i] = i < n ? ctx->clears[i].value : 0; if (L.words[i] > mx) mx = L.words[i]; }
-	unsigned gx = (mx + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
-	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, (const void*)&k_clear_list)];
-	hipLaunchKernelGGL(k_clear_list, dim3(gx, (unsigned)n), dim3(256), 0, ctx->stream, L);
-}
-hipError_t mcom_clear_later(mcom_ctx *ctx, void *p, size_t bytes, int byte_value)
-{
-	if (!bytes) return hipSuccess;
-	if ((bytes & 3) || ((uintptr_t)p & 3) || bytes > ((size_t)256 << 10)) { mcom_clear_flush(ctx); return hipMemsetAsync(p, byte_value, bytes, ctx->stream); }
-	if (ctx->n_clears == 8) mcom_clear_flush(ctx);
-	const uint32_t b = (uint32_t)(byte_value & 0xFF);
-	ctx->clears[ctx->n_clears++] = mcom_ctx::Clear{p, (uint32_t)(bytes / 4), b | (b << 8) | (b << 16) | (b << 24)};
-	return hipSuccess;
 }
 
 #define MCOM_PIN_BYTES 4096
 hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-	mcom_clear_flush(ctx);
 	for (const mcom_ctx::ScanTotal &t : ctx->scan_last)                            // the total of a scan that is on its way: already in pinned memory
 		if (t.last && t.last == src && t.bytes == bytes && t.gen == ctx->launch_gen) { mcom_ctx::PinWait w{dst, 0, bytes}; w.from = ctx->scan_tot + t.slot; ctx->pin_wait.push_back(w); return hipSuccess; }
 	if (bytes <= 256) {
@@ -67,7 +36,6 @@ hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t byte
 }
 hipError_t mcom_stream_sync(mcom_ctx *ctx)
 {
-	mcom_clear_flush(ctx);
 	hipError_t e = hipStreamSynchronize(ctx->stream);
 	++ctx->launch_gen;                                                             // (what a scan left in pinned memory is consumed below)
 	if (e == hipSuccess && ctx->poison && *ctx->poison) {                        // a kernel's bounded wait ran out (scan.hip): its results are wrong
@@ -147,7 +115,6 @@ void mcom_dfree(void *p)
 
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
 {
-	mcom_clear_flush(ctx);                                                        // (a queued clear may point into the workspace that is about to move)
 	if (bytes <= ctx->ws_bytes) return MCOM_OK;
 	if (ctx->ws) { MCOM_HIP(ctx, hipStreamSynchronize(ctx->stream)); MCOM_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
 	if (ctx->device >= 0 && ctx->device < 16) {

@@ -356,7 +356,7 @@ int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t
 	uint32_t *perm = nullptr;
 	if (mcom_dmalloc(&perm, ((size_t)n_groups + 128) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "group order");
 	uint32_t *bins = perm + n_groups, *cursor = bins + 40;
-	hipError_t er = mcom_clear_later(ctx, bins, 80 * 4);
+	hipError_t er = hipMemsetAsync(bins, 0, 80 * 4, ctx->stream);
 	const unsigned blocks = (n_groups + 255) / 256;
 	if (er == hipSuccess) {
 		MCOM_LAUNCH(k_bs_sizes, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins);

@@ -444,7 +444,7 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 	                   arena_cap, arenas - 1, cursor, d_moff); }
 	MCOM_LAUNCH_CHECK(ctx);
 	// counts are in d_moff[0..n), d_moff[n] = 0, then an exclusive scan over n+1 entries leaves the total in d_moff[n]
-	MCOM_HIP(ctx, mcom_clear_later(ctx, d_moff + n, 4));
+	MCOM_HIP(ctx, hipMemsetAsync(d_moff + n, 0, 4, ctx->stream));
 	if ((rc = mcom_scan_u32(ctx, d_moff, d_moff, n + 1, scr))) return rc;
 	std::vector<unsigned long long> fill(arenas);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, fill.data(), cursor, arenas * 8));
@@ -666,7 +666,7 @@ extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 
 	for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
 	if (h_max_bucket) *h_max_bucket = mx;
 	uint32_t *ovf = (uint32_t*)(base + sort_b);
-	MCOM_HIP(ctx, mcom_clear_later(ctx, ovf, 4));
+	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
 	if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
 		mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
 		rc = mcom_flag_sort_buckets(ctx, part, tmp, mi->part_bst, nb, b, mx, ovf);
@@ -902,7 +902,7 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
 	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, mcom_clear_later(ctx, hits + n_query, 4));
+	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
 	uint32_t n_pairs = 0;

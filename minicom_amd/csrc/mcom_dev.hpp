@@ -53,8 +53,6 @@ struct mcom_ctx {
 	unsigned long long *scan_tot = nullptr, *d_scan_tot = nullptr;               // host / device view of the ring (after the poison word)
 	// (an entry stands only while no other kernel has been launched and the stream has not been synchronised since its scan: launch_gen)
 	struct ScanTotal { const void *last; uint32_t bytes, slot, gen; } scan_last[8] = {}; uint32_t scan_last_at = 0, launch_gen = 1;
-	// small clears waiting for the next kernel launch (mcom_clear_later): up to 8 regions go out in ONE launch instead of a fill each
-	struct Clear { void *p; uint32_t words, value; } clears[8]; int n_clears = 0;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
 	struct PinWait { void *dst; size_t off, bytes; const void *from = nullptr; };   // from != nullptr: the value waits there (a scan's total), not in the page
@@ -83,14 +81,7 @@ struct McomProfScope {
 // Every kernel launch of the library goes through MCOM_LAUNCH: hipLaunchKernelGGL, plus -- while the profiler is on -- a tally of
 // the instantiation under the class whose scope is open.  mcom_prof_kernels turns the addresses into names with the runtime's own
 // table (hipKernelNameRefByPtr, demangled): the spelling rocprofv3 prints for the same kernel, template arguments included.
-// A counter or a small table cleared in front of the kernel that uses it cost a fill launch of its own -- 152 per step in round 4's
-// first profile.  mcom_clear_later queues the clear (regions of whole 32-bit words, at most 256 KB); the queue goes out as ONE launch
-// (k_clear_list, api.hip) right before the next MCOM_LAUNCH, and before anything else that could see the memory: a stream
-// synchronisation, a small read-back (mcom_d2h_async).  Use it only where the next operation on the stream is such a launch.
-hipError_t mcom_clear_later(mcom_ctx *ctx, void *p, size_t bytes, int byte_value = 0);
-void mcom_clear_flush(mcom_ctx *ctx);
 #define MCOM_LAUNCH(kernel, grid, block, lds, stream, ...) do { \
-	if (ctx->n_clears) mcom_clear_flush(ctx); \
 	++ctx->launch_gen; \
 	if (ctx->prof_on) ++ctx->prof_kernels[std::make_pair(ctx->prof_cur, (const void*)&kernel)]; \
 	hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)

@@ -617,7 +617,7 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t 
 		int rcw = mcom_ws_reserve(ctx, 1024 * 4 * 8);
 		if (rcw) return rcw;
 		sets = (unsigned long long*)ctx->ws;
-		MCOM_HIP(ctx, mcom_clear_later(ctx, sets, 1024 * 4 * 8));
+		MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 1024 * 4 * 8, ctx->stream));
 	}
 	if (!d_keys || !d_sgbits || !d_sgflag || !d_cbits || !d_coff || !d_woff || !d_claim || g.n_parts < 1 || g.n_lines < 1)
 		return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");

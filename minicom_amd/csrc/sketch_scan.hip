@@ -566,7 +566,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	uint32_t *scr = (uint32_t*)(b0 + 5 * n4);
 	uint32_t *bins = (uint32_t*)(b0 + 5 * n4 + scr_b), *cursor = bins + SSC_BINS, *start = cursor + SSC_BINS, *misc = start + SSC_BINS;   // misc[0] longest, [1] overflowed strings
 	mcom_mm128 *tmp = (mcom_mm128*)(b0 + head);
-	MCOM_HIP(ctx, mcom_clear_later(ctx, bins, (3 * SSC_BINS + 16) * 4));
+	MCOM_HIP(ctx, hipMemsetAsync(bins, 0, (3 * SSC_BINS + 16) * 4, ctx->stream));
 	MCOM_LAUNCH(k_ssc_prepare, dim3((nn + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, room, base, n + 1, scr))) return rc;
@@ -598,7 +598,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	ctx->sketch_strings += n;
-	MCOM_HIP(ctx, mcom_clear_later(ctx, cnt + n, 4));
+	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
 	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;
 	uint32_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_moff + n, 4));

@@ -428,7 +428,7 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	uint2 *ovf_list = (uint2*)(ovf + 2);
 	uint32_t *ovf_dst = ovf + 2 + 2 * (size_t)ntiles;
 	MCOM_LAUNCH(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
-	MCOM_HIP(ctx, mcom_clear_later(ctx, ovf, 4));
+	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
 	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);

@@ -86,7 +86,7 @@ int mcom_table_fill_buckets(mcom_ctx *ctx, const mcom_mm128 *sorted, const uint3
 	int rc = mcom_ws_reserve(ctx, 256);
 	if (rc) return rc;
 	uint32_t *meta = (uint32_t*)ctx->ws;
-	MCOM_HIP(ctx, mcom_clear_later(ctx, meta, 8));
+	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 8, ctx->stream));
 	const size_t lds = (size_t)16 * t->region;
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_table_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	MCOM_LAUNCH(k_table_bucket, dim3(bucket1 - bucket0), dim3(256), lds, ctx->stream, sorted, bstart, (int)t->bbits, t->region, t->slots, meta, bucket0, start_base);
