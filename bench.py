@@ -326,7 +326,7 @@ def main():
     try:
         ok, err = True, None
         try:
-            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check, ab_events=not a.no_event_ab)
+            dt, agg, ref_digest, checked, reads, n_total, n_local = measure(n_job, seed, a.steps, a.warmup, not a.no_check, ab_events=not a.no_event_ab and world == 1)
         except (McomError, RuntimeError) as e:                                  # e.g. out of memory at a size no single card could rehearse
             ok, err = False, f"{type(e).__name__}: {e}"
         if not agree(ok):

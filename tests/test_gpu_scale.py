@@ -211,3 +211,31 @@ def test_pipeline_equals_the_sequential_oracle_on_repeat_rich_reads(n, L, sub_ra
           f"big_bins {p.stat('big_bins')}, big_bin_reads {p.stat('big_bin_reads')}, passes {p.stat('passes')}", flush=True)
     _assert_equal_sets(o, p)
     p.close(); o.close()
+
+
+def test_paired_end_file_set_of_4m_reads_of_150_bases_keeps_every_pair(tmp_path):
+    """BASELINE configs[4]'s mode at a size the fixtures do not reach: 2 x 2 M reads of 150 bases, the second half of the set standing in for
+    the mates (the pairing is by read id: any second file will do).  The paired-end file set is written by the device encoders in four
+    stream sets and decoded by this repo's decoder: every (read, mate) pair comes back, side by side."""
+    import minicom_amd
+    from minicom_amd.pipeline import Pipeline, decompress_pe
+    n, L = 4_000_000, 150
+    ctx = minicom_amd.Context(0)
+    reads = ctx.synth_reads(1005, n, L)
+    ctx.sync()
+    host = reads.cpu().numpy()[:, :L]
+    half = n // 2
+    p = Pipeline(reads, L=L, host_threads=8, stream_sets=4)
+    p.pre_process()
+    d = tmp_path / "pe"; d.mkdir()
+    t = time.time()
+    p.cluster_dump(str(d), paired=True)
+    print(f"\n[paired end, {n} reads] dumped in {time.time() - t:.2f} s (device {p.stat('t_dump_gpu') / 1e3:.3f} s)", flush=True)
+    p.close()
+    o1, o2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    assert decompress_pe(str(d), str(o1), str(o2)) == half
+    a = np.frombuffer(o1.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+    b = np.frombuffer(o2.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+    got = np.sort(np.ascontiguousarray(np.concatenate([a, b], axis=1)).view(f"S{2 * L}").ravel())
+    want = np.sort(np.ascontiguousarray(np.concatenate([host[:half], host[half:]], axis=1)).view(f"S{2 * L}").ravel())
+    assert np.array_equal(got, want)
