@@ -212,7 +212,9 @@ int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm12
  * head the new list, cp_cluster order :397-434), the others came through it unmerged.  A pair of two of those others was a candidate
  * in the round before, with the same strings at the same positions, and did not pass then (a passing pair of two contigs that both
  * stay unclaimed does not exist: the first of the two to be visited takes the other, :286-343) -- so it is not evaluated again.
- * Same output as mcom_find_next_candidates; n_new = 0 evaluates every pair.                                                    */
+ * Queries of such a contig probe the index only through keys that a new contig has there (a bit map of those keys), and their other
+ * pairs are not listed: h_counts[0] counts the pairs listed.  Same output as mcom_find_next_candidates; n_new = 0 lists and
+ * evaluates every pair.                                                                                                          */
 int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
                                   const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
                                   mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);

@@ -199,9 +199,9 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 							uint8_t hd = D[at]; uint16_t hi = I[at];
 							do {
 								const uint8_t md = hd; const uint16_t mi = hi;
-								const uint32_t pos = bb[l];
+								const uint32_t pos = atomicAdd(&bb[l], 1u);                  // (one LDS operation for the read and the ++)
 								hd = D[pos]; hi = I[pos];
-								D[pos] = md; I[pos] = mi; bb[l] = pos + 1;
+								D[pos] = md; I[pos] = mi;
 								l = (int)hd;
 							} while (l != q);
 							D[at] = hd; I[at] = hi;

@@ -44,7 +44,9 @@ def pmc(fetch_csv, write_csv, out):
 
 def trace(db, out, step=None):
     con = sqlite3.connect(db)
-    rows = list(con.execute("select name, start, end from kernels order by start"))
+    have = [d[0] for d in con.execute("select * from kernels limit 0").description]
+    extra = [c for c in ("grid_x", "workgroup_x", "lds_size", "vgpr_count", "scratch_size") if c in have]       # launch shape, when the view has it
+    rows = list(con.execute("select name, start, end%s from kernels order by start" % "".join(", " + c for c in extra)))
     short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")
     starts = [i for i, r in enumerate(rows) if short(r[0]).startswith("k_classify_")]
     step = len(starts) - 1 if step is None else step
@@ -52,8 +54,8 @@ def trace(db, out, step=None):
     t0 = rows[a][1]
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "start_us", "duration_us"])
-        for n, s, e in rows[a:b]:
+        w.writerow(["kernel", "start_us", "duration_us"] + extra)
+        for n, s, e, *x in rows[a:b]:
             n = short(n)
             depth = 0
             for i, ch in enumerate(n):
@@ -61,7 +63,7 @@ def trace(db, out, step=None):
                 elif ch == ">": depth -= 1
                 elif ch == "(" and depth == 0:
                     n = n[:i]; break
-            w.writerow([n, round((s - t0) / 1e3, 2), round((e - s) / 1e3, 2)])
+            w.writerow([n, round((s - t0) / 1e3, 2), round((e - s) / 1e3, 2)] + list(x))
 
 
 if __name__ == "__main__":
