@@ -101,6 +101,13 @@ int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size
 int mcom_process_reads_packed(mcom_ctx *ctx, const uint64_t *d_in_packed, const uint64_t *d_in_nmask, size_t n, int L, int k, int e,
                               uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt, uint64_t *d_nmask, mcom_mm128 *d_rec);
 
+/* The reads that are not class 0 (all-A / all-T / all-N, near-poly, N-heavy: the reference's special files, preprocess.c:84-126,
+ * :219-224), as a list: d_list[i] = rid << 8 | class for i < min(*d_count, cap), in NO particular order (the caller sorts: rid
+ * order is file order); *d_count = how many there are (it may exceed cap: take the class array itself then).  A handful per
+ * million reads on real data: the host learns them from a few bytes instead of from one byte per read.  Asynchronous on the
+ * context's stream; d_count is cleared by the call.                                                                        */
+int mcom_special_reads(mcom_ctx *ctx, const uint8_t *d_cls, size_t n, uint64_t *d_list, uint32_t cap, uint32_t *d_count);
+
 /* Batched mm_sketch_two (sketch.c:238-289) on packed rows.  d_rids (optional): sketch rows
  * d_rids[i] of d_packed and stamp that rid (the re-sketch of rejected reads with k-1, k-2, ...,
  * kthread_bucket.c:205, :489); NULL: rows rid0+i... i.e. row i with rid rid0+i.                 */

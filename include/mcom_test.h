@@ -35,6 +35,10 @@ struct mcomh_pipeline;
  * return an error, none may hang.                                                                                                   */
 int  mcomh_test_inject_failure(struct mcomh_pipeline *p, long k);
 long mcomh_test_flag_exchanges(const struct mcomh_pipeline *p);
+/* Reads of another class than 0 reach the host as a list made on the device (mcom_special_reads): `first` entries travel with the
+ * count, up to `cap` in a second copy, and beyond `cap` the class array itself is copied.  Defaults 4096 and 2^20; small values let
+ * a test walk all three paths with a few dozen reads.  Before mcomh_kt_for_reads.                                              */
+int  mcomh_test_special_capacity(struct mcomh_pipeline *p, uint32_t first, uint32_t cap);
 
 #ifdef __cplusplus
 }

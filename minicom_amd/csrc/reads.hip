@@ -452,6 +452,34 @@ __global__ void k_mask_records(const uint8_t *__restrict__ cls, size_t n, mcom_m
 	if (t < n && cls[t] != MCOM_CLS_SKETCH) { mcom_mm128 o; o.x = U64MAX; o.y = U64MAX; rec[t] = o; }
 }
 
+// the reads of another class than 0, listed (rid << 8 | class): eight class bytes per thread, nearly always one zero word
+__global__ void k_special_reads(const uint8_t *__restrict__ cls, size_t n, uint64_t *__restrict__ list, uint32_t cap, uint32_t *__restrict__ count)
+{
+	const size_t r0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+	if (r0 >= n) return;
+	uint64_t w = 0;
+	if (r0 + 8 <= n) w = *(const uint64_t*)(cls + r0);
+	else for (size_t j = 0; r0 + j < n; ++j) w |= (uint64_t)cls[r0 + j] << (8 * j);
+	if (w == 0) return;
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t c = (uint32_t)(w >> (8 * j)) & 255u;
+		if (!c) continue;
+		const uint32_t at = atomicAdd(count, 1u);
+		if (at < cap) list[at] = ((uint64_t)(r0 + j) << 8) | c;
+	}
+}
+extern "C" int mcom_special_reads(mcom_ctx *ctx, const uint8_t *d_cls, size_t n, uint64_t *d_list, uint32_t cap, uint32_t *d_count)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!d_count || (cap && !d_list)) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
+	if (n == 0) return MCOM_OK;
+	if (!d_cls || ((uintptr_t)d_cls & 7)) return mcom_fail(ctx, MCOM_E_ARG, "class array: null or not 8-byte aligned");
+	MCOM_LAUNCH(k_special_reads, dim3((unsigned)((n / 8 + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_list, cap, d_count);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // synthetic reads (minicom_amd/synth.py, plumbing=False); one thread per base
 // ------------------------------------------------------------------------------------------------

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void k_rs_plan(const Job *__restrict__ jobs, s
                                                  int w, int k, RsPlan *__restrict__ plan, uint64_t *__restrict__ seg_start, uint64_t *__restrict__ seg_end,
                                                  unsigned long long *__restrict__ seg_chars)
 {
-	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	unsigned long long mine = 0;
-	if (j < nj) {
+	// (a grid of at most 1024 workgroups and one atomic each: a wave per 64 jobs put 47 000 atomics on one address in the first round)
+	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < nj; j += (size_t)gridDim.x * blockDim.x) {
 		const Job J = jobs[j];
 		const bool afirst = J.pos_ori >= J.pos;
 		const uint32_t f = afirst ? J.ci : J.cj, s = afirst ? J.cj : J.ci;
@@ -58,10 +58,15 @@ __global__ __launch_bounds__(256) void k_rs_plan(const Job *__restrict__ jobs, s
 		P.s0 = (int32_t)s0; P.keep_lo = (int32_t)keep_lo; P.keep_hi = (int32_t)keep_hi; P.left_hi = (int32_t)left_hi; P.tail_lo = (int32_t)tail_lo;
 		plan[j] = P;
 		seg_start[j] = soff2[j] + (uint64_t)s0; seg_end[j] = soff2[j] + (uint64_t)s1;
-		mine = (unsigned long long)(s1 - s0);
+		mine += (unsigned long long)(s1 - s0);
 	}
+	__shared__ unsigned long long wg_sum;
+	if (threadIdx.x == 0) wg_sum = 0;
 	for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
-	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(seg_chars, mine);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&wg_sum, mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && wg_sum) atomicAdd(seg_chars, wg_sum);
 }
 
 // first index in [a, b) whose position is >= v
@@ -140,7 +145,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	RsCut *cut = b_cut.get<RsCut>(nj);
 	if (!plan || !seg_start || !seg_end || !d_chars || !smoff || !cut) return mcom_fail(ctx, MCOM_E_NOMEM, "resketch buffers");
 	MCOM_HIP(ctx, hipMemsetAsync(d_chars, 0, 8, ctx->stream));
-	MCOM_LAUNCH(k_rs_plan, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, d_soff2, w, k, plan, seg_start,
+	MCOM_LAUNCH(k_rs_plan, dim3((unsigned)std::min<size_t>((nj + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, d_soff2, w, k, plan, seg_start,
 	                   seg_end, d_chars);
 	MCOM_LAUNCH_CHECK(ctx);
 	unsigned long long seg_chars = 0;

@@ -31,7 +31,10 @@ __device__ __forceinline__ uint32_t ssc_len(const uint64_t *off, const uint64_t 
 	return (uint32_t)((off_end ? off_end[t] : off[t + 1]) - off[t]);
 }
 
-// room, length bin and the longest string
+// room, length bin and the longest string.  A workgroup takes a run of 256-string chunks and adds its counts to the global bins
+// ONCE (round 4: with a workgroup per chunk, 30 000 workgroups x ~15 occupied bins queued on four cache lines -- the kernel's whole
+// 0.36 ms on 8 M strings; the same for the cursors of k_ssc_order below).
+#define SSC_GRID 1024
 __global__ __launch_bounds__(256) void k_ssc_prepare(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, uint32_t n, int w,
                                                      uint32_t *__restrict__ room, uint32_t *__restrict__ bins, uint32_t *__restrict__ longest)
 {
@@ -40,13 +43,19 @@ __global__ __launch_bounds__(256) void k_ssc_prepare(const uint64_t *__restrict_
 	for (int q = threadIdx.x; q < SSC_BINS; q += 256) h[q] = 0;
 	if (threadIdx.x == 0) mx = 0;
 	__syncthreads();
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	if (t < n) {
-		const uint32_t len = ssc_len(off, off_end, t);
-		room[t] = len ? 3u * len / (uint32_t)(w + 1) + 6u : 0u;
-		atomicAdd(&h[len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1], 1u);
-		atomicMax(&mx, len);
-	} else if (t == n) room[t] = 0;
+	const uint32_t chunks = n / 256u + 1u, per = (chunks + gridDim.x - 1) / gridDim.x;      // (n + 1 entries: room[n] = 0)
+	const uint32_t c0 = blockIdx.x * per, c1 = c0 + per < chunks ? c0 + per : chunks;
+	uint32_t lmx = 0;
+	for (uint32_t c = c0; c < c1; ++c) {
+		const uint32_t t = c * 256u + threadIdx.x;
+		if (t < n) {
+			const uint32_t len = ssc_len(off, off_end, t);
+			room[t] = len ? 3u * len / (uint32_t)(w + 1) + 6u : 0u;
+			atomicAdd(&h[len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1], 1u);
+			lmx = len > lmx ? len : lmx;
+		} else if (t == n) room[t] = 0;
+	}
+	if (lmx) atomicMax(&mx, lmx);
 	__syncthreads();
 	for (int q = threadIdx.x; q < SSC_BINS; q += 256) if (h[q]) atomicAdd(&bins[q], h[q]);
 	if (threadIdx.x == 0 && mx > *longest) atomicMax(longest, mx);
@@ -58,20 +67,29 @@ __global__ void k_ssc_starts(const uint32_t *__restrict__ bins, uint32_t *__rest
 	uint32_t a = 0;
 	for (int q = SSC_BINS - 1; q >= 0; --q) { start[q] = a; a += bins[q]; }
 }
-// perm: the strings, longest bin first
+// perm: the strings, longest bin first (a workgroup counts its run of chunks, reserves its room in every bin once, then places)
 __global__ __launch_bounds__(256) void k_ssc_order(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, uint32_t n,
                                                    const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ perm)
 {
 	__shared__ uint32_t h[SSC_BINS], base[SSC_BINS];
 	for (int q = threadIdx.x; q < SSC_BINS; q += 256) h[q] = 0;
 	__syncthreads();
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	uint32_t bin = 0, r = 0;
-	if (t < n) { const uint32_t len = ssc_len(off, off_end, t); bin = len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1; r = atomicAdd(&h[bin], 1u); }
+	const uint32_t chunks = (n + 255u) / 256u, per = (chunks + gridDim.x - 1) / gridDim.x;
+	const uint32_t c0 = blockIdx.x * per, c1 = c0 + per < chunks ? c0 + per : chunks;
+	for (uint32_t c = c0; c < c1; ++c) {
+		const uint32_t t = c * 256u + threadIdx.x;
+		if (t < n) { const uint32_t len = ssc_len(off, off_end, t); atomicAdd(&h[len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1], 1u); }
+	}
 	__syncthreads();
-	for (int q = threadIdx.x; q < SSC_BINS; q += 256) base[q] = h[q] ? start[q] + atomicAdd(&cursor[q], h[q]) : 0u;
+	for (int q = threadIdx.x; q < SSC_BINS; q += 256) { base[q] = h[q] ? start[q] + atomicAdd(&cursor[q], h[q]) : 0u; h[q] = 0; }
 	__syncthreads();
-	if (t < n) perm[base[bin] + r] = t;
+	for (uint32_t c = c0; c < c1; ++c) {
+		const uint32_t t = c * 256u + threadIdx.x;
+		if (t < n) {
+			const uint32_t len = ssc_len(off, off_end, t), bin = len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1;
+			perm[base[bin] + atomicAdd(&h[bin], 1u)] = t;
+		}
+	}
 }
 
 // lane q of workgroup b scans string list[64 b + q] (list = NULL: the string of that index); at most room[t] records go to
@@ -567,11 +585,11 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	uint32_t *bins = (uint32_t*)(b0 + 5 * n4 + scr_b), *cursor = bins + SSC_BINS, *start = cursor + SSC_BINS, *misc = start + SSC_BINS;   // misc[0] longest, [1] overflowed strings
 	mcom_mm128 *tmp = (mcom_mm128*)(b0 + head);
 	MCOM_HIP(ctx, hipMemsetAsync(bins, 0, (3 * SSC_BINS + 16) * 4, ctx->stream));
-	MCOM_LAUNCH(k_ssc_prepare, dim3((nn + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
+	MCOM_LAUNCH(k_ssc_prepare, dim3(std::min<uint32_t>((nn + 1 + 255) / 256, SSC_GRID)), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, room, base, n + 1, scr))) return rc;
 	MCOM_LAUNCH(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
-	MCOM_LAUNCH(k_ssc_order, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
+	MCOM_LAUNCH(k_ssc_order, dim3(std::min<uint32_t>((nn + 255) / 256, SSC_GRID)), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, start, cursor, perm);
 	uint32_t h2[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[0], misc, 4));
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h2[1], base + n, 4));

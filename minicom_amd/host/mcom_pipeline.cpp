@@ -248,7 +248,8 @@ struct mcomh_pipeline {
 	DevBuf<uint64_t> d_packed, d_nmask; DevBuf<uint8_t> d_cls; DevBuf<uint16_t> d_ncnt; DevBuf<mcom_mm128> d_rec;
 	// host
 	std::vector<uint8_t> h_ascii;            // only when the reads came from the host (needed for the N dump)
-	PinVec<uint8_t> h_cls;
+	PinVec<uint8_t> h_cls; bool h_cls_valid = false;     // (the class array on the host: only when the list of special reads overflowed, or for mcomh_dump_stages)
+	DevBuf<uint64_t> d_special; PinVec<uint64_t> h_special;
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile;
 	U32Pooled sg;
 	U8Pooled sg_flag;
@@ -308,6 +309,7 @@ struct mcomh_pipeline {
 	std::vector<uint64_t> shard_lo;                                        // [world + 1] first read of every rank
 	std::vector<uint64_t> sg_round_len;                                    // this rank's singles + rejects per bucket round
 	bool sg_gathered = true;
+	uint32_t sp_cap = 1u << 20, sp_first = 4096;                          // room of the special-read list on the device / entries copied with the count (mcomh_test_special_capacity)
 	long inject_at = -1, flag_exchanges = 0;                             // test hook: fail right before the inject_at-th flag exchange (mcomh_test_inject_failure)
 	bool peers_know = false;                                          // multi-GPU: a failure has been announced to (or learnt from) the other ranks
 	uint32_t cix_c0 = 0, cix_c1 = 0;                                       // contigs whose 17-mers this rank indexes in Stage 2
@@ -623,6 +625,7 @@ extern "C" int mcomh_create_from_fastq(mcomh_pipeline **out, int device, void *h
 // test hook (include/mcom_test.h): this rank fails, as if its local work had, right before its k-th flag exchange
 extern "C" int mcomh_test_inject_failure(mcomh_pipeline *p, long k) { if (!p) return MCOM_E_ARG; p->inject_at = k; return MCOM_OK; }
 extern "C" long mcomh_test_flag_exchanges(const mcomh_pipeline *p) { return p ? p->flag_exchanges : 0; }
+extern "C" int mcomh_test_special_capacity(mcomh_pipeline *p, uint32_t first, uint32_t cap) { if (!p || !cap || !first) return MCOM_E_ARG; p->sp_first = first; p->sp_cap = cap; return MCOM_OK; }
 
 extern "C" int mcomh_set_records(mcomh_pipeline *p, const uint64_t *d_x, const uint32_t *d_ylow)
 {
@@ -732,27 +735,28 @@ static int kt_for_reads_impl(mcomh_pipeline *p)
 		}
 		p->stat["t_x_reads"] += now_ms() - tx;
 	}
-	if (!p->h_cls.resize(n + 8)) return p->fail(MCOM_E_NOMEM, "classes");
-	memset(p->h_cls.data() + n, 0, 8);
-	// the classes travel while the bucket stage starts; a thread sorts the special reads into their lists (rid order) once
-	// they have arrived -- nobody reads those lists before Stage 2
+	// The special reads (another class than 0: a handful per million on real data) are listed on the device and the LIST travels,
+	// on the copy stream, while the bucket stage starts; a thread sorts it into the seven id lists (rid order) -- nobody reads those
+	// before Stage 2.  Rounds 1-3 sent the class array itself: 100 MB of PCIe per 100 M reads beside the first sort pass, which ran
+	// 1.8 instead of 0.4 ms under it.  A list that outgrows its room (a file of N reads) falls back to the array.
 	p->join_cls();
 	p->cls_failed = false;
+	p->h_cls_valid = false;
 	for (std::vector<uint32_t> *v : {&p->allA, &p->allT, &p->allN, &p->fpA, &p->fpT, &p->fpN, &p->Nfile}) v->clear();   // a second call must not append twice
 	if (!p->ev_cls && (rc = p->hipc(hipEventCreateWithFlags(&p->ev_cls, hipEventDisableTiming), "event"))) return rc;
-	// on the copy stream, behind the kernels that wrote the classes: the bucket stage does not wait for 100 MB of PCIe
+	const uint32_t SP_CAP = p->sp_cap, SP_FIRST = std::min(p->sp_first, p->sp_cap);
+	if (!p->d_special.reserve((size_t)SP_CAP + 1) || !p->h_special.resize((size_t)SP_FIRST + 1)) return p->fail(MCOM_E_NOMEM, "special reads");
+	uint32_t *d_count = (uint32_t*)(p->d_special.p + SP_CAP);
+	if ((rc = p->gpu(mcom_special_reads(p->ctx, p->d_cls.p, n, p->d_special.p, SP_CAP, d_count)))) return rc;
 	if ((rc = p->hipc(hipEventRecord(p->ev_main, p->stream), "event")) || (rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_main, 0), "wait")) ||
-	    (n && (rc = p->hipc(hipMemcpyAsync(p->h_cls.data(), p->d_cls.p, n, hipMemcpyDeviceToHost, p->copy_stream), "copy classes"))) ||
+	    (rc = p->hipc(hipMemcpyAsync(p->h_special.data() + SP_FIRST, d_count, 8, hipMemcpyDeviceToHost, p->copy_stream), "copy special reads")) ||
+	    (rc = p->hipc(hipMemcpyAsync(p->h_special.data(), p->d_special.p, (size_t)SP_FIRST * 8, hipMemcpyDeviceToHost, p->copy_stream), "copy special reads")) ||
 	    (rc = p->hipc(hipEventRecord(p->ev_cls, p->copy_stream), "event"))) return rc;
-	p->cls_thread = std::thread([p, n]() {
-		if (hipEventSynchronize(p->ev_cls) != hipSuccess) { p->cls_failed = true; return; }
-		for (size_t r = 0; r < n; ++r) {
-			if ((r & 7) == 0) {                                                   // nearly every read is class 0: skip eight at a time
-				uint64_t w8; memcpy(&w8, p->h_cls.data() + r, 8);
-				if (w8 == 0) { r += 7; continue; }
-			}
-			switch (p->h_cls[r]) {
-			case MCOM_CLS_SKETCH: break;
+	p->cls_thread = std::thread([p, n, SP_CAP, SP_FIRST]() {
+		if (hipSetDevice(p->device) != hipSuccess || hipEventSynchronize(p->ev_cls) != hipSuccess) { p->cls_failed = true; return; }
+		const uint32_t count = (uint32_t)p->h_special[SP_FIRST];
+		auto put = [p](size_t r, uint32_t c) {
+			switch (c) {
 			case MCOM_CLS_ALLA: p->allA.push_back((uint32_t)r); break;
 			case MCOM_CLS_ALLT: p->allT.push_back((uint32_t)r); break;
 			case MCOM_CLS_ALLN: p->allN.push_back((uint32_t)r); break;
@@ -762,6 +766,32 @@ static int kt_for_reads_impl(mcomh_pipeline *p)
 			case MCOM_CLS_NHEAVY: p->Nfile.push_back((uint32_t)r); break;
 			default: break;
 			}
+		};
+		if (count <= SP_CAP) {
+			std::vector<uint64_t> all;
+			const uint64_t *lst = p->h_special.data();
+			if (count > SP_FIRST) {                                                // (the copy stream is this thread's until the event of the next call)
+				all.resize(count);
+				if (hipMemcpyAsync(all.data(), p->d_special.p, (size_t)count * 8, hipMemcpyDeviceToHost, p->copy_stream) != hipSuccess ||
+				    hipStreamSynchronize(p->copy_stream) != hipSuccess) { p->cls_failed = true; return; }
+				lst = all.data();
+			}
+			std::vector<uint64_t> srt(lst, lst + count);
+			std::sort(srt.begin(), srt.end());                                      // rid order = file order
+			for (uint64_t e : srt) put((size_t)(e >> 8), (uint32_t)e & 255u);
+			return;
+		}
+		// more special reads than the list holds: the class array itself
+		if (!p->h_cls.resize(n + 8)) { p->cls_failed = true; return; }
+		memset(p->h_cls.data() + n, 0, 8);
+		if (hipMemcpyAsync(p->h_cls.data(), p->d_cls.p, n, hipMemcpyDeviceToHost, p->copy_stream) != hipSuccess || hipStreamSynchronize(p->copy_stream) != hipSuccess) { p->cls_failed = true; return; }
+		p->h_cls_valid = true;
+		for (size_t r = 0; r < n; ++r) {
+			if ((r & 7) == 0) {                                                   // most reads are class 0: skip eight at a time
+				uint64_t w8; memcpy(&w8, p->h_cls.data() + r, 8);
+				if (w8 == 0) { r += 7; continue; }
+			}
+			put(r, p->h_cls[r]);
 		}
 	});
 	p->stat["t_reads"] += busy_now(p) - t0;
@@ -1971,6 +2001,10 @@ extern "C" int mcomh_dump_stages(mcomh_pipeline *p, const char *path)
 	int rc = mcomh_kt_for_reads(p);
 	if (rc) { fclose(f); return rc; }
 	p->join_cls();
+	if (!p->h_cls_valid && p->n) {
+		if (!p->h_cls.resize(p->n + 8) || hipMemcpy(p->h_cls.data(), p->d_cls.p, p->n, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return p->fail(MCOM_E_HIP, "copy classes"); }
+		p->h_cls_valid = true;
+	}
 	const int L = p->L, W = p->W;
 	fprintf(f, "PARAMS L %d k %d b %d rw %d e %d cbthr %d m %d n %zu\n", L, p->k, NB_BITS, p->rw, p->e, p->cbthr, p->m, p->n);
 	fprintf(f, "STAGE reads\nREADS %zu\n", p->n);

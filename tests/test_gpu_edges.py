@@ -45,6 +45,32 @@ def test_pipeline_equals_oracle_at_the_edges(name):
     p.close(); o.close()
 
 
+@pytest.mark.parametrize("first,cap", [(4096, 1 << 20), (8, 1 << 20), (8, 16)])
+def test_special_reads_reach_the_host_as_a_list_or_as_the_class_array(first, cap):
+    """Reads of another class than 0 are listed on the device (mcom_special_reads): a few entries travel with the count, more in a
+    second copy, and a list that outgrows its room falls back to the class array.  All three paths must give the oracle's id lists."""
+    import ctypes as C
+    import oracle
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    r = synth.synth_reads(21, 3000, 100, plumbing=True)
+    r[5:40] = ord("A"); r[100:130] = ord("T"); r[700:712] = ord("N")
+    r[1000:1300:7, 10:70] = ord("N")
+    r[2000:2030, 3:] = ord("A")                                      # near poly-A
+    o = oracle.Pipeline(r); o.run_all()
+    p = Pipeline(r, host_threads=2)
+    p.lib.mcomh_test_special_capacity.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    assert p.lib.mcomh_test_special_capacity(p._h, first, cap) == 0
+    p.pre_process()
+    n_special = sum(len(o.id_list(l)) for l in ("fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"))
+    assert n_special > 100
+    for lst in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+        assert np.array_equal(o.id_list(lst), p.id_list(lst)), lst
+    for (r0, m0), (r1, m1) in zip(o.contigs(), p.contigs()):
+        assert r0 == r1 and np.array_equal(m0, m1)
+    p.close(); o.close()
+
+
 def test_pipeline_on_an_empty_read_set():
     """No reads (the reference reads none and goes on, bseq.c:38-66): every stage runs and leaves nothing."""
     from minicom_amd.pipeline import Pipeline
