@@ -19,7 +19,8 @@ int mcom_set_index_capacity(mcom_ctx *ctx, int entries);
 int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
 /* mcom_sketch_contigs has three kernels: one lane per string (windows up to 64 entries, strings below 32768 characters) with a ring of
  * 32-bit hash prefixes (k odd: ties are settled by recomputing the hashes from the string) or of 64-bit hashes, and one wave per
- * string; wave_per_string = 1 forces the last, 2 the 64-bit ring, 0 = the default choice.  Same sketch every way.
+ * string (also the choice for 8192 strings or fewer); wave_per_string = 1 forces the last, 2 the 64-bit ring, 4 the lane per string
+ * with its default ring whatever the number of strings, 0 = the default choice.  Same sketch every way.
  * mcom_set_sketch_prefix_bits (1..30; default 14: prefixes of up to 14 bits live in 16-bit ring words, wider ones in 32-bit words)
  * sets the prefix width of the first: a few bits make ties the rule (tests); wave_per_string = 3 keeps 32-bit words at any width.    */
 int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);

@@ -308,6 +308,7 @@ extern "C" int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string)
 	ctx->sketch_wave_only = wave_per_string == 1;
 	ctx->sketch_ring64 = wave_per_string == 2;
 	ctx->sketch_ring32_only = wave_per_string == 3;
+	ctx->sketch_lane_always = wave_per_string >= 2;
 	return MCOM_OK;
 }
 extern "C" int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits)

@@ -415,8 +415,10 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, &chars, d_off + n, 8));
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	}
-	// millions of short strings: one lane per string (sketch_scan.hip); wide windows and very long strings stay with the wave per string
-	if (!ctx->sketch_wave_only) {
+	// millions of short strings: one lane per string (sketch_scan.hip); wide windows and very long strings stay with the wave per string,
+	// and so does a handful of strings (the last merge rounds sketch a few hundred segments: a lane needs ~95 ns per base, 0.35 ms
+	// for the longest whatever their number, where 8192 waves are all resident and go through it 128 bases at a time)
+	if (!ctx->sketch_wave_only && (n > 8192 || ctx->sketch_lane_always)) {
 		const int rs = mcom_sketch_strings_scan(ctx, d_seq, d_off, d_off_end, chars, d_ids, n, w, k, limit, d_moff, d_out, cap, h_total);
 		if (rs != -1) return rs;
 	}
@@ -818,28 +820,28 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 // ------------------------------------------------------------------------------------------------
 // Round 4, second cut: a query minimizer of a contig that came through the round before unmerged (id >= n_new) can only pass with a
 // NEW contig (k_fn_eval's comment), i.e. through a key that a new contig has in the index.  k_fn_newkeys marks those keys in a bit
-// map (2^FN_KEY_BITS bits, L2 resident); such a query probes the table only where the map says so and lists no pair otherwise --
-// the pairs left out are exactly pairs k_fn_eval would fail without looking.
-#define FN_KEY_BITS 26
-__device__ __forceinline__ uint32_t fn_key_bit(uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> (64 - FN_KEY_BITS)); }
-__global__ void k_fn_newkeys(const mcom_mm128 *__restrict__ irec, size_t n, uint32_t n_new, uint32_t *__restrict__ keymap)
+// map (about 16 bits per such key, 128 KB .. 8 MB: L2 resident); such a query
+// probes the table only where the map says so and lists no pair otherwise -- the pairs left out are exactly pairs k_fn_eval would
+// fail without looking.
+__device__ __forceinline__ uint32_t fn_key_bit(uint64_t x, int kbits) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> (64 - kbits)); }
+__global__ void k_fn_newkeys(const mcom_mm128 *__restrict__ irec, size_t n, uint32_t n_new, int kbits, uint32_t *__restrict__ keymap)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const mcom_mm128 t = irec[i];
-	if ((uint32_t)(t.y >> 32) < n_new) { const uint32_t h = fn_key_bit(t.x); atomicOr(&keymap[h >> 5], 1u << (h & 31)); }
+	if ((uint32_t)(t.y >> 32) < n_new) { const uint32_t h = fn_key_bit(t.x, kbits); atomicOr(&keymap[h >> 5], 1u << (h & 31)); }
 }
 __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t region, uint32_t bbits, const mcom_mm128 *__restrict__ q, size_t nq,
-                            uint32_t n_new, const uint32_t *__restrict__ keymap, uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
+                            uint32_t n_new, int kbits, const uint32_t *__restrict__ keymap, uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
 	const mcom_mm128 t = q[i];
 	uint32_t s = 0, c = 0;
 	bool look = t.x != U64MAX;
-	if (look && n_new && (uint32_t)(t.y >> 32) >= n_new) { const uint32_t h = fn_key_bit(t.x); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
+	if (look && n_new && (uint32_t)(t.y >> 32) >= n_new) { const uint32_t h = fn_key_bit(t.x, kbits); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
 	if (look) mcom_table_find_any(slots, log2cap, region, bbits, t.x, s, c);
-	hits[i] = c; first[i] = s;                     // the later passes read these instead of probing the table again
+	hits[i] = c; if (c) first[i] = s;              // the later passes read these instead of probing the table again (first: only where there are hits)
 }
 // Round 4: the evaluation runs one thread per (query, hit) PAIR.  Three queries in four have no hit, and the others between one
 // and thousands: with a thread per query (rounds 1-3) a wave ran as long as its busiest lane while most lanes had nothing to do, and
@@ -909,7 +911,11 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	const size_t nq1 = n_query + 1;
 	const size_t hit_b = (nq1 * 4 + 255) & ~(size_t)255;
 	const size_t scr1_b = (mcom_scan_scratch_elems(nq1) * 4 + 1024 + 255) & ~(size_t)255;
-	const size_t map_b = n_new ? (size_t)1 << (FN_KEY_BITS - 3) : 0;
+	// ~16 map bits per key of a new contig (a contig has about six keys in the index), 8 MB at most: a map that stays in the L2s beats a
+	// sparser one that does not (measured: 32 bits per key up to 32 MB made the rounds with a million new contigs 7 % slower)
+	int kbits = 20;
+	while (kbits < 26 && ((uint64_t)1 << kbits) < (uint64_t)n_new * 6 * 16) ++kbits;
+	const size_t map_b = n_new ? (size_t)1 << (kbits - 3) : 0;
 	int rc = mcom_ws_reserve(ctx, hit_b + scr1_b + map_b);
 	if (rc) return rc;
 	uint32_t *hits = (uint32_t*)ctx->ws;
@@ -920,9 +926,9 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
 	if (n_new) {
 		MCOM_HIP(ctx, hipMemsetAsync(keymap, 0, map_b, ctx->stream));
-		if (mi->n) MCOM_LAUNCH(k_fn_newkeys, dim3((unsigned)((mi->n + 255) / 256)), dim3(256), 0, ctx->stream, mi->rec, mi->n, n_new, keymap);
+		if (mi->n) MCOM_LAUNCH(k_fn_newkeys, dim3((unsigned)((mi->n + 255) / 256)), dim3(256), 0, ctx->stream, mi->rec, mi->n, n_new, kbits, keymap);
 	}
-	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, n_new, keymap, hits, first);
+	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, n_new, kbits, keymap, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));

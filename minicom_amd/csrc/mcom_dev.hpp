@@ -40,6 +40,7 @@ struct mcom_ctx {
 	uint32_t bs_cap = 0;
 	// contig sketch: true = always the wave-per-string kernel (tests compare the two)
 	bool sketch_wave_only = false;
+	bool sketch_lane_always = false;                        // (test hook: the lane-per-string kernel for a handful of strings too)
 	// ... 2 = the lane-per-string kernel with the ring of 64-bit hashes even where the ring of 32-bit prefixes applies (k odd); and the
 	// prefix width of the latter (tests narrow it to a few bits so that prefix ties, one in 2^30 otherwise, happen all the time)
 	bool sketch_ring64 = false, sketch_ring32_only = false; int sketch_prefix_bits = 14;   // (measured: 14 bits in 16-bit words 8.0 ms, 30 bits in 32-bit words 9.3, 12 bits 9.4, 64-bit ring 11.8)

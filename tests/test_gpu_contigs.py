@@ -36,9 +36,19 @@ def _recs(t):
     return records_to_numpy(t)
 
 
-def test_sketch_contigs_equals_reference_vectors(ctx, kat):
-    """mm_sketch_lh_ori golden outputs (including N runs, palindromes, w = 1)."""
+@pytest.mark.parametrize("kernel", ["default", "lane"])
+def test_sketch_contigs_equals_reference_vectors(ctx, kat, kernel):
+    """mm_sketch_lh_ori golden outputs (including N runs, palindromes, w = 1), through the default choice of kernel (a wave per string
+    for so few strings) and through the lane-per-string kernel that sketches the millions."""
     import torch
+    ctx.set_sketch_kernel(4 if kernel == "lane" else 0)
+    try:
+        _sketch_reference_vectors(ctx, kat, torch)
+    finally:
+        ctx.set_sketch_kernel(0)
+
+
+def _sketch_reference_vectors(ctx, kat, torch):
     by = {}
     for t in kat["LH"]:
         by.setdefault((t["w"], t["k"]), []).append(t)
@@ -201,7 +211,7 @@ def test_idx_build_keeps_the_reference_order_inside_big_buckets(ctx, n, nkeys, n
     idx.close()
 
 
-@pytest.mark.parametrize("kernel", ["default", "wave", "ring64", "prefix3", "prefix9", "prefix30", "ring32prefix5"])
+@pytest.mark.parametrize("kernel", ["default", "lane", "wave", "ring64", "prefix3", "prefix9", "prefix30", "ring32prefix5"])
 @pytest.mark.parametrize("w,k", [(44, 31), (19, 31), (3, 17), (10, 16), (128, 21), (5, 8), (1, 9), (7, 31), (4, 24), (64, 31), (20, 13), (33, 25)])
 def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, kernel):
     """Tie-rich strings (short-period repeats, homopolymers, copied blocks, ambiguous bases): equal hashes inside a
@@ -214,8 +224,10 @@ def test_sketch_contigs_with_repeats_and_ties_equals_oracle(ctx, w, k, kernel):
         pytest.skip("w = 128 takes the wave-per-string kernel anyway")
     if "prefix" in kernel and k % 2 == 0:
         pytest.skip("the prefix ring is for odd k")
-    ctx.set_sketch_kernel({"default": 0, "wave": 1, "ring64": 2, "ring32prefix5": 3}.get(kernel, 0))        # 3: 32-bit ring words whatever the prefix width
+    ctx.set_sketch_kernel({"default": 0, "wave": 1, "ring64": 2, "ring32prefix5": 3}.get(kernel, 4))        # 3: 32-bit ring words whatever the prefix width; 4: a lane per string for these 160 strings too (0 gives them a wave each)
     ctx.set_sketch_prefix_bits(5 if kernel == "ring32prefix5" else int(kernel[6:]) if kernel.startswith("prefix") else 14)
+    if kernel == "lane" and k % 2 == 0:
+        pytest.skip("the same kernel as ring64 for even k")
     from test_gpu_resketch import _string
     rng = np.random.default_rng(100 * w + k)
     refs = []
