@@ -124,23 +124,34 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 	__syncthreads();
 	// rs_insertsort of every range of at most 64 positions among the bins [first bin .. ] of [rb, re): bin of position p = D[p]
 	// when by_bins, else the one range [rb, re) itself.  The ranks are final: the records are written out.
+	// (round 4: a chunk none of whose positions lies in a small bin is passed over -- at the levels where nearly everything shares one
+	// digit that is every chunk, and each cost two barriers and a gather of 192 keys; the three keys a lane gathers travel together)
 	auto finish_small = [&](uint32_t rb, uint32_t re, bool by_bins) {
 		for (uint32_t base = rb; base < re; base += 64) {
+			const uint32_t p = base + (uint32_t)lane;
+			uint32_t b0 = rb, e0 = re;
+			if (by_bins && p < re) { const uint32_t d = D[p]; e0 = be[d]; b0 = d ? be[d - 1] : rb; }
+			const bool small = p < re && e0 - b0 <= 64;
+			if (!__any(small)) continue;                                         // uniform: the workgroup is one wave
 			const uint32_t w0 = base >= rb + 64 ? base - 64 : rb;                // the window starts at most 64 positions before the chunk
 			const uint32_t w1 = base + 128 < re ? base + 128 : re;
 			__syncthreads();
-			for (uint32_t q = w0 + lane; q < w1; q += 64) KW[q - w0] = rec[I[q]].x;
+			{
+				const uint32_t q0 = w0 + lane, q1 = q0 + 64, q2 = q0 + 128;
+				uint64_t k0 = 0, k1 = 0, k2 = 0;
+				if (q0 < w1) k0 = rec[I[q0]].x;
+				if (q1 < w1) k1 = rec[I[q1]].x;
+				if (q2 < w1) k2 = rec[I[q2]].x;
+				if (q0 < w1) KW[q0 - w0] = k0;
+				if (q1 < w1) KW[q1 - w0] = k1;
+				if (q2 < w1) KW[q2 - w0] = k2;
+			}
 			__syncthreads();
-			const uint32_t p = base + (uint32_t)lane;
-			if (p < re) {
-				uint32_t b0 = rb, e0 = re;
-				if (by_bins) { const uint32_t d = D[p]; e0 = be[d]; b0 = d ? be[d - 1] : rb; }
-				if (e0 - b0 <= 64) {
-					const uint64_t mine = KW[p - w0];
-					uint32_t rank = b0;
-					for (uint32_t q = b0; q < e0; ++q) { const uint64_t k = KW[q - w0]; rank += (k < mine || (k == mine && q < p)) ? 1u : 0u; }
-					out[beg + rank] = rec[I[p]];
-				}
+			if (small) {
+				const uint64_t mine = KW[p - w0];
+				uint32_t rank = b0;
+				for (uint32_t q = b0; q < e0; ++q) { const uint64_t k = KW[q - w0]; rank += (k < mine || (k == mine && q < p)) ? 1u : 0u; }
+				out[beg + rank] = rec[I[p]];
 			}
 		}
 	};
@@ -155,7 +166,13 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 		// rs_sort (ksort.h:123-152): digits, histogram and bin bounds by all lanes
 		for (int q = lane; q < 256; q += 64) be[q] = 0;
 		__syncthreads();
-		for (uint32_t i = rb + lane; i < re; i += 64) { const uint32_t d = (uint32_t)(rec[I[i]].x >> s) & 255u; D[i] = (uint8_t)d; atomicAdd(&be[d], 1u); }
+		for (uint32_t i0 = rb + lane; i0 < re; i0 += 256) {                      // four gathers in flight per lane
+			uint64_t kx[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + 64u * u; kx[u] = i < re ? rec[I[i]].x : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + 64u * u; if (i < re) { const uint32_t d = (uint32_t)(kx[u] >> s) & 255u; D[i] = (uint8_t)d; atomicAdd(&be[d], 1u); } }
+		}
 		__syncthreads();
 		{
 			const uint32_t c0 = be[4 * lane], c1 = be[4 * lane + 1], c2 = be[4 * lane + 2], c3 = be[4 * lane + 3];
