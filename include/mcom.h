@@ -161,7 +161,8 @@ int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
                       uint64_t total_words, uint64_t *d_cbits);
 /* The same for the set after a merge round (cp_cluster, kthread_cb.c:397-434: the merged contigs first, then the untouched ones
  * in their order): contigs [0, n_first) are packed from their strings, contig n_first + u takes the packed words of contig
- * d_keepidx[u] of the set before the round (d_cbits_old / d_coff_old).  Same words as mcom_pack_contigs.                        */
+ * d_keepidx[u] of the set before the round (d_cbits_old / d_coff_old).  Same words as mcom_pack_contigs; d_cbits has room for
+ * total_words + 2 words and the two behind the set are cleared (a window at the very end of the last contig reads past it).      */
 int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                              uint64_t total_words, uint32_t n_first, const uint64_t *d_cbits_old, const uint64_t *d_coff_old,
                              const uint32_t *d_keepidx, uint64_t *d_cbits);

@@ -113,6 +113,29 @@ void mcom_dfree(void *p)
 	g_blk_live.erase(it);
 }
 
+void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes)
+{
+	const size_t need = (bytes + 7) & ~(size_t)7;
+	if (need && need <= 4096) {
+		if (!ctx->zpool) {
+			if (hipMalloc((void**)&ctx->zpool, mcom_ctx::ZPOOL_BYTES) != hipSuccess) { ctx->zpool = nullptr; (void)hipGetLastError(); }
+			ctx->zpool_off = mcom_ctx::ZPOOL_BYTES;                                    // (cleared by its first use)
+		}
+		if (ctx->zpool) {
+			if (ctx->zpool_off + need > mcom_ctx::ZPOOL_BYTES) {
+				if (hipMemsetAsync(ctx->zpool, 0, mcom_ctx::ZPOOL_BYTES, ctx->stream) != hipSuccess) { (void)hipGetLastError(); goto plain; }
+				ctx->zpool_off = 0;
+			}
+			void *p = ctx->zpool + ctx->zpool_off;
+			ctx->zpool_off += need;
+			return p;
+		}
+	}
+plain:
+	if (!fallback || hipMemsetAsync(fallback, 0, bytes, ctx->stream) != hipSuccess) { ctx->err = "clearing a counter failed"; return nullptr; }
+	return fallback;
+}
+
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes)
 {
 	if (bytes <= ctx->ws_bytes) return MCOM_OK;
@@ -169,6 +192,7 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 	}
 	if (ctx->pin) (void)hipHostFree(ctx->pin);
 	if (ctx->scan_parts) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->scan_parts); }
+	if (ctx->zpool) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->zpool); }
 	if (ctx->poison) (void)hipHostFree((void*)ctx->poison);
 	delete ctx;
 }
@@ -176,6 +200,7 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 extern "C" int mcom_set_stream(mcom_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return MCOM_E_ARG;
+	if (ctx->zpool && ctx->stream != (hipStream_t)hip_stream) { (void)hipStreamSynchronize(ctx->stream); ctx->zpool_off = mcom_ctx::ZPOOL_BYTES; }   // (the pool's order is the stream's)
 	ctx->stream = (hipStream_t)hip_stream;
 	return MCOM_OK;
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, 
 // can only make a live edge wait one more round (every edge is stale at most once).
 __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__restrict__ pairs, uint32_t n, uint8_t *matched, uint8_t *dead,
                                                          unsigned long long *best, uint32_t n_contigs, uint32_t *__restrict__ sel, unsigned int *state, int max_rounds,
-                                                         unsigned int *poison)
+                                                         unsigned int *poison, unsigned int *__restrict__ host_copy)
 {
 	// state[0] = barrier counter; on a line of their own: state[32 + round % 3] = "some edge bid in this round", state[36] = rounds with bids,
 	// state[37] = did not settle; state[64 ...] = the release words
@@ -78,7 +78,11 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 		if (round > 1) {
 			const bool any = *(volatile unsigned int*)(state + 32 + (round - 1) % 3) != 0;
 			if (!any || round - 1 >= max_rounds) {
-				if (blockIdx.x == 0 && threadIdx.x == 0) { state[36] = (unsigned int)(any ? round - 1 : round - 2); state[37] = any ? 1u : 0u; }
+				if (blockIdx.x == 0 && threadIdx.x == 0) {
+					const unsigned int r36 = (unsigned int)(any ? round - 1 : round - 2), r37 = any ? 1u : 0u;
+					state[36] = r36; state[37] = r37;
+					if (host_copy) { host_copy[0] = r36; host_copy[1] = r37; }               // (pinned memory: the read-back needs no copy, scan.hip)
+				}
 				return;
 			}
 		}
@@ -120,14 +124,28 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 	}
 }
 
+// the flags of the contigs and the kernel's own arrays cleared in ONE launch (two or three fills before: the runtime splits a fill whose
+// size is not a multiple of four)
+__global__ void k_claim_clear(uint8_t *__restrict__ flag, size_t n_flag, uint4 *__restrict__ base16, size_t n16)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = t; i < n16; i += stride) base16[i] = make_uint4(0, 0, 0, 0);
+	const size_t head = ((16 - ((uintptr_t)flag & 15)) & 15) < n_flag ? ((16 - ((uintptr_t)flag & 15)) & 15) : n_flag;   // bytes in front of the first 16-byte boundary
+	const size_t mid16 = (n_flag - head) / 16;
+	uint4 *f16 = (uint4*)(flag + head);
+	for (size_t i = t; i < mid16; i += stride) f16[i] = make_uint4(0, 0, 0, 0);
+	if (t < head) flag[t] = 0;
+	const size_t tail0 = head + mid16 * 16;
+	if (t < n_flag - tail0) flag[tail0 + t] = 0;
+}
+
 extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t n_pairs, size_t n_contigs, int max_rounds, uint32_t *d_jobs,
                                 uint8_t *d_flag, uint64_t *h_nj, int *h_rounds)
 {
 	if (!ctx || !h_nj) return MCOM_E_ARG;
 	*h_nj = 0; if (h_rounds) *h_rounds = 0;
 	if (n_contigs && !d_flag) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	if (n_contigs) MCOM_HIP(ctx, hipMemsetAsync(d_flag, 0, n_contigs, ctx->stream));
-	if (n_pairs == 0) return MCOM_OK;
+	if (n_pairs == 0) { if (n_contigs) MCOM_HIP(ctx, hipMemsetAsync(d_flag, 0, n_contigs, ctx->stream)); return MCOM_OK; }
 	if (!d_pairs || !d_jobs || n_pairs >= (1ull << 32) - 1 || n_contigs >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "bad claim arguments");
 	int rc = mcom_scan_prepare(ctx);                                               // (the poison flag)
 	if (rc) return rc;
@@ -141,7 +159,11 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	uint32_t *sel = (uint32_t*)(base + best_b + dead_b);
 	unsigned int *state = (unsigned int*)(base + best_b + dead_b + sel_b);
 	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4));
-	MCOM_HIP(ctx, hipMemsetAsync(base, 0, best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4), ctx->stream));   // best = 0: below every bid; dead, sel, state = 0
+	{   // best = 0: below every bid; dead, sel, state = 0; and the contigs' flags
+		const size_t n16 = (best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4)) / 16;
+		size_t cb = (n16 + 255) / 256; if (cb > (size_t)ctx->n_cu * 8) cb = (size_t)ctx->n_cu * 8;
+		MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
+	}
 	const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
 	unsigned int hs[2] = {0, 0};
 	{
@@ -151,7 +173,10 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 		uint32_t n32 = (uint32_t)n_pairs;
 		// a plain launch: what a grid barrier needs is that every workgroup is resident, which the grid's size guarantees (one workgroup
 		// per CU) and a cooperative launch would only check (rocprofv3's kernel trace crashed on the cooperative one)
-		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, max_rounds, ctx->d_poison);
+		uint32_t ring = 0;
+		unsigned int *host_copy = (unsigned int*)mcom_ring_slot(ctx, &ring);
+		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, max_rounds, ctx->d_poison, host_copy);
+		if (host_copy) mcom_ring_register(ctx, state + 36, 8, ring);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state + 36, 8));
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));

@@ -329,8 +329,8 @@ extern "C" int mcom_group_consensus(mcom_ctx *ctx, const uint64_t *d_packed, uin
 	const uint32_t n_rest = n_groups - n_small;
 	const uint32_t *glist = perm ? perm + n_small : nullptr;
 	if (n_rest == 0) { MCOM_HIP(ctx, mcom_stream_sync(ctx)); mcom_dfree(perm); return MCOM_OK; }
-	unsigned int *big = (unsigned int*)ctx->ws;
-	hipError_t er = hipMemsetAsync(big, 0, 4, ctx->stream);
+	unsigned int *big = (unsigned int*)mcom_zeroed(ctx, ctx->ws, 4);
+	hipError_t er = big ? hipSuccess : hipErrorUnknown;
 	if (er == hipSuccess) {
 		McomProfScope ps_(ctx, PROF_CONSENSUS);
 #define MCOM_GC(NU) case NU: MCOM_LAUNCH((k_group_consensus_reg<NU>), dim3(n_rest), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, \
@@ -498,9 +498,10 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 {
 	if (n_tiles == 0) return MCOM_OK;
 	// the flag lives behind everything the callers keep in the workspace (they reserve their own part first)
-	unsigned int *big = nullptr;
-	MCOM_HIP(ctx, mcom_dmalloc((void**)&big, 256));
-	MCOM_HIP(ctx, hipMemsetAsync(big, 0, 4, ctx->stream));
+	unsigned int *big0 = nullptr;
+	MCOM_HIP(ctx, mcom_dmalloc((void**)&big0, 256));
+	unsigned int *big = (unsigned int*)mcom_zeroed(ctx, big0, 4);
+	if (!big) { mcom_dfree(big0); return mcom_fail(ctx, MCOM_E_HIP, "clear"); }
 	{ McomProfScope ps_(ctx, PROF_CONSENSUS);
 	MCOM_LAUNCH(k_merge_consensus_reg, dim3(n_tiles), dim3(64), 0, ctx->stream, d_packed, mcom_words_per_read(L), d_members, d_job_off, d_ref_off,
 	                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist); }
@@ -513,7 +514,7 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 		                   d_tile_job, d_tile_idx, n_tiles, L, d_refs, d_reg_lo, d_reg_hi, big, d_tlist);
 		e1 = mcom_stream_sync(ctx);
 	}
-	mcom_dfree(big);
+	mcom_dfree(big0);
 	if (e1 != hipSuccess) return mcom_fail(ctx, MCOM_E_HIP, "merge consensus: %s", hipGetErrorString(e1));
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;

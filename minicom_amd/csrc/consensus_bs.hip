@@ -369,8 +369,8 @@ int mcom_group_consensus_small(mcom_ctx *ctx, const uint64_t *d_packed, uint64_t
 	*d_perm_out = nullptr; *n_small = 0;
 	uint32_t *perm = nullptr;
 	if (mcom_dmalloc(&perm, ((size_t)n_groups + 128) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "group order");
-	uint32_t *bins = perm + n_groups, *cursor = bins + 40;
-	hipError_t er = hipMemsetAsync(bins, 0, 80 * 4, ctx->stream);
+	uint32_t *bins = (uint32_t*)mcom_zeroed(ctx, perm + n_groups, 80 * 4), *cursor = bins ? bins + 40 : nullptr;
+	hipError_t er = bins ? hipSuccess : hipErrorUnknown;
 	const unsigned blocks = std::min<unsigned>((n_groups + 255) / 256, BS_ORDER_GRID);
 	if (er == hipSuccess) {
 		MCOM_LAUNCH(k_bs_sizes, dim3(blocks), dim3(256), 0, ctx->stream, d_group_off, n_groups, bins);

@@ -560,8 +560,9 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 // instead of a byte.
 __global__ __launch_bounds__(256) void k_packed_carry(const uint64_t *__restrict__ cbits_old, const uint64_t *__restrict__ coff_old,
                                                       const uint32_t *__restrict__ keepidx, size_t nkeep, size_t first,
-                                                      const uint64_t *__restrict__ coff_new, uint64_t *__restrict__ cbits_new)
+                                                      const uint64_t *__restrict__ coff_new, uint64_t *__restrict__ cbits_new, uint64_t total_words)
 {
+	if (blockIdx.x == 0 && threadIdx.x < 2) cbits_new[total_words + threadIdx.x] = 0;   // the two words behind the set (a window at its very end reads past it)
 	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;       // sixteen lanes per contig
 	if (u >= nkeep) return;
 	const int lane = threadIdx.x & 15;
@@ -583,7 +584,8 @@ extern "C" int mcom_pack_contigs_merged(mcom_ctx *ctx, const uint8_t *d_seq, con
 	if (n_first) MCOM_LAUNCH(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n_first);
 	const size_t nkeep = n - n_first;
 	if (nkeep) MCOM_LAUNCH(k_packed_carry, dim3((unsigned)((nkeep * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_cbits_old, d_coff_old, d_keepidx, nkeep,
-	                              (size_t)n_first, d_coff, d_cbits);
+	                              (size_t)n_first, d_coff, d_cbits, total_words);
+	else MCOM_HIP(ctx, hipMemsetAsync(d_cbits + total_words, 0, 16, ctx->stream));
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }
@@ -667,8 +669,8 @@ extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 
 	uint32_t mx = 0;
 	for (uint32_t q = 0; q < nb; ++q) mx = std::max(mx, hb[q + 1] - hb[q]);
 	if (h_max_bucket) *h_max_bucket = mx;
-	uint32_t *ovf = (uint32_t*)(base + sort_b);
-	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
+	uint32_t *ovf = (uint32_t*)mcom_zeroed(ctx, base + sort_b, 4);
+	if (!ovf) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 	if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
 		mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
 		rc = mcom_flag_sort_buckets(ctx, part, tmp, mi->part_bst, nb, b, mx, ovf);
@@ -836,6 +838,7 @@ __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
+	if (i == 0) hits[nq] = 0;                     // (the scan over nq + 1 counts leaves the number of pairs there)
 	const mcom_mm128 t = q[i];
 	uint32_t s = 0, c = 0;
 	bool look = t.x != U64MAX;
@@ -930,7 +933,6 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	}
 	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, n_new, kbits, keymap, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, hipMemsetAsync(hits + n_query, 0, 4, ctx->stream));
 	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
 	uint32_t n_pairs = 0;

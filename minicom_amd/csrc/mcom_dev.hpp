@@ -55,6 +55,10 @@ struct mcom_ctx {
 	// (an entry stands only while no other kernel has been launched and the stream has not been synchronised since its scan: launch_gen)
 	struct ScanTotal { const void *last; uint32_t bytes, slot, gen; } scan_last[8] = {}; uint32_t scan_last_at = 0, launch_gen = 1;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
+	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
+	// a whole when it is used up, instead of one 4-byte fill launch in front of every such kernel (mcom_zeroed, api.hip)
+	enum { ZPOOL_BYTES = 64 * 1024 };
+	unsigned char *zpool = nullptr; size_t zpool_off = 0;
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
 	struct PinWait { void *dst; size_t off, bytes; const void *from = nullptr; };   // from != nullptr: the value waits there (a scan's total), not in the page
 	unsigned char *pin = nullptr; size_t pin_off = 0;
@@ -95,6 +99,12 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
 hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes);
 hipError_t mcom_stream_sync(mcom_ctx *ctx);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
+// `bytes` (<= 4096, rounded up to 8) of zeroed device memory for a kernel of the context's stream to count into; the caller reads what it
+// needs back before it returns (the pool is cleared and reused after a few thousand requests).  Without the pool: `fallback` cleared by a
+// fill, as before.  nullptr: the fill failed.
+void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes);
+unsigned long long *mcom_ring_slot(mcom_ctx *ctx, uint32_t *slot);                      // scan.hip: a kernel's one-value result straight into pinned memory
+void mcom_ring_register(mcom_ctx *ctx, const void *d_result, uint32_t bytes, uint32_t slot);
 // recycled device blocks for the library's own objects (api.hip)
 hipError_t mcom_dmalloc(void **out, size_t bytes);
 void mcom_dfree(void *p);

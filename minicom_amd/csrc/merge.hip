@@ -97,8 +97,8 @@ extern "C" int mcom_window_layout(mcom_ctx *ctx, const uint64_t *d_soff, size_t 
 	if (!d_soff) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_ws_reserve(ctx, al256(scan64_scratch_elems(n + 1) * 8) + 512);
 	if (rc) return rc;
-	unsigned long long *mx = (unsigned long long*)((char*)ctx->ws + al256(scan64_scratch_elems(n + 1) * 8));
-	MCOM_HIP(ctx, hipMemsetAsync(mx, 0, 8, ctx->stream));
+	unsigned long long *mx = (unsigned long long*)mcom_zeroed(ctx, (char*)ctx->ws + al256(scan64_scratch_elems(n + 1) * 8), 8);
+	if (!mx) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 	MCOM_LAUNCH(k_window_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_soff, n, L, d_woff, mx);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = scan64(ctx, d_woff, d_woff, n + 1, (uint64_t*)ctx->ws))) return rc;
@@ -204,8 +204,8 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	void *sortws = w.take<char>(mcom_sort_ws_bytes(total));
 	uint64_t *scr = w.take<uint64_t>(scan64_scratch_elems(nj + 1));
 	uint32_t *tiles = w.take<uint32_t>(MCOM_GROUP_SCRATCH(total));
-	unsigned long long *meta = w.take<unsigned long long>(4);               // [0] maxlen, [1] error flag
-	MCOM_HIP(ctx, hipMemsetAsync(meta, 0, 32, ctx->stream));
+	unsigned long long *meta = (unsigned long long*)mcom_zeroed(ctx, w.take<unsigned long long>(4), 32);   // [0] maxlen, [1] error flag
+	if (!meta) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 	MCOM_LAUNCH(k_job_fill, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, jobs, nj, d_mem, d_moff, d_jmoff, key_bits, rec,
 	                   (unsigned int*)(meta + 1));
 	MCOM_LAUNCH_CHECK(ctx);

@@ -144,7 +144,8 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	uint32_t *smoff = b_moff.get<uint32_t>(nj + 2);
 	RsCut *cut = b_cut.get<RsCut>(nj);
 	if (!plan || !seg_start || !seg_end || !d_chars || !smoff || !cut) return mcom_fail(ctx, MCOM_E_NOMEM, "resketch buffers");
-	MCOM_HIP(ctx, hipMemsetAsync(d_chars, 0, 8, ctx->stream));
+	d_chars = (unsigned long long*)mcom_zeroed(ctx, d_chars, 8);
+	if (!d_chars) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 	MCOM_LAUNCH(k_rs_plan, dim3((unsigned)std::min<size_t>((nj + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (const Job*)d_jobs, nj, d_soff, d_soff2, w, k, plan, seg_start,
 	                   seg_end, d_chars);
 	MCOM_LAUNCH_CHECK(ctx);

@@ -176,6 +176,22 @@ static int scan_one(mcom_ctx *ctx, const T *in, T *out, size_t n)
 	return MCOM_OK;
 }
 
+// The ring of pinned words for OTHER kernels whose result is one value written by one thread at their end (a fold's totals, the
+// claim kernel's round count): mcom_ring_slot before the launch says where the kernel stores the value beside its place in device
+// memory, mcom_ring_register after the launch makes mcom_d2h_async find it there -- no copy launch for the read-back.
+unsigned long long *mcom_ring_slot(mcom_ctx *ctx, uint32_t *slot)
+{
+	if (mcom_scan_prepare(ctx)) return nullptr;
+	if (++ctx->scan_epoch == 0) ctx->scan_epoch = 1;
+	*slot = ctx->scan_epoch % mcom_ctx::SCAN_TOTALS;
+	for (mcom_ctx::ScanTotal &t : ctx->scan_last) if (t.slot == *slot) t.last = nullptr;
+	return ctx->d_scan_tot + *slot;
+}
+void mcom_ring_register(mcom_ctx *ctx, const void *d_result, uint32_t bytes, uint32_t slot)      // bytes <= 8; right after the launch
+{
+	ctx->scan_last[ctx->scan_last_at++ % 8] = mcom_ctx::ScanTotal{d_result, bytes, slot, ctx->launch_gen};
+}
+
 // exported to the other translation units of the library (the scratch arguments are what rounds 1-3 needed: unused, kept so that
 // the callers' workspace layouts stay as they are)
 int mcom_scan_u32(mcom_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *) { return scan_one<uint32_t>(ctx, in, out, n); }

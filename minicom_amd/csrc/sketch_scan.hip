@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t ssc_len(const uint64_t *off, const uint64_t 
 // 0.36 ms on 8 M strings; the same for the cursors of k_ssc_order below).
 #define SSC_GRID 1024
 __global__ __launch_bounds__(256) void k_ssc_prepare(const uint64_t *__restrict__ off, const uint64_t *__restrict__ off_end, uint32_t n, int w,
-                                                     uint32_t *__restrict__ room, uint32_t *__restrict__ bins, uint32_t *__restrict__ longest)
+                                                     uint32_t *__restrict__ room, uint32_t *__restrict__ bins, uint32_t *__restrict__ longest, uint32_t *__restrict__ cnt)
 {
 	__shared__ uint32_t h[SSC_BINS];
 	__shared__ uint32_t mx;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_ssc_prepare(const uint64_t *__restrict_
 			room[t] = len ? 3u * len / (uint32_t)(w + 1) + 6u : 0u;
 			atomicAdd(&h[len >> 2 < SSC_BINS ? len >> 2 : SSC_BINS - 1], 1u);
 			lmx = len > lmx ? len : lmx;
-		} else if (t == n) room[t] = 0;
+		} else if (t == n) { room[t] = 0; cnt[t] = 0; }                     // (the scans over n + 1 entries find their last one cleared)
 	}
 	if (lmx) atomicMax(&mx, lmx);
 	__syncthreads();
@@ -585,7 +585,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	uint32_t *bins = (uint32_t*)(b0 + 5 * n4 + scr_b), *cursor = bins + SSC_BINS, *start = cursor + SSC_BINS, *misc = start + SSC_BINS;   // misc[0] longest, [1] overflowed strings
 	mcom_mm128 *tmp = (mcom_mm128*)(b0 + head);
 	MCOM_HIP(ctx, hipMemsetAsync(bins, 0, (3 * SSC_BINS + 16) * 4, ctx->stream));
-	MCOM_LAUNCH(k_ssc_prepare, dim3(std::min<uint32_t>((nn + 1 + 255) / 256, SSC_GRID)), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc);
+	MCOM_LAUNCH(k_ssc_prepare, dim3(std::min<uint32_t>((nn + 1 + 255) / 256, SSC_GRID)), dim3(256), 0, ctx->stream, d_off, d_off_end, nn, w, room, bins, misc, cnt);
 	MCOM_LAUNCH_CHECK(ctx);
 	if ((rc = mcom_scan_u32(ctx, room, base, n + 1, scr))) return rc;
 	MCOM_LAUNCH(k_ssc_starts, dim3(1), dim3(64), 0, ctx->stream, bins, start);
@@ -616,8 +616,7 @@ int mcom_sketch_strings_scan(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	ctx->sketch_strings += n;
-	MCOM_HIP(ctx, hipMemsetAsync(cnt + n, 0, 4, ctx->stream));
-	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;
+	if ((rc = mcom_scan_u32(ctx, cnt, d_moff, n + 1, scr))) return rc;                // (cnt[n] = 0: k_ssc_prepare)
 	uint32_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_moff + n, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));

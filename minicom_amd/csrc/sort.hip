@@ -424,11 +424,12 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 {
 	if (n == 0) return MCOM_OK;
 	const uint32_t ntiles = (uint32_t)(n / 3072 + 1);
-	uint32_t *start = d_scratch, *ovf = d_scratch + ((ntiles + 3) & ~1u);     // [count, pad, list of ntiles pairs, ntiles offsets]
-	uint2 *ovf_list = (uint2*)(ovf + 2);
-	uint32_t *ovf_dst = ovf + 2 + 2 * (size_t)ntiles;
+	uint32_t *start = d_scratch, *ovf0 = d_scratch + ((ntiles + 3) & ~1u);    // [count, pad, list of ntiles pairs, ntiles offsets]
+	uint2 *ovf_list = (uint2*)(ovf0 + 2);
+	uint32_t *ovf_dst = ovf0 + 2 + 2 * (size_t)ntiles;
 	MCOM_LAUNCH(k_tile_starts, dim3((ntiles + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_goff, ng, n, ntiles, start);
-	MCOM_HIP(ctx, hipMemsetAsync(ovf, 0, 4, ctx->stream));
+	uint32_t *ovf = (uint32_t*)mcom_zeroed(ctx, ovf0, 4);                       // the count (a zeroed word of the context's pool)
+	if (!ovf) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
@@ -590,7 +591,8 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 		{
 			McomProfScope ps_(ctx, PROF_RADIX_PASS);
 			MCOM_LAUNCH(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
-			MCOM_HIP(ctx, hipMemsetAsync(ovf_count, 0, 4, ctx->stream));
+			ovf_count = (uint32_t*)mcom_zeroed(ctx, ovf_count, 4);
+			if (!ovf_count) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 			MCOM_LAUNCH(k_segment_sort, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits,
 			                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf_count, ovf_list);
 			MCOM_LAUNCH_CHECK(ctx);

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_table_bucket(const mcom_mm128 *__restri
 	ulonglong2 *dst = (ulonglong2*)(slots + 2 * ((size_t)v * R));
 	for (uint32_t q = threadIdx.x; q < R; q += 256) dst[q] = make_ulonglong2(reg[2 * q], reg[2 * q + 1]);
 }
-__global__ __launch_bounds__(1024) void k_table_fold(const uint2 *__restrict__ per_bucket, uint32_t nb, uint32_t *__restrict__ meta /* [0] keys, [1] longest run */)
+__global__ __launch_bounds__(1024) void k_table_fold(const uint2 *__restrict__ per_bucket, uint32_t nb, uint32_t *__restrict__ meta /* [0] keys, [1] longest run */,
+                                                     uint32_t *__restrict__ host_copy)
 {
 	__shared__ uint32_t wsum[16], wmax[16];
 	uint32_t a = 0, m = 0;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(1024) void k_table_fold(const uint2 *__restrict__ p
 	if (threadIdx.x == 0) {
 		for (int w = 1; w < 16; ++w) { a += wsum[w]; m = wmax[w] > m ? wmax[w] : m; }
 		meta[0] = a; meta[1] = m;
+		if (host_copy) { host_copy[0] = a; host_copy[1] = m; }                      // (pinned memory: the read-back needs no copy, scan.hip)
 	}
 }
 
@@ -122,7 +124,10 @@ int mcom_table_fill_buckets(mcom_ctx *ctx, const mcom_mm128 *sorted, const uint3
 		MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_table_bucket<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
 		MCOM_LAUNCH(k_table_bucket<false>, dim3(nb), dim3(256), lds0, ctx->stream, sorted, bstart, (int)t->bbits, t->region, t->slots, per_bucket, bucket0, start_base);
 	}
-	MCOM_LAUNCH(k_table_fold, dim3(1), dim3(1024), 0, ctx->stream, per_bucket, nb, meta);
+	uint32_t ring = 0;
+	uint32_t *host_copy = (uint32_t*)mcom_ring_slot(ctx, &ring);
+	MCOM_LAUNCH(k_table_fold, dim3(1), dim3(1024), 0, ctx->stream, per_bucket, nb, meta, host_copy);
+	if (host_copy) mcom_ring_register(ctx, meta, 8, ring);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t hm[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hm, meta, 8));

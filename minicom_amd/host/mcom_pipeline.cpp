@@ -1433,7 +1433,6 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				if (!p->d_coff_words_alt.reserve(nn + 1) || !p->d_clen_alt.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, B.soff.p, nn, p->d_coff_words_alt.p, p->d_clen_alt.p, &tw2)))) return rc;
 				if (!p->d_cbits_alt.reserve(tw2 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits_alt.p + tw2, 0, 2 * 8, p->stream), "clear"))) return rc;
 				if ((rc = p->gpu(mcom_pack_contigs_merged(p->ctx, B.seq.p, B.soff.p, p->d_coff_words_alt.p, (uint32_t)nn, tw2, (uint32_t)nj, p->d_cbits.p, p->d_coff_words.p,
 				                                          d_keepidx.p, p->d_cbits_alt.p)))) return rc;
 				p->d_cbits.swap(p->d_cbits_alt); p->d_coff_words.swap(p->d_coff_words_alt); p->d_clen.swap(p->d_clen_alt);
