@@ -117,17 +117,21 @@ void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes)
 {
 	const size_t need = (bytes + 7) & ~(size_t)7;
 	if (need && need <= 4096) {
+		const size_t half = mcom_ctx::ZPOOL_BYTES / 2;
 		if (!ctx->zpool) {
 			if (hipMalloc((void**)&ctx->zpool, mcom_ctx::ZPOOL_BYTES) != hipSuccess) { ctx->zpool = nullptr; (void)hipGetLastError(); }
-			ctx->zpool_off = mcom_ctx::ZPOOL_BYTES;                                    // (cleared by its first use)
+			ctx->zpool_half = 1; ctx->zpool_used = half;                               // (the first request clears and takes half 0)
 		}
 		if (ctx->zpool) {
-			if (ctx->zpool_off + need > mcom_ctx::ZPOOL_BYTES) {
-				if (hipMemsetAsync(ctx->zpool, 0, mcom_ctx::ZPOOL_BYTES, ctx->stream) != hipSuccess) { (void)hipGetLastError(); goto plain; }
-				ctx->zpool_off = 0;
+			// two halves: when one is used up the OTHER one is cleared and taken, so what was handed out stays as its kernel left it for
+			// at least half a pool of further requests (a caller may read its counter back a few launches later, not thousands)
+			if (ctx->zpool_used + need > half) {
+				const int nh = ctx->zpool_half ^ 1;
+				if (hipMemsetAsync(ctx->zpool + (size_t)nh * half, 0, half, ctx->stream) != hipSuccess) { (void)hipGetLastError(); goto plain; }
+				ctx->zpool_half = nh; ctx->zpool_used = 0;
 			}
-			void *p = ctx->zpool + ctx->zpool_off;
-			ctx->zpool_off += need;
+			void *p = ctx->zpool + (size_t)ctx->zpool_half * half + ctx->zpool_used;
+			ctx->zpool_used += need;
 			return p;
 		}
 	}
@@ -200,7 +204,7 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 extern "C" int mcom_set_stream(mcom_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return MCOM_E_ARG;
-	if (ctx->zpool && ctx->stream != (hipStream_t)hip_stream) { (void)hipStreamSynchronize(ctx->stream); ctx->zpool_off = mcom_ctx::ZPOOL_BYTES; }   // (the pool's order is the stream's)
+	if (ctx->zpool && ctx->stream != (hipStream_t)hip_stream) { (void)hipStreamSynchronize(ctx->stream); ctx->zpool_used = mcom_ctx::ZPOOL_BYTES; }   // (the pool's order is the stream's: the next request clears a half on the new one)
 	ctx->stream = (hipStream_t)hip_stream;
 	return MCOM_OK;
 }

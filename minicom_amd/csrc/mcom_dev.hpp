@@ -58,7 +58,7 @@ struct mcom_ctx {
 	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
 	// a whole when it is used up, instead of one 4-byte fill launch in front of every such kernel (mcom_zeroed, api.hip)
 	enum { ZPOOL_BYTES = 64 * 1024 };
-	unsigned char *zpool = nullptr; size_t zpool_off = 0;
+	unsigned char *zpool = nullptr; size_t zpool_used = 0; int zpool_half = 0;
 	// small results on their way to the host (mcom_d2h_async): a page of pinned memory and who waits for what
 	struct PinWait { void *dst; size_t off, bytes; const void *from = nullptr; };   // from != nullptr: the value waits there (a scan's total), not in the page
 	unsigned char *pin = nullptr; size_t pin_off = 0;
@@ -100,7 +100,7 @@ hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t byte
 hipError_t mcom_stream_sync(mcom_ctx *ctx);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
 // `bytes` (<= 4096, rounded up to 8) of zeroed device memory for a kernel of the context's stream to count into; the caller reads what it
-// needs back before it returns (the pool is cleared and reused after a few thousand requests).  Without the pool: `fallback` cleared by a
+// needs back before it returns (the pool has two halves, cleared and taken in turn: a word keeps its value for thousands of further requests).  Without the pool: `fallback` cleared by a
 // fill, as before.  nullptr: the fill failed.
 void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes);
 unsigned long long *mcom_ring_slot(mcom_ctx *ctx, uint32_t *slot);                      // scan.hip: a kernel's one-value result straight into pinned memory

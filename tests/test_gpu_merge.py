@@ -312,3 +312,17 @@ def test_compact_live_and_window_layout(ctx):
     woff, nw, ml = ctx.window_layout(torch.from_numpy(soff).cuda(), 100)
     want = np.concatenate([[0], np.cumsum(np.maximum(lens - 99, 0))])
     assert np.array_equal(woff.cpu().numpy(), want) and nw == int(want[-1]) and ml == int(lens.max())
+
+
+def test_counters_from_the_zeroed_pool_survive_its_turnover(ctx):
+    """Kernels that count into one word (maxima, overflow counts, totals) take it from a pool of zeroed words with two halves that are
+    cleared and taken in turn (csrc/api.hip, mcom_zeroed): thousands of requests in a row -- several turnovers -- must all start from zero."""
+    import torch
+    rng = np.random.default_rng(5)
+    for it in range(9000):
+        n = 3 + it % 5
+        lens = rng.integers(10, 4000, n)
+        soff = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+        woff, nw, longest = ctx.window_layout(soff, 100)
+        assert longest == int(lens.max()), (it, longest, lens)
+        assert nw == int(np.maximum(lens - 99, 0).sum())
