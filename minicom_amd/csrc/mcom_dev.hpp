@@ -118,7 +118,8 @@ size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 // grouped records (x < 2^bits ascends from group to group) sorted by x inside their groups, in tiles of whole groups (sort.hip)
-#define MCOM_GROUP_SCRATCH(n) (4 * ((size_t)(n) / 3072 + 1) + 16)
+#define MCOM_GROUP_TILE 1280                 // records per tile of mcom_sort_groups_by_x: with a group of up to ~750 behind it a tile fits the small segment sort (2048)
+#define MCOM_GROUP_SCRATCH(n) (4 * ((size_t)(n) / MCOM_GROUP_TILE + 1) + 16)
 int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, size_t n, const uint64_t *d_goff, size_t ng, int bits, uint32_t *d_scratch);
 // consensus of one column range per job (consensus.hip)
 // d_tlist: the n_tiles tiles to do out of the tile arrays (NULL: all of them)

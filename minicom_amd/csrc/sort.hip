@@ -15,8 +15,8 @@
 #include <cmath>
 
 #define RS_THREADS 256
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)   // 4096 records = 64 KiB staged in LDS
+#define RS_ITEMS 8
+#define RS_TILE (RS_THREADS * RS_ITEMS)   // 2048 records = 32 KiB staged in LDS (4096: two workgroups per CU, 1.3 waves per SIMD -- SQ pass)
 
 struct KeySpec {
 	int mode;       // 0: key = x (64 bits);  1: composite minimizer key;  2: low kbits of x;  3: owner rank of the bucket
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const mcom_mm128 *
 // prefix can split) is left alone and sorted afterwards by the nine-pass sort, together with the others of its kind.
 #define SS_THREADS 256
 #define SS_CAP 4096
-#define SS_ITEMS (SS_CAP / SS_THREADS)
+#define SS_CAP_SMALL 2048                    // half the LDS: six workgroups per CU instead of three (2.6 waves per SIMD with the large form, SQ pass)
 
 __device__ __forceinline__ uint32_t msd_key(const KeySpec &ks, uint64_t x)
 {
@@ -185,14 +185,17 @@ __global__ void k_seg_bounds(const mcom_mm128 *__restrict__ s, size_t n, KeySpec
 	if (i == n - 1) for (uint32_t k = cur + 1; k <= nseg; ++k) seg_start[k] = (uint32_t)n;
 }
 
+template <int CAP>
 __global__ __launch_bounds__(SS_THREADS) void k_segment_sort(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out, const uint32_t *__restrict__ seg_start,
-                                                             KeySpec full, int sig_bits, uint32_t cap, uint32_t *__restrict__ ovf_count, uint2 *__restrict__ ovf_list)
+                                                             KeySpec full, int sig_bits, uint32_t cap, uint32_t *__restrict__ ovf_count, uint2 *__restrict__ ovf_list,
+                                                             const uint2 *__restrict__ seg_list = nullptr /* the segments by their bounds instead of seg_start */)
 {
-	__shared__ uint64_t keys[SS_CAP];
-	__shared__ uint16_t idx[2][SS_CAP];
+	constexpr int SS_ITEMS = CAP / SS_THREADS;
+	__shared__ uint64_t keys[CAP];
+	__shared__ uint16_t idx[2][CAP];
 	__shared__ uint32_t wcnt[SS_THREADS / 64][256];
 	__shared__ uint32_t wsum[SS_THREADS / 64];
-	const uint32_t s0 = seg_start[blockIdx.x], n = seg_start[blockIdx.x + 1] - s0;
+	const uint32_t s0 = seg_list ? seg_list[blockIdx.x].x : seg_start[blockIdx.x], n = (seg_list ? seg_list[blockIdx.x].y : seg_start[blockIdx.x + 1]) - s0;
 	if (n == 0) return;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	if (n == 1) { if (tid == 0) out[s0] = in[s0]; return; }
@@ -405,7 +408,7 @@ extern "C" int mcom_sort_by_rid(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n)
 
 // ---- records already grouped (the members of one merged contig, of one contig) need no global pass at all ------------------------
 // Groups goff[0..ng] of consecutive records, each to be sorted by x (whose high bits are the group's number, so that x
-// ascends from group to group): whole groups are packed into tiles of about 3000 records and every tile goes through
+// ascends from group to group): whole groups are packed into tiles of about 1300 records (3000 until round 4) and every tile goes through
 // k_segment_sort -- its "highest differing bit" test makes it sort just the key bits plus the few bits in which the group
 // numbers of one tile differ.  One read and one write of the records where the LSD sort of (group | key) made five passes.
 // A tile swollen by a group of thousands of records goes through the global passes instead.
@@ -414,7 +417,7 @@ __global__ void k_tile_starts(const uint64_t *__restrict__ goff, size_t ng, size
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t > ntiles) return;
 	if (t == ntiles) { start[t] = (uint32_t)n; return; }
-	const uint64_t target = (uint64_t)t * 3072ull;
+	const uint64_t target = (uint64_t)t * (uint64_t)MCOM_GROUP_TILE;
 	size_t lo = 0, hi = ng;                                                  // first group boundary at or behind the target
 	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (goff[mid] < target) lo = mid + 1; else hi = mid; }
 	start[t] = (uint32_t)(goff[lo] < n ? goff[lo] : n);
@@ -423,7 +426,7 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
                           uint32_t *d_scratch /* MCOM_GROUP_SCRATCH(n) uint32, 8-byte aligned */)
 {
 	if (n == 0) return MCOM_OK;
-	const uint32_t ntiles = (uint32_t)(n / 3072 + 1);
+	const uint32_t ntiles = (uint32_t)(n / MCOM_GROUP_TILE + 1);
 	uint32_t *start = d_scratch, *ovf0 = d_scratch + ((ntiles + 3) & ~1u);    // [count, pad, list of ntiles pairs, ntiles offsets]
 	uint2 *ovf_list = (uint2*)(ovf0 + 2);
 	uint32_t *ovf_dst = ovf0 + 2 + 2 * (size_t)ntiles;
@@ -433,8 +436,9 @@ int mcom_sort_groups_by_x(mcom_ctx *ctx, mcom_mm128 *d_in, mcom_mm128 *d_out, si
 	const KeySpec ks{0, 0, 64, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
 	{
 		McomProfScope ps_(ctx, PROF_RADIX_PASS);
-		MCOM_LAUNCH(k_segment_sort, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64,
-		                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf, ovf_list);
+		const uint32_t scap = ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP_SMALL;
+		if (scap <= SS_CAP_SMALL) MCOM_LAUNCH(k_segment_sort<SS_CAP_SMALL>, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64, scap, ovf, ovf_list);
+		else MCOM_LAUNCH(k_segment_sort<SS_CAP>, dim3(ntiles), dim3(SS_THREADS), 0, ctx->stream, d_in, d_out, start, ks, 64, scap, ovf, ovf_list);
 	}
 	MCOM_LAUNCH_CHECK(ctx);
 	uint32_t novf = 0;
@@ -587,18 +591,34 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 			MCOM_LAUNCH_CHECK(ctx);
 			src = dst; dst = dst == w.tmp ? d_sorted : w.tmp;
 		}
-		uint32_t novf = 0;
+		uint32_t novf = 0, scap_used = 0;
 		{
 			McomProfScope ps_(ctx, PROF_RADIX_PASS);
 			MCOM_LAUNCH(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
 			ovf_count = (uint32_t*)mcom_zeroed(ctx, ovf_count, 4);
 			if (!ovf_count) return mcom_fail(ctx, MCOM_E_HIP, "clear");
-			MCOM_LAUNCH(k_segment_sort, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits,
-			                   ctx->seg_cap ? ctx->seg_cap : (uint32_t)SS_CAP, ovf_count, ovf_list);
+			// segments of ~1500 records on average fit the small form; a read set whose average is higher keeps the large one
+			const uint32_t scap = ctx->seg_cap ? ctx->seg_cap : ((n >> B) <= 1600 ? (uint32_t)SS_CAP_SMALL : (uint32_t)SS_CAP);
+			scap_used = scap;
+			if (scap <= SS_CAP_SMALL) MCOM_LAUNCH(k_segment_sort<SS_CAP_SMALL>, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits, scap, ovf_count, ovf_list);
+			else MCOM_LAUNCH(k_segment_sort<SS_CAP>, dim3(nseg), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits, scap, ovf_count, ovf_list);
 			MCOM_LAUNCH_CHECK(ctx);
 		}
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, &novf, ovf_count, 4));
 		MCOM_HIP(ctx, mcom_stream_sync(ctx));
+		if (novf && !ctx->seg_cap && scap_used == (uint32_t)SS_CAP_SMALL && 2 * (size_t)novf <= (size_t)nseg) {
+			// the few segments between the small form's capacity and the large one's (a couple of dozen of 65 536 at an average of 1 500):
+			// the large form over their list; what it cannot hold either is listed behind them and goes on to the nine-pass sort
+			uint32_t *ovf2 = (uint32_t*)mcom_zeroed(ctx, ovf_count, 4);
+			if (!ovf2) return mcom_fail(ctx, MCOM_E_HIP, "clear");
+			{ McomProfScope ps_(ctx, PROF_RADIX_PASS);
+			MCOM_LAUNCH(k_segment_sort<SS_CAP>, dim3(novf), dim3(SS_THREADS), 0, ctx->stream, w.tmp, d_sorted, seg_start, full, sig_bits, (uint32_t)SS_CAP, ovf2, ovf_list + novf, (const uint2*)ovf_list); }
+			MCOM_LAUNCH_CHECK(ctx);
+			uint32_t novf2 = 0;
+			MCOM_HIP(ctx, mcom_d2h_async(ctx, &novf2, ovf2, 4));
+			MCOM_HIP(ctx, mcom_stream_sync(ctx));
+			ovf_list += novf; novf = novf2;
+		}
 		ctx->sort_overflow_segments += novf;
 		if (novf) {
 			// segments beyond the LDS arrays (one minimizer shared by thousands of reads): gathered, sorted by the whole key with the

@@ -137,6 +137,27 @@ def test_sort_group_segments_beyond_the_lds_sort(ctx):
         ctx.set_segment_capacity(0)
 
 
+def test_sort_group_segments_between_the_two_lds_capacities(ctx):
+    """The segment sort comes in two sizes (2048 records in half the LDS, 4096): a segment between the two leaves the small form and
+    is sorted by the large one from a list; only what exceeds that goes on to the nine-pass sort (sort.hip).  Five minimizers with
+    3 000 reads each, two with 20 000, ordinary records around them."""
+    rng = np.random.default_rng(12)
+    n = 90000
+    keys = rng.integers(0, 1 << 62, 7, dtype=np.uint64)
+    rec = np.zeros(n, dtype=[("x", "<u8"), ("y", "<u8")])
+    rec["x"] = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    at = 0
+    for q, cnt in enumerate([3000, 3000, 3000, 3000, 3000, 20000, 20000]):
+        rec["x"][at:at + cnt] = keys[q]; at += cnt
+    perm = rng.permutation(n)
+    rec["x"] = rec["x"][perm]
+    pos = rng.integers(30, 100, n).astype(np.uint64)
+    rec["y"] = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, n).astype(np.uint64)
+    before = ctx.counter("sort_overflow_segments")
+    _check_sort_group(ctx, rec, 100, 31, 31)
+    assert ctx.counter("sort_overflow_segments") - before == 2
+
+
 def test_sort_group_two_million_records_use_wider_msd_keys(ctx):
     """Above 2048 records per bucket the MSD key takes hash bits too (three global passes instead of two at 2^25 records)."""
     import oracle
