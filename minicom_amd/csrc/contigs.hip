@@ -655,13 +655,19 @@ extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 
 	if (rc) return rc;
 	char *base = (char*)ctx->ws;
 	mcom_mm128 *part = mi->rec + base_rec;
-	if (n) MCOM_HIP(ctx, hipMemcpyAsync(part, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
-	if (b == 0) return n ? mcom_sort_by_x(ctx, part, n, 2 * k, base) : MCOM_OK;             // stable: equal minimizers keep their input order
+	if (b == 0) {
+		if (n) MCOM_HIP(ctx, hipMemcpyAsync(part, d_rec, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+		return n ? mcom_sort_by_x(ctx, part, n, 2 * k, base) : MCOM_OK;                    // stable: equal minimizers keep their input order
+	}
 	const uint32_t nb = 1u << b;
 	if (!n) { MCOM_HIP(ctx, hipMemsetAsync(mi->part_bst, 0, ((size_t)nb + 1) * 4, ctx->stream)); return MCOM_OK; }
-	// records go to bucket x & (2^b-1) in input order (kthread_bucket.c:468-473), every bucket is then sorted by radix_sort_128x
-	rc = mcom_sort_by_low_bits(ctx, part, n, b, base);
-	if (!rc) rc = mcom_bucket_starts(ctx, part, n, b, mi->part_bst);
+	// records go to bucket x & (2^b-1) in input order (kthread_bucket.c:468-473), every bucket is then sorted by radix_sort_128x.
+	// Round 4: the passes read the caller's records and leave their result in the workspace, the bucket sort reads it there and
+	// writes the index (two copies of all records per build before: into the index in front of the passes, out of the workspace behind the sort)
+	mcom_mm128 *byb = nullptr;                                                    // the records by bucket (in the sort workspace)
+	if (d_rec == part) return mcom_fail(ctx, MCOM_E_ARG, "the records of an index part must not lie in the index itself");
+	rc = mcom_sort_by_low_bits_into_ws(ctx, d_rec, part, n, b, base, &byb);
+	if (!rc) rc = mcom_bucket_starts(ctx, byb, n, b, mi->part_bst);
 	if (rc) return rc;
 	std::vector<uint32_t> hb(nb + 1);
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hb.data(), mi->part_bst, (nb + 1) * 4));
@@ -671,11 +677,11 @@ extern "C" int mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 
 	if (h_max_bucket) *h_max_bucket = mx;
 	uint32_t *ovf = (uint32_t*)mcom_zeroed(ctx, base + sort_b, 4);
 	if (!ovf) return mcom_fail(ctx, MCOM_E_HIP, "clear");
-	if (2 * k - b <= 48) {                                              // compact elements: x >> b fits 48 bits
-		mcom_mm128 *tmp = (mcom_mm128*)base;                              // the sort workspace starts with n records of scratch
-		rc = mcom_flag_sort_buckets(ctx, part, tmp, mi->part_bst, nb, b, mx, ovf);
-		if (!rc) MCOM_HIP(ctx, hipMemcpyAsync(part, tmp, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
-	} else rc = mcom_flag_sort_ranges(ctx, part, mi->part_bst, nb, mx, ovf);
+	if (2 * k - b <= 48) rc = mcom_flag_sort_buckets(ctx, byb, part, mi->part_bst, nb, b, mx, ovf);   // compact elements: x >> b fits 48 bits
+	else {
+		MCOM_HIP(ctx, hipMemcpyAsync(part, byb, n * sizeof(mcom_mm128), hipMemcpyDeviceToDevice, ctx->stream));
+		rc = mcom_flag_sort_ranges(ctx, part, mi->part_bst, nb, mx, ovf);
+	}
 	if (rc) return rc;
 	uint32_t ov = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &ov, ovf, 4));

@@ -117,6 +117,7 @@ int mcom_scan_prepare(mcom_ctx *ctx);                    // the scratch of the o
 size_t mcom_sort_ws_bytes(size_t n);
 int mcom_sort_by_x(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
 int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, void *ws);
+int mcom_sort_by_low_bits_into_ws(mcom_ctx *ctx, const mcom_mm128 *d_src, mcom_mm128 *d_a, size_t n, int bits, void *ws, mcom_mm128 **d_sorted);
 // grouped records (x < 2^bits ascends from group to group) sorted by x inside their groups, in tiles of whole groups (sort.hip)
 #define MCOM_GROUP_TILE 1280                 // records per tile of mcom_sort_groups_by_x: with a group of up to ~750 behind it a tile fits the small segment sort (2048)
 #define MCOM_GROUP_SCRATCH(n) (4 * ((size_t)(n) / MCOM_GROUP_TILE + 1) + 16)

@@ -357,6 +357,31 @@ int mcom_sort_by_low_bits(mcom_ctx *ctx, mcom_mm128 *d_a, size_t n, int bits, vo
 	return MCOM_OK;
 }
 
+// the same from a source that is left alone, through d_a and the workspace's record buffer, the result IN THE WORKSPACE (*d_sorted):
+// what comes next (the index's bucket sort) reads it there and writes d_a -- no copy in front of the passes, none behind them
+int mcom_sort_by_low_bits_into_ws(mcom_ctx *ctx, const mcom_mm128 *d_src, mcom_mm128 *d_a, size_t n, int bits, void *ws, mcom_mm128 **d_sorted)
+{
+	SortWs w; sort_ws_layout(n, &w, (char*)ws);
+	*d_sorted = w.tmp;
+	if (n == 0) return MCOM_OK;
+	const KeySpec ks{2, 0, bits, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0}};
+	const int passes = (bits + 7) / 8;
+	const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+	const mcom_mm128 *src = d_src;
+	mcom_mm128 *dst = (passes & 1) ? w.tmp : d_a;                            // so that the last pass lands in the workspace
+	for (int p = 0; p < passes; ++p) {
+		McomProfScope ps_(ctx, PROF_RADIX_PASS);
+		MCOM_LAUNCH(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, n, ks, p, w.hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		int rc = scan_u32(ctx, w.hist, w.hist, (size_t)256 * nblocks, w.scratch);
+		if (rc) return rc;
+		MCOM_LAUNCH(k_radix_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, src, dst, n, ks, p, w.hist, nblocks);
+		MCOM_LAUNCH_CHECK(ctx);
+		src = dst; dst = dst == w.tmp ? d_a : w.tmp;
+	}
+	return MCOM_OK;
+}
+
 // ---- multi-GPU exchange -------------------------------------------------------------------
 // Bucket beta = x & (2^b - 1) belongs to rank (beta * ranks) >> b: contiguous bucket ranges in rank order, so that
 // "rank 0's groups, then rank 1's, ..." is the reference's visiting order (buckets ascending, kthread_bucket.c:531-560).
