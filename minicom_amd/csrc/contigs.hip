@@ -929,9 +929,11 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	if (rc) return rc;
 	uint32_t *hits = (uint32_t*)ctx->ws;
 	uint32_t *keymap = n_new ? (uint32_t*)((char*)ctx->ws + hit_b + scr1_b) : nullptr;
-	uint32_t *first = nullptr;
+	uint32_t *first = nullptr, *pair_off = nullptr;                            // pair_off: the scanned counts, in an allocation of its own (the workspace may move below)
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
+	if (mcom_dmalloc(&pair_off, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
+	FirstGuard off_guard{pair_off};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
 	if (n_new) {
 		MCOM_HIP(ctx, hipMemsetAsync(keymap, 0, map_b, ctx->stream));
@@ -939,23 +941,21 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	}
 	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, n_new, kbits, keymap, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
-	rc = mcom_scan_u32(ctx, hits, hits, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
+	rc = mcom_scan_u32(ctx, hits, pair_off, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
 	uint32_t n_pairs = 0;
-	MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_pairs, hits + n_query, 4));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &n_pairs, pair_off + n_query, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (h_counts) h_counts[0] = n_pairs;
 	if (n_pairs == 0) return MCOM_OK;
-	// pass 2: evaluate pairs; the workspace may move, so the offsets are kept in a fresh allocation
-	uint32_t *pair_off = nullptr, *pass = nullptr, *pair_q = nullptr;
+	// pass 2: evaluate pairs
+	uint32_t *pass = nullptr, *pair_q = nullptr;
 	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
-	hipError_t e = mcom_dmalloc(&pair_off, nq1 * 4);
-	if (e == hipSuccess) e = mcom_dmalloc(&pass, ((size_t)n_pairs + 1) * 4);
+	hipError_t e = mcom_dmalloc(&pass, ((size_t)n_pairs + 1) * 4);
 	if (e == hipSuccess) e = mcom_dmalloc(&pair_q, (size_t)n_pairs * 4);
-	auto cleanup = [&]() { if (pair_off) mcom_dfree(pair_off); if (pass) mcom_dfree(pass); if (pair_q) mcom_dfree(pair_q); };
+	auto cleanup = [&]() { if (pass) mcom_dfree(pass); if (pair_q) mcom_dfree(pair_q); };
 	if (e != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
-	hipError_t e1 = hipMemcpyAsync(pair_off, hits, nq1 * 4, hipMemcpyDeviceToDevice, ctx->stream);
-	if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate buffers: %s", hipGetErrorString(e1)); }
+	hipError_t e1 = hipSuccess;
 	rc = mcom_ws_reserve(ctx, scr2_b);
 	if (rc) { cleanup(); return rc; }
 	const unsigned pb = (unsigned)(((size_t)n_pairs + 255) / 256);
