@@ -485,6 +485,10 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcomh_destroy(p); return MCOM_E_ARG; }
 	if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&p->ev_sg, hipEventDisableTiming) != hipSuccess) { mcomh_destroy(p); return MCOM_E_HIP; }   // (every failure exit releases what exists)
+	// the copy stream's own library context (Stage 2 runs the singletons' rows and the dictionary screen there beside the index build):
+	// made with the pipeline, not in front of the first pass (0.8 ms of an idle GPU between the stages); a failure here is not one yet
+	if (mcom_create(&p->ctx2, p->device, p->copy_stream) != MCOM_OK) p->ctx2 = nullptr;
+	if (hipEventCreateWithFlags(&p->ev_early, hipEventDisableTiming) != hipSuccess) { p->ev_early = nullptr; (void)hipGetLastError(); }
 	if (host_reads) {
 		p->pitch = (size_t)L;
 		p->h_ascii.assign(host_reads, host_reads + n * (size_t)L);
