@@ -63,6 +63,8 @@ def load_library():
     L.mcom_prof_kernels.restype = i32; L.mcom_prof_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
     L.mcom_process_reads.restype = i32
     L.mcom_process_reads.argtypes = [vp, vp, sz, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
+    L.mcom_special_reads.restype = i32
+    L.mcom_special_reads.argtypes = [vp, vp, sz, vp, u32, vp]
     L.mcom_process_reads_packed.restype = i32
     L.mcom_process_reads_packed.argtypes = [vp, vp, vp, sz, i32, i32, i32, u32, vp, vp, vp, vp, vp]
     L.mcom_sketch_reads.restype = i32
@@ -216,6 +218,17 @@ class Context:
         self._check(self.lib.mcom_process_reads_packed(self._h, self._p(in_packed, torch.int64), self._p(in_nmask, torch.int64), n, L, k, e, rid0,
                                                        self._p(packed), self._p(cls), self._p(ncnt), self._p(nmask), self._p(rec)))
         return {"packed": packed, "cls": cls, "ncnt": ncnt, "nmask": nmask, "rec": rec}
+
+    def special_reads(self, cls, cap: int = 1 << 20):
+        """mcom_special_reads: the reads of another class than 0 as (rid << 8 | class), in no particular order.  Returns (list int64 [min(count, cap)], count)."""
+        torch = _torch()
+        n = int(cls.shape[0])
+        out = torch.empty(max(cap, 1), dtype=torch.int64, device=self.device)
+        cnt = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._check(self.lib.mcom_special_reads(self._h, self._p(cls, torch.uint8), n, self._p(out), cap, self._p(cnt)))
+        self.sync()
+        c = int(cnt[0].item())
+        return out[: min(c, cap)], c
 
     def sketch_reads(self, packed, L: int, k: int, rids=None, rid0: int = 0, out=None):
         """mcom_sketch_reads.  packed: int64 [N, W]; rids: optional int32 [n] row selector."""

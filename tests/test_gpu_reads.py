@@ -186,3 +186,24 @@ def test_reads_packed_on_the_host_give_what_the_character_matrix_gives(L):
         for name in ("packed", "cls", "ncnt", "nmask"):
             assert torch.equal(got[name], want[name]), (name, in_place)
         assert torch.equal(got["rec"], want["rec"]), in_place
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 100003])
+def test_special_reads_lists_every_read_of_another_class(ctx, n):
+    """mcom_special_reads: (rid << 8 | class) of every read whose class is not 0, whatever n modulo the eight class bytes a thread takes;
+    a list that is too short still reports the full count."""
+    import torch
+    rng = np.random.default_rng(n + 3)
+    cls = np.zeros(n, dtype=np.uint8)
+    if n:
+        hot = rng.random(n) < (0.3 if n < 100 else 0.01)
+        cls[hot] = rng.integers(1, 8, int(hot.sum()))
+        cls[-1] = 5
+    d = torch.from_numpy(cls).cuda() if n else torch.zeros(0, dtype=torch.uint8, device="cuda")
+    lst, count = ctx.special_reads(d)
+    want = np.sort((np.flatnonzero(cls).astype(np.int64) << 8) | cls[cls != 0].astype(np.int64))
+    assert count == len(want)
+    assert np.array_equal(np.sort(lst.cpu().numpy()), want)
+    if count > 2:
+        short, c2 = ctx.special_reads(d, cap=2)
+        assert c2 == count and len(short) == 2 and set(short.cpu().numpy().tolist()) <= set(want.tolist())
