@@ -68,6 +68,7 @@ def lib():
     L.mcomo_contig_members.restype = vp; L.mcomo_contig_members.argtypes = [vp, sz]
     L.mcomo_counter.restype = sz; L.mcomo_counter.argtypes = [vp, cp]
     L.mcomo_list.restype = vp; L.mcomo_list.argtypes = [vp, cp, C.POINTER(sz)]
+    L.mcomo_result_digest.restype = None; L.mcomo_result_digest.argtypes = [vp, C.POINTER(u64)]
     L.mcomo_synth_reads.restype = None
     L.mcomo_synth_reads.argtypes = [u64, u64, i32, i32, C.c_double, u64, u64, vp]
     _lib = L
@@ -187,6 +188,13 @@ class Pipeline:
         rc = lib().mcomo_dump_stages(self._h, path.encode())
         if rc:
             raise OSError("cannot write " + path)
+
+    def result_digest(self):
+        """The product's mcomh_result_digest restated over the oracle's contig set: eight numbers, equal iff strings, member
+        lists, offsets and id lists are."""
+        out = (C.c_uint64 * 8)()
+        lib().mcomo_result_digest(self._h, out)
+        return [int(x) for x in out]
 
     def counter(self, name: str) -> int:
         return int(lib().mcomo_counter(self._h, name.encode()))

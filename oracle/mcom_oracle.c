@@ -938,6 +938,8 @@ static void dump_contigs(FILE *f, const char *stage, const vcontig *cv)
 	}
 }
 
+static FILE *g_log;                                                       /* progress lines of a long run (digest_main.c) */
+void mcomo_set_log(FILE *f) { g_log = f; }
 static void run_stage2(mcomo_ctx *c, FILE *f)
 {
 	long pre = 0; int pass = 0;
@@ -958,6 +960,7 @@ static void run_stage2(mcomo_ctx *c, FILE *f)
 			dump_contigs(f, "realign", &c->C[c->idxv]);
 		}
 		free(before.a);
+		if (g_log) { fprintf(g_log, "realign pass %d thr %d: %ld reads in contigs\n", pass, thr, cr); fflush(g_log); }
 		long lim = (c->sg.n > 1000000 && c->L >= 68) ? 10000 : 1000;
 		++pass;
 		if (cr - pre < lim) break;
@@ -1003,6 +1006,7 @@ int mcomo_dump_stages(mcomo_ctx *c, const char *path)
 	return 0;
 }
 
+void mcomo_stage_realign_all(mcomo_ctx *c) { run_stage2(c, 0); }          /* preprocess.c:197-232 */
 void mcomo_run_all(mcomo_ctx *c)
 {
 	mcomo_stage_reads(c);
@@ -1038,6 +1042,49 @@ size_t mcomo_counter(const mcomo_ctx *c, const char *name)
 	return 0;
 }
 
+/* ---- result digest: the same eight numbers as the product's mcomh_result_digest (include/mcom_host.h) computed from the
+ * oracle's own contig set, so that a run too large to compare array by array can still be compared exactly: { contigs,
+ * characters, members, unclustered reads, digest of the concatenated strings, of the concatenated member words, of the two
+ * offset arrays, of the id lists }.  A digest of a byte array = position-weighted wrapping sum and xor of its little-endian
+ * 64-bit words (a tail of fewer than eight bytes zero-extended), folded as sum ^ rotl(xor, 23). */
+typedef struct { uint64_t s, x, i, part; int have; } dg_t;
+static void dg_word(dg_t *d, uint64_t v) { d->s += v * (2 * (d->i & 0xFFFFF) + 1); d->x ^= v; ++d->i; }
+static void dg_bytes(dg_t *d, const void *p_, size_t n)
+{
+	const uint8_t *p = (const uint8_t*)p_;
+	for (size_t q = 0; q < n; ++q) {
+		d->part |= (uint64_t)p[q] << (8 * d->have);
+		if (++d->have == 8) { dg_word(d, d->part); d->part = 0; d->have = 0; }
+	}
+}
+static uint64_t dg_end(dg_t *d)
+{
+	if (d->have) { dg_word(d, d->part); d->part = 0; d->have = 0; }
+	return d->s ^ ((d->x << 23) | (d->x >> 41));
+}
+void mcomo_result_digest(const mcomo_ctx *c, uint64_t out[8])
+{
+	const vcontig *V = &c->C[c->idxv];
+	dg_t ds, dm, dso, dmo; memset(&ds, 0, sizeof ds); dm = dso = dmo = ds;
+	uint64_t chars = 0, members = 0;
+	for (size_t i = 0; i < V->n; ++i) {
+		const size_t len = strlen(V->a[i].ref);
+		dg_word(&dso, chars); dg_word(&dmo, members);
+		dg_bytes(&ds, V->a[i].ref, len);
+		for (size_t j = 0; j < V->a[i].n; ++j) dg_word(&dm, V->a[i].a[j]);
+		chars += len; members += V->a[i].n;
+	}
+	if (V->n) { dg_word(&dso, chars); dg_word(&dmo, members); }
+	out[0] = V->n; out[1] = chars; out[2] = members;
+	out[4] = dg_end(&ds); out[5] = dg_end(&dm); out[6] = dg_end(&dso) + 3 * dg_end(&dmo);
+	uint64_t h = 0, nsg = 0;
+	for (size_t i = 0; i < c->sg.n; ++i) if (!c->sg_flag || !c->sg_flag[i]) { h = h * 0x9E3779B97F4A7C15ull + c->sg.a[i] + 1; ++nsg; }
+	out[3] = nsg;
+	const v32 *L7[7] = { &c->allA, &c->allT, &c->allN, &c->fpA, &c->fpT, &c->fpN, &c->Nfile };
+	for (int q = 0; q < 7; ++q) { h = h * 0xD6E8FEB86659FD93ull + L7[q]->n; for (size_t i = 0; i < L7[q]->n; ++i) h = h * 0x9E3779B97F4A7C15ull + L7[q]->a[i] + 1; }
+	out[7] = h;
+}
+
 /* ================================================================================================
  * synthetic reads: same counter-based generator as minicom_amd/synth.py (plumbing=False)
  * ============================================================================================== */
@@ -1067,6 +1114,26 @@ void mcomo_synth_reads(uint64_t seed, uint64_t n_reads, int L, int coverage, dou
 			if (strand) o[L - 1 - i] = "ACGT"[3 - b]; else o[i] = "ACGT"[b];
 		}
 	}
+}
+
+/* a context over the synthetic set itself, generated straight into the context's rows (a 100 M-read set has no room for a
+ * second copy of its characters) */
+mcomo_ctx *mcomo_new_synth(uint64_t seed, size_t n, int L, int coverage, double sub_rate, const mcomo_params *p)
+{
+	mcomo_ctx *c = mcomo_new(0, 0, L, p);
+	free(c->seq); free(c->cls); free(c->rec0); free(c->npos);
+	c->n = n;
+	c->seq = (char*)malloc(n * (size_t)(L + 1));
+	c->cls = (uint8_t*)calloc(n ? n : 1, 1);
+	c->rec0 = (mcomo_mm128*)calloc(n ? n : 1, sizeof *c->rec0);
+	c->npos = (v32*)calloc(n ? n : 1, sizeof *c->npos);
+	char *row = (char*)malloc((size_t)L);
+	for (size_t i = 0; i < n; ++i) {
+		mcomo_synth_reads(seed, n, L, coverage, sub_rate, i, 1, row);
+		memcpy(c->seq + i * (size_t)(L + 1), row, (size_t)L); c->seq[i * (size_t)(L + 1) + L] = 0;
+	}
+	free(row);
+	return c;
 }
 
 /* named id lists: allA allT allN fpA fpT fpN Nfile sg */

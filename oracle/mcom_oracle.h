@@ -76,6 +76,8 @@ void mcomo_stage_combine(mcomo_ctx *c);   /* combine_cluster   kthread_cb.c:570 
 /* one Stage-2 pass: updateSingle + realign_hash (preprocess.c:203-204); returns reads in contigs */
 long mcomo_stage_realign_pass(mcomo_ctx *c, int thr);
 void mcomo_update_single(mcomo_ctx *c);   /* preprocess.c:243 */
+void mcomo_stage_realign_all(mcomo_ctx *c);  /* every Stage-2 pass + the closing updateSingle   preprocess.c:197-232 */
+void mcomo_set_log(FILE *f);              /* progress lines of a long run, one per Stage-2 pass */
 /* runs everything and writes the same text as "refdump stages" */
 int  mcomo_dump_stages(mcomo_ctx *c, const char *path);
 /* runs everything without dumping (CPU baseline); fills counters */
@@ -96,9 +98,14 @@ const uint64_t *mcomo_contig_members(const mcomo_ctx *c, size_t i);
 size_t mcomo_counter(const mcomo_ctx *c, const char *name);
 const uint32_t *mcomo_list(const mcomo_ctx *c, const char *name, size_t *n);
 
+/* the product's mcomh_result_digest restated over the oracle's contig set (include/mcom_host.h): equal digests = equal
+ * contig strings, member lists, offsets and id lists */
+void mcomo_result_digest(const mcomo_ctx *c, uint64_t out[8]);
+
 /* ---- synthetic reads (same generator as minicom_amd/synth.py, plumbing=False) ------------------ */
 void mcomo_synth_reads(uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,
                        uint64_t first, uint64_t count, char *out /* [count][L] */);
+mcomo_ctx *mcomo_new_synth(uint64_t seed, size_t n, int L, int coverage, double sub_rate, const mcomo_params *p);
 
 #ifdef __cplusplus
 }

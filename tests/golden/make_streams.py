@@ -49,7 +49,39 @@ def make(tag, variant, prefix="streams_", paired=False):
         print(tag, {n: os.path.getsize(os.path.join(out, n)) for n in sorted(os.listdir(out))})
 
 
+def make_md5(name, variant, seed, n, L):
+    """The reference's own timed region (preprocess.c:137-234) as the checker at a size no fixture file could hold: the compiled
+    reference at one thread on the synthetic set (seed, n, L) of minicom_amd/synth.py; only the md5 of every stream file it
+    writes is kept (tests/golden/<name>.md5.json).  1 M x 100: ~40 s, 1 M x 150: ~75 s, 4 M x 150: minutes."""
+    import hashlib
+    import json
+    import time
+    reads = synth.synth_reads(seed, n, L)
+    with tempfile.TemporaryDirectory() as td:
+        fq = os.path.join(td, "in.fastq")
+        out = os.path.join(td, "out"); os.makedirs(out)
+        cwd = os.path.join(td, "cwd"); os.makedirs(os.path.join(cwd, "output_ref"))
+        synth.write_fastq_fast(fq, reads, tricky_quality=False)
+        t = time.time()
+        subprocess.run([os.path.join(REF, variant, "minicom_bin"), fq, out], cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+        dt = time.time() - t
+        files = {nm: {"md5": hashlib.md5(open(os.path.join(out, nm), "rb").read()).hexdigest(), "bytes": os.path.getsize(os.path.join(out, nm))}
+                 for nm in sorted(os.listdir(out))}
+    doc = {"generator": "minicom_amd.synth.synth_reads(seed, n, L)", "seed": seed, "n": n, "L": L, "reference_variant": variant,
+           "reference_threads": 1, "reference_seconds": round(dt, 1), "files": files}
+    with open(os.path.join(HERE, name + ".md5.json"), "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True); f.write("\n")
+    print(name, round(dt, 1), "s", {k: v["bytes"] for k, v in files.items()})
+
+
 if __name__ == "__main__":
+    if "--c0" in sys.argv:                                              # BASELINE configs[0] exactly, and the 150-base shape at that size
+        make_md5("c0_streams_1m_100", "L100", 1001, 1_000_000, 100)
+        make_md5("c0_streams_1m_150", "L150", 1002, 1_000_000, 150)
+        sys.exit(0)
+    if "--c0-4m" in sys.argv:
+        make_md5("c0_streams_4m_150", "L150", 1002, 4_000_000, 150)
+        sys.exit(0)
     if "--only-L150-modes" in sys.argv:
         make("stages_L150", "L150_order", prefix="streams_order_")
         make("stages_L150", "L150_pe", prefix="streams_pe_", paired=True)

@@ -118,6 +118,37 @@ def test_fastq_to_stream_files_equals_the_reference(golden_dir, tmp_path, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c0_streams_1m_100", "c0_streams_1m_150", "c0_streams_4m_150"])
+def test_stream_files_equal_the_reference_run_on_configs0(golden_dir, tmp_path, name):
+    """BASELINE configs[0] exactly (1 M x 100 bp, seed 1001), the 150-base shape at that size and at 4 M reads: the reference itself
+    (oracle/_ref/L100|L150/minicom_bin, one thread, its whole timed region preprocess.c:137-234 and its writer) ran on these sets
+    in the build container and the md5 of every stream file it wrote is the fixture (tests/golden/make_streams.py --c0).  File ->
+    stream files here must give the same bytes: no oracle in between."""
+    import hashlib
+    import json
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    path = os.path.join(golden_dir, name + ".md5.json")
+    if not os.path.exists(path):
+        pytest.skip(name + ": fixture not generated")
+    doc = json.load(open(path))
+    reads = synth.synth_reads(doc["seed"], doc["n"], doc["L"])
+    fq = str(tmp_path / "in.fastq")
+    synth.write_fastq_fast(fq, reads, tricky_quality=False)
+    p = Pipeline.from_fastq(fq, host_threads=8)
+    assert (p.n, p.L) == (doc["n"], doc["L"])
+    p.pre_process()
+    d = tmp_path / "streams"; d.mkdir()
+    p.cluster_dump(str(d))
+    p.close()
+    assert sorted(os.listdir(d)) == sorted(doc["files"])
+    for nm, want in doc["files"].items():
+        data = (d / nm).read_bytes()
+        assert len(data) == want["bytes"], nm
+        assert hashlib.md5(data).hexdigest() == want["md5"], nm
+
+
+@pytest.mark.gpu
 def test_from_fastq_reports_unequal_lengths(tmp_path):
     from minicom_amd.hip import McomError
     from minicom_amd.pipeline import Pipeline

@@ -146,6 +146,7 @@ def test_pipeline_equals_the_sequential_oracle_on_8m_reads():
     assert np.array_equal(np.cumsum([0] + [len(m) for _, m in oc]).astype(np.uint64), moff)
     for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
         assert np.array_equal(o.id_list(name), p.id_list(name)), name
+    assert o.result_digest() == list(p.result_digest())                   # the digest restated in the oracle: what pins the 100 M-read runs above
     p.close(); o.close()
 
 
@@ -175,6 +176,7 @@ def _assert_equal_sets(o, p):
     assert np.array_equal(np.cumsum([0] + [len(m) for _, m in oc]).astype(np.uint64), moff)
     for name in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
         assert np.array_equal(o.id_list(name), p.id_list(name)), name
+    assert o.result_digest() == list(p.result_digest())
 
 
 def test_pipeline_equals_the_sequential_oracle_on_2m_reads_of_150_bases():

@@ -99,3 +99,40 @@ def test_synth_generator_c_equals_numpy():
     a = synth.synth_reads(11, 1000, 100, first=400, count=100)
     b = oracle.synth_reads(11, 1000, 100, first=400, count=100)
     assert np.array_equal(a, b) and np.array_equal(a, synth.synth_reads(11, 1000, 100)[400:500])
+
+
+def test_result_digest_of_the_oracle_equals_the_formula_of_the_product():
+    """oracle.Pipeline.result_digest restates mcomh_result_digest (include/mcom_host.h; minicom_amd/csrc/dist.hip k_digest) over the
+    oracle's own contig set; here the same eight numbers from the flat arrays with numpy: what tests/golden/scale_digests.json
+    (oracle runs at 100 M x 150 bp and 67 M x 100 bp) and tests/test_gpu_scale.py compare is this function."""
+    from minicom_amd import synth
+    reads = synth.synth_reads(77, 30000, 100, plumbing=True)
+    o = oracle.Pipeline(reads); o.run_all()
+    cs = o.contigs()
+    M = (1 << 64) - 1
+
+    def dg(b: bytes) -> int:
+        b = b + b"\0" * (-len(b) % 8)
+        w = np.frombuffer(b, dtype="<u8")
+        wt = (2 * (np.arange(len(w), dtype=np.uint64) & np.uint64(0xFFFFF)) + np.uint64(1))
+        with np.errstate(over="ignore"):
+            s = int(np.sum(w * wt, dtype=np.uint64)) if len(w) else 0
+        x = int(np.bitwise_xor.reduce(w)) if len(w) else 0
+        return s ^ (((x << 23) | (x >> 41)) & M)
+    refs = b"".join(r for r, _ in cs)
+    mem = np.concatenate([m for _, m in cs]).astype("<u8")
+    soff = np.cumsum([0] + [len(r) for r, _ in cs]).astype("<u8")
+    moff = np.cumsum([0] + [len(m) for _, m in cs]).astype("<u8")
+    h = 0
+    sg = o.id_list("sg")
+    for v in sg:
+        h = (h * 0x9E3779B97F4A7C15 + int(v) + 1) & M
+    for name in ("allA", "allT", "allN", "fpA", "fpT", "fpN", "Nfile"):
+        lst = o.id_list(name)
+        h = (h * 0xD6E8FEB86659FD93 + len(lst)) & M
+        for v in lst:
+            h = (h * 0x9E3779B97F4A7C15 + int(v) + 1) & M
+    want = [len(cs), len(refs), len(mem), len(sg), dg(refs), dg(mem.tobytes()), (dg(soff.tobytes()) + 3 * dg(moff.tobytes())) & M, h]
+    assert len(cs) > 500 and len(sg) > 10
+    assert o.result_digest() == want
+    o.close()
