@@ -25,6 +25,13 @@ int mcom_set_consensus_capacity(mcom_ctx *ctx, uint32_t members);
  * sets the prefix width of the first: a few bits make ties the rule (tests); wave_per_string = 3 keeps 32-bit words at any width.    */
 int mcom_set_sketch_kernel(mcom_ctx *ctx, int wave_per_string);
 int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
+/* mcom_claim_pairs settles all rounds inside ONE launch whose workgroups meet at a grid barrier, which only works while every workgroup
+ * is resident; a barrier wait that runs out raises the context's poison flag and the launch-per-round loop (two launches and a host
+ * round trip per round: needs no co-residency) redoes the claiming.  route 0 = that default, 1 = the loop at once, 2 = the first barrier
+ * of the one-launch kernel gives up at once (the flag trips, the loop takes over).  Same jobs and flags every way.
+ * mcom_claim_fallbacks: how often the loop has run in this context.                                                               */
+int mcom_set_claim_route(mcom_ctx *ctx, int route);
+int mcom_claim_fallbacks(const mcom_ctx *ctx);
 
 
 /* ---- libmcom_host.so ---- */

@@ -21,8 +21,10 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...)
 #define MCOM_PIN_BYTES 4096
 hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-	for (const mcom_ctx::ScanTotal &t : ctx->scan_last)                            // the total of a scan that is on its way: already in pinned memory
+	for (uint32_t q = 0; q < 8; ++q) {                                             // the total of a scan that is on its way: already in pinned memory (newest entry first)
+		const mcom_ctx::ScanTotal &t = ctx->scan_last[(ctx->scan_last_at + 7u - q) % 8u];
 		if (t.last && t.last == src && t.bytes == bytes && t.gen == ctx->launch_gen) { mcom_ctx::PinWait w{dst, 0, bytes}; w.from = ctx->scan_tot + t.slot; ctx->pin_wait.push_back(w); return hipSuccess; }
+	}
 	if (bytes <= 256) {
 		if (!ctx->pin && hipHostMalloc((void**)&ctx->pin, MCOM_PIN_BYTES, hipHostMallocDefault) != hipSuccess) { ctx->pin = nullptr; (void)hipGetLastError(); }
 		const size_t need = (bytes + 7) & ~(size_t)7;
@@ -34,14 +36,21 @@ hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t byte
 	}
 	return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
 }
-hipError_t mcom_stream_sync(mcom_ctx *ctx)
+hipError_t mcom_stream_sync(mcom_ctx *ctx) { return mcom_stream_sync_poison(ctx, nullptr); }
+// poisoned != nullptr: a tripped poison flag is REPORTED there instead of failing the call -- for a caller that launched the kernel
+// whose wait may run out and has another way to the same result (mcom_claim_pairs: the launch-per-round loop)
+hipError_t mcom_stream_sync_poison(mcom_ctx *ctx, bool *poisoned)
 {
 	hipError_t e = hipStreamSynchronize(ctx->stream);
 	++ctx->launch_gen;                                                             // (what a scan left in pinned memory is consumed below)
-	if (e == hipSuccess && ctx->poison && *ctx->poison) {                        // a kernel's bounded wait ran out (scan.hip): its results are wrong
+	if (poisoned) *poisoned = false;
+	if (e == hipSuccess && ctx->poison && *ctx->poison) {                        // a kernel's bounded wait ran out: its results are wrong
 		*ctx->poison = 0;
-		ctx->err = "a device-side wait ran out (one-launch scan): results of this stream are invalid";
-		e = hipErrorLaunchFailure;
+		if (poisoned) *poisoned = true;
+		else {
+			ctx->err = "a device-side wait ran out: results of this stream are invalid";
+			e = hipErrorLaunchFailure;
+		}
 	}
 	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, w.from ? w.from : (const void*)(ctx->pin + w.off), w.bytes);
 	ctx->pin_wait.clear(); ctx->pin_off = 0;
@@ -346,6 +355,13 @@ extern "C" int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits)
 	ctx->sketch_prefix_bits = bits;
 	return MCOM_OK;
 }
+extern "C" int mcom_set_claim_route(mcom_ctx *ctx, int route)
+{
+	if (!ctx || route < 0 || route > 2) return MCOM_E_ARG;
+	ctx->claim_route = route;
+	return MCOM_OK;
+}
+extern "C" int mcom_claim_fallbacks(const mcom_ctx *ctx) { return ctx ? (int)ctx->claim_fallbacks : 0; }
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
 {
 	if (!ctx) return MCOM_E_ARG;

@@ -27,14 +27,16 @@ __global__ void k_claim_jobs(const mcom_mm128 *__restrict__ pairs, size_t n, con
 // round override those of an earlier one and `best` needs no clear between rounds.  The barrier is the guide's recipe (each wave's
 // stores drained by __syncthreads, one lane's agent-scope release, a counter, that lane's agent-scope acquire, __syncthreads) and its
 // wait is bounded: a workgroup that gives up raises the context's poison flag and leaves -- the others leave at their next barrier
-// for the same reason -- and the host falls back to the launch-per-round loop.
+// for the same reason -- and mcom_claim_pairs redoes the claiming with the launch-per-round loop below (k_claim_bid / k_claim_take),
+// which needs no co-residency.  Residency is NOT guaranteed by the grid's size alone: another process or thread-rank on the card
+// running its own persistent kernel, or a CU mask, can keep a workgroup from starting; then the waits run out and the loop takes over.
 #define CL_THREADS 1024
 #define CL_REL_LINES 16                     // copies of the release word, one cache line each: 16 pollers per line instead of 256 on one
 #define CL_STATE_WORDS (64 + CL_REL_LINES * 32)
 // One workgroup of 1024 threads per CU: a barrier of 256 arrivals (the first form had 1024 workgroups of 256 threads polling ONE word
 // with agent-scope loads while the late arrivals' atomics queued behind the polls on that word's L2 channel: ~50 us per barrier,
 // 13 ms per step against 6.2 ms for the launch-per-round loop).  The last to arrive releases everybody through CL_REL_LINES words.
-__device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, unsigned int &gen, unsigned int *poison)
+__device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, unsigned int &gen, unsigned int *poison, unsigned int poll_limit)
 {
 	__shared__ int ok_s;
 	__syncthreads();
@@ -43,13 +45,14 @@ __device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, 
 		++gen;
 		unsigned int *rel = state + 64;
 		int ok = 1;
-		if (atomicAdd(state, 1u) == gen * G - 1u) {
+		if (poll_limit == 0) { *poison = 1u; ok = 0; }                           // (test hook, mcom_set_claim_route(2): give up at once)
+		else if (atomicAdd(state, 1u) == gen * G - 1u) {
 			for (int j = 0; j < CL_REL_LINES; ++j) __hip_atomic_store(rel + 32 * j, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
 			unsigned int *mine = rel + 32 * (blockIdx.x % CL_REL_LINES);
 			unsigned int polls = 0;
 			while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
-				if (++polls > (1u << 23) || ((polls & 4095u) == 0 && *(volatile unsigned int*)poison)) { *poison = 1u; ok = 0; break; }   // (the flag lives in host memory: looked at rarely)
+				if (++polls > poll_limit || ((polls & 4095u) == 0 && *(volatile unsigned int*)poison)) { *poison = 1u; ok = 0; break; }   // (the flag lives in host memory: looked at rarely)
 				__builtin_amdgcn_s_sleep(8);
 			}
 		}
@@ -67,7 +70,7 @@ __device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, 
 // can only make a live edge wait one more round (every edge is stale at most once).
 __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__restrict__ pairs, uint32_t n, uint8_t *matched, uint8_t *dead,
                                                          unsigned long long *best, uint32_t n_contigs, uint32_t *__restrict__ sel, unsigned int *state, int max_rounds,
-                                                         unsigned int *poison, unsigned int *__restrict__ host_copy)
+                                                         unsigned int *poison, unsigned int *__restrict__ host_copy, unsigned int poll_limit)
 {
 	// state[0] = barrier counter; on a line of their own: state[32 + round % 3] = "some edge bid in this round", state[36] = rounds with bids,
 	// state[37] = did not settle; state[64 ...] = the release words
@@ -120,8 +123,39 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 		}
 		if (__any(live) && (threadIdx.x & 63) == 0 && *(volatile unsigned int*)(state + 32 + round % 3) == 0) state[32 + round % 3] = 1;
 		if (blockIdx.x == 0 && threadIdx.x == 0) state[32 + (round + 1) % 3] = 0;                // the next round's flag (nobody else touches it in this phase)
-		if (!cl_barrier(state, G, gen, poison)) return;
+		if (!cl_barrier(state, G, gen, poison, poll_limit)) return;
 	}
+}
+
+// ---- the launch-per-round loop (rounds 1-3's form, back as the fallback): one launch places the bids of the live edges, one takes
+// the edges that won at both ends; the host reads "some edge bid" after every round.  Bids carry their round, so nothing is cleared
+// between rounds.  No workgroup waits for another: this form works whatever else occupies the card.
+__global__ void k_claim_bid(const mcom_mm128 *__restrict__ pairs, uint32_t n, const uint8_t *__restrict__ matched, uint8_t *__restrict__ dead,
+                            unsigned long long *__restrict__ best, uint32_t round, unsigned int *__restrict__ any)
+{
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	bool live = false;
+	if (e < n && !dead[e]) {
+		const mcom_mm128 pr = pairs[e];
+		const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
+		if (matched[ci] || matched[cj]) dead[e] = 1;
+		else {
+			const unsigned long long key = ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - e);
+			atomicMax(&best[ci], key); atomicMax(&best[cj], key);
+			live = true;
+		}
+	}
+	if (__any(live) && (threadIdx.x & 63) == 0 && *(volatile unsigned int*)any == 0) *any = 1u;
+}
+__global__ void k_claim_take(const mcom_mm128 *__restrict__ pairs, uint32_t n, uint8_t *__restrict__ matched, uint8_t *__restrict__ dead,
+                             const unsigned long long *__restrict__ best, uint32_t round, uint32_t *__restrict__ sel)
+{
+	const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n || dead[e]) return;
+	const mcom_mm128 pr = pairs[e];
+	const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
+	const unsigned long long key = ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - e);
+	if (best[ci] == key && best[cj] == key) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; dead[e] = 1; }   // the earliest live edge at both ends: nobody else writes these flags in this launch
 }
 
 // the flags of the contigs and the kernel's own arrays cleared in ONE launch (two or three fills before: the runtime splits a fill whose
@@ -159,27 +193,50 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	uint32_t *sel = (uint32_t*)(base + best_b + dead_b);
 	unsigned int *state = (unsigned int*)(base + best_b + dead_b + sel_b);
 	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4));
-	{   // best = 0: below every bid; dead, sel, state = 0; and the contigs' flags
-		const size_t n16 = (best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4)) / 16;
-		size_t cb = (n16 + 255) / 256; if (cb > (size_t)ctx->n_cu * 8) cb = (size_t)ctx->n_cu * 8;
-		MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
-	}
 	const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
 	unsigned int hs[2] = {0, 0};
-	{
+	const size_t n16 = (best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4)) / 16;
+	size_t cb = (n16 + 255) / 256; if (cb > (size_t)ctx->n_cu * 8) cb = (size_t)ctx->n_cu * 8;
+	// best = 0: below every bid; dead, sel, state = 0; and the contigs' flags
+	MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
+	bool loop = ctx->claim_route == 1;
+	if (!loop) {
 		unsigned grid = (unsigned)ctx->n_cu;
 		const unsigned need = (unsigned)((n_pairs + 16 * CL_THREADS - 1) / (16 * CL_THREADS));
 		if (grid > need) grid = need;
 		uint32_t n32 = (uint32_t)n_pairs;
-		// a plain launch: what a grid barrier needs is that every workgroup is resident, which the grid's size guarantees (one workgroup
-		// per CU) and a cooperative launch would only check (rocprofv3's kernel trace crashed on the cooperative one)
+		// a plain launch of one workgroup per CU (rocprofv3's kernel trace crashed on a cooperative one).  Every workgroup is resident as long
+		// as nothing else holds the CUs; when something does, the barrier waits run out, the poison flag trips and the loop below takes over.
+		// (a stale bid can make a live edge wait one more round, every edge at most once: the kernel's own budget is twice the caller's)
 		uint32_t ring = 0;
 		unsigned int *host_copy = (unsigned int*)mcom_ring_slot(ctx, &ring);
-		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, max_rounds, ctx->d_poison, host_copy);
+		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, 2 * max_rounds + 2, ctx->d_poison, host_copy,
+		            ctx->claim_route == 2 ? 0u : (1u << 23));
 		if (host_copy) mcom_ring_register(ctx, state + 36, 8, ring);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state + 36, 8));
-		MCOM_HIP(ctx, mcom_stream_sync(ctx));
+		bool poisoned = false;
+		MCOM_HIP(ctx, mcom_stream_sync_poison(ctx, &poisoned));
+		if (poisoned) {                                                               // what the kernel left is partial: start again
+			loop = true; hs[0] = hs[1] = 0;
+			MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
+		}
+	}
+	if (loop) {
+		++ctx->claim_fallbacks;
+		const uint32_t n32 = (uint32_t)n_pairs;
+		int round = 1;
+		for (;; ++round) {
+			if (round > max_rounds) { hs[0] = (unsigned)max_rounds; hs[1] = 1; break; }
+			MCOM_HIP(ctx, hipMemsetAsync(state + 32, 0, 4, ctx->stream));
+			MCOM_LAUNCH(k_claim_bid, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)round, state + 32);
+			MCOM_LAUNCH(k_claim_take, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)round, sel);
+			MCOM_LAUNCH_CHECK(ctx);
+			unsigned int any = 0;
+			MCOM_HIP(ctx, mcom_d2h_async(ctx, &any, state + 32, 4));
+			MCOM_HIP(ctx, mcom_stream_sync(ctx));
+			if (!any) { hs[0] = (unsigned)(round - 1); hs[1] = 0; break; }
+		}
 	}
 	if (hs[1]) return mcom_fail(ctx, MCOM_E_OVERFLOW, "claiming did not settle in %d rounds", max_rounds);
 	if (h_rounds) *h_rounds = (int)hs[0];

@@ -54,6 +54,9 @@ struct mcom_ctx {
 	unsigned long long *scan_tot = nullptr, *d_scan_tot = nullptr;               // host / device view of the ring (after the poison word)
 	// (an entry stands only while no other kernel has been launched and the stream has not been synchronised since its scan: launch_gen)
 	struct ScanTotal { const void *last; uint32_t bytes, slot, gen; } scan_last[8] = {}; uint32_t scan_last_at = 0, launch_gen = 1;
+	// first-come claiming (claim.hip): 0 = the one-launch kernel with the launch-per-round loop behind it, 1 = the loop at once, 2 = the
+	// one-launch kernel's first barrier gives up (test hook: the poison flag trips and the loop takes over); how often the loop ran
+	int claim_route = 0; uint64_t claim_fallbacks = 0;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
 	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
 	// a whole when it is used up, instead of one 4-byte fill launch in front of every such kernel (mcom_zeroed, api.hip)
@@ -98,11 +101,13 @@ int mcom_fail(mcom_ctx *ctx, int code, const char *fmt, ...);
 // everywhere in the library -- hands them to their destinations.  (mcom_fail drops what is still on its way.)
 hipError_t mcom_d2h_async(mcom_ctx *ctx, void *dst, const void *src, size_t bytes);
 hipError_t mcom_stream_sync(mcom_ctx *ctx);
+hipError_t mcom_stream_sync_poison(mcom_ctx *ctx, bool *poisoned);
 int mcom_ws_reserve(mcom_ctx *ctx, size_t bytes);
 // `bytes` (<= 4096, rounded up to 8) of zeroed device memory for a kernel of the context's stream to count into; the caller reads what it
 // needs back before it returns (the pool has two halves, cleared and taken in turn: a word keeps its value for thousands of further requests).  Without the pool: `fallback` cleared by a
 // fill, as before.  nullptr: the fill failed.
 void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes);
+void mcom_ring_flush_slot(mcom_ctx *ctx, uint32_t slot);
 unsigned long long *mcom_ring_slot(mcom_ctx *ctx, uint32_t *slot);                      // scan.hip: a kernel's one-value result straight into pinned memory
 void mcom_ring_register(mcom_ctx *ctx, const void *d_result, uint32_t bytes, uint32_t slot);
 // recycled device blocks for the library's own objects (api.hip)
@@ -139,6 +144,10 @@ int mcom_scan64(mcom_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n, uint
 #define MCOM_HIP(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) \
 	return mcom_fail(ctx, MCOM_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
 #define MCOM_LAUNCH_CHECK(ctx) MCOM_HIP(ctx, hipGetLastError())
+// A fill or a copy INTO device memory on the context's stream can overwrite the last element of a scan whose total waits in the pinned
+// ring (scan.hip): like a kernel launch it ends the validity of those entries.  (`ctx` is in scope wherever the library moves device data.)
+#define hipMemsetAsync(...) (++ctx->launch_gen, hipMemsetAsync(__VA_ARGS__))
+#define hipMemcpyAsync(dst_, src_, n_, kind_, st_) (((kind_) != hipMemcpyDeviceToHost ? ++ctx->launch_gen : 0u), hipMemcpyAsync(dst_, src_, n_, kind_, st_))
 
 #define U64MAX 0xFFFFFFFFFFFFFFFFull
 

@@ -583,19 +583,22 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		if (nc > i) verify(i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3);
 	}
 	if (stats) {
-		// the three counts of a lane travel as ONE word (20 bits each: a wave's sums stay far below 2^20) through one reduction, and a
-		// workgroup sends one set of atomics (three reductions and three atomics per wave cost 0.8 of the kernel's 19 ms)
+		// the three counts of a lane travel as ONE word through one reduction, and a workgroup sends one set of atomics (three reductions and
+		// three atomics per wave cost 0.8 of the kernel's 19 ms).  Fields of 16 / 28 / 20 bits for lookups / verified / passing: a lane's
+		// counts are clamped (255, 2^20 - 1, 4095 -- a lane does a handful of lookups, but a heavy repeat key gives it thousands of
+		// candidates) so that the sums over the 256 lanes of the workgroup cannot carry into the neighbouring field
 		__shared__ unsigned long long wg_sum;
 		if (threadIdx.x == 0) wg_sum = 0;
-		unsigned long long pk = (unsigned long long)(n_look & 0xFFFFFu) | ((unsigned long long)(n_cand & 0xFFFFFu) << 20) | ((unsigned long long)(n_pass & 0xFFFFFu) << 40);
+		const unsigned long long f_look = n_look < 255u ? n_look : 255u, f_cand = n_cand < 0xFFFFFu ? n_cand : 0xFFFFFu, f_pass = n_pass < 4095u ? n_pass : 4095u;
+		unsigned long long pk = f_look | (f_cand << 16) | (f_pass << 44);
 		for (int o = 32; o; o >>= 1) pk += __shfl_xor(pk, o);
 		__syncthreads();
-		if ((threadIdx.x & 63) == 0) atomicAdd(&wg_sum, pk);                          // (four waves: 22 bits a field at most)
+		if ((threadIdx.x & 63) == 0) atomicAdd(&wg_sum, pk);
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			// 1024 sets of counters: millions of atomics on three addresses would serialise on one L2 channel
 			unsigned long long *st = stats + 4 * (blockIdx.x & 1023);
-			const unsigned long long a = wg_sum & 0xFFFFFu, b = (wg_sum >> 20) & 0xFFFFFu, c = wg_sum >> 40;
+			const unsigned long long a = wg_sum & 0xFFFFu, b = (wg_sum >> 16) & 0xFFFFFFFu, c = wg_sum >> 44;
 			atomicAdd(&st[0], a); if (b) atomicAdd(&st[1], b); if (c) atomicAdd(&st[2], c);
 		}
 	}

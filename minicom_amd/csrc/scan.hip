@@ -6,12 +6,14 @@
 //   1. it sums its chunk and publishes the sum as two self-validating words { epoch << 32 | half of the sum };
 //   2. it adds up the sums of the chunks before it (wave 0; a word whose epoch is not this launch's is not there yet);
 //   3. it scans its chunk, tile by tile, from that base.
-// Step 2 waits for other workgroups, so every one of them must be running or able to start: the grid never exceeds 2 workgroups of
-// 256 threads per CU (a CU holds 8 of them; no LDS or register pressure), and a workgroup that publishes waits for nobody before
-// it does -- a wait can only be for a workgroup that is running or about to be dispatched into a free slot.  Even so the wait is
-// BOUNDED: after ~2^22 polls a workgroup gives up, raises the context's poison flag (a word of pinned host memory that
-// mcom_stream_sync checks) and finishes with a wrong base; the call that synchronises next fails with MCOM_E_HIP instead of the
-// GPU hanging.  The epoch words make a clear of the scratch between launches unnecessary.
+// Step 2 waits for other workgroups.  No co-residency is assumed (round 5): a workgroup's chunk is not its blockIdx but a TICKET it draws
+// when it starts (one atomic per workgroup), so the chunks in front of it belong to workgroups that started before it -- they are running
+// or done, they publish without waiting for anybody, and the wait ends whatever else occupies the card and in whatever order the
+// workgroups are dispatched.  (The workgroup that draws the last ticket puts the counter back to zero for the next launch: launches of
+// one stream do not overlap, and every context has a counter of its own.)  The wait is BOUNDED all the same: after ~2^22 polls a
+// workgroup gives up, raises the context's poison flag (a word of pinned host memory that mcom_stream_sync checks) and finishes with a
+// wrong base; the call that synchronises next fails with MCOM_E_HIP instead of the GPU hanging -- which now takes a workgroup that died,
+// not one that was kept waiting.  The epoch words make a clear of the scratch between launches unnecessary.
 #include "mcom_dev.hpp"
 
 #define SO_THREADS 256
@@ -64,7 +66,19 @@ __global__ __launch_bounds__(SO_THREADS) void k_scan_one(const T *in, T *out, si
 	__shared__ T wsum[SO_THREADS / 64];
 	__shared__ T s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint32_t g = blockIdx.x, G = gridDim.x;
+	const uint32_t G = gridDim.x;
+	uint32_t g = 0;
+	if (G > 1) {
+		__shared__ uint32_t s_ticket;
+		if (tid == 0) {
+			unsigned int *ticket = (unsigned int*)(parts + 2 * SO_MAX_WG);
+			const uint32_t t = atomicAdd(ticket, 1u);
+			if (t == G - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody draws after the last: ready for the next launch
+			s_ticket = t;
+		}
+		__syncthreads();
+		g = s_ticket;
+	}
 	const size_t first = (size_t)g * tiles_per_wg * TILE;
 	size_t last = first + (size_t)tiles_per_wg * TILE; if (last > n) last = n;
 	T base = 0;
@@ -146,8 +160,8 @@ int mcom_scan_prepare(mcom_ctx *ctx)
 	*ctx->poison = 0;
 	MCOM_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_poison, (void*)ctx->poison, 0));
 	ctx->scan_tot = (unsigned long long*)((char*)ctx->poison + 64); ctx->d_scan_tot = (unsigned long long*)((char*)ctx->d_poison + 64);
-	MCOM_HIP(ctx, hipMalloc((void**)&ctx->scan_parts, (size_t)2 * SO_MAX_WG * 8));
-	MCOM_HIP(ctx, hipMemsetAsync(ctx->scan_parts, 0, (size_t)2 * SO_MAX_WG * 8, ctx->stream));
+	MCOM_HIP(ctx, hipMalloc((void**)&ctx->scan_parts, (size_t)2 * SO_MAX_WG * 8 + 64));             // (+ the ticket counter)
+	MCOM_HIP(ctx, hipMemsetAsync(ctx->scan_parts, 0, (size_t)2 * SO_MAX_WG * 8 + 64, ctx->stream));
 	ctx->scan_epoch = 0;
 	return MCOM_OK;
 }
@@ -168,12 +182,22 @@ static int scan_one(mcom_ctx *ctx, const T *in, T *out, size_t n)
 	const uint32_t slot = ctx->scan_epoch % mcom_ctx::SCAN_TOTALS, gen_before = ctx->launch_gen;
 	MCOM_LAUNCH(k_scan_one<T>, dim3((unsigned)G), dim3(SO_THREADS), 0, ctx->stream, in, out, n, (uint32_t)per, ctx->scan_parts, ctx->scan_epoch, ctx->d_poison, ctx->d_scan_tot + slot);
 	MCOM_LAUNCH_CHECK(ctx);
+	mcom_ring_flush_slot(ctx, slot);                                               // (the ring came round: a read-back still waiting on that word is served now)
 	for (mcom_ctx::ScanTotal &t : ctx->scan_last) {
-		if (t.slot == slot) t.last = nullptr;                                      // (the ring came round: that total is gone)
+		if (t.slot == slot) t.last = nullptr;                                      // (that total is gone)
+		if (t.last && (const char*)t.last >= (const char*)out && (const char*)t.last < (const char*)(out + n)) t.last = nullptr;   // this scan overwrites it (a reused scratch array)
 		if (t.gen == gen_before) t.gen = ctx->launch_gen;                          // scans in a row: the earlier ones' totals still stand
 	}
 	ctx->scan_last[ctx->scan_last_at++ % 8] = mcom_ctx::ScanTotal{(const void*)(out + n - 1), (uint32_t)sizeof(T), slot, ctx->launch_gen};
 	return MCOM_OK;
+}
+
+// A ring word about to be handed out again may still be what a queued read-back (mcom_d2h_async, PinWait::from) waits for -- 64 scans or
+// ring slots between a read-back and its synchronisation: the stream is synchronised and the waiting values delivered before the word is reused.
+void mcom_ring_flush_slot(mcom_ctx *ctx, uint32_t slot)
+{
+	for (const mcom_ctx::PinWait &w : ctx->pin_wait)
+		if (w.from == (const void*)(ctx->scan_tot + slot)) { (void)mcom_stream_sync(ctx); return; }
 }
 
 // The ring of pinned words for OTHER kernels whose result is one value written by one thread at their end (a fold's totals, the
@@ -184,6 +208,7 @@ unsigned long long *mcom_ring_slot(mcom_ctx *ctx, uint32_t *slot)
 	if (mcom_scan_prepare(ctx)) return nullptr;
 	if (++ctx->scan_epoch == 0) ctx->scan_epoch = 1;
 	*slot = ctx->scan_epoch % mcom_ctx::SCAN_TOTALS;
+	mcom_ring_flush_slot(ctx, *slot);
 	for (mcom_ctx::ScanTotal &t : ctx->scan_last) if (t.slot == *slot) t.last = nullptr;
 	return ctx->d_scan_tot + *slot;
 }

@@ -232,10 +232,8 @@ extern "C" int mcom_dump_members_at(mcom_ctx *ctx, const uint64_t *d_packed, con
 	if (rc) return rc;
 	uint64_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, tlen + n_members, 8));
-	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q) {                 // where the text of given members starts (stream sets cut at contig boundaries)
-		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
+	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q)                   // where the text of given members starts (stream sets cut at contig boundaries; checked at the entry)
 		MCOM_HIP(ctx, hipMemcpyAsync(&h_text_at[q], tlen + h_at_members[q], 8, hipMemcpyDeviceToHost, ctx->stream));
-	}
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
 	if (!d_text && !text_cap) return MCOM_OK;                                   // a sizing call: d_pos and d_dir are complete, the text's length known
@@ -376,8 +374,9 @@ __global__ void k_pe_ids(const uint32_t *__restrict__ lists, size_t n_list, cons
 	const uint32_t rid = i < n_list ? lists[i] : (uint32_t)(mem[i - n_list] >> 32);
 	if (rid < half) return;
 	const uint32_t second_before = (uint32_t)i - pre[i];                          // reads of the second file in front of this one
-	if (i < n_list) ids_sp[second_before] = mpv[rid - half];
-	else ids_0[second_before - ((uint32_t)n_list - pre[n_list])] = mpv[rid - half];
+	const uint32_t mate = rid - half < half ? mpv[rid - half] : 0xFFFFFFFFu;          // (an id beyond the two files: not a read of this job)
+	if (i < n_list) ids_sp[second_before] = mate;
+	else ids_0[second_before - ((uint32_t)n_list - pre[n_list])] = mate;
 }
 // file.bin: one bit per read of a range of seq (1 = second file), least significant first (bit_push, breads.h:241-248)
 __global__ void k_pe_bits(const uint32_t *__restrict__ first, size_t lo, size_t n, uint8_t *__restrict__ out)
@@ -450,6 +449,8 @@ extern "C" int mcom_dump_ids_text_at(mcom_ctx *ctx, const uint64_t *d_mem, uint6
 	*h_text_bytes = 0;
 	if (n_members == 0) return MCOM_OK;
 	if (!d_mem) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q)                   // (before any read-back is queued: a return from the middle would leave one pending)
+		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
 	uint64_t *len = nullptr;
 	if (mcom_dmalloc(&len, (n_members + 1) * 8) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "id text scratch");
 	struct Guard { mcom_ctx *c; uint64_t *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, len};
@@ -461,10 +462,8 @@ extern "C" int mcom_dump_ids_text_at(mcom_ctx *ctx, const uint64_t *d_mem, uint6
 	if (rc) return rc;
 	uint64_t total = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, len + n_members, 8));
-	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q) {
-		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
+	for (int q = 0; q < n_at && h_at_members && h_text_at; ++q)
 		MCOM_HIP(ctx, hipMemcpyAsync(&h_text_at[q], len + h_at_members[q], 8, hipMemcpyDeviceToHost, ctx->stream));
-	}
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_text_bytes = total;
 	if (!d_text && !text_cap) return MCOM_OK;                                    // a sizing call
@@ -489,6 +488,11 @@ extern "C" int mcom_dump_pairing_at(mcom_ctx *ctx, const uint32_t *d_lists, uint
 	if (N == 0) return MCOM_OK;
 	if (N >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32-2 reads");
 	if ((n_list && !d_lists) || (n_members && !d_mem) || !d_ids_sp || !d_file_sp || !d_ids_0 || !d_file_0) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	// every read of the two files is in exactly one place (a list or a contig), so the mate of every second-file read is listed too and
+	// every entry of the mate table below is written; an input that breaks this would give pair ids made of uninitialised memory
+	if (N != 2 * (uint64_t)half) return mcom_fail(ctx, MCOM_E_ARG, "pairing: %llu listed reads + %llu members, but two files of %u reads", (unsigned long long)n_list, (unsigned long long)n_members, half);
+	for (int q = 0; q < n_at && h_at_members && h_second_at; ++q)
+		if (h_at_members[q] > n_members) return mcom_fail(ctx, MCOM_E_ARG, "member %llu of %llu", (unsigned long long)h_at_members[q], (unsigned long long)n_members);
 	uint32_t *first = nullptr, *pre = nullptr, *mpv = nullptr;
 	auto drop = [&]() { if (first) mcom_dfree(first); if (pre) mcom_dfree(pre); if (mpv) mcom_dfree(mpv); };
 	if (mcom_dmalloc(&first, (N + 1) * 4) != hipSuccess || mcom_dmalloc(&pre, (N + 1) * 4) != hipSuccess || mcom_dmalloc(&mpv, ((size_t)half + 1) * 4) != hipSuccess) {
@@ -509,7 +513,7 @@ extern "C" int mcom_dump_pairing_at(mcom_ctx *ctx, const uint32_t *d_lists, uint
 		if (e == hipSuccess) e = hipMemcpyAsync(&cnt[1], pre + N, 4, hipMemcpyDeviceToHost, ctx->stream);
 		for (int q = 0; q < n_at && h_at_members && h_second_at && e == hipSuccess; ++q) {   // (first-file reads in front of member m, turned into second-file ones below)
 			h_second_at[q] = 0;
-			if (h_at_members[q] <= n_members) e = hipMemcpyAsync(&h_second_at[q], pre + n_list + h_at_members[q], 4, hipMemcpyDeviceToHost, ctx->stream);
+			e = hipMemcpyAsync(&h_second_at[q], pre + n_list + h_at_members[q], 4, hipMemcpyDeviceToHost, ctx->stream);
 		}
 	}
 	if (e == hipSuccess) e = mcom_stream_sync(ctx);

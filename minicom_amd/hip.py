@@ -287,6 +287,16 @@ class Context:
         self.lib.mcom_set_sketch_prefix_bits.restype = C.c_int; self.lib.mcom_set_sketch_prefix_bits.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.mcom_set_sketch_prefix_bits(self._h, bits))
 
+    def set_claim_route(self, route: int):
+        """Test hook of mcom_claim_pairs: 0 = default (one launch, the launch-per-round loop behind it), 1 = the loop at once, 2 = the
+        one-launch kernel's first barrier gives up (poison flag trips, the loop takes over)."""
+        self.lib.mcom_set_claim_route.restype = C.c_int; self.lib.mcom_set_claim_route.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_claim_route(self._h, route))
+
+    def claim_fallbacks(self) -> int:
+        self.lib.mcom_claim_fallbacks.restype = C.c_int; self.lib.mcom_claim_fallbacks.argtypes = [C.c_void_p]
+        return int(self.lib.mcom_claim_fallbacks(self._h))
+
     def set_consensus_capacity(self, members: int):
         """Test hook of the merge consensus: units that more than `members` members reach use the wave-per-tile kernel (0 = default 127)."""
         self.lib.mcom_set_consensus_capacity.restype = C.c_int; self.lib.mcom_set_consensus_capacity.argtypes = [C.c_void_p, C.c_uint32]

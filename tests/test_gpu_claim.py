@@ -71,6 +71,39 @@ def test_claim_chain_needs_many_rounds_and_reports_when_it_does_not_settle(ctx):
         ctx.claim_pairs(rec, n, max_rounds=10)
 
 
+@pytest.mark.parametrize("route", [1, 2])
+def test_claim_falls_back_to_the_launch_per_round_loop(ctx, route):
+    """The one-launch kernel's grid barrier needs every workgroup resident (another process or thread-rank on the card can prevent
+    that).  route 2 makes its first barrier give up: the poison flag trips, mcom_claim_pairs notices, clears it and redoes the claiming
+    with two launches and a read-back per round; route 1 takes that loop at once.  Same jobs and flags as the sequential loop, and the
+    context stays usable (the next default call runs the one-launch kernel again)."""
+    import torch
+    before = ctx.claim_fallbacks()
+    try:
+        ctx.set_claim_route(route)
+        for n, deg, near in [(5000, 4, 0), (200000, 3, 0), (3000, 2, 1)]:
+            rng = np.random.default_rng(n + deg + near)
+            pairs = _lists(rng, n, deg, near)
+            want_jobs, want_flag = _sequential(pairs, n)
+            rec = torch.from_numpy(_records(pairs).view(np.int64)).cuda()
+            jobs, flag, rounds = ctx.claim_pairs(rec, n)
+            ctx.sync()
+            assert jobs.cpu().numpy().tolist() == [list(j) for j in want_jobs]
+            assert np.array_equal(flag.cpu().numpy(), want_flag) and rounds >= 1
+        assert ctx.claim_fallbacks() == before + 3
+        from minicom_amd.hip import McomError
+        chain = [(i, i + 1, 7, 9) for i in range(399)]
+        rec = torch.from_numpy(_records(chain).view(np.int64)).cuda()
+        with pytest.raises(McomError):
+            ctx.claim_pairs(rec, 400, max_rounds=10)
+    finally:
+        ctx.set_claim_route(0)
+    pairs = _lists(np.random.default_rng(5), 5000, 4)
+    want_jobs, _ = _sequential(pairs, 5000)
+    jobs, _, _ = ctx.claim_pairs(torch.from_numpy(_records(pairs).view(np.int64)).cuda(), 5000)
+    assert jobs.cpu().numpy().tolist() == [list(j) for j in want_jobs] and ctx.claim_fallbacks() == before + 4
+
+
 def test_claim_empty(ctx):
     import torch
     jobs, flag, rounds = ctx.claim_pairs(torch.zeros((0, 2), dtype=torch.int64, device="cuda"), 7)
