@@ -227,6 +227,15 @@ int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_
                                   const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
                                   mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
 
+/* The same over a contig set that the merge rounds leave where it is (cp_cluster, kthread_cb.c:397-434, without its copies: the set is
+ * an append-only store, a contig's index -- and the id in its records -- never changes, and the list of a round is d_ord, the
+ * contigs in visiting order; NULL: the store's own order).  d_rec / d_roff: all minimizer records of the store and their offsets per
+ * contig; the queries are the records of contigs d_ord[0 .. n_contigs) in that order.  The contigs the round before made are the
+ * ones with index >= first_new (n_new of them; n_new = 0: the first round, every pair is evaluated).  Same pairs, same order.      */
+int mcom_find_next_candidates_ord(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_ord, size_t n_contigs,
+                                  const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t first_new, uint32_t n_new,
+                                  mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
+
 /* ---- contig consensus on the device ------------------------------------- */
 /* construct_ref (kthread_bucket.c:69-377) for all n_groups groups of mcom_sort_group's output at once.
  * In : d_members / d_group_off as mcom_sort_group returns them (sketch records y in cmpcluster order).
@@ -250,6 +259,10 @@ int mcom_merge_consensus(mcom_ctx *ctx, const uint64_t *d_packed, const uint64_t
  * builders push into the index, kthread_bucket.c:463, kthread_cb.c:370, :423).  h_total may be NULL.      */
 int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, size_t n, uint32_t m,
                           uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total);
+
+/* ... for a set whose contigs are not stored in the order they are visited in: contig d_ord[c] is the c-th (NULL: the set's own order) */
+int mcom_minimizer_prefix_ord(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, const uint32_t *d_ord, size_t n, uint32_t m,
+                              uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total);
 
 /* ---- a10..a15: Stage-2 realignment --------------------------------------------------------------- */
 /* setglobalarrays_realign (kthread_hash_realign.c:153-206): first/last base of every dictionary key.
@@ -489,6 +502,28 @@ int mcom_records_carry(mcom_ctx *ctx, const mcom_mm128 *d_rec, const uint32_t *d
 int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
                          const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
                          uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars);
+
+/* ... the merged contigs get the ids id_base + j (a store that the merged contigs are appended to: their index there)             */
+int mcom_resketch_merged_at(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
+                            const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k, uint32_t id_base,
+                            uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars);
+/* mcom_merge_members with the room at d_jm stated: MCOM_E_OVERFLOW, h_totals[0] = the members to come and nothing written, when
+ * jm_cap (elements) is too small.                                                                                               */
+int mcom_merge_members_cap(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
+                           int key_bits, uint64_t *d_jm, uint64_t jm_cap, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals);
+/* Merge rounds without cp_cluster's copies (kthread_cb.c:397-434).  The contig set is an append-only store: strings, member lists,
+ * minimizer records and packed words with offset arrays that gain one entry per contig ever made; a round appends its merged contigs
+ * behind everything (mcom_merge_members / _consensus_jobs / mcom_resketch_merged_at / mcom_pack_contigs write behind the store's end with
+ * offsets from 0, mcom_offsets_append turns those into entries of the store's arrays: d_dst[j] = base + d_rel[j], j = 0 .. n) and
+ * mcom_order_next makes the list of the next round: the nj new contigs (indices first_new ...) in claiming order, then the contigs of
+ * d_ord[0 .. n) (NULL: 0 .. n-1) whose d_flag[index] is 0, in their order -- cp_cluster's order.  *h_nkeep = how many those are.
+ * mcom_contigs_gather copies the contigs d_idx[0 .. n_idx) into a set of their own, in that order (offset arrays from 0;
+ * h_totals = { chars, members }): the store becomes an ordinary set again when the rounds are over.                                */
+int mcom_offsets_append(mcom_ctx *ctx, const uint64_t *d_rel, size_t n, uint64_t base, uint64_t *d_dst);
+int mcom_offsets_append_u32(mcom_ctx *ctx, const uint32_t *d_rel, size_t n, uint32_t base, uint32_t *d_dst);
+int mcom_order_next(mcom_ctx *ctx, const uint32_t *d_ord, size_t n, const uint8_t *d_flag, uint32_t first_new, size_t nj, uint32_t *d_ord2, uint64_t *h_nkeep);
+int mcom_contigs_gather(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_soff, const uint64_t *d_mem, const uint64_t *d_moff,
+                        const uint32_t *d_idx, size_t n_idx, uint8_t *d_seq2, uint64_t *d_soff2, uint64_t *d_mem2, uint64_t *d_moff2, uint64_t *h_totals);
 
 /* ---- the stream files of cluster_dump, made where the data is (kthread_dump.c:142-236, :364-417) ---- */
 /* print_encode for every member of every contig: d_mem / d_moff = the member lists in dump order (cmpcluster2 inside a contig,

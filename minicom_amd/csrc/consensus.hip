@@ -523,23 +523,29 @@ int mcom_merge_consensus_regions(mcom_ctx *ctx, const uint64_t *d_packed, const 
 // ------------------------------------------------------------------------------------------------
 // first m minimizers of every contig out of the full sketch: out_moff[c] = c' start, fixed stride not needed
 // ------------------------------------------------------------------------------------------------
-__global__ void k_prefix_counts(const uint32_t *__restrict__ moff, size_t n, uint32_t m, uint32_t *__restrict__ cnt)
+// (ord: the contigs in the order they are taken in -- contig ord[c] of the set is the c-th of the output; NULL = the set's own order)
+__global__ void k_prefix_counts(const uint32_t *__restrict__ moff, const uint32_t *__restrict__ ord, size_t n, uint32_t m, uint32_t *__restrict__ cnt)
 {
 	const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (c < n) { const uint32_t k = moff[c + 1] - moff[c]; cnt[c] = k < m ? k : m; }
+	if (c < n) { const uint32_t i = ord ? ord[c] : (uint32_t)c; const uint32_t k = moff[i + 1] - moff[i]; cnt[c] = k < m ? k : m; }
 	if (c == n) cnt[c] = 0;
 }
-__global__ void k_prefix_copy(const uint32_t *__restrict__ moff, const mcom_mm128 *__restrict__ rec, size_t n, uint32_t m,
+__global__ void k_prefix_copy(const uint32_t *__restrict__ moff, const mcom_mm128 *__restrict__ rec, const uint32_t *__restrict__ ord, size_t n, uint32_t m,
                               const uint32_t *__restrict__ ooff, mcom_mm128 *__restrict__ out)
 {
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const size_t c = t / m; const uint32_t q = (uint32_t)(t - c * m);
 	if (c >= n) return;
-	if (q < ooff[c + 1] - ooff[c]) out[ooff[c] + q] = rec[moff[c] + q];
+	if (q < ooff[c + 1] - ooff[c]) out[ooff[c] + q] = rec[moff[ord ? ord[c] : (uint32_t)c] + q];
 }
 
 extern "C" int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, size_t n, uint32_t m,
                                      uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total)
+{
+	return mcom_minimizer_prefix_ord(ctx, d_moff, d_rec, nullptr, n, m, d_out_moff, d_out, h_total);
+}
+extern "C" int mcom_minimizer_prefix_ord(mcom_ctx *ctx, const uint32_t *d_moff, const mcom_mm128 *d_rec, const uint32_t *d_ord, size_t n, uint32_t m,
+                                         uint32_t *d_out_moff, mcom_mm128 *d_out, uint64_t *h_total)
 {
 	if (!ctx) return MCOM_E_ARG;
 	if (h_total) *h_total = 0;
@@ -550,12 +556,12 @@ extern "C" int mcom_minimizer_prefix(mcom_ctx *ctx, const uint32_t *d_moff, cons
 	const size_t scr_b = (mcom_scan_scratch_elems(n + 1) * 4 + 1024 + 255) & ~(size_t)255;
 	int rc = mcom_ws_reserve(ctx, scr_b);
 	if (rc) return rc;
-	MCOM_LAUNCH(k_prefix_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, n, m, d_out_moff);
+	MCOM_LAUNCH(k_prefix_counts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_ord, n, m, d_out_moff);
 	MCOM_LAUNCH_CHECK(ctx);
 	rc = mcom_scan_u32(ctx, d_out_moff, d_out_moff, n + 1, (uint32_t*)ctx->ws);
 	if (rc) return rc;
 	const size_t tot = n * (size_t)m;
-	MCOM_LAUNCH(k_prefix_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_rec, n, m, d_out_moff, d_out);
+	MCOM_LAUNCH(k_prefix_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, d_moff, d_rec, d_ord, n, m, d_out_moff, d_out);
 	MCOM_LAUNCH_CHECK(ctx);
 	if (h_total) {
 		uint32_t total = 0;

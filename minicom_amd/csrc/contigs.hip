@@ -832,15 +832,19 @@ extern "C" int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint
 // probes the table only where the map says so and lists no pair otherwise -- the pairs left out are exactly pairs k_fn_eval would
 // fail without looking.
 __device__ __forceinline__ uint32_t fn_key_bit(uint64_t x, int kbits) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> (64 - kbits)); }
-__global__ void k_fn_newkeys(const mcom_mm128 *__restrict__ irec, size_t n, uint32_t n_new, int kbits, uint32_t *__restrict__ keymap)
+// Which contigs are new in this round: ids [new_lo, new_lo + new_span) (new_span = 0: all of them, the first round).  The copying form of
+// the merge rounds puts the new contigs at the head of the list (new_lo = 0, new_span = their number); the form that leaves the set where
+// it is gives them the ids behind everybody else's (new_lo = first new id, new_span = 2^32 - 1).
+__device__ __forceinline__ bool fn_is_new(uint32_t id, uint32_t new_lo, uint32_t new_span) { return id >= new_lo && (uint32_t)(id - new_lo) < new_span; }
+__global__ void k_fn_newkeys(const mcom_mm128 *__restrict__ irec, size_t n, uint32_t new_lo, uint32_t new_span, int kbits, uint32_t *__restrict__ keymap)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const mcom_mm128 t = irec[i];
-	if ((uint32_t)(t.y >> 32) < n_new) { const uint32_t h = fn_key_bit(t.x, kbits); atomicOr(&keymap[h >> 5], 1u << (h & 31)); }
+	if (fn_is_new((uint32_t)(t.y >> 32), new_lo, new_span)) { const uint32_t h = fn_key_bit(t.x, kbits); atomicOr(&keymap[h >> 5], 1u << (h & 31)); }
 }
 __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t region, uint32_t bbits, const mcom_mm128 *__restrict__ q, size_t nq,
-                            uint32_t n_new, int kbits, const uint32_t *__restrict__ keymap, uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
+                            uint32_t new_lo, uint32_t new_span, int kbits, const uint32_t *__restrict__ keymap, uint32_t *__restrict__ hits, uint32_t *__restrict__ first)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nq) return;
@@ -848,9 +852,44 @@ __global__ void k_fn_counts(const uint64_t *__restrict__ slots, uint32_t log2cap
 	const mcom_mm128 t = q[i];
 	uint32_t s = 0, c = 0;
 	bool look = t.x != U64MAX;
-	if (look && n_new && (uint32_t)(t.y >> 32) >= n_new) { const uint32_t h = fn_key_bit(t.x, kbits); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
+	if (look && new_span && !fn_is_new((uint32_t)(t.y >> 32), new_lo, new_span)) { const uint32_t h = fn_key_bit(t.x, kbits); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
 	if (look) mcom_table_find_any(slots, log2cap, region, bbits, t.x, s, c);
 	hits[i] = c; if (c) first[i] = s;              // the later passes read these instead of probing the table again (first: only where there are hits)
+}
+// The same over a set whose contigs are NOT stored in visiting order (round 5: a merge round leaves the unmerged contigs where they are and
+// appends the merged ones; `ord` lists the contigs in visiting order, k_fn_qcounts + a scan give the first query number of each): sixteen
+// lanes per contig walk its records; a query with hits leaves its y in qy (the pair kernels read it there: the records themselves are
+// not in query order).
+__global__ void k_fn_qcounts(const uint32_t *__restrict__ roff, const uint32_t *__restrict__ ord, size_t n, uint32_t *__restrict__ cnt)
+{
+	const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (u > n) return;
+	if (u == n) { cnt[u] = 0; return; }
+	const uint32_t c = ord ? ord[u] : (uint32_t)u;
+	cnt[u] = roff[c + 1] - roff[c];
+}
+__global__ __launch_bounds__(256) void k_fn_counts_ord(const uint64_t *__restrict__ slots, uint32_t log2cap, uint32_t region, uint32_t bbits,
+                                                       const mcom_mm128 *__restrict__ rec, const uint32_t *__restrict__ roff, const uint32_t *__restrict__ ord,
+                                                       const uint32_t *__restrict__ qoff, size_t n, uint32_t nq, uint32_t new_lo, uint32_t new_span, int kbits,
+                                                       const uint32_t *__restrict__ keymap, uint32_t *__restrict__ hits, uint32_t *__restrict__ first,
+                                                       uint64_t *__restrict__ qy)
+{
+	const size_t u = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+	if (u >= n) return;
+	const int lane = threadIdx.x & 15;
+	if (u == 0 && lane == 0) hits[nq] = 0;
+	const uint32_t c = ord ? ord[u] : (uint32_t)u;
+	const uint32_t r0 = roff[c], cnt = roff[c + 1] - r0, q0 = qoff[u];
+	const bool old_contig = new_span && !fn_is_new(c, new_lo, new_span);
+	for (uint32_t t = lane; t < cnt; t += 16) {
+		const mcom_mm128 v = rec[r0 + t];
+		uint32_t s = 0, k = 0;
+		bool look = v.x != U64MAX;
+		if (look && old_contig) { const uint32_t h = fn_key_bit(v.x, kbits); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
+		if (look) mcom_table_find_any(slots, log2cap, region, bbits, v.x, s, k);
+		hits[q0 + t] = k;
+		if (k) { first[q0 + t] = s; qy[q0 + t] = v.y; }
+	}
 }
 // Round 4: the evaluation runs one thread per (query, hit) PAIR.  Three queries in four have no hit, and the others between one
 // and thousands: with a thread per query (rounds 1-3) a wave ran as long as its busiest lane while most lanes had nothing to do, and
@@ -868,19 +907,19 @@ __global__ void k_fn_expand(const uint32_t *__restrict__ pair_off, size_t nq, ui
 // same positions, and a passing pair of two contigs that both stay unclaimed does not exist (the first of the two to be visited would
 // have taken the other, kthread_cb.c:286-343) -- so it failed match_pro then and fails it now.
 __global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
-                          const mcom_mm128 *__restrict__ q, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q, uint32_t n_pairs,
+                          const mcom_mm128 *__restrict__ q, const uint64_t *__restrict__ qy, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q, uint32_t n_pairs,
                           const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint32_t *__restrict__ clen,
-                          int cbthr, uint32_t n_new, uint32_t *__restrict__ pass)
+                          int cbthr, uint32_t new_lo, uint32_t new_span, uint32_t *__restrict__ pass)
 {
 	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n_pairs) return;
 	const uint32_t i = pair_q[p];
 	const uint32_t u = p - pair_off[i], s = first[i];
-	const uint64_t my = q[i].y, y = irec[s + u].y;
+	const uint64_t my = qy ? qy[i] : q[i].y, y = irec[s + u].y;
 	const uint32_t ci = (uint32_t)(my >> 32), pos_ori = (uint32_t)my >> 1;   // the id IS the contig index here (include/mcom.h, "contig ids")
 	const uint32_t cj = (uint32_t)(y >> 32), pos = (uint32_t)y >> 1;
 	uint32_t ok = 0;
-	if (cj != ci && ((my ^ y) & 1) == 0 && (n_new == 0 || ci < n_new || cj < n_new)) {
+	if (cj != ci && ((my ^ y) & 1) == 0 && (new_span == 0 || fn_is_new(ci, new_lo, new_span) || fn_is_new(cj, new_lo, new_span))) {
 		const uint32_t mis = match_pro_packed(cbits + coff[ci], clen[ci], cbits + coff[cj], clen[cj], (int)pos_ori, (int)pos, (uint32_t)cbthr);
 		ok = mis <= (uint32_t)cbthr;
 	}
@@ -888,7 +927,7 @@ __global__ void k_fn_eval(const uint32_t *__restrict__ first, const mcom_mm128 *
 	if (p == 0) pass[n_pairs] = 0;                                               // the scan over n_pairs + 1 flags leaves the number of passing pairs here
 }
 __global__ void k_fn_emit(const uint32_t *__restrict__ first, const mcom_mm128 *__restrict__ irec,
-                          const mcom_mm128 *__restrict__ q, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q,
+                          const mcom_mm128 *__restrict__ q, const uint64_t *__restrict__ qy, const uint32_t *__restrict__ pair_off, const uint32_t *__restrict__ pair_q,
                           const uint32_t *__restrict__ pass_pre, uint32_t n_pairs,
                           mcom_mm128 *__restrict__ out)
 {
@@ -897,7 +936,7 @@ __global__ void k_fn_emit(const uint32_t *__restrict__ first, const mcom_mm128 *
 	const uint32_t here = pass_pre[p], nxt = pass_pre[p + 1];                       // (n_pairs + 1 scanned flags)
 	if (nxt == here) return;
 	const uint32_t i = pair_q[p];
-	mcom_mm128 v; v.x = q[i].y; v.y = irec[first[i] + (p - pair_off[i])].y;        // x = query y (contig i, pos_ori, dir), y = hit y
+	mcom_mm128 v; v.x = qy ? qy[i] : q[i].y; v.y = irec[first[i] + (p - pair_off[i])].y;   // x = query y (contig i, pos_ori, dir), y = hit y
 	out[here] = v;
 }
 
@@ -907,14 +946,34 @@ extern "C" int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, cons
 {
 	return mcom_find_next_candidates_new(ctx, mi, d_query, n_query, d_cbits, d_coff, d_clen, cbthr, 0, d_out, cap, h_counts);
 }
-extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
-                                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
-                                             mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
+// the two forms share everything behind the hit counts: queries given in visiting order (d_query) or contigs given in visiting order
+// over records that lie elsewhere (d_roff + d_ord over d_query as the record array)
+static int find_next_impl(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query, const uint32_t *d_roff, const uint32_t *d_ord, size_t n_contigs,
+                          const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t new_lo, uint32_t new_span, uint32_t n_new_hint,
+                          mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
 {
 	if (!ctx || !mi) return MCOM_E_ARG;
 	if (h_counts) { h_counts[0] = h_counts[1] = 0; }
-	if (n_query == 0) return MCOM_OK;
+	const bool by_contig = d_roff != nullptr;
+	if (by_contig ? n_contigs == 0 : n_query == 0) return MCOM_OK;
 	if (!d_query || !d_cbits || !d_coff || !d_clen) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	uint32_t *qoff = nullptr;
+	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } };
+	if (by_contig) {                                                             // first query number of every contig, in visiting order
+		if (mcom_dmalloc(&qoff, (n_contigs + 1) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
+	}
+	FirstGuard qoff_guard{qoff};
+	if (by_contig) {
+		MCOM_LAUNCH(k_fn_qcounts, dim3((unsigned)((n_contigs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_roff, d_ord, n_contigs, qoff);
+		MCOM_LAUNCH_CHECK(ctx);
+		int rc0 = mcom_scan_u32(ctx, qoff, qoff, n_contigs + 1, nullptr);
+		if (rc0) return rc0;
+		uint32_t nq = 0;
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &nq, qoff + n_contigs, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
+		n_query = nq;
+		if (n_query == 0) return MCOM_OK;
+	}
 	if (n_query >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many query minimizers");
 	// pass 1: hits per query -> pair offsets
 	const size_t nq1 = n_query + 1;
@@ -923,23 +982,30 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	// ~16 map bits per key of a new contig (a contig has about six keys in the index), 8 MB at most: a map that stays in the L2s beats a
 	// sparser one that does not (measured: 32 bits per key up to 32 MB made the rounds with a million new contigs 7 % slower)
 	int kbits = 20;
-	while (kbits < 26 && ((uint64_t)1 << kbits) < (uint64_t)n_new * 6 * 16) ++kbits;
-	const size_t map_b = n_new ? (size_t)1 << (kbits - 3) : 0;
+	while (kbits < 26 && ((uint64_t)1 << kbits) < (uint64_t)n_new_hint * 6 * 16) ++kbits;
+	const size_t map_b = new_span ? (size_t)1 << (kbits - 3) : 0;
 	int rc = mcom_ws_reserve(ctx, hit_b + scr1_b + map_b);
 	if (rc) return rc;
 	uint32_t *hits = (uint32_t*)ctx->ws;
-	uint32_t *keymap = n_new ? (uint32_t*)((char*)ctx->ws + hit_b + scr1_b) : nullptr;
+	uint32_t *keymap = new_span ? (uint32_t*)((char*)ctx->ws + hit_b + scr1_b) : nullptr;
 	uint32_t *first = nullptr, *pair_off = nullptr;                            // pair_off: the scanned counts, in an allocation of its own (the workspace may move below)
+	uint64_t *qy = nullptr;
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
-	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } } first_guard{first};
+	FirstGuard first_guard{first};
 	if (mcom_dmalloc(&pair_off, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	FirstGuard off_guard{pair_off};
+	if (by_contig && mcom_dmalloc(&qy, nq1 * 8) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
+	FirstGuard qy_guard{(uint32_t*)qy};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
-	if (n_new) {
+	if (new_span) {
 		MCOM_HIP(ctx, hipMemsetAsync(keymap, 0, map_b, ctx->stream));
-		if (mi->n) MCOM_LAUNCH(k_fn_newkeys, dim3((unsigned)((mi->n + 255) / 256)), dim3(256), 0, ctx->stream, mi->rec, mi->n, n_new, kbits, keymap);
+		if (mi->n) MCOM_LAUNCH(k_fn_newkeys, dim3((unsigned)((mi->n + 255) / 256)), dim3(256), 0, ctx->stream, mi->rec, mi->n, new_lo, new_span, kbits, keymap);
 	}
-	MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, n_new, kbits, keymap, hits, first);
+	if (by_contig)
+		MCOM_LAUNCH(k_fn_counts_ord, dim3((unsigned)((n_contigs * 16 + 255) / 256)), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits,
+		            d_query, d_roff, d_ord, (const uint32_t*)qoff, n_contigs, (uint32_t)n_query, new_lo, new_span, kbits, keymap, hits, first, qy);
+	else
+		MCOM_LAUNCH(k_fn_counts, dim3(qb), dim3(256), 0, ctx->stream, mi->tab.slots, mi->tab.log2cap, mi->tab.region, mi->tab.bbits, d_query, n_query, new_lo, new_span, kbits, keymap, hits, first);
 	MCOM_LAUNCH_CHECK(ctx);
 	rc = mcom_scan_u32(ctx, hits, pair_off, nq1, (uint32_t*)((char*)ctx->ws + hit_b));
 	if (rc) return rc;
@@ -961,7 +1027,7 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	const unsigned pb = (unsigned)(((size_t)n_pairs + 255) / 256);
 	{ McomProfScope ps_(ctx, PROF_FIND_NEXT);
 	MCOM_LAUNCH(k_fn_expand, dim3(qb), dim3(256), 0, ctx->stream, pair_off, n_query, pair_q);
-	MCOM_LAUNCH(k_fn_eval, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, n_pairs, d_cbits, d_coff, d_clen, cbthr, n_new, pass); }
+	MCOM_LAUNCH(k_fn_eval, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, (const uint64_t*)qy, pair_off, pair_q, n_pairs, d_cbits, d_coff, d_clen, cbthr, new_lo, new_span, pass); }
 	uint32_t n_pass = 0;
 	rc = mcom_scan_u32(ctx, pass, pass, (size_t)n_pairs + 1, (uint32_t*)ctx->ws);
 	if (rc) { cleanup(); return rc; }
@@ -972,10 +1038,23 @@ extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, 
 	if (n_pass > cap) { cleanup(); return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u passing candidates but room for %zu", n_pass, cap); }
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
-		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, pair_off, pair_q, pass, n_pairs, d_out);
+		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, (const uint64_t*)qy, pair_off, pair_q, pass, n_pairs, d_out);
 		e1 = mcom_stream_sync(ctx);
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}
 	cleanup();
 	return MCOM_OK;
+}
+extern "C" int mcom_find_next_candidates_new(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
+                                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t n_new,
+                                             mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
+{
+	return find_next_impl(ctx, mi, d_query, n_query, nullptr, nullptr, 0, d_cbits, d_coff, d_clen, cbthr, 0, n_new, n_new, d_out, cap, h_counts);
+}
+extern "C" int mcom_find_next_candidates_ord(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_rec, const uint32_t *d_roff, const uint32_t *d_ord, size_t n_contigs,
+                                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr, uint32_t first_new, uint32_t n_new,
+                                             mcom_mm128 *d_out, size_t cap, uint64_t *h_counts)
+{
+	if (!d_roff) return ctx ? mcom_fail(ctx, MCOM_E_ARG, "null device pointer") : MCOM_E_ARG;
+	return find_next_impl(ctx, mi, d_rec, 0, d_roff, d_ord, n_contigs, d_cbits, d_coff, d_clen, cbthr, first_new, n_new ? 0xFFFFFFFFu : 0u, n_new, d_out, cap, h_counts);
 }

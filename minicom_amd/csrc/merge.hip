@@ -175,6 +175,11 @@ __global__ void k_job_len(const mcom_mm128 *__restrict__ rec, const uint64_t *__
 extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
                                   int key_bits, uint64_t *d_jm, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals)
 {
+	return mcom_merge_members_cap(ctx, d_mem, d_moff, d_jobs, nj, L, key_bits, d_jm, ~(uint64_t)0, d_jmoff, d_jroff, h_totals);
+}
+extern "C" int mcom_merge_members_cap(mcom_ctx *ctx, const uint64_t *d_mem, const uint64_t *d_moff, const uint32_t *d_jobs, size_t nj, int L,
+                                      int key_bits, uint64_t *d_jm, uint64_t jm_cap, uint64_t *d_jmoff, uint64_t *d_jroff, uint64_t *h_totals)
+{
 	if (!ctx || !h_totals) return MCOM_E_ARG;
 	h_totals[0] = h_totals[1] = h_totals[2] = 0;
 	if (nj == 0) {
@@ -197,6 +202,7 @@ extern "C" int mcom_merge_members(mcom_ctx *ctx, const uint64_t *d_mem, const ui
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &total, d_jmoff + nj, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (total >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many members in one merge round");
+	if (total > jm_cap) { h_totals[0] = total; return mcom_fail(ctx, MCOM_E_OVERFLOW, "%llu merged members but room for %llu", (unsigned long long)total, (unsigned long long)jm_cap); }
 	const size_t rec_b = al256(total * sizeof(mcom_mm128));
 	if ((rc = mcom_ws_reserve(ctx, rec_b + mcom_sort_ws_bytes(total) + al256(scan64_scratch_elems(nj + 1) * 8) + al256(MCOM_GROUP_SCRATCH(total) * 4) + 1024))) return rc;
 	WsCut w{(char*)ctx->ws, 0};
@@ -485,6 +491,106 @@ extern "C" int mcom_contigs_carry(mcom_ctx *ctx, const uint8_t *d_seq, const uin
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[0], d_soff2 + nj + nkeep, 8));
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[1], d_moff2 + nj + nkeep, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	return MCOM_OK;
+}
+
+
+// the contigs d_idx[0 .. n_idx) of a set, in that order, as a set of their own (strings, member lists, both offset arrays from 0): what
+// the store of the merge rounds is turned into when the rounds are over -- the one copy that is left of cp_cluster's
+extern "C" int mcom_contigs_gather(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_soff, const uint64_t *d_mem, const uint64_t *d_moff,
+                                   const uint32_t *d_idx, size_t n_idx, uint8_t *d_seq2, uint64_t *d_soff2, uint64_t *d_mem2, uint64_t *d_moff2, uint64_t *h_totals)
+{
+	if (!ctx || !h_totals) return MCOM_E_ARG;
+	h_totals[0] = h_totals[1] = 0;
+	if (!d_soff2 || !d_moff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_HIP(ctx, hipMemsetAsync(d_soff2, 0, 8, ctx->stream));
+	MCOM_HIP(ctx, hipMemsetAsync(d_moff2, 0, 8, ctx->stream));
+	if (n_idx == 0) return MCOM_OK;
+	if (!d_seq || !d_soff || !d_mem || !d_moff || !d_idx || !d_seq2 || !d_mem2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	int rc = mcom_ws_reserve(ctx, 2 * al256((n_idx + 1) * 8) + al256(scan64_scratch_elems(n_idx + 1) * 8) + 256);
+	if (rc) return rc;
+	WsCut w{(char*)ctx->ws, 0};
+	uint64_t *ss = w.take<uint64_t>(n_idx + 1), *ms = w.take<uint64_t>(n_idx + 1);
+	uint64_t *scr64 = w.take<uint64_t>(scan64_scratch_elems(n_idx + 1));
+	const unsigned kb = (unsigned)((n_idx + 1 + 255) / 256);
+	MCOM_LAUNCH(k_keep_sizes, dim3(kb), dim3(256), 0, ctx->stream, d_idx, n_idx, d_soff, d_moff, ss, ms);
+	MCOM_LAUNCH_CHECK(ctx);
+	if ((rc = scan64(ctx, ss, ss, n_idx + 1, scr64)) || (rc = scan64(ctx, ms, ms, n_idx + 1, scr64))) return rc;
+	MCOM_LAUNCH(k_keep_offsets, dim3(kb), dim3(256), 0, ctx->stream, ss, ms, n_idx, (size_t)0, d_soff2, d_moff2);
+	MCOM_LAUNCH(k_keep_copy, dim3((unsigned)((n_idx * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_idx, n_idx, (size_t)0, d_seq, d_soff, d_mem, d_moff,
+	                   d_seq2, d_soff2, d_mem2, d_moff2);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[0], d_soff2 + n_idx, 8));
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &h_totals[1], d_moff2 + n_idx, 8));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	return MCOM_OK;
+}
+
+// ---- merge rounds that leave the set where it is (round 5) -------------------------------------------------------------------------
+// cp_cluster (kthread_cb.c:397-434) copies every unmerged contig into the other buffer each round; the order of the new list --
+// merged contigs in claiming order, then the others in their order -- is all that later code needs from that.  Here the contig set is
+// an append-only store (strings, member lists, minimizer records, packed words: offset arrays with one more entry per contig ever
+// made, a contig's index never changes) and the list is an array of indices into it (`ord`).  A round appends its merged contigs and
+// makes the next list; nothing is copied but the list.
+__global__ void k_off_append64(const uint64_t *__restrict__ rel, size_t n, uint64_t base, uint64_t *__restrict__ dst)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j <= n) dst[j] = base + rel[j];
+}
+__global__ void k_off_append32(const uint32_t *__restrict__ rel, size_t n, uint32_t base, uint32_t *__restrict__ dst)
+{
+	const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j <= n) dst[j] = base + rel[j];
+}
+extern "C" int mcom_offsets_append(mcom_ctx *ctx, const uint64_t *d_rel, size_t n, uint64_t base, uint64_t *d_dst)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!d_rel || !d_dst) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_LAUNCH(k_off_append64, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rel, n, base, d_dst);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+extern "C" int mcom_offsets_append_u32(mcom_ctx *ctx, const uint32_t *d_rel, size_t n, uint32_t base, uint32_t *d_dst)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (!d_rel || !d_dst) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_LAUNCH(k_off_append32, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rel, n, base, d_dst);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+__global__ void k_ord_flags(const uint32_t *__restrict__ ord, const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ kf)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i <= n) kf[i] = (i < n && !flag[ord ? ord[i] : (uint32_t)i]) ? 1u : 0u;
+}
+__global__ void k_ord_next(const uint32_t *__restrict__ ord, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ kpos, size_t n, uint32_t first_new, size_t nj,
+                           uint32_t *__restrict__ ord2)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nj) ord2[i] = first_new + (uint32_t)i;
+	if (i < n) { const uint32_t c = ord ? ord[i] : (uint32_t)i; if (!flag[c]) ord2[nj + kpos[i]] = c; }
+}
+extern "C" int mcom_order_next(mcom_ctx *ctx, const uint32_t *d_ord, size_t n, const uint8_t *d_flag, uint32_t first_new, size_t nj, uint32_t *d_ord2, uint64_t *h_nkeep)
+{
+	if (!ctx || !h_nkeep) return MCOM_E_ARG;
+	*h_nkeep = 0;
+	if (n + nj == 0) return MCOM_OK;
+	if (!d_ord2 || (n && !d_flag)) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (n + nj >= (1ull << 32) - 1 || (uint64_t)first_new + nj >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32 - 2 contigs");
+	uint32_t *kf = nullptr;
+	if (mcom_dmalloc(&kf, (n + 1) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "order scratch");
+	struct G { mcom_ctx *c; uint32_t *p; ~G() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } g{ctx, kf};
+	const size_t m = n > nj ? n : nj;
+	MCOM_LAUNCH(k_ord_flags, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_ord, d_flag, n, kf);
+	MCOM_LAUNCH_CHECK(ctx);
+	int rc = mcom_scan_u32(ctx, kf, kf, n + 1, nullptr);
+	if (rc) return rc;
+	uint32_t keep = 0;
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, &keep, kf + n, 4));
+	MCOM_LAUNCH(k_ord_next, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_ord, d_flag, (const uint32_t*)kf, n, first_new, nj, d_ord2);
+	MCOM_LAUNCH_CHECK(ctx);
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	*h_nkeep = keep;
 	return MCOM_OK;
 }
 

@@ -95,13 +95,13 @@ __global__ void k_rs_count(const RsPlan *__restrict__ plan, size_t nj, const mco
 }
 
 __global__ __launch_bounds__(256) void k_rs_write(const RsPlan *__restrict__ plan, const RsCut *__restrict__ cut, size_t nj, const mcom_mm128 *__restrict__ rec,
-                                                  const mcom_mm128 *__restrict__ srec, const uint32_t *__restrict__ roff2, mcom_mm128 *__restrict__ out)
+                                                  const mcom_mm128 *__restrict__ srec, const uint32_t *__restrict__ roff2, mcom_mm128 *__restrict__ out, uint32_t id_base)
 {
 	const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;     // sixteen lanes per job: a merged contig holds a few dozen records
 	if (j >= nj) return;
 	const int lane = threadIdx.x & 15;
 	const RsPlan P = plan[j]; const RsCut C = cut[j];
-	const uint64_t id = (uint64_t)(uint32_t)j << 32;                        // the contig index (include/mcom.h, "contig ids")
+	const uint64_t id = (uint64_t)(id_base + (uint32_t)j) << 32;             // the contig index (include/mcom.h, "contig ids")
 	mcom_mm128 *dst = out + roff2[j];
 	for (uint32_t t = lane; t < C.nl; t += 16) { mcom_mm128 r = rec[C.l0 + t]; r.y = id | (r.y & 0xFFFFFFFFull); dst[t] = r; }
 	dst += C.nl;
@@ -129,13 +129,19 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
                                     const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k,
                                     uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars)
 {
+	return mcom_resketch_merged_at(ctx, d_jobs, nj, d_soff, d_rec, d_roff, d_seq2, d_soff2, merged_chars, w, k, 0, d_roff2, d_rec2, cap2, h_total, h_sketched_chars);
+}
+extern "C" int mcom_resketch_merged_at(mcom_ctx *ctx, const uint32_t *d_jobs, size_t nj, const uint64_t *d_soff, const mcom_mm128 *d_rec,
+                                       const uint32_t *d_roff, const uint8_t *d_seq2, const uint64_t *d_soff2, uint64_t merged_chars, int w, int k, uint32_t id_base,
+                                       uint32_t *d_roff2, mcom_mm128 *d_rec2, size_t cap2, uint64_t *h_total, uint64_t *h_sketched_chars)
+{
 	if (!ctx || !h_total) return MCOM_E_ARG;
 	*h_total = 0;
 	if (h_sketched_chars) *h_sketched_chars = 0;
 	if (k < 1 || k > 31 || !(k & 1) || w < 1 || w > 128) return mcom_fail(ctx, MCOM_E_ARG, "w=%d (1..128) or k=%d (odd, 1..31) out of range", w, k);
 	if (!d_roff2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	if (nj == 0) { MCOM_HIP(ctx, hipMemsetAsync(d_roff2, 0, 4, ctx->stream)); return MCOM_OK; }
-	if (nj >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32 - 2 contigs: record ids overflow");
+	if ((uint64_t)id_base + nj >= (1ull << 32) - 1) return mcom_fail(ctx, MCOM_E_ARG, "more than 2^32 - 2 contigs: record ids overflow");
 	if (!d_jobs || !d_soff || !d_rec || !d_roff || !d_seq2 || !d_soff2 || !d_rec2) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	DevBlock b_plan, b_s0, b_s1, b_cnt, b_moff, b_srec, b_cut;
 	RsPlan *plan = b_plan.get<RsPlan>(nj);
@@ -175,7 +181,7 @@ extern "C" int mcom_resketch_merged(mcom_ctx *ctx, const uint32_t *d_jobs, size_
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	*h_total = total;
 	if (total > cap2) return mcom_fail(ctx, MCOM_E_OVERFLOW, "%u minimizers but room for %zu", total, cap2);
-	MCOM_LAUNCH(k_rs_write, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2);
+	MCOM_LAUNCH(k_rs_write, dim3((unsigned)((nj * 16 + 255) / 256)), dim3(256), 0, ctx->stream, plan, cut, nj, d_rec, srec, d_roff2, d_rec2, id_base);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));                          // the temporaries go back to the pool
 	return MCOM_OK;

@@ -536,6 +536,42 @@ class Context:
                                                 self._p(moff2, torch.int64), self._p(keepidx), tot))
         return keepidx[:nkeep], (int(tot[0]), int(tot[1]))
 
+    def order_next(self, ord_, n: int, flag, first_new: int, nj: int):
+        """mcom_order_next: the list of the next merge round.  ord_ int32 [n] or None (0 .. n-1), flag uint8 indexed by contig."""
+        torch = _torch()
+        self.lib.mcom_order_next.restype = C.c_int
+        self.lib.mcom_order_next.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint64)]
+        out = torch.empty(max(n + nj, 1), dtype=torch.int32, device=self.device)
+        nk = C.c_uint64()
+        self._check(self.lib.mcom_order_next(self._h, self._p(ord_, torch.int32) if ord_ is not None else None, n, self._p(flag, torch.uint8) if flag is not None else None,
+                                             first_new, nj, self._p(out), C.byref(nk)))
+        return out[: nj + int(nk.value)], int(nk.value)
+
+    def contigs_gather(self, seq, soff, mem, moff, idx):
+        """mcom_contigs_gather: contigs idx[...] of a set as a set of their own.  Returns (seq2, soff2, mem2, moff2)."""
+        torch = _torch()
+        self.lib.mcom_contigs_gather.restype = C.c_int
+        self.lib.mcom_contigs_gather.argtypes = [C.c_void_p] * 6 + [C.c_size_t] + [C.c_void_p] * 4 + [C.POINTER(C.c_uint64)]
+        k = int(idx.shape[0])
+        seq2 = torch.empty(int(seq.shape[0]) + 16, dtype=torch.uint8, device=self.device)
+        mem2 = torch.empty(int(mem.shape[0]) + 1, dtype=torch.int64, device=self.device)
+        soff2 = torch.empty(k + 1, dtype=torch.int64, device=self.device); moff2 = torch.empty(k + 1, dtype=torch.int64, device=self.device)
+        tot = (C.c_uint64 * 2)()
+        self._check(self.lib.mcom_contigs_gather(self._h, self._p(seq), self._p(soff, torch.int64), self._p(mem, torch.int64), self._p(moff, torch.int64),
+                                                 self._p(idx, torch.int32), k, self._p(seq2), self._p(soff2), self._p(mem2), self._p(moff2), tot))
+        return seq2[: int(tot[0])], soff2, mem2[: int(tot[1])], moff2
+
+    def offsets_append(self, rel, base: int, dst, at: int):
+        """mcom_offsets_append / _u32: dst[at + j] = base + rel[j] for the n + 1 entries of rel."""
+        torch = _torch()
+        n = int(rel.shape[0]) - 1
+        if rel.dtype == torch.int64:
+            self.lib.mcom_offsets_append.restype = C.c_int; self.lib.mcom_offsets_append.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+            self._check(self.lib.mcom_offsets_append(self._h, self._p(rel), n, base, C.c_void_p(dst.data_ptr() + 8 * at)))
+        else:
+            self.lib.mcom_offsets_append_u32.restype = C.c_int; self.lib.mcom_offsets_append_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+            self._check(self.lib.mcom_offsets_append_u32(self._h, self._p(rel, torch.int32), n, base, C.c_void_p(dst.data_ptr() + 4 * at)))
+
     def members_finalize(self, mem, moff, passes, key_bits: int):
         """mcom_members_finalize.  mem int64 [M], moff int64 [n+1]; passes: list of (contig int32 [k], member int64 [k]).
         Returns (mem2 int64, moff2 int64 [n+1])."""

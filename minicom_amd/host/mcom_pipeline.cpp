@@ -899,8 +899,11 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 					rc = mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, D.n, D.chars, D.members,
 					                            D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc);
 					if (rc != MCOM_E_OVERFLOW) break;
-					if (!D.seq.grow(D.chars + gc[1] + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + 1, D.members, p->stream) ||
-					    !D.soff.grow(D.n + gc[0] + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+					// (round 1 makes nearly all the contigs: room for what combine_cluster will append behind them -- its merge rounds leave the
+					// set where it is and add the merged contigs, about 1.3 x the set in all -- so that no round has to move the store)
+					const uint64_t slack_c = r == 1 ? (D.chars + gc[1]) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + gc[2]) * 13 / 10 : 0, slack_n = r == 1 ? (D.n + gc[0]) * 13 / 10 : 0;
+					if (!D.seq.grow(D.chars + gc[1] + slack_c + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + slack_m + 1, D.members, p->stream) ||
+					    !D.soff.grow(D.n + gc[0] + slack_n + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + slack_n + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
 				}
 				if (rc) return p->gpu(rc);
 				D.n += gc[0]; D.chars += gc[1]; D.members += gc[2];
@@ -925,8 +928,9 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 				tn += cn[q]; tc += cc[q]; tm += cm[q];
 				n_sg_total += all[5 * q + 3] + (last ? all[5 * q + 4] : 0);
 			}
-			if (!D.seq.grow(D.chars + tc + 16, D.chars, p->stream) || !D.mem.grow(D.members + tm + 1, D.members, p->stream) ||
-			    !D.soff.grow(D.n + tn + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + tn + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
+			const uint64_t slack_c = r == 1 ? (D.chars + tc) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + tm) * 13 / 10 : 0, slack_n = r == 1 ? (D.n + tn) * 13 / 10 : 0;   // (see the single-GPU branch)
+			if (!D.seq.grow(D.chars + tc + slack_c + 16, D.chars, p->stream) || !D.mem.grow(D.members + tm + slack_m + 1, D.members, p->stream) ||
+			    !D.soff.grow(D.n + tn + slack_n + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + tn + slack_n + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
 			if (ng) {
 				uint64_t gc2[4];
 				if ((rc = p->gpu(mcom_groups_to_contigs(p->ctx, d_members.p, d_goff.p, ng, d_keep.p, d_nkept.p, d_sv.p, d_reflen.p, d_refs.p, RS, fn[me] - 1, fc[me], fm[me],
@@ -1204,8 +1208,14 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 	long pre = 0;
 	int rc;
 	ContigSet &C = p->C;
-	DevSet A, B, Tm;                                                         // Tm: a rank's share of a round's merged contigs (multi-GPU)
-	DevBuf<uint32_t> moff_m, d_jobs, d_keepidx; DevBuf<mcom_mm128> rec_m, d_pairs, d_pairs_loc; DevBuf<uint8_t> d_flag;
+	// Round 5: the contig set of this stage is an append-only STORE (S: strings, member lists, minimizer records; the packed words in
+	// p->d_cbits & co.).  A contig's index in it never changes -- so neither do the ids in its records -- and the list of a round is
+	// `ord`, indices into the store in visiting order (nullptr: the store's own order, the first round).  cp_cluster's copies of the
+	// unmerged contigs (kthread_cb.c:397-434) are gone: a round appends what it merged and makes the next list (include/mcom.h,
+	// "Merge rounds without cp_cluster's copies"); when the rounds are over the list is gathered into an ordinary set, once.
+	DevSet S, Tm;                                                            // Tm: a rank's share of a round's merged contigs (multi-GPU)
+	DevBuf<uint32_t> ord, ord2, moff_m, d_jobs, roff_t, d_ids; DevBuf<uint64_t> jmoff_t, jroff_t, cw_t;
+	DevBuf<mcom_mm128> rec_m, d_pairs, d_pairs_loc; DevBuf<uint8_t> d_flag;
 	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
 	struct Job { uint32_t ci, cj, pos_ori, pos; };
 	PinVec<Job> jobs;
@@ -1213,69 +1223,81 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 	auto lap = [&](const char *nm) { const double t = busy_now(p); p->stat[nm] += t - tl; tl = t; };
 	// the set of the bucket stage is on the device already (kt_for_bucket); a set that only exists on the host is uploaded
 	uint64_t maxlen = 2 * (uint64_t)L;                                        // a group's consensus spans at most 2L columns
-	if (p->dC_valid) { A.swap(p->dC); p->dC_valid = false; }
+	if (p->dC_valid) { S.swap(p->dC); p->dC_valid = false; }
 	else {
-		A.n = C.n(); A.chars = C.ref.size(); A.members = C.mem.size();
-		for (size_t i = 0; i < A.n; ++i) maxlen = std::max<uint64_t>(maxlen, C.rsize(i));
-		if (A.n) {
-			if (!A.seq.reserve(A.chars + 16) || !A.soff.reserve(A.n + 1) || !A.mem.reserve(A.members + 1) || !A.moff.reserve(A.n + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
-			if ((rc = p->h2d(A.seq.p, (const uint8_t*)C.ref.data(), A.chars, "upload contigs")) || (rc = p->h2d(A.soff.p, C.roff.data(), A.n + 1, "upload offsets")) ||
-			    (rc = p->h2d(A.mem.p, C.mem.data(), A.members, "upload members")) || (rc = p->h2d(A.moff.p, C.moff.data(), A.n + 1, "upload offsets")) ||
+		S.n = C.n(); S.chars = C.ref.size(); S.members = C.mem.size();
+		for (size_t i = 0; i < S.n; ++i) maxlen = std::max<uint64_t>(maxlen, C.rsize(i));
+		if (S.n) {
+			if (!S.seq.reserve(S.chars + 16) || !S.soff.reserve(S.n + 1) || !S.mem.reserve(S.members + 1) || !S.moff.reserve(S.n + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
+			if ((rc = p->h2d(S.seq.p, (const uint8_t*)C.ref.data(), S.chars, "upload contigs")) || (rc = p->h2d(S.soff.p, C.roff.data(), S.n + 1, "upload offsets")) ||
+			    (rc = p->h2d(S.mem.p, C.mem.data(), S.members, "upload members")) || (rc = p->h2d(S.moff.p, C.moff.data(), S.n + 1, "upload offsets")) ||
 			    (rc = p->sync("upload contig set"))) return rc;
 		}
 	}
-	if (A.n) {
+	const uint64_t chars0 = S.chars, members0 = S.members;                    // a merged string is no longer than its parents together: bounds of every later list
+	if (S.n) {
 		const double tg = busy_now(p);
 		lap("t_cb_upload");
-		if ((rc = p->comm ? sketch_first_dist(p, A, A.n, A.chars, 0, A.nrec) : sketch_first(p, A, A.n, A.chars, 0, A.nrec))) return rc;   // find_next's own sketch (:234)
+		if ((rc = p->comm ? sketch_first_dist(p, S, S.n, S.chars, 0, S.nrec) : sketch_first(p, S, S.n, S.chars, 0, S.nrec))) return rc;   // find_next's own sketch (:234)
+		// room for the records the merge rounds append (about 1.3 x the first sketch in all): made once, here
+		if (S.rec.cap < S.nrec * 23 / 10 && !S.rec.grow((size_t)(S.nrec * 23 / 10 + 1024), (size_t)S.nrec, p->stream)) return p->fail(MCOM_E_NOMEM, "record store");
 		lap("t_cb_sketch");
 		p->stat["t_gpu"] += busy_now(p) - tg;
 	}
-	bool packed_ready = false;                                                 // d_cbits & co. describe A (made at the end of the round before)
+	bool packed_ready = false;                                                 // d_cbits & co. describe the store
+	bool listed = false;                                                       // `ord` is in use (some round has merged something)
 	p->cbits_for_dC = false;
-	uint32_t n_new = 0;                                                        // contigs [0, n_new) of A were made by the round before (0: the first round)
+	size_t n_live = S.n;                                                       // contigs of the current list
+	uint32_t first_new = 0, n_new = 0;                                         // the contigs the round before made: indices [first_new, first_new + n_new) (0: the first round)
+	if (p->comm && n_live) {                                                   // (multi-GPU: shares are ranges of the list, so the list is spelled out from the start)
+		uint64_t nk = 0;
+		if (!ord.reserve(n_live + 1)) return p->fail(MCOM_E_NOMEM, "contig list");
+		if ((rc = p->gpu(mcom_order_next(p->ctx, nullptr, 0, nullptr, 0, n_live, ord.p, &nk)))) return rc;
+		listed = true;
+	}
+	// room behind the end of a store array, made by growing it (the data in front is kept); the bucket stage leaves some (arena_slack)
+	auto room64 = [&](DevBuf<uint64_t> &b, uint64_t used, uint64_t more) { return b.grow((size_t)(used + more), (size_t)used, p->stream); };
 	for (;;) {
-		const size_t n = A.n;
+		const size_t n = n_live, n_store = S.n;
+		const uint32_t *lst = listed ? ord.p : nullptr;
 		uint64_t n_pass = 0;
 		if (n) {
 			const double tg = busy_now(p);
 			uint64_t tw = 0, tm = 0;
 			if (!packed_ready) {
-				if (!p->d_coff_words.reserve(n + 1) || !p->d_clen.reserve(n + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
-				if ((rc = p->gpu(mcom_contig_layout(p->ctx, A.soff.p, n, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
+				if (!p->d_coff_words.reserve(n_store + 1) || !p->d_clen.reserve(n_store + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p, n_store, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
 				p->total_words = tw;
-				if (!p->d_cbits.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+				if (!p->d_cbits.reserve(tw * 24 / 10 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
 				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
-				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, A.seq.p, A.soff.p, p->d_coff_words.p, (uint32_t)n, tw, p->d_cbits.p)))) return rc;
+				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, S.seq.p, S.soff.p, p->d_coff_words.p, (uint32_t)n_store, tw, p->d_cbits.p)))) return rc;
 				packed_ready = true;
 			}
 			// the first m minimizers are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
 			if (!moff_m.reserve(n + 2) || !rec_m.reserve(n * (size_t)p->m + 16)) return p->fail(MCOM_E_NOMEM, "index records");
-			if ((rc = p->gpu(mcom_minimizer_prefix(p->ctx, A.roff.p, A.rec.p, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
+			if ((rc = p->gpu(mcom_minimizer_prefix_ord(p->ctx, S.roff.p, S.rec.p, lst, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
 			lap("t_cb_pack");
 			mcom_idx *mi = nullptr;
 			if ((rc = p->comm ? build_index_dist(p, rec_m.p, tm, &mi) : p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;   // mm_idx_generation (:580)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
 			if (!p->comm) {
-				size_t cap = std::max<size_t>(1024, A.nrec);
+				size_t cap = std::max<size_t>(1024, S.nrec / 2 + 1024);
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-					rc = mcom_find_next_candidates_new(p->ctx, mi, A.rec.p, A.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, n_new, d_pairs.p, d_pairs.cap, hc);
+					rc = mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, lst, n, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs.p, d_pairs.cap, hc);
 					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 					break;
 				}
 			} else {
 				// multi-GPU: every rank holds the whole index (6 minimizers per contig) and evaluates the queries of its share of
-				// the contigs; the passing pairs come out in visiting order, so the shares concatenate in rank order
+				// the list; the passing pairs come out in visiting order, so the shares concatenate in rank order
 				const int R = p->world, me = p->rank;
 				const size_t c0 = n * (size_t)me / R, c1 = n * (size_t)(me + 1) / R;
-				uint32_t qr[2] = {0, 0};
-				if ((rc = p->d2h(&qr[0], A.roff.p + c0, 1, "copy")) || (rc = p->d2h(&qr[1], A.roff.p + c1, 1, "copy")) || (rc = p->sync("copy"))) { mcom_idx_destroy(p->ctx, mi); return rc; }
-				size_t cap = std::max<size_t>(1024, (size_t)(qr[1] - qr[0]));
+				size_t cap = std::max<size_t>(1024, S.nrec / (2 * (size_t)R) + 1024);
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs_loc.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-					rc = mcom_find_next_candidates_new(p->ctx, mi, A.rec.p + qr[0], qr[1] - qr[0], p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, n_new, d_pairs_loc.p, d_pairs_loc.cap, hc);
+					rc = mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, ord.p + c0, c1 - c0, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs_loc.p, d_pairs_loc.cap, hc);
 					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 					break;
 				}
@@ -1298,21 +1320,22 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			p->stat["cand_pairs"] += (double)hc[0];
 		}
 		// first-come claiming in contig order (find_next :267-343 at one thread) = the greedy matching over the pair list,
-		// settled in rounds on the device; a list that does not settle goes through the sequential loop on the host
+		// settled in rounds on the device; a list that does not settle goes through the sequential loop on the host.  The flags are
+		// indexed like everything else: by the contig's index in the store.
 		size_t nj = 0;
 		bool on_device = false;
 		if (n) {
-			if (!d_jobs.reserve(4 * (n / 2 + 1)) || !d_flag.reserve(n)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+			if (!d_jobs.reserve(4 * (n / 2 + 1)) || !d_flag.reserve(n_store + 16)) return p->fail(MCOM_E_NOMEM, "claim buffers");
 			uint64_t njv = 0; int rounds = 0;
-			rc = mcom_claim_pairs(p->ctx, d_pairs.p, n_pass, n, 4096, d_jobs.p, d_flag.p, &njv, &rounds);
+			rc = mcom_claim_pairs(p->ctx, d_pairs.p, n_pass, n_store, 4096, d_jobs.p, d_flag.p, &njv, &rounds);
 			if (rc == MCOM_OK) { on_device = true; nj = (size_t)njv; p->stat["claim_rounds"] += rounds; }
 			else if (rc != MCOM_E_OVERFLOW) return p->gpu(rc);
 		}
 		if (!on_device) {
 		if (!pairs.resize(n_pass)) return p->fail(MCOM_E_NOMEM, "candidate pairs");
 		if ((rc = p->d2h(pairs.data(), d_pairs.p, n_pass, "copy candidates")) || (rc = p->sync("candidates"))) return rc;
-		if (!flag.resize(n) || !jobs.resize(n / 2 + 1)) return p->fail(MCOM_E_NOMEM, "claim buffers");
-		if (n) memset(flag.data(), 0, n);
+		if (!flag.resize(n_store) || !jobs.resize(n / 2 + 1)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+		if (n_store) memset(flag.data(), 0, n_store);
 		for (size_t q = 0; q < n_pass;) {
 			const uint32_t ci = (uint32_t)(pairs[q].x >> 32);
 			size_t qe = q;
@@ -1328,134 +1351,189 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			}
 			q = qe;
 		}
-		if (nj && ((rc = p->h2d(d_jobs.p, (const uint32_t*)jobs.data(), 4 * nj, "upload claimed pairs")) || (rc = p->h2d(d_flag.p, flag.data(), n, "upload flags")) ||
+		if (nj && ((rc = p->h2d(d_jobs.p, (const uint32_t*)jobs.data(), 4 * nj, "upload claimed pairs")) || (rc = p->h2d(d_flag.p, flag.data(), n_store, "upload flags")) ||
 		           (rc = p->sync("upload claims")))) return rc;
 		}
 		lap("t_claim");
 		if (nj) {
 			const double tg = busy_now(p);
 			const size_t nkeep = n - 2 * nj, nn = nj + nkeep;
-			if (!d_keepidx.reserve(nkeep + 1) || !B.mem.reserve(A.members + 1) || !B.moff.reserve(nn + 1) ||
-			    !B.seq.reserve(A.chars + 16) || !B.soff.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+			if ((uint64_t)n_store + nj >= (1ull << 32) - 2) return p->fail(MCOM_E_ARG, "more than 2^32 contigs made in the merge rounds");
+			// the offset arrays of the store gain nj entries
+			if (!S.soff.grow(n_store + nj + 2, n_store + 1, p->stream) || !S.moff.grow(n_store + nj + 2, n_store + 1, p->stream) ||
+			    !S.roff.grow(n_store + nj + 2, n_store + 1, p->stream) || !p->d_coff_words.grow(n_store + nj + 2, n_store + 1, p->stream) ||
+			    !p->d_clen.grow(n_store + nj + 2, n_store, p->stream) || !jmoff_t.reserve(nj + 2) || !jroff_t.reserve(nj + 2) || !roff_t.reserve(nj + 2) || !cw_t.reserve(nj + 2))
+				return p->fail(MCOM_E_NOMEM, "merge buffers");
 			// merged member lists (:297-325) in cmpcluster2 order as construct_ref2 sorts them first (:107)
 			int kb = 2; while ((1ull << kb) < 4 * maxlen + 4) ++kb;
 			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);
-			uint64_t tot[3] = {0, 0, 0}, t2[2] = {0, 0};
+			uint64_t tot[3] = {0, 0, 0};
 			uint64_t tn = 0;                                                             // minimizer records of the merged contigs
-			bool merged_sketched = false;
+			const bool rs = p->resketch && (p->k & 1);
 			if (!p->comm) {
-			if ((rc = p->gpu(mcom_merge_members(p->ctx, A.mem.p, A.moff.p, d_jobs.p, nj, L, kb, B.mem.p, B.moff.p, B.soff.p, tot)))) return rc;
-			maxlen = std::max(maxlen, tot[2]);
-			lap("t_merge_members");
-			// construct_ref2 of every merged contig (:327)
-			if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, B.mem.p, B.moff.p, B.soff.p, nj, tot[1], L, B.seq.p, p->full_consensus ? nullptr : d_jobs.p, A.seq.p, A.soff.p)))) return rc;
-			lap("t_merge_cons");
+				for (int attempt = 0;; ++attempt) {
+					rc = mcom_merge_members_cap(p->ctx, S.mem.p, S.moff.p, d_jobs.p, nj, L, kb, S.mem.p + S.members, S.mem.cap - S.members, jmoff_t.p, jroff_t.p, tot);
+					if (rc == MCOM_E_OVERFLOW && attempt == 0) { if (!room64(S.mem, S.members, tot[0] + 1)) return p->fail(MCOM_E_NOMEM, "member store"); p->stat["store_grows"] += 1; continue; }
+					if (rc) return p->gpu(rc);
+					break;
+				}
+				maxlen = std::max(maxlen, tot[2]);
+				lap("t_merge_members");
+				// construct_ref2 of every merged contig (:327), written behind the strings of the store
+				if (S.seq.cap < S.chars + tot[1] + 16) { if (!S.seq.grow((size_t)(S.chars + tot[1] + 16), (size_t)S.chars, p->stream)) return p->fail(MCOM_E_NOMEM, "string store"); p->stat["store_grows"] += 1; }
+				if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, S.mem.p + S.members, jmoff_t.p, jroff_t.p, nj, tot[1], L, S.seq.p + S.chars,
+				                                           p->full_consensus ? nullptr : d_jobs.p, S.seq.p, S.soff.p)))) return rc;
+				lap("t_merge_cons");
+				// their minimizers: only around the overlaps, the parents' records carry the rest (csrc/resketch.hip); even k: sketched whole
+				uint64_t sk = 0;
+				if (rs) {
+					for (int attempt = 0;; ++attempt) {
+						rc = mcom_resketch_merged_at(p->ctx, d_jobs.p, nj, S.soff.p, S.rec.p, S.roff.p, S.seq.p + S.chars, jroff_t.p, tot[1], p->rw, p->k, (uint32_t)n_store,
+						                             roff_t.p, S.rec.p ? S.rec.p + S.nrec : nullptr, S.rec.cap > S.nrec ? S.rec.cap - (size_t)S.nrec : 0, &tn, &sk);
+						if (rc == MCOM_E_OVERFLOW && attempt == 0) { if (!S.rec.grow((size_t)(S.nrec + tn + 1), (size_t)S.nrec, p->stream)) return p->fail(MCOM_E_NOMEM, "record store"); p->stat["store_grows"] += 1; continue; }
+						if (rc) return p->gpu(rc);
+						break;
+					}
+					p->stat["resketch_saved_bases"] += (double)(tot[1] - sk);
+				} else {
+					uint64_t nk = 0;
+					if (!d_ids.reserve(nj + 1)) return p->fail(MCOM_E_NOMEM, "contig ids");
+					if ((rc = p->gpu(mcom_order_next(p->ctx, nullptr, 0, nullptr, (uint32_t)n_store, nj, d_ids.p, &nk)))) return rc;
+					size_t cap = std::max<size_t>(1024, tot[1] / 8 + nj);
+					for (int attempt = 0;; ++attempt) {
+						if (S.rec.cap < S.nrec + cap && !S.rec.grow((size_t)(S.nrec + cap), (size_t)S.nrec, p->stream)) return p->fail(MCOM_E_NOMEM, "record store");
+						rc = mcom_sketch_contigs(p->ctx, S.seq.p + S.chars, jroff_t.p, d_ids.p, nj, p->rw, p->k, 0, roff_t.p, S.rec.p + S.nrec, cap, &tn);
+						if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tn; continue; }
+						if (rc) return p->gpu(rc);
+						break;
+					}
+					sk = tot[1];
+				}
+				p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tn;
+				if (S.nrec + tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records in the store");
+				// the store's offset arrays: entries n_store .. n_store + nj
+				if ((rc = p->gpu(mcom_offsets_append(p->ctx, jmoff_t.p, nj, S.members, S.moff.p + n_store))) || (rc = p->gpu(mcom_offsets_append(p->ctx, jroff_t.p, nj, S.chars, S.soff.p + n_store))) ||
+				    (rc = p->gpu(mcom_offsets_append_u32(p->ctx, roff_t.p, nj, (uint32_t)S.nrec, S.roff.p + n_store)))) return rc;
+				lap("t_cb_sketch");
 			} else {
 				// Multi-GPU: the merges of a round are independent (find_next :297-381 works on one claimed pair): a rank merges its share of
-				// the claimed pairs -- member lists, construct_ref2, the sketch around the overlap -- and the merged contigs are all-gathered
-				// into the head of the new set, in claiming order.
+				// the claimed pairs -- member lists, construct_ref2, the sketch around the overlap -- in buffers of its own, and the shares are
+				// all-gathered straight behind the end of every rank's store, in claiming order.
 				const int R = p->world, me = p->rank;
 				const size_t j0 = nj * (size_t)me / R, j1 = nj * (size_t)(me + 1) / R, njl = j1 - j0;
 				DevSet &T = Tm;
-				uint64_t tl[3] = {0, 0, 0}, tnl = 0, sk = 0;
-				const bool rs = p->resketch && (p->k & 1);
+				uint64_t tl3[3] = {0, 0, 0}, tnl = 0, sk = 0;
 				if (njl) {
-					if (!T.mem.reserve(A.members + 1) || !T.moff.reserve(njl + 2) || !T.soff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
-					if ((rc = p->gpu(mcom_merge_members(p->ctx, A.mem.p, A.moff.p, d_jobs.p + 4 * j0, njl, L, kb, T.mem.p, T.moff.p, T.soff.p, tl)))) return rc;
-					if (!T.seq.reserve(tl[1] + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
-					if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, T.mem.p, T.moff.p, T.soff.p, njl, tl[1], L, T.seq.p, p->full_consensus ? nullptr : d_jobs.p + 4 * j0, A.seq.p, A.soff.p)))) return rc;
+					if (!T.mem.reserve(members0 + 1) || !T.moff.reserve(njl + 2) || !T.soff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_merge_members(p->ctx, S.mem.p, S.moff.p, d_jobs.p + 4 * j0, njl, L, kb, T.mem.p, T.moff.p, T.soff.p, tl3)))) return rc;
+					if (!T.seq.reserve(tl3[1] + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_merge_consensus_jobs(p->ctx, p->d_packed.p, T.mem.p, T.moff.p, T.soff.p, njl, tl3[1], L, T.seq.p, p->full_consensus ? nullptr : d_jobs.p + 4 * j0, S.seq.p, S.soff.p)))) return rc;
+					if (!T.roff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+					size_t cap = std::max<size_t>(1024, tl3[1] / 8 + njl);
 					if (rs) {
-						if (!T.roff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
-						size_t cap = std::max<size_t>(1024, tl[1] / 8 + njl);
 						for (int attempt = 0;; ++attempt) {
 							if (!T.rec.reserve(cap)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-							rc = mcom_resketch_merged(p->ctx, d_jobs.p + 4 * j0, njl, A.soff.p, A.rec.p, A.roff.p, T.seq.p, T.soff.p, tl[1], p->rw, p->k, T.roff.p, T.rec.p, cap, &tnl, &sk);
+							rc = mcom_resketch_merged_at(p->ctx, d_jobs.p + 4 * j0, njl, S.soff.p, S.rec.p, S.roff.p, T.seq.p, T.soff.p, tl3[1], p->rw, p->k, (uint32_t)(n_store + j0), T.roff.p, T.rec.p, cap, &tnl, &sk);
 							if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tnl; continue; }
 							if (rc) return p->gpu(rc);
 							break;
 						}
-						p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tnl; p->stat["resketch_saved_bases"] += (double)(tl[1] - sk);
+						p->stat["resketch_saved_bases"] += (double)(tl3[1] - sk);
+					} else {
+						uint64_t nk = 0;
+						if (!d_ids.reserve(njl + 1)) return p->fail(MCOM_E_NOMEM, "contig ids");
+						if ((rc = p->gpu(mcom_order_next(p->ctx, nullptr, 0, nullptr, (uint32_t)(n_store + j0), njl, d_ids.p, &nk)))) return rc;
+						for (int attempt = 0;; ++attempt) {
+							if (!T.rec.reserve(cap)) return p->fail(MCOM_E_NOMEM, "minimizer records");
+							rc = mcom_sketch_contigs(p->ctx, T.seq.p, T.soff.p, d_ids.p, njl, p->rw, p->k, 0, T.roff.p, T.rec.p, cap, &tnl);
+							if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tnl; continue; }
+							if (rc) return p->gpu(rc);
+							break;
+						}
+						sk = tl3[1];
 					}
+					p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tnl;
 				}
 				lap("t_merge_local");
-				const uint64_t mine[4] = {tl[0], tl[1], tl[2], tnl};
+				const uint64_t mine[4] = {tl3[0], tl3[1], tl3[2], tnl};
 				std::vector<uint64_t> all, fj(R), cj(R), fm(R), cm(R), fc(R), cc(R), fr(R), cr(R);
 				if ((rc = gather_host(p, mine, 4, all))) return rc;
 				for (int q = 0; q < R; ++q) {
-					fj[q] = nj * (size_t)q / R; cj[q] = nj * (size_t)(q + 1) / R - fj[q];
-					fm[q] = tot[0]; cm[q] = all[4 * q]; tot[0] += cm[q]; fc[q] = tot[1]; cc[q] = all[4 * q + 1]; tot[1] += cc[q];
-					tot[2] = std::max(tot[2], all[4 * q + 2]); fr[q] = tn; cr[q] = all[4 * q + 3]; tn += cr[q];
+					fj[q] = n_store + nj * (size_t)q / R; cj[q] = nj * (size_t)(q + 1) / R - nj * (size_t)q / R;
+					fm[q] = S.members + tot[0]; cm[q] = all[4 * q]; tot[0] += cm[q]; fc[q] = S.chars + tot[1]; cc[q] = all[4 * q + 1]; tot[1] += cc[q];
+					tot[2] = std::max(tot[2], all[4 * q + 2]); fr[q] = S.nrec + tn; cr[q] = all[4 * q + 3]; tn += cr[q];
 				}
 				maxlen = std::max(maxlen, tot[2]);
-				if (tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records");
-				// offsets and ids of the share move to their global values, then everything travels
-				if (njl && ((rc = p->gpu(mcom_offsets_rebase(p->ctx, T.moff.p, njl, fm[me]))) || (rc = p->gpu(mcom_offsets_rebase(p->ctx, T.soff.p, njl, fc[me]))))) return rc;
-				if (rs && njl && (rc = p->gpu(mcom_records_rebase(p->ctx, T.rec.p, tnl, (uint32_t)j0, T.roff.p, njl, (uint32_t)fr[me])))) return rc;
-				if (!B.seq.reserve(std::max<uint64_t>(A.chars, tot[1]) + 16)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+				if (S.nrec + tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records in the store");
+				// offsets of the share move to their places in the store, then everything travels
+				if (njl && ((rc = p->gpu(mcom_offsets_rebase(p->ctx, T.moff.p, njl, fm[me]))) || (rc = p->gpu(mcom_offsets_rebase(p->ctx, T.soff.p, njl, fc[me]))) ||
+				            (rc = p->gpu(mcom_records_rebase(p->ctx, T.rec.p, 0, 0, T.roff.p, njl, (uint32_t)fr[me]))))) return rc;
+				if (!room64(S.mem, S.members, tot[0] + 1) || !S.seq.grow((size_t)(S.chars + tot[1] + 16), (size_t)S.chars, p->stream) || !S.rec.grow((size_t)(S.nrec + tn + 1), (size_t)S.nrec, p->stream))
+					return p->fail(MCOM_E_NOMEM, "contig store");
 				const double tx = now_ms();
-				if ((rc = gatherv(p, B.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, B.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, B.seq.p, fc, cc, T.seq.p, false)) || (rc = gatherv(p, B.soff.p, fj, cj, T.soff.p, false))) return rc;
-				if ((rc = p->h2d(B.moff.p + nj, &tot[0], 1, "upload")) || (rc = p->h2d(B.soff.p + nj, &tot[1], 1, "upload"))) return rc;
-				if (rs) {
-					if (!B.roff.reserve(nn + 2) || !B.rec.reserve(tn + (size_t)A.nrec + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-					if ((rc = gatherv(p, B.rec.p, fr, cr, T.rec.p)) || (rc = gatherv(p, B.roff.p, fj, cj, T.roff.p, false))) return rc;
-					const uint32_t t32 = (uint32_t)tn;
-					if ((rc = p->h2d(B.roff.p + nj, &t32, 1, "upload"))) return rc;
-					merged_sketched = true;
-				}
-				if ((rc = p->sync("merged contigs"))) return rc;                             // (tot / t32 live on this stack frame)
+				const uint64_t em = S.members + tot[0], ec = S.chars + tot[1]; const uint32_t er = (uint32_t)(S.nrec + tn);
+				if ((rc = gatherv(p, S.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, S.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, S.seq.p, fc, cc, T.seq.p, false)) || (rc = gatherv(p, S.soff.p, fj, cj, T.soff.p, false)) ||
+				    (rc = gatherv(p, S.rec.p, fr, cr, T.rec.p, false)) || (rc = gatherv(p, S.roff.p, fj, cj, T.roff.p, false))) return rc;
+				if ((rc = p->h2d(S.moff.p + n_store + nj, &em, 1, "upload")) || (rc = p->h2d(S.soff.p + n_store + nj, &ec, 1, "upload")) || (rc = p->h2d(S.roff.p + n_store + nj, &er, 1, "upload"))) return rc;
+				if ((rc = p->sync("merged contigs"))) return rc;                             // (em / ec / er live on this stack frame)
 				p->stat["t_x_merged"] += now_ms() - tx;
 				lap("t_merge_gather");
 			}
-			// next contig list: the merged ones in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
-			if ((rc = p->gpu(mcom_contigs_carry(p->ctx, A.seq.p, A.soff.p, A.mem.p, A.moff.p, n, d_flag.p, nj, nkeep, B.seq.p, B.soff.p, B.mem.p, B.moff.p,
-			                                    d_keepidx.p, t2)))) return rc;
-			B.n = nn; B.chars = t2[0]; B.members = t2[1];
-			if (B.members != A.members) return p->fail(MCOM_E_ARG, "merge round lost members: %llu of %llu", (unsigned long long)B.members, (unsigned long long)A.members);
-			lap("t_cb_copy");
-			// minimizers: merged contigs are sketched, the untouched ones keep theirs under their new index
-			if (merged_sketched) { B.n = nn; }
-			else if (p->resketch && (p->k & 1)) {
-				// only around the overlaps; the parents' records carry the rest (csrc/resketch.hip)
-				B.n = nn;
-				if (!B.roff.reserve(nn + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
-				size_t cap = std::max<size_t>(1024, tot[1] / 8 + nj);
-				uint64_t sk = 0;
-				for (int attempt = 0;; ++attempt) {
-					if (!B.rec.reserve(cap + (size_t)A.nrec)) return p->fail(MCOM_E_NOMEM, "minimizer records");
-					rc = mcom_resketch_merged(p->ctx, d_jobs.p, nj, A.soff.p, A.rec.p, A.roff.p, B.seq.p, B.soff.p, tot[1], p->rw, p->k, B.roff.p, B.rec.p, cap, &tn, &sk);
-					if (rc == MCOM_E_OVERFLOW && attempt == 0) { cap = tn; continue; }
-					if (rc) return p->gpu(rc);
-					break;
-				}
-				p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tn; p->stat["resketch_saved_bases"] += (double)(tot[1] - sk);
-			} else if ((rc = sketch_first(p, B, nj, tot[1], (size_t)A.nrec, tn))) return rc;
-			if ((rc = p->gpu(mcom_records_carry(p->ctx, A.rec.p, A.roff.p, d_keepidx.p, nkeep, (uint32_t)nj, (uint32_t)tn, B.rec.p, B.rec.cap, B.roff.p, &B.nrec)))) return rc;
-			lap("t_cb_sketch");
+			// the packed form of the new contigs, behind the packed store
 			{
-				// the packed form of the new set: the merged contigs are packed, the others' words copied from this round's
 				uint64_t tw2 = 0;
-				if (!p->d_coff_words_alt.reserve(nn + 1) || !p->d_clen_alt.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
-				if ((rc = p->gpu(mcom_contig_layout(p->ctx, B.soff.p, nn, p->d_coff_words_alt.p, p->d_clen_alt.p, &tw2)))) return rc;
-				if (!p->d_cbits_alt.reserve(tw2 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-				if ((rc = p->gpu(mcom_pack_contigs_merged(p->ctx, B.seq.p, B.soff.p, p->d_coff_words_alt.p, (uint32_t)nn, tw2, (uint32_t)nj, p->d_cbits.p, p->d_coff_words.p,
-				                                          d_keepidx.p, p->d_cbits_alt.p)))) return rc;
-				p->d_cbits.swap(p->d_cbits_alt); p->d_coff_words.swap(p->d_coff_words_alt); p->d_clen.swap(p->d_clen_alt);
-				p->total_words = tw2;
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p + n_store, nj, cw_t.p, p->d_clen.p + n_store, &tw2)))) return rc;
+				if (p->d_cbits.cap < p->total_words + tw2 + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + tw2 + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
+				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, S.seq.p, S.soff.p + n_store, cw_t.p, (uint32_t)nj, tw2, p->d_cbits.p + p->total_words))) ||
+				    (rc = p->hipc(hipMemsetAsync(p->d_cbits.p + p->total_words + tw2, 0, 16, p->stream), "clear")) ||
+				    (rc = p->gpu(mcom_offsets_append(p->ctx, cw_t.p, nj, p->total_words, p->d_coff_words.p + n_store)))) return rc;
+				p->total_words += tw2;
 				lap("t_cb_pack");
 			}
-			A.swap(B);
-			n_new = (uint32_t)nj;
+			// next list: the merged contigs in claiming order, then the untouched ones in their order (cp_cluster, :397-434)
+			uint64_t nk = 0;
+			if (!ord2.reserve(nn + 1)) return p->fail(MCOM_E_NOMEM, "contig list");
+			if ((rc = p->gpu(mcom_order_next(p->ctx, lst, n, d_flag.p, (uint32_t)n_store, nj, ord2.p, &nk)))) return rc;
+			if (nk != nkeep) return p->fail(MCOM_E_ARG, "merge round: %llu contigs unclaimed but %zu expected", (unsigned long long)nk, nkeep);
+			ord.swap(ord2); listed = true;
+			first_new = (uint32_t)n_store; n_new = (uint32_t)nj;
+			S.n = n_store + nj; S.members += tot[0]; S.chars += tot[1]; S.nrec += tn;
+			n_live = nn;
+			lap("t_cb_copy");
 			p->stat["t_gpu"] += busy_now(p) - tg;
 		} else packed_ready = packed_ready && n != 0;
 		p->stat["merge_rounds"] += 1;
-		const long tot = (long)A.n;
+		const long tot = (long)n_live;
 		if (std::labs(pre - tot) < 100) break;                                              // :625
 		pre = tot;
 	}
-	// the final set stays on the device, for Stage 2 and beyond; the host learns the offsets when Stage 2 asks for them
+	// the list becomes an ordinary set (the one copy left of cp_cluster's): it stays on the device, for Stage 2 and beyond; the host
+	// learns the offsets when Stage 2 asks for them
 	p->maxlen = maxlen;
-	p->stat["contigs_combine"] = (double)A.n;
-	p->dC.swap(A); p->dC_valid = true;
+	p->stat["contigs_combine"] = (double)n_live;
+	p->stat["store_contigs"] = (double)S.n; p->stat["store_chars"] = (double)S.chars;
+	if (listed && n_live) {
+		DevSet F;
+		uint64_t t2[2] = {0, 0}, tw = 0;
+		if (!F.seq.reserve(chars0 + 16) || !F.mem.reserve(members0 + 1) || !F.soff.reserve(n_live + 1) || !F.moff.reserve(n_live + 1)) return p->fail(MCOM_E_NOMEM, "contig set");
+		if ((rc = p->gpu(mcom_contigs_gather(p->ctx, S.seq.p, S.soff.p, S.mem.p, S.moff.p, ord.p, n_live, F.seq.p, F.soff.p, F.mem.p, F.moff.p, t2)))) return rc;
+		F.n = n_live; F.chars = t2[0]; F.members = t2[1];
+		if (F.members != members0) return p->fail(MCOM_E_ARG, "merge rounds lost members: %llu of %llu", (unsigned long long)F.members, (unsigned long long)members0);
+		if (packed_ready) {
+			if (!p->d_coff_words_alt.reserve(n_live + 1) || !p->d_clen_alt.reserve(n_live + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+			if ((rc = p->gpu(mcom_contig_layout(p->ctx, F.soff.p, n_live, p->d_coff_words_alt.p, p->d_clen_alt.p, &tw)))) return rc;
+			if (!p->d_cbits_alt.reserve(tw + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+			if ((rc = p->gpu(mcom_pack_contigs_merged(p->ctx, F.seq.p, F.soff.p, p->d_coff_words_alt.p, (uint32_t)n_live, tw, 0, p->d_cbits.p, p->d_coff_words.p, ord.p, p->d_cbits_alt.p)))) return rc;
+			if ((rc = p->sync("packed set"))) return rc;
+			p->d_cbits.swap(p->d_cbits_alt); p->d_coff_words.swap(p->d_coff_words_alt); p->d_clen.swap(p->d_clen_alt);
+			p->total_words = tw;
+		}
+		p->dC.swap(F);
+	} else {
+		S.nrec = 0;
+		p->dC.swap(S);
+	}
+	p->dC_valid = true;
 	p->cbits_for_dC = packed_ready && p->dC.n != 0;                          // Stage 2 takes the packed set as it is
 	p->hostC_valid = false; p->host_off_valid = false;
 	lap("t_cb_download");

@@ -326,3 +326,39 @@ def test_counters_from_the_zeroed_pool_survive_its_turnover(ctx):
         woff, nw, longest = ctx.window_layout(soff, 100)
         assert longest == int(lens.max()), (it, longest, lens)
         assert nw == int(np.maximum(lens - 99, 0).sum())
+
+
+def test_merge_rounds_without_copies_list_offsets_and_gather(ctx):
+    """The pieces of the merge rounds that leave the contig set where it is (include/mcom.h, "Merge rounds without cp_cluster's copies";
+    the reference copies every unmerged contig every round, kthread_cb.c:397-434): the next round's list = new contigs in claiming order,
+    then the unclaimed ones of this round's list in their order; offsets of appended contigs; the gather that ends the rounds."""
+    import torch
+    rng = np.random.default_rng(11)
+    n_store = 5000
+    # a list over a store: a random subset in random order (what several rounds leave), flags on some of them and on contigs outside the list
+    lst = rng.permutation(n_store)[:3000].astype(np.int32)
+    flag = (rng.random(n_store) < 0.3).astype(np.uint8)
+    nj = 400
+    got, nk = ctx.order_next(_dev(lst), len(lst), _dev(flag), n_store, nj)
+    want = np.concatenate([np.arange(n_store, n_store + nj), lst[flag[lst] == 0]]).astype(np.int32)
+    assert nk == int((flag[lst] == 0).sum()) and np.array_equal(got.cpu().numpy(), want)
+    got, nk = ctx.order_next(None, n_store, _dev(flag), n_store, 0)                        # no list yet: the store's own order
+    assert np.array_equal(got.cpu().numpy(), np.nonzero(flag == 0)[0].astype(np.int32))
+    got, nk = ctx.order_next(None, 0, None, 77, 1000)                                      # nothing but new contigs: 77, 78, ...
+    assert nk == 0 and np.array_equal(got.cpu().numpy(), np.arange(77, 1077, dtype=np.int32))
+    # offsets of appended contigs
+    rel = np.concatenate([[0], np.cumsum(rng.integers(1, 900, 300))]).astype(np.int64)
+    dst = torch.zeros(1000, dtype=torch.int64, device="cuda")
+    ctx.offsets_append(_dev(rel), 123456789012, dst, 650); ctx.sync()
+    assert np.array_equal(dst.cpu().numpy()[650:951], rel + 123456789012) and int(dst[:650].abs().sum()) == 0 and int(dst[951:].abs().sum()) == 0
+    rel32 = rel.astype(np.int32); dst32 = torch.zeros(1000, dtype=torch.int32, device="cuda")
+    ctx.offsets_append(_dev(rel32), 4000, dst32, 10); ctx.sync()
+    assert np.array_equal(dst32.cpu().numpy()[10:311], rel32 + 4000)
+    # the gather: contigs of the list as a set of their own
+    slen = rng.integers(0, 700, n_store); mlen = rng.integers(1, 40, n_store)
+    soff = np.concatenate([[0], np.cumsum(slen)]).astype(np.int64); moff = np.concatenate([[0], np.cumsum(mlen)]).astype(np.int64)
+    seq = ACGT[rng.integers(0, 4, int(soff[-1]))]; mem = rng.integers(0, 1 << 62, int(moff[-1]), dtype=np.int64)
+    s2, so2, m2, mo2 = ctx.contigs_gather(_dev(seq), _dev(soff), _dev(mem), _dev(moff), _dev(lst))
+    assert np.array_equal(s2.cpu().numpy(), np.concatenate([seq[soff[c]:soff[c + 1]] for c in lst]))
+    assert np.array_equal(m2.cpu().numpy(), np.concatenate([mem[moff[c]:moff[c + 1]] for c in lst]))
+    assert np.array_equal(so2.cpu().numpy(), np.concatenate([[0], np.cumsum(slen[lst])])) and np.array_equal(mo2.cpu().numpy(), np.concatenate([[0], np.cumsum(mlen[lst])]))
