@@ -383,6 +383,37 @@ class Context:
             self._check(rc)
             return out[: int(cnt[1])], int(cnt[0])
 
+    def minimizer_prefix_ord(self, moff, rec, ord_, m: int):
+        """mcom_minimizer_prefix_ord: the first m records of contigs ord_[0 ..] (None: all, in order), concatenated.  Returns (moff2, records)."""
+        torch = _torch()
+        self.lib.mcom_minimizer_prefix_ord.restype = C.c_int
+        self.lib.mcom_minimizer_prefix_ord.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        n = int(ord_.shape[0]) if ord_ is not None else int(moff.shape[0]) - 1
+        moff2 = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+        out = self.empty_records(max(n * m, 1))
+        tot = C.c_uint64()
+        self._check(self.lib.mcom_minimizer_prefix_ord(self._h, self._p(moff, torch.int32), self._p(rec), self._p(ord_, torch.int32) if ord_ is not None else None, n, m,
+                                                       self._p(moff2), self._p(out), C.byref(tot)))
+        return moff2, out[: int(tot.value)]
+
+    def find_next_candidates_ord(self, idx, rec, roff, ord_, cg, cbthr: int, first_new: int = 0, n_new: int = 0):
+        """mcom_find_next_candidates_ord: queries = the records of contigs ord_[0 ..] (None: all) of a store.  Returns (pairs, n_pairs_listed)."""
+        self.lib.mcom_find_next_candidates_ord.restype = C.c_int
+        self.lib.mcom_find_next_candidates_ord.argtypes = [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 3 + [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+        torch = _torch()
+        n = int(ord_.shape[0]) if ord_ is not None else int(roff.shape[0]) - 1
+        cnt = (C.c_uint64 * 2)()
+        cap = 1024
+        while True:
+            out = self.empty_records(cap)
+            rc = self.lib.mcom_find_next_candidates_ord(self._h, idx._h, self._p(rec), self._p(roff, torch.int32), self._p(ord_, torch.int32) if ord_ is not None else None, n,
+                                                        self._p(cg["cbits"]), self._p(cg["coff"]), self._p(cg["clen"]), cbthr, first_new, n_new, self._p(out), cap, cnt)
+            if rc == -4:
+                cap = int(cnt[1])
+                continue
+            self._check(rc)
+            return out[: int(cnt[1])], int(cnt[0])
+
     # -- Stage 2
     def gather_rows(self, packed, rids, L: int):
         torch = _torch()

@@ -172,6 +172,64 @@ def test_find_next_candidates_on_reference_fixture_contigs(ctx, golden_dir, tag)
     idx.close()
 
 
+@pytest.mark.parametrize("tag", ["stages_L100", "stages_L150"])
+def test_find_next_candidates_over_a_list_of_a_store(ctx, golden_dir, tag):
+    """The merge rounds leave the contig set where it is (round 5): the contigs of a round are a LIST of indices into a store, visited in
+    list order (cp_cluster's order, kthread_cb.c:397-434, without its copies), ids are store indices.  Same fixture contigs as above, visited
+    through a shuffled list that leaves some contigs of the store out: index from the first six minimizers in list order, queries in list
+    order, candidates as find_next would list them (:267-291); then the same with the upper part of the store marked "made by the round
+    before": pairs of two older contigs are not evaluated again."""
+    import torch
+    import oracle
+    reads = _golden_reads(golden_dir, tag)
+    p = oracle.Pipeline(reads)
+    p.stage_reads(); p.stage_bucket()
+    refs = [r for r, _ in p.contigs()]
+    k, rw, cbthr, m = p.counter("k"), p.counter("rw"), 8, 6
+    n = len(refs)
+    rng = np.random.default_rng(len(refs))
+    lst = rng.permutation(n)[: n - n // 7].astype(np.int32)                      # a seventh of the store is dead (merged away in earlier rounds)
+    cg = ctx.upload_contigs(refs)
+    roff, rec = ctx.sketch_contigs(cg["seq"], cg["off"], n, rw, k)              # the store's records: ids = store indices
+    d_lst = torch.from_numpy(lst).cuda()
+    _, first6 = ctx.minimizer_prefix_ord(roff, rec, d_lst, m)
+    idx = ctx.idx_build(first6, k)
+    table = {}
+    sk = {int(i): oracle.sketch_lh_ori(refs[i], rw, k, int(i)) for i in lst}
+    for i in lst:
+        mz = sk[int(i)][:m]
+        for x, y in zip(mz["x"].tolist(), mz["y"].tolist()):
+            table.setdefault(x, []).append(y)
+    first_new = n - n // 4
+
+    def expect(new_from):
+        want = []
+        for i in lst:
+            r = refs[i]
+            for x, y in zip(sk[int(i)]["x"].tolist(), sk[int(i)]["y"].tolist()):
+                for hy in table.get(x, []):
+                    rid = hy >> 32
+                    if rid == i or (hy & 1) != (y & 1) or (new_from and i < new_from and rid < new_from):
+                        continue
+                    if oracle.match_pro(r, refs[rid], (y & 0xFFFFFFFF) >> 1, (hy & 0xFFFFFFFF) >> 1) <= cbthr:
+                        want.append((y, hy))
+        return want
+    for new_from, n_new in ((0, 0), (first_new, n - first_new)):
+        pairs, _ = ctx.find_next_candidates_ord(idx, rec, roff, d_lst, cg, cbthr, new_from, n_new)
+        ctx.sync()
+        got = _recs(pairs)
+        want = expect(new_from)
+        assert list(zip(got["x"].tolist(), got["y"].tolist())) == want and len(want) > 5
+    # no list: the store's own order = the plain entry point
+    _, first6 = ctx.minimizer_prefix_ord(roff, rec, None, m)
+    idx2 = ctx.idx_build(first6, k)
+    a, na = ctx.find_next_candidates_ord(idx2, rec, roff, None, cg, cbthr)
+    b, nb = ctx.find_next_candidates(idx2, rec, cg, cbthr)
+    ctx.sync()
+    assert na == nb and torch.equal(a, b)
+    idx.close(); idx2.close()
+
+
 def test_radix_sort_ref_order_reproduces_the_reference_permutation(ctx, kat):
     """Every golden radix_sort_128x vector, including the sizes where the reference sort is unstable."""
     import torch
