@@ -225,7 +225,7 @@ def main():
     STATS = ("windows", "passes", "rounds", "merge_rounds", "claim_rounds", "resketch", "n_sg0", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
              "sort_overflow_segments", "sketch_bases", "sort_records", "sketch_strings", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "ra_lookups", "ra_verified",
              "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "x_cindex_entries", "contigs_bucket", "contigs_combine",
-             "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")
+             "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex", "store_grows", "store_contigs", "store_chars")
 
     def measure(n_total, seed, steps, warmup, check, ab_events=False):
         """K timed steps of one job of n_total reads; returns (seconds, aggregate stats, digests, reads, make)."""
@@ -534,7 +534,7 @@ def main():
                        "fell_back": fell_back, "host_threads": threads,
                        "per_step": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("rounds", "merge_rounds", "claim_rounds", "passes", "windows", "resketch", "n_sg0", "contigs_bucket",
                                                                                   "contigs_combine", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
-                                                                                  "sort_overflow_segments", "x_records", "x_cindex_entries")},
+                                                                                  "sort_overflow_segments", "x_records", "x_cindex_entries", "store_grows", "store_contigs", "store_chars")},
                        "stage_ms_rank0": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
                                                                                         "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")},
                        "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step; cost: event_overhead)",

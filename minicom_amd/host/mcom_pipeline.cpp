@@ -1102,7 +1102,7 @@ static int sketch_first(P *p, DevSet &S, size_t n_first, uint64_t chars_first, s
 {
 	total = 0;
 	p->stat["sketch_bases"] += (double)chars_first;                // one launch per call
-	if (!S.roff.reserve(S.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	if (!S.roff.reserve(std::max(S.n + 2, S.soff.cap))) return p->fail(MCOM_E_NOMEM, "minimizer offsets");   // (room for the contigs the merge rounds append, as the other offset arrays)
 	size_t cap = std::max<size_t>(1024, chars_first / 8 + n_first);
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (!S.rec.reserve(cap + room)) return p->fail(MCOM_E_NOMEM, "minimizer records");
@@ -1121,7 +1121,7 @@ static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_fir
 	total = 0;
 	const int R = p->world, me = p->rank;
 	const size_t c0 = n_first * (size_t)me / R, c1 = n_first * (size_t)(me + 1) / R, nloc = c1 - c0;
-	if (!S.roff.reserve(S.n + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
+	if (!S.roff.reserve(std::max(S.n + 2, S.soff.cap))) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
 	DevBuf<mcom_mm128> tmp; DevBuf<uint32_t> toff;
 	if (!toff.reserve(nloc + 2)) return p->fail(MCOM_E_NOMEM, "minimizer offsets");
 	size_t cap = std::max<size_t>(1024, chars_first / 8 / R + nloc + 1024);
@@ -1265,7 +1265,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			const double tg = busy_now(p);
 			uint64_t tw = 0, tm = 0;
 			if (!packed_ready) {
-				if (!p->d_coff_words.reserve(n_store + 1) || !p->d_clen.reserve(n_store + 1)) return p->fail(MCOM_E_NOMEM, "contig layout");
+				if (!p->d_coff_words.reserve(std::max(n_store + 1, S.soff.cap)) || !p->d_clen.reserve(std::max(n_store + 1, S.soff.cap))) return p->fail(MCOM_E_NOMEM, "contig layout");   // (with the room the store's offset arrays have)
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p, n_store, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
 				p->total_words = tw;
 				if (!p->d_cbits.reserve(tw * 24 / 10 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
@@ -1282,7 +1282,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			lap("t_cb_idx");
 			uint64_t hc[2] = {0, 0};
 			if (!p->comm) {
-				size_t cap = std::max<size_t>(1024, S.nrec / 2 + 1024);
+				size_t cap = std::max<size_t>(1024, (size_t)S.nrec);                      // (the store's records: at least the list's, which bounded the pairs in every run so far; more: the call says how many)
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
 					rc = mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, lst, n, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs.p, d_pairs.cap, hc);
@@ -1294,7 +1294,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				// the list; the passing pairs come out in visiting order, so the shares concatenate in rank order
 				const int R = p->world, me = p->rank;
 				const size_t c0 = n * (size_t)me / R, c1 = n * (size_t)(me + 1) / R;
-				size_t cap = std::max<size_t>(1024, S.nrec / (2 * (size_t)R) + 1024);
+				size_t cap = std::max<size_t>(1024, (size_t)S.nrec / (size_t)R + 1024);
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs_loc.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
 					rc = mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, ord.p + c0, c1 - c0, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs_loc.p, d_pairs_loc.cap, hc);
