@@ -900,8 +900,9 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 					                            D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc);
 					if (rc != MCOM_E_OVERFLOW) break;
 					// (round 1 makes nearly all the contigs: room for what combine_cluster will append behind them -- its merge rounds leave the
-					// set where it is and add the merged contigs, about 1.3 x the set in all -- so that no round has to move the store)
-					const uint64_t slack_c = r == 1 ? (D.chars + gc[1]) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + gc[2]) * 13 / 10 : 0, slack_n = r == 1 ? (D.n + gc[0]) * 13 / 10 : 0;
+					// set where it is and add the merged contigs: about 1.5 x the strings and, since nearly every member sits in a contig that
+					// merges, 3 x the member lists in all -- so that no round has to move the store)
+					const uint64_t slack_c = r == 1 ? (D.chars + gc[1]) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + gc[2]) * 7 / 2 : 0, slack_n = r == 1 ? (D.n + gc[0]) * 13 / 10 : 0;
 					if (!D.seq.grow(D.chars + gc[1] + slack_c + 16, D.chars, p->stream) || !D.mem.grow(D.members + gc[2] + slack_m + 1, D.members, p->stream) ||
 					    !D.soff.grow(D.n + gc[0] + slack_n + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + gc[0] + slack_n + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
 				}
@@ -928,7 +929,7 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 				tn += cn[q]; tc += cc[q]; tm += cm[q];
 				n_sg_total += all[5 * q + 3] + (last ? all[5 * q + 4] : 0);
 			}
-			const uint64_t slack_c = r == 1 ? (D.chars + tc) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + tm) * 13 / 10 : 0, slack_n = r == 1 ? (D.n + tn) * 13 / 10 : 0;   // (see the single-GPU branch)
+			const uint64_t slack_c = r == 1 ? (D.chars + tc) * 13 / 10 : 0, slack_m = r == 1 ? (D.members + tm) * 7 / 2 : 0, slack_n = r == 1 ? (D.n + tn) * 13 / 10 : 0;   // (see the single-GPU branch)
 			if (!D.seq.grow(D.chars + tc + slack_c + 16, D.chars, p->stream) || !D.mem.grow(D.members + tm + slack_m + 1, D.members, p->stream) ||
 			    !D.soff.grow(D.n + tn + slack_n + 2, D.n + 1, p->stream) || !D.moff.grow(D.n + tn + slack_n + 2, D.n + 1, p->stream)) return p->fail(MCOM_E_NOMEM, "contig set");
 			if (ng) {
@@ -1285,7 +1286,9 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				size_t cap = std::max<size_t>(1024, (size_t)S.nrec);                      // (the store's records: at least the list's, which bounded the pairs in every run so far; more: the call says how many)
 				for (int attempt = 0; attempt < 2; ++attempt) {
 					if (!d_pairs.reserve(cap)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-					rc = mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, lst, n, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs.p, d_pairs.cap, hc);
+					// (no list yet: the store is the list and its records are the queries in visiting order -- one thread per query)
+					rc = listed ? mcom_find_next_candidates_ord(p->ctx, mi, S.rec.p, S.roff.p, lst, n, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, first_new, n_new, d_pairs.p, d_pairs.cap, hc)
+					            : mcom_find_next_candidates_new(p->ctx, mi, S.rec.p, (size_t)S.nrec, p->d_cbits.p, p->d_coff_words.p, p->d_clen.p, p->cbthr, 0, d_pairs.p, d_pairs.cap, hc);
 					if (rc == MCOM_E_OVERFLOW) { cap = hc[1]; continue; }
 					break;
 				}
