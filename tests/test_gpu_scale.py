@@ -241,3 +241,73 @@ def test_paired_end_file_set_of_4m_reads_of_150_bases_keeps_every_pair(tmp_path)
     got = np.sort(np.ascontiguousarray(np.concatenate([a, b], axis=1)).view(f"S{2 * L}").ravel())
     want = np.sort(np.ascontiguousarray(np.concatenate([host[:half], host[half:]], axis=1)).view(f"S{2 * L}").ravel())
     assert np.array_equal(got, want)
+
+
+def test_paired_end_over_eight_ranks_2x16m_reads_of_150_bases(tmp_path):
+    """BASELINE configs[4]'s mode and rank count at the size one card holds eight replicas of: paired end, 2 x 16 M reads of 150 bases
+    (the reference treats the two files as one read pool, preprocess.c:60-68, and pairs by read id when it dumps,
+    kthread_dump_pe.c:218-619), cut into eight shards -- mates live on different ranks -- and run by eight ranks (threads of this
+    process on the one card, Comm.threads; every exchange of the pipeline happens, through process memory).  Every rank ends with the
+    single-GPU digest; the paired-end file set rank 7 writes is decoded by this repo's decoder and every (read, mate) pair comes back."""
+    import threading
+    import torch
+    import minicom_amd
+    from minicom_amd.distributed import Comm, DistPipeline
+    from minicom_amd.pipeline import Pipeline, decompress_pe, pool_trim
+    n, L, world = 32_000_000, 150, 8
+    half = n // 2
+    ctx = minicom_amd.Context(0)
+    reads = ctx.synth_reads(1005, n, L)                                  # (configs[4]'s seed; rows [0, n/2) = file 1, rows [n/2, n) = the mates)
+    ctx.sync()
+    p = Pipeline(reads, L=L, host_threads=8)
+    p.pre_process()
+    want = p.result_digest()
+    p.close()
+    pool_trim()
+    comms, hub = Comm.threads(world)
+    out, errors = [None] * world, []
+    d = tmp_path / "pe"; d.mkdir()
+
+    def rank_main(rank):
+        try:
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            q = DistPipeline(reads[lo:hi], lo, n, comms[rank], L=L, device=0, host_threads=4, stream_sets=4)
+            q.pre_process()
+            out[rank] = q.result_digest()
+            if rank == world - 1:
+                q.cluster_dump(str(d), paired=True)
+            q.close()
+        except Exception as e:                                                  # noqa: BLE001
+            errors.append((rank, repr(e))); hub.abort()
+    t0 = time.time()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors
+    print(f"\n[paired end, {n} reads, {world} ranks] {time.time() - t0:.1f} s", flush=True)
+    for c in comms:
+        c.close()
+    assert out == [want] * world
+    host = reads.cpu().numpy()[:, :L]
+    del reads
+    torch.cuda.empty_cache(); pool_trim()
+    o1, o2 = tmp_path / "r1.txt", tmp_path / "r2.txt"
+    assert decompress_pe(str(d), str(o1), str(o2)) == half
+    a = np.frombuffer(o1.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+    b = np.frombuffer(o2.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+    # the multiset of (read, mate) pairs, compared through a 64-bit hash per pair (two sorted arrays of 16 M strings of 300 bytes would
+    # take 20 GB of host memory; a collision among 16 M hashes of 64 bits has probability 1e-5 and could only hide an error, not make one)
+    def pair_hashes(x, y):
+        out = np.empty(x.shape[0], dtype=np.uint64)
+        wt = (np.arange(1, 2 * L + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+        with np.errstate(over="ignore"):
+            for lo in range(0, x.shape[0], 1 << 20):
+                hi = min(x.shape[0], lo + (1 << 20))
+                row = np.concatenate([x[lo:hi], y[lo:hi]], axis=1).astype(np.uint64)
+                h = (row * wt[None, :]).sum(axis=1, dtype=np.uint64)
+                h ^= h >> np.uint64(29); h *= np.uint64(0xBF58476D1CE4E5B9); h ^= h >> np.uint64(32)
+                out[lo:hi] = h
+        return np.sort(out)
+    got = pair_hashes(a, b)
+    del a, b
+    want_pairs = pair_hashes(host[:half], host[half:])
+    assert np.array_equal(got, want_pairs)
