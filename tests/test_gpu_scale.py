@@ -311,3 +311,18 @@ def test_paired_end_over_eight_ranks_2x16m_reads_of_150_bases(tmp_path):
     del a, b
     want_pairs = pair_hashes(host[:half], host[half:])
     assert np.array_equal(got, want_pairs)
+
+
+def test_120m_reads_of_150_bases_beyond_the_sorted_index_placement():
+    """Above ~93 M x 150 bp the partitions of the Stage-2 contig index outgrow the LDS-sorted placement (14 336 entries) and are placed by the
+    scattered kernel (same index; profiles/r05_size_sweep.txt: 502 Mreads/s at 120 M, 496 at 150 M, 485 at 200 M against 529 at 100 M -- a
+    slope, not a cliff).  The properties of the 100 M-read test at 120 M reads: every read in exactly one place, every member on its contig,
+    two runs bit-identical."""
+    n, L = 120_000_000, 150
+    st = {}
+    res, d1, d2 = _run_checked(n, L, 1002, stats=st)
+    assert d1 == d2
+    assert res["n_reads"] == n and res["members"] + res["n_sg"] + sum(res["n_" + k] for k in ("allA", "allT", "allN", "fpA", "fpT", "fpN", "Nfile")) == n
+    assert res["members"] > 0.8 * n and res["members_checked"] == res["members"]
+    assert res["max_mismatch"] <= L // 2 and res["mean_mismatch"] < 0.02 * L
+    assert st["cix_entries"] > 65535 * 14336                              # (more entries than the sorted placement can take in 65 535 partitions)
