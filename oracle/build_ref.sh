@@ -61,8 +61,24 @@ build_variant() {   # name readlen extra_defines...
   echo "built $d"
 }
 
+# INTEGRATION.md section A as a link: the reference's own main / pre_process / cluster_dump / reader objects of a variant built above,
+# with oracle/shim_stages.cpp (the four stage drivers over libmcom_host.so) in the place of the reference's kthread_reads / _bucket /
+# _cb / _hash_realign / bbhashdict objects -> oracle/_ref/<variant>/minicom_gpu (needs the product libraries: skipped when they are not built)
+build_shim() {   # variant
+  local d=$OUT/$1
+  local LIBD=$HERE/../minicom_amd/lib
+  [ -f "$LIBD/libmcom_host.so" ] && [ -f "$LIBD/libmcom_hip.so" ] || { echo "libmcom_host.so not built: no $1/minicom_gpu"; return 0; }
+  local CXXFLAGS; CXXFLAGS=$(base_flags)
+  $CXX -c $CXXFLAGS -I"$d" -I"$REF" -I"$HERE" "$HERE/shim_stages.cpp" -o "$d/shim_stages.o"
+  $CXX $CXXFLAGS "$d/minicommain.o" "$d/preprocess.o" "$d/kthread_dump.o" "$d/bseq.o" "$d/misc.o" "$d/sketch.o" "$d/kthread_idx.o" "$d/shim_stages.o" \
+       -o "$d/minicom_gpu" -L"$LIBD" -lmcom_host -lmcom_hip -Wl,-rpath,'$ORIGIN/../../../minicom_amd/lib' -lm -lz -lpthread
+  echo "built $d/minicom_gpu"
+}
+
 build_variant L100 100
 build_variant L150 150
+build_shim L100
+build_shim L150
 build_variant L40 40
 build_variant L75 75
 ININUMDICT=4 build_variant L100_s4 100
