@@ -47,6 +47,10 @@ long mcomh_test_flag_exchanges(const struct mcomh_pipeline *p);
  * count, up to `cap` in a second copy, and beyond `cap` the class array itself is copied.  Defaults 4096 and 2^20; small values let
  * a test walk all three paths with a few dozen reads.  Before mcomh_kt_for_reads.                                              */
 int  mcomh_test_special_capacity(struct mcomh_pipeline *p, uint32_t first, uint32_t cap);
+/* A gzip file of several members is inflated and parsed by all cores (host/mcom_fastq_gz.cpp); whatever that route does not take goes to
+ * the sequential reader, with the same rows.  Work items (groups of members) of the last file the parallel route read to its end, 0 when
+ * the last file went to the sequential reader: lets a test tell which of the two it has checked.                                    */
+long mcomh_test_gz_items(void);
 
 #ifdef __cplusplus
 }

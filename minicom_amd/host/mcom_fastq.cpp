@@ -30,6 +30,10 @@
 #include <string>
 #include <vector>
 
+// mcom_fastq_gz.cpp: a gzip file of several members, inflated and parsed by all cores
+int mcom_fastq_gz_members_to_device(const char *path, int device, int *L_io, uint8_t **d_reads, size_t *n_out, size_t *n_members_out, std::string *err);
+int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_reads, uint8_t *host_out, size_t host_cap, size_t *n_out, size_t *n_members_out, std::string *err);
+
 namespace {
 
 // kseq-like record reader over a gz stream: yields one sequence at a time, appended to `out`
@@ -110,6 +114,11 @@ extern "C" int mcomh_fastq_read(const char *path, int *L, uint8_t *out, size_t c
 {
 	if (!path || !L || !n) return MCOM_E_ARG;
 	*n = 0;
+	if (out) {                                                                // a gzip file of several members: all cores (mcom_fastq_gz.cpp); anything it does not take falls through
+		int L2 = *L; size_t n2 = 0, members = 0; std::string msg;
+		const int gz = mcom_fastq_gz_members(path, -1, &L2, nullptr, out, cap_reads, &n2, &members, &msg);
+		if (gz == 1) { *L = L2; *n = n2; return MCOM_OK; }
+	}
 	gzFile f = gzopen(path, "rb");
 	if (!f) return MCOM_E_ARG;
 	gzbuffer(f, 1 << 20);
@@ -143,6 +152,12 @@ extern "C" int mcomh_fastq_to_device(const char *path, int device, int *L, size_
 		const int fast = fastq_to_device_mapped(path, device, L, d_reads, n);
 		if (fast == 1) return MCOM_OK;
 		if (fast < 0) return fail(fast, "upload failed");
+	}
+	{                                                                         // a gzip file of several members (bgzip, concatenated gzip): inflated and parsed by all cores (mcom_fastq_gz.cpp)
+		std::string msg; size_t members = 0;
+		const int gz = mcom_fastq_gz_members_to_device(path, device, L, d_reads, n, &members, &msg);
+		if (gz == 1) return MCOM_OK;
+		if (gz < 0) return fail(gz, msg.empty() ? "upload failed" : msg.c_str());
 	}
 	gzFile f = gzopen(path, "rb");
 	if (!f) return fail(MCOM_E_ARG, "cannot open the input file");
@@ -254,6 +269,7 @@ static size_t usable_cpus()
 	}
 	return n;
 }
+size_t mcom_usable_cpus() { return usable_cpus(); }                            // (mcom_fastq_gz.cpp)
 static int parser_threads(size_t size)
 {
 	// round 4: as many parser threads as the process has CPUs for, up to 64 (round 3 stopped at 16 whatever the host)

@@ -1,0 +1,363 @@
+// minicom_amd/host/mcom_fastq_gz.cpp -- .fastq.gz whose gzip stream has MORE THAN ONE MEMBER, inflated and parsed by all cores (round 5).
+//
+// The reference reads its input through zlib's gzread (bseq.c:19-36, kseq.h), one thread; real inputs are .fastq.gz.  A gzip file is a
+// sequence of members and most of the tools that write sequencing data write many of them: bgzip / htslib (BGZF: members of at most
+// 64 KB, their compressed size in an extra field of the header), bcl-convert, pigz -i, or simply `cat a.gz b.gz`.  Members are
+// independent deflate streams, so a file of many members can be inflated by many threads -- which one member cannot (a deflate
+// stream is only decodable from its start).  This file does that:
+//
+//   discovery   the member that starts at offset 0 says whether the file is BGZF (then the member starts are walked header by header,
+//               exactly) or not (then a start is looked for behind each of ~4 x threads evenly spaced offsets: the bytes 1f 8b 08 with
+//               legal flag bits, confirmed by inflating the first kilobytes there).  One member only: not this route (return 0).
+//   groups      consecutive members are grouped into work items of a few MB of compressed data, numbered in file order
+//   workers     a worker takes the next item, inflates it (checking that every member ends exactly where the next begins: a false
+//               start found by the search cannot survive that), finds the first record boundary of its text by the records' shape
+//               (a '@' line, a line of L bases, a '+' line, a line of L characters; mcom_fastq.cpp does the same for plain files), parses
+//               from there up to and including the record that starts in its text and ends in the next item's (it waits for that
+//               text), and leaves the sequence lines as rows of L characters
+//   uploader    one thread takes the items in order and sends their rows to HBM behind those of the items before (the same
+//               growing array as the sequential reader's)
+// A window of items bounds the memory (a worker does not start item i before item i - window has been sent).  Anything that is not
+// the fixed-length four-line layout -- FASTA, sequences over several lines, carriage returns, reads of several lengths -- and any
+// inconsistency (a member that does not end at the next start, a text without a record boundary) makes the route step back (return 0)
+// and the sequential reader takes the file, which also words the error messages.  Characters outside ACGTN are refused as everywhere.
+#include "../../include/mcom.h"
+#include <hip/hip_runtime_api.h>
+#include <zlib.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+size_t mcom_usable_cpus();                                                     // mcom_fastq.cpp
+static std::atomic<long> g_last_items{0};
+// test hook (include/mcom_test.h): work items of the last file this route read to its end (0: the last file went to the sequential reader)
+extern "C" long mcomh_test_gz_items(void) { return g_last_items.load(); }
+
+namespace {
+struct Fd { int f; ~Fd() { if (f >= 0) close(f); } };
+
+bool read_at(int fd, void *dst, size_t n, size_t off)
+{
+	char *d = (char*)dst;
+	while (n) { const ssize_t g = pread(fd, d, n, (off_t)off); if (g <= 0) return false; d += g; off += (size_t)g; n -= (size_t)g; }
+	return true;
+}
+// a gzip member header at h (at least 18 bytes readable, `have` bytes in all): 0 = not one; otherwise 1, and *bgzf_size = the member's
+// compressed size when the header carries BGZF's BC field (0 otherwise)
+int member_header(const unsigned char *h, size_t have, uint32_t *bgzf_size)
+{
+	*bgzf_size = 0;
+	if (have < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) return 0;
+	if (h[3] & 4) {                                                             // FEXTRA: subfields of { SI1, SI2, LEN, data }
+		const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+		size_t p = 12, e = std::min(have, 12 + xlen);
+		while (p + 4 <= e) {
+			const size_t sl = (size_t)h[p + 2] | ((size_t)h[p + 3] << 8);
+			if (h[p] == 'B' && h[p + 1] == 'C' && sl == 2 && p + 6 <= e) { *bgzf_size = ((uint32_t)h[p + 4] | ((uint32_t)h[p + 5] << 8)) + 1u; break; }
+			p += 4 + sl;
+		}
+	}
+	return 1;
+}
+// does a deflate stream that makes sense start here?  (the first bytes inflate without an error and give some output)
+bool inflates_here(const unsigned char *p, size_t n)
+{
+	z_stream z; memset(&z, 0, sizeof z);
+	if (inflateInit2(&z, 15 + 16) != Z_OK) return false;
+	unsigned char out[4096];
+	z.next_in = const_cast<unsigned char*>(p); z.avail_in = (uInt)std::min<size_t>(n, 1 << 16);
+	z.next_out = out; z.avail_out = sizeof out;
+	const int rc = inflate(&z, Z_SYNC_FLUSH);
+	const bool ok = (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) && z.total_out > 0;
+	bool text = ok;
+	for (uLong i = 0; text && i < z.total_out; ++i) text = out[i] == '\n' || (out[i] >= 32 && out[i] < 127);   // (a FASTQ file is printable text)
+	inflateEnd(&z);
+	return text;
+}
+inline const char *next_line(const char *p, const char *e) { const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p)); return nl ? nl + 1 : e; }
+// a record of the shape at p, all of it inside [p, e): its end; nullptr: not one (or not all of it there)
+inline const char *record_in(const char *p, const char *e, int L)
+{
+	if (p >= e || *p != '@') return nullptr;
+	const char *s = next_line(p, e);
+	if (s + L >= e || s[L] != '\n') return nullptr;
+	const char *plus = s + L + 1;
+	if (plus >= e || *plus != '+') return nullptr;
+	const char *q = next_line(plus, e);
+	if (q + L >= e || q[L] != '\n') return nullptr;
+	return q + L + 1;
+}
+struct Item {
+	size_t begin = 0, end = 0;                                                  // compressed bytes [begin, end): whole members
+	std::vector<char> text;                                                    // what they inflate to
+	size_t first = 0;                                                           // offset of the first record that starts in this text (text.size(): none)
+	std::vector<unsigned char> rows; size_t n_rows = 0;                         // the sequence lines of the records that start in this text
+	int state = 0;                                                              // 0 waiting, 1 text there, 2 rows there, 3 sent
+};
+}  // namespace
+
+// 1 = the reads are on the device (*d_reads [n][L] characters, hipMalloc'ed), 0 = not this route (nothing kept), < 0 = error (err says what).
+// host_out != NULL: the rows go to host memory instead (room for host_cap rows; MCOM_E_OVERFLOW when there are more) and no GPU is touched.
+int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_reads, uint8_t *host_out, size_t host_cap, size_t *n_out, size_t *n_members_out, std::string *err)
+{
+	if (d_reads) *d_reads = nullptr;
+	*n_out = 0;
+	g_last_items = 0;
+	if (n_members_out) *n_members_out = 0;
+	Fd fd{open(path, O_RDONLY)};
+	if (fd.f < 0) return 0;
+	struct stat st;
+	if (fstat(fd.f, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 64) return 0;
+	const size_t size = (size_t)st.st_size;
+	unsigned char head[64];
+	if (!read_at(fd.f, head, sizeof head, 0)) return 0;
+	uint32_t bsz = 0;
+	if (!member_header(head, sizeof head, &bsz)) return 0;
+	// ---- discovery ------------------------------------------------------------------------------------------------------------------
+	const size_t nt = std::max<size_t>(1, std::min<size_t>(64, mcom_usable_cpus()));
+	std::vector<size_t> starts;                                                 // member starts that bound the work items (ascending, starts[0] = 0)
+	starts.push_back(0);
+	size_t n_members = 1;
+	const size_t target = std::max<size_t>((size_t)256 << 10, std::min<size_t>((size_t)16 << 20, size / (8 * nt) + 1));   // compressed bytes per item
+	if (bsz) {                                                                   // BGZF: every header says where the next one is
+		size_t off = 0, last_cut = 0;
+		std::vector<unsigned char> buf((size_t)1 << 20);
+		size_t b0 = 0, bn = 0;                                                   // buf holds file bytes [b0, b0 + bn)
+		for (;;) {
+			if (off + 18 > size) return 0;                                       // (a BGZF file ends with an empty member: 28 bytes)
+			if (off < b0 || off + 32 > b0 + bn) { b0 = off; bn = std::min(buf.size(), size - off); if (!read_at(fd.f, buf.data(), bn, b0)) return 0; }
+			uint32_t s = 0;
+			if (!member_header(buf.data() + (off - b0), bn - (off - b0), &s) || !s) return 0;
+			const size_t nxt = off + s;
+			if (nxt > size) return 0;
+			if (nxt == size) break;
+			++n_members;
+			if (nxt - last_cut >= target) { starts.push_back(nxt); last_cut = nxt; }
+			off = nxt;
+		}
+	} else {                                                                     // any gzip: look for a member start behind evenly spaced offsets
+		std::vector<unsigned char> buf((size_t)8 << 20);
+		const size_t step = std::max(target, size / (4 * nt) + 1);
+		for (size_t want = step; want + 64 < size; want += step) {
+			size_t found = 0;
+			for (size_t base = want; base + 64 < size && base < want + ((size_t)64 << 20) && !found; base += buf.size() - 64) {
+				const size_t bn = std::min(buf.size(), size - base);
+				if (!read_at(fd.f, buf.data(), bn, base)) return 0;
+				const unsigned char *p = buf.data(), *e = buf.data() + bn - 32;
+				while (p < e && !found) {
+					p = (const unsigned char*)memchr(p, 0x1f, (size_t)(e - p));
+					if (!p) break;
+					uint32_t s = 0;
+					if (member_header(p, (size_t)(buf.data() + bn - p), &s) && inflates_here(p, (size_t)(buf.data() + bn - p))) found = base + (size_t)(p - buf.data());
+					++p;
+				}
+			}
+			if (found && found > starts.back()) { starts.push_back(found); ++n_members; want = std::max(want, found); }
+		}
+	}
+	if (starts.size() < 2) return 0;                                             // one member (or one work item): nothing to share out
+	if (n_members_out) *n_members_out = n_members;
+	const size_t ni = starts.size();
+	std::vector<Item> items(ni);
+	for (size_t i = 0; i < ni; ++i) { items[i].begin = starts[i]; items[i].end = i + 1 < ni ? starts[i + 1] : size; }
+	// ---- the read length: from the head of the first item's text -------------------------------------------------------------------
+	int L = *L_io;
+	// ---- workers + uploader --------------------------------------------------------------------------------------------------------
+	std::mutex mu; std::condition_variable cv;
+	std::atomic<size_t> next_item{0};
+	size_t sent = 0;                                                            // items the uploader is done with (guarded by mu)
+	std::atomic<int> fail{0};                                                   // 1 = not this route after all, < 0 = error
+	std::string fail_msg;
+	const size_t window = 3 * nt + 2;
+	int L_shared = L;                                                           // (guarded by mu; item 0 settles it when *L_io is 0)
+	auto give_up = [&](int code, const char *msg) { { std::lock_guard<std::mutex> g(mu); if (!fail) { fail = code; fail_msg = msg; } } cv.notify_all(); };
+	auto worker = [&]() {
+		std::vector<unsigned char> in;
+		for (;;) {
+			const size_t i = next_item.fetch_add(1);
+			if (i >= ni || fail) return;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || i < sent + window; }); if (fail) return; }
+			Item &it = items[i];
+			// inflate the item's members
+			in.resize(it.end - it.begin);
+			if (!read_at(fd.f, in.data(), in.size(), it.begin)) { give_up(MCOM_E_ARG, "read error"); return; }
+			it.text.clear(); it.text.reserve(in.size() * 5);
+			z_stream z; memset(&z, 0, sizeof z);
+			if (inflateInit2(&z, 15 + 16) != Z_OK) { give_up(MCOM_E_NOMEM, "zlib"); return; }
+			z.next_in = in.data(); z.avail_in = (uInt)0;
+			size_t fed = 0;
+			bool bad = false;
+			for (;;) {
+				if (z.avail_in == 0 && fed < in.size()) { const size_t k = std::min<size_t>(in.size() - fed, (size_t)1 << 30); z.next_in = in.data() + fed; z.avail_in = (uInt)k; fed += k; }
+				const size_t have = it.text.size();
+				it.text.resize(have + ((size_t)4 << 20));
+				z.next_out = (unsigned char*)it.text.data() + have; z.avail_out = (uInt)((size_t)4 << 20);
+				const int rc = inflate(&z, Z_NO_FLUSH);
+				it.text.resize(have + (((size_t)4 << 20) - z.avail_out));
+				if (rc == Z_STREAM_END) {
+					const size_t used = fed - z.avail_in;                          // the member ended here
+					if (used == in.size()) break;
+					if (inflateReset(&z) != Z_OK) { bad = true; break; }           // the next member of the item follows
+					continue;
+				}
+				if (rc != Z_OK && rc != Z_BUF_ERROR) { bad = true; break; }
+				if (rc == Z_BUF_ERROR && z.avail_in == 0 && fed == in.size()) { bad = true; break; }   // the data ran out inside a member: the item does not end at a member boundary
+			}
+			inflateEnd(&z);
+			if (bad) { give_up(1, "the members do not tile the file"); return; }
+			// the read length (item 0, from its first record) and this text's first record boundary
+			const char *tb = it.text.data(), *te = tb + it.text.size();
+			int len;
+			if (i == 0) {
+				if (it.text.empty() || tb[0] != '@') { give_up(1, "not FASTQ"); return; }
+				const char *s0 = next_line(tb, te);
+				const char *s1 = (const char*)memchr(s0, '\n', (size_t)(te - s0));
+				if (!s1) { give_up(1, "no sequence line"); return; }
+				len = (int)(s1 - s0);
+				{ std::lock_guard<std::mutex> g(mu); if (L_shared == 0) L_shared = len; len = L_shared; }
+				if (len < 1 || len > 256 || (int)(s1 - s0) != len) { give_up(1, "read length"); return; }
+				it.first = 0;
+				cv.notify_all();
+			} else {
+				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || L_shared != 0; }); if (fail) return; len = L_shared; }
+				// candidates: the text's own first byte (a line start iff the text before ended with a newline, which nobody knows yet: the shape
+				// decides, and a wrong guess makes the record across the two texts fail its shape test -- the route steps back), then the line starts
+				const char *p = tb == te ? te : next_line(tb, te);
+				const char *found = nullptr;
+				if (record_in(tb, te, len)) found = tb;
+				for (int tries = 0; !found && tries < 8 && p < te; ++tries) { if (record_in(p, te, len)) found = p; else p = next_line(p, te); }
+				it.first = found ? (size_t)(found - tb) : it.text.size();
+				if (!found && it.text.size() > (size_t)(8 * (2 * len + 512))) { give_up(1, "no record boundary"); return; }
+			}
+			{ std::lock_guard<std::mutex> g(mu); it.state = 1; }
+			cv.notify_all();
+			// parse: the records that start in this text; the last one may end in the following texts
+			it.rows.clear(); it.n_rows = 0;
+			it.rows.reserve((it.text.size() / (size_t)(2 * len + 6) + 2) * (size_t)len);
+			size_t pos = it.first;
+			unsigned bad_char = 0;
+			auto take = [&](const char *seq) {
+				const size_t at = it.rows.size();
+				it.rows.resize(at + (size_t)len);
+				memcpy(it.rows.data() + at, seq, (size_t)len);
+				for (int q = 0; q < len; ++q) { const char c = seq[q]; bad_char |= (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N'); }
+				++it.n_rows;
+			};
+			while (pos < it.text.size()) {
+				const char *q = record_in(tb + pos, te, len);
+				if (!q) break;
+				take(next_line(tb + pos, te));
+				pos = (size_t)(q - tb);
+			}
+			if (pos < it.text.size()) {
+				// a record starts at pos and does not end in this text: put it together with the heads of the following texts
+				std::string rec(tb + pos, it.text.size() - pos);
+				bool done = false;
+				for (size_t j = i + 1; !done; ++j) {
+					if (j >= ni) {                                                    // the file ends here: the last line may lack its newline
+						rec.push_back('\n');
+						const char *q = record_in(rec.data(), rec.data() + rec.size(), len);
+						if (!q || q != rec.data() + rec.size()) { give_up(1, "the last record is not of the shape"); return; }
+						take(next_line(rec.data(), rec.data() + rec.size()));
+						done = true; break;
+					}
+					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[j].state >= 1; }); if (fail) return; }
+					const Item &nx = items[j];
+					const size_t headn = std::min(nx.first, nx.text.size());
+					rec.append(nx.text.data(), headn);                                // what lies in front of that text's first record belongs to this one
+					if (headn < nx.text.size() || j + 1 == ni) {
+						if (headn == nx.text.size() && j + 1 == ni && (rec.empty() || rec.back() != '\n')) rec.push_back('\n');
+						const char *q = record_in(rec.data(), rec.data() + rec.size(), len);
+						if (!q || q != rec.data() + rec.size()) { give_up(1, "a record across two members is not of the shape"); return; }
+						take(next_line(rec.data(), rec.data() + rec.size()));
+						done = true;
+					}
+				}
+			} else if (i + 1 < ni) {
+				// this text ends exactly at a record's end: the next text must start with a record (its first == 0), checked by its own worker's
+				// search (a record at its first byte is tried first); nothing to do here
+			}
+			if (bad_char) { give_up(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)"); return; }
+			{ std::lock_guard<std::mutex> g(mu); it.state = 2; }
+			cv.notify_all();
+		}
+	};
+	uint8_t *dev = nullptr; size_t dev_cap = 0, total = 0;
+	int up_rc = 0;
+	std::thread up([&]() {
+		hipStream_t cs = nullptr;
+		unsigned char *pin[2] = {nullptr, nullptr}; size_t pin_cap = 0; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+		int cur = 0;
+		auto bail = [&](int code, const char *msg) { up_rc = code; give_up(code, msg); };
+		const bool to_host = host_out != nullptr;
+		if (!to_host && (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess)) { bail(MCOM_E_HIP, "no usable GPU"); cs = nullptr; }
+		for (size_t i = 0; i < ni && (cs || to_host); ++i) {
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[i].state >= 2; }); if (fail) break; }
+			Item &it = items[i];
+			int len; { std::lock_guard<std::mutex> g(mu); len = L_shared; }
+			const size_t bytes = it.n_rows * (size_t)len;
+			if (bytes && to_host) {
+				if (total + it.n_rows > host_cap) { total += it.n_rows; bail(MCOM_E_OVERFLOW, "more reads than the caller has room for"); break; }
+				memcpy(host_out + total * (size_t)len, it.rows.data(), bytes);
+				total += it.n_rows;
+			} else if (bytes) {
+				if (bytes > pin_cap) {
+					for (int q = 0; q < 2; ++q) { if (busy[q]) { (void)hipEventSynchronize(ev[q]); busy[q] = false; } if (pin[q]) (void)hipHostFree(pin[q]); pin[q] = nullptr; }
+					pin_cap = bytes + bytes / 2;
+					for (int q = 0; q < 2; ++q) if (hipHostMalloc((void**)&pin[q], pin_cap, hipHostMallocDefault) != hipSuccess || (!ev[q] && hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess)) { bail(MCOM_E_NOMEM, "pinned blocks"); break; }
+					if (fail) break;
+				}
+				if (total + it.n_rows > dev_cap) {
+					size_t want = dev_cap ? dev_cap * 2 : std::max<size_t>(it.n_rows * (ni + 1), (size_t)1 << 20);
+					while (want < total + it.n_rows) want *= 2;
+					uint8_t *nd = nullptr;
+					if (hipMalloc(&nd, want * (size_t)len + 16) != hipSuccess) { bail(MCOM_E_NOMEM, "out of device memory"); break; }
+					if (hipStreamSynchronize(cs) != hipSuccess || (dev && total && hipMemcpy(nd, dev, total * (size_t)len, hipMemcpyDeviceToDevice) != hipSuccess)) { (void)hipFree(nd); bail(MCOM_E_HIP, "upload failed"); break; }
+					if (dev) (void)hipFree(dev);
+					dev = nd; dev_cap = want;
+				}
+				if (busy[cur]) { if (hipEventSynchronize(ev[cur]) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; } busy[cur] = false; }
+				memcpy(pin[cur], it.rows.data(), bytes);
+				if (hipMemcpyAsync(dev + total * (size_t)len, pin[cur], bytes, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(ev[cur], cs) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; }
+				busy[cur] = true; cur ^= 1;
+				total += it.n_rows;
+			}
+			std::vector<unsigned char>().swap(it.rows);
+			if (i) std::vector<char>().swap(items[i - 1].text);                    // (item i's rows are made: nobody reads the text before it any more)
+			{ std::lock_guard<std::mutex> g(mu); it.state = 3; sent = i + 1; }
+			cv.notify_all();
+		}
+		if (cs) { if (hipStreamSynchronize(cs) != hipSuccess && !up_rc) up_rc = MCOM_E_HIP; (void)hipStreamDestroy(cs); }
+		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (ev[q]) (void)hipEventDestroy(ev[q]); }
+	});
+	std::vector<std::thread> th;
+	for (size_t t = 0; t < std::max<size_t>(2, std::min(nt, ni)); ++t) th.emplace_back(worker);   // (two at least: the worker of item i waits for the text of item i + 1, which somebody else must make)
+	for (auto &x : th) x.join();
+	{ std::lock_guard<std::mutex> g(mu); if (!fail && next_item < ni) fail = 1; }
+	cv.notify_all();
+	up.join();
+	if (fail || up_rc) {
+		if (dev) (void)hipFree(dev);
+		const int code = fail ? (int)fail : up_rc;
+		if (code < 0 && err) *err = fail_msg;
+		return code < 0 ? code : 0;
+	}
+	if (!total) { if (dev) (void)hipFree(dev); return 0; }
+	*L_io = L_shared; *n_out = total;
+	if (d_reads) *d_reads = dev;
+	g_last_items = (long)ni;
+	return 1;
+}
+int mcom_fastq_gz_members_to_device(const char *path, int device, int *L_io, uint8_t **d_reads, size_t *n_out, size_t *n_members_out, std::string *err)
+{
+	return mcom_fastq_gz_members(path, device, L_io, d_reads, nullptr, 0, n_out, n_members_out, err);
+}

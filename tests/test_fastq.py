@@ -70,6 +70,102 @@ def test_errors_the_reference_exits_on(tmp_path):
         read_fastq(p, L=12)
 
 
+def _gzip_members(path, data, cuts, level=1):
+    with open(path, "wb") as f:
+        for a, b in zip([0] + cuts, cuts + [len(data)]):
+            f.write(gzip.compress(data[a:b], level))
+
+
+def _bgzf(path, data, block=60000):
+    """what bgzip writes: members of at most 64 KB with their compressed size in a BC extra field, an empty member at the end"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for a in range(0, len(data), block):
+            blk = data[a:a + block]
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            comp = c.compress(blk) + c.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(blk), len(blk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_gzip_files_of_many_members_are_read_by_all_cores_and_equal_the_plain_file(tmp_path):
+    """Real inputs are .fastq.gz, and most writers of sequencing data write gzip files of many members (bgzip, bcl-convert, pigz -i):
+    host/mcom_fastq_gz.cpp inflates the members in parallel and parses every piece of text from the first record boundary it finds by
+    shape, a record that straddles two pieces being put together by the piece it starts in (the reference: gzread in one thread,
+    bseq.c:19-36).  Members cut at arbitrary bytes (inside names, sequences, quality lines, between a newline and '@', at record ends),
+    BGZF blocks, quality lines that start with '@' and '+': the rows equal the array the file was written from.  One member, a
+    name that contains '@' at a cut, FASTA: the sequential reader takes over, same rows."""
+    import re
+    from minicom_amd import synth
+    from minicom_amd.pipeline import read_fastq
+    L = 100
+    reads = np.concatenate([synth.synth_reads(5, 199000, L), synth.synth_reads(6, 1000, L, plumbing=True)])
+    fq = str(tmp_path / "a.fastq")
+    synth.write_fastq_fast(fq, reads)                                          # (tricky quality lines: every third starts with '@', every fifth with '+')
+    data = open(fq, "rb").read()
+    n = reads.shape[0]
+    out = np.empty((n, L), dtype=np.uint8)
+
+    def read_into(path, cap=n):
+        import ctypes as C
+        from minicom_amd.pipeline import load_host_library
+        lib = load_host_library()
+        Lc, cnt = C.c_int(0), C.c_size_t()
+        rc = lib.mcomh_fastq_read(path.encode(), C.byref(Lc), out.ctypes.data_as(C.c_void_p), cap, C.byref(cnt))
+        lib.mcomh_test_gz_items.restype = C.c_long
+        items.append(lib.mcomh_test_gz_items())
+        return rc, Lc.value, cnt.value
+    items = []
+    rng = np.random.default_rng(1)
+    recs = [m.start() + 1 for m in re.finditer(b"\n@r", data)]
+    for name, cuts in (("random", sorted({int(x) for x in rng.integers(1, len(data) - 1, 120)})),
+                       ("record_ends", [recs[i] for i in range(500, len(recs), 1500)]),
+                       ("around_newlines", sorted({recs[i] + d for i in range(700, len(recs), 2100) for d in (-1, 0, 1)}))):
+        p = str(tmp_path / (name + ".fastq.gz"))
+        _gzip_members(p, data, cuts)
+        out[:] = 0
+        assert read_into(p) == (0, L, n) and np.array_equal(out, reads), name
+        assert items[-1] >= 8, (name, items)                                   # (the parallel route read it, in that many work items)
+    p = str(tmp_path / "b.fastq.gz")
+    _bgzf(p, data)
+    out[:] = 0
+    assert read_into(p) == (0, L, n) and np.array_equal(out, reads) and items[-1] >= 8
+    rc, _, cnt = read_into(p, cap=n - 5)                                       # more reads than the caller has room for
+    assert rc != 0
+    # one member: nothing to share out, the sequential reader
+    with gzip.open(str(tmp_path / "one.fastq.gz"), "wb", compresslevel=1) as g:
+        g.write(data)
+    assert np.array_equal(read_fastq(str(tmp_path / "one.fastq.gz")), reads)
+    # a character outside ACGTN in a many-member file is an error, not a silent change
+    bad = bytearray(data); bad[recs[70000] + 12] = ord("a")
+    _gzip_members(str(tmp_path / "bad.fastq.gz"), bytes(bad), sorted({int(x) for x in rng.integers(1, len(data) - 1, 60)}))
+    assert read_into(str(tmp_path / "bad.fastq.gz"))[0] != 0
+    # multi-line FASTA in many members: not the four-line layout, the sequential reader reads it
+    fa = b"".join(b">s%d\n%s\n%s\n" % (i, reads[i, :60].tobytes(), reads[i, 60:].tobytes()) for i in range(30000))
+    _gzip_members(str(tmp_path / "x.fa.gz"), fa, sorted({int(x) for x in rng.integers(1, len(fa) - 1, 30)}))
+    assert np.array_equal(read_fastq(str(tmp_path / "x.fa.gz")), reads[:30000])
+
+
+@pytest.mark.gpu
+def test_pipeline_from_a_gzip_file_of_many_members(tmp_path):
+    """file -> HBM through the parallel gzip route -> pipeline = the pipeline over the array"""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    reads = np.concatenate([synth.synth_reads(81, 299000, 150), synth.synth_reads(82, 1000, 150, plumbing=True)])
+    fq = str(tmp_path / "r.fastq")
+    synth.write_fastq_fast(fq, reads)
+    data = open(fq, "rb").read()
+    rng = np.random.default_rng(3)
+    _gzip_members(fq + ".gz", data, sorted({int(x) for x in rng.integers(1, len(data) - 1, 90)}))
+    p = Pipeline.from_fastq(fq + ".gz", host_threads=4)
+    assert (p.n, p.L) == reads.shape
+    p.pre_process()
+    q = Pipeline(reads, host_threads=4); q.pre_process()
+    assert p.result_digest() == q.result_digest()
+    p.close(); q.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", [0, 700])
 def test_pipeline_from_fastq_equals_pipeline_from_array(tmp_path, chunk):
