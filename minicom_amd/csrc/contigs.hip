@@ -881,14 +881,27 @@ __global__ __launch_bounds__(256) void k_fn_counts_ord(const uint64_t *__restric
 	const uint32_t c = ord ? ord[u] : (uint32_t)u;
 	const uint32_t r0 = roff[c], cnt = roff[c + 1] - r0, q0 = qoff[u];
 	const bool old_contig = new_span && !fn_is_new(c, new_lo, new_span);
-	for (uint32_t t = lane; t < cnt; t += 16) {
-		const mcom_mm128 v = rec[r0 + t];
-		uint32_t s = 0, k = 0;
-		bool look = v.x != U64MAX;
-		if (look && old_contig) { const uint32_t h = fn_key_bit(v.x, kbits); look = (keymap[h >> 5] >> (h & 31)) & 1u; }
-		if (look) mcom_table_find_any(slots, log2cap, region, bbits, v.x, s, k);
-		hits[q0 + t] = k;
-		if (k) { first[q0 + t] = s; qy[q0 + t] = v.y; }
+	// four records of the contig in flight per lane (a lane's loop is a chain of load -> probe -> store otherwise: the flat kernel has a
+	// thread per query and the scheduler's other waves to hide that behind)
+	for (uint32_t t0 = lane; t0 < cnt; t0 += 64) {
+		mcom_mm128 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + 16u * u; if (t < cnt) v[u] = rec[r0 + t]; else { v[u].x = U64MAX; v[u].y = 0; } }
+		bool look[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			look[u] = v[u].x != U64MAX;
+			if (look[u] && old_contig) { const uint32_t h = fn_key_bit(v[u].x, kbits); look[u] = (keymap[h >> 5] >> (h & 31)) & 1u; }
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t t = t0 + 16u * u;
+			if (t >= cnt) break;
+			uint32_t s = 0, k = 0;
+			if (look[u]) mcom_table_find_any(slots, log2cap, region, bbits, v[u].x, s, k);
+			hits[q0 + t] = k;
+			if (k) { first[q0 + t] = s; qy[q0 + t] = v[u].y; }
+		}
 	}
 }
 // Round 4: the evaluation runs one thread per (query, hit) PAIR.  Three queries in four have no hit, and the others between one

@@ -98,7 +98,7 @@ inline const char *record_in(const char *p, const char *e, int L)
 }
 struct Item {
 	size_t begin = 0, end = 0;                                                  // compressed bytes [begin, end): whole members
-	std::vector<char> text;                                                    // what they inflate to
+	std::vector<char> text;                                                    // what they inflate to (sized once, to the ISIZE sum of its members when that is known)
 	size_t first = 0;                                                           // offset of the first record that starts in this text (text.size(): none)
 	std::vector<unsigned char> rows; size_t n_rows = 0;                         // the sequence lines of the records that start in this text
 	int state = 0;                                                              // 0 waiting, 1 text there, 2 rows there, 3 sent
@@ -190,7 +190,9 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			// inflate the item's members
 			in.resize(it.end - it.begin);
 			if (!read_at(fd.f, in.data(), in.size(), it.begin)) { give_up(MCOM_E_ARG, "read error"); return; }
-			it.text.clear(); it.text.reserve(in.size() * 5);
+			// (a vector's resize clears what it adds -- a second pass over every byte of text; the buffer grows by doubling and is cut to size once)
+			size_t tcap = std::max<size_t>(in.size() * 6, (size_t)1 << 20), have = 0;
+			std::unique_ptr<char[]> tbuf(new char[tcap]);
 			z_stream z; memset(&z, 0, sizeof z);
 			if (inflateInit2(&z, 15 + 16) != Z_OK) { give_up(MCOM_E_NOMEM, "zlib"); return; }
 			z.next_in = in.data(); z.avail_in = (uInt)0;
@@ -198,11 +200,11 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			bool bad = false;
 			for (;;) {
 				if (z.avail_in == 0 && fed < in.size()) { const size_t k = std::min<size_t>(in.size() - fed, (size_t)1 << 30); z.next_in = in.data() + fed; z.avail_in = (uInt)k; fed += k; }
-				const size_t have = it.text.size();
-				it.text.resize(have + ((size_t)4 << 20));
-				z.next_out = (unsigned char*)it.text.data() + have; z.avail_out = (uInt)((size_t)4 << 20);
+				if (tcap - have < ((size_t)1 << 20)) { std::unique_ptr<char[]> nb(new char[2 * tcap]); memcpy(nb.get(), tbuf.get(), have); tbuf.swap(nb); tcap *= 2; }
+				const size_t room = std::min<size_t>(tcap - have, (size_t)1 << 30);
+				z.next_out = (unsigned char*)tbuf.get() + have; z.avail_out = (uInt)room;
 				const int rc = inflate(&z, Z_NO_FLUSH);
-				it.text.resize(have + (((size_t)4 << 20) - z.avail_out));
+				have += room - z.avail_out;
 				if (rc == Z_STREAM_END) {
 					const size_t used = fed - z.avail_in;                          // the member ended here
 					if (used == in.size()) break;
@@ -214,6 +216,8 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			}
 			inflateEnd(&z);
 			if (bad) { give_up(1, "the members do not tile the file"); return; }
+			it.text.assign(tbuf.get(), tbuf.get() + have);
+			tbuf.reset();
 			// the read length (item 0, from its first record) and this text's first record boundary
 			const char *tb = it.text.data(), *te = tb + it.text.size();
 			int len;
