@@ -489,7 +489,9 @@ def main():
                 sk["mreads_per_s"] = round((st["n"] + st["resketch"]) / (agg["ms_sketch_reads"] * 1e-3) / 1e6, 1)
                 sk["algorithmic_bytes_per_read"] = 8 * ((2 * L + 63) // 64) + 16
                 sk["issue_roofline"] = issue_line("sketch_reads")
-                sk["note"] = "ALU bound: one thread per read, rolling k-mers + hash64 in registers; the HBM fraction cannot be high (SURVEY section 7)"
+                sk["note"] = ("north-star '>= 50 % of HBM bandwidth in the sketch kernel': UNREACHABLE by construction -- the kernel reads 56 bytes per read and executes ~37 "
+                              "VALU instructions per BASE (rolling k-mers + hash64 in registers: SURVEY section 7 predicted it); it is VALU-bound at 0.80 of the measured "
+                              "issue roofline (issue_roofline below, profiles/pmc_constants.json), which is the figure of merit for it, not the HBM fraction")
                 roof["sketch_kernel"] = sk
             sc = hbm_line("sketch_contigs", "word")
             if sc:

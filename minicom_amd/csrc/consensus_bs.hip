@@ -307,22 +307,36 @@ __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__res
 	for (int t = 0; t < BS_KM; ++t) { c.p[t] = 0; c.q[t] = 0; }
 	uint32_t n = 0; bool over = false;
 	uint64_t i = a;
+	// Round 5: two members deep.  A member costs a chain of two dependent gathers (its word, then two words of its read's row -- a random
+	// 64-byte sector of a 4 GB array); with only the next member WORD in flight every member paid the row's latency in full.  Now the row
+	// words of member i + 1 and the word of member i + 2 travel while member i is counted.
+	auto row_words = [&](uint64_t yy, uint64_t &wa, uint64_t &wb) {
+		const long off_ = (long)((uint32_t)yy >> 1);
+		const int s0_ = (int)(c0 - off_);
+		const int t0_ = (yy & 1) ? L - 32 - s0_ : s0_;
+		const int wj_ = t0_ >> 5, sh_ = 2 * (t0_ & 31);
+		const uint64_t *row = packed + (size_t)(yy >> 32) * W;
+		wa = (wj_ >= 0 && wj_ < W) ? row[wj_] : 0ull;
+		wb = (sh_ && wj_ + 1 >= 0 && wj_ + 1 < W) ? row[wj_ + 1] : 0ull;
+	};
 	uint64_t y = (valid && i < m1) ? members[i] : ~0ull;
+	uint64_t y1 = (valid && i + 1 < m1) ? members[i + 1] : ~0ull;
+	uint64_t wa = 0, wb = 0;
+	if (valid && i < m1 && (long)((uint32_t)y >> 1) < c0 + 32) row_words(y, wa, wb);
 	for (;;) {
 		const long off = (long)((uint32_t)y >> 1);
 		const bool act = valid && !over && i < m1 && off < ce;
 		if (!__ballot(act)) break;
-		const uint64_t y_next = (act && i + 1 < m1) ? members[i + 1] : ~0ull;   // travels while this member is counted
+		uint64_t wa1 = 0, wb1 = 0, y2 = ~0ull;
+		if (act && i + 1 < m1 && (long)((uint32_t)y1 >> 1) < ce) row_words(y1, wa1, wb1);
+		if (act && i + 2 < m1) y2 = members[i + 2];
 		if (act) {
 			if (n == depth_cap) over = true;
 			else {
 				const uint32_t dir = (uint32_t)(y & 1);
 				const int s0 = (int)(c0 - off);                                // read position under the unit's first column (> -32, < L)
 				const int t0 = dir ? L - 32 - s0 : s0;
-				const int wj = t0 >> 5, sh = 2 * (t0 & 31);
-				const uint64_t *row = packed + (size_t)(y >> 32) * W;
-				const uint64_t wa = (wj >= 0 && wj < W) ? row[wj] : 0ull;
-				const uint64_t wb = (sh && wj + 1 >= 0 && wj + 1 < W) ? row[wj + 1] : 0ull;
+				const int sh = 2 * (t0 & 31);
 				uint64_t x = sh ? (wa >> sh) | (wb << (64 - sh)) : wa;
 				if (dir) x = ~bs_rev(x);
 				const int e0 = L - s0 < (int)(ce - c0) ? L - s0 : (int)(ce - c0);
@@ -333,8 +347,8 @@ __global__ __launch_bounds__(64) void k_merge_consensus_bs(const uint64_t *__res
 				++n;
 			}
 			++i;
+			y = y1; wa = wa1; wb = wb1; y1 = y2;
 		}
-		y = act ? y_next : y;
 	}
 	if (!valid) return;
 	if (over) {
