@@ -353,6 +353,13 @@ int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *
                         uint64_t *h_counts);
 int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
                       int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words);
+/* mcom_cindex_place in its two steps (round 5): 2a sorts the entries by partition -- the sorted arrays are one of the two pairs handed in
+ * (*d_key_sorted / *d_slot_sorted say which), the entries of partition v are [d_pstart[v], d_pstart[v + 1]) (n_parts + 1 device words) --
+ * and 2b makes the table from them.  The Stage-2 join (mcom_realign_join) works on the result of 2a alone.                          */
+int mcom_cindex_partition(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
+                          int L, int ininumdict, uint64_t geom, uint32_t *d_pstart, const uint32_t **d_key_sorted, const uint64_t **d_slot_sorted);
+int mcom_cindex_assemble(mcom_ctx *ctx, const uint32_t *d_key_sorted, const uint64_t *d_slot_sorted, const uint32_t *d_pstart, int L, int ininumdict,
+                         uint64_t geom, uint64_t *d_keys, uint64_t n_words);
 int mcom_dicts_eligible(mcom_ctx *ctx, const mcom_dicts *d, const uint64_t *d_sgbits, int maxsearch, uint32_t *d_elig);
 /* Screen before mcom_dicts_build: *h_may_exceed = 0 proves that no bin of any dictionary over these singletons
  * holds more than maxsearch reads (hashed counters, an upper bound of every bin), so the read-driven pass needs
@@ -370,6 +377,21 @@ int mcom_realign_pass_reads(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t geom
                             const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs,
                             int L, int ininumdict, int thr, uint64_t *d_claim, uint64_t *d_stats);
 
+/* Stage 2 without the table (round 5; csrc/realign.hip, "PARTITION-LOCAL JOIN"): the singletons' keys are sorted by index partition like
+ * the entries (mcom_cindex_partition leaves those as d_ekey / d_eslot / d_epstart) and one workgroup per partition joins the two lists in
+ * LDS; every match is verified as mcom_realign_pass_reads verifies it.  d_claim [n_sg] as there (UINT64_MAX = unclaimed).  A candidate that
+ * fails at `thr` for its distance alone (<= maxthr) is kept as a deferred tuple (16 bytes: claim key; read id | distance << 32 | the two
+ * encode_byte answers) in d_defer [defer_cap]: mcom_realign_deferred is the whole pass at a later threshold -- d_rids / d_sgflag / n_sg: that
+ * pass's singleton list and flags, d_map: scratch of n_reads words.  *h_status = 1: not applicable (a dictionary bin may exceed maxsearch,
+ * a partition holds more queries than LDS takes, more than 2^27 singletons, more deferred tuples than defer_cap) -- nothing of the
+ * output is valid then and the caller builds the table (mcom_cindex_assemble) and runs mcom_realign_pass_reads.  One share only.
+ * Both synchronous.                                                                                                                */
+int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d_ekey, const uint64_t *d_eslot, const uint32_t *d_epstart,
+                      const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_rids, size_t n_sg, const uint64_t *d_cbits,
+                      const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr, int maxthr, int maxsearch,
+                      uint64_t *d_claim, uint64_t *d_stats, uint64_t *d_defer, uint64_t defer_cap, uint64_t *h_n_defer, int *h_status);
+int mcom_realign_deferred(mcom_ctx *ctx, const uint64_t *d_defer, uint64_t n_defer, const uint32_t *d_rids, const uint8_t *d_sgflag, size_t n_sg,
+                          uint32_t *d_map, size_t n_reads, int thr, uint64_t *d_claim, uint64_t *d_stats);
 /* encode_byte (kthread_hash_realign.c:283-314), batched: d_ok[i] = 1 when the run-length mismatch text of read row i
  * (d_rows [n][W], packed) against the L bases of contig d_contig[i] from base d_pos[i] on -- their reverse complement when
  * d_dir[i] != 0, as :446-461 compare a reverse-strand read -- is at most 0.4 L characters long (the match-run counter is not

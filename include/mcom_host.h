@@ -49,6 +49,9 @@ typedef struct {
 	                       beg_pos.bin.T, dir.bin.T, dif_char.txt.T [, ids.bin.T | ids.txt.T, peids.bin.T, file.bin.T], info.txt = "L n_threads"
 	                       (kthread_dump.c:370-379) -- and its decoder takes them in parallel (decompress.c:1248-1300); here the contigs are cut
 	                       into that many runs of about equal member counts.  The `minicom -t N` command line passes N (device encoders only)   */
+	int stage2_table;   /* 1 = Stage 2 through the table of rounds 1-4 (mcom_cindex_place + mcom_realign_pass_reads in every pass) instead of the
+	                       partition-local join of round 5 (mcom_realign_join once, mcom_realign_deferred in the later passes); same claims (A/B
+	                       switch and cross-check; several GPUs and inputs the join does not take use the table by themselves)                */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

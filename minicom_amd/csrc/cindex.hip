@@ -676,33 +676,31 @@ extern "C" int mcom_cindex_entries(mcom_ctx *ctx, const uint64_t *d_cbits, const
 	return MCOM_OK;
 }
 
-// Step 2: this share's table from its n_ent entries (what mcom_cindex_entries made, or what the other ranks sent: any order),
-// sorted by partition in two passes (one when they arrive grouped by the partition's HIGH byte: grouped != 0), then one
-// workgroup per partition.  d_key / d_slot are overwritten; d_key_tmp / d_slot_tmp: scratch of n_ent entries each.
-extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent64, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
-                                 int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words)
+// Step 2a: n_ent entries in any order (grouped = 0) or grouped by the partition's HIGH byte (grouped != 0, what mcom_cindex_entries
+// leaves with one share) -> sorted by partition, in two passes (one when grouped).  d_key / d_slot are overwritten, d_key_tmp / d_slot_tmp
+// are scratch of n_ent entries each; the sorted arrays are one of the two pairs (*d_key_sorted, *d_slot_sorted) and the entries of
+// partition v are [d_pstart[v], d_pstart[v + 1]) (d_pstart: n_parts + 1 words on the device).  Round 5: a step of its own, because the
+// Stage-2 join (realign_join.hip) works on the sorted entries themselves and never needs the table of step 2b.
+extern "C" int mcom_cindex_partition(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent64, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
+                                     int L, int ininumdict, uint64_t geom, uint32_t *d_pstart, const uint32_t **d_key_sorted, const uint64_t **d_slot_sorted)
 {
-	if (!ctx) return MCOM_E_ARG;
+	if (!ctx || !d_key_sorted || !d_slot_sorted) return MCOM_E_ARG;
 	CixGeom g;
 	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
 	cix_unpack(geom, g);
-	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
-	if (!d_keys || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	if (!d_pstart || g.n_parts < 1 || g.n_lines < 1) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
 	if (n_ent64 >= (1ull << 32)) return mcom_fail(ctx, MCOM_E_ARG, "too many contig index entries for one share");
 	if (n_ent64 && (!d_key || !d_slot || !d_key_tmp || !d_slot_tmp)) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const uint32_t n_ent = (uint32_t)n_ent64;
-	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
 	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
-	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
 	const uint32_t nbA = std::max<uint32_t>(1, (uint32_t)(((size_t)n_ent + CX_TILE - 1) / CX_TILE));   // tiles of the flat pass
 	const uint32_t nbR = nbA + 256;                                                                       // at most: every region ends in a short tile
-	const size_t hist_b = cx_al((size_t)256 * nbR * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nbR + 2) * 4 + 1024), tab_b = cx_al(((size_t)g.n_parts + 2) * 4);
+	const size_t hist_b = cx_al((size_t)256 * nbR * 4 + 64), scr_b = cx_al(mcom_scan_scratch_elems((size_t)256 * nbR + 2) * 4 + 1024);
 	char *tmp = nullptr;
-	if (mcom_dmalloc(&tmp, hist_b + scr_b + 2 * tab_b + cx_al(sizeof(CxTiles)) + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
+	if (mcom_dmalloc(&tmp, hist_b + scr_b + cx_al(sizeof(CxTiles)) + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
 	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
-	uint32_t *hist = (uint32_t*)tmp, *scr = (uint32_t*)(tmp + hist_b), *pstart = (uint32_t*)(tmp + hist_b + scr_b);
-	uint8_t *redo = (uint8_t*)(tmp + hist_b + scr_b + tab_b);
-	CxTiles *tiles = (CxTiles*)(tmp + hist_b + scr_b + 2 * tab_b);
+	uint32_t *hist = (uint32_t*)tmp, *scr = (uint32_t*)(tmp + hist_b);
+	CxTiles *tiles = (CxTiles*)(tmp + hist_b + scr_b);
 	const uint32_t *skey = d_key; const uint64_t *sslot = d_slot;                         // the arrays that end up sorted by partition
 	int rc;
 	uint32_t *ik = d_key, *ok = d_key_tmp; uint64_t *is = d_slot, *os = d_slot_tmp;
@@ -726,22 +724,61 @@ extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slo
 		std::swap(ik, ok); std::swap(is, os);
 		skey = ik; sslot = is;
 	}
-	MCOM_LAUNCH(k_cx_pstart, dim3((g.n_parts + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const CxTiles*)tiles, hist, n_ent, g.n_parts, pstart);
+	MCOM_LAUNCH(k_cx_pstart, dim3((g.n_parts + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const CxTiles*)tiles, hist, n_ent, g.n_parts, d_pstart);
 	MCOM_LAUNCH_CHECK(ctx);
+	*d_key_sorted = skey; *d_slot_sorted = sslot;
+	return MCOM_OK;                                                                     // (the guard waits for the stream: the scratch is in use until then)
+}
+
+// Step 2b: the table from entries sorted by partition (step 2a): one workgroup per partition.
+extern "C" int mcom_cindex_assemble(mcom_ctx *ctx, const uint32_t *d_key_sorted, const uint64_t *d_slot_sorted, const uint32_t *d_pstart, int L, int ininumdict,
+                                    uint64_t geom, uint64_t *d_keys, uint64_t n_words)
+{
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	cix_unpack(geom, g);
+	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
+	if (!d_keys || !d_pstart || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	const uint64_t ext_cap = (n_words - CIX_HEAD_WORDS) / 8 - main_lines;
+	McomProfScope ps_(ctx, PROF_CINDEX_BUILD);
+	MCOM_HIP(ctx, hipMemsetAsync(d_keys, 0, CIX_HEAD_WORDS * 8, ctx->stream));
+	uint8_t *redo = nullptr;
+	if (mcom_dmalloc(&redo, (size_t)g.n_parts + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
+	struct Guard { mcom_ctx *c; uint8_t *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, redo};
 	const size_t lds = (size_t)3 * g.n_lines * 4;
 	if (lds > 150 * 1024) return mcom_fail(ctx, MCOM_E_ARG, "contig index: partitions of %u lines", g.n_lines);
 	MCOM_HIP(ctx, hipMemsetAsync(redo, 0, g.n_parts, ctx->stream));
-	MCOM_LAUNCH(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
+	MCOM_LAUNCH(k_cx_assemble_sorted, dim3(g.n_parts), dim3(CS_THREADS), 0, ctx->stream, d_key_sorted, d_slot_sorted, d_pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo,
 	                   ctx->cix_cap_set ? std::min<uint32_t>(ctx->cix_cap, CS_CAP) : (uint32_t)CS_CAP);
 	MCOM_LAUNCH_CHECK(ctx);
 	MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_cx_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	MCOM_LAUNCH(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, skey, sslot, pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
+	MCOM_LAUNCH(k_cx_assemble, dim3(g.n_parts), dim3(CA_THREADS), lds, ctx->stream, d_key_sorted, d_slot_sorted, d_pstart, g.n_parts, g.n_lines, (unsigned long long*)d_keys, ext_cap, redo);
 	MCOM_LAUNCH_CHECK(ctx);
 	uint64_t used = 0;
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &used, d_keys, 8));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	if (used > ext_cap) return mcom_fail(ctx, MCOM_E_OVERFLOW, "contig index: %llu extension lines needed, room for %llu", (unsigned long long)used, (unsigned long long)ext_cap);
 	return MCOM_OK;
+}
+
+// Step 2 = 2a + 2b: this share's table from its n_ent entries (what mcom_cindex_entries made, or what the other ranks sent: any order).
+extern "C" int mcom_cindex_place(mcom_ctx *ctx, uint32_t *d_key, uint64_t *d_slot, uint64_t n_ent64, int grouped, uint32_t *d_key_tmp, uint64_t *d_slot_tmp,
+                                 int L, int ininumdict, uint64_t geom, uint64_t *d_keys, uint64_t n_words)
+{
+	if (!ctx) return MCOM_E_ARG;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	cix_unpack(geom, g);
+	const uint64_t main_lines = (uint64_t)g.n_parts * g.n_lines;
+	if (!d_keys || g.n_parts < 1 || g.n_lines < 1 || n_words < CIX_HEAD_WORDS + 8 * (main_lines + 1)) return mcom_fail(ctx, MCOM_E_ARG, "bad contig index buffers");
+	uint32_t *pstart = nullptr;
+	if (mcom_dmalloc(&pstart, ((size_t)g.n_parts + 2) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "contig index: scratch");
+	struct Guard { mcom_ctx *c; uint32_t *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, pstart};
+	const uint32_t *skey = nullptr; const uint64_t *sslot = nullptr;
+	int rc = mcom_cindex_partition(ctx, d_key, d_slot, n_ent64, grouped, d_key_tmp, d_slot_tmp, L, ininumdict, geom, pstart, &skey, &sslot);
+	if (rc) return rc;
+	return mcom_cindex_assemble(ctx, skey, sslot, pstart, L, ininumdict, geom, d_keys, n_words);
 }
 
 // both steps for one GPU: 24 bytes per entry of temporaries from the library's block pool

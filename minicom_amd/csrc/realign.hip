@@ -921,3 +921,292 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 	const int rc = mcom_dicts_screen_begin(ctx, d_sgbits, n_sg, L, ininumdict, maxsearch);
 	return rc ? rc : mcom_dicts_screen_end(ctx, h_may_exceed);
 }
+
+// ====================================================================================================================================
+// Round 5: Stage 2 as a PARTITION-LOCAL JOIN -- no table, no random line in HBM.
+//
+// mcom_realign_pass_reads sends 193 M lookups (100 M x 150 bp, first pass) into a 16.8 GB table: random 64-byte lines at 13 G lines/s,
+// two thirds of what the card delivers for that pattern over that footprint (address translation: tools/ubench/random_lines.hip).  The
+// entries of that table are already SORTED BY PARTITION when mcom_cindex_place starts placing them (mcom_cindex_partition), and a key's
+// partition is a function of the key alone.  So the singletons' keys are sorted the same way -- { partition | home bits, tag | singleton |
+// lane } tuples through the same two radix passes -- and a workgroup per partition joins the two lists in LDS: the partition's few
+// thousand queries go into an LDS hash table keyed by the 28 bits (home bits, tag) the index would have compared, the partition's
+// ~12 k entries stream past it, and every match is a candidate that is verified exactly as k_realign_reads verifies it (window, distance,
+// the exact key, the "a lower dictionary sees the same window" rule, encode_byte).  What moves through HBM is streams (entries 12 bytes
+// each, queries 12 bytes each, twice for their two passes) plus the verification's gathers, which the table design pays as well.
+//
+// Three things the table design did beside the lookups come for free here:
+//   * the placement of the entries into the table (k_cx_assemble_sorted: 5 ms, 16.8 GB) is not needed;
+//   * the dictionary screen (k_bin_screen: 4.8 ms of random atomics) -- "does any (dictionary, key) bin hold more than maxsearch
+//     singletons" -- is answered inside the join: the queries of one bin sit in one partition's LDS table, a query counts the queries with
+//     its own (home bits, tag, lane) there, an upper bound of its bin (two keys may share the 28 bits).  A count above maxsearch, a
+//     partition with more queries than the LDS table takes, or more singletons than the tuple format numbers: *h_status = 1 and the caller
+//     builds the table after all (mcom_cindex_assemble from the same sorted entries) and runs the passes as before;
+//   * the LATER PASSES (preprocess.c:197-232: thr = e, e + S, ...) need no second look at the index: a (singleton, contig window) pair's
+//     test depends on the threshold only through "distance <= thr" and the rule about which encode_byte tests apply (:393, :461), so the
+//     first pass keeps every candidate that fails only for its distance (<= maxthr) as a DEFERRED tuple { claim key, read id, distance,
+//     the two encode_byte answers }, and a later pass is a kernel over those tuples (mcom_realign_deferred) -- a few million at most:
+//     a 17-mer hit that is not at the read's true place has a distance around 0.75 L, far above maxthr = L / 2.
+// Same claims as mcom_realign_pass_reads, pass by pass (tests/test_gpu_realign.py compares the two on the reference's fixtures and on
+// sets with repeats; the pipeline tests compare whole runs with the reference's dumps and the oracle).
+// ====================================================================================================================================
+#define RJ_THREADS 1024
+// LDS hash slots of a partition's queries: 2^LS of key + value (64 KB at LS = 13, 128 KB at 14: the host picks by the mean number of
+// queries per partition); the table takes 0.69 of them
+#define RJ_QUEUE 2048                       // candidates waiting for their verification
+#define RJ_EMPTY 0xFFFFFFFFu
+
+// the queries: one tuple per (singleton, lane) with a lane for every (direction, dictionary) the scan asks (kthread_hash_realign.c:440:
+// not the reverse direction of a dictionary that starts at base 0), flagged singletons included (they count in the bins)
+__global__ void k_rj_queries(CixGeom g, const uint64_t *__restrict__ sgbits, size_t n_sg, int W, uint32_t lane_mask, int n_lanes, int lg_lanes,
+                             uint32_t *__restrict__ qkey, uint64_t *__restrict__ qslot)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t sg = t >> lg_lanes;
+	const int q = (int)(t & ((1u << lg_lanes) - 1u));
+	if (sg >= n_sg || !((lane_mask >> q) & 1u)) return;
+	const int dir = q / g.nd, l = q - dir * g.nd;
+	const uint64_t *rb = sgbits + sg * (size_t)W;
+	uint64_t key = bits_key(rb, g.ds[l], g.klen);
+	const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
+	if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
+	uint32_t own, part, h16;
+	cix_hash(key, 1u, g.n_parts, own, part, h16);
+	const size_t at = sg * (size_t)n_lanes + (size_t)__popc(lane_mask & ((1u << q) - 1u));
+	qkey[at] = (part << 16) | h16;
+	qslot[at] = (cix_tag(key) << CIX_TAG_SHIFT) | ((uint64_t)sg << 5) | (uint64_t)q;
+}
+
+template <int LS> __device__ __forceinline__ uint32_t rj_hash(uint32_t kid) { return (kid * 0x9E3779B1u) >> (32 - LS); }
+
+// One workgroup per partition.  defer: { claim key, read id | distance << 32 | encode_byte forward ok << 40 | reverse ok << 41 }
+template <int W, int LS>
+__global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_t *__restrict__ ekey, const unsigned long long *__restrict__ eslot,
+                                                        const uint32_t *__restrict__ epstart, const uint32_t *__restrict__ qkey,
+                                                        const unsigned long long *__restrict__ qslot, const uint32_t *__restrict__ qpstart,
+                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag, const uint32_t *__restrict__ rids,
+                                                        const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
+                                                        int thr, int maxthr, uint32_t maxsearch, unsigned long long *__restrict__ claim,
+                                                        unsigned long long *__restrict__ stats, ulonglong2 *__restrict__ defer, unsigned long long defer_cap,
+                                                        unsigned long long *__restrict__ defer_count, unsigned int *__restrict__ status)
+{
+	constexpr uint32_t RJ_SLOTS = 1u << LS, RJ_QMAX = (RJ_SLOTS / 16) * 11;
+	__shared__ uint32_t K[RJ_SLOTS], V[RJ_SLOTS];
+	__shared__ unsigned long long QC[RJ_QUEUE];
+	__shared__ uint32_t QV[RJ_QUEUE];
+	__shared__ uint32_t q_n;
+	const uint32_t part = blockIdx.x;
+	const uint32_t q0 = qpstart[part], nq = qpstart[part + 1] - q0;
+	const uint32_t e0 = epstart[part], ne = epstart[part + 1] - e0;
+	const int tid = threadIdx.x;
+	if (nq == 0) return;                                                          // nobody asks for a key of this partition
+	if (nq > RJ_QMAX) { if (tid == 0) *status = 1u; return; }
+	for (uint32_t i = tid; i < RJ_SLOTS; i += RJ_THREADS) K[i] = RJ_EMPTY;
+	if (tid == 0) q_n = 0;
+	__syncthreads();
+	uint32_t n_look = 0, n_cand = 0, n_pass = 0;
+	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
+		const uint32_t k32 = qkey[q0 + i];
+		const unsigned long long sl = qslot[q0 + i];
+		const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(sl >> CIX_TAG_SHIFT);
+		uint32_t h = rj_hash<LS>(kid);
+		while (atomicCAS(&K[h], RJ_EMPTY, kid) != RJ_EMPTY) h = (h + 1) & (RJ_SLOTS - 1);
+		V[h] = (uint32_t)sl;                                                         // singleton << 5 | lane
+	}
+	__syncthreads();
+	// the screen: a forward query counts the queries of its own (28 bits, lane) -- at least its bin of dictionary l
+	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
+		const uint32_t k32 = qkey[q0 + i];
+		const unsigned long long sl = qslot[q0 + i];
+		const uint32_t code = (uint32_t)sl & 31u;
+		if ((int)code >= g.nd) continue;
+		const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(sl >> CIX_TAG_SHIFT);
+		uint32_t same = 0;
+		for (uint32_t h = rj_hash<LS>(kid); K[h] != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) same += (K[h] == kid && (V[h] & 31u) == code);
+		if (same > maxsearch) *status = 1u;
+		n_look += sgflag[(uint32_t)sl >> 5] ? 0u : 1u;
+	}
+	// reverse lanes count as lookups too (statistics)
+	for (uint32_t i = tid; i < nq; i += RJ_THREADS) { const unsigned long long sl = qslot[q0 + i]; if ((int)((uint32_t)sl & 31u) >= g.nd && !sgflag[(uint32_t)sl >> 5]) ++n_look; }
+	const int L = g.L;
+
+	auto verify = [&](unsigned long long v, uint32_t qv) {
+		const uint32_t sg = qv >> 5;
+		const int q = (int)(qv & 31u);
+		if (sgflag[sg]) return;
+		const int dir = q / g.nd, l = q - dir * g.nd;
+		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
+		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
+		const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
+		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
+		++n_cand;
+		uint64_t win[W], x[W];
+		const uint64_t *rb = sgbits + (size_t)sg * W;
+		contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
+		int dist = 0;
+#pragma unroll
+		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ rb[w]; dist += __popcll(x[w]); }
+		if (dist > maxthr || bits_key(x, g.ds[l], g.klen) != 0) return;                      // a tag is not the key: exact check here
+		for (int l2 = 0; l2 < l; ++l2)
+			if ((!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;         // a lower dictionary claims the same tuple with a smaller key
+		uint64_t mm[W];
+#pragma unroll
+		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
+		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+		if (dist <= thr) {
+			if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) return; }                          // :393
+			else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) return;                       // :461
+			++n_pass;
+			atomicMin(&claim[sg], ck);
+			return;
+		}
+		// fails for its distance alone at this threshold: a later pass decides (the read may be claimed or flagged by then)
+		const bool okf = !dir ? encode_ok_sparse<W>(mm, L, false) : true;
+		const bool okr = dir ? encode_ok_sparse<W>(mm, L, true) : true;
+		if (!dir && !okf) return;                                                            // (the forward test does not depend on the threshold)
+		const unsigned long long at = atomicAdd(defer_count, 1ull);
+		if (at < defer_cap) defer[at] = make_ulonglong2(ck, (unsigned long long)rids[sg] | ((unsigned long long)dist << 32) | ((unsigned long long)okf << 40) | ((unsigned long long)okr << 41));
+	};
+	auto drain = [&]() {
+		__syncthreads();
+		const uint32_t n = q_n < RJ_QUEUE ? q_n : RJ_QUEUE;
+		for (uint32_t c = tid; c < n; c += RJ_THREADS) verify(QC[c], QV[c]);
+		__syncthreads();
+		if (tid == 0) q_n = 0;
+		__syncthreads();
+	};
+	for (uint32_t base = 0; base < ne; base += RJ_THREADS) {
+		const uint32_t i = base + tid;
+		if (i < ne) {
+			const uint32_t k32 = ekey[e0 + i];
+			const unsigned long long v = eslot[e0 + i];
+			const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(v >> CIX_TAG_SHIFT);
+			for (uint32_t h = rj_hash<LS>(kid), kk; (kk = K[h]) != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) {
+				if (kk != kid) continue;
+				const uint32_t pos = atomicAdd(&q_n, 1u);
+				if (pos < RJ_QUEUE) { QC[pos] = v; QV[pos] = V[h]; }
+				else verify(v, V[h]);                                                        // (the queue is full: verified where it was found)
+			}
+		}
+		__syncthreads();
+		if (q_n >= RJ_QUEUE - RJ_THREADS) drain();                                           // (uniform: q_n is read between two barriers)
+		else __syncthreads();
+	}
+	drain();
+	if (stats) {
+		__shared__ unsigned long long st3[3];
+		if (tid < 3) st3[tid] = 0;
+		__syncthreads();
+		unsigned long long a = n_look, b = n_cand, c = n_pass;
+		for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+		if ((tid & 63) == 0) { atomicAdd(&st3[0], a); atomicAdd(&st3[1], b); atomicAdd(&st3[2], c); }
+		__syncthreads();
+		if (tid < 3 && st3[tid]) atomicAdd(&stats[4 * (blockIdx.x & 1023) + tid], st3[tid]);
+	}
+}
+
+__global__ void k_rj_map(const uint32_t *__restrict__ rids, size_t n, uint32_t *__restrict__ map)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) map[rids[i]] = (uint32_t)i;
+}
+__global__ void k_rj_deferred(const ulonglong2 *__restrict__ defer, size_t n, const uint32_t *__restrict__ map, const uint8_t *__restrict__ sgflag, int thr,
+                              unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long np = 0;
+	if (t < n) {
+		const ulonglong2 d = defer[t];
+		const uint32_t cur = map[(uint32_t)d.y];
+		const int dist = (int)((d.y >> 32) & 0xFFull);
+		const bool dir = (d.x >> 4) & 1ull;
+		if (cur != 0xFFFFFFFFu && !sgflag[cur] && dist <= thr && (!dir || thr <= 24 || ((d.y >> 41) & 1ull))) { atomicMin(&claim[cur], d.x); np = 1; }
+	}
+	for (int o = 32; o; o >>= 1) np += __shfl_xor(np, o);
+	if (stats && (threadIdx.x & 63) == 0 && np) atomicAdd(&stats[2], np);
+}
+
+extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d_ekey, const uint64_t *d_eslot, const uint32_t *d_epstart,
+                                 const uint64_t *d_sgbits, const uint8_t *d_sgflag, const uint32_t *d_rids, size_t n_sg, const uint64_t *d_cbits,
+                                 const uint64_t *d_coff, const uint64_t *d_woff, uint32_t n_contigs, int L, int ininumdict, int thr, int maxthr, int maxsearch,
+                                 uint64_t *d_claim, uint64_t *d_stats, uint64_t *d_defer, uint64_t defer_cap, uint64_t *h_n_defer, int *h_status)
+{
+	if (!ctx || !h_n_defer || !h_status) return MCOM_E_ARG;
+	*h_n_defer = 0; *h_status = 0;
+	CixGeom g;
+	if (L < 1 || L > 256 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad dictionary layout");
+	cix_unpack(geom, g);
+	g.pbits = cix_pbits(n_contigs);
+	if (g.n_owners != 1) return mcom_fail(ctx, MCOM_E_ARG, "the join works on a whole index: one share");
+	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
+	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+	if (n_contigs == 0 || n_sg == 0) return MCOM_OK;
+	if (!d_ekey || !d_eslot || !d_epstart || !d_sgbits || !d_sgflag || !d_rids || !d_cbits || !d_coff || !d_woff || !d_claim || (defer_cap && !d_defer) || maxsearch < 1 || maxthr < thr || maxthr > 255)
+		return mcom_fail(ctx, MCOM_E_ARG, "bad join arguments");
+	if (n_sg >= (1ull << 27) || 2 * g.nd > 32) { *h_status = 1; return MCOM_OK; }                  // (the tuple holds singleton << 5 | lane in 32 bits)
+	const int W = mcom_words_per_read(L);
+	uint32_t lane_mask = 0; int n_lanes = 0;
+	for (int q = 0; q < 2 * g.nd; ++q) { const int dir = q / g.nd, l = q - dir * g.nd; if (!(dir && g.ds[l] <= 0)) { lane_mask |= 1u << q; ++n_lanes; } }
+	const uint64_t nq = (uint64_t)n_sg * (uint64_t)n_lanes;
+	if (nq >= (1ull << 32)) { *h_status = 1; return MCOM_OK; }
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const size_t key_b = al((size_t)nq * 4 + 4), slot_b = al((size_t)nq * 8 + 8), ps_b = al(((size_t)g.n_parts + 2) * 4);
+	char *tmp = nullptr;
+	if (mcom_dmalloc(&tmp, 2 * key_b + 2 * slot_b + ps_b + 4096 * 8 + 512) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "join: %zu bytes of query tuples", 2 * key_b + 2 * slot_b);
+	struct Guard { mcom_ctx *c; char *p; ~Guard() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } guard{ctx, tmp};
+	uint32_t *qkA = (uint32_t*)tmp, *qkB = (uint32_t*)(tmp + key_b);
+	uint64_t *qsA = (uint64_t*)(tmp + 2 * key_b), *qsB = (uint64_t*)(tmp + 2 * key_b + slot_b);
+	uint32_t *qps = (uint32_t*)(tmp + 2 * key_b + 2 * slot_b);
+	unsigned long long *sets = (unsigned long long*)(tmp + 2 * key_b + 2 * slot_b + ps_b);          // 1024 x 4 statistics words, then the deferred count and the status
+	unsigned long long *d_cnt = sets + 4096;
+	unsigned int *d_status = (unsigned int*)(d_cnt + 1);
+	MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 4096 * 8 + 16, ctx->stream));
+	{
+		const int lg_lanes = 2 * g.nd <= 16 ? 4 : 5;
+		const uint64_t blocks = ((n_sg << lg_lanes) + 255) / 256;
+		if (blocks >= (1ull << 31)) { *h_status = 1; return MCOM_OK; }
+		McomProfScope ps_(ctx, PROF_REALIGN_READS);
+		MCOM_LAUNCH(k_rj_queries, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g, d_sgbits, n_sg, W, lane_mask, n_lanes, lg_lanes, qkA, qsA);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	const uint32_t *qk = nullptr; const uint64_t *qs = nullptr;
+	int rc = mcom_cindex_partition(ctx, qkA, qsA, nq, 0, qkB, qsB, L, ininumdict, geom, qps, &qk, &qs);
+	if (rc) return rc;
+	{
+		McomProfScope ps_(ctx, PROF_REALIGN_READS);
+		const bool wide = nq / g.n_parts + 1 > 4600;                                      // (mean queries per partition: the small table takes 5632)
+#define MCOM_RJ_ARGS g, d_ekey, (const unsigned long long*)d_eslot, d_epstart, qk, (const unsigned long long*)qs, (const uint32_t*)qps, d_sgbits, d_sgflag, d_rids, d_cbits, d_coff, d_woff, \
+		thr, maxthr, (uint32_t)maxsearch, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt, d_status
+#define MCOM_CASE(WW) case WW: if (wide) MCOM_LAUNCH((k_rj_join<WW, 14>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS); \
+		else MCOM_LAUNCH((k_rj_join<WW, 13>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS); break;
+		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+		default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_CASE
+#undef MCOM_RJ_ARGS
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	if (d_stats) MCOM_LAUNCH(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
+	unsigned long long hc[2] = {0, 0};
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hc, d_cnt, 16));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	*h_n_defer = hc[0];
+	*h_status = (unsigned int)(hc[1] & 0xFFFFFFFFull) ? 1 : 0;
+	if (hc[0] > defer_cap) *h_status = 1;                                                           // (more deferred candidates than the caller has room for)
+	return MCOM_OK;
+}
+
+extern "C" int mcom_realign_deferred(mcom_ctx *ctx, const uint64_t *d_defer, uint64_t n_defer, const uint32_t *d_rids, const uint8_t *d_sgflag, size_t n_sg,
+                                     uint32_t *d_map, size_t n_reads, int thr, uint64_t *d_claim, uint64_t *d_stats)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_sg) MCOM_HIP(ctx, hipMemsetAsync(d_claim, 0xFF, n_sg * 8, ctx->stream));
+	if (d_stats) MCOM_HIP(ctx, hipMemsetAsync(d_stats, 0, 3 * 8, ctx->stream));
+	if (n_sg == 0 || n_defer == 0) return MCOM_OK;
+	if (!d_defer || !d_rids || !d_sgflag || !d_map || !d_claim) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	MCOM_HIP(ctx, hipMemsetAsync(d_map, 0xFF, n_reads * 4, ctx->stream));
+	MCOM_LAUNCH(k_rj_map, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_rids, n_sg, d_map);
+	MCOM_LAUNCH(k_rj_deferred, dim3((unsigned)((n_defer + 255) / 256)), dim3(256), 0, ctx->stream, (const ulonglong2*)d_defer, (size_t)n_defer, (const uint32_t*)d_map, d_sgflag, thr,
+	            (unsigned long long*)d_claim, (unsigned long long*)d_stats);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}

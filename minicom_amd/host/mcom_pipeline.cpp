@@ -300,6 +300,12 @@ struct mcomh_pipeline {
 	bool host_dump = false;                                           // true: cluster_dump's default mode on the host, as the -p / paired-end modes (A/B switch)
 	int window_scan = 0;                                              // 1: window-driven kernel (mcom_realign_pass) instead
 	bool stage2_uploaded = false;
+	// Stage 2 as a partition-local join (round 5, csrc/realign.hip): the index entries sorted by partition, kept until the first pass has
+	// joined them with the singletons' keys (jn_entries); what that pass defers is all the later passes need (jn_deferred)
+	bool stage2_table = false;                                         // true: the table of rounds 1-4 in every pass (A/B switch)
+	DevBuf<uint32_t> jn_keyA, jn_keyB, jn_pstart, jn_map; DevBuf<uint64_t> jn_slotA, jn_slotB, jn_defer;
+	const uint32_t *jn_ek = nullptr; const uint64_t *jn_es = nullptr;
+	bool jn_entries = false, jn_deferred = false; uint64_t jn_ndefer = 0, jn_nwords = 0;
 	bool screen_clear = false;                                             // a pass of this Stage 2 proved that no dictionary bin exceeds maxsearch
 	std::map<std::string, double> stat;
 	// multi-GPU (include/mcom_host.h, mcomh_create_dist): this rank holds reads [rid0, rid0 + n_local) of n; packed rows,
@@ -480,6 +486,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->host_dump = pp->host_dump == 1;
 	p->stream_sets = pp->stream_sets > 1 ? std::min(pp->stream_sets, 4096) : 1;
 	p->overlap_screen = pp->overlap_screen == 1;
+	p->stage2_table = pp->stage2_table == 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcomh_destroy(p); return MCOM_E_ARG; }
@@ -1840,9 +1847,11 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 			if (mcom_cindex_plan_shared(p->n_windows, (uint32_t)nc, p->L, p->numdict, R, me, &ne, &share, &p->cix_geom, &nwords) ||
 			    mcom_cindex_plan(nwin_mine, c1 - c0, p->L, p->numdict, &cap_mine, nullptr, nullptr)) return p->fail(MCOM_E_ARG, "contig index: %llu windows are more than one share of %d holds (2^32 positions, or 65 535 partitions of 12 000 lines = 2.75 G entries)", (unsigned long long)p->n_windows, R);
 			DevBuf<uint32_t> keyA, keyB; DevBuf<uint64_t> slotA, slotB;
+			const bool use_join = R == 1 && !p->stage2_table && p->maxthr <= 255;
+			p->jn_entries = false; p->jn_deferred = false; p->jn_ndefer = 0;
 			std::vector<uint64_t> cnt((size_t)R, 0);
 			for (int attempt = 0;; ++attempt) {                                 // a repeat-rich set may need a larger extension area for its heavy keys
-				if (!p->d_cix_keys.reserve(nwords) || !keyA.reserve(cap_mine + 1) || !slotA.reserve(cap_mine + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
+				if ((!use_join && !p->d_cix_keys.reserve(nwords)) || !keyA.reserve(cap_mine + 1) || !slotA.reserve(cap_mine + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 				if ((rc = p->gpu(mcom_cindex_entries(p->ctx, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, c0, c1, p->L, p->numdict, p->cix_geom,
 				                                     keyA.p, slotA.p, cap_mine + 1, cnt.data())))) return rc;
 				uint64_t n_ent = cnt[0];
@@ -1861,6 +1870,12 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 					if (!keyA.reserve(b + 1) || !slotA.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 					n_ent = b;
 					rc = mcom_cindex_place(p->ctx, keyB.p, slotB.p, n_ent, 0, keyA.p, slotA.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);
+				} else if (use_join) {
+					// one GPU (round 5): the entries are sorted by partition and kept; the first pass joins them with the singletons' keys and no
+					// table is placed (the pass builds it from these arrays after all when the join does not take the input)
+					if (!keyB.reserve(n_ent + 1) || !slotB.reserve(n_ent + 1) || !p->jn_pstart.reserve((size_t)(p->cix_geom & 0xFFFFu) + 2)) return p->fail(MCOM_E_NOMEM, "contig index");
+					rc = mcom_cindex_partition(p->ctx, keyA.p, slotA.p, n_ent, 1, keyB.p, slotB.p, p->L, p->numdict, p->cix_geom, p->jn_pstart.p, &p->jn_ek, &p->jn_es);
+					if (!rc) { p->jn_keyA.swap(keyA); p->jn_keyB.swap(keyB); p->jn_slotA.swap(slotA); p->jn_slotB.swap(slotB); p->jn_entries = true; p->jn_nwords = nwords; }
 				} else {
 					if (!keyB.reserve(n_ent + 1) || !slotB.reserve(n_ent + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 					rc = mcom_cindex_place(p->ctx, keyA.p, slotA.p, n_ent, 1, keyB.p, slotB.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);
@@ -1875,7 +1890,7 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 				nwords += std::max<uint64_t>(nwords / 4, 8 * (share / 7 + 1024) / (attempt < 2 ? 4 : 1));
 				p->stat["cix_rebuilds"] += 1;
 			}
-			p->stat["cix_slots"] += (double)nwords;
+			if (!p->jn_entries) p->stat["cix_slots"] += (double)nwords;
 		}
 		p->stage2_uploaded = true;
 	}
@@ -1909,9 +1924,50 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 		mcom_dicts *dicts = nullptr;
 		bool big = false;
 		int may_exceed = 1;
+		DevBuf<uint64_t> d_st;
+		if (!d_st.reserve(4)) return p->fail(MCOM_E_NOMEM, "pass counters");
+		bool joined = false;                                                                 // this pass's claims are made (join or deferred tuples)
+		if (p->jn_entries) {
+			// the first pass of a Stage 2 on one GPU: partition-local join of the sorted index entries with the singletons' keys
+			const uint64_t dcap = std::max<uint64_t>((uint64_t)1 << 20, n_sg / 2);
+			int status = 1; uint64_t nd_ = 0;
+			if (!p->jn_defer.reserve(2 * dcap + 2)) return p->fail(MCOM_E_NOMEM, "deferred candidates");
+			if ((rc = p->gpu(mcom_realign_join(p->ctx, p->cix_geom, p->jn_ek, p->jn_es, p->jn_pstart.p, d_sgbits.p, d_flag.p, d_sg.p, n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p,
+			                                   (uint32_t)nc, p->L, p->numdict, thr, p->maxthr, p->maxsearch, d_claim.p, d_st.p, p->jn_defer.p, dcap, &nd_, &status)))) return rc;
+			if (!status) {
+				joined = true; p->jn_deferred = true; p->jn_ndefer = nd_; p->screen_clear = true;
+				p->stat["join_passes"] += 1; p->stat["join_deferred"] += (double)nd_;
+			} else {
+				// not for the join (a dictionary bin may exceed maxsearch, a partition too full for LDS ...): the table from the same entries
+				p->stat["join_fallbacks"] += 1;
+				uint64_t nwords = p->jn_nwords;
+				for (int attempt = 0;; ++attempt) {
+					if (!p->d_cix_keys.reserve(nwords)) return p->fail(MCOM_E_NOMEM, "contig index");
+					rc = mcom_cindex_assemble(p->ctx, p->jn_ek, p->jn_es, p->jn_pstart.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);
+					if (rc != MCOM_E_OVERFLOW) break;
+					if (attempt == 3) return p->fail(MCOM_E_OVERFLOW, "contig index: the extension area stays too small");
+					nwords += std::max<uint64_t>(nwords / 4, 1 << 16);
+					p->stat["cix_rebuilds"] += 1;
+				}
+				if (rc) return p->gpu(rc);
+				p->stat["cix_slots"] += (double)nwords;
+			}
+			p->jn_entries = false;                                                            // either way the sorted entries have done their work
+			{ DevBuf<uint32_t> a, b; DevBuf<uint64_t> c, d; a.swap(p->jn_keyA); b.swap(p->jn_keyB); c.swap(p->jn_slotA); d.swap(p->jn_slotB); }
+			p->jn_ek = nullptr; p->jn_es = nullptr;
+		} else if (p->jn_deferred) {
+			// a later pass: every candidate that can pass at this threshold was kept by the first pass
+			if (!p->jn_map.reserve(p->n + 1)) return p->fail(MCOM_E_NOMEM, "read map");
+			if ((rc = p->gpu(mcom_realign_deferred(p->ctx, p->jn_defer.p, p->jn_ndefer, d_sg.p, d_flag.p, n_sg, p->jn_map.p, p->n, thr, d_claim.p, d_st.p)))) return rc;
+			joined = true;
+			p->stat["join_passes"] += 1;
+		}
+		if (joined) may_exceed = 0;
 		// (singletons only leave between the passes of one Stage 2, so a bin never grows: once the screen has proved that none
 		// exceeds maxsearch, it holds for the later passes too)
-		if (early) {
+		if (joined) {
+			if (early) { p->early.on = false; int dummy = 0; (void)mcom_dicts_screen_end(p->ctx2, &dummy); }
+		} else if (early) {
 			p->early.on = false;
 			if ((rc = mcom_dicts_screen_end(p->ctx2, &may_exceed))) return p->fail(rc, "%s", mcom_last_error(p->ctx2));
 		} else if (p->screen_clear) may_exceed = 0;
@@ -1934,10 +1990,9 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 			rc = p->gpu(mcom_realign_pass(p->ctx, dicts, d_sgbits.p, d_flag.p, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc,
 			                              p->n_windows, thr, p->maxsearch, d_claim.p, nullptr));
 		else {
-			DevBuf<uint64_t> d_st;
 			rc = MCOM_OK;
-			if (!d_st.reserve(4)) rc = p->fail(MCOM_E_NOMEM, "pass counters");
-			if (!rc && !big)
+			if (joined) {}
+			else if (!rc && !big)
 				rc = p->gpu(mcom_realign_pass_reads(p->ctx, p->d_cix_keys.p, p->cix_geom, d_sgbits.p, d_flag.p, nullptr,
 				                                    n_sg, p->d_cbits.p, p->d_coff_words.p, p->d_woff.p, (uint32_t)nc, p->L, p->numdict, thr, d_claim.p, d_st.p));
 			else if (!rc)

@@ -224,3 +224,28 @@ def test_packed_rows_with_forwarded_minimizers_equal_resketching():
     assert all(r0 == r1 and np.array_equal(m0, m1) for (r0, m0), (r1, m1) in zip(ca, cb))
     assert np.array_equal(a.id_list("sg"), b.id_list("sg"))
     a.close(); b.close(); ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform_150", "uniform_100", "repeats"])
+def test_stage2_join_equals_stage2_through_the_table(kind):
+    """Round 5: Stage 2 on one GPU is a partition-local join of the index entries with the singletons' keys (no table; later passes
+    from the candidates the first pass deferred) -- csrc/realign.hip, mcom_realign_join / mcom_realign_deferred.  stage2_table = 1
+    runs realign_hash_search's lookups through the table of rounds 1-4 in every pass (kthread_hash_realign.c:316-508 either way): the
+    whole result must be the same, pass for pass (the digest covers strings, member lists in appending order, offsets and lists).
+    Repeat-rich reads have dictionary bins above maxsearch: there the join steps back by itself and builds the table."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    if kind == "repeats":
+        reads = synth.repeat_rich_reads(400_000, 100, 0.02)
+    else:
+        L = int(kind.split("_")[1])
+        reads = np.concatenate([synth.synth_reads(311, 1_500_000, L, sub_rate=0.02), synth.synth_reads(312, 4000, L, plumbing=True)])
+    a = Pipeline(reads, host_threads=4); a.pre_process()
+    b = Pipeline(reads, host_threads=4, stage2_table=1); b.pre_process()
+    assert a.result_digest() == b.result_digest()
+    assert b.stat("join_passes") == 0 and a.stat("passes") == b.stat("passes") >= 2
+    if kind == "repeats":
+        assert a.stat("join_fallbacks") >= 1 and a.stat("big_bins") > 0
+    else:
+        assert a.stat("join_fallbacks") == 0 and a.stat("join_passes") == a.stat("passes") and a.stat("join_deferred") > 0
+    a.close(); b.close()
