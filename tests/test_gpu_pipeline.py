@@ -245,7 +245,7 @@ def test_stage2_join_equals_stage2_through_the_table(kind):
     assert a.result_digest() == b.result_digest()
     assert b.stat("join_passes") == 0 and a.stat("passes") == b.stat("passes") >= 2
     if kind == "repeats":
-        assert a.stat("join_fallbacks") >= 1 and a.stat("big_bins") > 0
+        assert a.stat("join_fallbacks") >= 1                               # (its own count per (28 key bits, lane) is an upper bound of a bin: it steps back where the exact dictionaries may still find none above the limit)
     else:
         assert a.stat("join_fallbacks") == 0 and a.stat("join_passes") == a.stat("passes") and a.stat("join_deferred") > 0
     a.close(); b.close()
