@@ -74,8 +74,8 @@ def cpu_baseline(L, sample):
             "sample": f"{sample} reads x {L} bp, same generator; oracle/mcom_oracle.c, one thread", "seconds": round(dt, 3), "variants_that_failed": tried or None}
 
 
-CINDEX_NOTE = ("model 'passes': the bytes this radix-partitioned build moves by design (streaming passes over the entries + one placement pass per partition: "
-               "cindex_bytes() in this file, DESIGN.md section 3); two launches per build (entries, placement: the multi-GPU exchange sits between them)")
+CINDEX_NOTE = ("model 'passes': the bytes the radix partitioning moves by design (two streaming passes over the index entries; round 5 on one GPU: no placement, "
+               "the singletons' query tuples through the same two passes instead -- cindex_bytes() in this file, DESIGN.md section 3)")
 KERNELS = ("classify_pack", "sketch_reads", "radix_pass", "sketch_contigs", "find_next", "dict_build", "realign_windows", "consensus",
            "cindex_build", "realign_reads")
 
@@ -89,7 +89,13 @@ def algorithmic_bytes(name, st, L, nd):
         return (8 * W + 16) * (st["n"] + st["resketch"])
     if name == "classify_pack":        # ASCII in, packed row + class + N count out
         return (L + 8 * W + 3) * st["n"]
-    if name == "realign_reads":        # per lookup one 64-B line of keys; per verified window value + offsets + packed window; per singleton row, flag, claim
+    if name == "realign_reads":
+        if st.get("join_passes", 0) and not st.get("join_fallbacks", 0):
+            # round 5, the partition-local join (k_rj_queries + k_rj_join): per singleton its row in and its claim out; per query a 12-byte
+            # tuple out and, sorted, in again; the index entries streamed once (12 bytes each); per verified candidate the singleton's row, the
+            # contig window and the offsets around it
+            return (8 * W + 9) * st["ra_singletons"] + 24 * st["ra_lookups"] + 12 * st.get("cix_entries", 0) + (24 + 8 * W + 8 * (W + 1)) * st["ra_verified"]
+        # per lookup one 64-B line of keys; per verified window value + offsets + packed window; per singleton row, flag, claim
         return 64 * st["ra_lookups"] + (8 + 24 + 8 * (W + 1)) * st["ra_verified"] + (8 * W + 9) * st["ra_singletons"]
     if name == "cindex_build":
         return cindex_bytes(st)
@@ -102,7 +108,12 @@ def cindex_bytes(st):
     """The contig 17-mer index of Stage 2 (csrc/cindex.hip), model "passes": what THIS build moves by design.  Per entry (12 bytes:
     4 of partition + home bits, 8 of slot): written by pass 1, read twice (histogram: the 4-byte half only) and written by pass 2,
     read by the placement (its second read comes from L2); plus the table, written once."""
-    return (12 + 4 + 12 + 12 + 12) * st.get("cix_entries", 0) + 8 * st.get("cix_slots", 0)
+    b = (12 + 4 + 12 + 12) * st.get("cix_entries", 0)
+    if st.get("cix_slots", 0):
+        b += 12 * st.get("cix_entries", 0) + 8 * st.get("cix_slots", 0)      # the placement (the table route: several GPUs, stage2_table, inputs the join does not take)
+    if st.get("join_passes", 0) and not st.get("join_fallbacks", 0):
+        b += (4 + 12 + 12) * 2 * st.get("ra_lookups", 0)                     # round 5: the singletons' query tuples go through the same two passes (timed in this class)
+    return b
 
 
 # HBM traffic and SQ figures per kernel from the PMC passes committed under profiles/ (separate rocprofv3 runs of this same command,
@@ -225,7 +236,7 @@ def main():
     STATS = ("windows", "passes", "rounds", "merge_rounds", "claim_rounds", "resketch", "n_sg0", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
              "sort_overflow_segments", "sketch_bases", "sort_records", "sketch_strings", "t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "ra_lookups", "ra_verified",
              "ra_singletons", "cix_slots", "cix_entries", "sketch_records", "x_records", "x_cindex_entries", "contigs_bucket", "contigs_combine",
-             "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex", "store_grows", "store_contigs", "store_chars")
+             "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex", "store_grows", "store_contigs", "store_chars", "join_passes", "join_fallbacks", "join_deferred", "ra_passing")
 
     def measure(n_total, seed, steps, warmup, check, ab_events=False):
         """K timed steps of one job of n_total reads; returns (seconds, aggregate stats, digests, reads, make)."""
@@ -543,7 +554,7 @@ def main():
                        "fell_back": fell_back, "host_threads": threads,
                        "per_step": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("rounds", "merge_rounds", "claim_rounds", "passes", "windows", "resketch", "n_sg0", "contigs_bucket",
                                                                                   "contigs_combine", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
-                                                                                  "sort_overflow_segments", "x_records", "x_cindex_entries", "store_grows", "store_contigs", "store_chars")},
+                                                                                  "sort_overflow_segments", "x_records", "x_cindex_entries", "store_grows", "store_contigs", "store_chars", "join_passes", "join_fallbacks", "join_deferred")},
                        "stage_ms_rank0": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("t_reads", "t_bucket", "t_combine", "t_realign", "t_gpu", "t_x_reads", "t_x_records",
                                                                                         "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")},
                        "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step; cost: event_overhead)",
