@@ -979,22 +979,24 @@ __global__ void k_rj_queries(CixGeom g, const uint64_t *__restrict__ sgbits, siz
 
 template <int LS> __device__ __forceinline__ uint32_t rj_hash(uint32_t kid) { return (kid * 0x9E3779B1u) >> (32 - LS); }
 
-// One workgroup per partition.  defer: { claim key, read id | distance << 32 | encode_byte forward ok << 40 | reverse ok << 41 }
-template <int W, int LS>
+// One workgroup per partition joins; the matches leave as a list of candidates { entry's slot word, singleton << 5 | lane } that a
+// second kernel verifies one per thread.  (The first form verified inside the join kernel: 1024 threads per workgroup cap a thread at
+// 128 registers, the verification -- five-word window, its reverse complement, the mismatch words -- spilled 400 bytes per thread
+// to scratch and the kernel took 37 ms.  Split, the join is an LDS kernel with a handful of registers and the verification runs at
+// the occupancy its registers allow, as it does in k_realign_reads.)
+template <int LS>
 __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_t *__restrict__ ekey, const unsigned long long *__restrict__ eslot,
                                                         const uint32_t *__restrict__ epstart, const uint32_t *__restrict__ qkey,
                                                         const unsigned long long *__restrict__ qslot, const uint32_t *__restrict__ qpstart,
-                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag, const uint32_t *__restrict__ rids,
-                                                        const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
-                                                        int thr, int maxthr, uint32_t maxsearch, unsigned long long *__restrict__ claim,
-                                                        unsigned long long *__restrict__ stats, ulonglong2 *__restrict__ defer, unsigned long long defer_cap,
-                                                        unsigned long long *__restrict__ defer_count, unsigned int *__restrict__ status)
+                                                        uint32_t maxsearch, unsigned long long *__restrict__ cand_v, uint32_t *__restrict__ cand_q,
+                                                        unsigned long long cand_cap, unsigned long long *__restrict__ cand_count, unsigned int *__restrict__ status)
 {
 	constexpr uint32_t RJ_SLOTS = 1u << LS, RJ_QMAX = (RJ_SLOTS / 16) * 11;
 	__shared__ uint32_t K[RJ_SLOTS], V[RJ_SLOTS];
 	__shared__ unsigned long long QC[RJ_QUEUE];
 	__shared__ uint32_t QV[RJ_QUEUE];
 	__shared__ uint32_t q_n;
+	__shared__ unsigned long long q_base;
 	const uint32_t part = blockIdx.x;
 	const uint32_t q0 = qpstart[part], nq = qpstart[part + 1] - q0;
 	const uint32_t e0 = epstart[part], ne = epstart[part + 1] - e0;
@@ -1004,7 +1006,6 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 	for (uint32_t i = tid; i < RJ_SLOTS; i += RJ_THREADS) K[i] = RJ_EMPTY;
 	if (tid == 0) q_n = 0;
 	__syncthreads();
-	uint32_t n_look = 0, n_cand = 0, n_pass = 0;
 	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
 		const uint32_t k32 = qkey[q0 + i];
 		const unsigned long long sl = qslot[q0 + i];
@@ -1014,63 +1015,25 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		V[h] = (uint32_t)sl;                                                         // singleton << 5 | lane
 	}
 	__syncthreads();
-	// the screen: a forward query counts the queries of its own (28 bits, lane) -- at least its bin of dictionary l
-	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
-		const uint32_t k32 = qkey[q0 + i];
-		const unsigned long long sl = qslot[q0 + i];
-		const uint32_t code = (uint32_t)sl & 31u;
+	// the screen: a forward query counts the queries of its own (28 bits, lane) -- at least its bin of dictionary l.  (Walking from the
+	// slot a query hashes to covers every query with its 28 bits: they all lie in that run of occupied slots.)
+	for (uint32_t i = tid; i < RJ_SLOTS; i += RJ_THREADS) {
+		const uint32_t kid = K[i];
+		if (kid == RJ_EMPTY) continue;
+		const uint32_t code = V[i] & 31u;
 		if ((int)code >= g.nd) continue;
-		const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(sl >> CIX_TAG_SHIFT);
 		uint32_t same = 0;
 		for (uint32_t h = rj_hash<LS>(kid); K[h] != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) same += (K[h] == kid && (V[h] & 31u) == code);
 		if (same > maxsearch) *status = 1u;
-		n_look += sgflag[(uint32_t)sl >> 5] ? 0u : 1u;
 	}
-	// reverse lanes count as lookups too (statistics)
-	for (uint32_t i = tid; i < nq; i += RJ_THREADS) { const unsigned long long sl = qslot[q0 + i]; if ((int)((uint32_t)sl & 31u) >= g.nd && !sgflag[(uint32_t)sl >> 5]) ++n_look; }
-	const int L = g.L;
-
-	auto verify = [&](unsigned long long v, uint32_t qv) {
-		const uint32_t sg = qv >> 5;
-		const int q = (int)(qv & 31u);
-		if (sgflag[sg]) return;
-		const int dir = q / g.nd, l = q - dir * g.nd;
-		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
-		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
-		const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
-		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
-		++n_cand;
-		uint64_t win[W], x[W];
-		const uint64_t *rb = sgbits + (size_t)sg * W;
-		contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
-		int dist = 0;
-#pragma unroll
-		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ rb[w]; dist += __popcll(x[w]); }
-		if (dist > maxthr || bits_key(x, g.ds[l], g.klen) != 0) return;                      // a tag is not the key: exact check here
-		for (int l2 = 0; l2 < l; ++l2)
-			if ((!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;         // a lower dictionary claims the same tuple with a smaller key
-		uint64_t mm[W];
-#pragma unroll
-		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
-		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
-		if (dist <= thr) {
-			if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) return; }                          // :393
-			else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) return;                       // :461
-			++n_pass;
-			atomicMin(&claim[sg], ck);
-			return;
-		}
-		// fails for its distance alone at this threshold: a later pass decides (the read may be claimed or flagged by then)
-		const bool okf = !dir ? encode_ok_sparse<W>(mm, L, false) : true;
-		const bool okr = dir ? encode_ok_sparse<W>(mm, L, true) : true;
-		if (!dir && !okf) return;                                                            // (the forward test does not depend on the threshold)
-		const unsigned long long at = atomicAdd(defer_count, 1ull);
-		if (at < defer_cap) defer[at] = make_ulonglong2(ck, (unsigned long long)rids[sg] | ((unsigned long long)dist << 32) | ((unsigned long long)okf << 40) | ((unsigned long long)okr << 41));
-	};
+	// the queue leaves for the candidate list: one reservation per workgroup and hand-over
 	auto drain = [&]() {
 		__syncthreads();
 		const uint32_t n = q_n < RJ_QUEUE ? q_n : RJ_QUEUE;
-		for (uint32_t c = tid; c < n; c += RJ_THREADS) verify(QC[c], QV[c]);
+		if (tid == 0) q_base = n ? atomicAdd(cand_count, (unsigned long long)n) : 0ull;
+		__syncthreads();
+		const unsigned long long b0 = q_base;
+		for (uint32_t c = tid; c < n; c += RJ_THREADS) if (b0 + c < cand_cap) { cand_v[b0 + c] = QC[c]; cand_q[b0 + c] = QV[c]; }
 		__syncthreads();
 		if (tid == 0) q_n = 0;
 		__syncthreads();
@@ -1085,7 +1048,10 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 				if (kk != kid) continue;
 				const uint32_t pos = atomicAdd(&q_n, 1u);
 				if (pos < RJ_QUEUE) { QC[pos] = v; QV[pos] = V[h]; }
-				else verify(v, V[h]);                                                        // (the queue is full: verified where it was found)
+				else {                                                                       // (the queue is full -- a key that thousands of singletons share: straight to the list)
+					const unsigned long long at = atomicAdd(cand_count, 1ull);
+					if (at < cand_cap) { cand_v[at] = v; cand_q[at] = V[h]; }
+				}
 			}
 		}
 		__syncthreads();
@@ -1093,16 +1059,78 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		else __syncthreads();
 	}
 	drain();
+}
+
+// one candidate per thread: defer = { claim key, read id | distance << 32 | encode_byte forward ok << 40 | reverse ok << 41 }
+template <int W>
+__global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned long long *__restrict__ cand_v, const uint32_t *__restrict__ cand_q, size_t n_cand_in,
+                                                   const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag, const uint32_t *__restrict__ rids,
+                                                   const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
+                                                   int thr, int maxthr, unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats,
+                                                   ulonglong2 *__restrict__ defer, unsigned long long defer_cap, unsigned long long *__restrict__ defer_count)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t n_cand = 0, n_pass = 0;
+	const int L = g.L;
+	if (t < n_cand_in) do {
+		const unsigned long long v = cand_v[t];
+		const uint32_t qv = cand_q[t];
+		const uint32_t sg = qv >> 5;
+		const int q = (int)(qv & 31u);
+		if (sgflag[sg]) break;
+		const int dir = q / g.nd, l = q - dir * g.nd;
+		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
+		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
+		const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
+		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) break;
+		++n_cand;
+		uint64_t win[W], x[W];
+		const uint64_t *rb = sgbits + (size_t)sg * W;
+		contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
+		int dist = 0;
+#pragma unroll
+		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ rb[w]; dist += __popcll(x[w]); }
+		if (dist > maxthr || bits_key(x, g.ds[l], g.klen) != 0) break;                       // a tag is not the key: exact check here
+		bool lower = false;
+		for (int l2 = 0; l2 < l; ++l2)
+			if ((!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) lower = true;   // a lower dictionary claims the same tuple with a smaller key
+		if (lower) break;
+		uint64_t mm[W];
+#pragma unroll
+		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
+		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+		if (dist <= thr) {
+			if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) break; }                          // :393
+			else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) break;                       // :461
+			++n_pass;
+			atomicMin(&claim[sg], ck);
+			break;
+		}
+		// fails for its distance alone at this threshold: a later pass decides (the read may be claimed or flagged by then)
+		const bool okf = !dir ? encode_ok_sparse<W>(mm, L, false) : true;
+		const bool okr = dir ? encode_ok_sparse<W>(mm, L, true) : true;
+		if (!dir && !okf) break;                                                            // (the forward test does not depend on the threshold)
+		const unsigned long long at = atomicAdd(defer_count, 1ull);
+		if (at < defer_cap) defer[at] = make_ulonglong2(ck, (unsigned long long)rids[sg] | ((unsigned long long)dist << 32) | ((unsigned long long)okf << 40) | ((unsigned long long)okr << 41));
+	} while (0);
 	if (stats) {
-		__shared__ unsigned long long st3[3];
-		if (tid < 3) st3[tid] = 0;
+		__shared__ unsigned long long st2[2];
+		if (threadIdx.x < 2) st2[threadIdx.x] = 0;
 		__syncthreads();
-		unsigned long long a = n_look, b = n_cand, c = n_pass;
-		for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
-		if ((tid & 63) == 0) { atomicAdd(&st3[0], a); atomicAdd(&st3[1], b); atomicAdd(&st3[2], c); }
+		unsigned long long b = n_cand, c = n_pass;
+		for (int o = 32; o; o >>= 1) { b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+		if ((threadIdx.x & 63) == 0) { if (b) atomicAdd(&st2[0], b); if (c) atomicAdd(&st2[1], c); }
 		__syncthreads();
-		if (tid < 3 && st3[tid]) atomicAdd(&stats[4 * (blockIdx.x & 1023) + tid], st3[tid]);
+		if (threadIdx.x < 2 && st2[threadIdx.x]) atomicAdd(&stats[4 * (blockIdx.x & 1023) + 1 + threadIdx.x], st2[threadIdx.x]);
 	}
+}
+// the lookups of the pass (statistics): queries of unflagged singletons
+__global__ void k_rj_count(const uint8_t *__restrict__ sgflag, size_t n_sg, int n_lanes, unsigned long long *__restrict__ stats)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long v = (i < n_sg && !sgflag[i]) ? (unsigned long long)n_lanes : 0ull;
+	for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+	if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[4 * (blockIdx.x & 1023)], v);
 }
 
 __global__ void k_rj_map(const uint32_t *__restrict__ rids, size_t n, uint32_t *__restrict__ map)
@@ -1160,7 +1188,7 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 	unsigned long long *sets = (unsigned long long*)(tmp + 2 * key_b + 2 * slot_b + ps_b);          // 1024 x 4 statistics words, then the deferred count and the status
 	unsigned long long *d_cnt = sets + 4096;
 	unsigned int *d_status = (unsigned int*)(d_cnt + 1);
-	MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 4096 * 8 + 16, ctx->stream));
+	MCOM_HIP(ctx, hipMemsetAsync(sets, 0, 4096 * 8 + 32, ctx->stream));            // (+ deferred count, status, candidate count)
 	{
 		const int lg_lanes = 2 * g.nd <= 16 ? 4 : 5;
 		const uint64_t blocks = ((n_sg << lg_lanes) + 255) / 256;
@@ -1172,19 +1200,36 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 	const uint32_t *qk = nullptr; const uint64_t *qs = nullptr;
 	int rc = mcom_cindex_partition(ctx, qkA, qsA, nq, 0, qkB, qsB, L, ininumdict, geom, qps, &qk, &qs);
 	if (rc) return rc;
+	// the candidate list lives in the pair of tuple arrays the sort did not end in (room for nq candidates: more -- a repeat whose key
+	// thousands of singletons and thousands of contig positions share -- and the table route takes over)
+	unsigned long long *cand_v = (unsigned long long*)(qs == qsA ? qsB : qsA);
+	uint32_t *cand_q = qk == qkA ? qkB : qkA;
+	unsigned long long *d_ccnt = d_cnt + 2;
 	{
 		McomProfScope ps_(ctx, PROF_REALIGN_READS);
 		const bool wide = nq / g.n_parts + 1 > 4600;                                      // (mean queries per partition: the small table takes 5632)
-#define MCOM_RJ_ARGS g, d_ekey, (const unsigned long long*)d_eslot, d_epstart, qk, (const unsigned long long*)qs, (const uint32_t*)qps, d_sgbits, d_sgflag, d_rids, d_cbits, d_coff, d_woff, \
-		thr, maxthr, (uint32_t)maxsearch, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt, d_status
-#define MCOM_CASE(WW) case WW: if (wide) MCOM_LAUNCH((k_rj_join<WW, 14>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS); \
-		else MCOM_LAUNCH((k_rj_join<WW, 13>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS); break;
-		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
-		default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
-#undef MCOM_CASE
+#define MCOM_RJ_ARGS g, d_ekey, (const unsigned long long*)d_eslot, d_epstart, qk, (const unsigned long long*)qs, (const uint32_t*)qps, (uint32_t)maxsearch, cand_v, cand_q, (unsigned long long)nq, d_ccnt, d_status
+		if (wide) MCOM_LAUNCH((k_rj_join<14>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS);
+		else MCOM_LAUNCH((k_rj_join<13>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS);
 #undef MCOM_RJ_ARGS
 		MCOM_LAUNCH_CHECK(ctx);
 	}
+	unsigned long long hcc[3] = {0, 0, 0};
+	MCOM_HIP(ctx, mcom_d2h_async(ctx, hcc, d_cnt, 24));
+	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	if ((unsigned int)(hcc[1] & 0xFFFFFFFFull) || hcc[2] > nq) { *h_status = 1; return MCOM_OK; }
+	const size_t n_cand = (size_t)hcc[2];
+	if (n_cand) {
+		McomProfScope ps_(ctx, PROF_REALIGN_READS);
+		const unsigned vb = (unsigned)((n_cand + 255) / 256);
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_rj_verify<WW>), dim3(vb), dim3(256), 0, ctx->stream, g, (const unsigned long long*)cand_v, (const uint32_t*)cand_q, n_cand, d_sgbits, d_sgflag, d_rids, \
+		d_cbits, d_coff, d_woff, thr, maxthr, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt); break;
+		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+		default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+#undef MCOM_CASE
+		MCOM_LAUNCH_CHECK(ctx);
+	}
+	if (d_stats) MCOM_LAUNCH(k_rj_count, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgflag, n_sg, n_lanes, sets);
 	if (d_stats) MCOM_LAUNCH(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
 	unsigned long long hc[2] = {0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hc, d_cnt, 16));
