@@ -950,10 +950,10 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 // Same claims as mcom_realign_pass_reads, pass by pass (tests/test_gpu_realign.py compares the two on the reference's fixtures and on
 // sets with repeats; the pipeline tests compare whole runs with the reference's dumps and the oracle).
 // ====================================================================================================================================
-#define RJ_THREADS 1024
+#define RJ_THREADS 512                      // two workgroups per CU (76 KB of LDS each at LS = 13): one's loads travel while the other works in LDS
 // LDS hash slots of a partition's queries: 2^LS of key + value (64 KB at LS = 13, 128 KB at 14: the host picks by the mean number of
 // queries per partition); the table takes 0.69 of them
-#define RJ_QUEUE 2048                       // candidates waiting for their verification
+#define RJ_QUEUE 1024                       // candidates of a workgroup on their way to the list
 #define RJ_EMPTY 0xFFFFFFFFu
 
 // the queries: one tuple per (singleton, lane) with a lane for every (direction, dictionary) the scan asks (kthread_hash_realign.c:440:
@@ -1038,11 +1038,14 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		if (tid == 0) q_n = 0;
 		__syncthreads();
 	};
+	// (the next batch's entries are loaded before this one is probed: the loop is a chain of load -> LDS -> barrier otherwise)
+	uint32_t k32n = 0; unsigned long long vn = 0;
+	if ((uint32_t)tid < ne) { k32n = ekey[e0 + tid]; vn = eslot[e0 + tid]; }
 	for (uint32_t base = 0; base < ne; base += RJ_THREADS) {
 		const uint32_t i = base + tid;
+		const uint32_t k32 = k32n; const unsigned long long v = vn;
+		if (i + RJ_THREADS < ne) { k32n = ekey[e0 + i + RJ_THREADS]; vn = eslot[e0 + i + RJ_THREADS]; }
 		if (i < ne) {
-			const uint32_t k32 = ekey[e0 + i];
-			const unsigned long long v = eslot[e0 + i];
 			const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(v >> CIX_TAG_SHIFT);
 			for (uint32_t h = rj_hash<LS>(kid), kk; (kk = K[h]) != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) {
 				if (kk != kid) continue;
