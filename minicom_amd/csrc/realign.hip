@@ -954,6 +954,7 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 // LDS hash slots of a partition's queries: 2^LS of key + value (64 KB at LS = 13, 128 KB at 14: the host picks by the mean number of
 // queries per partition); the table takes 0.69 of them
 #define RJ_QUEUE 1024                       // candidates of a workgroup on their way to the list
+#define RJ_CHUNK 2048u                      // candidates a workgroup reserves room for at a time
 #define RJ_EMPTY 0xFFFFFFFFu
 
 // the queries: one tuple per (singleton, lane) with a lane for every (direction, dictionary) the scan asks (kthread_hash_realign.c:440:
@@ -995,8 +996,8 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 	__shared__ uint32_t K[RJ_SLOTS], V[RJ_SLOTS];
 	__shared__ unsigned long long QC[RJ_QUEUE];
 	__shared__ uint32_t QV[RJ_QUEUE];
-	__shared__ uint32_t q_n;
-	__shared__ unsigned long long q_base;
+	__shared__ uint32_t q_n, w_left;
+	__shared__ unsigned long long q_base, w_base;
 	const uint32_t part = blockIdx.x;
 	const uint32_t q0 = qpstart[part], nq = qpstart[part + 1] - q0;
 	const uint32_t e0 = epstart[part], ne = epstart[part + 1] - e0;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 	if (nq == 0) return;                                                          // nobody asks for a key of this partition
 	if (nq > RJ_QMAX) { if (tid == 0) *status = 1u; return; }
 	for (uint32_t i = tid; i < RJ_SLOTS; i += RJ_THREADS) K[i] = RJ_EMPTY;
-	if (tid == 0) q_n = 0;
+	if (tid == 0) { q_n = 0; w_left = 0; w_base = 0; }
 	__syncthreads();
 	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
 		const uint32_t k32 = qkey[q0 + i];
@@ -1027,10 +1028,16 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		if (same > maxsearch) *status = 1u;
 	}
 	// the queue leaves for the candidate list: one reservation per workgroup and hand-over
+	// (room in the list is reserved RJ_CHUNK candidates at a time: one returning atomic on the list's counter per hand-over -- 600 000 of
+	// them from 65 000 workgroups, each waited for between two barriers -- made this kernel 30 ms; what a workgroup leaves unused of
+	// its last chunk stays marked empty and the verification skips it)
 	auto drain = [&]() {
 		__syncthreads();
 		const uint32_t n = q_n < RJ_QUEUE ? q_n : RJ_QUEUE;
-		if (tid == 0) q_base = n ? atomicAdd(cand_count, (unsigned long long)n) : 0ull;
+		if (tid == 0) {
+			if (w_left < n) { w_base = atomicAdd(cand_count, (unsigned long long)RJ_CHUNK); w_left = RJ_CHUNK; }
+			q_base = w_base; w_base += n; w_left -= n;
+		}
 		__syncthreads();
 		const unsigned long long b0 = q_base;
 		for (uint32_t c = tid; c < n; c += RJ_THREADS) if (b0 + c < cand_cap) { cand_v[b0 + c] = QC[c]; cand_q[b0 + c] = QV[c]; }
@@ -1080,7 +1087,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 			}
 		}
 		__syncthreads();
-		if (q_n >= RJ_QUEUE / 4) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~100 on average, 1024 at most)
+		if (q_n >= RJ_QUEUE / 2) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~100 on average)
 		else __syncthreads();
 	}
 	drain();
@@ -1098,8 +1105,9 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 	uint32_t n_cand = 0, n_pass = 0;
 	const int L = g.L;
 	if (t < n_cand_in) do {
-		const unsigned long long v = cand_v[t];
 		const uint32_t qv = cand_q[t];
+		if (qv == RJ_EMPTY) break;                                                           // (the unused end of a workgroup's last chunk)
+		const unsigned long long v = cand_v[t];
 		const uint32_t sg = qv >> 5;
 		const int q = (int)(qv & 31u);
 		if (sgflag[sg]) break;
@@ -1225,15 +1233,20 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 	const uint32_t *qk = nullptr; const uint64_t *qs = nullptr;
 	int rc = mcom_cindex_partition(ctx, qkA, qsA, nq, 0, qkB, qsB, L, ininumdict, geom, qps, &qk, &qs);
 	if (rc) return rc;
-	// the candidate list lives in the pair of tuple arrays the sort did not end in (room for nq candidates: more -- a repeat whose key
-	// thousands of singletons and thousands of contig positions share -- and the table route takes over)
-	unsigned long long *cand_v = (unsigned long long*)(qs == qsA ? qsB : qsA);
-	uint32_t *cand_q = qk == qkA ? qkB : qkA;
+	// the candidate list: room for 1.5 x the queries (chunks are not filled to the end; more candidates than that -- a repeat whose key
+	// thousands of singletons and thousands of contig positions share -- and the table route takes over), marked empty
+	const unsigned long long ccap = nq + nq / 2 + RJ_CHUNK;
+	char *ctmp = nullptr;
+	if (mcom_dmalloc(&ctmp, al((size_t)ccap * 8) + al((size_t)ccap * 4) + 256) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "join: candidate list");
+	Guard cguard{ctx, ctmp};
+	unsigned long long *cand_v = (unsigned long long*)ctmp;
+	uint32_t *cand_q = (uint32_t*)(ctmp + al((size_t)ccap * 8));
+	MCOM_HIP(ctx, hipMemsetAsync(cand_q, 0xFF, (size_t)ccap * 4, ctx->stream));
 	unsigned long long *d_ccnt = d_cnt + 2;
 	{
 		McomProfScope ps_(ctx, PROF_REALIGN_READS);
 		const bool wide = nq / g.n_parts + 1 > 4600;                                      // (mean queries per partition: the small table takes 5632)
-#define MCOM_RJ_ARGS g, d_ekey, (const unsigned long long*)d_eslot, d_epstart, qk, (const unsigned long long*)qs, (const uint32_t*)qps, (uint32_t)maxsearch, cand_v, cand_q, (unsigned long long)nq, d_ccnt, d_status
+#define MCOM_RJ_ARGS g, d_ekey, (const unsigned long long*)d_eslot, d_epstart, qk, (const unsigned long long*)qs, (const uint32_t*)qps, (uint32_t)maxsearch, cand_v, cand_q, ccap, d_ccnt, d_status
 		if (wide) MCOM_LAUNCH((k_rj_join<14>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS);
 		else MCOM_LAUNCH((k_rj_join<13>), dim3(g.n_parts), dim3(RJ_THREADS), 0, ctx->stream, MCOM_RJ_ARGS);
 #undef MCOM_RJ_ARGS
@@ -1242,7 +1255,7 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 	unsigned long long hcc[3] = {0, 0, 0};
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, hcc, d_cnt, 24));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
-	if ((unsigned int)(hcc[1] & 0xFFFFFFFFull) || hcc[2] > nq) { *h_status = 1; return MCOM_OK; }
+	if ((unsigned int)(hcc[1] & 0xFFFFFFFFull) || hcc[2] > ccap) { *h_status = 1; return MCOM_OK; }
 	const size_t n_cand = (size_t)hcc[2];
 	if (n_cand) {
 		McomProfScope ps_(ctx, PROF_REALIGN_READS);
