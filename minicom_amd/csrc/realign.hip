@@ -1052,42 +1052,23 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		const uint32_t i = base + tid;
 		const uint32_t k32 = k32n; const unsigned long long v = vn;
 		if (i + RJ_THREADS < ne) { k32n = ekey[e0 + i + RJ_THREADS]; vn = eslot[e0 + i + RJ_THREADS]; }
-		// a thread's first two matches go to the queue through ONE LDS atomic per wave (a counter that every match of a partition bumps
-		// on its own is a queue of its own: 2 700 matches x ~100 cycles each); further matches of the same entry -- a key many singletons
-		// share -- take the slow way
-		uint32_t m0 = 0, m1 = 0, nm = 0;
+		// (an index entry of a 30 x genome matches three or four queries -- the singletons that cover its position -- so a match takes its
+		// queue slot with an LDS atomic of its own: a wave-wide reservation for "the first two matches" sent the rest down the slow way and
+		// was twice as slow)
 		if (i < ne) {
 			const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(v >> CIX_TAG_SHIFT);
 			for (uint32_t h = rj_hash<LS>(kid), kk; (kk = K[h]) != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) {
 				if (kk != kid) continue;
-				if (nm == 0) m0 = V[h];
-				else if (nm == 1) m1 = V[h];
-				else {
+				const uint32_t pos = atomicAdd(&q_n, 1u);
+				if (pos < RJ_QUEUE) { QC[pos] = v; QV[pos] = V[h]; }
+				else {                                                                       // (the queue is full -- a key that thousands of singletons share: straight to the list)
 					const unsigned long long at = atomicAdd(cand_count, 1ull);
 					if (at < cand_cap) { cand_v[at] = v; cand_q[at] = V[h]; }
 				}
-				++nm;
-			}
-		}
-		{
-			const uint32_t mine = nm < 2 ? nm : 2;
-			uint32_t inc = mine;
-			const int lane = tid & 63;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) { const uint32_t t2 = __shfl_up(inc, d, 64); if (lane >= d) inc += t2; }
-			const uint32_t tot = __shfl(inc, 63, 64);
-			uint32_t wbase = 0;
-			if (lane == 63 && tot) wbase = atomicAdd(&q_n, tot);
-			wbase = __shfl(wbase, 63, 64);
-			uint32_t pos = wbase + inc - mine;
-			for (uint32_t u = 0; u < mine; ++u, ++pos) {
-				const uint32_t qv = u ? m1 : m0;
-				if (pos < RJ_QUEUE) { QC[pos] = v; QV[pos] = qv; }
-				else { const unsigned long long at = atomicAdd(cand_count, 1ull); if (at < cand_cap) { cand_v[at] = v; cand_q[at] = qv; } }
 			}
 		}
 		__syncthreads();
-		if (q_n >= RJ_QUEUE / 2) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~100 on average)
+		if (q_n >= RJ_QUEUE / 2) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~350 on average)
 		else __syncthreads();
 	}
 	drain();
