@@ -953,7 +953,7 @@ extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t
 #define RJ_THREADS 512                      // two workgroups per CU (76 KB of LDS each at LS = 13): one's loads travel while the other works in LDS
 // LDS hash slots of a partition's queries: 2^LS of key + value (64 KB at LS = 13, 128 KB at 14: the host picks by the mean number of
 // queries per partition); the table takes 0.69 of them
-#define RJ_QUEUE 1024                       // candidates of a workgroup on their way to the list
+#define RJ_QUEUE 1280                       // candidates of a workgroup on their way to the list (a batch of 2048 entries adds ~430); 79 KB of LDS with the table: two workgroups per CU
 #define RJ_CHUNK 2048u                      // candidates a workgroup reserves room for at a time
 #define RJ_EMPTY 0xFFFFFFFFu
 
@@ -1007,13 +1007,20 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 	for (uint32_t i = tid; i < RJ_SLOTS; i += RJ_THREADS) K[i] = RJ_EMPTY;
 	if (tid == 0) { q_n = 0; w_left = 0; w_base = 0; }
 	__syncthreads();
-	for (uint32_t i = tid; i < nq; i += RJ_THREADS) {
-		const uint32_t k32 = qkey[q0 + i];
-		const unsigned long long sl = qslot[q0 + i];
-		const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(sl >> CIX_TAG_SHIFT);
-		uint32_t h = rj_hash<LS>(kid);
-		while (atomicCAS(&K[h], RJ_EMPTY, kid) != RJ_EMPTY) h = (h + 1) & (RJ_SLOTS - 1);
-		V[h] = (uint32_t)sl;                                                         // singleton << 5 | lane
+	// (four tuples of a thread in flight at a time: with one, every round of the loop waited for its own pair of loads)
+	for (uint32_t i0 = tid; i0 < nq; i0 += 4 * RJ_THREADS) {
+		uint32_t k4[4]; unsigned long long s4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * RJ_THREADS; if (i < nq) { k4[u] = qkey[q0 + i]; s4[u] = qslot[q0 + i]; } }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t i = i0 + u * RJ_THREADS;
+			if (i >= nq) break;
+			const uint32_t kid = ((k4[u] & 0xFFFFu) << 12) | (uint32_t)(s4[u] >> CIX_TAG_SHIFT);
+			uint32_t h = rj_hash<LS>(kid);
+			while (atomicCAS(&K[h], RJ_EMPTY, kid) != RJ_EMPTY) h = (h + 1) & (RJ_SLOTS - 1);
+			V[h] = (uint32_t)s4[u];                                                      // singleton << 5 | lane
+		}
 	}
 	__syncthreads();
 	// the screen: a forward query counts the queries of its own (28 bits, lane) -- at least its bin of dictionary l.  (Walking from the
@@ -1045,18 +1052,24 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 		if (tid == 0) q_n = 0;
 		__syncthreads();
 	};
-	// (the next batch's entries are loaded before this one is probed: the loop is a chain of load -> LDS -> barrier otherwise)
-	uint32_t k32n = 0; unsigned long long vn = 0;
-	if ((uint32_t)tid < ne) { k32n = ekey[e0 + tid]; vn = eslot[e0 + tid]; }
-	for (uint32_t base = 0; base < ne; base += RJ_THREADS) {
-		const uint32_t i = base + tid;
-		const uint32_t k32 = k32n; const unsigned long long v = vn;
-		if (i + RJ_THREADS < ne) { k32n = ekey[e0 + i + RJ_THREADS]; vn = eslot[e0 + i + RJ_THREADS]; }
-		// (an index entry of a 30 x genome matches three or four queries -- the singletons that cover its position -- so a match takes its
-		// queue slot with an LDS atomic of its own: a wave-wide reservation for "the first two matches" sent the rest down the slow way and
-		// was twice as slow)
-		if (i < ne) {
-			const uint32_t kid = ((k32 & 0xFFFFu) << 12) | (uint32_t)(v >> CIX_TAG_SHIFT);
+	// (a batch = four entries per thread, and the next batch's are loaded before this one is probed: the loop is a chain of
+	// load -> LDS -> barrier otherwise, with sixteen waves on the CU to hide it)
+	constexpr uint32_t RJ_BATCH = 4 * RJ_THREADS;
+	uint32_t kn[4]; unsigned long long vn4[4];
+#pragma unroll
+	for (int u = 0; u < 4; ++u) { const uint32_t i = tid + u * RJ_THREADS; kn[u] = 0; vn4[u] = 0; if (i < ne) { kn[u] = ekey[e0 + i]; vn4[u] = eslot[e0 + i]; } }
+	for (uint32_t base = 0; base < ne; base += RJ_BATCH) {
+		uint32_t kc[4]; unsigned long long vc[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { kc[u] = kn[u]; vc[u] = vn4[u]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = base + RJ_BATCH + tid + u * RJ_THREADS; if (i < ne) { kn[u] = ekey[e0 + i]; vn4[u] = eslot[e0 + i]; } }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t i = base + tid + u * RJ_THREADS;
+			if (i >= ne) break;
+			const unsigned long long v = vc[u];
+			const uint32_t kid = ((kc[u] & 0xFFFFu) << 12) | (uint32_t)(v >> CIX_TAG_SHIFT);
 			for (uint32_t h = rj_hash<LS>(kid), kk; (kk = K[h]) != RJ_EMPTY; h = (h + 1) & (RJ_SLOTS - 1)) {
 				if (kk != kid) continue;
 				const uint32_t pos = atomicAdd(&q_n, 1u);
@@ -1068,7 +1081,7 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 			}
 		}
 		__syncthreads();
-		if (q_n >= RJ_QUEUE / 2) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~350 on average)
+		if (q_n >= 384) drain();                                                    // (uniform: q_n is read between two barriers; a batch adds ~350 on average)
 		else __syncthreads();
 	}
 	drain();
@@ -1096,7 +1109,15 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
 		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
 		const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
-		if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) break;
+		if (jj < 0) break;
+		// The claim key this candidate would bid is known before anything is loaded.  A read at its true place is found by most of its
+		// dictionaries -- seven or eight candidates for ONE window, spread over the whole list (their keys hash to different partitions) --
+		// and only the smallest key counts: a candidate whose key is not below the singleton's claim so far can change nothing.  (Its
+		// deferred tuple is not needed either: a singleton with a claim leaves the list after this pass.)  One 8-byte gather instead of
+		// the singleton's row, the contig's offsets and its window for about two candidates in three.
+		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+		if (__hip_atomic_load(&claim[sg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= ck) break;
+		if ((uint64_t)jj >= woff[c + 1] - woff[c]) break;
 		++n_cand;
 		uint64_t win[W], x[W];
 		const uint64_t *rb = sgbits + (size_t)sg * W;
@@ -1112,7 +1133,6 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		uint64_t mm[W];
 #pragma unroll
 		for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
-		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
 		if (dist <= thr) {
 			if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) break; }                          // :393
 			else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) break;                       // :461
