@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(RJ_THREADS) void k_rj_join(CixGeom g, const uint32_
 // one candidate per thread: defer = { claim key, read id | distance << 32 | encode_byte forward ok << 40 | reverse ok << 41 }
 template <int W>
 __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned long long *__restrict__ cand_v, const uint32_t *__restrict__ cand_q, size_t n_cand_in,
-                                                   const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag, const uint32_t *__restrict__ rids,
-                                                   const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
+                                                   const uint64_t *__restrict__ sgbits, const uint32_t *__restrict__ rids,
+                                                   const uint64_t *__restrict__ cbits, const ulonglong2 *__restrict__ cgeo,
                                                    int thr, int maxthr, unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats,
                                                    ulonglong2 *__restrict__ defer, unsigned long long defer_cap, unsigned long long *__restrict__ defer_count)
 {
@@ -1104,7 +1104,6 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		const unsigned long long v = cand_v[t];
 		const uint32_t sg = qv >> 5;
 		const int q = (int)(qv & 31u);
-		if (sgflag[sg]) break;
 		const int dir = q / g.nd, l = q - dir * g.nd;
 		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
 		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
@@ -1116,12 +1115,16 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		// deferred tuple is not needed either: a singleton with a claim leaves the list after this pass.)  One 8-byte gather instead of
 		// the singleton's row, the contig's offsets and its window for about two candidates in three.
 		const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+		// (a flagged singleton -- near-poly-A / -T at this threshold -- carries the claim 0 while this kernel runs: no key is below it, and
+		// its flag needs no gather of its own; k_rj_unflag puts UINT64_MAX back.  The kernel runs at the card's rate for random 64-byte
+		// lines from a gigabyte: every line saved per candidate counts)
 		if (__hip_atomic_load(&claim[sg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= ck) break;
-		if ((uint64_t)jj >= woff[c + 1] - woff[c]) break;
+		const ulonglong2 cg = cgeo[c];                                                       // { first word of the packed contig, its windows }
+		if ((uint64_t)jj >= cg.y) break;
 		++n_cand;
 		uint64_t win[W], x[W];
 		const uint64_t *rb = sgbits + (size_t)sg * W;
-		contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
+		contig_window<W>(cbits + cg.x, (uint64_t)jj, L, dir != 0, win);
 		int dist = 0;
 #pragma unroll
 		for (int w = 0; w < W; ++w) { x[w] = win[w] ^ rb[w]; dist += __popcll(x[w]); }
@@ -1157,6 +1160,17 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		__syncthreads();
 		if (threadIdx.x < 2 && st2[threadIdx.x]) atomicAdd(&stats[4 * (blockIdx.x & 1023) + 1 + threadIdx.x], st2[threadIdx.x]);
 	}
+}
+// flagged singletons: claim 0 while the verification runs (set = true), UINT64_MAX afterwards; and the contigs' { first word, windows }
+__global__ void k_rj_unflag(const uint8_t *__restrict__ sgflag, size_t n_sg, bool set, unsigned long long *__restrict__ claim)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_sg && sgflag[i]) claim[i] = set ? 0ull : ~0ull;
+}
+__global__ void k_rj_cgeo(const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff, uint32_t n, ulonglong2 *__restrict__ cgeo)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < n) cgeo[c] = make_ulonglong2(coff[c], woff[c + 1] - woff[c]);
 }
 // the lookups of the pass (statistics): queries of unflagged singletons
 __global__ void k_rj_count(const uint8_t *__restrict__ sgflag, size_t n_sg, int n_lanes, unsigned long long *__restrict__ stats)
@@ -1259,14 +1273,21 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 	if ((unsigned int)(hcc[1] & 0xFFFFFFFFull) || hcc[2] > ccap) { *h_status = 1; return MCOM_OK; }
 	const size_t n_cand = (size_t)hcc[2];
 	if (n_cand) {
+		ulonglong2 *cgeo = nullptr;
+		if (mcom_dmalloc(&cgeo, ((size_t)n_contigs + 1) * 16) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "join: contig geometry");
+		struct G2 { mcom_ctx *c; ulonglong2 *p; ~G2() { (void)hipStreamSynchronize(c->stream); mcom_dfree(p); } } g2{ctx, cgeo};
+		MCOM_LAUNCH(k_rj_cgeo, dim3((n_contigs + 255) / 256), dim3(256), 0, ctx->stream, d_coff, d_woff, n_contigs, cgeo);
+		MCOM_LAUNCH(k_rj_unflag, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgflag, n_sg, true, (unsigned long long*)d_claim);
 		McomProfScope ps_(ctx, PROF_REALIGN_READS);
 		const unsigned vb = (unsigned)((n_cand + 255) / 256);
-#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_rj_verify<WW>), dim3(vb), dim3(256), 0, ctx->stream, g, (const unsigned long long*)cand_v, (const uint32_t*)cand_q, n_cand, d_sgbits, d_sgflag, d_rids, \
-		d_cbits, d_coff, d_woff, thr, maxthr, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt); break;
+#define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_rj_verify<WW>), dim3(vb), dim3(256), 0, ctx->stream, g, (const unsigned long long*)cand_v, (const uint32_t*)cand_q, n_cand, d_sgbits, d_rids, \
+		d_cbits, (const ulonglong2*)cgeo, thr, maxthr, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt); break;
 		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
 		default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
+		MCOM_LAUNCH(k_rj_unflag, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgflag, n_sg, false, (unsigned long long*)d_claim);
 		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));                                              // (cgeo goes back to the pool)
 	}
 	if (d_stats) MCOM_LAUNCH(k_rj_count, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgflag, n_sg, n_lanes, sets);
 	if (d_stats) MCOM_LAUNCH(k_stats_fold, dim3(1), dim3(3), 0, ctx->stream, sets, (unsigned long long*)d_stats);
