@@ -254,9 +254,9 @@ def main():
         if not agree(alloc_err is None):
             raise alloc_err if alloc_err is not None else McomError("another rank could not allocate its shard of the reads")
 
-        def make():
+        def make(**kw):
             if not distributed:
-                return Pipeline(reads, L=L, device=local_rank, host_threads=threads)
+                return Pipeline(reads, L=L, device=local_rank, host_threads=threads, **kw)
             return DistPipeline(reads, rank * n_local, n_total, comm, L=L, device=local_rank, host_threads=threads)
         agg, digests, observed = {}, [], {}
 
@@ -306,6 +306,21 @@ def main():
                     raise SystemExit("a step without events gave another result")
             barrier()
             agg["_events_off_s"] = time.perf_counter() - t1
+        # A/B of Stage 2 as a partition-local join (mcomh_params.stage2_join: no index table): the same K steps, untimed for `value`
+        agg["_join_s"] = None
+        if ab_events and not distributed:
+            try:
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    q = make(stage2_join=1); q.pre_process()
+                    if q.result_digest() != digests[0]:
+                        raise SystemExit("a step with the Stage-2 join gave another result")
+                    agg["_join_passes"] = q.stat("join_passes"); agg["_join_fallbacks"] = q.stat("join_fallbacks")
+                    q.close()
+                torch.cuda.synchronize()
+                agg["_join_s"] = time.perf_counter() - t1
+            except McomError as e:
+                agg["_join_err"] = str(e)
         agg["_observed"] = observed
         checked = None
         if check:
@@ -535,6 +550,13 @@ def main():
         if agg.get("_events_off_s"):
             ev_ab = {"ms_per_step_with_events": round(dt / a.steps * 1e3, 2), "ms_per_step_without_events": round(agg["_events_off_s"] / a.steps * 1e3, 2), "steps_each": a.steps,
                      "note": "the timed steps carry the HIP events of the kernel timing (the contract's live measurement); the same K steps repeated without them, same process, same inputs"}
+        join_ab = None
+        if agg.get("_join_s"):
+            join_ab = {"ms_per_step_table": round((agg["_events_off_s"] or dt) / a.steps * 1e3, 2), "ms_per_step_join": round(agg["_join_s"] / a.steps * 1e3, 2), "steps_each": a.steps,
+                       "join_passes": agg.get("_join_passes"), "join_fallbacks": agg.get("_join_fallbacks"),
+                       "note": "Stage 2 on one GPU as a partition-local join (mcomh_params.stage2_join = 1: index entries sorted by partition joined in LDS with the singletons' keys, no table, later "
+                               "passes from deferred candidates; csrc/realign.hip) against the default table route, same steps without events, same digest: built, exact, the same speed -- the "
+                               "table stays the default (DESIGN.md section 3.4)"}
         ppp = a.steps
         res = {
             "metric": "Mreads/s (sketch+index+overlap) on 150bp reads, 1/2/4/8 GPU; bit-exact decompress",
@@ -550,7 +572,7 @@ def main():
                                                                      "claimed-pair range, Stage-2 index shared out by key -- all over RCCL send/recv groups; result replicated, identical to the "
                                                                      "single-GPU result",
                        "scaling_note": ("reads per GPU: 100 M at N = 1 (configs[1]), 62.5 M at N > 1 (configs[3] = 500 M at N = 8); value_strong_100m = configs[1]'s job over the same GPUs. "
-                                        "No multi-GPU node was available to this build: the N > 1 path is exact (tests), its scaling unmeasured (profiles/r04_dist_work.json: per-rank work on one card)"),
+                                        "No multi-GPU node was available to this build: the N > 1 path is exact (tests), its scaling unmeasured (profiles/r05_dist_work.json: per-rank work on one card)"),
                        "fell_back": fell_back, "host_threads": threads,
                        "per_step": {q: round(agg.get(q, 0.0) / ppp, 1) for q in ("rounds", "merge_rounds", "claim_rounds", "passes", "windows", "resketch", "n_sg0", "contigs_bucket",
                                                                                   "contigs_combine", "big_bins", "big_bin_reads", "big_bin_tuples", "dict_builds", "cix_rebuilds",
@@ -566,6 +588,7 @@ def main():
             "value_file_to_streams_order_preserving": e2e_modes.get("order"),
             "value_file_to_streams_paired_end": e2e_modes.get("paired"),
             "value_file_to_streams_gz": e2e_modes.get("gz"),
+            "stage2_join_ab": join_ab,
             "value_strong_100m": strong,
             "whole_step": whole,
             "event_overhead": ev_ab,

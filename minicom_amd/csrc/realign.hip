@@ -1093,11 +1093,10 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
                                                    const uint64_t *__restrict__ sgbits, const uint32_t *__restrict__ rids,
                                                    const uint64_t *__restrict__ cbits, const ulonglong2 *__restrict__ cgeo,
                                                    int thr, int maxthr, unsigned long long *__restrict__ claim, unsigned long long *__restrict__ stats,
-                                                   ulonglong2 *__restrict__ defer, unsigned long long defer_cap, unsigned long long *__restrict__ defer_count, int lmode)
+                                                   ulonglong2 *__restrict__ defer, unsigned long long defer_cap, unsigned long long *__restrict__ defer_count)
 {
-	// lmode: two launches over the list -- first the candidates of dictionary 0 (an eighth of them), then the others.  A read at its true
-	// place nearly always matches there with dictionary 0 too, and once that claim stands every other dictionary's candidate for the same
-	// window is dropped by its key alone (below): in list order -- random in the dictionaries -- two or three of the eight were verified
+	// (measured and dropped: two launches over the list, the candidates of dictionary 0 first so that their claims drop the other
+	// dictionaries' candidates for the same window by key alone -- 4.8 + 9.2 ms against 13.1 in one launch)
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t n_cand = 0, n_pass = 0;
 	const int L = g.L;
@@ -1107,7 +1106,6 @@ __global__ __launch_bounds__(256) void k_rj_verify(CixGeom g, const unsigned lon
 		const uint32_t sg = qv >> 5;
 		const int q = (int)(qv & 31u);
 		const int dir = q / g.nd, l = q - dir * g.nd;
-		if ((l == 0) != (lmode == 0)) break;                                                // (the other launch's candidate)
 		const unsigned long long v = cand_v[t];
 		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
 		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
@@ -1285,10 +1283,9 @@ extern "C" int mcom_realign_join(mcom_ctx *ctx, uint64_t geom, const uint32_t *d
 		McomProfScope ps_(ctx, PROF_REALIGN_READS);
 		const unsigned vb = (unsigned)((n_cand + 255) / 256);
 #define MCOM_CASE(WW) case WW: MCOM_LAUNCH((k_rj_verify<WW>), dim3(vb), dim3(256), 0, ctx->stream, g, (const unsigned long long*)cand_v, (const uint32_t*)cand_q, n_cand, d_sgbits, d_rids, \
-		d_cbits, (const ulonglong2*)cgeo, thr, maxthr, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt, lmode); break;
-		for (int lmode = 0; lmode < 2; ++lmode)
-			switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
-			default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
+		d_cbits, (const ulonglong2*)cgeo, thr, maxthr, (unsigned long long*)d_claim, d_stats ? sets : nullptr, (ulonglong2*)d_defer, (unsigned long long)defer_cap, d_cnt); break;
+		switch (W) { MCOM_CASE(1) MCOM_CASE(2) MCOM_CASE(3) MCOM_CASE(4) MCOM_CASE(5) MCOM_CASE(6) MCOM_CASE(7) MCOM_CASE(8)
+		default: return mcom_fail(ctx, MCOM_E_ARG, "unsupported read length"); }
 #undef MCOM_CASE
 		MCOM_LAUNCH(k_rj_unflag, dim3((unsigned)((n_sg + 255) / 256)), dim3(256), 0, ctx->stream, d_sgflag, n_sg, false, (unsigned long long*)d_claim);
 		MCOM_LAUNCH_CHECK(ctx);

@@ -302,7 +302,7 @@ struct mcomh_pipeline {
 	bool stage2_uploaded = false;
 	// Stage 2 as a partition-local join (round 5, csrc/realign.hip): the index entries sorted by partition, kept until the first pass has
 	// joined them with the singletons' keys (jn_entries); what that pass defers is all the later passes need (jn_deferred)
-	bool stage2_table = false;                                         // true: the table of rounds 1-4 in every pass (A/B switch)
+	bool stage2_table = true;                                          // false: the partition-local join (mcomh_params.stage2_join)
 	DevBuf<uint32_t> jn_keyA, jn_keyB, jn_pstart, jn_map; DevBuf<uint64_t> jn_slotA, jn_slotB, jn_defer;
 	const uint32_t *jn_ek = nullptr; const uint64_t *jn_es = nullptr;
 	bool jn_entries = false, jn_deferred = false; uint64_t jn_ndefer = 0, jn_nwords = 0;
@@ -486,7 +486,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->host_dump = pp->host_dump == 1;
 	p->stream_sets = pp->stream_sets > 1 ? std::min(pp->stream_sets, 4096) : 1;
 	p->overlap_screen = pp->overlap_screen == 1;
-	p->stage2_table = pp->stage2_table == 1;
+	p->stage2_table = pp->stage2_join != 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
 	if (p->k > 31 || p->k < 11 || p->rw < 1 || p->rw > 128) { mcomh_destroy(p); return MCOM_E_ARG; }

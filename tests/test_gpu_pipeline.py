@@ -228,9 +228,9 @@ def test_packed_rows_with_forwarded_minimizers_equal_resketching():
 
 @pytest.mark.parametrize("kind", ["uniform_150", "uniform_100", "repeats"])
 def test_stage2_join_equals_stage2_through_the_table(kind):
-    """Round 5: Stage 2 on one GPU is a partition-local join of the index entries with the singletons' keys (no table; later passes
-    from the candidates the first pass deferred) -- csrc/realign.hip, mcom_realign_join / mcom_realign_deferred.  stage2_table = 1
-    runs realign_hash_search's lookups through the table of rounds 1-4 in every pass (kthread_hash_realign.c:316-508 either way): the
+    """Round 5: Stage 2 on one GPU can run as a partition-local join of the index entries with the singletons' keys (stage2_join = 1: no
+    table; later passes from the candidates the first pass deferred) -- csrc/realign.hip, mcom_realign_join / mcom_realign_deferred.  The
+    default runs realign_hash_search's lookups through the table in every pass (kthread_hash_realign.c:316-508 either way): the
     whole result must be the same, pass for pass (the digest covers strings, member lists in appending order, offsets and lists).
     Repeat-rich reads have dictionary bins above maxsearch: there the join steps back by itself and builds the table."""
     from minicom_amd import synth
@@ -240,8 +240,8 @@ def test_stage2_join_equals_stage2_through_the_table(kind):
     else:
         L = int(kind.split("_")[1])
         reads = np.concatenate([synth.synth_reads(311, 1_500_000, L, sub_rate=0.02), synth.synth_reads(312, 4000, L, plumbing=True)])
-    a = Pipeline(reads, host_threads=4); a.pre_process()
-    b = Pipeline(reads, host_threads=4, stage2_table=1); b.pre_process()
+    a = Pipeline(reads, host_threads=4, stage2_join=1); a.pre_process()
+    b = Pipeline(reads, host_threads=4); b.pre_process()
     assert a.result_digest() == b.result_digest()
     assert b.stat("join_passes") == 0 and a.stat("passes") == b.stat("passes") >= 2
     if kind == "repeats":
