@@ -14,6 +14,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _oracle_digest(n, L, seed):
+    """The sequential oracle's result digest of this very read set (oracle/digest_main.c, run in the build container: hours of one core), when
+    tests/golden/scale_digests.json holds it; None otherwise."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scale_digests.json")
+    if not os.path.exists(path):
+        return None
+    for e in json.load(open(path))["runs"]:
+        if (e["n"], e["L"], e["seed"], e.get("coverage", 30)) == (n, L, seed, 30):
+            return [int(v) for v in e["digest"]]
+    return None
+
+
 def _run_checked(n, L, seed, coverage=30, stats=None):
     import torch
     import minicom_amd
@@ -47,6 +61,11 @@ def test_config1_100m_reads_of_150_bases():
     n, L = 100_000_000, 150
     res, d1, d2 = _run_checked(n, L, 1002)
     assert d1 == d2                                                        # deterministic, bit for bit
+    want = _oracle_digest(n, L, 1002)
+    if want is not None:                                                   # ... and equal to the sequential oracle's result on the same 100 M reads
+        assert list(d1) == want
+    else:
+        print("(tests/golden/scale_digests.json has no oracle digest for this set: properties only)", flush=True)
     assert res["n_reads"] == n and res["members"] + res["n_sg"] + sum(res["n_" + k] for k in ("allA", "allT", "allN", "fpA", "fpT", "fpN", "Nfile")) == n
     assert res["members"] > 0.8 * n and res["n_contigs"] > 1_000_000       # 30x coverage: most reads end up in contigs
     assert res["max_mismatch"] <= L // 2 and res["mean_mismatch"] < 0.02 * L
@@ -113,6 +132,11 @@ def test_config2_67m_reads_of_100_bases():
     n, L = 67_000_000, 100
     res, d1, d2 = _run_checked(n, L, 1003)
     assert d1 == d2
+    want = _oracle_digest(n, L, 1003)
+    if want is not None:
+        assert list(d1) == want
+    else:
+        print("(tests/golden/scale_digests.json has no oracle digest for this set: properties only)", flush=True)
     assert res["members"] > 0.7 * n and res["n_contigs"] > 500_000
     assert res["max_mismatch"] <= L // 2 and res["mean_mismatch"] < 0.02 * L
 
