@@ -68,6 +68,7 @@ def lib():
     L.mcomo_contig_members.restype = vp; L.mcomo_contig_members.argtypes = [vp, sz]
     L.mcomo_counter.restype = sz; L.mcomo_counter.argtypes = [vp, cp]
     L.mcomo_list.restype = vp; L.mcomo_list.argtypes = [vp, cp, C.POINTER(sz)]
+    L.mcomo_construct_ref2.restype = C.c_long; L.mcomo_construct_ref2.argtypes = [vp, sz, i32, vp, sz, vp, sz]
     L.mcomo_result_digest.restype = None; L.mcomo_result_digest.argtypes = [vp, C.POINTER(u64)]
     L.mcomo_synth_reads.restype = None
     L.mcomo_synth_reads.argtypes = [u64, u64, i32, i32, C.c_double, u64, u64, vp]
@@ -132,6 +133,18 @@ def match_pro(s0: bytes, s1: bytes, i: int, j: int) -> int:
 
 def encode_byte(seq: bytes, ref: bytes, pos: int, d: int, L: int) -> int:
     return int(lib().mcomo_encode_byte(seq, ref, pos, d, L))
+
+
+def construct_ref2(reads: np.ndarray, members) -> bytes:
+    """construct_ref2 (kthread_cb.c:105-218) of one member list over reads [n, L]: the consensus string."""
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    n, L = reads.shape
+    mem = np.array(members, dtype=np.uint64)
+    cap = int(((int(mem.max()) & 0xFFFFFFFF) >> 1) + 2 * L + 8)
+    buf = C.create_string_buffer(cap)
+    ln = lib().mcomo_construct_ref2(_ptr(reads), n, L, _ptr(mem), len(mem), buf, cap)
+    assert ln >= 0
+    return buf.raw[:ln]
 
 
 def string_to_bits(s: bytes) -> np.ndarray:

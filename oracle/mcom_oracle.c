@@ -634,6 +634,26 @@ static void construct_ref2(mcomo_ctx *c, contig_t *p)
 	free(t); free(cnt);
 }
 
+/* construct_ref2 alone, for a test that has members and reads but no pipeline around them: members [m] (rid << 32 | offset << 1 | dir, sorted
+ * in place by cmpcluster2 as :107 does), reads [n][L]; the consensus goes to ref (NUL-terminated; cap bytes); returns its length or -1 */
+long mcomo_construct_ref2(const char *reads, size_t n, int L, uint64_t *members, size_t m, char *ref, size_t cap)
+{
+	if (!m) return -1;
+	init_tables();
+	mcomo_ctx c; memset(&c, 0, sizeof c);
+	c.n = n; c.L = L;
+	c.seq = (char*)malloc(n * (size_t)(L + 1));
+	for (size_t i = 0; i < n; ++i) { memcpy(c.seq + i * (size_t)(L + 1), reads + i * (size_t)L, (size_t)L); c.seq[i * (size_t)(L + 1) + L] = 0; }
+	contig_t p; memset(&p, 0, sizeof p);
+	p.a = members; p.n = p.m = m;
+	construct_ref2(&c, &p);
+	const size_t len = strlen(p.ref);
+	long out = -1;
+	if (len + 1 <= cap) { memcpy(ref, p.ref, len + 1); out = (long)len; }
+	free(p.ref); free(c.seq);
+	return out;
+}
+
 /* ---- one merge round: find_next for every unflagged contig, then copy the rest
  *                                                     kthread_cb.c:220-395, :397-434, :502-568 */
 static void merge_round(mcomo_ctx *c, int index)

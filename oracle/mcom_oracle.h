@@ -98,6 +98,10 @@ const uint64_t *mcomo_contig_members(const mcomo_ctx *c, size_t i);
 size_t mcomo_counter(const mcomo_ctx *c, const char *name);
 const uint32_t *mcomo_list(const mcomo_ctx *c, const char *name, size_t *n);
 
+/* construct_ref2 (kthread_cb.c:105-218) on its own: members [m] are sorted in place (cmpcluster2, :107), reads [n][L]; returns the
+ * consensus' length (ref NUL-terminated, cap bytes) or -1 */
+long mcomo_construct_ref2(const char *reads, size_t n, int L, uint64_t *members, size_t m, char *ref, size_t cap);
+
 /* the product's mcomh_result_digest restated over the oracle's contig set (include/mcom_host.h): equal digests = equal
  * contig strings, member lists, offsets and id lists */
 void mcomo_result_digest(const mcomo_ctx *c, uint64_t out[8]);

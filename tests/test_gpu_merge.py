@@ -223,6 +223,11 @@ def test_merge_round_pieces_against_numpy(ctx, L):
     part = ctx.merge_consensus_jobs(d_packed, jm, jmoff, jroff, tot[1], L, jobs=d_jobs, seq=d_seq, soff=d_soff)
     assert full.cpu().numpy().tobytes() == b"".join(want_refs)
     assert torch.equal(full, part)                                               # counting only the overlap changes nothing
+    # ... and the oracle's construct_ref2 (oracle/mcom_oracle.c, pinned on the reference's stage dumps) says the same, list by list: the numpy
+    # restatement above and the kernels are not just each other's mirror
+    import oracle
+    for lst, want in list(zip(want_m, want_refs))[::3]:
+        assert oracle.construct_ref2(reads, lst) == want
     # units deeper than the bit-sliced counters hold go tile by tile through the wave-per-tile kernel: the same consensus
     ctx.set_consensus_capacity(3)
     try:
