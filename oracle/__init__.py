@@ -140,7 +140,7 @@ def construct_ref2(reads: np.ndarray, members) -> bytes:
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     n, L = reads.shape
     mem = np.array(members, dtype=np.uint64)
-    cap = int(((int(mem.max()) & 0xFFFFFFFF) >> 1) + 2 * L + 8)
+    cap = int(((mem & np.uint64(0xFFFFFFFF)) >> np.uint64(1)).max()) + 2 * L + 8
     buf = C.create_string_buffer(cap)
     ln = lib().mcomo_construct_ref2(_ptr(reads), n, L, _ptr(mem), len(mem), buf, cap)
     assert ln >= 0
