@@ -98,15 +98,20 @@ __global__ __launch_bounds__(64) void k_flag_sort(mcom_mm128 *__restrict__ rec, 
 //     insertion loop, no second index array;
 //   * larger ranges go on the stack for the next level, as in the reference (ksort.h:146-151).
 #define FST_STACK 96
+struct FsTok { uint16_t b, e; uint32_t shift; };                             // a pending range of a bucket of at most 65 535 records
 __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__restrict__ in, mcom_mm128 *__restrict__ out,
                                                          const uint32_t *__restrict__ bstart, uint32_t nr, uint32_t lds_cap,
                                                          uint32_t *__restrict__ overflow)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	uint32_t *bb = (uint32_t*)smem, *be = bb + 256;                           // fill pointer / end of every bin of the current level
-	FsRange *stk = (FsRange*)(be + 256);
-	uint64_t *KW = (uint64_t*)(stk + FST_STACK);                             // keys of a window of 192 positions
-	uint16_t *I = (uint16_t*)(KW + 192);                                     // [cap] which record of the bucket stands at a position
+	// (round 5: what a bucket needs beside its tokens went from 4 736 to 3 328 bytes -- the LDS a bucket takes decides how many buckets a CU
+	// walks at once, and the walk is nothing but latency: the key window of the finishing step lies over the fill pointers, which are dead by
+	// then -- bb[q] == be[q] for every bin once the permutation is done --, and a pending range is 8 bytes)
+	uint64_t *KW = (uint64_t*)smem;                                          // keys of a window of 192 positions (finish_small only)
+	uint32_t *bb = (uint32_t*)smem;                                          // fill pointer of every bin of the current level (permutation only)
+	uint32_t *be = (uint32_t*)(KW + 192);                                    // end of every bin of the current level
+	FsTok *stk = (FsTok*)(be + 256);
+	uint16_t *I = (uint16_t*)(stk + FST_STACK);                              // [cap] which record of the bucket stands at a position
 	uint8_t *D = (uint8_t*)(I + lds_cap);                                    // [cap] its digit at the current level
 	const uint32_t r = blockIdx.x;
 	if (r >= nr) return;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 	if (n > lds_cap || n > 65535u) {                                           // does not fit: the record form, in HBM, by one lane
 		for (uint32_t i = lane; i < n; i += 64) out[beg + i] = in[beg + i];
 		__threadfence(); __syncthreads();
-		if (lane == 0) flag_sort_range(out + beg, n, bb, be, stk, FST_STACK, overflow);
+		if (lane == 0) flag_sort_range(out + beg, n, bb, be, (FsRange*)stk, (uint32_t)(FST_STACK * sizeof(FsTok) / sizeof(FsRange)), overflow);
 		return;
 	}
 	const mcom_mm128 *rec = in + beg;
@@ -157,10 +162,10 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 	};
 	if (n <= 64) { finish_small(0, n, false); return; }                        // radix_sort (ksort.h:153-157)
 	uint32_t sp = 1;                                                           // uniform: every lane keeps the same count
-	if (lane == 0) stk[0] = FsRange{0, n, 56};
+	if (lane == 0) stk[0] = FsTok{0, (uint16_t)n, 56};
 	__syncthreads();
 	while (sp) {
-		const FsRange rg = stk[--sp];
+		const FsTok rg = stk[--sp];
 		const uint32_t rb = rg.b, re = rg.e, s = rg.shift;
 		__syncthreads();                                                       // everybody has read the entry before a push reuses it
 		// rs_sort (ksort.h:123-152): digits, histogram and bin bounds by all lanes
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 		// nothing ever writes into bin q ahead of bb[q] (a cycle closes AT bb[q]) -- so the first element of a bin that is not in place
 		// is found by all lanes at once.  Lane 0 then goes from cycle to cycle on its own and asks the wave again only after eight
 		// in-place elements in a row.  The cycles themselves stay with one lane: they are the reference's order of equal keys.
+		// (Round 5, measured and dropped: lane 0 going from BIN to bin on its own as well -- a level has ~100 bins that hold something, each
+		// costs two barriers and a scan -- 11.5 -> 14.5 ms per step: what the wave does per bin is scalar code, what lane 0 does instead is not.)
 		for (int q0 = 0; q0 < 256; q0 += 64) {
 			uint64_t live = __ballot(bb[q0 + lane] != be[q0 + lane]);             // uniform
 			while (live) {
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(64) void k_flag_sort_tokens(const mcom_mm128 *__res
 				const uint64_t bm = __ballot(big);
 				if (big) {
 					const uint32_t at = sp + (uint32_t)__popcll(bm & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-					if (at < FST_STACK) stk[at] = FsRange{b0, e0, nxt}; else *overflow = 1;
+					if (at < FST_STACK) stk[at] = FsTok{(uint16_t)b0, (uint16_t)e0, nxt}; else *overflow = 1;
 				}
 				sp += (uint32_t)__popcll(bm);
 			}
@@ -262,7 +269,7 @@ int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_
 {
 	if (nr == 0) return MCOM_OK;
 	(void)low_bits;                                                            // (the records of a bucket share their low bits: their order by x is the order of the keys)
-	const size_t fixed = 2 * 256 * 4 + FST_STACK * sizeof(FsRange) + 192 * 8;
+	const size_t fixed = 192 * 8 + 256 * 4 + FST_STACK * sizeof(FsTok);
 	size_t cap = max_range < 64 ? 64 : max_range;
 	const size_t lds_max = 150 * 1024;
 	if (cap > 65535) cap = 65535;
