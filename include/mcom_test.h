@@ -51,6 +51,10 @@ int  mcomh_test_special_capacity(struct mcomh_pipeline *p, uint32_t first, uint3
  * the sequential reader, with the same rows.  Work items (groups of members) of the last file the parallel route read to its end, 0 when
  * the last file went to the sequential reader: lets a test tell which of the two it has checked.                                    */
 long mcomh_test_gz_items(void);
+/* The member-parallel route decodes with its own DEFLATE decoder (host/mcom_inflate.cpp), not zlib: one gzip member at in[0 .. in_n) into
+ * out[0 .. out_cap).  0 = decoded (*in_used bytes were the member, *out_n bytes came out, CRC-32 and ISIZE checked), 1 = out is too
+ * small, < 0 = truncated (-1) / not a valid member (-2).  For tests that hold it against zlib.                                        */
+int  mcomh_test_gunzip(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_cap, size_t *in_used, size_t *out_n);
 
 #ifdef __cplusplus
 }

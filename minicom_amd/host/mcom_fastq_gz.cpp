@@ -24,6 +24,8 @@
 #include "../../include/mcom.h"
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
+#include <emmintrin.h>
+#include "mcom_inflate.hpp"
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -96,11 +98,32 @@ inline const char *record_in(const char *p, const char *e, int L)
 	if (q + L >= e || q[L] != '\n') return nullptr;
 	return q + L + 1;
 }
+// does a sequence line hold anything but A C G T N?  (sixteen characters at a time; the last sixteen overlap the ones before)
+inline bool not_acgtn(const unsigned char *s, int len)
+{
+	if (len < 16) { bool bad = false; for (int q = 0; q < len; ++q) { const unsigned char c = s[q]; bad |= (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N'); } return bad; }
+	const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T'), n = _mm_set1_epi8('N');
+	__m128i ok = _mm_set1_epi8((char)0xFF);
+	auto step = [&](const unsigned char *p) {
+		const __m128i v = _mm_loadu_si128((const __m128i*)p);
+		ok = _mm_and_si128(ok, _mm_or_si128(_mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, a), _mm_cmpeq_epi8(v, c)), _mm_or_si128(_mm_cmpeq_epi8(v, g), _mm_cmpeq_epi8(v, t))), _mm_cmpeq_epi8(v, n)));
+	};
+	int q = 0;
+	for (; q + 16 <= len; q += 16) step(s + q);
+	if (q < len) step(s + len - 16);
+	return _mm_movemask_epi8(ok) != 0xFFFF;
+}
 struct Item {
 	size_t begin = 0, end = 0;                                                  // compressed bytes [begin, end): whole members
-	std::vector<char> text;                                                    // what they inflate to (sized once, to the ISIZE sum of its members when that is known)
+	struct Text {                                                              // what they inflate to: the buffer the decoder wrote into, as it is
+		std::unique_ptr<char[]> p; size_t n = 0;
+		const char *data() const { return p.get(); }
+		size_t size() const { return n; }
+		bool empty() const { return n == 0; }
+		void drop() { p.reset(); n = 0; }
+	} text;
 	size_t first = 0;                                                           // offset of the first record that starts in this text (text.size(): none)
-	std::vector<unsigned char> rows; size_t n_rows = 0;                         // the sequence lines of the records that start in this text
+	std::unique_ptr<unsigned char[]> rows; size_t n_rows = 0;                   // the sequence lines of the records that start in this text
 	int state = 0;                                                              // 0 waiting, 1 text there, 2 rows there, 3 sent
 };
 }  // namespace
@@ -190,34 +213,23 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			// inflate the item's members
 			in.resize(it.end - it.begin);
 			if (!read_at(fd.f, in.data(), in.size(), it.begin)) { give_up(MCOM_E_ARG, "read error"); return; }
-			// (a vector's resize clears what it adds -- a second pass over every byte of text; the buffer grows by doubling and is cut to size once)
+			// every member of the item, one behind the other, by the decoder of mcom_inflate.cpp (header, deflate stream, CRC-32 and ISIZE checked;
+			// a member must end where the next begins).  The text buffer grows by doubling when a member does not fit; the member is then decoded again.
 			size_t tcap = std::max<size_t>(in.size() * 6, (size_t)1 << 20), have = 0;
-			std::unique_ptr<char[]> tbuf(new char[tcap]);
-			z_stream z; memset(&z, 0, sizeof z);
-			if (inflateInit2(&z, 15 + 16) != Z_OK) { give_up(MCOM_E_NOMEM, "zlib"); return; }
-			z.next_in = in.data(); z.avail_in = (uInt)0;
-			size_t fed = 0;
+			std::unique_ptr<char[]> tbuf(new char[tcap + 16]);
 			bool bad = false;
-			for (;;) {
-				if (z.avail_in == 0 && fed < in.size()) { const size_t k = std::min<size_t>(in.size() - fed, (size_t)1 << 30); z.next_in = in.data() + fed; z.avail_in = (uInt)k; fed += k; }
-				if (tcap - have < ((size_t)1 << 20)) { std::unique_ptr<char[]> nb(new char[2 * tcap]); memcpy(nb.get(), tbuf.get(), have); tbuf.swap(nb); tcap *= 2; }
-				const size_t room = std::min<size_t>(tcap - have, (size_t)1 << 30);
-				z.next_out = (unsigned char*)tbuf.get() + have; z.avail_out = (uInt)room;
-				const int rc = inflate(&z, Z_NO_FLUSH);
-				have += room - z.avail_out;
-				if (rc == Z_STREAM_END) {
-					const size_t used = fed - z.avail_in;                          // the member ended here
-					if (used == in.size()) break;
-					if (inflateReset(&z) != Z_OK) { bad = true; break; }           // the next member of the item follows
+			for (size_t at = 0; at < in.size();) {
+				size_t used = 0, got = 0;
+				const int rc = mcom_gunzip_member(in.data() + at, in.size() - at, (uint8_t*)tbuf.get() + have, tcap - have, &used, &got);
+				if (rc == MCOM_INFLATE_ROOM) {
+					std::unique_ptr<char[]> nb(new char[2 * tcap + 16]); memcpy(nb.get(), tbuf.get(), have); tbuf.swap(nb); tcap *= 2;
 					continue;
 				}
-				if (rc != Z_OK && rc != Z_BUF_ERROR) { bad = true; break; }
-				if (rc == Z_BUF_ERROR && z.avail_in == 0 && fed == in.size()) { bad = true; break; }   // the data ran out inside a member: the item does not end at a member boundary
+				if (rc != MCOM_INFLATE_OK) { bad = true; break; }
+				at += used; have += got;
 			}
-			inflateEnd(&z);
 			if (bad) { give_up(1, "the members do not tile the file"); return; }
-			it.text.assign(tbuf.get(), tbuf.get() + have);
-			tbuf.reset();
+			it.text.p = std::move(tbuf); it.text.n = have;
 			// the read length (item 0, from its first record) and this text's first record boundary
 			const char *tb = it.text.data(), *te = tb + it.text.size();
 			int len;
@@ -245,15 +257,16 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			{ std::lock_guard<std::mutex> g(mu); it.state = 1; }
 			cv.notify_all();
 			// parse: the records that start in this text; the last one may end in the following texts
-			it.rows.clear(); it.n_rows = 0;
-			it.rows.reserve((it.text.size() / (size_t)(2 * len + 6) + 2) * (size_t)len);
+			it.n_rows = 0;
+			const size_t row_cap = it.text.size() / (size_t)(2 * len + 5) + 2;       // (a record is at least "@\n" + L + "\n+\n" + L + "\n")
+			it.rows.reset(new unsigned char[row_cap * (size_t)len + 16]);
 			size_t pos = it.first;
 			unsigned bad_char = 0;
 			auto take = [&](const char *seq) {
-				const size_t at = it.rows.size();
-				it.rows.resize(at + (size_t)len);
-				memcpy(it.rows.data() + at, seq, (size_t)len);
-				for (int q = 0; q < len; ++q) { const char c = seq[q]; bad_char |= (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N'); }
+				if (it.n_rows >= row_cap) { bad_char |= 2u; return; }
+				unsigned char *dst = it.rows.get() + it.n_rows * (size_t)len;
+				memcpy(dst, seq, (size_t)len);
+				bad_char |= not_acgtn(dst, len) ? 1u : 0u;
 				++it.n_rows;
 			};
 			while (pos < it.text.size()) {
@@ -290,6 +303,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 				// this text ends exactly at a record's end: the next text must start with a record (its first == 0), checked by its own worker's
 				// search (a record at its first byte is tried first); nothing to do here
 			}
+			if (bad_char & 2u) { give_up(1, "more records than the text has room for"); return; }
 			if (bad_char) { give_up(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)"); return; }
 			{ std::lock_guard<std::mutex> g(mu); it.state = 2; }
 			cv.notify_all();
@@ -311,7 +325,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			const size_t bytes = it.n_rows * (size_t)len;
 			if (bytes && to_host) {
 				if (total + it.n_rows > host_cap) { total += it.n_rows; bail(MCOM_E_OVERFLOW, "more reads than the caller has room for"); break; }
-				memcpy(host_out + total * (size_t)len, it.rows.data(), bytes);
+				memcpy(host_out + total * (size_t)len, it.rows.get(), bytes);
 				total += it.n_rows;
 			} else if (bytes) {
 				if (bytes > pin_cap) {
@@ -330,13 +344,13 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 					dev = nd; dev_cap = want;
 				}
 				if (busy[cur]) { if (hipEventSynchronize(ev[cur]) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; } busy[cur] = false; }
-				memcpy(pin[cur], it.rows.data(), bytes);
+				memcpy(pin[cur], it.rows.get(), bytes);
 				if (hipMemcpyAsync(dev + total * (size_t)len, pin[cur], bytes, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(ev[cur], cs) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; }
 				busy[cur] = true; cur ^= 1;
 				total += it.n_rows;
 			}
-			std::vector<unsigned char>().swap(it.rows);
-			if (i) std::vector<char>().swap(items[i - 1].text);                    // (item i's rows are made: nobody reads the text before it any more)
+			it.rows.reset();
+			if (i) items[i - 1].text.drop();                    // (item i's rows are made: nobody reads the text before it any more)
 			{ std::lock_guard<std::mutex> g(mu); it.state = 3; sent = i + 1; }
 			cv.notify_all();
 		}

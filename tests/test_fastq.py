@@ -147,6 +147,67 @@ def test_gzip_files_of_many_members_are_read_by_all_cores_and_equal_the_plain_fi
     assert np.array_equal(read_fastq(str(tmp_path / "x.fa.gz")), reads[:30000])
 
 
+def test_the_member_decoder_against_zlib():
+    """host/mcom_inflate.cpp (the DEFLATE decoder of the member-parallel route: 64-bit bit buffer, one look-up per symbol, matches copied
+    by words, CRC-32 by carry-less multiplication) against zlib as the checker: every compression level and strategy (stored, fixed and
+    dynamic Huffman blocks, Huffman-only, run-length), empty / tiny / incompressible / highly repetitive / FASTQ-like inputs, output
+    buffers that fit exactly and not at all, members followed by other bytes, every kind of truncation; and flipped bits and random bytes
+    behind a valid header must give an error code -- the decoder never trusts its input (the reference reads through zlib's gzread,
+    bseq.c:19-36, which has the same obligations)."""
+    import ctypes as C
+    import random
+    import zlib
+    from minicom_amd.pipeline import load_host_library
+    lib = load_host_library()
+    lib.mcomh_test_gunzip.restype = C.c_int
+    lib.mcomh_test_gunzip.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def gun(data, cap):
+        out = C.create_string_buffer(max(cap, 1))
+        u, n = C.c_size_t(), C.c_size_t()
+        rc = lib.mcomh_test_gunzip(data, len(data), out, cap, C.byref(u), C.byref(n))
+        return rc, u.value, out.raw[:n.value]
+
+    def gz(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, header=b""):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+        return co.compress(data) + co.flush()
+    rng = random.Random(5)
+    r = np.random.default_rng(3)
+    fq = b"".join(b"@A00:1:HX:1:1101:%d:%d 1:N:0:ACGT\n" % (1000 + i % 3000, i) + np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, 150)].tobytes() + b"\n+\n" +
+                  np.frombuffer(b"FFFFFFF:,#", dtype=np.uint8)[r.integers(0, 10, 150)].tobytes() + b"\n" for i in range(3000))
+    cases = [b"", b"a", b"abc" * 5, bytes(1000), os.urandom(70000), b"ACGT" * 20000, fq, bytes(range(256)) * 300,
+             b"".join(bytes([rng.randrange(4) + 65]) * rng.randrange(1, 400) for _ in range(3000))]
+    for ci, data in enumerate(cases):
+        for lvl in (0, 1, 4, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                c = gz(data, lvl, strat)
+                for cap in (len(data), len(data) + 1000):
+                    assert gun(c + b"TRAIL", cap) == (0, len(c), data), (ci, lvl, strat, cap)
+                if data:
+                    assert gun(c, len(data) - 1)[0] == 1, (ci, lvl, strat)              # no room: said so, nothing written behind the buffer
+                for cut in (1, 5, len(c) // 2, len(c) - 9, len(c) - 1):
+                    if 0 < cut < len(c):
+                        assert gun(c[:cut], len(data) + 100)[0] < 0, (ci, lvl, strat, cut)
+    # header fields: extra, name, comment, header CRC
+    with io.BytesIO() as b:
+        with gzip.GzipFile(filename="reads.fastq", mode="wb", fileobj=b, compresslevel=6) as g:
+            g.write(fq)
+        named = b.getvalue()
+    assert gun(named, len(fq)) == (0, len(named), fq)
+    body = gz(fq, 6)[10:]
+    fancy = b"\x1f\x8b\x08\x1e\0\0\0\0\0\x03" + b"\x05\x00ab\x01\x00z" + b"name\0" + b"comment\0" + b"\x12\x34" + body
+    assert gun(fancy, len(fq)) == (0, len(fancy), fq)
+    # damaged members: an error code every time (the CRC catches what still decodes)
+    c = bytearray(gz(fq, 6))
+    for _ in range(1500):
+        d = bytearray(c)
+        for _ in range(rng.randrange(1, 4)):
+            d[rng.randrange(10, len(d))] ^= 1 << rng.randrange(8)
+        assert gun(bytes(d), len(fq) + rng.randrange(0, 2000))[0] != 0
+    for _ in range(1500):                                                          # random bytes as a deflate stream: any answer but a fault
+        gun(b"\x1f\x8b\x08\x00\0\0\0\0\0\x03" + os.urandom(rng.randrange(1, 3000)), rng.randrange(0, 100000))
+
+
 @pytest.mark.gpu
 def test_pipeline_from_a_gzip_file_of_many_members(tmp_path):
     """file -> HBM through the parallel gzip route -> pipeline = the pipeline over the array"""
