@@ -31,6 +31,9 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -85,17 +88,28 @@ bool inflates_here(const unsigned char *p, size_t n)
 	inflateEnd(&z);
 	return text;
 }
-inline const char *next_line(const char *p, const char *e) { const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p)); return nl ? nl + 1 : e; }
-// a record of the shape at p, all of it inside [p, e): its end; nullptr: not one (or not all of it there)
-inline const char *record_in(const char *p, const char *e, int L)
+// the start of the line behind the one p is in (e: there is none).  Names and '+' lines are short: sixteen bytes at a time in place of a call
+inline const char *next_line(const char *p, const char *e)
+{
+	while (e - p >= 16) {
+		const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)p), _mm_set1_epi8('\n')));
+		if (m) return p + __builtin_ctz((unsigned)m) + 1;
+		p += 16;
+	}
+	const char *nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+	return nl ? nl + 1 : e;
+}
+// a record of the shape at p, all of it inside [p, e): its end, *seq = its sequence line; nullptr: not one (or not all of it there)
+inline const char *record_in(const char *p, const char *e, int L, const char **seq = nullptr)
 {
 	if (p >= e || *p != '@') return nullptr;
 	const char *s = next_line(p, e);
 	if (s + L >= e || s[L] != '\n') return nullptr;
 	const char *plus = s + L + 1;
 	if (plus >= e || *plus != '+') return nullptr;
-	const char *q = next_line(plus, e);
+	const char *q = plus + 1 < e && plus[1] == '\n' ? plus + 2 : next_line(plus, e);
 	if (q + L >= e || q[L] != '\n') return nullptr;
+	if (seq) *seq = s;
 	return q + L + 1;
 }
 // does a sequence line hold anything but A C G T N?  (sixteen characters at a time; the last sixteen overlap the ones before)
@@ -113,17 +127,42 @@ inline bool not_acgtn(const unsigned char *s, int len)
 	if (q < len) step(s + len - 16);
 	return _mm_movemask_epi8(ok) != 0xFFFF;
 }
+// Buffers that go round: the texts and the rows of a file are tens of gigabytes that would otherwise be fresh pages every time (a page fault
+// per 4 KB, under one lock for all threads); a window of items bounds how many are out at once.  `pinned`: page-locked blocks the uploader's
+// copies can leave from directly.
+struct Pool {
+	std::mutex m; std::vector<std::pair<void*, size_t>> idle; bool pinned = false; size_t made = 0;
+	void *get(size_t want, size_t *cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(m);
+			size_t best = idle.size();
+			for (size_t i = 0; i < idle.size(); ++i) if (idle[i].second >= want && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+			if (best < idle.size()) { void *p = idle[best].first; *cap = idle[best].second; idle[best] = idle.back(); idle.pop_back(); return p; }
+			if (idle.size() > 8) { void *p = idle.back().first; idle.pop_back(); release(p); }      // (none fits and plenty lie around: do not hoard)
+		}
+		const size_t c = want + want / 8 + 4096;
+		void *p = nullptr;
+		if (pinned) { if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) return nullptr; }
+		else p = malloc(c);
+		if (p) { std::lock_guard<std::mutex> g(m); ++made; }
+		*cap = c;
+		return p;
+	}
+	void put(void *p, size_t cap) { if (!p) return; std::lock_guard<std::mutex> g(m); idle.emplace_back(p, cap); }
+	void release(void *p) { if (pinned) (void)hipHostFree(p); else free(p); }
+	~Pool() { for (auto &b : idle) release(b.first); }
+};
 struct Item {
 	size_t begin = 0, end = 0;                                                  // compressed bytes [begin, end): whole members
 	struct Text {                                                              // what they inflate to: the buffer the decoder wrote into, as it is
-		std::unique_ptr<char[]> p; size_t n = 0;
-		const char *data() const { return p.get(); }
+		char *p = nullptr; size_t cap = 0, n = 0;
+		const char *data() const { return p; }
 		size_t size() const { return n; }
 		bool empty() const { return n == 0; }
-		void drop() { p.reset(); n = 0; }
 	} text;
 	size_t first = 0;                                                           // offset of the first record that starts in this text (text.size(): none)
-	std::unique_ptr<unsigned char[]> rows; size_t n_rows = 0;                   // the sequence lines of the records that start in this text
+	unsigned char *rows = nullptr; size_t rows_cap = 0, n_rows = 0;             // the sequence lines of the records that start in this text
 	int state = 0;                                                              // 0 waiting, 1 text there, 2 rows there, 3 sent
 };
 }  // namespace
@@ -136,6 +175,8 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 	*n_out = 0;
 	g_last_items = 0;
 	if (n_members_out) *n_members_out = 0;
+	const auto wall0 = std::chrono::steady_clock::now();
+	auto wall = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); };
 	Fd fd{open(path, O_RDONLY)};
 	if (fd.f < 0) return 0;
 	struct stat st;
@@ -150,7 +191,9 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 	std::vector<size_t> starts;                                                 // member starts that bound the work items (ascending, starts[0] = 0)
 	starts.push_back(0);
 	size_t n_members = 1;
-	const size_t target = std::max<size_t>((size_t)256 << 10, std::min<size_t>((size_t)16 << 20, size / (8 * nt) + 1));   // compressed bytes per item
+	// (round 5, with the faster decoder: items of ~1/32 of a thread's share -- a few MB of compressed data -- so that the last items of the threads end
+	// together and the first rows reach the uploader early)
+	const size_t target = std::max<size_t>((size_t)256 << 10, std::min<size_t>((size_t)4 << 20, size / (32 * nt) + 1));   // compressed bytes per item
 	if (bsz) {                                                                   // BGZF: every header says where the next one is
 		size_t off = 0, last_cut = 0;
 		std::vector<unsigned char> buf((size_t)1 << 20);
@@ -168,24 +211,40 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			off = nxt;
 		}
 	} else {                                                                     // any gzip: look for a member start behind evenly spaced offsets
-		std::vector<unsigned char> buf((size_t)8 << 20);
-		const size_t step = std::max(target, size / (4 * nt) + 1);
-		for (size_t want = step; want + 64 < size; want += step) {
-			size_t found = 0;
-			for (size_t base = want; base + 64 < size && base < want + ((size_t)64 << 20) && !found; base += buf.size() - 64) {
-				const size_t bn = std::min(buf.size(), size - base);
-				if (!read_at(fd.f, buf.data(), bn, base)) return 0;
-				const unsigned char *p = buf.data(), *e = buf.data() + bn - 32;
-				while (p < e && !found) {
-					p = (const unsigned char*)memchr(p, 0x1f, (size_t)(e - p));
-					if (!p) break;
-					uint32_t s = 0;
-					if (member_header(p, (size_t)(buf.data() + bn - p), &s) && inflates_here(p, (size_t)(buf.data() + bn - p))) found = base + (size_t)(p - buf.data());
-					++p;
+		const size_t step = target;
+		const size_t np = size > 64 + step ? (size - 64 - 1) / step : 0;         // probes at step, 2 step, ...
+		std::vector<size_t> found(np, 0);
+		std::atomic<size_t> next_probe{0};
+		std::atomic<bool> io_error{false};
+		auto prober = [&]() {
+			std::vector<unsigned char> buf((size_t)1 << 20);
+			for (;;) {
+				const size_t k = next_probe.fetch_add(1);
+				if (k >= np) return;
+				const size_t want = (k + 1) * step;
+				// (a start further away than the next probe's offset is that probe's to find)
+				for (size_t base = want; base + 64 < size && base < want + step && !found[k]; base += buf.size() - 64) {
+					const size_t bn = std::min(buf.size(), size - base);
+					if (!read_at(fd.f, buf.data(), bn, base)) { io_error = true; return; }
+					const unsigned char *p = buf.data(), *e = buf.data() + bn - 32;
+					while (p < e && !found[k]) {
+						p = (const unsigned char*)memchr(p, 0x1f, (size_t)(e - p));
+						if (!p) break;
+						uint32_t s = 0;
+						if (base + (size_t)(p - buf.data()) < want + step && member_header(p, (size_t)(buf.data() + bn - p), &s) && inflates_here(p, (size_t)(buf.data() + bn - p)))
+							found[k] = base + (size_t)(p - buf.data());
+						++p;
+					}
 				}
 			}
-			if (found && found > starts.back()) { starts.push_back(found); ++n_members; want = std::max(want, found); }
+		};
+		{
+			std::vector<std::thread> pt;
+			for (size_t t = 0; t < std::min(nt, std::max<size_t>(np, 1)); ++t) pt.emplace_back(prober);
+			for (auto &x : pt) x.join();
 		}
+		if (io_error) return 0;
+		for (size_t k = 0; k < np; ++k) if (found[k] && found[k] > starts.back()) { starts.push_back(found[k]); ++n_members; }
 	}
 	if (starts.size() < 2) return 0;                                             // one member (or one work item): nothing to share out
 	if (n_members_out) *n_members_out = n_members;
@@ -203,33 +262,50 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 	const size_t window = 3 * nt + 2;
 	int L_shared = L;                                                           // (guarded by mu; item 0 settles it when *L_io is 0)
 	auto give_up = [&](int code, const char *msg) { { std::lock_guard<std::mutex> g(mu); if (!fail) { fail = code; fail_msg = msg; } } cv.notify_all(); };
+	Pool texts, rowbufs;
+	rowbufs.pinned = host_out == nullptr;                                      // (towards the device the rows leave from page-locked blocks)
+	if (rowbufs.pinned && hipSetDevice(device) != hipSuccess) return MCOM_E_HIP;
+	const bool trace = getenv("MCOM_GZ_TRACE") != nullptr;
+	const double w_discovery = wall();
+	double w_workers = 0, w_first_sent = 0;
+	std::atomic<long long> t_read{0}, t_inflate{0}, t_parse{0}, t_wait{0}, t_up_wait{0}, t_up_copy{0};
+	auto now_ns = []() { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	auto worker = [&]() {
 		std::vector<unsigned char> in;
+		if (rowbufs.pinned) (void)hipSetDevice(device);                           // (this thread may be the one that page-locks a new block)
 		for (;;) {
 			const size_t i = next_item.fetch_add(1);
 			if (i >= ni || fail) return;
+			long long tq = now_ns();
 			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || i < sent + window; }); if (fail) return; }
+			t_wait += now_ns() - tq; tq = now_ns();
 			Item &it = items[i];
 			// inflate the item's members
 			in.resize(it.end - it.begin);
 			if (!read_at(fd.f, in.data(), in.size(), it.begin)) { give_up(MCOM_E_ARG, "read error"); return; }
+			t_read += now_ns() - tq; tq = now_ns();
 			// every member of the item, one behind the other, by the decoder of mcom_inflate.cpp (header, deflate stream, CRC-32 and ISIZE checked;
 			// a member must end where the next begins).  The text buffer grows by doubling when a member does not fit; the member is then decoded again.
-			size_t tcap = std::max<size_t>(in.size() * 6, (size_t)1 << 20), have = 0;
-			std::unique_ptr<char[]> tbuf(new char[tcap + 16]);
+			size_t tcap = 0, have = 0;
+			char *tbuf = (char*)texts.get(std::max<size_t>(in.size() * 6, (size_t)1 << 20), &tcap);
+			if (!tbuf) { give_up(MCOM_E_NOMEM, "out of memory"); return; }
 			bool bad = false;
 			for (size_t at = 0; at < in.size();) {
 				size_t used = 0, got = 0;
-				const int rc = mcom_gunzip_member(in.data() + at, in.size() - at, (uint8_t*)tbuf.get() + have, tcap - have, &used, &got);
+				const int rc = mcom_gunzip_member(in.data() + at, in.size() - at, (uint8_t*)tbuf + have, tcap - 16 - have, &used, &got);
 				if (rc == MCOM_INFLATE_ROOM) {
-					std::unique_ptr<char[]> nb(new char[2 * tcap + 16]); memcpy(nb.get(), tbuf.get(), have); tbuf.swap(nb); tcap *= 2;
+					size_t ncap = 0;
+					char *nb = (char*)texts.get(2 * tcap, &ncap);
+					if (!nb) { texts.put(tbuf, tcap); give_up(MCOM_E_NOMEM, "out of memory"); return; }
+					memcpy(nb, tbuf, have); texts.put(tbuf, tcap); tbuf = nb; tcap = ncap;
 					continue;
 				}
 				if (rc != MCOM_INFLATE_OK) { bad = true; break; }
 				at += used; have += got;
 			}
-			if (bad) { give_up(1, "the members do not tile the file"); return; }
-			it.text.p = std::move(tbuf); it.text.n = have;
+			if (bad) { texts.put(tbuf, tcap); give_up(1, "the members do not tile the file"); return; }
+			it.text.p = tbuf; it.text.cap = tcap; it.text.n = have;
+			t_inflate += now_ns() - tq; tq = now_ns();
 			// the read length (item 0, from its first record) and this text's first record boundary
 			const char *tb = it.text.data(), *te = tb + it.text.size();
 			int len;
@@ -259,20 +335,22 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			// parse: the records that start in this text; the last one may end in the following texts
 			it.n_rows = 0;
 			const size_t row_cap = it.text.size() / (size_t)(2 * len + 5) + 2;       // (a record is at least "@\n" + L + "\n+\n" + L + "\n")
-			it.rows.reset(new unsigned char[row_cap * (size_t)len + 16]);
+			it.rows = (unsigned char*)rowbufs.get(row_cap * (size_t)len + 16, &it.rows_cap);
+			if (!it.rows) { give_up(MCOM_E_NOMEM, "out of (page-locked) memory"); return; }
 			size_t pos = it.first;
 			unsigned bad_char = 0;
 			auto take = [&](const char *seq) {
 				if (it.n_rows >= row_cap) { bad_char |= 2u; return; }
-				unsigned char *dst = it.rows.get() + it.n_rows * (size_t)len;
+				unsigned char *dst = it.rows + it.n_rows * (size_t)len;
 				memcpy(dst, seq, (size_t)len);
 				bad_char |= not_acgtn(dst, len) ? 1u : 0u;
 				++it.n_rows;
 			};
 			while (pos < it.text.size()) {
-				const char *q = record_in(tb + pos, te, len);
+				const char *sq = nullptr;
+				const char *q = record_in(tb + pos, te, len, &sq);
 				if (!q) break;
-				take(next_line(tb + pos, te));
+				take(sq);
 				pos = (size_t)(q - tb);
 			}
 			if (pos < it.text.size()) {
@@ -303,6 +381,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 				// this text ends exactly at a record's end: the next text must start with a record (its first == 0), checked by its own worker's
 				// search (a record at its first byte is tried first); nothing to do here
 			}
+			t_parse += now_ns() - tq;
 			if (bad_char & 2u) { give_up(1, "more records than the text has room for"); return; }
 			if (bad_char) { give_up(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)"); return; }
 			{ std::lock_guard<std::mutex> g(mu); it.state = 2; }
@@ -313,29 +392,35 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 	int up_rc = 0;
 	std::thread up([&]() {
 		hipStream_t cs = nullptr;
-		unsigned char *pin[2] = {nullptr, nullptr}; size_t pin_cap = 0; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
-		int cur = 0;
+		// copies in flight: the block a copy leaves from goes back to the pool when the event behind the copy has happened
+		struct Flight { void *p; size_t cap; hipEvent_t ev; };
+		std::vector<Flight> flying; std::vector<hipEvent_t> spare;
+		auto land = [&](size_t keep) {                                          // wait until at most `keep` copies are in flight
+			while (flying.size() > keep) {
+				if (hipEventSynchronize(flying.front().ev) != hipSuccess) return false;
+				rowbufs.put(flying.front().p, flying.front().cap); spare.push_back(flying.front().ev);
+				flying.erase(flying.begin());
+			}
+			return true;
+		};
 		auto bail = [&](int code, const char *msg) { up_rc = code; give_up(code, msg); };
 		const bool to_host = host_out != nullptr;
 		if (!to_host && (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess)) { bail(MCOM_E_HIP, "no usable GPU"); cs = nullptr; }
 		for (size_t i = 0; i < ni && (cs || to_host); ++i) {
+			long long tq = now_ns();
 			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[i].state >= 2; }); if (fail) break; }
+			t_up_wait += now_ns() - tq; tq = now_ns();
 			Item &it = items[i];
 			int len; { std::lock_guard<std::mutex> g(mu); len = L_shared; }
 			const size_t bytes = it.n_rows * (size_t)len;
+			bool kept = false;                                                      // the block stays out (a copy is leaving from it)
 			if (bytes && to_host) {
 				if (total + it.n_rows > host_cap) { total += it.n_rows; bail(MCOM_E_OVERFLOW, "more reads than the caller has room for"); break; }
-				memcpy(host_out + total * (size_t)len, it.rows.get(), bytes);
+				memcpy(host_out + total * (size_t)len, it.rows, bytes);
 				total += it.n_rows;
 			} else if (bytes) {
-				if (bytes > pin_cap) {
-					for (int q = 0; q < 2; ++q) { if (busy[q]) { (void)hipEventSynchronize(ev[q]); busy[q] = false; } if (pin[q]) (void)hipHostFree(pin[q]); pin[q] = nullptr; }
-					pin_cap = bytes + bytes / 2;
-					for (int q = 0; q < 2; ++q) if (hipHostMalloc((void**)&pin[q], pin_cap, hipHostMallocDefault) != hipSuccess || (!ev[q] && hipEventCreateWithFlags(&ev[q], hipEventDisableTiming) != hipSuccess)) { bail(MCOM_E_NOMEM, "pinned blocks"); break; }
-					if (fail) break;
-				}
 				if (total + it.n_rows > dev_cap) {
-					size_t want = dev_cap ? dev_cap * 2 : std::max<size_t>(it.n_rows * (ni + 1), (size_t)1 << 20);
+					size_t want = dev_cap ? dev_cap * 2 : std::max<size_t>(it.n_rows * (ni + 1) + it.n_rows / 4, (size_t)1 << 20);
 					while (want < total + it.n_rows) want *= 2;
 					uint8_t *nd = nullptr;
 					if (hipMalloc(&nd, want * (size_t)len + 16) != hipSuccess) { bail(MCOM_E_NOMEM, "out of device memory"); break; }
@@ -343,26 +428,39 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 					if (dev) (void)hipFree(dev);
 					dev = nd; dev_cap = want;
 				}
-				if (busy[cur]) { if (hipEventSynchronize(ev[cur]) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; } busy[cur] = false; }
-				memcpy(pin[cur], it.rows.get(), bytes);
-				if (hipMemcpyAsync(dev + total * (size_t)len, pin[cur], bytes, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(ev[cur], cs) != hipSuccess) { bail(MCOM_E_HIP, "upload failed"); break; }
-				busy[cur] = true; cur ^= 1;
+				if (!land(6)) { bail(MCOM_E_HIP, "upload failed"); break; }
+				hipEvent_t ev = nullptr;
+				if (!spare.empty()) { ev = spare.back(); spare.pop_back(); }
+				else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { bail(MCOM_E_HIP, "event"); break; }
+				if (hipMemcpyAsync(dev + total * (size_t)len, it.rows, bytes, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(ev, cs) != hipSuccess) { spare.push_back(ev); bail(MCOM_E_HIP, "upload failed"); break; }
+				flying.push_back(Flight{it.rows, it.rows_cap, ev}); kept = true;
 				total += it.n_rows;
 			}
-			it.rows.reset();
-			if (i) items[i - 1].text.drop();                    // (item i's rows are made: nobody reads the text before it any more)
+			if (!kept) rowbufs.put(it.rows, it.rows_cap);
+			it.rows = nullptr;
+			t_up_copy += now_ns() - tq;
+			if (i) { texts.put(items[i - 1].text.p, items[i - 1].text.cap); items[i - 1].text.p = nullptr; }   // (item i's rows are made: nobody reads the text before it any more)
+			if (i == 0) w_first_sent = wall();
 			{ std::lock_guard<std::mutex> g(mu); it.state = 3; sent = i + 1; }
 			cv.notify_all();
 		}
-		if (cs) { if (hipStreamSynchronize(cs) != hipSuccess && !up_rc) up_rc = MCOM_E_HIP; (void)hipStreamDestroy(cs); }
-		for (int q = 0; q < 2; ++q) { if (pin[q]) (void)hipHostFree(pin[q]); if (ev[q]) (void)hipEventDestroy(ev[q]); }
+		if (cs) { if (hipStreamSynchronize(cs) != hipSuccess && !up_rc) up_rc = MCOM_E_HIP; }
+		(void)land(0);
+		for (auto &f : flying) { rowbufs.put(f.p, f.cap); spare.push_back(f.ev); }     // (only after a failed wait)
+		for (hipEvent_t e : spare) (void)hipEventDestroy(e);
+		if (cs) (void)hipStreamDestroy(cs);
 	});
 	std::vector<std::thread> th;
 	for (size_t t = 0; t < std::max<size_t>(2, std::min(nt, ni)); ++t) th.emplace_back(worker);   // (two at least: the worker of item i waits for the text of item i + 1, which somebody else must make)
 	for (auto &x : th) x.join();
+	w_workers = wall();
 	{ std::lock_guard<std::mutex> g(mu); if (!fail && next_item < ni) fail = 1; }
 	cv.notify_all();
 	up.join();
+	for (Item &it : items) { if (it.text.p) { texts.put(it.text.p, it.text.cap); it.text.p = nullptr; } if (it.rows) { rowbufs.put(it.rows, it.rows_cap); it.rows = nullptr; } }
+	if (trace) fprintf(stderr, "mcom_fastq_gz: wall: discovery %.3f, first item sent %.3f, workers joined %.3f, uploader joined %.3f\n", w_discovery, w_first_sent, w_workers, wall());
+	if (trace) fprintf(stderr, "mcom_fastq_gz: %zu items, %zu threads; worker seconds (sum over threads): wait %.3f read %.3f inflate %.3f parse %.3f; uploader: wait %.3f copy %.3f\n", ni, th.size(),
+	                   t_wait / 1e9, t_read / 1e9, t_inflate / 1e9, t_parse / 1e9, t_up_wait / 1e9, t_up_copy / 1e9);
 	if (fail || up_rc) {
 		if (dev) (void)hipFree(dev);
 		const int code = fail ? (int)fail : up_rc;

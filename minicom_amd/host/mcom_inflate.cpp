@@ -6,8 +6,9 @@
 // output buffer in front of it -- which is what lets it drop what zlib's streaming interface pays for:
 //   * a 64-bit bit buffer refilled by one unaligned 8-byte load (no per-byte loop), valid for up to three literals, or a length
 //     with its extra bits, between refills;
-//   * one table look-up per symbol: 11 bits of the stream index the literal/length table (8 for distances), an entry carries the
-//     symbol's value or base, its extra-bit count and its code length; longer codes go through a second-level table;
+//   * one table look-up per symbol -- or per TWO literals when both codes fit the 11 index bits, as the two-to-four-bit codes of bases and
+//     binned qualities do: 11 bits of the stream index the literal/length table (8 for distances), an entry carries the symbol's value or
+//     base, its extra-bit count and its code length; longer codes go through a second-level table;
 //   * matches copied eight bytes at a time (distance 1 -- a run of one quality character -- as a fill), literals stored as they
 //     are decoded, no sliding window: the output buffer is the window;
 //   * bounds are checked per loop iteration against margins, the last bytes of either buffer go through a careful loop.
@@ -28,7 +29,11 @@ inline void store64(u8 *p, u64 v) { memcpy(p, &v, 8); }
 // ---- table entries ---------------------------------------------------------------------------------------------------------------------
 // bits 0-7 code length (bits to take from the stream for the code itself), bits 8-10 kind, bits 12-15 extra bits (kind LEN / DIST) or
 // second-level index bits (kind SUB), bits 16-31 literal / base value / offset of the second-level table
+// Literal entries of the literal/length table carry bit 11 (LITF) and may hold TWO literals (bit 8 set: the second one's code follows the
+// first one's inside the 11 index bits -- bases and binned qualities have codes of two to four bits): value = first | second << 8, code
+// length = both codes together.
 enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4 };
+const uint32_t LITF = 0x800u, LIT2 = 0x100u;
 inline u32 mk(u32 bits, u32 kind, u32 extra, u32 val) { return bits | (kind << 8) | (extra << 12) | (val << 16); }
 inline u32 e_bits(u32 e) { return e & 255u; }
 inline u32 e_kind(u32 e) { return (e >> 8) & 7u; }
@@ -44,7 +49,7 @@ const u8 dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7,
 
 inline u32 ll_entry(int sym, u32 bits)
 {
-	if (sym < 256) return mk(bits, K_LIT, 0, (u32)sym);
+	if (sym < 256) return mk(bits, K_LIT, 0, (u32)sym) | LITF;
 	if (sym == 256) return mk(bits, K_EOB, 0, 0);
 	if (sym > 285) return mk(bits, K_BAD, 0, 0);
 	return mk(bits, K_LEN, len_extra[sym - 257], len_base[sym - 257]);
@@ -106,6 +111,21 @@ bool build_table(const u8 *lens, int n, u32 *table, int P, int table_size, ENTRY
 
 struct Tables { u32 ll[LL_SIZE]; u32 d[D_SIZE]; };
 
+// first-level literal entries whose remaining index bits hold a second whole literal become entries of two (from the top down: the entry
+// looked at for the second literal has a smaller index and is still single)
+void pair_literals(u32 *t)
+{
+	for (int i = (1 << LL_BITS) - 1; i >= 0; --i) {
+		const u32 e = t[i];
+		if (!(e & LITF)) continue;
+		const u32 l1 = e_bits(e);
+		if (l1 >= (u32)LL_BITS) continue;
+		const u32 e2 = t[(u32)i >> l1];
+		if (!(e2 & LITF) || e_bits(e2) > (u32)LL_BITS - l1) continue;
+		t[i] = (l1 + e_bits(e2)) | LITF | LIT2 | ((e_val(e) | (e_val(e2) << 8)) << 16);
+	}
+}
+
 struct Fixed { Tables t; Fixed() {
 	u8 l[288 + 32];
 	for (int i = 0; i < 144; ++i) l[i] = 8;
@@ -114,6 +134,7 @@ struct Fixed { Tables t; Fixed() {
 	for (int i = 280; i < 288; ++i) l[i] = 8;
 	for (int i = 0; i < 32; ++i) l[288 + i] = 5;
 	build_table(l, 288, t.ll, LL_BITS, LL_SIZE, ll_entry);
+	pair_literals(t.ll);
 	build_table(l + 288, 32, t.d, D_BITS, D_SIZE, d_entry);
 } };
 const Tables &fixed_tables() { static const Fixed f; return f.t; }
@@ -250,6 +271,7 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 			if (!dyn) dyn = new (std::nothrow) Tables;
 			if (!dyn) return MCOM_INFLATE_NOMEM;
 			if (!build_table(lens, hlit, dyn->ll, LL_BITS, LL_SIZE, ll_entry) || !build_table(lens + hlit, hdist, dyn->d, D_BITS, D_SIZE, d_entry)) return MCOM_INFLATE_CORRUPT;
+			pair_literals(dyn->ll);
 			T = dyn;
 		}
 		const u32 *const lt = T->ll, *const dt = T->d;
@@ -261,31 +283,34 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 #define MCOM_REFILL() do { bb |= load64(in) << bl; in += (63 - bl) >> 3; bl |= 56; } while (0)
 			// (a refill may leave bits of the next byte above bl: they are that byte's own low bits and the next refill, or the careful
 			// loop's byte-wise one, puts the same bits in the same places)
-			while (in <= in_fast && out <= out_fast) {
-				MCOM_REFILL();
-				u32 e = lt[bb & LM];
-				if (e_kind(e) == K_LIT) {                                            // up to three literals (<= 11 bits each) on one refill
-					bb >>= e_bits(e); bl -= e_bits(e); *out++ = (u8)e_val(e);
+			// The entry of the NEXT symbol is looked up as soon as the bits in front of it are known -- behind the last literal, behind a
+			// match's distance and in front of its copy -- so that the table's latency passes while bytes are stored.
+#define MCOM_LITS() do { bb >>= e_bits(e); bl -= e_bits(e); const u16 two = (u16)(e >> 16); memcpy(out, &two, 2); out += 1 + ((e >> 8) & 1u); } while (0)
+			MCOM_REFILL();
+			u32 e = lt[bb & LM];
+			while (in <= in_fast && out <= out_fast) {                               // (here: at least 56 bits in the buffer, e belongs to them)
+				if (e & LITF) {                                                      // up to three look-ups of one or two literals (<= 11 bits each) on one refill
+					MCOM_LITS();
 					e = lt[bb & LM];
-					if (e_kind(e) == K_LIT) {
-						bb >>= e_bits(e); bl -= e_bits(e); *out++ = (u8)e_val(e);
+					if (e & LITF) {
+						MCOM_LITS();
 						e = lt[bb & LM];
-						if (e_kind(e) == K_LIT) { bb >>= e_bits(e); bl -= e_bits(e); *out++ = (u8)e_val(e); continue; }
+						if (e & LITF) { MCOM_LITS(); MCOM_REFILL(); e = lt[bb & LM]; continue; }
 					}
 				}
 				if (e_kind(e) == K_SUB) {
 					e = lt[e_val(e) + ((u32)(bb >> LL_BITS) & ((1u << e_extra(e)) - 1))];
-					if (e_kind(e) == K_LIT) { bb >>= e_bits(e); bl -= e_bits(e); *out++ = (u8)e_val(e); continue; }
+					if (e & LITF) { MCOM_LITS(); MCOM_REFILL(); e = lt[bb & LM]; continue; }
 				}
 				if (e_kind(e) != K_LEN) {
 					if (e_kind(e) == K_EOB) { bb >>= e_bits(e); bl -= e_bits(e); eob = true; break; }
 					return MCOM_INFLATE_CORRUPT;
 				}
-				bb >>= e_bits(e); bl -= e_bits(e);                                   // (33 + 15 + 5 bits at most since the refill)
+				bb >>= e_bits(e); bl -= e_bits(e);                                   // (22 + 15 + 5 bits at most since the refill)
 				const u32 xb = e_extra(e);
 				const u32 length = e_val(e) + ((u32)bb & ((1u << xb) - 1));
 				bb >>= xb; bl -= xb;
-				MCOM_REFILL();
+				if (bl < 32) MCOM_REFILL();                                          // (a match right behind a match has bits enough left for its distance: 15 + 13)
 				u32 d = dt[bb & DM];
 				if (e_kind(d) == K_SUB) d = dt[e_val(d) + ((u32)(bb >> D_BITS) & ((1u << e_extra(d)) - 1))];
 				if (e_kind(d) != K_LEN) return MCOM_INFLATE_CORRUPT;
@@ -293,6 +318,8 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 				const u32 dxb = e_extra(d);
 				const u32 dist = e_val(d) + ((u32)bb & ((1u << dxb) - 1));
 				bb >>= dxb; bl -= dxb;
+				MCOM_REFILL();
+				e = lt[bb & LM];
 				if (dist > (size_t)(out - out0)) return MCOM_INFLATE_CORRUPT;
 				const u8 *src = out - dist; u8 *const end = out + length;
 				if (dist >= 8) {
@@ -302,11 +329,11 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 					const u64 v = 0x0101010101010101ull * *src;
 					do { store64(out, v); out += 8; } while (out < end);
 				} else {
-					// a pattern of 2 - 7 bytes: spelled out until eight bytes are there, then copied from eight behind... byte by byte is enough here
-					do { *out++ = *src++; } while (out < end);
+					do { *out++ = *src++; } while (out < end);                          // (a pattern of 2 - 7 bytes: byte by byte)
 				}
 				out = end;
 			}
+#undef MCOM_LITS
 #undef MCOM_REFILL
 			bb &= bl < 64 ? (((u64)1 << bl) - 1) : ~(u64)0;                          // (drop the bits a refill left above bl)
 		}
@@ -315,10 +342,15 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 			fill();
 			u32 e = lt[bb & LM];
 			if (e_kind(e) == K_SUB) e = lt[e_val(e) + ((u32)(bb >> LL_BITS) & ((1u << e_extra(e)) - 1))];
-			if (e_kind(e) == K_BAD) return bl < 15 && in == in_end ? MCOM_INFLATE_TRUNCATED : MCOM_INFLATE_CORRUPT;
+			if (!(e & LITF) && e_kind(e) == K_BAD) return bl < 15 && in == in_end ? MCOM_INFLATE_TRUNCATED : MCOM_INFLATE_CORRUPT;
 			if (e_bits(e) > bl) return MCOM_INFLATE_TRUNCATED;
 			bb >>= e_bits(e); bl -= e_bits(e);
-			if (e_kind(e) == K_LIT) { if (out == out_end) return MCOM_INFLATE_ROOM; *out++ = (u8)e_val(e); continue; }
+			if (e & LITF) {
+				const size_t k = 1 + ((e >> 8) & 1u);
+				if ((size_t)(out_end - out) < k) return MCOM_INFLATE_ROOM;
+				*out++ = (u8)e_val(e); if (k == 2) *out++ = (u8)(e >> 24);
+				continue;
+			}
 			if (e_kind(e) == K_EOB) { eob = true; break; }
 			const u32 xb = e_extra(e);
 			if (bl < xb) return MCOM_INFLATE_TRUNCATED;
