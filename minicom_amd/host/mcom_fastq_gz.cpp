@@ -10,13 +10,14 @@
 //               exactly) or not (then a start is looked for behind each of ~4 x threads evenly spaced offsets: the bytes 1f 8b 08 with
 //               legal flag bits, confirmed by inflating the first kilobytes there).  One member only: not this route (return 0).
 //   groups      consecutive members are grouped into work items of a few MB of compressed data, numbered in file order
-//   workers     a worker takes the next item, inflates it (checking that every member ends exactly where the next begins: a false
-//               start found by the search cannot survive that), finds the first record boundary of its text by the records' shape
-//               (a '@' line, a line of L bases, a '+' line, a line of L characters; mcom_fastq.cpp does the same for plain files), parses
-//               from there up to and including the record that starts in its text and ends in the next item's (it waits for that
-//               text), and leaves the sequence lines as rows of L characters
-//   uploader    one thread takes the items in order and sends their rows to HBM behind those of the items before (the same
-//               growing array as the sequential reader's)
+//   workers     a worker takes the next item, decodes its members (host/mcom_inflate.cpp; every member must end exactly where the next
+//               begins: a false start found by the search cannot survive that), finds the first record boundary of its text by the
+//               records' shape (a '@' line, a line of L bases, a '+' line, a line of L characters; mcom_fastq.cpp does the same for plain
+//               files), parses the records that lie whole in its text and leaves their sequence lines as rows of L characters in a
+//               page-locked block
+//   uploader    one thread takes the items in order, puts the record that starts in an item's text and ends in the next one's together
+//               (both texts are there by then), and sends the rows to HBM behind those of the items before (the same growing array as
+//               the sequential reader's), straight from the block they were written to
 // A window of items bounds the memory (a worker does not start item i before item i - window has been sent).  Anything that is not
 // the fixed-length four-line layout -- FASTA, sequences over several lines, carriage returns, reads of several lengths -- and any
 // inconsistency (a member that does not end at the next start, a text without a record boundary) makes the route step back (return 0)
@@ -162,6 +163,7 @@ struct Item {
 		bool empty() const { return n == 0; }
 	} text;
 	size_t first = 0;                                                           // offset of the first record that starts in this text (text.size(): none)
+	size_t tail = 0;                                                            // offset of the record that starts in this text and ends in a later one (text.size(): none)
 	unsigned char *rows = nullptr; size_t rows_cap = 0, n_rows = 0;             // the sequence lines of the records that start in this text
 	int state = 0;                                                              // 0 waiting, 1 text there, 2 rows there, 3 sent
 };
@@ -353,34 +355,9 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 				take(sq);
 				pos = (size_t)(q - tb);
 			}
-			if (pos < it.text.size()) {
-				// a record starts at pos and does not end in this text: put it together with the heads of the following texts
-				std::string rec(tb + pos, it.text.size() - pos);
-				bool done = false;
-				for (size_t j = i + 1; !done; ++j) {
-					if (j >= ni) {                                                    // the file ends here: the last line may lack its newline
-						rec.push_back('\n');
-						const char *q = record_in(rec.data(), rec.data() + rec.size(), len);
-						if (!q || q != rec.data() + rec.size()) { give_up(1, "the last record is not of the shape"); return; }
-						take(next_line(rec.data(), rec.data() + rec.size()));
-						done = true; break;
-					}
-					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[j].state >= 1; }); if (fail) return; }
-					const Item &nx = items[j];
-					const size_t headn = std::min(nx.first, nx.text.size());
-					rec.append(nx.text.data(), headn);                                // what lies in front of that text's first record belongs to this one
-					if (headn < nx.text.size() || j + 1 == ni) {
-						if (headn == nx.text.size() && j + 1 == ni && (rec.empty() || rec.back() != '\n')) rec.push_back('\n');
-						const char *q = record_in(rec.data(), rec.data() + rec.size(), len);
-						if (!q || q != rec.data() + rec.size()) { give_up(1, "a record across two members is not of the shape"); return; }
-						take(next_line(rec.data(), rec.data() + rec.size()));
-						done = true;
-					}
-				}
-			} else if (i + 1 < ni) {
-				// this text ends exactly at a record's end: the next text must start with a record (its first == 0), checked by its own worker's
-				// search (a record at its first byte is tried first); nothing to do here
-			}
+			// a record that starts at pos and does not end in this text is put together by the uploader, which passes the items in order and
+			// has the following texts at hand by then (a worker that waited for its neighbour's text here stood still for a fifth of its time)
+			it.tail = pos;
 			t_parse += now_ns() - tq;
 			if (bad_char & 2u) { give_up(1, "more records than the text has room for"); return; }
 			if (bad_char) { give_up(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)"); return; }
@@ -412,6 +389,30 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			t_up_wait += now_ns() - tq; tq = now_ns();
 			Item &it = items[i];
 			int len; { std::lock_guard<std::mutex> g(mu); len = L_shared; }
+			if (it.tail < it.text.size()) {
+				// the record across the end of this text: its start here, then what lies in front of the following texts' first records
+				std::string rec(it.text.data() + it.tail, it.text.size() - it.tail);
+				bool done = false, bad_shape = false;
+				for (size_t j = i + 1; !done && !bad_shape; ++j) {
+					if (j >= ni) { rec.push_back('\n'); done = true; break; }              // the file ends here: the last line may lack its newline
+					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[j].state >= 1; }); if (fail) break; }
+					const Item &nx = items[j];
+					const size_t headn = std::min(nx.first, nx.text.size());
+					rec.append(nx.text.data(), headn);
+					if (headn < nx.text.size() || j + 1 == ni) {
+						if (headn == nx.text.size() && j + 1 == ni && (rec.empty() || rec.back() != '\n')) rec.push_back('\n');
+						done = true;
+					}
+				}
+				if (fail) break;
+				const char *sq = nullptr;
+				const char *q = done ? record_in(rec.data(), rec.data() + rec.size(), len, &sq) : nullptr;
+				if (!q || q != rec.data() + rec.size()) { bail(1, "a record across two members is not of the shape"); break; }
+				if ((it.n_rows + 1) * (size_t)len + 16 > it.rows_cap) { bail(1, "more records than the text has room for"); break; }
+				memcpy(it.rows + it.n_rows * (size_t)len, sq, (size_t)len);
+				if (not_acgtn(it.rows + it.n_rows * (size_t)len, len)) { bail(MCOM_E_ARG, "a sequence holds a character outside ACGTN (lower-case and IUPAC codes are not representable)"); break; }
+				++it.n_rows;
+			}
 			const size_t bytes = it.n_rows * (size_t)len;
 			bool kept = false;                                                      // the block stays out (a copy is leaving from it)
 			if (bytes && to_host) {
@@ -439,7 +440,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			if (!kept) rowbufs.put(it.rows, it.rows_cap);
 			it.rows = nullptr;
 			t_up_copy += now_ns() - tq;
-			if (i) { texts.put(items[i - 1].text.p, items[i - 1].text.cap); items[i - 1].text.p = nullptr; }   // (item i's rows are made: nobody reads the text before it any more)
+			if (i) { texts.put(items[i - 1].text.p, items[i - 1].text.cap); items[i - 1].text.p = nullptr; }   // (item i is through: nobody reads the text before it any more)
 			if (i == 0) w_first_sent = wall();
 			{ std::lock_guard<std::mutex> g(mu); it.state = 3; sent = i + 1; }
 			cv.notify_all();
