@@ -105,7 +105,8 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
             res["gzip_members"] = gz_members
             res["fastq_text_GB_per_s"] = round(n * (2 * L + 6 + len(str(n))) / (t1 - t0) / 1e9, 2)
             res["note"] = ("the same from a .fastq.gz of %d gzip members (8 MB of text each, zlib level 1; quality lines are all 'I', so this file inflates "
-                           "faster than sequencer output would): members inflated and parsed by all cores, rows sent as characters; a gzip file of ONE member "
+                           "faster than sequencer output would): members shared out over all cores, decoded by the library's own DEFLATE decoder (host/mcom_inflate.cpp, "
+                           "~2 x zlib per core; CRC-32 checked) and parsed there, rows sent as characters from page-locked blocks; a gzip file of ONE member "
                            "can only be inflated by one thread (the sequential reader: ~1.5 Mreads/s)" % gz_members)
         p.close()
         res["reference"] = _reference_on_prefix(fq, td, n, L, ref_reads) if mode == "default" and ref_reads else None
