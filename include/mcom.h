@@ -159,6 +159,10 @@ int mcom_sketch_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
  * (so d_coff[c+1] - d_coff[c] = ceil(2*len/64) + 1; total_words = their sum).  Non-ACGT packs as A.   */
 int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                       uint64_t total_words, uint64_t *d_cbits);
+/* The same for the words [w_lo, w_hi) of the layout only (the other words of d_cbits are not touched): on several GPUs a rank packs its
+ * share of the words -- shares need not end where contigs do -- and the shares are all-gathered (round 5; before, every rank packed all). */
+int mcom_pack_contigs_words(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                            uint64_t total_words, uint64_t *d_cbits, uint64_t w_lo, uint64_t w_hi);
 /* The same for the set after a merge round (cp_cluster, kthread_cb.c:397-434: the merged contigs first, then the untouched ones
  * in their order): contigs [0, n_first) are packed from their strings, contig n_first + u takes the packed words of contig
  * d_keepidx[u] of the set before the round (d_cbits_old / d_coff_old).  Same words as mcom_pack_contigs; d_cbits has room for

@@ -475,17 +475,21 @@ int mcom_sketch_strings(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 #define PK_T 256
 __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                        const uint64_t *__restrict__ coff, uint32_t n, uint64_t total_words,
-                                                       uint64_t *__restrict__ cbits, uint32_t n_first)
+                                                       uint64_t *__restrict__ cbits, uint32_t n_first, uint64_t w_lo = 0, uint64_t w_hi = ~0ull)
 {
 	__shared__ uint64_t CO[PK_T / 2 + 4], OF[PK_T / 2 + 4];
 	__shared__ uint32_t SB[PK_T * 8 + 16];
 	__shared__ uint32_t srch[16];
 	__shared__ uint64_t lo_s, hi_s;
-	const uint64_t g0 = (uint64_t)blockIdx.x * PK_T;
+	const uint64_t g0 = w_lo + (uint64_t)blockIdx.x * PK_T;                    // (w_lo, w_hi: the words [w_lo, w_hi) only -- a rank's share of the set)
 	if (n_first < n) {                                                       // only the first n_first contigs: the words below coff[n_first]
 		total_words = coff[n_first]; n = n_first;
 		if (g0 >= total_words) return;
 	}
+	const uint64_t off_n = off[n];                                           // (read before total_words shrinks to the share's end: the end of the concatenation)
+	const uint64_t all_words = total_words;
+	if (w_hi < total_words) total_words = w_hi;
+	if (g0 >= total_words) return;
 	const uint64_t g = g0 + threadIdx.x;
 	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return coff[c] <= g0; }, srch);
 	if (threadIdx.x == 0) { lo_s = 0; hi_s = 0; }
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict
 	const int NC = PK_T / 2 + 2;
 	for (int t = threadIdx.x; t < NC; t += PK_T) {
 		const uint64_t c = (uint64_t)c0 + t;
-		CO[t] = c < n ? coff[c] : (c == n ? total_words : ~0ull);         // coff may hold n entries only
+		CO[t] = c < n ? coff[c] : (c == n ? all_words : ~0ull);           // coff may hold n entries only
 		OF[t] = c <= n ? off[c] : off[n];
 	}
 	__syncthreads();
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict
 	__syncthreads();
 	const uint64_t start4 = lo_s & ~3ull;
 	const uint64_t ndw = hi_s > start4 ? (hi_s - start4 + 3) / 4 + 1 : 0;            // one more word for the funnel shift
-	const uint64_t seq_dw = (off[n] + 3) / 4;                                          // do not read past the concatenation
+	const uint64_t seq_dw = (off_n + 3) / 4;                                           // do not read past the concatenation
 	const uint32_t *seq32 = (const uint32_t*)(seq + start4);                           // the base pointer is 4-byte aligned
 	for (uint64_t i = threadIdx.x; i < ndw; i += PK_T) SB[i] = (start4 / 4 + i) < seq_dw ? seq32[i] : 0u;
 	__syncthreads();
@@ -541,18 +545,24 @@ __global__ __launch_bounds__(PK_T) void k_pack_contigs(const uint8_t *__restrict
 	cbits[g] = v;
 }
 
+extern "C" int mcom_pack_contigs_words(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
+                                       uint64_t total_words, uint64_t *d_cbits, uint64_t w_lo, uint64_t w_hi)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (w_hi > total_words) w_hi = total_words;
+	if (n == 0 || total_words == 0 || w_lo >= w_hi) return MCOM_OK;
+	if (!d_seq || !d_off || !d_coff || !d_cbits) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const uint64_t blocks = (w_hi - w_lo + 255) / 256;
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
+	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
+	MCOM_LAUNCH(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n, w_lo, w_hi);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
 extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                                  uint64_t total_words, uint64_t *d_cbits)
 {
-	if (!ctx) return MCOM_E_ARG;
-	if (n == 0 || total_words == 0) return MCOM_OK;
-	if (!d_seq || !d_off || !d_coff || !d_cbits) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	const uint64_t blocks = (total_words + 255) / 256;
-	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many words");
-	if (((uintptr_t)d_seq & 3) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 4-byte boundary");
-	MCOM_LAUNCH(k_pack_contigs, dim3((unsigned)blocks), dim3(PK_T), 0, ctx->stream, d_seq, d_off, d_coff, n, total_words, d_cbits, n);
-	MCOM_LAUNCH_CHECK(ctx);
-	return MCOM_OK;
+	return mcom_pack_contigs_words(ctx, d_seq, d_off, d_coff, n, total_words, d_cbits, 0, total_words);
 }
 
 // A merge round changes the merged contigs only: they (the first n_first of the new set) are packed, the packed words of the

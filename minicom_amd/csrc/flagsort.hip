@@ -282,14 +282,15 @@ int mcom_flag_sort_buckets(mcom_ctx *ctx, const mcom_mm128 *d_in, mcom_mm128 *d_
 	return MCOM_OK;
 }
 
-// starts of the runs of equal (x & mask) in an array sorted by that value: bstart[v] = first index with value >= v
+// starts of the runs of equal (x & mask) in an array sorted by that value: bstart[v] = first index with value >= v, v = 0 .. nb (one
+// thread per v, binary search: see k_seg_bounds in sort.hip)
 __global__ void k_bucket_starts(const mcom_mm128 *__restrict__ rec, size_t n, uint64_t mask, uint32_t nb, uint32_t *__restrict__ bstart)
 {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	const uint64_t cur = i < n ? (rec[i].x & mask) : (uint64_t)nb;
-	const uint64_t prev = i > 0 ? (rec[i - 1].x & mask) + 1 : 0;
-	for (uint64_t v = prev; v <= cur && v <= nb; ++v) bstart[v] = (uint32_t)i;   // also fills the empty values in between
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > nb) return;
+	size_t lo = 0, hi = n;
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((rec[mid].x & mask) < (uint64_t)v) lo = mid + 1; else hi = mid; }
+	bstart[v] = (uint32_t)lo;
 }
 
 // sorts every range of d_rec given by d_bstart[0..nr] into the reference's order
@@ -310,7 +311,7 @@ int mcom_flag_sort_ranges(mcom_ctx *ctx, mcom_mm128 *d_rec, const uint32_t *d_bs
 int mcom_bucket_starts(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int bits, uint32_t *d_bstart)
 {
 	const uint32_t nb = 1u << bits;
-	MCOM_LAUNCH(k_bucket_starts, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, n, (uint64_t)nb - 1, nb, d_bstart);
+	MCOM_LAUNCH(k_bucket_starts, dim3((nb + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_rec, n, (uint64_t)nb - 1, nb, d_bstart);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

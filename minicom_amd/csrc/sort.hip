@@ -174,15 +174,16 @@ __device__ __forceinline__ uint32_t msd_key(const KeySpec &ks, uint64_t x)
 	uint64_t lo; uint32_t hi; make_key(ks, x, 0, lo, hi);
 	return (uint32_t)lo;
 }
-// seg_start[k] = first record whose MSD key is >= k (records sorted by it); seg_start[nseg] = n
+// seg_start[k] = first record whose MSD key is >= k (records sorted by it); seg_start[nseg] = n.  One thread per k and a binary search
+// (round 5; before: one thread per record writing the starts between its neighbour's key and its own -- a rank of several GPUs holds one
+// stretch of the keys, and the one thread in front of it wrote tens of thousands of starts in a row: 0.6 ms per launch)
 __global__ void k_seg_bounds(const mcom_mm128 *__restrict__ s, size_t n, KeySpec ks, uint32_t nseg, uint32_t *__restrict__ seg_start)
 {
-	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t cur = msd_key(ks, s[i].x);
-	const uint32_t first = i ? msd_key(ks, s[i - 1].x) + 1 : 0u;
-	for (uint32_t k = first; k <= cur; ++k) seg_start[k] = (uint32_t)i;
-	if (i == n - 1) for (uint32_t k = cur + 1; k <= nseg; ++k) seg_start[k] = (uint32_t)n;
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > nseg) return;
+	size_t lo = 0, hi = n;
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (msd_key(ks, s[mid].x) < k) lo = mid + 1; else hi = mid; }
+	seg_start[k] = (uint32_t)lo;
 }
 
 template <int CAP>
@@ -619,7 +620,7 @@ extern "C" int mcom_sort_group(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n,
 		uint32_t novf = 0, scap_used = 0;
 		{
 			McomProfScope ps_(ctx, PROF_RADIX_PASS);
-			MCOM_LAUNCH(k_seg_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
+			MCOM_LAUNCH(k_seg_bounds, dim3((nseg + 1 + 255) / 256), dim3(256), 0, ctx->stream, w.tmp, n, msd, nseg, seg_start);
 			ovf_count = (uint32_t*)mcom_zeroed(ctx, ovf_count, 4);
 			if (!ovf_count) return mcom_fail(ctx, MCOM_E_HIP, "clear");
 			// segments of ~1500 records on average fit the small form; a read set whose average is higher keeps the large one

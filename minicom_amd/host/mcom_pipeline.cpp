@@ -1162,22 +1162,36 @@ static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_fir
 // Multi-GPU form of mm_idx_generation (kthread_idx.c:116-170 is a loop over independent buckets): a rank sorts the records of its
 // bucket range (ascending ranges in rank order, as in the bucket stage) and builds their table regions; sorted records and regions
 // are all-gathered into the replicated index, which every rank then queries for its share of the contigs.
-static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm, mcom_idx **out)
+// (round 5: rec_m holds the index records of THIS RANK'S SHARE of the list only -- tm_loc of them, in list order; they are partitioned by the
+// rank that owns their bucket and travel there, where the shares arrive in rank order = list order = the order mm_idx_generation pushes
+// in.  Before, every rank extracted and partitioned the records of the whole list: 2.3 ms per rank of an 8-rank job.)
+static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm_loc, mcom_idx **out)
 {
 	const int R = p->world, me = p->rank;
 	*out = nullptr;
 	int rc;
-	DevBuf<mcom_mm128> part;
-	if (!part.reserve(tm + 1)) return p->fail(MCOM_E_NOMEM, "index records");
-	std::vector<uint64_t> cnt(R, 0), first(R, 0);
-	if ((rc = p->gpu(mcom_partition_by_owner(p->ctx, rec_m, tm, NB_BITS, R, part.p, cnt.data())))) return rc;
-	uint64_t tot = 0;
-	for (int q = 0; q < R; ++q) { first[q] = tot; tot += cnt[q]; }
-	if (tot != tm) return p->fail(MCOM_E_ARG, "index records without a minimizer");
+	DevBuf<mcom_mm128> send, part;
+	if (!send.reserve(tm_loc + 1)) return p->fail(MCOM_E_NOMEM, "index records");
+	std::vector<uint64_t> mine(R, 0), all, cnt(R, 0), first(R, 0);
+	if ((rc = p->gpu(mcom_partition_by_owner(p->ctx, rec_m, tm_loc, NB_BITS, R, send.p, mine.data())))) return rc;
+	{ uint64_t t = 0; for (int q = 0; q < R; ++q) t += mine[q]; if (t != tm_loc) return p->fail(MCOM_E_ARG, "index records without a minimizer"); }
+	if ((rc = gather_host(p, mine.data(), R, all))) return rc;
+	uint64_t tm = 0;
+	for (int q = 0; q < R; ++q) { for (int s2 = 0; s2 < R; ++s2) cnt[q] += all[(size_t)s2 * R + q]; first[q] = tm; tm += cnt[q]; }
+	{
+		std::vector<uint64_t> so(R), sb(R), ro(R), rb(R);
+		uint64_t a = 0, b = 0;
+		for (int q = 0; q < R; ++q) { so[q] = a * 16; sb[q] = mine[q] * 16; a += mine[q]; ro[q] = b * 16; rb[q] = all[(size_t)q * R + me] * 16; b += all[(size_t)q * R + me]; }
+		if (b != cnt[me]) return p->fail(MCOM_E_ARG, "index exchange: counts disagree");
+		if (!part.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "index records");
+		const double tx = now_ms();
+		if ((rc = alltoallv_dev(p, send.p, so.data(), sb.data(), part.p, ro.data(), rb.data()))) return rc;
+		p->stat["t_x_index"] += now_ms() - tx;
+	}
 	mcom_idx *mi = nullptr;
 	if ((rc = p->gpu(mcom_idx_create(p->ctx, tm, p->k, NB_BITS, &mi)))) return rc;
 	uint32_t mx = 0;
-	rc = p->gpu(mcom_idx_sort_part(p->ctx, mi, part.p + first[me], cnt[me], first[me], &mx));
+	rc = p->gpu(mcom_idx_sort_part(p->ctx, mi, part.p, cnt[me], first[me], &mx));
 	uint64_t mxa = mx;
 	if (!rc) rc = allreduce_host(p, &mxa, 1, 2);
 	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
@@ -1263,6 +1277,20 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 		if ((rc = p->gpu(mcom_order_next(p->ctx, nullptr, 0, nullptr, 0, n_live, ord.p, &nk)))) return rc;
 		listed = true;
 	}
+	// the packed form of n contigs (strings in S.seq, `tw` words in all) at `out`: on several GPUs a rank packs its share of the WORDS and the
+	// shares are all-gathered (every rank packing everything was 2 ms per rank of an 8-rank job: profiles/r05_dist_kernels.txt)
+	auto pack_words = [&](const uint64_t *soff, const uint64_t *cw, size_t n, uint64_t tw, uint64_t *out) -> int {
+		if (!p->comm || tw < 4096) return p->gpu(mcom_pack_contigs(p->ctx, S.seq.p, soff, cw, (uint32_t)n, tw, out));
+		const int R = p->world, me = p->rank;
+		std::vector<uint64_t> first(R), cnt(R);
+		for (int q = 0; q < R; ++q) { first[q] = tw * (uint64_t)q / R; cnt[q] = tw * (uint64_t)(q + 1) / R - first[q]; }
+		int rc2 = p->gpu(mcom_pack_contigs_words(p->ctx, S.seq.p, soff, cw, (uint32_t)n, tw, out, first[me], first[me] + cnt[me]));
+		if (rc2) return rc2;
+		const double tx = now_ms();
+		rc2 = gatherv(p, out, first, cnt);
+		p->stat["t_x_packed"] += now_ms() - tx;
+		return rc2;
+	};
 	// room behind the end of a store array, made by growing it (the data in front is kept); the bucket stage leaves some (arena_slack)
 	auto room64 = [&](DevBuf<uint64_t> &b, uint64_t used, uint64_t more) { return b.grow((size_t)(used + more), (size_t)used, p->stream); };
 	for (;;) {
@@ -1278,12 +1306,16 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				p->total_words = tw;
 				if (!p->d_cbits.reserve(tw * 24 / 10 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
 				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
-				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, S.seq.p, S.soff.p, p->d_coff_words.p, (uint32_t)n_store, tw, p->d_cbits.p)))) return rc;
+				if ((rc = pack_words(S.soff.p, p->d_coff_words.p, n_store, tw, p->d_cbits.p))) return rc;
 				packed_ready = true;
 			}
 			// the first m minimizers are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
 			if (!moff_m.reserve(n + 2) || !rec_m.reserve(n * (size_t)p->m + 16)) return p->fail(MCOM_E_NOMEM, "index records");
-			if ((rc = p->gpu(mcom_minimizer_prefix_ord(p->ctx, S.roff.p, S.rec.p, lst, n, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
+			{
+				// (several GPUs: the records of this rank's share of the list; build_index_dist sends them to their buckets' owners)
+				const size_t a0 = p->comm ? n * (size_t)p->rank / (size_t)p->world : 0, a1 = p->comm ? n * (size_t)(p->rank + 1) / (size_t)p->world : n;
+				if ((rc = p->gpu(mcom_minimizer_prefix_ord(p->ctx, S.roff.p, S.rec.p, lst ? lst + a0 : nullptr, a1 - a0, (uint32_t)p->m, moff_m.p, rec_m.p, &tm)))) return rc;
+			}
 			lap("t_cb_pack");
 			mcom_idx *mi = nullptr;
 			if ((rc = p->comm ? build_index_dist(p, rec_m.p, tm, &mi) : p->gpu(mcom_idx_build(p->ctx, rec_m.p, tm, p->k, NB_BITS, &mi)))) return rc;   // mm_idx_generation (:580)
@@ -1494,7 +1526,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				uint64_t tw2 = 0;
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p + n_store, nj, cw_t.p, p->d_clen.p + n_store, &tw2)))) return rc;
 				if (p->d_cbits.cap < p->total_words + tw2 + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + tw2 + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
-				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, S.seq.p, S.soff.p + n_store, cw_t.p, (uint32_t)nj, tw2, p->d_cbits.p + p->total_words))) ||
+				if ((rc = pack_words(S.soff.p + n_store, cw_t.p, nj, tw2, p->d_cbits.p + p->total_words)) ||
 				    (rc = p->hipc(hipMemsetAsync(p->d_cbits.p + p->total_words + tw2, 0, 16, p->stream), "clear")) ||
 				    (rc = p->gpu(mcom_offsets_append(p->ctx, cw_t.p, nj, p->total_words, p->d_coff_words.p + n_store)))) return rc;
 				p->total_words += tw2;
