@@ -95,6 +95,8 @@ def main():
     base = None
     for world in ([] if a.no_baseline else [0]) + worlds:             # 0 = the single-GPU code path (mcomh_create), the baseline
         label = "single_gpu_path" if world == 0 else str(world)
+        from minicom_amd.pipeline import pool_trim
+        pool_trim()                                                     # (the blocks the world before left in the pools are of other sizes: they only stand in the way)
         for attempt in ["warm-up"] * (a.runs - 1) + ["measured"]:
             t0 = time.time()
             res, sent = run_world(reads, n, L, max(world, 1), world == 0)
