@@ -444,6 +444,13 @@ def main():
             e2e_modes["gz"] = {k: r[k] for k in ("mode", "reads", "value", "unit", "seconds", "stream_bytes", "fastq_bytes", "gzip_members", "fastq_text_GB_per_s", "note")}
         except Exception as e:                                                   # noqa: BLE001
             e2e_modes["gz"] = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
+        # ... and from a .fastq.gz of ONE member (plain `gzip`): one decoding thread, the others parse (a quarter of the reads: it is the slow road)
+        try:
+            pool_trim(); torch.cuda.empty_cache()
+            r = file_to_streams(max(a.e2e_reads // 4, 1_000_000), L, SEED, host_threads=threads, ref_reads=0, gz=True, gz_one_member=True)
+            e2e_modes["gz_one"] = {k: r[k] for k in ("mode", "reads", "value", "unit", "seconds", "stream_bytes", "fastq_bytes", "gzip_members", "fastq_text_GB_per_s", "note")}
+        except Exception as e:                                                   # noqa: BLE001
+            e2e_modes["gz_one"] = {"value": None, "note": f"not measured: {type(e).__name__}: {e}"}
 
     if rank == 0:
         nd = len(minicom_amd.hip.dict_layout(L)[0])
@@ -590,6 +597,7 @@ def main():
             "value_file_to_streams_order_preserving": e2e_modes.get("order"),
             "value_file_to_streams_paired_end": e2e_modes.get("paired"),
             "value_file_to_streams_gz": e2e_modes.get("gz"),
+            "value_file_to_streams_gz_one_member": e2e_modes.get("gz_one"),
             "stage2_join_ab": join_ab,
             "value_strong_100m": strong,
             "whole_step": whole,

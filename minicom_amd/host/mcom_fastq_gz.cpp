@@ -7,8 +7,10 @@
 // stream is only decodable from its start).  This file does that:
 //
 //   discovery   the member that starts at offset 0 says whether the file is BGZF (then the member starts are walked header by header,
-//               exactly) or not (then a start is looked for behind each of ~4 x threads evenly spaced offsets: the bytes 1f 8b 08 with
-//               legal flag bits, confirmed by inflating the first kilobytes there).  One member only: not this route (return 0).
+//               exactly) or not (then a start is looked for behind evenly spaced offsets, by all threads: the bytes 1f 8b 08 with
+//               legal flag bits, confirmed by inflating the first kilobytes there).  One member only (plain `gzip`): that member cannot
+//               be cut, but ONE thread decodes it in pieces of text -- ~1 GB/s against gzread's 0.25 -- and the pieces are the work
+//               items of the same workers, which then only parse ("streaming" below).
 //   groups      consecutive members are grouped into work items of a few MB of compressed data, numbered in file order
 //   workers     a worker takes the next item, decodes its members (host/mcom_inflate.cpp; every member must end exactly where the next
 //               begins: a false start found by the search cannot survive that), finds the first record boundary of its text by the
@@ -28,6 +30,7 @@
 #include <emmintrin.h>
 #include "mcom_inflate.hpp"
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
@@ -157,8 +160,8 @@ struct Pool {
 struct Item {
 	size_t begin = 0, end = 0;                                                  // compressed bytes [begin, end): whole members
 	struct Text {                                                              // what they inflate to: the buffer the decoder wrote into, as it is
-		char *p = nullptr; size_t cap = 0, n = 0;
-		const char *data() const { return p; }
+		char *p = nullptr; size_t cap = 0, n = 0, off = 0;                     // (off: one member in pieces -- the 32 KB before the piece lie in front of it)
+		const char *data() const { return p + off; }
 		size_t size() const { return n; }
 		bool empty() const { return n == 0; }
 	} text;
@@ -248,11 +251,17 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 		if (io_error) return 0;
 		for (size_t k = 0; k < np; ++k) if (found[k] && found[k] > starts.back()) { starts.push_back(found[k]); ++n_members; }
 	}
-	if (starts.size() < 2) return 0;                                             // one member (or one work item): nothing to share out
+	// One member (or too few to share out): the member cannot be cut, but its decoding and the parsing can be two stages -- ONE thread
+	// decodes (host/mcom_inflate.cpp with its output in pieces, ~1 GB/s of text against gzread's 0.25) and hands pieces of text to the
+	// same workers, which only parse.  The pieces are the items; how many there will be is known when the member ends.
+	const bool streaming = starts.size() < 2;
 	if (n_members_out) *n_members_out = n_members;
-	const size_t ni = starts.size();
-	std::vector<Item> items(ni);
-	for (size_t i = 0; i < ni; ++i) { items[i].begin = starts[i]; items[i].end = i + 1 < ni ? starts[i + 1] : size; }
+	const size_t piece = std::max<size_t>((size_t)8 << 20, size / 60 + 1);      // bytes of text per piece (DEFLATE expands at most 1032 x: at most ~62 000 pieces)
+	const size_t ni_cap = streaming ? (size_t)65536 : starts.size();
+	std::vector<Item> items(ni_cap);
+	std::atomic<size_t> ni{streaming ? (size_t)-1 : starts.size()};             // the number of items ((size_t)-1: not known yet)
+	size_t produced = streaming ? 0 : starts.size();                            // items that exist (guarded by mu)
+	if (!streaming) for (size_t i = 0; i < starts.size(); ++i) { items[i].begin = starts[i]; items[i].end = i + 1 < starts.size() ? starts[i + 1] : size; }
 	// ---- the read length: from the head of the first item's text -------------------------------------------------------------------
 	int L = *L_io;
 	// ---- workers + uploader --------------------------------------------------------------------------------------------------------
@@ -261,7 +270,8 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 	size_t sent = 0;                                                            // items the uploader is done with (guarded by mu)
 	std::atomic<int> fail{0};                                                   // 1 = not this route after all, < 0 = error
 	std::string fail_msg;
-	const size_t window = 3 * nt + 2;
+	const size_t window = streaming ? nt + 4 : 3 * nt + 2;
+	std::atomic<size_t> est_items{0};                                           // (streaming: the decoder's guess after its first piece, for the size of the device array)
 	int L_shared = L;                                                           // (guarded by mu; item 0 settles it when *L_io is 0)
 	auto give_up = [&](int code, const char *msg) { { std::lock_guard<std::mutex> g(mu); if (!fail) { fail = code; fail_msg = msg; } } cv.notify_all(); };
 	Pool texts, rowbufs;
@@ -279,9 +289,10 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			const size_t i = next_item.fetch_add(1);
 			if (i >= ni || fail) return;
 			long long tq = now_ns();
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || i < sent + window; }); if (fail) return; }
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || i >= ni || (i < produced && i < sent + window); }); if (fail || i >= ni) return; }
 			t_wait += now_ns() - tq; tq = now_ns();
 			Item &it = items[i];
+			if (!streaming) {
 			// inflate the item's members
 			in.resize(it.end - it.begin);
 			if (!read_at(fd.f, in.data(), in.size(), it.begin)) { give_up(MCOM_E_ARG, "read error"); return; }
@@ -307,6 +318,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 			}
 			if (bad) { texts.put(tbuf, tcap); give_up(1, "the members do not tile the file"); return; }
 			it.text.p = tbuf; it.text.cap = tcap; it.text.n = have;
+			}
 			t_inflate += now_ns() - tq; tq = now_ns();
 			// the read length (item 0, from its first record) and this text's first record boundary
 			const char *tb = it.text.data(), *te = tb + it.text.size();
@@ -385,7 +397,7 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 		if (!to_host && (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess)) { bail(MCOM_E_HIP, "no usable GPU"); cs = nullptr; }
 		for (size_t i = 0; i < ni && (cs || to_host); ++i) {
 			long long tq = now_ns();
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[i].state >= 2; }); if (fail) break; }
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || i >= ni || items[i].state >= 2; }); if (fail || i >= ni) break; }
 			t_up_wait += now_ns() - tq; tq = now_ns();
 			Item &it = items[i];
 			int len; { std::lock_guard<std::mutex> g(mu); len = L_shared; }
@@ -394,8 +406,8 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 				std::string rec(it.text.data() + it.tail, it.text.size() - it.tail);
 				bool done = false, bad_shape = false;
 				for (size_t j = i + 1; !done && !bad_shape; ++j) {
+					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || j >= ni || items[j].state >= 1; }); if (fail) break; }
 					if (j >= ni) { rec.push_back('\n'); done = true; break; }              // the file ends here: the last line may lack its newline
-					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || items[j].state >= 1; }); if (fail) break; }
 					const Item &nx = items[j];
 					const size_t headn = std::min(nx.first, nx.text.size());
 					rec.append(nx.text.data(), headn);
@@ -421,7 +433,8 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 				total += it.n_rows;
 			} else if (bytes) {
 				if (total + it.n_rows > dev_cap) {
-					size_t want = dev_cap ? dev_cap * 2 : std::max<size_t>(it.n_rows * (ni + 1) + it.n_rows / 4, (size_t)1 << 20);
+					const size_t items_in_all = ni != (size_t)-1 ? (size_t)ni : std::max<size_t>(est_items.load(), i + 1);
+					size_t want = dev_cap ? dev_cap * 2 : std::max<size_t>(it.n_rows * (items_in_all + 1) + it.n_rows / 4, (size_t)1 << 20);
 					while (want < total + it.n_rows) want *= 2;
 					uint8_t *nd = nullptr;
 					if (hipMalloc(&nd, want * (size_t)len + 16) != hipSuccess) { bail(MCOM_E_NOMEM, "out of device memory"); break; }
@@ -451,16 +464,84 @@ int mcom_fastq_gz_members(const char *path, int device, int *L_io, uint8_t **d_r
 		for (hipEvent_t e : spare) (void)hipEventDestroy(e);
 		if (cs) (void)hipStreamDestroy(cs);
 	});
+	// ---- streaming: the one thread that decodes -------------------------------------------------------------------------------------
+	auto producer = [&]() {
+		void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd.f, 0);
+		if (map == MAP_FAILED) { give_up(1, "mmap"); return; }
+		(void)madvise(map, size, MADV_SEQUENTIAL);
+		const uint8_t *base = (const uint8_t*)map;
+		const size_t H = 32768;
+		std::vector<char> hist(H);
+		size_t at = 0, k = 0;
+		bool file_done = false;
+		while (!file_done && !fail) {
+			// the member's header (RFC 1952)
+			uint32_t b2 = 0;
+			if (size - at < 18 || !member_header(base + at, size - at, &b2)) { give_up(1, "not a gzip member"); break; }
+			const unsigned flg = base[at + 3];
+			size_t hp = at + 10;
+			if (flg & 4) { hp += 2 + ((size_t)base[at + 10] | ((size_t)base[at + 11] << 8)); }
+			if (flg & 8) { while (hp < size && base[hp]) ++hp; ++hp; }
+			if (flg & 16) { while (hp < size && base[hp]) ++hp; ++hp; }
+			if (flg & 2) hp += 2;
+			if (hp + 8 > size) { give_up(1, "truncated gzip file"); break; }
+			mcom_inflate_stream st;
+			mcom_inflate_begin(&st, base + hp, size - hp);
+			uint32_t crc = 0; uint64_t isize = 0; size_t hist_n = 0;
+			bool member_done = false;
+			while (!member_done) {
+				if (k >= ni_cap) { give_up(1, "too many pieces"); break; }
+				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return fail || produced < sent + window; }); if (fail) break; }
+				size_t cap = 0;
+				char *buf = (char*)texts.get(H + piece + 64, &cap);
+				if (!buf) { give_up(MCOM_E_NOMEM, "out of memory"); break; }
+				memcpy(buf + H - hist_n, hist.data() + H - hist_n, hist_n);       // (the history sits at the END of hist)
+				size_t n = 0;
+				const long long tq = now_ns();
+				const int rc = mcom_inflate_run(&st, (uint8_t*)buf + H, piece, hist_n, &n);
+				if (rc != MCOM_INFLATE_OK && rc != MCOM_INFLATE_ROOM) { texts.put(buf, cap); give_up(1, "not a valid deflate stream"); break; }
+				crc = mcom_crc32(crc, (const uint8_t*)buf + H, n); isize += n;
+				t_inflate += now_ns() - tq;
+				if (n >= H) { memcpy(hist.data(), buf + H + n - H, H); hist_n = H; }
+				else { memmove(hist.data(), hist.data() + n, H - n); memcpy(hist.data() + H - n, buf + H, n); hist_n = std::min(H, hist_n + n); }
+				member_done = rc == MCOM_INFLATE_OK;
+				if (member_done) {
+					const size_t tr = (size_t)(st.in - base);
+					if (tr + 8 > size) { texts.put(buf, cap); give_up(1, "truncated gzip file"); break; }
+					const uint32_t c = (uint32_t)base[tr] | ((uint32_t)base[tr + 1] << 8) | ((uint32_t)base[tr + 2] << 16) | ((uint32_t)base[tr + 3] << 24);
+					const uint32_t z = (uint32_t)base[tr + 4] | ((uint32_t)base[tr + 5] << 8) | ((uint32_t)base[tr + 6] << 16) | ((uint32_t)base[tr + 7] << 24);
+					if (c != crc || z != (uint32_t)isize) { texts.put(buf, cap); give_up(1, "gzip member: CRC-32 or length differ"); break; }
+					at = tr + 8;
+					file_done = at >= size;
+				}
+				if (k == 0) { const size_t used = std::max<size_t>((size_t)(st.in - base), 1); est_items = size / used + size / used / 8 + 3; }
+				{
+					std::lock_guard<std::mutex> g(mu);
+					Item &it = items[k];
+					it.text.p = buf; it.text.cap = cap; it.text.n = n; it.text.off = H;
+					produced = ++k;
+					if (file_done) ni = k;
+				}
+				cv.notify_all();
+			}
+			mcom_inflate_end(&st);
+			if (!member_done) break;
+		}
+		munmap(map, size);
+	};
+	std::thread prod;
+	if (streaming) prod = std::thread(producer);
 	std::vector<std::thread> th;
-	for (size_t t = 0; t < std::max<size_t>(2, std::min(nt, ni)); ++t) th.emplace_back(worker);   // (two at least: the worker of item i waits for the text of item i + 1, which somebody else must make)
+	for (size_t t = 0; t < std::max<size_t>(2, std::min<size_t>(nt, ni)); ++t) th.emplace_back(worker);   // (two at least: the worker of item i waits for the text of item i + 1, which somebody else must make)
 	for (auto &x : th) x.join();
+	if (prod.joinable()) prod.join();
 	w_workers = wall();
 	{ std::lock_guard<std::mutex> g(mu); if (!fail && next_item < ni) fail = 1; }
 	cv.notify_all();
 	up.join();
 	for (Item &it : items) { if (it.text.p) { texts.put(it.text.p, it.text.cap); it.text.p = nullptr; } if (it.rows) { rowbufs.put(it.rows, it.rows_cap); it.rows = nullptr; } }
 	if (trace) fprintf(stderr, "mcom_fastq_gz: wall: discovery %.3f, first item sent %.3f, workers joined %.3f, uploader joined %.3f\n", w_discovery, w_first_sent, w_workers, wall());
-	if (trace) fprintf(stderr, "mcom_fastq_gz: %zu items, %zu threads; worker seconds (sum over threads): wait %.3f read %.3f inflate %.3f parse %.3f; uploader: wait %.3f copy %.3f\n", ni, th.size(),
+	if (trace) fprintf(stderr, "mcom_fastq_gz: %zu items, %zu threads; worker seconds (sum over threads): wait %.3f read %.3f inflate %.3f parse %.3f; uploader: wait %.3f copy %.3f\n", (size_t)ni, th.size(),
 	                   t_wait / 1e9, t_read / 1e9, t_inflate / 1e9, t_parse / 1e9, t_up_wait / 1e9, t_up_copy / 1e9);
 	if (fail || up_rc) {
 		if (dev) (void)hipFree(dev);

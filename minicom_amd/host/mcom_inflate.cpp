@@ -16,6 +16,7 @@
 // index is masked, every distance checked against the bytes written, every copy against the end of the buffer.
 // Tests: tests/test_fastq.py (python's zlib as the checker: all levels, stored / fixed / dynamic blocks, random and corrupt input).
 #include "mcom_inflate.hpp"
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <immintrin.h>
@@ -207,18 +208,41 @@ uint32_t mcom_crc32(uint32_t crc, const uint8_t *p, size_t n)
 	return ~c;
 }
 
-// One raw deflate stream at in[0 .. in_n) into out[0 .. out_cap).  MCOM_INFLATE_OK: *in_used bytes were the stream (it ends on a byte
-// boundary behind its last block), *out_n bytes came out.
-int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_cap, size_t *in_used, size_t *out_n)
+// The decoder proper, resumable at the output side: the whole input is there (a mapped file, a member in memory), the output comes in
+// pieces.  mcom_inflate_run decodes into out[0 .. out_cap) until the stream ends (MCOM_INFLATE_OK) or the piece is full (MCOM_INFLATE_ROOM:
+// call again with the next piece); `hist` bytes in front of out are earlier output of the same stream that matches may reach back into
+// (a caller that changes buffers copies the last 32 KB in front of the new one).  A piece may end anywhere, also inside a match's room:
+// a symbol that does not fit is not started.
+void mcom_inflate_begin(mcom_inflate_stream *s, const uint8_t *in, size_t in_n)
 {
-	const u8 *in = in0, *const in_end = in0 + in_n;
+	memset(s, 0, sizeof *s);
+	s->in = in; s->in_end = in + in_n;
+}
+void mcom_inflate_end(mcom_inflate_stream *s) { delete (Tables*)s->dyn; s->dyn = nullptr; }
+
+int mcom_inflate_run(mcom_inflate_stream *S, uint8_t *out0, size_t out_cap, size_t hist, size_t *out_n)
+{
+	const u8 *in = S->in, *const in_end = S->in_end;
 	u8 *out = out0, *const out_end = out0 + out_cap;
-	u64 bb = 0; u32 bl = 0;                                                       // bit buffer: bl valid bits at the bottom of bb, nothing above them
-	Tables *dyn = nullptr;
-	struct Free { Tables *&p; ~Free() { delete p; } } free_dyn{dyn};
-	auto fill = [&]() { while (bl < 56 && in < in_end) { bb |= (u64)*in++ << bl; bl += 8; } };   // (bl stays below 64)
-	int last = 0;
-	while (!last) {
+	u64 bb = S->bb; u32 bl = S->bl;                                               // bit buffer: bl valid bits at the bottom of bb, nothing above them
+	Tables *dyn = (Tables*)S->dyn;
+	int last = S->last;
+	int phase = S->phase;                                                         // 0 in front of a block header, 1 inside a Huffman block, 2 inside a stored block
+	const Tables *T = (const Tables*)S->tables;
+	u32 stored_left = S->stored_left;
+	// (errors leave the stream where it is: it is not continued.  A macro, not a lambda: a closure over in / bb / bl by reference costs the loops their registers)
+#define MCOM_LEAVE(code) do { S->in = in; S->bb = bb; S->bl = bl; S->dyn = dyn; S->last = last; S->phase = phase; S->tables = T; S->stored_left = stored_left; \
+                              *out_n = (size_t)(out - out0); return (code); } while (0)
+#define fill() do { while (bl < 56 && in < in_end) { bb |= (u64)*in++ << bl; bl += 8; } } while (0)   /* (bl stays below 64) */
+	for (;;) {
+		if (phase == 2) {                                                          // the bytes of a stored block
+			const size_t k = std::min<size_t>(stored_left, (size_t)(out_end - out));
+			memcpy(out, in, k); in += k; out += k; stored_left -= (u32)k;
+			if (stored_left) MCOM_LEAVE(MCOM_INFLATE_ROOM);
+			phase = 0;
+		}
+		if (phase == 0) {
+		if (last) break;
 		fill();
 		if (bl < 3) return MCOM_INFLATE_TRUNCATED;
 		last = (int)(bb & 1); const u32 type = (u32)(bb >> 1) & 3u;
@@ -230,12 +254,10 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 			if ((len ^ nlen) != 0xFFFFu) return MCOM_INFLATE_CORRUPT;
 			in += 4;
 			if ((size_t)(in_end - in) < len) return MCOM_INFLATE_TRUNCATED;
-			if ((size_t)(out_end - out) < len) return MCOM_INFLATE_ROOM;
-			memcpy(out, in, len); in += len; out += len;
+			stored_left = len; phase = 2;
 			continue;
 		}
 		if (type == 3) return MCOM_INFLATE_CORRUPT;
-		const Tables *T;
 		if (type == 1) T = &fixed_tables();
 		else {
 			fill();
@@ -268,11 +290,13 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 				memset(lens + at, v, rep); at += (int)rep;
 			}
 			if (lens[256] == 0) return MCOM_INFLATE_CORRUPT;                       // no end-of-block code
-			if (!dyn) dyn = new (std::nothrow) Tables;
+			if (!dyn) { dyn = new (std::nothrow) Tables; S->dyn = dyn; }          // (the stream owns it from here: mcom_inflate_end)
 			if (!dyn) return MCOM_INFLATE_NOMEM;
 			if (!build_table(lens, hlit, dyn->ll, LL_BITS, LL_SIZE, ll_entry) || !build_table(lens + hlit, hdist, dyn->d, D_BITS, D_SIZE, d_entry)) return MCOM_INFLATE_CORRUPT;
 			pair_literals(dyn->ll);
 			T = dyn;
+		}
+		phase = 1;
 		}
 		const u32 *const lt = T->ll, *const dt = T->d;
 		const u32 LM = (1u << LL_BITS) - 1, DM = (1u << D_BITS) - 1;
@@ -320,7 +344,7 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 				bb >>= dxb; bl -= dxb;
 				MCOM_REFILL();
 				e = lt[bb & LM];
-				if (dist > (size_t)(out - out0)) return MCOM_INFLATE_CORRUPT;
+				if (dist > hist + (size_t)(out - out0)) return MCOM_INFLATE_CORRUPT;
 				const u8 *src = out - dist; u8 *const end = out + length;
 				if (dist >= 8) {
 					store64(out, load64(src)); store64(out + 8, load64(src + 8));
@@ -340,6 +364,7 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 		// ---- the careful loop: the same decoding with every step checked ----------------------------------------------------------------
 		while (!eob) {
 			fill();
+			const u8 *const in_s = in; const u64 bb_s = bb; const u32 bl_s = bl;  // (a symbol that does not fit the piece is taken back whole)
 			u32 e = lt[bb & LM];
 			if (e_kind(e) == K_SUB) e = lt[e_val(e) + ((u32)(bb >> LL_BITS) & ((1u << e_extra(e)) - 1))];
 			if (!(e & LITF) && e_kind(e) == K_BAD) return bl < 15 && in == in_end ? MCOM_INFLATE_TRUNCATED : MCOM_INFLATE_CORRUPT;
@@ -347,7 +372,7 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 			bb >>= e_bits(e); bl -= e_bits(e);
 			if (e & LITF) {
 				const size_t k = 1 + ((e >> 8) & 1u);
-				if ((size_t)(out_end - out) < k) return MCOM_INFLATE_ROOM;
+				if ((size_t)(out_end - out) < k) { in = in_s; bb = bb_s; bl = bl_s; MCOM_LEAVE(MCOM_INFLATE_ROOM); }
 				*out++ = (u8)e_val(e); if (k == 2) *out++ = (u8)(e >> 24);
 				continue;
 			}
@@ -365,16 +390,30 @@ int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_
 			const u32 dxb = e_extra(d);
 			const u32 dist = e_val(d) + ((u32)bb & ((1u << dxb) - 1));
 			bb >>= dxb; bl -= dxb;
-			if (dist > (size_t)(out - out0)) return MCOM_INFLATE_CORRUPT;
-			if ((size_t)(out_end - out) < length) return MCOM_INFLATE_ROOM;
+			if (dist > hist + (size_t)(out - out0)) return MCOM_INFLATE_CORRUPT;
+			if ((size_t)(out_end - out) < length) { in = in_s; bb = bb_s; bl = bl_s; MCOM_LEAVE(MCOM_INFLATE_ROOM); }
 			const u8 *src = out - dist;
 			for (u32 i = 0; i < length; ++i) out[i] = src[i];
 			out += length;
 		}
+		phase = 0;                                                                 // the block's end code: the next header, or the end
 	}
-	in -= bl >> 3;                                                                 // whole bytes still in the buffer were never part of the stream
-	*in_used = (size_t)(in - in0); *out_n = (size_t)(out - out0);
-	return MCOM_INFLATE_OK;
+	in -= bl >> 3; bb = 0; bl = 0;                                                 // whole bytes still in the buffer were never part of the stream
+	MCOM_LEAVE(MCOM_INFLATE_OK);
+#undef MCOM_LEAVE
+#undef fill
+}
+
+// One raw deflate stream at in[0 .. in_n) into out[0 .. out_cap), all at once.  MCOM_INFLATE_OK: *in_used bytes were the stream (it ends on
+// a byte boundary behind its last block), *out_n bytes came out.  MCOM_INFLATE_ROOM: out is too small (nothing is kept).
+int mcom_inflate_raw(const uint8_t *in0, size_t in_n, uint8_t *out0, size_t out_cap, size_t *in_used, size_t *out_n)
+{
+	mcom_inflate_stream st;
+	mcom_inflate_begin(&st, in0, in_n);
+	const int rc = mcom_inflate_run(&st, out0, out_cap, 0, out_n);
+	*in_used = (size_t)(st.in - in0);
+	mcom_inflate_end(&st);
+	return rc;
 }
 
 // One gzip member (header, deflate stream, CRC-32 + ISIZE) at in[0 .. in_n).

@@ -133,10 +133,19 @@ def test_gzip_files_of_many_members_are_read_by_all_cores_and_equal_the_plain_fi
     assert read_into(p) == (0, L, n) and np.array_equal(out, reads) and items[-1] >= 8
     rc, _, cnt = read_into(p, cap=n - 5)                                       # more reads than the caller has room for
     assert rc != 0
-    # one member: nothing to share out, the sequential reader
-    with gzip.open(str(tmp_path / "one.fastq.gz"), "wb", compresslevel=1) as g:
-        g.write(data)
+    # ONE member (what plain `gzip` writes) cannot be cut, but decoding and parsing are two stages: one thread decodes the member in pieces of
+    # text (mcom_inflate_run), the workers parse the pieces -- the pieces are the work items.  With and without the last newline.
+    for name, body in (("one", data), ("one_no_newline", data[:-1])):
+        with gzip.open(str(tmp_path / (name + ".fastq.gz")), "wb", compresslevel=1) as g:
+            g.write(body)
+        out[:] = 0
+        assert read_into(str(tmp_path / (name + ".fastq.gz"))) == (0, L, n) and np.array_equal(out, reads), name
+        assert items[-1] >= 4, (name, items)
     assert np.array_equal(read_fastq(str(tmp_path / "one.fastq.gz")), reads)
+    # a damaged member (one bit of its CRC-32) is an error whichever reader meets it
+    dmg = bytearray(open(str(tmp_path / "one.fastq.gz"), "rb").read()); dmg[-6] ^= 1
+    open(str(tmp_path / "dmg.fastq.gz"), "wb").write(bytes(dmg))
+    assert read_into(str(tmp_path / "dmg.fastq.gz"))[0] != 0
     # a character outside ACGTN in a many-member file is an error, not a silent change
     bad = bytearray(data); bad[recs[70000] + 12] = ord("a")
     _gzip_members(str(tmp_path / "bad.fastq.gz"), bytes(bad), sorted({int(x) for x in rng.integers(1, len(data) - 1, 60)}))

@@ -40,8 +40,36 @@ def gzip_members(src: str, dst: str, member_bytes: int = 8 << 20, level: int = 1
     return n
 
 
+def gzip_one_member(src: str, dst: str, chunk_bytes: int = 8 << 20, level: int = 1, threads: int = 16) -> None:
+    """src -> dst as a gzip file of ONE member (what plain `gzip` writes), made by many threads the way pigz makes it: every chunk becomes a
+    raw deflate stream that ends on a byte boundary without a final block (Z_SYNC_FLUSH), the last one ends the stream, and the pieces
+    one behind the other are one valid deflate stream; header and CRC-32 / ISIZE trailer around it."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(arg):
+        block, last = arg
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return c.compress(block) + (c.flush(zlib.Z_FINISH) if last else c.flush(zlib.Z_SYNC_FLUSH))
+    total = os.path.getsize(src)
+    crc, done = 0, 0
+    with open(src, "rb") as f, open(dst, "wb") as g, ThreadPoolExecutor(threads) as ex:
+        g.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        while done < total:
+            blocks = [b for b in (f.read(chunk_bytes) for _ in range(4 * threads)) if b]
+            args = []
+            for b in blocks:
+                done += len(b); args.append((b, done >= total))
+            for comp in ex.map(one, args):
+                g.write(comp)
+            for b in blocks:
+                crc = zlib.crc32(b, crc)
+        g.write(struct.pack("<II", crc, total & 0xFFFFFFFF))
+
+
 def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads: int = 1_000_000, workdir: str | None = None, keep: bool = False, mode: str = "default",
-                    gz: bool = False):
+                    gz: bool = False, gz_one_member: bool = False):
     """mode: "default" (multiset of reads), "order" (minicom -p), "paired" (minicompe: the first n / 2 reads are file 1, the others their
     mates in file 2); gz: the input is a .fastq.gz of many members (8 MB of text each), inflated and parsed by all cores
     (host/mcom_fastq_gz.cpp)"""
@@ -74,7 +102,10 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
         if gz:
             for path in (fq, fq2):
                 if path:
-                    gz_members += gzip_members(path, path + ".gz", threads=max(1, host_cores()))
+                    if gz_one_member:
+                        gzip_one_member(path, path + ".gz", threads=max(1, host_cores())); gz_members += 1
+                    else:
+                        gz_members += gzip_members(path, path + ".gz", threads=max(1, host_cores()))
                     os.remove(path)
             fq, fq2 = fq + ".gz", (fq2 + ".gz" if fq2 else None)
         t_write_input = time.perf_counter() - t
@@ -101,7 +132,12 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
                "fastq_GB_per_s": round(size / (t1 - t0) / 1e9, 2),
                "note": "FASTQ file (page cache) -> parse -> HBM -> Stage 1 + Stage 2 -> stream files written; the entropy coder (bsc / 7z / xz, external) is not part of it",
                "input_written_in_s": round(t_write_input, 1)}
-        if gz:
+        if gz and gz_one_member:
+            res["gzip_members"] = 1
+            res["fastq_text_GB_per_s"] = round(n * (2 * L + 6 + len(str(n))) / (t1 - t0) / 1e9, 2)
+            res["note"] = ("the same from a .fastq.gz of ONE gzip member (what plain `gzip` writes; zlib level 1): the member cannot be cut, so one thread decodes it in pieces "
+                           "of text (host/mcom_inflate.cpp) and the other cores parse the pieces; gzread + one parsing thread, as the reference reads, ran at ~1.5 Mreads/s")
+        elif gz:
             res["gzip_members"] = gz_members
             res["fastq_text_GB_per_s"] = round(n * (2 * L + 6 + len(str(n))) / (t1 - t0) / 1e9, 2)
             res["note"] = ("the same from a .fastq.gz of %d gzip members (8 MB of text each, zlib level 1; quality lines are all 'I', so this file inflates "
