@@ -233,6 +233,19 @@ def test_pipeline_from_a_gzip_file_of_many_members(tmp_path):
     p.pre_process()
     q = Pipeline(reads, host_threads=4); q.pre_process()
     assert p.result_digest() == q.result_digest()
+    p.close()
+    # ... and through the two-stage route of a file of ONE member (one decoding thread, pieces of text parsed by the others, rows sent from
+    # page-locked blocks): the same pipeline
+    import ctypes as C
+    from minicom_amd.pipeline import load_host_library
+    with gzip.open(str(tmp_path / "one.fastq.gz"), "wb", compresslevel=1) as g:
+        g.write(data)
+    p = Pipeline.from_fastq(str(tmp_path / "one.fastq.gz"), host_threads=4)
+    lib = load_host_library(); lib.mcomh_test_gz_items.restype = C.c_long
+    assert lib.mcomh_test_gz_items() >= 4                                       # (the pieces: it did not go to the sequential reader)
+    assert (p.n, p.L) == reads.shape
+    p.pre_process()
+    assert p.result_digest() == q.result_digest()
     p.close(); q.close()
 
 
