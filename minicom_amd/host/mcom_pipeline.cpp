@@ -416,6 +416,8 @@ static int allreduce_host(P *p, uint64_t *vals, size_t n, int op)
 }
 // all-gather of a device array: rank q's part is elements [first[q], first[q] + cnt[q]); send = NULL: mine is in place.
 // guarded = false: the exchange directly follows another one, with nothing in between that can fail
+// bytes this rank has sent so far (the exchanges' statistics b_x_*: what each of them sends per step)
+static double xbytes(P *p) { uint64_t b = 0; if (p->comm) mcomh_comm_stats(p->comm, &b, nullptr); return (double)b; }
 template <class T> static int gatherv(P *p, T *buf, const std::vector<uint64_t> &first, const std::vector<uint64_t> &cnt, const T *send = nullptr, bool guarded = true)
 {
 	const int R = p->world;
@@ -733,7 +735,7 @@ static int kt_for_reads_impl(mcomh_pipeline *p)
 		const int R = p->world;
 		std::vector<uint64_t> first(R), cnt(R), fW(R), cW(R), fN(R), cN(R);
 		for (int q = 0; q < R; ++q) { first[q] = p->shard_lo[q]; cnt[q] = p->shard_lo[q + 1] - p->shard_lo[q]; fW[q] = first[q] * p->W; cW[q] = cnt[q] * p->W; fN[q] = first[q] * p->NW; cN[q] = cnt[q] * p->NW; }
-		const double tx = now_ms();
+		const double tx = now_ms(), bx0 = xbytes(p);
 		if ((rc = gatherv(p, p->d_packed.p, fW, cW)) || (rc = gatherv(p, p->d_cls.p, first, cnt, (const uint8_t*)nullptr, false))) return rc;
 		uint32_t mx = 0;
 		if ((rc = p->gpu(mcom_max_u16(p->ctx, p->d_ncnt.p, nl, &mx)))) return rc;
@@ -744,7 +746,7 @@ static int kt_for_reads_impl(mcomh_pipeline *p)
 			if (r0 && (rc = p->hipc(hipMemsetAsync(p->d_nmask.p, 0, r0 * p->NW * 8, p->stream), "clear"))) return rc;
 			if (r0 + nl < n && (rc = p->hipc(hipMemsetAsync(p->d_nmask.p + (r0 + nl) * p->NW, 0, (n - r0 - nl) * p->NW * 8, p->stream), "clear"))) return rc;
 		}
-		p->stat["t_x_reads"] += now_ms() - tx;
+		p->stat["t_x_reads"] += now_ms() - tx; p->stat["b_x_reads"] += xbytes(p) - bx0;
 	}
 	// The special reads (another class than 0: a handful per million on real data) are listed on the device and the LIST travels,
 	// on the copy stream, while the bucket stage starts; a thread sorts it into the seven id lists (rid order) -- nobody reads those
@@ -862,7 +864,7 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 		if (dist) {
 			// the exchange of the round: round 1 moves every kept read's record, later rounds the re-sketched rejects
 			// (kthread_bucket.c:205-212, :489-496 push them into the other bucket set)
-			const double tx = now_ms();
+			const double tx = now_ms(), bx0 = xbytes(p);
 			std::vector<uint64_t> cnt(R, 0), all;
 			if (!d_part.reserve(n_cur + 1)) return p->fail(MCOM_E_NOMEM, "exchange buffers");
 			if ((rc = p->gpu(mcom_partition_by_owner(p->ctx, cur, n_cur, NB_BITS, R, d_part.p, cnt.data()))) || (rc = gather_host(p, cnt.data(), R, all))) return rc;
@@ -876,7 +878,7 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 			if (r > 1 && (rc = p->gpu(mcom_sort_by_rid(p->ctx, d_recv.p, (size_t)b)))) return rc;
 			cur = d_recv.p; n_cur = (size_t)b;
 			p->stat["x_records"] += (double)b;
-			p->stat["t_x_records"] += now_ms() - tx;
+			p->stat["t_x_records"] += now_ms() - tx; p->stat["b_x_records"] += xbytes(p) - bx0;
 		}
 		size_t ns = 0, ng = 0, nm = 0, nrej = 0;
 		const double tg = busy_now(p);
@@ -945,9 +947,9 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 				                                        D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc2)))) return rc;
 				if (gc2[0] != gc[0] || gc2[1] != gc[1] || gc2[2] != gc[2] || gc2[3] != gc[3]) return p->fail(MCOM_E_ARG, "contig counts changed between the two calls");
 			}
-			const double tx = now_ms();
+			const double tx = now_ms(), bx0 = xbytes(p);
 			if ((rc = gatherv(p, D.seq.p, fc, cc)) || (rc = gatherv(p, D.soff.p, fn, cn, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.mem.p, fm, cm, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.moff.p, fn, cn, (const uint64_t*)nullptr, false))) return rc;
-			p->stat["t_x_contigs"] += now_ms() - tx;
+			p->stat["t_x_contigs"] += now_ms() - tx; p->stat["b_x_contigs"] += xbytes(p) - bx0;
 			D.n += tn; D.chars += tc; D.members += tm;
 			nrej = gc[3];
 		}
@@ -1151,9 +1153,9 @@ static int sketch_first_dist(P *p, DevSet &S, size_t n_first, uint64_t chars_fir
 	if (total >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records");
 	if (!S.rec.reserve(total + room + 1)) return p->fail(MCOM_E_NOMEM, "minimizer records");
 	if ((rc = p->gpu(mcom_records_rebase(p->ctx, tmp.p, tl, (uint32_t)c0, toff.p, nloc, (uint32_t)first[me])))) return rc;
-	const double tx = now_ms();
+	const double tx = now_ms(), bx0 = xbytes(p);
 	if ((rc = gatherv(p, S.rec.p, first, cnt, tmp.p)) || (rc = gatherv(p, S.roff.p, fo, co, toff.p, false))) return rc;
-	p->stat["t_x_sketch"] += now_ms() - tx;
+	p->stat["t_x_sketch"] += now_ms() - tx; p->stat["b_x_sketch"] += xbytes(p) - bx0;
 	const uint32_t t32 = (uint32_t)total;
 	if ((rc = p->h2d(S.roff.p + n_first, &t32, 1, "upload")) || (rc = p->sync("upload"))) return rc;
 	return MCOM_OK;
@@ -1184,9 +1186,9 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm_loc, mcom
 		for (int q = 0; q < R; ++q) { so[q] = a * 16; sb[q] = mine[q] * 16; a += mine[q]; ro[q] = b * 16; rb[q] = all[(size_t)q * R + me] * 16; b += all[(size_t)q * R + me]; }
 		if (b != cnt[me]) return p->fail(MCOM_E_ARG, "index exchange: counts disagree");
 		if (!part.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "index records");
-		const double tx = now_ms();
+		const double tx = now_ms(), bx0 = xbytes(p);
 		if ((rc = alltoallv_dev(p, send.p, so.data(), sb.data(), part.p, ro.data(), rb.data()))) return rc;
-		p->stat["t_x_index"] += now_ms() - tx;
+		p->stat["t_x_index"] += now_ms() - tx; p->stat["b_x_index"] += xbytes(p) - bx0;
 	}
 	mcom_idx *mi = nullptr;
 	if ((rc = p->gpu(mcom_idx_create(p->ctx, tm, p->k, NB_BITS, &mi)))) return rc;
@@ -1201,14 +1203,14 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm_loc, mcom
 	const bool global_table = rc == MCOM_E_OVERFLOW;                                  // the same on every rank: mxa is
 	mcom_mm128 *d_rec = nullptr; uint64_t *d_slots = nullptr; uint32_t region = 0;
 	mcom_idx_buffers(mi, &d_rec, &d_slots, &region);
-	const double tx = now_ms();
+	const double tx = now_ms(), bx0 = xbytes(p);
 	rc = gatherv(p, d_rec, first, cnt);
 	if (!rc && !global_table) {
 		std::vector<uint64_t> fs(R), cs(R);
 		for (int q = 0; q < R; ++q) { fs[q] = 2ull * bucket0(q) * region; cs[q] = 2ull * (bucket0(q + 1) - bucket0(q)) * region; }
 		rc = gatherv(p, d_slots, fs, cs);
 	}
-	p->stat["t_x_index"] += now_ms() - tx;
+	p->stat["t_x_index"] += now_ms() - tx; p->stat["b_x_index"] += xbytes(p) - bx0;
 	if (!rc && global_table) { rc = p->gpu(mcom_idx_table_global(p->ctx, mi)); p->stat["idx_global_tables"] += 1; }
 	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
 	*out = mi;
@@ -1286,9 +1288,9 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 		for (int q = 0; q < R; ++q) { first[q] = tw * (uint64_t)q / R; cnt[q] = tw * (uint64_t)(q + 1) / R - first[q]; }
 		int rc2 = p->gpu(mcom_pack_contigs_words(p->ctx, S.seq.p, soff, cw, (uint32_t)n, tw, out, first[me], first[me] + cnt[me]));
 		if (rc2) return rc2;
-		const double tx = now_ms();
+		const double tx = now_ms(), bx0 = xbytes(p);
 		rc2 = gatherv(p, out, first, cnt);
-		p->stat["t_x_packed"] += now_ms() - tx;
+		p->stat["t_x_packed"] += now_ms() - tx; p->stat["b_x_packed"] += xbytes(p) - bx0;
 		return rc2;
 	};
 	// room behind the end of a store array, made by growing it (the data in front is kept); the bucket stage leaves some (arena_slack)
@@ -1349,9 +1351,9 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				hc[0] = hc[1] = 0;
 				for (int q = 0; q < R; ++q) { first[q] = hc[1]; cnt[q] = all[2 * q + 1]; hc[0] += all[2 * q]; hc[1] += all[2 * q + 1]; }
 				if (!d_pairs.reserve(hc[1] + 1)) { mcom_idx_destroy(p->ctx, mi); return p->fail(MCOM_E_NOMEM, "candidate pairs"); }
-				const double tx = now_ms();
+				const double tx = now_ms(), bx0 = xbytes(p);
 				rc = gatherv(p, d_pairs.p, first, cnt, d_pairs_loc.p);
-				p->stat["t_x_pairs"] += now_ms() - tx;
+				p->stat["t_x_pairs"] += now_ms() - tx; p->stat["b_x_pairs"] += xbytes(p) - bx0;
 				if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
 			}
 			mcom_idx_destroy(p->ctx, mi);
@@ -1512,13 +1514,13 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				            (rc = p->gpu(mcom_records_rebase(p->ctx, T.rec.p, 0, 0, T.roff.p, njl, (uint32_t)fr[me]))))) return rc;
 				if (!room64(S.mem, S.members, tot[0] + 1) || !S.seq.grow((size_t)(S.chars + tot[1] + 16), (size_t)S.chars, p->stream) || !S.rec.grow((size_t)(S.nrec + tn + 1), (size_t)S.nrec, p->stream))
 					return p->fail(MCOM_E_NOMEM, "contig store");
-				const double tx = now_ms();
+				const double tx = now_ms(), bx0 = xbytes(p);
 				const uint64_t em = S.members + tot[0], ec = S.chars + tot[1]; const uint32_t er = (uint32_t)(S.nrec + tn);
 				if ((rc = gatherv(p, S.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, S.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, S.seq.p, fc, cc, T.seq.p, false)) || (rc = gatherv(p, S.soff.p, fj, cj, T.soff.p, false)) ||
 				    (rc = gatherv(p, S.rec.p, fr, cr, T.rec.p, false)) || (rc = gatherv(p, S.roff.p, fj, cj, T.roff.p, false))) return rc;
 				if ((rc = p->h2d(S.moff.p + n_store + nj, &em, 1, "upload")) || (rc = p->h2d(S.soff.p + n_store + nj, &ec, 1, "upload")) || (rc = p->h2d(S.roff.p + n_store + nj, &er, 1, "upload"))) return rc;
 				if ((rc = p->sync("merged contigs"))) return rc;                             // (em / ec / er live on this stack frame)
-				p->stat["t_x_merged"] += now_ms() - tx;
+				p->stat["t_x_merged"] += now_ms() - tx; p->stat["b_x_merged"] += xbytes(p) - bx0;
 				lap("t_merge_gather");
 			}
 			// the packed form of the new contigs, behind the packed store
@@ -1889,7 +1891,7 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 				uint64_t n_ent = cnt[0];
 				if (R > 1) {
 					// the exchange: entries to the owner of their key (4 + 8 bytes each, two all-to-alls)
-					const double tx = now_ms();
+					const double tx = now_ms(), bx0 = xbytes(p);
 					std::vector<uint64_t> all, so(R), sb(R), ro(R), rb(R);
 					if ((rc = gather_host(p, cnt.data(), R, all))) return rc;
 					uint64_t a = 0, b = 0;
@@ -1898,7 +1900,7 @@ static int realign_hash_impl(mcomh_pipeline *p, int thr, long *cluster_reads)
 					auto scaled = [&](const std::vector<uint64_t> &v, uint64_t m) { std::vector<uint64_t> o(v); for (auto &x : o) x *= m; return o; };
 					if ((rc = alltoallv_dev(p, keyA.p, scaled(so, 4).data(), scaled(sb, 4).data(), keyB.p, scaled(ro, 4).data(), scaled(rb, 4).data())) ||
 					    (rc = alltoallv_dev(p, slotA.p, scaled(so, 8).data(), scaled(sb, 8).data(), slotB.p, scaled(ro, 8).data(), scaled(rb, 8).data(), false))) return rc;
-					p->stat["t_x_cindex"] += now_ms() - tx; p->stat["x_cindex_entries"] += (double)(a - cnt[me]);
+					p->stat["t_x_cindex"] += now_ms() - tx; p->stat["b_x_cindex"] += xbytes(p) - bx0; p->stat["x_cindex_entries"] += (double)(a - cnt[me]);
 					if (!keyA.reserve(b + 1) || !slotA.reserve(b + 1)) return p->fail(MCOM_E_NOMEM, "contig index");
 					n_ent = b;
 					rc = mcom_cindex_place(p->ctx, keyB.p, slotB.p, n_ent, 0, keyA.p, slotA.p, p->L, p->numdict, p->cix_geom, p->d_cix_keys.p, nwords);

@@ -52,7 +52,8 @@ def run_world(reads, n, L, world, single_gpu_path):
             counters = {k: p.stat(k) for k in ("rounds", "merge_rounds", "passes", "contigs_bucket", "contigs_combine", "cix_entries", "x_records", "x_cindex_entries")}
             laps = {k: round(p.stat(k), 2) for k in ("t_bk_pre", "t_bk_sort", "t_bk_gpu", "t_cb_upload", "t_cb_sketch", "t_cb_pack", "t_cb_idx", "t_cb_findnext", "t_claim", "t_merge_members", "t_merge_cons",
                                                      "t_merge_local", "t_merge_gather", "t_cb_copy", "t_cb_download", "t_cb_join", "t_cb_sg", "t_ra_setup", "t_ra_gpu", "t_ra_update", "t_ra_append", "t_ra_materialize",
-                                                     "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_pairs", "t_x_merged", "t_x_cindex")}
+                                                     "t_x_reads", "t_x_records", "t_x_contigs", "t_x_sketch", "t_x_index", "t_x_packed", "t_x_pairs", "t_x_merged", "t_x_cindex")}
+            laps.update({k: int(p.stat(k)) for k in ("b_x_reads", "b_x_records", "b_x_contigs", "b_x_sketch", "b_x_index", "b_x_packed", "b_x_pairs", "b_x_merged", "b_x_cindex")})
             res[rank] = {"reads": hi - lo, "stages": st, "busy_ms": round(sum(v["busy_ms"] for v in st.values()), 2), "kernel_classes_ms": prof,
                          "digest": digest, "counters": counters, "host_laps_ms": laps}
             p.close()
