@@ -195,6 +195,8 @@ int  mcom_idx_build(mcom_ctx *ctx, const mcom_mm128 *d_rec, size_t n, int k, int
 int  mcom_idx_create(mcom_ctx *ctx, size_t n, int k, int b, mcom_idx **out);
 int  mcom_idx_sort_part(mcom_ctx *ctx, mcom_idx *mi, const mcom_mm128 *d_rec, size_t n, size_t base_rec, uint32_t *h_max_bucket);
 int  mcom_idx_table_part(mcom_ctx *ctx, mcom_idx *mi, uint32_t max_bucket_all, uint32_t bucket0, uint32_t bucket1);
+/* the regions of all buckets from the sorted records of all parts, once they have been received (instead of receiving the regions too) */
+int  mcom_idx_table_all(mcom_ctx *ctx, mcom_idx *mi, uint32_t max_bucket_all);
 int  mcom_idx_table_global(mcom_ctx *ctx, mcom_idx *mi);
 int  mcom_idx_buffers(mcom_idx *mi, mcom_mm128 **d_rec, uint64_t **d_slots, uint32_t *region);
 /* radix_sort_128x with the reference's exact element order (sequential emulation, see mcom_radix_sort_128x

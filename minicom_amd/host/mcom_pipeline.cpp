@@ -1197,20 +1197,20 @@ static int build_index_dist(P *p, const mcom_mm128 *rec_m, uint64_t tm_loc, mcom
 	uint64_t mxa = mx;
 	if (!rc) rc = allreduce_host(p, &mxa, 1, 2);
 	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
-	auto bucket0 = [&](int q) { return (uint32_t)((((uint64_t)q << NB_BITS) + R - 1) / R); };   // first bucket with (beta * R) >> b == q
-	rc = mcom_idx_table_part(p->ctx, mi, (uint32_t)mxa, bucket0(me), bucket0(me + 1));
-	if (rc && rc != MCOM_E_OVERFLOW) { p->gpu(rc); mcom_idx_destroy(p->ctx, mi); return rc; }
-	const bool global_table = rc == MCOM_E_OVERFLOW;                                  // the same on every rank: mxa is
+	// the sorted parts are all-gathered; the table regions are made from them on every rank (round 5: the regions, sized for the fullest
+	// bucket and a quarter full, were 3 GB of the 13.8 a rank sent per step)
 	mcom_mm128 *d_rec = nullptr; uint64_t *d_slots = nullptr; uint32_t region = 0;
 	mcom_idx_buffers(mi, &d_rec, &d_slots, &region);
+	(void)d_slots; (void)region;
 	const double tx = now_ms(), bx0 = xbytes(p);
 	rc = gatherv(p, d_rec, first, cnt);
-	if (!rc && !global_table) {
-		std::vector<uint64_t> fs(R), cs(R);
-		for (int q = 0; q < R; ++q) { fs[q] = 2ull * bucket0(q) * region; cs[q] = 2ull * (bucket0(q + 1) - bucket0(q)) * region; }
-		rc = gatherv(p, d_slots, fs, cs);
-	}
 	p->stat["t_x_index"] += now_ms() - tx; p->stat["b_x_index"] += xbytes(p) - bx0;
+	bool global_table = false;
+	if (!rc) {
+		rc = mcom_idx_table_all(p->ctx, mi, (uint32_t)mxa);
+		if (rc == MCOM_E_OVERFLOW) { global_table = true; rc = MCOM_OK; }                 // (the same on every rank: mxa is)
+		else if (rc) p->gpu(rc);
+	}
 	if (!rc && global_table) { rc = p->gpu(mcom_idx_table_global(p->ctx, mi)); p->stat["idx_global_tables"] += 1; }
 	if (rc) { mcom_idx_destroy(p->ctx, mi); return rc; }
 	*out = mi;
