@@ -201,7 +201,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
 	bool loop = ctx->claim_route == 1;
 	if (!loop) {
-		unsigned grid = (unsigned)ctx->n_cu;
+		unsigned grid = (unsigned)ctx->n_cu;                                       // (round 5, tried: two workgroups per CU -- they are not resident together, the barrier waits ran out and the loop below took over: 5.8 s)
 		const unsigned need = (unsigned)((n_pairs + 16 * CL_THREADS - 1) / (16 * CL_THREADS));
 		if (grid > need) grid = need;
 		uint32_t n32 = (uint32_t)n_pairs;
