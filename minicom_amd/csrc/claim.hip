@@ -98,6 +98,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 		for (uint32_t c = blockIdx.x * CL_THREADS + threadIdx.x; c < chunks; c += stride) {
 			const uint4 d16 = ((const uint4*)dead)[c];
 			const uint32_t dw[4] = {d16.x, d16.y, d16.z, d16.w};
+			uint32_t bid_ci = 0xFFFFFFFFu;                                              // the query of the last edge of this chunk that bid
 #pragma unroll
 			for (int w = 0; w < 4; ++w) {
 				if (dw[w] == 0x01010101u) continue;
@@ -108,15 +109,19 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 					const mcom_mm128 pr = pairs[e];
 					const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
 					const unsigned long long inv = (unsigned long long)(0xFFFFFFFFu - e);
-					const bool mi = matched[ci] != 0, mj = matched[cj] != 0;
+					const bool mi = round > 1 && matched[ci] != 0, mj = round > 1 && matched[cj] != 0;   // (nothing is matched before the first takes: two random loads per edge less in the phase that sees every edge)
 					if (round > 1 && bestP[ci] == (pkey | inv) && bestP[cj] == (pkey | inv)) {   // the winner of the round before at both ends
 						if (!mi && !mj) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; }          // (a stale bid: an end was matched meanwhile)
 						dead[e] = 1;
 						continue;
 					}
 					if (mi || mj) { dead[e] = 1; continue; }
-					atomicMax(&bestC[ci], rkey | inv);
+					// The edges of one query lie one behind the other and share the end ci: an earlier one that bids in this phase is the smaller
+					// bidder there whatever this one does, so this one's bid at ci is left out (round 5: a third of the atomics of the first
+					// round).  At cj it must bid: it stands in front of later queries' edges there until its own fate is known.
+					if (bid_ci != ci) atomicMax(&bestC[ci], rkey | inv);
 					atomicMax(&bestC[cj], rkey | inv);
+					bid_ci = ci;
 					live = true;
 				}
 			}
