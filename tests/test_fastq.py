@@ -217,6 +217,26 @@ def test_the_member_decoder_against_zlib():
         gun(b"\x1f\x8b\x08\x00\0\0\0\0\0\x03" + os.urandom(rng.randrange(1, 3000)), rng.randrange(0, 100000))
 
 
+def test_the_member_decoder_under_the_sanitizers(tmp_path):
+    """tests/fuzz_inflate.cpp: the decoder compiled with AddressSanitizer + UBSan (CPU build: the GPU pool has no sanitizer runs) against exact-size
+    heap buffers, pieces of odd sizes, thousands of mutated members and random bytes -- an input is never trusted, no access leaves a buffer."""
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    host = os.path.join(here, "..", "minicom_amd", "host")
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "fuzz_inflate")
+    b = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + host,
+                        os.path.join(here, "fuzz_inflate.cpp"), os.path.join(host, "mcom_inflate.cpp"), "-lz", "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "exact ok 400" in r.stdout and "room 300" in r.stdout
+
+
 @pytest.mark.gpu
 def test_pipeline_from_a_gzip_file_of_many_members(tmp_path):
     """file -> HBM through the parallel gzip route -> pipeline = the pipeline over the array"""
