@@ -249,3 +249,55 @@ def test_stage2_join_equals_stage2_through_the_table(kind):
     else:
         assert a.stat("join_fallbacks") == 0 and a.stat("join_passes") == a.stat("passes") and a.stat("join_deferred") > 0
     a.close(); b.close()
+
+
+def _degenerate_sets(L):
+    """Read sets at the edges of the domain: a handful of reads, nothing but copies of one read (one huge group), homopolymers (the special-read
+    files of kthread_reads.c:84-126), nothing but N (Nfile, :219-224), reads just below and above the 0.4 L limit of N, a read and its reverse
+    complement, and a two-letter genome (every k-mer everywhere: long index runs and bins)."""
+    from minicom_amd import synth
+    rng = np.random.default_rng(L)
+    base = synth.synth_reads(4242 + L, 400, L)
+    comp = np.zeros(256, dtype=np.uint8); comp[list(b"ACGTN")] = list(b"TGCAN")
+    sets = {}
+    for n in (1, 2, 3, 65):
+        sets["first_%d" % n] = base[:n].copy()
+    sets["copies_of_one"] = np.repeat(base[:1], 300, axis=0)
+    sets["homopolymers"] = np.concatenate([np.full((40, L), ord(c), dtype=np.uint8) for c in "ACGT"] + [base[:50]])
+    sets["all_N"] = np.full((30, L), ord("N"), dtype=np.uint8)
+    withn = base[:200].copy()
+    for i in range(200):                                                       # N counts from 0 to just above 0.4 L, anywhere in the read
+        k = (i * (int(0.4 * L) + 3)) // 199
+        withn[i, rng.choice(L, size=k, replace=False)] = ord("N")
+    sets["N_around_the_limit"] = withn
+    sets["with_reverse_complements"] = np.concatenate([base[:150], comp[base[:150, ::-1]]])
+    two = np.frombuffer(b"AC", dtype=np.uint8)[rng.integers(0, 2, size=(1, 4 * L))][0]
+    sets["two_letter_genome"] = np.stack([two[o:o + L] for o in rng.integers(0, 3 * L, size=300)])
+    return sets
+
+
+@pytest.mark.parametrize("L", [40, 100, 150, 256])
+def test_degenerate_read_sets_equal_the_oracle_and_survive_the_round_trip(L, tmp_path):
+    """The edges of the domain through the whole path: final contigs, member lists and every id list equal the sequential oracle's, and the
+    stream files decode to the multiset of reads that went in (N restored).  L = 256 is the longest read the row layout holds."""
+    import oracle
+    from minicom_amd.pipeline import Pipeline, decompress
+    for name, reads in _degenerate_sets(L).items():
+        reads = np.ascontiguousarray(reads)
+        o = oracle.Pipeline(reads); o.run_all()
+        p = Pipeline(reads, host_threads=2); p.pre_process()
+        oc, pc = o.contigs(), p.contigs()
+        assert len(oc) == len(pc), (name, len(oc), len(pc))
+        for (r0, m0), (r1, m1) in zip(oc, pc):
+            assert r0 == r1 and np.array_equal(m0, m1), name
+        for lst in ("sg", "fpA", "fpT", "fpN", "allA", "allT", "allN", "Nfile"):
+            assert np.array_equal(o.id_list(lst), p.id_list(lst)), (name, lst)
+        td = str(tmp_path / ("%s_%d" % (name, L))); os.makedirs(td)
+        p.cluster_dump(td)
+        out = os.path.join(td, "reads.txt")
+        assert decompress(td, out) == reads.shape[0], name
+        got = np.frombuffer(open(out, "rb").read(), dtype=np.uint8).reshape(reads.shape[0], L + 1)[:, :L]
+        a = np.sort(np.ascontiguousarray(got).view("S%d" % L).ravel()); b = np.sort(reads.view("S%d" % L).ravel())
+        assert np.array_equal(a, b), name
+        p.close(); o.close()
+
