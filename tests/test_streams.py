@@ -327,3 +327,38 @@ def test_one_stream_set_per_thread_as_the_reference_writes_them(tmp_path, mode):
             check(rows, r2.read_bytes().split(b"\n")[:-1])
         else:
             check(rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [100, 150])
+def test_order_and_paired_end_round_trips_at_the_edges_of_the_domain(tmp_path, L):
+    """`minicom -p` and `minicompe` on read sets at the edges: two reads, copies of one read, homopolymers and all-N reads among ordinary ones,
+    a pair of identical mates: the order-preserving set decodes to the reads in their order, the paired-end set to every mate pair."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, decompress, decompress_pe
+    base = synth.synth_reads(900 + L, 300, L)
+    sets = {"two": base[:2].copy(), "copies_of_one": np.repeat(base[:1], 64, axis=0),
+            "specials": np.concatenate([np.full((6, L), ord("A"), dtype=np.uint8), np.full((4, L), ord("N"), dtype=np.uint8), base[:90], np.full((6, L), ord("T"), dtype=np.uint8), base[90:184]]),
+            "identical_mates": np.concatenate([base[:100], base[:100]])}
+    for name, reads in sets.items():
+        reads = np.ascontiguousarray(reads)
+        n = reads.shape[0]
+        p = Pipeline(reads, host_threads=2); p.pre_process()
+        d = tmp_path / ("o_%s_%d" % (name, L)); d.mkdir()
+        p.cluster_dump(str(d), order=True)
+        out = tmp_path / ("o_%s_%d.txt" % (name, L))
+        assert decompress(str(d), str(out), order=True) == n, name
+        got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(n, L + 1)[:, :L]
+        assert np.array_equal(got, reads), name
+        half = n // 2
+        d2 = tmp_path / ("p_%s_%d" % (name, L)); d2.mkdir()
+        p.cluster_dump(str(d2), paired=True)
+        p.close()
+        o1, o2 = tmp_path / ("p1_%s_%d.txt" % (name, L)), tmp_path / ("p2_%s_%d.txt" % (name, L))
+        assert decompress_pe(str(d2), str(o1), str(o2)) == half, name
+        a = np.frombuffer(o1.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+        b = np.frombuffer(o2.read_bytes(), dtype=np.uint8).reshape(half, L + 1)[:, :L]
+        got = np.sort(np.concatenate([a, b], axis=1).view("S%d" % (2 * L)).ravel())
+        want = np.sort(np.ascontiguousarray(np.concatenate([reads[:half], reads[half:2 * half]], axis=1)).view("S%d" % (2 * L)).ravel())
+        assert np.array_equal(got, want), name
+
