@@ -301,3 +301,16 @@ def test_degenerate_read_sets_equal_the_oracle_and_survive_the_round_trip(L, tmp
         assert np.array_equal(a, b), name
         p.close(); o.close()
 
+
+def test_no_reads_at_all(tmp_path):
+    """An empty read set is a legal input of the library (the reference's script refuses an empty file before it gets that far): no contigs, a
+    digest of zeros, stream files that decode to nothing."""
+    from minicom_amd.pipeline import Pipeline, decompress
+    for L in (100, 150):
+        p = Pipeline(np.zeros((0, L), dtype=np.uint8), L=L, host_threads=2); p.pre_process()
+        assert len(p.contigs()) == 0 and list(p.result_digest()) == [0] * 8 and p.id_list("sg").size == 0
+        td = str(tmp_path / str(L)); os.makedirs(td)
+        p.cluster_dump(td)
+        assert decompress(td, os.path.join(td, "o.txt")) == 0 and os.path.getsize(os.path.join(td, "o.txt")) == 0
+        p.close()
+
