@@ -172,6 +172,21 @@ def brief(why, keep=6):
     return why if len(why) <= keep else why[:keep] + [f"... and {len(why) - keep} more"]
 
 
+def oracle_digest_verdict(n, L, seed, genome, digest):
+    """Is the digest the sequential oracle's of this very read set?  tests/golden/scale_digests.json holds the digests oracle/digest_main printed in the
+    build container (a fixture: data, hours of one core per line); nothing of oracle/ runs here."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "scale_digests.json")
+    try:
+        runs = json.load(open(path))["runs"]
+    except (OSError, ValueError, KeyError):
+        return {"equal": None, "note": "tests/golden/scale_digests.json is missing"}
+    for e in runs:
+        if genome == "uniform" and (e["n"], e["L"], e["seed"], e.get("coverage", 30)) == (n, L, seed, 30):
+            return {"equal": [int(v) for v in e["digest"]] == [int(v) for v in digest],
+                    "note": f"tests/golden/scale_digests.json: oracle/digest_main {seed} {n} {L}, {e['oracle_seconds']} s of one core in the build container"}
+    return {"equal": None, "note": "the oracle has not been run on this read set (tests/golden/scale_digests.json)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -591,7 +606,7 @@ def main():
                        "kernel_timing": "HIP events around the hot kernel classes on the launch stream, inside the timed steps (pooled events, ~100 pairs per step; cost: event_overhead)",
                        "results": "contig set (strings + member lists) complete in HBM at the end of a step, its digest read back inside the step; host copy on demand"},
             "result": {"digest": [str(v) for v in ref_digest], "digest_fields": "contigs, chars, members, unclustered, strings, member words, offsets, lists",
-                       "every_timed_step_equal": True, "checked_run": checked},
+                       "every_timed_step_equal": True, "checked_run": checked, "sequential_oracle": oracle_digest_verdict(n_total, L, seed, a.genome, ref_digest)},
             "value_host_to_host": h2h,
             "value_file_to_streams": e2e,
             "value_file_to_streams_order_preserving": e2e_modes.get("order"),
