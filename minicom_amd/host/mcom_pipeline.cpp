@@ -2564,20 +2564,37 @@ static int cluster_dump_device(mcomh_pipeline *p, const char *folder, int mode)
 	}
 	p->stat["t_dump_gpu"] += now_ms() - t0;
 	const double tw = now_ms();
+	// the file images are written side by side (round 5: one fwrite after the other was 0.046 s of the paired-end set's 0.08 at 20 M reads -- the page
+	// cache takes what one core copies into it)
+	struct Job { std::string path; const void *data; size_t bytes; };
+	std::vector<Job> jobs;
 	for (int t = 0; t < T; ++t) {
 		const std::string sfx = "." + std::to_string(t);
 		const size_t pos_a = D.n ? 4 * (size_t)sc[t] + 2 * (size_t)sm[t] : 0, pos_b = D.n ? 4 * (size_t)sc[t + 1] + 2 * (size_t)sm[t + 1] : 0;
-		if (!write_file(dir + "/ref.bin" + sfx, h_ref.data() + sref[t], D.n ? (size_t)(sref[t + 1] - sref[t]) : 0) ||
-		    !write_file(dir + "/beg_pos.bin" + sfx, h_pos.data() + pos_a, pos_b - pos_a) ||
-		    !write_file(dir + "/dir.bin" + sfx, h_dir.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : 0) ||
-		    !write_file(dir + "/dif_char.txt" + sfx, h_text.data() + stext[t], D.n ? (size_t)(stext[t + 1] - stext[t]) : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
-		if (order && !write_file(dir + "/ids.bin" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0)) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);   // kthread_dump.c:266-269
-		if (pe && (!write_file(dir + "/ids.txt" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0) ||
-		           !write_file(dir + "/peids.bin" + sfx, h_pe_0.data() + 4 * ssecond[t], D.n ? (size_t)(4 * (ssecond[t + 1] - ssecond[t])) : 0) ||
-		           !write_file(dir + "/file.bin" + sfx, h_fb_0.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : h_fb_0.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+		jobs.push_back(Job{dir + "/ref.bin" + sfx, h_ref.data() + sref[t], D.n ? (size_t)(sref[t + 1] - sref[t]) : 0});
+		jobs.push_back(Job{dir + "/beg_pos.bin" + sfx, h_pos.data() + pos_a, pos_b - pos_a});
+		jobs.push_back(Job{dir + "/dir.bin" + sfx, h_dir.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : 0});
+		jobs.push_back(Job{dir + "/dif_char.txt" + sfx, h_text.data() + stext[t], D.n ? (size_t)(stext[t + 1] - stext[t]) : 0});
+		if (order) jobs.push_back(Job{dir + "/ids.bin" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0});   // kthread_dump.c:266-269
+		if (pe) {
+			jobs.push_back(Job{dir + "/ids.txt" + sfx, h_ids.data() + sids[t], D.n ? (size_t)(sids[t + 1] - sids[t]) : 0});
+			jobs.push_back(Job{dir + "/peids.bin" + sfx, h_pe_0.data() + 4 * ssecond[t], D.n ? (size_t)(4 * (ssecond[t + 1] - ssecond[t])) : 0});
+			jobs.push_back(Job{dir + "/file.bin" + sfx, h_fb_0.data() + sdir[t], D.n ? (size_t)(sdir[t + 1] - sdir[t]) : h_fb_0.size()});
+		}
 	}
-	if (!write_file(dir + "/single.seq", h_single.data(), h_single.size())) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
-	if (pe && (!write_file(dir + "/peids.bin.sp", h_pe_sp.data(), h_pe_sp.size()) || !write_file(dir + "/file.bin.sp", h_fb_sp.data(), h_fb_sp.size()))) return p->fail(MCOM_E_ARG, "cannot write pairing streams");
+	jobs.push_back(Job{dir + "/single.seq", h_single.data(), h_single.size()});
+	if (pe) { jobs.push_back(Job{dir + "/peids.bin.sp", h_pe_sp.data(), h_pe_sp.size()}); jobs.push_back(Job{dir + "/file.bin.sp", h_fb_sp.data(), h_fb_sp.size()}); }
+	{
+		std::sort(jobs.begin(), jobs.end(), [](const Job &x, const Job &y) { return x.bytes > y.bytes; });   // the large ones first
+		std::atomic<size_t> next{0}; std::atomic<bool> failed{false};
+		auto writer = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= jobs.size()) return; if (!write_file(jobs[i].path, jobs[i].data, jobs[i].bytes)) failed = true; } };
+		const size_t nthreads = std::min<size_t>(std::min<size_t>(8, (size_t)std::max(1, p->host_threads)), jobs.size());
+		std::vector<std::thread> wt;
+		for (size_t q = 1; q < nthreads; ++q) wt.emplace_back(writer);
+		writer();
+		for (auto &x : wt) x.join();
+		if (failed) return p->fail(MCOM_E_ARG, "cannot write into %s", folder);
+	}
 	if (order && (!write_ids(dir + "/allA.ids.bin", allA) || !write_ids(dir + "/allT.ids.bin", allT) || !write_ids(dir + "/allN.ids.bin", allN) ||
 	              !write_ids(dir + "/AA.ids.bin", fpA) || !write_ids(dir + "/TT.ids.bin", fpT) || !write_ids(dir + "/NN.ids.bin", fpN) ||
 	              !write_ids(dir + "/Nfile.ids.bin", nfile) || !write_ids(dir + "/singleFile.ids.bin", single_ids))) return p->fail(MCOM_E_ARG, "cannot write id streams");
