@@ -143,7 +143,7 @@ def file_to_streams(n: int, L: int, seed: int, host_threads: int = 16, ref_reads
             res["note"] = ("the same from a .fastq.gz of %d gzip members (8 MB of text each, zlib level 1; quality lines are all 'I', so this file inflates "
                            "faster than sequencer output would): members shared out over all cores, decoded by the library's own DEFLATE decoder (host/mcom_inflate.cpp, "
                            "~2 x zlib per core; CRC-32 checked) and parsed there, rows sent as characters from page-locked blocks; a gzip file of ONE member "
-                           "can only be inflated by one thread (the sequential reader: ~1.5 Mreads/s)" % gz_members)
+                           "is decoded by one thread and parsed by the others: value_file_to_streams_gz_one_member" % gz_members)
         p.close()
         res["reference"] = _reference_on_prefix(fq, td, n, L, ref_reads) if mode == "default" and ref_reads else None
         return res
