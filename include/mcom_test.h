@@ -32,6 +32,12 @@ int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
  * mcom_claim_fallbacks: how often the loop has run in this context.                                                               */
 int mcom_set_claim_route(mcom_ctx *ctx, int route);
 int mcom_claim_fallbacks(const mcom_ctx *ctx);
+/* mcom_dicts_screen counts the singletons' (dictionary, key) pairs in hashed counters.  route 0 = the default: the counter numbers are
+ * binned by counter range (a region per workgroup and bin, no global atomics) and every bin is counted in LDS; a set whose keys pile up in
+ * one region (copies of one read) overflows it and goes through the global-atomics kernel instead.  1 = that kernel at once, 2 = regions of
+ * a few keys, so that any input overflows (the fall-back runs).  Same answer every way.  mcom_screen_fallbacks: how often it ran.       */
+int mcom_set_screen_route(mcom_ctx *ctx, int route);
+int mcom_screen_fallbacks(const mcom_ctx *ctx);
 
 
 /* ---- libmcom_host.so ---- */

@@ -362,6 +362,13 @@ extern "C" int mcom_set_claim_route(mcom_ctx *ctx, int route)
 	return MCOM_OK;
 }
 extern "C" int mcom_claim_fallbacks(const mcom_ctx *ctx) { return ctx ? (int)ctx->claim_fallbacks : 0; }
+extern "C" int mcom_set_screen_route(mcom_ctx *ctx, int route)
+{
+	if (!ctx || route < 0 || route > 2) return MCOM_E_ARG;
+	ctx->screen_route = route;
+	return MCOM_OK;
+}
+extern "C" int mcom_screen_fallbacks(const mcom_ctx *ctx) { return ctx ? (int)ctx->screen_fallbacks : 0; }
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
 {
 	if (!ctx) return MCOM_E_ARG;

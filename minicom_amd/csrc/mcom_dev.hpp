@@ -58,6 +58,11 @@ struct mcom_ctx {
 	// one-launch kernel's first barrier gives up (test hook: the poison flag trips and the loop takes over); how often the loop ran
 	int claim_route = 0; uint64_t claim_fallbacks = 0;
 	unsigned int *screen_flag = nullptr;                                      // mcom_dicts_screen_begin .. _end
+	// the screen's two routes (realign.hip): 0 = keys binned by counter range and counted in LDS, with the global-atomics kernel behind it
+	// for a set whose keys pile up in one bin's region; 1 = the global-atomics kernel at once; 2 = regions of a few keys (test hook: the
+	// binned route overflows and the other one takes over); the arguments _end needs to run the other route; how often it did
+	int screen_route = 0; uint64_t screen_fallbacks = 0;
+	struct ScreenArgs { const uint64_t *sgbits; size_t n_sg; int L, ininumdict, maxsearch, n_shares, share; } screen_args = {};
 	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
 	// a whole when it is used up, instead of one 4-byte fill launch in front of every such kernel (mcom_zeroed, api.hip)
 	enum { ZPOOL_BYTES = 64 * 1024 };

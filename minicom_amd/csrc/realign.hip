@@ -868,17 +868,110 @@ __global__ void k_bin_screen_max(const unsigned int *__restrict__ table, size_t 
 	if (i < n && table[i] > maxsearch) *exceeded = 1;
 }
 
-// begin: the counting kernels are put on the context's stream and the call returns; end: waits for them and reads the answer.
-// (mcom_dicts_screen is the two in one.  The pipeline runs the screen on a second stream beside the contig index build: the
-// two use different parts of the memory system -- atomics against streaming writes.)
-extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int n_shares, int share)
+// ---- the same counters WITHOUT global atomics (round 5) --------------------------------------------------------------------------
+// k_bin_screen is 128 M atomics on random words of a 64 MB table (100 M x 150 bp: 16 M singletons x 8 dictionaries): 4.8 ms, served by
+// the memory side at 27 G atomics a second whatever the kernel does.  The counters do not have to be in HBM: cut the counter numbers
+// into BINS of 2^14 consecutive counters -- what one workgroup holds in LDS -- and count in two steps.  k_screen_scatter: a workgroup
+// takes a stretch of the singletons sub-tile by sub-tile (32 K keys: thirty-two per thread), counts the keys of a
+// sub-tile by bin and places them with LDS atomics, i.e. puts the 16-bit counter numbers in bin order in LDS and appends every bin's run to the
+// REGION that this workgroup owns in that bin (fill pointers in LDS: nothing is reserved in global memory, no atomics leave the CU).
+// k_screen_count: one workgroup per bin adds the regions of all workgroups up in LDS counters and looks at the largest.  The keys are
+// hashes, so the regions fill evenly; one that overflows all the same (copies of one read: one key a million times) raises bit 1 of
+// the flag and mcom_dicts_screen_end runs k_bin_screen instead.  A counter per ~16-32 keys (collisions only add: still an upper bound of
+// every bin in it, and ~32 is far below any limit worth asking about).
+namespace {
+constexpr int SCR_THREADS = 1024, SCR_KPT = 32, SCR_KT = SCR_THREADS * SCR_KPT;      // keys of a sub-tile
+constexpr int SCR_MAXBINS = 1024, SCR_CB = 14;                                       // bins at most; counters of a bin = 2^SCR_CB at most
+constexpr size_t SCR_LDS_SCATTER = 2 * (size_t)SCR_KT + 4 * (4 * (size_t)SCR_MAXBINS + 16);
+}
+__global__ __launch_bounds__(1024) void k_screen_scatter(const uint64_t *__restrict__ sgbits, size_t n_sg, int W, int nd, CixGeom g, uint32_t log2t, uint32_t log2bins,
+                                                         uint32_t sg_per_wg, uint32_t sg_per_tile, uint32_t capw, uint16_t *__restrict__ out, uint32_t *__restrict__ cnt,
+                                                         unsigned int *__restrict__ flag, uint32_t n_shares, uint32_t share)
 {
-	if (!ctx) return MCOM_E_ARG;
-	if (n_shares < 1 || share < 0 || share >= n_shares) return mcom_fail(ctx, MCOM_E_ARG, "bad share");
-	ctx->screen_flag = nullptr;
-	if (n_sg == 0) return MCOM_OK;
-	CixGeom g;
-	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
+	extern __shared__ __align__(16) unsigned char scr_lds[];
+	uint16_t *stage = (uint16_t*)scr_lds;
+	uint32_t *hist = (uint32_t*)(scr_lds + 2 * (size_t)SCR_KT), *base = hist + SCR_MAXBINS, *fill = base + SCR_MAXBINS, *cur = fill + SCR_MAXBINS, *wsum = cur + SCR_MAXBINS;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, bins = 1u << log2bins, cb = log2t - log2bins, vmask = (1u << cb) - 1u;
+	const size_t sg0 = (size_t)blockIdx.x * sg_per_wg, sg1 = sg0 + sg_per_wg < n_sg ? sg0 + sg_per_wg : n_sg;
+	if (tid < bins) fill[tid] = 0;
+	bool over = false;
+	for (size_t ts = sg0; ts < sg1; ts += sg_per_tile) {
+		const uint32_t nk = (uint32_t)((ts + sg_per_tile < sg1 ? ts + sg_per_tile : sg1) - ts) * (uint32_t)nd;
+		if (tid < bins) hist[tid] = 0;
+		__syncthreads();
+		// (the counter number of a key is made twice -- once to count its bin, once to place it: thirty-two of them do not fit a thread's
+		// registers beside everything else, the first form spilled a kilobyte per lane -- the rows come out of the L1 the second time)
+		auto counter_of = [&](uint32_t q) -> uint32_t {
+			const uint32_t sl = q / (uint32_t)nd; const int l = (int)(q - sl * (uint32_t)nd);
+			const uint64_t key = bits_key(sgbits + (ts + sl) * (size_t)W, g.ds[l], g.klen);
+			if (n_shares > 1) { uint32_t own, part, h16; cix_hash(key, n_shares, 1u, own, part, h16); if (own != share) return 0xFFFFFFFFu; }
+			const uint64_t h = (key * 8 + (uint64_t)l + 1) * 0x9E3779B97F4A7C15ull;          // (k_bin_screen's counter)
+			return (uint32_t)(h >> (64 - log2t));
+		};
+#pragma unroll 4
+		for (int r = 0; r < SCR_KPT; ++r) {
+			const uint32_t q = (uint32_t)r * SCR_THREADS + tid;
+			if (q < nk) { const uint32_t idx = counter_of(q); if (idx != 0xFFFFFFFFu) atomicAdd(&hist[idx >> cb], 1u); }
+		}
+		__syncthreads();
+		{	// first place of every bin in the staging area (an entry per thread: bins <= 1024); does the region hold the run?
+			const uint32_t v = tid < bins ? hist[tid] : 0u;
+			uint32_t inc = v;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
+			if (lane == 63u) wsum[tid >> 6] = inc;
+			__syncthreads();
+			uint32_t pre = 0;
+			for (uint32_t w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+			if (tid < bins) { base[tid] = pre + inc - v; cur[tid] = pre + inc - v; if (fill[tid] + v > capw) over = true; }
+		}
+		__syncthreads();
+#pragma unroll 4
+		for (int r = 0; r < SCR_KPT; ++r) {
+			const uint32_t q = (uint32_t)r * SCR_THREADS + tid;
+			if (q < nk) { const uint32_t idx = counter_of(q); if (idx != 0xFFFFFFFFu) stage[atomicAdd(&cur[idx >> cb], 1u)] = (uint16_t)(idx & vmask); }
+		}
+		__syncthreads();
+		for (uint32_t b = tid >> 6; b < bins; b += SCR_THREADS / 64) {                 // a wave per bin: runs leave as 128-byte stores
+			const uint32_t n = hist[b], f = fill[b], s0 = base[b];
+			if (f + n <= capw) {
+				uint16_t *dst = out + ((size_t)b * gridDim.x + blockIdx.x) * capw + f;
+				for (uint32_t j = lane; j < n; j += 64) dst[j] = stage[s0 + j];
+			}
+		}
+		__syncthreads();
+		if (tid < bins) { const uint32_t f = fill[tid] + hist[tid]; fill[tid] = f < capw ? f : capw; }
+	}
+	if (tid < bins) cnt[(size_t)tid * gridDim.x + blockIdx.x] = over ? 0u : fill[tid];
+	if (over) atomicOr(flag, 2u);
+}
+__global__ __launch_bounds__(1024) void k_screen_count(const uint16_t *__restrict__ out, const uint32_t *__restrict__ cnt, uint32_t n_wg, uint32_t capw, uint32_t cb,
+                                                       uint32_t maxsearch, unsigned int *__restrict__ flag)
+{
+	extern __shared__ __align__(16) unsigned char scr_lds[];
+	uint32_t *ctr = (uint32_t*)scr_lds;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, nctr = 1u << cb, b = blockIdx.x;
+	for (uint32_t i = tid; i < nctr; i += SCR_THREADS) ctr[i] = 0;
+	__syncthreads();
+	for (uint32_t w = tid >> 6; w < n_wg; w += SCR_THREADS / 64) {
+		const uint32_t n = cnt[(size_t)b * n_wg + w];
+		const uint16_t *src = out + ((size_t)b * n_wg + w) * capw;
+		for (uint32_t j = 8u * lane; j < n; j += 512u) {                             // eight numbers per lane and step (capw is a multiple of 8)
+			const uint4 v = *(const uint4*)(src + j);
+			const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u) if (j + u < n) atomicAdd(&ctr[(ww[u >> 1] >> (16u * (u & 1u))) & 0xFFFFu], 1u);
+		}
+	}
+	__syncthreads();
+	uint32_t m = 0;
+	for (uint32_t i = tid; i < nctr; i += SCR_THREADS) m = ctr[i] > m ? ctr[i] : m;
+	if (m > maxsearch) atomicOr(flag, 1u);
+}
+
+// the global-atomics route: table + flag in the workspace
+static int screen_atomics(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, const CixGeom &g, int maxsearch, int n_shares, int share)
+{
 	const uint64_t nkeys = (uint64_t)n_sg * (uint64_t)g.nd;
 	const uint64_t nmine = nkeys / (uint64_t)n_shares + 1;
 	// a counter per ~8 keys: collisions only add (the count stays an upper bound of every bin in it) and ~8 is far below any limit worth
@@ -898,6 +991,52 @@ extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_s
 	ctx->screen_flag = flag;
 	return MCOM_OK;
 }
+
+// begin: the counting kernels are put on the context's stream and the call returns; end: waits for them and reads the answer.
+// (mcom_dicts_screen is the two in one.  The pipeline can run the screen on a second stream beside the contig index build.)
+extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int n_shares, int share)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n_shares < 1 || share < 0 || share >= n_shares) return mcom_fail(ctx, MCOM_E_ARG, "bad share");
+	ctx->screen_flag = nullptr;
+	if (n_sg == 0) return MCOM_OK;
+	CixGeom g;
+	if (!d_sgbits || L < 1 || L > 256 || maxsearch < 1 || cix_geom(L, ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
+	ctx->screen_args = mcom_ctx::ScreenArgs{d_sgbits, n_sg, L, ininumdict, maxsearch, n_shares, share};
+	if (ctx->screen_route == 1) return screen_atomics(ctx, d_sgbits, n_sg, L, g, maxsearch, n_shares, share);
+	const uint64_t nkeys = (uint64_t)n_sg * (uint64_t)g.nd;
+	const uint64_t nmine = nkeys / (uint64_t)n_shares + 1;
+	uint32_t lg = 10; while (lg < (uint32_t)SCR_CB + 10u && (16ull << lg) < nmine) ++lg;      // (1024 bins of 2^14 counters at most: 16 M counters)
+	const uint32_t log2bins = lg > (uint32_t)SCR_CB ? lg - (uint32_t)SCR_CB : 0u, bins = 1u << log2bins, cb = lg - log2bins;
+	const uint32_t sg_per_tile = (uint32_t)(SCR_KT / g.nd);
+	uint64_t n_wg = (n_sg + sg_per_tile - 1) / sg_per_tile;
+	if (n_wg > 2ull * (uint64_t)ctx->n_cu) n_wg = 2ull * (uint64_t)ctx->n_cu;
+	const uint64_t sg_per_wg = (n_sg + n_wg - 1) / n_wg;
+	if (sg_per_wg >= (1ull << 31) / (uint64_t)g.nd) return screen_atomics(ctx, d_sgbits, n_sg, L, g, maxsearch, n_shares, share);
+	// a region: 5/4 of an even share of the workgroup's keys + 256 (the keys are hashes: a run of 32 K / bins keys per sub-tile, +- its root)
+	uint64_t capw = ctx->screen_route == 2 ? 8 : ((sg_per_wg * (uint64_t)g.nd / bins) * 5 / 4 + 256 + 7) & ~7ull;
+	const size_t out_b = ((size_t)bins * n_wg * capw * 2 + 255) & ~(size_t)255, cnt_b = ((size_t)bins * n_wg * 4 + 255) & ~(size_t)255;
+	int rc = mcom_ws_reserve(ctx, out_b + cnt_b + 256);
+	if (rc) return rc;
+	uint16_t *out = (uint16_t*)ctx->ws;
+	uint32_t *cnt = (uint32_t*)((char*)ctx->ws + out_b);
+	unsigned int *flag = (unsigned int*)((char*)ctx->ws + out_b + cnt_b);
+	MCOM_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+	static bool attr_set = false;
+	if (!attr_set) {
+		MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_screen_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCR_LDS_SCATTER));
+		MCOM_HIP(ctx, hipFuncSetAttribute((const void*)k_screen_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << SCR_CB)));
+		attr_set = true;
+	}
+	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
+	MCOM_LAUNCH(k_screen_scatter, dim3((unsigned)n_wg), dim3(SCR_THREADS), SCR_LDS_SCATTER, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, log2bins,
+	            (uint32_t)sg_per_wg, sg_per_tile, (uint32_t)capw, out, cnt, flag, (uint32_t)n_shares, (uint32_t)share);
+	MCOM_LAUNCH(k_screen_count, dim3(bins), dim3(SCR_THREADS), (size_t)4 << cb, ctx->stream, (const uint16_t*)out, (const uint32_t*)cnt, (uint32_t)n_wg, (uint32_t)capw, cb,
+	            (uint32_t)maxsearch, flag); }
+	MCOM_LAUNCH_CHECK(ctx);
+	ctx->screen_flag = flag;
+	return MCOM_OK;
+}
 extern "C" int mcom_dicts_screen_begin(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch)
 {
 	return mcom_dicts_screen_begin_shared(ctx, d_sgbits, n_sg, L, ininumdict, maxsearch, 1, 0);
@@ -911,7 +1050,18 @@ extern "C" int mcom_dicts_screen_end(mcom_ctx *ctx, int *h_may_exceed)
 	MCOM_HIP(ctx, mcom_d2h_async(ctx, &hf, ctx->screen_flag, 4));
 	MCOM_HIP(ctx, mcom_stream_sync(ctx));
 	ctx->screen_flag = nullptr;
-	*h_may_exceed = hf ? 1 : 0;
+	if (hf & 2u) {                                                                  // a region overflowed: the counters were not all made -- the other route
+		const mcom_ctx::ScreenArgs a = ctx->screen_args;
+		CixGeom g;
+		if (cix_geom(a.L, a.ininumdict, g)) return mcom_fail(ctx, MCOM_E_ARG, "bad screen arguments");
+		++ctx->screen_fallbacks;
+		const int rc = screen_atomics(ctx, a.sgbits, a.n_sg, a.L, g, a.maxsearch, a.n_shares, a.share);
+		if (rc) return rc;
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &hf, ctx->screen_flag, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
+		ctx->screen_flag = nullptr;
+	}
+	*h_may_exceed = (hf & 1u) ? 1 : 0;
 	return MCOM_OK;
 }
 extern "C" int mcom_dicts_screen(mcom_ctx *ctx, const uint64_t *d_sgbits, size_t n_sg, int L, int ininumdict, int maxsearch, int *h_may_exceed)

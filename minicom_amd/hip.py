@@ -297,6 +297,16 @@ class Context:
         self.lib.mcom_claim_fallbacks.restype = C.c_int; self.lib.mcom_claim_fallbacks.argtypes = [C.c_void_p]
         return int(self.lib.mcom_claim_fallbacks(self._h))
 
+    def set_screen_route(self, route: int):
+        """Test hook of mcom_dicts_screen: 0 = default (keys binned by counter range, counted in LDS; the global-atomics kernel behind it),
+        1 = the global-atomics kernel at once, 2 = regions of a few keys (every input overflows: the fall-back runs)."""
+        self.lib.mcom_set_screen_route.restype = C.c_int; self.lib.mcom_set_screen_route.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_screen_route(self._h, route))
+
+    def screen_fallbacks(self) -> int:
+        self.lib.mcom_screen_fallbacks.restype = C.c_int; self.lib.mcom_screen_fallbacks.argtypes = [C.c_void_p]
+        return int(self.lib.mcom_screen_fallbacks(self._h))
+
     def set_consensus_capacity(self, members: int):
         """Test hook of the merge consensus: units that more than `members` members reach use the wave-per-tile kernel (0 = default 127)."""
         self.lib.mcom_set_consensus_capacity.restype = C.c_int; self.lib.mcom_set_consensus_capacity.argtypes = [C.c_void_p, C.c_uint32]

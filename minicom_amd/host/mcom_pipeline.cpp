@@ -253,6 +253,7 @@ struct mcomh_pipeline {
 	std::vector<uint32_t> allA, allT, allN, fpA, fpT, fpN, Nfile;
 	U32Pooled sg;
 	U8Pooled sg_flag;
+	bool sg_flag_zero = false;                                        // sg_flag was cleared and nobody has written to it since (updateSingle need not look through 16 M zeros)
 	// the flags of the last Stage-2 pass as they came from the device (0 live, 1 / 2 near-poly, 3 claimed); sg_flag (1 = gone) is
 	// made from them only when somebody looks (ensure_sg_flag): a pass does not wait for a 16 M-entry host loop
 	PinVec<uint8_t> raw_flags; bool raw_flags_valid = false;
@@ -348,7 +349,7 @@ static void ensure_sg_flag(P *p)
 	p->sg_flag.resize(n);
 	const uint8_t *f = p->raw_flags.data(); uint8_t *sf = p->sg_flag.data();
 	for (size_t i = 0; i < n; ++i) sf[i] = f[i] ? 1 : 0;                       // flagged or claimed
-	p->raw_flags_valid = false;
+	p->raw_flags_valid = false; p->sg_flag_zero = false;
 }
 static int ensure_host_contigs(P *p, bool wait_data = true);
 static const char ACGT[] = "ACGT";
@@ -1597,7 +1598,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 		p->n_sg_live = p->sg.size(); p->sg_live_valid = true; p->sg_uploaded = true;
 	}
 	p->raw_flags_valid = false;
-	p->sg_flag.assign(p->sg.size(), 0);                                                     // preprocess.c:182
+	p->sg_flag.assign(p->sg.size(), 0); p->sg_flag_zero = true;                             // preprocess.c:182
 	p->stage2_uploaded = false;
 	p->screen_clear = false;
 	p->stat["t_combine"] += busy_now(p) - t0;
@@ -1616,14 +1617,15 @@ static int update_single_impl(mcomh_pipeline *p)
 	if (p->sg_next_valid) {                                             // compacted on the device when the pass ended
 		p->sg.swap(p->sg_next); p->sg_next_valid = false;
 		p->raw_flags_valid = false;
-		p->sg_flag.assign(p->sg.size(), 0);
+		p->sg_flag.assign(p->sg.size(), 0); p->sg_flag_zero = true;
 		return MCOM_OK;
 	}
 	ensure_sg_flag(p);
 	if (!p->sg_uploaded) p->sg_live_valid = false;
 	p->sg_uploaded = false;
 	const size_t n = p->sg.size();
-	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); return MCOM_OK; }
+	if (p->sg_flag.size() != n) { p->sg_flag.assign(n, 0); p->sg_flag_zero = true; return MCOM_OK; }
+	if (p->sg_flag_zero) return MCOM_OK;                                 // cleared and untouched (the state after combine_cluster)
 	// nothing flagged (the state after combine_cluster): nothing to compact; eight flags per test
 	const uint8_t *f = p->sg_flag.data();
 	size_t i = 0;
@@ -1642,7 +1644,7 @@ static int update_single_impl(mcomh_pipeline *p)
 	parallel_for(nt, n - head, [&](int t, size_t b, size_t e) { uint32_t *dst = out.data() + head + cnt[(size_t)t]; for (size_t q = head + b; q < head + e; ++q) if (!f[q]) *dst++ = src[q]; });
 	p->sg.swap(out);
 	p->sg_live_valid = false;                                           // the list on the device is the uncompacted one
-	p->sg_flag.assign(nn, 0);
+	p->sg_flag.assign(nn, 0); p->sg_flag_zero = true;
 	return MCOM_OK;
 }
 

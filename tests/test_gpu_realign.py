@@ -221,6 +221,37 @@ def test_read_driven_pass_equals_window_scan_also_with_bins_above_maxsearch(ctx,
     dicts.close()
 
 
+@pytest.mark.parametrize("L,n_sg,copies,overflows", [(150, 300_000, 0, False), (150, 300_000, 3000, True), (100, 40_000, 3000, None), (40, 5_000, 0, False),
+                                                      (150, 700, 700, False), (150, 4_500_000, 0, False), (256, 70_000, 70_000, None)])
+def test_dictionary_screen_binned_in_lds_and_by_global_atomics_give_sound_answers(ctx, L, n_sg, copies, overflows):
+    """mcom_dicts_screen's routes (include/mcom_test.h): counter numbers binned by counter range and counted in LDS (default), global
+    atomics (the fall-back), and the default made to overflow its regions.  Whatever the route: the answer "no bin exceeds maxsearch" only
+    when that is true (checked against the bins of the dictionaries actually built, constructdictionary_realign,
+    kthread_hash_realign.c:3-140), and always for a generous limit.  `copies` rows are one and the same read: one key per dictionary,
+    `copies` times, side by side in the list -- the pile-up that overflows a region of the binned route when the counters fill several bins."""
+    import torch
+    rng = np.random.default_rng(L + n_sg)
+    W = (2 * L + 63) // 64
+    rows = rng.integers(-2**63, 2**63 - 1, size=(n_sg, W), dtype=np.int64)
+    if copies:
+        at = min(n_sg // 3, n_sg - copies)
+        rows[at:at + copies] = rows[0]
+    sgbits = torch.from_numpy(rows).cuda()
+    dicts = ctx.dicts_build(sgbits, L)
+    m = int(max(dicts.maxbin))
+    assert m >= max(copies, 1)
+    try:
+        for route, falls_back in ((0, overflows), (1, False), (2, True)):
+            ctx.set_screen_route(route)
+            before = ctx.screen_fallbacks()
+            if m > 1: assert ctx.dicts_screen(sgbits, L, m - 1)                           # a bin of m reads exceeds m - 1: the screen must see it
+            else: ctx.dicts_screen(sgbits, L, 1)
+            if falls_back is not None: assert (ctx.screen_fallbacks() > before) == falls_back
+            assert not ctx.dicts_screen(sgbits, L, m + 400)                               # (a counter holds its bins + a few dozen colliding keys)
+    finally:
+        ctx.set_screen_route(0)
+
+
 def test_index_keeps_heavy_repeats_in_runs_of_their_own(ctx):
     """Keys with hundreds of copies among the contigs (a 1 kb segment in 120 contigs, poly-A and (AC)n stretches): their
     entries leave the partitions for runs in the extension area (csrc/cindex.hip, CIX_HEAVY).  The claims must still be the
