@@ -218,7 +218,8 @@ int mcom_match_pro(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_cof
  * has the same strand bit and match_pro <= cbthr.  d_out receives the passing pairs in that order as
  * { x = query y (contig index in the id, pos_ori, dir), y = hit y (other contig, pos, dir) }.  The merge
  * flags (:286, :339) change while merging and stay with the caller.  h_counts = { pairs, passing }.
- * MCOM_E_OVERFLOW when cap is too small.  Synchronous.                                                */
+ * MCOM_E_OVERFLOW when cap is too small.  The counts are back when the call returns; d_out is complete when
+ * the context's stream reaches that point (round 5: no wait for the last kernel).                         */
 int mcom_find_next_candidates(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d_query, size_t n_query,
                               const uint64_t *d_cbits, const uint64_t *d_coff, const uint32_t *d_clen, int cbthr,
                               mcom_mm128 *d_out, size_t cap, uint64_t *h_counts);
@@ -470,7 +471,7 @@ int mcom_groups_to_contigs(mcom_ctx *ctx, const uint64_t *d_members, const uint3
  * pairs in the reference's visiting order (as mcom_find_next_candidates emits them).  The reference takes a pair
  * iff neither contig has been taken by an earlier pair, which is the greedy matching over the list; it is settled
  * in rounds (a pair that is the earliest live pair at both of its contigs is taken).  Out: d_jobs = *h_nj x
- * { ci, cj, pos_ori, pos } in claiming order, d_flag[n_contigs] = 1 for every claimed contig.
+ * { ci, cj, pos_ori, pos } in claiming order (room for n_contigs / 2 + 1 jobs), d_flag[n_contigs] = 1 for every claimed contig.
  * MCOM_E_OVERFLOW when the list has not settled after max_rounds (the caller then claims sequentially).      */
 int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t n_pairs, size_t n_contigs, int max_rounds, uint32_t *d_jobs,
                      uint8_t *d_flag, uint64_t *h_nj, int *h_rounds);

@@ -54,6 +54,7 @@ hipError_t mcom_stream_sync_poison(mcom_ctx *ctx, bool *poisoned)
 	}
 	if (e == hipSuccess) for (const mcom_ctx::PinWait &w : ctx->pin_wait) memcpy(w.dst, w.from ? w.from : (const void*)(ctx->pin + w.off), w.bytes);
 	ctx->pin_wait.clear(); ctx->pin_off = 0;
+	if (e == hipSuccess && !ctx->free_later.empty()) { for (void *q : ctx->free_later) mcom_dfree(q); ctx->free_later.clear(); }
 	return e;
 }
 
@@ -121,6 +122,8 @@ void mcom_dfree(void *p)
 	g_blk_free.emplace(it->second, p);
 	g_blk_live.erase(it);
 }
+
+void mcom_dfree_later(mcom_ctx *ctx, void *p) { if (p) ctx->free_later.push_back(p); }
 
 void *mcom_zeroed(mcom_ctx *ctx, void *fallback, size_t bytes)
 {
@@ -194,6 +197,7 @@ extern "C" int mcom_create(mcom_ctx **out, int device, void *hip_stream)
 extern "C" void mcom_destroy(mcom_ctx *ctx)
 {
 	if (!ctx) return;
+	if (!ctx->free_later.empty()) { (void)hipStreamSynchronize(ctx->stream); for (void *q : ctx->free_later) mcom_dfree(q); ctx->free_later.clear(); }
 	if (ctx->ws) {
 		(void)hipStreamSynchronize(ctx->stream);
 		void *drop = ctx->ws;
@@ -213,6 +217,7 @@ extern "C" void mcom_destroy(mcom_ctx *ctx)
 extern "C" int mcom_set_stream(mcom_ctx *ctx, void *hip_stream)
 {
 	if (!ctx) return MCOM_E_ARG;
+	if (!ctx->free_later.empty() && ctx->stream != (hipStream_t)hip_stream) { (void)hipStreamSynchronize(ctx->stream); for (void *q : ctx->free_later) mcom_dfree(q); ctx->free_later.clear(); }
 	if (ctx->zpool && ctx->stream != (hipStream_t)hip_stream) { (void)hipStreamSynchronize(ctx->stream); ctx->zpool_used = mcom_ctx::ZPOOL_BYTES; }   // (the pool's order is the stream's: the next request clears a half on the new one)
 	ctx->stream = (hipStream_t)hip_stream;
 	return MCOM_OK;

@@ -9,11 +9,13 @@
 // genome, so the chains of dependent edges are short and a few dozen rounds finish tens of millions of edges.
 #include "mcom_dev.hpp"
 
+// (cap: jobs the caller's array holds -- the kernel also runs on what a claiming launch whose barrier gave up left behind, which
+// nobody looks at but which must not be written past the array)
 __global__ void k_claim_jobs(const mcom_mm128 *__restrict__ pairs, size_t n, const uint32_t *__restrict__ sel, const uint32_t *__restrict__ spre,
-                             uint32_t *__restrict__ jobs)
+                             uint32_t *__restrict__ jobs, uint32_t cap)
 {
 	const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n || !sel[e]) return;
+	if (e >= n || !sel[e] || spre[e] >= cap) return;
 	const mcom_mm128 pr = pairs[e];
 	uint32_t *j = jobs + 4 * (size_t)spre[e];
 	j[0] = (uint32_t)(pr.x >> 32); j[1] = (uint32_t)(pr.y >> 32); j[2] = (uint32_t)pr.x >> 1; j[3] = (uint32_t)pr.y >> 1;
@@ -200,6 +202,9 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4));
 	const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
 	unsigned int hs[2] = {0, 0};
+	uint32_t nj = 0;
+	bool listed = false;                                                          // the jobs are in d_jobs and nj is known
+	const uint32_t job_cap = (uint32_t)(n_contigs / 2 + 1);                          // (an edge taken uses up two contigs; the caller's array holds that many jobs)
 	const size_t n16 = (best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4)) / 16;
 	size_t cb = (n16 + 255) / 256; if (cb > (size_t)ctx->n_cu * 8) cb = (size_t)ctx->n_cu * 8;
 	// best = 0: below every bid; dead, sel, state = 0; and the contigs' flags
@@ -220,12 +225,19 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 		if (host_copy) mcom_ring_register(ctx, state + 36, 8, ring);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state + 36, 8));
+		// The taken edges in list order and the jobs follow at once, before anybody knows how the launch ended: one round trip for
+		// { rounds, settled, jobs } instead of three (the poison flag, the count, the end of the workspace's use).  A launch whose barrier
+		// gave up leaves flags that mean nothing: what was made of them is made again below.
+		if ((rc = mcom_scan_u32(ctx, sel, spre, n_pairs + 1, nullptr))) return rc;     // sel[n_pairs] = 0 from the clear
+		MCOM_LAUNCH(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs, job_cap);
+		MCOM_LAUNCH_CHECK(ctx);
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &nj, spre + n_pairs, 4));
 		bool poisoned = false;
 		MCOM_HIP(ctx, mcom_stream_sync_poison(ctx, &poisoned));
 		if (poisoned) {                                                               // what the kernel left is partial: start again
 			loop = true; hs[0] = hs[1] = 0;
 			MCOM_LAUNCH(k_claim_clear, dim3((unsigned)cb), dim3(256), 0, ctx->stream, d_flag, n_contigs, (uint4*)base, n16);
-		}
+		} else listed = true;
 	}
 	if (loop) {
 		++ctx->claim_fallbacks;
@@ -246,13 +258,14 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	if (hs[1]) return mcom_fail(ctx, MCOM_E_OVERFLOW, "claiming did not settle in %d rounds", max_rounds);
 	if (h_rounds) *h_rounds = (int)hs[0];
 	// the taken edges in list order = the reference's claiming order
-	if ((rc = mcom_scan_u32(ctx, sel, spre, n_pairs + 1, nullptr))) return rc;      // sel[n_pairs] = 0 from the memset
-	uint32_t nj = 0;
-	MCOM_HIP(ctx, mcom_d2h_async(ctx, &nj, spre + n_pairs, 4));
-	MCOM_HIP(ctx, mcom_stream_sync(ctx));
+	if (!listed) {
+		if ((rc = mcom_scan_u32(ctx, sel, spre, n_pairs + 1, nullptr))) return rc;  // sel[n_pairs] = 0 from the clear
+		MCOM_HIP(ctx, mcom_d2h_async(ctx, &nj, spre + n_pairs, 4));
+		MCOM_HIP(ctx, mcom_stream_sync(ctx));
+		if (nj) MCOM_LAUNCH(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs, job_cap);
+		MCOM_LAUNCH_CHECK(ctx);
+	}
 	*h_nj = nj;
-	if (nj) MCOM_LAUNCH(k_claim_jobs, dim3(blocks), dim3(256), 0, ctx->stream, d_pairs, n_pairs, sel, spre, d_jobs);
-	MCOM_LAUNCH_CHECK(ctx);
-	MCOM_HIP(ctx, mcom_stream_sync(ctx));                                // the workspace is in use until here
+	// (no wait for the last kernel: the workspace belongs to this context's stream, and mcom_ws_reserve waits before it lets go of it)
 	return MCOM_OK;
 }

@@ -617,10 +617,10 @@ struct mcom_idx {
 extern "C" void mcom_idx_destroy(mcom_ctx *ctx, mcom_idx *mi)
 {
 	if (!mi) return;
-	if (ctx) (void)mcom_stream_sync(ctx);
-	if (mi->rec) mcom_dfree(mi->rec);
-	if (mi->part_bst) mcom_dfree(mi->part_bst);
-	mcom_table_free(&mi->tab);
+	// (no wait: the blocks go back to the pool when the context's stream is next synchronised -- the lookups that read them may still be
+	// on their way, and the pool is shared with other contexts)
+	if (ctx) { mcom_dfree_later(ctx, mi->rec); mcom_dfree_later(ctx, mi->part_bst); mcom_dfree_later(ctx, mi->tab.slots); mi->tab.slots = nullptr; }
+	else { if (mi->rec) mcom_dfree(mi->rec); if (mi->part_bst) mcom_dfree(mi->part_bst); mcom_table_free(&mi->tab); }
 	delete mi;
 }
 
@@ -994,11 +994,13 @@ static int find_next_impl(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d
 	if (by_contig ? n_contigs == 0 : n_query == 0) return MCOM_OK;
 	if (!d_query || !d_cbits || !d_coff || !d_clen) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	uint32_t *qoff = nullptr;
-	struct FirstGuard { uint32_t *p; ~FirstGuard() { mcom_dfree(p); } };
+	// (the blocks go back to the pool at the context's next synchronisation: the last kernels that read them are still on their way when
+	// this returns -- round 5: the call ended with a wait of its own for nothing but these frees)
+	struct FirstGuard { mcom_ctx *c; uint32_t *p; ~FirstGuard() { mcom_dfree_later(c, p); } };
 	if (by_contig) {                                                             // first query number of every contig, in visiting order
 		if (mcom_dmalloc(&qoff, (n_contigs + 1) * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
 	}
-	FirstGuard qoff_guard{qoff};
+	FirstGuard qoff_guard{ctx, qoff};
 	if (by_contig) {
 		MCOM_LAUNCH(k_fn_qcounts, dim3((unsigned)((n_contigs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_roff, d_ord, n_contigs, qoff);
 		MCOM_LAUNCH_CHECK(ctx);
@@ -1027,11 +1029,11 @@ static int find_next_impl(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d
 	uint32_t *first = nullptr, *pair_off = nullptr;                            // pair_off: the scanned counts, in an allocation of its own (the workspace may move below)
 	uint64_t *qy = nullptr;
 	if (mcom_dmalloc(&first, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
-	FirstGuard first_guard{first};
+	FirstGuard first_guard{ctx, first};
 	if (mcom_dmalloc(&pair_off, nq1 * 4) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
-	FirstGuard off_guard{pair_off};
+	FirstGuard off_guard{ctx, pair_off};
 	if (by_contig && mcom_dmalloc(&qy, nq1 * 8) != hipSuccess) return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers");
-	FirstGuard qy_guard{(uint32_t*)qy};
+	FirstGuard qy_guard{ctx, (uint32_t*)qy};
 	const unsigned qb = (unsigned)((n_query + 255) / 256);
 	if (new_span) {
 		MCOM_HIP(ctx, hipMemsetAsync(keymap, 0, map_b, ctx->stream));
@@ -1055,7 +1057,7 @@ static int find_next_impl(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d
 	const size_t scr2_b = (mcom_scan_scratch_elems(n_pairs) * 4 + 1024 + 255) & ~(size_t)255;
 	hipError_t e = mcom_dmalloc(&pass, ((size_t)n_pairs + 1) * 4);
 	if (e == hipSuccess) e = mcom_dmalloc(&pair_q, (size_t)n_pairs * 4);
-	auto cleanup = [&]() { if (pass) mcom_dfree(pass); if (pair_q) mcom_dfree(pair_q); };
+	auto cleanup = [&]() { mcom_dfree_later(ctx, pass); mcom_dfree_later(ctx, pair_q); };
 	if (e != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_NOMEM, "candidate buffers: %s", hipGetErrorString(e)); }
 	hipError_t e1 = hipSuccess;
 	rc = mcom_ws_reserve(ctx, scr2_b);
@@ -1075,7 +1077,7 @@ static int find_next_impl(mcom_ctx *ctx, const mcom_idx *mi, const mcom_mm128 *d
 	if (n_pass) {
 		if (!d_out) { cleanup(); return mcom_fail(ctx, MCOM_E_ARG, "null output pointer"); }
 		MCOM_LAUNCH(k_fn_emit, dim3(pb), dim3(256), 0, ctx->stream, first, mi->rec, d_query, (const uint64_t*)qy, pair_off, pair_q, pass, n_pairs, d_out);
-		e1 = mcom_stream_sync(ctx);
+		e1 = hipGetLastError();                                                     // (d_out is complete when the stream gets there: no wait here)
 		if (e1 != hipSuccess) { cleanup(); return mcom_fail(ctx, MCOM_E_HIP, "candidate emit: %s", hipGetErrorString(e1)); }
 	}
 	cleanup();

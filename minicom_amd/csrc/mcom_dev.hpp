@@ -61,6 +61,9 @@ struct mcom_ctx {
 	// the screen's two routes (realign.hip): 0 = keys binned by counter range and counted in LDS, with the global-atomics kernel behind it
 	// for a set whose keys pile up in one bin's region; 1 = the global-atomics kernel at once; 2 = regions of a few keys (test hook: the
 	// binned route overflows and the other one takes over); the arguments _end needs to run the other route; how often it did
+	// blocks of mcom_dmalloc that kernels in flight still use: given back to the pool by the next mcom_stream_sync (mcom_dfree_later) --
+	// the pool is shared by every context of the process, so a block may only go back once its stream has passed its last user
+	std::vector<void*> free_later;
 	int screen_route = 0; uint64_t screen_fallbacks = 0;
 	struct ScreenArgs { const uint64_t *sgbits; size_t n_sg; int L, ininumdict, maxsearch, n_shares, share; } screen_args = {};
 	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
@@ -118,6 +121,7 @@ void mcom_ring_register(mcom_ctx *ctx, const void *d_result, uint32_t bytes, uin
 // recycled device blocks for the library's own objects (api.hip)
 hipError_t mcom_dmalloc(void **out, size_t bytes);
 void mcom_dfree(void *p);
+void mcom_dfree_later(mcom_ctx *ctx, void *p);                                           // ... once the context's stream has been synchronised
 template <class T> static inline hipError_t mcom_dmalloc(T **out, size_t bytes) { return mcom_dmalloc((void**)out, bytes); }
 
 // internal helpers shared between translation units (sort.hip)

@@ -889,9 +889,10 @@ __global__ __launch_bounds__(1024) void k_screen_scatter(const uint64_t *__restr
                                                          unsigned int *__restrict__ flag, uint32_t n_shares, uint32_t share)
 {
 	extern __shared__ __align__(16) unsigned char scr_lds[];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, bins = 1u << log2bins;
 	uint16_t *stage = (uint16_t*)scr_lds;
-	uint32_t *hist = (uint32_t*)(scr_lds + 2 * (size_t)SCR_KT), *base = hist + SCR_MAXBINS, *fill = base + SCR_MAXBINS, *cur = fill + SCR_MAXBINS, *wsum = cur + SCR_MAXBINS;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, bins = 1u << log2bins, cb = log2t - log2bins, vmask = (1u << cb) - 1u;
+	uint32_t *hist = (uint32_t*)(scr_lds + 2 * (size_t)SCR_KT), *base = hist + bins, *fill = base + bins, *cur = fill + bins, *wsum = cur + bins;   // (sized by the launch: two workgroups per CU up to 512 bins)
+	const uint32_t cb = log2t - log2bins, vmask = (1u << cb) - 1u;
 	const size_t sg0 = (size_t)blockIdx.x * sg_per_wg, sg1 = sg0 + sg_per_wg < n_sg ? sg0 + sg_per_wg : n_sg;
 	if (tid < bins) fill[tid] = 0;
 	bool over = false;
@@ -1029,7 +1030,7 @@ extern "C" int mcom_dicts_screen_begin_shared(mcom_ctx *ctx, const uint64_t *d_s
 		attr_set = true;
 	}
 	{ McomProfScope ps_(ctx, PROF_DICT_BUILD);
-	MCOM_LAUNCH(k_screen_scatter, dim3((unsigned)n_wg), dim3(SCR_THREADS), SCR_LDS_SCATTER, ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, log2bins,
+	MCOM_LAUNCH(k_screen_scatter, dim3((unsigned)n_wg), dim3(SCR_THREADS), 2 * (size_t)SCR_KT + 4 * (4 * (size_t)bins + 16), ctx->stream, d_sgbits, n_sg, mcom_words_per_read(L), g.nd, g, lg, log2bins,
 	            (uint32_t)sg_per_wg, sg_per_tile, (uint32_t)capw, out, cnt, flag, (uint32_t)n_shares, (uint32_t)share);
 	MCOM_LAUNCH(k_screen_count, dim3(bins), dim3(SCR_THREADS), (size_t)4 << cb, ctx->stream, (const uint16_t*)out, (const uint32_t*)cnt, (uint32_t)n_wg, (uint32_t)capw, cb,
 	            (uint32_t)maxsearch, flag); }

@@ -1370,7 +1370,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 		size_t nj = 0;
 		bool on_device = false;
 		if (n) {
-			if (!d_jobs.reserve(4 * (n / 2 + 1)) || !d_flag.reserve(n_store + 16)) return p->fail(MCOM_E_NOMEM, "claim buffers");
+			if (!d_jobs.reserve(4 * (n_store / 2 + 1)) || !d_flag.reserve(n_store + 16)) return p->fail(MCOM_E_NOMEM, "claim buffers");
 			uint64_t njv = 0; int rounds = 0;
 			rc = mcom_claim_pairs(p->ctx, d_pairs.p, n_pass, n_store, 4096, d_jobs.p, d_flag.p, &njv, &rounds);
 			if (rc == MCOM_OK) { on_device = true; nj = (size_t)njv; p->stat["claim_rounds"] += rounds; }
