@@ -28,7 +28,9 @@ int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits);
 /* mcom_claim_pairs settles all rounds inside ONE launch whose workgroups meet at a grid barrier, which only works while every workgroup
  * is resident; a barrier wait that runs out raises the context's poison flag and the launch-per-round loop (two launches and a host
  * round trip per round: needs no co-residency) redoes the claiming.  route 0 = that default, 1 = the loop at once, 2 = the first barrier
- * of the one-launch kernel gives up at once (the flag trips, the loop takes over).  Same jobs and flags every way.
+ * of the one-launch kernel gives up at once (the flag trips, the loop takes over), 3 = the one-launch kernel without its tail (every round
+ * by the whole grid, also when a few edges are left; by default one workgroup finishes a list of at most 16384 live edges on its own).
+ * Same jobs and flags every way.
  * mcom_claim_fallbacks: how often the loop has run in this context.                                                               */
 int mcom_set_claim_route(mcom_ctx *ctx, int route);
 int mcom_claim_fallbacks(const mcom_ctx *ctx);

@@ -362,7 +362,7 @@ extern "C" int mcom_set_sketch_prefix_bits(mcom_ctx *ctx, int bits)
 }
 extern "C" int mcom_set_claim_route(mcom_ctx *ctx, int route)
 {
-	if (!ctx || route < 0 || route > 2) return MCOM_E_ARG;
+	if (!ctx || route < 0 || route > 3) return MCOM_E_ARG;
 	ctx->claim_route = route;
 	return MCOM_OK;
 }

@@ -70,31 +70,74 @@ __device__ __forceinline__ bool cl_barrier(unsigned int *state, unsigned int G, 
 // matched flags again, a barrier later) and it cannot change the result: an edge that IS taken was the smallest bidder at both ends
 // among bids that include every edge still truly alive there, and its ends were free -- the greedy matching's own rule.  A stale bid
 // can only make a live edge wait one more round (every edge is stale at most once).
+//
+// THE TAIL (round 5, second half): a round of the grid costs ~100 us whatever is left to do -- 256 workgroups meeting at the barrier, all
+// dead flags read once more -- and most rounds of a step have next to nothing left (43 rounds per step at 100 M reads, a few thousand
+// live edges after the first handful).  When a round ends with at most CL_TAIL edges alive, the next one LISTS the edges that bid in it,
+// and from there ONE workgroup runs the same phases over the list alone, meeting at __syncthreads; the other workgroups leave.
+#define CL_TAIL 16384
+// what an edge does in a phase; true: it placed its bids (it is alive).  skip_ci: its bid at the query's end is left out (see below)
+// Round 5: "this contig is taken" lives in the bid words themselves -- a take writes CL_TAKEN (above every bid) into both bid arrays
+// at both ends -- so a phase reads ONE random word per end (the winner of the round before, or CL_TAKEN) where it read two (that and
+// the contig's flag byte).  The flag array is still written, for the caller; nobody here reads it.
+#define CL_TAKEN 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ bool cl_edge(const mcom_mm128 *__restrict__ pairs, uint32_t e, int round, uint8_t *matched, uint8_t *dead, unsigned long long *bestC,
+                                        unsigned long long *bestP, unsigned long long rkey, unsigned long long pkey, uint32_t *__restrict__ sel, uint32_t &bid_ci)
+{
+	const mcom_mm128 pr = pairs[e];
+	const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
+	const unsigned long long inv = (unsigned long long)(0xFFFFFFFFu - e);
+	if (round > 1) {                                                            // (nothing is taken before the first takes: the phase that sees every edge reads nothing here)
+		const unsigned long long pi = bestP[ci], pj = bestP[cj];
+		if (pi == (pkey | inv) && pj == (pkey | inv)) {                        // the winner of the round before at both ends, and both still free
+			matched[ci] = 1; matched[cj] = 1; sel[e] = 1;
+			bestP[ci] = CL_TAKEN; bestP[cj] = CL_TAKEN; bestC[ci] = CL_TAKEN; bestC[cj] = CL_TAKEN;
+			dead[e] = 1;
+			return false;
+		}
+		if (pi == CL_TAKEN || pj == CL_TAKEN) { dead[e] = 1; return false; }   // (also the stale winner: an end was taken after it had bid)
+	}
+	// The edges of one query lie one behind the other and share the end ci: an earlier one that bids in this phase is the smaller
+	// bidder there whatever this one does, so this one's bid at ci is left out (round 5: a third of the atomics of the first
+	// round).  At cj it must bid: it stands in front of later queries' edges there until its own fate is known.
+	if (bid_ci != ci) atomicMax(&bestC[ci], rkey | inv);
+	atomicMax(&bestC[cj], rkey | inv);
+	bid_ci = ci;
+	return true;
+}
 __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__restrict__ pairs, uint32_t n, uint8_t *matched, uint8_t *dead,
                                                          unsigned long long *best, uint32_t n_contigs, uint32_t *__restrict__ sel, unsigned int *state, int max_rounds,
-                                                         unsigned int *poison, unsigned int *__restrict__ host_copy, unsigned int poll_limit)
+                                                         unsigned int *poison, unsigned int *__restrict__ host_copy, unsigned int poll_limit, uint32_t *__restrict__ tail_list, uint32_t tail_max)
 {
-	// state[0] = barrier counter; on a line of their own: state[32 + round % 3] = "some edge bid in this round", state[36] = rounds with bids,
-	// state[37] = did not settle; state[64 ...] = the release words
+	// state[0] = barrier counter; on a line of their own: state[32 + round % 3] = edges that bid in this round, state[35] = entries of the tail's
+	// list, state[36] = rounds with bids, state[37] = did not settle, state[38] = the round the tail began with (0: no tail); state[64 ...] = the release words
 	const unsigned int G = gridDim.x;
 	const uint32_t stride = G * CL_THREADS, chunks = (n + 15u) >> 4;
 	unsigned int gen = 0;
-	for (int round = 1; ; ++round) {
+	__shared__ unsigned int wg_live;
+	auto finish = [&](int round, bool any) {
+		const unsigned int r36 = (unsigned int)(any ? round - 1 : round - 2), r37 = any ? 1u : 0u;
+		state[36] = r36; state[37] = r37;
+		if (host_copy) { host_copy[0] = r36; host_copy[1] = r37; }               // (pinned memory: the read-back needs no copy, scan.hip)
+	};
+	int round = 1;
+	bool listing = false;                                                        // this round's bidders go to the tail's list
+	for (; ; ++round) {
 		if (round > 1) {
-			const bool any = *(volatile unsigned int*)(state + 32 + (round - 1) % 3) != 0;
-			if (!any || round - 1 >= max_rounds) {
-				if (blockIdx.x == 0 && threadIdx.x == 0) {
-					const unsigned int r36 = (unsigned int)(any ? round - 1 : round - 2), r37 = any ? 1u : 0u;
-					state[36] = r36; state[37] = r37;
-					if (host_copy) { host_copy[0] = r36; host_copy[1] = r37; }               // (pinned memory: the read-back needs no copy, scan.hip)
-				}
+			const unsigned int alive = *(volatile unsigned int*)(state + 32 + (round - 1) % 3);
+			if (!alive || round - 1 >= max_rounds) {
+				if (blockIdx.x == 0 && threadIdx.x == 0) finish(round, alive != 0);
 				return;
 			}
+			if (listing) break;                                                        // the list is made: the tail below
+			listing = alive <= tail_max;
 		}
+		if (threadIdx.x == 0) wg_live = 0;
+		__syncthreads();
 		const unsigned long long rkey = (unsigned long long)round << 32, pkey = (unsigned long long)(round - 1) << 32;
 		unsigned long long *bestC = best + (size_t)(round & 1) * n_contigs;
-		const unsigned long long *bestP = best + (size_t)((round - 1) & 1) * n_contigs;
-		bool live = false;
+		unsigned long long *bestP = best + (size_t)((round - 1) & 1) * n_contigs;
+		uint32_t live = 0;
 		// sixteen edges per step: one 16-byte load of their dead flags (most edges are dead after the first rounds, and a loop of
 		// dependent one-byte loads -- 114 per thread and phase -- was what the first form of this kernel spent its time on)
 		for (uint32_t c = blockIdx.x * CL_THREADS + threadIdx.x; c < chunks; c += stride) {
@@ -108,29 +151,48 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 				for (int b = 0; b < 4; ++b) {
 					const uint32_t e = c * 16 + w * 4 + b;
 					if (((dw[w] >> (8 * b)) & 0xFFu) || e >= n) continue;
-					const mcom_mm128 pr = pairs[e];
-					const uint32_t ci = (uint32_t)(pr.x >> 32), cj = (uint32_t)(pr.y >> 32);
-					const unsigned long long inv = (unsigned long long)(0xFFFFFFFFu - e);
-					const bool mi = round > 1 && matched[ci] != 0, mj = round > 1 && matched[cj] != 0;   // (nothing is matched before the first takes: two random loads per edge less in the phase that sees every edge)
-					if (round > 1 && bestP[ci] == (pkey | inv) && bestP[cj] == (pkey | inv)) {   // the winner of the round before at both ends
-						if (!mi && !mj) { matched[ci] = 1; matched[cj] = 1; sel[e] = 1; }          // (a stale bid: an end was matched meanwhile)
-						dead[e] = 1;
-						continue;
+					if (cl_edge(pairs, e, round, matched, dead, bestC, bestP, rkey, pkey, sel, bid_ci)) {
+						++live;
+						if (listing) tail_list[atomicAdd(state + 35, 1u)] = e;                   // (at most tail_max of them: who bids now bid in the round before)
 					}
-					if (mi || mj) { dead[e] = 1; continue; }
-					// The edges of one query lie one behind the other and share the end ci: an earlier one that bids in this phase is the smaller
-					// bidder there whatever this one does, so this one's bid at ci is left out (round 5: a third of the atomics of the first
-					// round).  At cj it must bid: it stands in front of later queries' edges there until its own fate is known.
-					if (bid_ci != ci) atomicMax(&bestC[ci], rkey | inv);
-					atomicMax(&bestC[cj], rkey | inv);
-					bid_ci = ci;
-					live = true;
 				}
 			}
 		}
-		if (__any(live) && (threadIdx.x & 63) == 0 && *(volatile unsigned int*)(state + 32 + round % 3) == 0) state[32 + round % 3] = 1;
-		if (blockIdx.x == 0 && threadIdx.x == 0) state[32 + (round + 1) % 3] = 0;                // the next round's flag (nobody else touches it in this phase)
+		for (int o = 32; o; o >>= 1) live += __shfl_xor(live, o);
+		if ((threadIdx.x & 63) == 0 && live) atomicAdd(&wg_live, live);
+		__syncthreads();
+		if (threadIdx.x == 0 && wg_live) atomicAdd(state + 32 + round % 3, wg_live);
+		if (blockIdx.x == 0 && threadIdx.x == 0) state[32 + (round + 1) % 3] = 0;                // the next round's count (nobody else touches it in this phase)
 		if (!cl_barrier(state, G, gen, poison, poll_limit)) return;
+	}
+	// ---- the tail: one workgroup, the listed edges, the same phases
+	if (blockIdx.x != 0) return;
+	const uint32_t n_list = *(volatile unsigned int*)(state + 35);
+	if (threadIdx.x == 0) state[38] = (unsigned int)round;
+	for (; ; ++round) {
+		// (round's predecessor had bidders -- the loop above or the end of the last turn saw to that -- and the budget holds)
+		if (threadIdx.x == 0) wg_live = 0;
+		__syncthreads();
+		const unsigned long long rkey = (unsigned long long)round << 32, pkey = (unsigned long long)(round - 1) << 32;
+		unsigned long long *bestC = best + (size_t)(round & 1) * n_contigs;
+		unsigned long long *bestP = best + (size_t)((round - 1) & 1) * n_contigs;
+		uint32_t live = 0;
+		for (uint32_t i = threadIdx.x; i < n_list; i += CL_THREADS) {
+			const uint32_t e = tail_list[i];
+			if (((volatile uint8_t*)dead)[e]) continue;
+			uint32_t bid_ci = 0xFFFFFFFFu;                                              // (every edge bids at both ends here)
+			live += cl_edge(pairs, e, round, matched, dead, bestC, bestP, rkey, pkey, sel, bid_ci) ? 1u : 0u;
+		}
+		for (int o = 32; o; o >>= 1) live += __shfl_xor(live, o);
+		if ((threadIdx.x & 63) == 0 && live) atomicAdd(&wg_live, live);
+		__threadfence();                                                             // bids, flags and takes of this phase: out, and nothing stale kept for the next
+		__syncthreads();
+		const unsigned int alive = wg_live;
+		__syncthreads();
+		if (!alive || round >= max_rounds) {
+			if (threadIdx.x == 0) finish(round + 1, alive != 0);
+			return;
+		}
 	}
 }
 
@@ -192,7 +254,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	if (rc) return rc;
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
 	const size_t best_b = al(2 * n_contigs * 8), dead_b = al(n_pairs + 16), sel_b = al((n_pairs + 1) * 4);
-	rc = mcom_ws_reserve(ctx, best_b + dead_b + 2 * sel_b + al(CL_STATE_WORDS * 4) + 256);
+	rc = mcom_ws_reserve(ctx, best_b + dead_b + 2 * sel_b + al(CL_STATE_WORDS * 4) + al(CL_TAIL * 4) + 256);
 	if (rc) return rc;
 	char *base = (char*)ctx->ws;
 	unsigned long long *best = (unsigned long long*)base;
@@ -200,6 +262,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 	uint32_t *sel = (uint32_t*)(base + best_b + dead_b);
 	unsigned int *state = (unsigned int*)(base + best_b + dead_b + sel_b);
 	uint32_t *spre = (uint32_t*)(base + best_b + dead_b + sel_b + al(CL_STATE_WORDS * 4));
+	uint32_t *tail_list = (uint32_t*)(base + best_b + dead_b + 2 * sel_b + al(CL_STATE_WORDS * 4));
 	const unsigned blocks = (unsigned)((n_pairs + 255) / 256);
 	unsigned int hs[2] = {0, 0};
 	uint32_t nj = 0;
@@ -221,7 +284,7 @@ extern "C" int mcom_claim_pairs(mcom_ctx *ctx, const mcom_mm128 *d_pairs, size_t
 		uint32_t ring = 0;
 		unsigned int *host_copy = (unsigned int*)mcom_ring_slot(ctx, &ring);
 		MCOM_LAUNCH(k_claim_all, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, d_pairs, n32, d_flag, dead, best, (uint32_t)n_contigs, sel, state, 2 * max_rounds + 2, ctx->d_poison, host_copy,
-		            ctx->claim_route == 2 ? 0u : (1u << 23));
+		            ctx->claim_route == 2 ? 0u : (1u << 23), tail_list, ctx->claim_route == 3 ? 0u : (uint32_t)CL_TAIL);
 		if (host_copy) mcom_ring_register(ctx, state + 36, 8, ring);
 		MCOM_LAUNCH_CHECK(ctx);
 		MCOM_HIP(ctx, mcom_d2h_async(ctx, hs, state + 36, 8));

@@ -289,7 +289,8 @@ class Context:
 
     def set_claim_route(self, route: int):
         """Test hook of mcom_claim_pairs: 0 = default (one launch, the launch-per-round loop behind it), 1 = the loop at once, 2 = the
-        one-launch kernel's first barrier gives up (poison flag trips, the loop takes over)."""
+        one-launch kernel's first barrier gives up (poison flag trips, the loop takes over), 3 = the one-launch kernel without the
+        single-workgroup tail."""
         self.lib.mcom_set_claim_route.restype = C.c_int; self.lib.mcom_set_claim_route.argtypes = [C.c_void_p, C.c_int]
         self._check(self.lib.mcom_set_claim_route(self._h, route))
 

@@ -104,6 +104,44 @@ def test_claim_falls_back_to_the_launch_per_round_loop(ctx, route):
     assert jobs.cpu().numpy().tolist() == [list(j) for j in want_jobs] and ctx.claim_fallbacks() == before + 4
 
 
+def test_claim_tail_by_one_workgroup_equals_the_whole_grid(ctx):
+    """Once at most 16384 edges are alive the one-launch kernel lists them and ONE workgroup runs the remaining rounds over the list
+    (csrc/claim.hip, "the tail"); route 3 keeps every round on the whole grid.  Same jobs and same flags (the number of rounds may
+    differ by the rounds that stale bids add: csrc/claim.hip), on lists far above the tail's size, near-diagonal lists (long chains) and a chain that does
+    not settle inside the budget."""
+    import torch
+    from minicom_amd.hip import McomError
+    try:
+        for n, deg, near in [(1_500_000, 3, 0), (400_000, 4, 2), (30_000, 2, 1), (9_000, 6, 0)]:
+            rng = np.random.default_rng(n + deg + near)
+            ci = np.repeat(np.arange(n, dtype=np.int64), rng.integers(0, deg + 1, n))
+            cj = rng.integers(0, n, len(ci)) if not near else np.clip(ci + rng.integers(-near, near + 1, len(ci)), 0, n - 1)
+            ok = ci != cj
+            ci, cj = ci[ok], cj[ok]
+            pairs = np.stack([ci, cj, rng.integers(0, 5000, len(ci)), rng.integers(0, 5000, len(ci))], axis=1)
+            rec = torch.from_numpy(_records(pairs.tolist()).view(np.int64)).cuda()
+            got = {}
+            for route in (0, 3):
+                ctx.set_claim_route(route)
+                jobs, flag, rounds = ctx.claim_pairs(rec, n)
+                ctx.sync()
+                got[route] = (jobs.cpu().numpy(), flag.cpu().numpy(), rounds)
+            assert np.array_equal(got[0][0], got[3][0]) and np.array_equal(got[0][1], got[3][1])
+            if n <= 30_000:
+                want_jobs, want_flag = _sequential(pairs.tolist(), n)
+                assert got[0][0].tolist() == [list(j) for j in want_jobs] and np.array_equal(got[0][1], want_flag)
+        chain = [(i, i + 1, 7, 9) for i in range(19_999)]
+        rec = torch.from_numpy(_records(chain).view(np.int64)).cuda()
+        for route in (0, 3):
+            ctx.set_claim_route(route)
+            with pytest.raises(McomError):
+                ctx.claim_pairs(rec, 20_000, max_rounds=300)
+            jobs, flag, rounds = ctx.claim_pairs(rec, 20_000, max_rounds=10_001)
+            assert jobs.shape[0] == 10_000 and rounds >= 9_999
+    finally:
+        ctx.set_claim_route(0)
+
+
 def test_claim_empty(ctx):
     import torch
     jobs, flag, rounds = ctx.claim_pairs(torch.zeros((0, 2), dtype=torch.int64, device="cuda"), 7)
