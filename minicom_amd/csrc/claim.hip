@@ -138,24 +138,49 @@ __global__ __launch_bounds__(CL_THREADS) void k_claim_all(const mcom_mm128 *__re
 		unsigned long long *bestC = best + (size_t)(round & 1) * n_contigs;
 		unsigned long long *bestP = best + (size_t)((round - 1) & 1) * n_contigs;
 		uint32_t live = 0;
-		// sixteen edges per step: one 16-byte load of their dead flags (most edges are dead after the first rounds, and a loop of
-		// dependent one-byte loads -- 114 per thread and phase -- was what the first form of this kernel spent its time on)
-		for (uint32_t c = blockIdx.x * CL_THREADS + threadIdx.x; c < chunks; c += stride) {
-			const uint4 d16 = ((const uint4*)dead)[c];
-			const uint32_t dw[4] = {d16.x, d16.y, d16.z, d16.w};
-			uint32_t bid_ci = 0xFFFFFFFFu;                                              // the query of the last edge of this chunk that bid
-#pragma unroll
-			for (int w = 0; w < 4; ++w) {
-				if (dw[w] == 0x01010101u) continue;
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					const uint32_t e = c * 16 + w * 4 + b;
-					if (((dw[w] >> (8 * b)) & 0xFFu) || e >= n) continue;
-					if (cl_edge(pairs, e, round, matched, dead, bestC, bestP, rkey, pkey, sel, bid_ci)) {
-						++live;
-						if (listing) tail_list[atomicAdd(state + 35, 1u)] = e;                   // (at most tail_max of them: who bids now bid in the round before)
+		// A wave takes 1024 consecutive edges at a time, lane = edge within a row of 64: the records of a row are ONE kilobyte (round 5; a
+		// thread used to own sixteen consecutive edges, so that a wave's load touched 64 lines 256 bytes apart, sixteen times over).  The
+		// dead flags come first, sixteen per lane in one load (most edges are dead after the first rounds): a block without a live edge
+		// costs that load, a row without one nothing.
+		const uint32_t lane = threadIdx.x & 63u, wv = (blockIdx.x * CL_THREADS + threadIdx.x) >> 6, n_wv = stride >> 6, blocks1k = (n + 1023u) >> 10;
+		for (uint32_t kb = wv; kb < blocks1k; kb += n_wv) {
+			const uint32_t e0 = kb << 10, ch = (e0 >> 4) + lane;
+			uint4 d16 = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+			if (ch < chunks) d16 = ((const uint4*)dead)[ch];
+			const unsigned long long some = __ballot(d16.x != 0x01010101u || d16.y != 0x01010101u || d16.z != 0x01010101u || d16.w != 0x01010101u);
+			if (!some) continue;
+			uint32_t carry_ci = 0xFFFFFFFFu; bool carry_bid = false;                   // the last edge of the row before (when that row was looked at)
+			for (uint32_t j = 0; j < 16; ++j) {
+				if (!((some >> (4 * j)) & 0xFull)) { carry_ci = 0xFFFFFFFFu; carry_bid = false; continue; }   // the row's four chunks are dead
+				const uint32_t e = e0 + 64u * j + lane;
+				bool bids = false;
+				uint32_t ci = 0xFFFFFFFFu, cj = 0;
+				unsigned long long inv = 0;
+				if (e < n && !dead[e]) {                                                  // (the line came with the load above)
+					const mcom_mm128 pr = pairs[e];
+					ci = (uint32_t)(pr.x >> 32); cj = (uint32_t)(pr.y >> 32);
+					inv = (unsigned long long)(0xFFFFFFFFu - e);
+					bids = true;
+					if (round > 1) {                                                       // (nothing is taken before the first takes)
+						const unsigned long long pi = bestP[ci], pj = bestP[cj];
+						if (pi == (pkey | inv) && pj == (pkey | inv)) {                   // the winner of the round before at both ends, and both still free
+							matched[ci] = 1; matched[cj] = 1; sel[e] = 1;
+							bestP[ci] = CL_TAKEN; bestP[cj] = CL_TAKEN; bestC[ci] = CL_TAKEN; bestC[cj] = CL_TAKEN;
+							dead[e] = 1; bids = false;
+						} else if (pi == CL_TAKEN || pj == CL_TAKEN) { dead[e] = 1; bids = false; }
 					}
 				}
+				// the edges of one query lie one behind the other and share the end ci: when the edge right in front bids in this phase it is
+				// the smaller bidder there whatever this one does, and this one's bid at ci is left out (a third of the first round's atomics)
+				uint32_t pci = (uint32_t)__shfl_up((int)ci, 1); int pb = __shfl_up(bids ? 1 : 0, 1);
+				if (lane == 0) { pci = carry_ci; pb = carry_bid ? 1 : 0; }
+				if (bids) {
+					if (!(pb && pci == ci)) atomicMax(&bestC[ci], rkey | inv);
+					atomicMax(&bestC[cj], rkey | inv);
+					++live;
+					if (listing) tail_list[atomicAdd(state + 35, 1u)] = e;                  // (at most tail_max of them: who bids now bid in the round before)
+				}
+				carry_ci = (uint32_t)__shfl((int)ci, 63); carry_bid = __shfl(bids ? 1 : 0, 63) != 0;
 			}
 		}
 		for (int o = 32; o; o >>= 1) live += __shfl_xor(live, o);
