@@ -457,7 +457,11 @@ __device__ __forceinline__ void contig_window(const uint64_t *__restrict__ conti
 // tuple they pass is appended to `tuples` {claim key, singleton} for the replay of those bins on the host
 // SHARED: the index is shared out by key over several GPUs (its own instantiation: the one-GPU kernel sits at 94 registers, five
 // waves per SIMD, and the ownership test's few more would leave it four -- 19 -> 21.5 ms)
-template <int W, int G, bool TUP, bool SHARED>
+// QPL (a kernel of its own again, lesson 6): (direction, dictionary) pairs per LANE.  On several GPUs a rank owns 1 / R of the keys, so with a
+// lane per pair seven lanes in eight of an 8-rank job drop out after the ownership test and a wave runs as long as ever for an eighth of
+// the lookups (profiles/r05_dist_kernels.txt: the eight ranks together spent 4 x the one-GPU kernel's time).  With QPL pairs per lane -- 16 / QPL
+// lanes per singleton, a lane going through its pairs one after the other -- the waves are as many as the lookups that are left.
+template <int W, int G, bool TUP, bool SHARED, int QPL>
 __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned long long *__restrict__ keys,
                                                        const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
                                                        const uint32_t *__restrict__ elig, size_t n_sg, const uint64_t *__restrict__ cbits,
@@ -466,22 +470,26 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
                                                        const uint8_t *__restrict__ mark, ulonglong2 *__restrict__ tuples,
                                                        unsigned long long tup_cap, unsigned long long *__restrict__ tup_count)
 {
+	constexpr int GL = G / QPL;                                                          // lanes per singleton
 	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const size_t sg = t / G;
-	const int q = (int)(t % G);
+	const size_t sg = t / GL;
+	const int q0 = (int)(t % GL);
 	uint32_t n_look = 0, n_cand = 0, n_pass = 0;                                          // (a lane's own counts: small)
-	const int dir = q / g.nd, l = q - dir * g.nd;
 	const int L = g.L;
-	bool live = sg < n_sg && q < 2 * g.nd && !(dir && g.ds[l] <= 0);                      // kthread_hash_realign.c:440
-	if (live && sgflag[sg]) live = false;
-	const uint32_t el = (live && elig) ? elig[sg] : 0xFFFFFFFFu;
-	if (live && !((el >> l) & 1u)) live = false;
-	const bool marked = TUP && live && mark[sg];
+	const bool sg_live = sg < n_sg && !sgflag[sg];
+	const uint32_t el = (sg_live && elig) ? elig[sg] : 0xFFFFFFFFu;
 	uint64_t row[W];
 #pragma unroll
 	for (int w = 0; w < W; ++w) row[w] = 0;
+	bool have_row = false;
+#pragma unroll 1
+	for (int it = 0; it < QPL; ++it) {
+	const int q = q0 + it * GL;
+	const int dir = q / g.nd, l = q - dir * g.nd;
+	bool live = sg_live && q < 2 * g.nd && !(dir && g.ds[l] <= 0);                      // kthread_hash_realign.c:440
+	if (live && !((el >> l) & 1u)) live = false;
+	const bool marked = TUP && live && mark[sg];
 	const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
-
 	// what one candidate (contig, position of the key) amounts to
 	auto verify = [&](uint64_t v) {
 		const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
@@ -516,9 +524,10 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	if (live) {
 		const uint64_t *rb = sgbits + sg * (size_t)W;
 		constexpr bool shared = SHARED;                                                    // the index is shared out by key: most keys are another rank's,
-		if (!shared) {                                                                     // and the row is loaded only once the key turns out to be this share's
+		if (!shared && !have_row) {                                                        // and the row is loaded only once the key turns out to be this share's
 #pragma unroll
 			for (int w = 0; w < W; ++w) row[w] = rb[w];
+			have_row = true;
 		}
 		uint64_t key = shared ? bits_key(rb, g.ds[l], g.klen) : bits_key(row, g.ds[l], g.klen);
 		const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
@@ -534,9 +543,10 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 		// replicated there, and the claim keys of all shares are MIN-reduced)
 		const bool mine = !SHARED || own == g.owner;
 		n_look += mine;
-		if (shared && mine) {
+		if (shared && mine && !have_row) {
 #pragma unroll
 			for (int w = 0; w < W; ++w) row[w] = rb[w];
+			have_row = true;
 		}
 		// the home line, then the lines behind it while entries were pushed on; when the home line says its keys are heavy (a repeat
 		// with more copies than a few lines hold) their entries are in a run of lines in the extension area, read afterwards
@@ -581,6 +591,7 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	for (int i = 0; i < RR_CAND; ++i) {
 		if (!__any(nc > i)) break;
 		if (nc > i) verify(i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3);
+	}
 	}
 	if (stats) {
 		// the three counts of a lane travel as ONE word through one reduction, and a workgroup sends one set of atomics (three reductions and
@@ -640,8 +651,11 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t 
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 #define MCOM_ARGS g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count
-#define MCOM_RA_LAUNCH(WW, GG, TT) do { if (g.n_owners > 1) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); \
-	else MCOM_LAUNCH((k_realign_reads<WW, GG, TT, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)
+#define MCOM_RA_LAUNCH(WW, GG, TT) do { \
+	if (g.n_owners >= 8) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 8>), dim3((unsigned)((n_sg * (uint64_t)(GG / 8) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else if (g.n_owners >= 3) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 4>), dim3((unsigned)((n_sg * (uint64_t)(GG / 4) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else if (g.n_owners > 1) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 2>), dim3((unsigned)((n_sg * (uint64_t)(GG / 2) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	else MCOM_LAUNCH((k_realign_reads<WW, GG, TT, false, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)
 #define MCOM_CASE(WW) case WW: \
 	if (d_mark) { if (G == 16) MCOM_RA_LAUNCH(WW, 16, true); else MCOM_RA_LAUNCH(WW, 32, true); } \
 	else if (G == 16) MCOM_RA_LAUNCH(WW, 16, false); else MCOM_RA_LAUNCH(WW, 32, false); break;
