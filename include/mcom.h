@@ -94,6 +94,13 @@ uint64_t mcom_counter(const mcom_ctx *ctx, const char *name);
 int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
                        uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
                        uint64_t *d_nmask, mcom_mm128 *d_rec);
+/* The two halves of mcom_process_reads as calls of their own (round 5): process_reads' counts, classes, N substitution and packing
+ * (kthread_reads.c:55-205) -- bound by HBM -- and mm_sketch_two over the packed rows with the records of the other classes blanked
+ * (kthread_reads.c:206-230, sketch.c:238) -- bound by the VALU.  A caller that cuts its reads into batches runs the sketch of one
+ * batch on one stream beside the classification of the next on another (mcomh_kt_for_reads does).  Same outputs as the one call.    */
+int mcom_classify_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int e,
+                        uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt, uint64_t *d_nmask);
+int mcom_sketch_classified(mcom_ctx *ctx, const uint64_t *d_packed, const uint8_t *d_cls, size_t n, int L, int k, uint32_t rid0, mcom_mm128 *d_rec);
 
 /* The same for reads the caller has packed already (round 4: a FASTQ parser that packs on the host sends 2 bits per base and one N
  * flag per base over PCIe instead of a byte per base): d_in_packed [n][W] codes A0 C1 G2 T3 with 0 at an N, d_in_nmask [n][ceil(L/64)].

@@ -54,6 +54,9 @@ typedef struct {
 	                       pass); same claims.  Measured at 100 M x 150 bp: the two take the same time, so the table stays the
 	                       default; the join needs 17 GB less.  Inputs the join does not take (a dictionary bin that may exceed maxsearch, ...) go
 	                       through the table by themselves                                                                                  */
+	int read_batches;   /* 1 = mcomh_kt_for_reads in four batches over two streams for reads resident in HBM: the classification of a batch (bound by
+	                       HBM) beside the sketch of the batch before (bound by the VALU), instead of one launch each over all reads.  Same arrays.
+	                       Measured at 100 M x 150 bp, steps alternating on one box: 178.7 against 179.5 ms -- off by default                      */
 } mcomh_params;
 
 typedef struct mcomh_pipeline mcomh_pipeline;

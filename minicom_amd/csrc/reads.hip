@@ -611,16 +611,16 @@ extern "C" int mcom_process_reads_packed(mcom_ctx *ctx, const uint64_t *d_in_pac
 	return MCOM_OK;
 }
 
-extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
-                                  uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
-                                  uint64_t *d_nmask, mcom_mm128 *d_rec)
+// process_reads without the sketch: classes, N counts, N masks, packed rows (what mcom_process_reads starts with; a caller that runs
+// the sketch of one batch beside the classification of the next -- one is bound by the VALU, the other by HBM -- asks for the parts)
+extern "C" int mcom_classify_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int e,
+                                   uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt, uint64_t *d_nmask)
 {
 	if (!ctx) return MCOM_E_ARG;
 	if (L < 1 || L > 256) return mcom_fail(ctx, MCOM_E_ARG, "read length %d out of range 1..256", L);
-	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
 	if (pitch < (size_t)L) return mcom_fail(ctx, MCOM_E_ARG, "pitch %zu < read length %d", pitch, L);
 	if (n == 0) return MCOM_OK;
-	if (!d_ascii || !d_packed || !d_cls || !d_ncnt || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (!d_ascii || !d_packed || !d_cls || !d_ncnt) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	const int W = mcom_words_per_read(L), NW = (L + 63) / 64;
 	const int G = 16;                                                       // L <= 128: 8 bases per lane; above: 16 bases per lane
 	const size_t waves = (n + (64 / G) - 1) / (64 / G);
@@ -642,11 +642,29 @@ extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t 
 	if (L <= 128) MCOM_LAUNCH((k_classify_pack<16>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW);
 	else          MCOM_LAUNCH(k_classify_pack16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_ascii, pitch, n, L, e, d_packed, W, d_cls, d_ncnt, d_nmask, NW); }
 	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+// ... and its end: the sketch of the packed rows (mm_sketch_two for the kept reads), records of the other classes blanked
+extern "C" int mcom_sketch_classified(mcom_ctx *ctx, const uint64_t *d_packed, const uint8_t *d_cls, size_t n, int L, int k, uint32_t rid0, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0) return MCOM_OK;
+	if (!d_packed || !d_cls || !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
 	int rc = mcom_sketch_reads(ctx, d_packed, nullptr, n, L, k, rid0, d_rec);
 	if (rc) return rc;
 	MCOM_LAUNCH(k_mask_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_cls, n, d_rec);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
+}
+extern "C" int mcom_process_reads(mcom_ctx *ctx, const uint8_t *d_ascii, size_t pitch, size_t n, int L, int k, int e,
+                                  uint32_t rid0, uint64_t *d_packed, uint8_t *d_cls, uint16_t *d_ncnt,
+                                  uint64_t *d_nmask, mcom_mm128 *d_rec)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (k < 1 || k > 31) return mcom_fail(ctx, MCOM_E_ARG, "k=%d out of range 1..31", k);
+	if (n && !d_rec) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	const int rc = mcom_classify_reads(ctx, d_ascii, pitch, n, L, e, d_packed, d_cls, d_ncnt, d_nmask);
+	return rc ? rc : mcom_sketch_classified(ctx, d_packed, d_cls, n, L, k, rid0, d_rec);
 }
 
 extern "C" int mcom_synth_reads(mcom_ctx *ctx, uint64_t seed, uint64_t n_reads, int L, int coverage, double sub_rate,

@@ -296,6 +296,7 @@ struct mcomh_pipeline {
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
 	int full_consensus = 0;                                           // 1: count every column of a merged contig (A/B switch)
+	bool read_batches = false;                                        // kt_for_reads in batches over two streams (A/B switch: mcomh_params.read_batches = 1)
 	bool overlap_screen = false;                                      // true: the first Stage-2 pass's row gather + screen on the copy stream (A/B switch)
 	int stream_sets = 1;                                              // stream sets cluster_dump writes (the reference: one per thread)
 	bool host_dump = false;                                           // true: cluster_dump's default mode on the host, as the -p / paired-end modes (A/B switch)
@@ -489,6 +490,7 @@ extern "C" int mcomh_create(mcomh_pipeline **out, int device, void *hip_stream, 
 	p->host_dump = pp->host_dump == 1;
 	p->stream_sets = pp->stream_sets > 1 ? std::min(pp->stream_sets, 4096) : 1;
 	p->overlap_screen = pp->overlap_screen == 1;
+	p->read_batches = pp->read_batches == 1;
 	p->stage2_table = pp->stage2_join != 1;
 	p->maxsearch_forced = pp->maxsearch > 0 ? pp->maxsearch : 0;
 	p->host_threads = pp->host_threads > 0 ? pp->host_threads : 1;
@@ -725,8 +727,44 @@ static int kt_for_reads_impl(mcomh_pipeline *p)
 		p->stat["h2d_chunks"] += (double)c;
 	} else {
 		// rows, classes and N masks are indexed by the global read id: a rank writes its shard's part of the whole arrays
-		rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, nl, p->L, p->k, p->e, (uint32_t)r0, p->d_packed.p + r0 * p->W, p->d_cls.p + r0, p->d_ncnt.p,
-		                               p->d_nmask.p + r0 * p->NW, p->d_rec.p));
+		// Round 5, behind a switch (mcomh_params.read_batches = 1): classification + packing stream the reads at HBM's rate (5 ms per 100 M
+		// reads), the sketch is bound by the VALU (13 ms): the reads go in a few batches over TWO streams, the classification of a batch
+		// starting when that of the batch before has ended -- beside that batch's sketch.  Same arrays, batch by batch.  Measured on one
+		// box, steps alternating (tools/ab_read_batches.py): 178.7 against 179.5 ms -- the kernels do run side by side (a batch's sketch takes
+		// twice its time alone) but the card gets little more done per millisecond, so one launch each stays the default.
+		const size_t NB = 4;
+		size_t bsz = ((nl + NB - 1) / NB + 63) & ~(size_t)63;                          // (whole 64-read units: the byte-stream kernel's 16-byte alignment holds for every batch)
+		const bool two = !dist && p->ctx2 && p->read_batches && nl >= ((size_t)1 << 22) && p->pitch == (size_t)p->L && (((uintptr_t)p->d_ascii) & 15) == 0 && nl < ((size_t)1 << 32);
+		if (!two) {
+			rc = p->gpu(mcom_process_reads(p->ctx, p->d_ascii, p->pitch, nl, p->L, p->k, p->e, (uint32_t)r0, p->d_packed.p + r0 * p->W, p->d_cls.p + r0, p->d_ncnt.p,
+			                               p->d_nmask.p + r0 * p->NW, p->d_rec.p));
+		} else {
+			hipEvent_t evc[NB] = {}; hipEvent_t ev_end = nullptr;
+			rc = MCOM_OK;
+			for (size_t c = 0; c < NB && !rc; ++c) rc = p->hipc(hipEventCreateWithFlags(&evc[c], hipEventDisableTiming), "event");
+			if (!rc) rc = p->hipc(hipEventCreateWithFlags(&ev_end, hipEventDisableTiming), "event");
+			// (the copy stream may still carry the last step's copies of this pipeline: nothing of this step is on it yet)
+			if (!rc) rc = p->hipc(hipEventRecord(p->ev_main, p->stream), "event");
+			if (!rc) rc = p->hipc(hipStreamWaitEvent(p->copy_stream, p->ev_main, 0), "wait");   // the reads are where the main stream left them
+			size_t c = 0;
+			for (size_t lo = 0; lo < nl && !rc; lo += bsz, ++c) {
+				const size_t cnt = std::min(bsz, nl - lo);
+				mcom_ctx *cx = (c & 1) ? p->ctx2 : p->ctx;
+				hipStream_t st = (c & 1) ? p->copy_stream : p->stream;
+				if (c) rc = p->hipc(hipStreamWaitEvent(st, evc[c - 1], 0), "wait");              // one classification at a time
+				if (!rc) { rc = mcom_classify_reads(cx, p->d_ascii + lo * p->pitch, p->pitch, cnt, p->L, p->e, p->d_packed.p + lo * p->W, p->d_cls.p + lo, p->d_ncnt.p + lo, p->d_nmask.p + lo * p->NW);
+				           if (rc) p->err = std::string("libmcom_hip: ") + mcom_last_error(cx); }
+				if (!rc) rc = p->hipc(hipEventRecord(evc[c], st), "event");
+				if (!rc) { rc = mcom_sketch_classified(cx, p->d_packed.p + lo * p->W, p->d_cls.p + lo, cnt, p->L, p->k, (uint32_t)lo, p->d_rec.p + lo);
+				           if (rc) p->err = std::string("libmcom_hip: ") + mcom_last_error(cx); }
+			}
+			if (!rc) rc = p->hipc(hipEventRecord(ev_end, p->copy_stream), "event");
+			if (!rc) rc = p->hipc(hipStreamWaitEvent(p->stream, ev_end, 0), "wait");          // everything behind this sees all batches
+			if (rc) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamSynchronize(p->stream); }
+			for (size_t q = 0; q < NB; ++q) if (evc[q]) (void)hipEventDestroy(evc[q]);
+			if (ev_end) (void)hipEventDestroy(ev_end);
+			p->stat["read_batches"] += (double)c;
+		}
 	}
 	if (rc) return rc;
 	if (dist) {

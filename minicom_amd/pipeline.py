@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 class Params(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("k", "e", "m", "w", "cbthr", "max_rounds", "step", "maxthr", "numdict", "host_threads", "maxsearch", "window_scan",
-                                         "full_consensus", "full_sketch", "overlap_screen", "host_dump", "stream_sets", "stage2_join")]
+                                         "full_consensus", "full_sketch", "overlap_screen", "host_dump", "stream_sets", "stage2_join", "read_batches")]
 
 
 def host_lib_path() -> str:

@@ -223,6 +223,24 @@ def test_pipeline_equals_the_sequential_oracle_on_2m_reads_of_150_bases():
     p.close(); o.close()
 
 
+def test_read_stage_in_batches_over_two_streams_gives_the_same_result():
+    """mcomh_params.read_batches = 1: classification and sketch of the reads in four batches over two streams (the classification of a
+    batch beside the sketch of the one before) instead of one launch each -- an A/B switch, same arrays: records, classes, N lists and
+    everything made of them.  6 M x 150 bp with N reads, poly-A/T and N-heavy reads (the switch takes 4 M reads or more on the device)."""
+    import torch
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline
+    n, L = 6_000_000, 150
+    reads = torch.from_numpy(synth.synth_reads(6262, n, L, plumbing=True)).cuda()
+    digests = []
+    for rb in (0, 1):
+        p = Pipeline(reads, L=L, host_threads=8, read_batches=rb); p.pre_process()
+        assert p.stat("read_batches") == (4 if rb else 0)
+        digests.append(p.result_digest())
+        p.close()
+    assert digests[0] == digests[1]
+
+
 @pytest.mark.parametrize("n,L,sub_rate", [(3_000_000, 100, 0.004), (2_000_000, 100, 0.04), (1_000_000, 150, 0.02)])
 def test_pipeline_equals_the_sequential_oracle_on_repeat_rich_reads(n, L, sub_rate):
     """A 200 kb genome with a 2 kb segment in forty copies, a tandem repeat, poly-A and (AT)n stretches at >= 750 x coverage:
