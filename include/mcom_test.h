@@ -40,6 +40,10 @@ int mcom_claim_fallbacks(const mcom_ctx *ctx);
  * a few keys, so that any input overflows (the fall-back runs).  Same answer every way.  mcom_screen_fallbacks: how often it ran.       */
 int mcom_set_screen_route(mcom_ctx *ctx, int route);
 int mcom_screen_fallbacks(const mcom_ctx *ctx);
+/* mcom_realign_pass_reads / _tuples over a SHARE of the keys (several GPUs: geom names more than one share).  route 0 = the default: a
+ * workgroup lists the (singleton, pair) tasks whose keys this share owns on a stack in LDS and a thread takes one task (k_realign_owned);
+ * 1 = the kernel of the whole index with several pairs per lane, a lane dropping the pairs it does not own.  Same claims either way.  */
+int mcom_set_lookup_route(mcom_ctx *ctx, int route);
 
 
 /* ---- libmcom_host.so ---- */

@@ -374,6 +374,12 @@ extern "C" int mcom_set_screen_route(mcom_ctx *ctx, int route)
 	return MCOM_OK;
 }
 extern "C" int mcom_screen_fallbacks(const mcom_ctx *ctx) { return ctx ? (int)ctx->screen_fallbacks : 0; }
+extern "C" int mcom_set_lookup_route(mcom_ctx *ctx, int route)
+{
+	if (!ctx || route < 0 || route > 1) return MCOM_E_ARG;
+	ctx->lookup_route = route;
+	return MCOM_OK;
+}
 extern "C" int mcom_set_index_capacity(mcom_ctx *ctx, int entries)
 {
 	if (!ctx) return MCOM_E_ARG;

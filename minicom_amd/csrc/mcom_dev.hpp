@@ -65,6 +65,7 @@ struct mcom_ctx {
 	// the pool is shared by every context of the process, so a block may only go back once its stream has passed its last user
 	std::vector<void*> free_later;
 	int screen_route = 0; uint64_t screen_fallbacks = 0;
+	int lookup_route = 0;                                                           // mcom_set_lookup_route (include/mcom_test.h)
 	struct ScreenArgs { const uint64_t *sgbits; size_t n_sg; int L, ininumdict, maxsearch, n_shares, share; } screen_args = {};
 	// a pool of zeroed words for the counters kernels add to (overflow counts, maxima, totals): handed out front to back and cleared as
 	// a whole when it is used up, instead of one 4-byte fill launch in front of every such kernel (mcom_zeroed, api.hip)

@@ -615,6 +615,198 @@ __global__ __launch_bounds__(256) void k_realign_reads(CixGeom g, const unsigned
 	}
 }
 
+// The lookups of a SHARE of the keys (multi-GPU), a thread per OWNED (singleton, pair) task.  With QPL pairs per lane (above) the lanes
+// of a wave own their keys in different turns of the loop, so a wave still walks the lookup's chain of dependent loads in nearly every
+// turn (profiles/r05_dist_kernels.txt: 5.25 ms per rank of eight against 1.5 for an eighth of the one-GPU kernel).  Here a workgroup goes
+// through its singletons in batches of 256 / (G / 4) (a lane computes four keys of a singleton and tests who owns them: arithmetic on one
+// row, no table access), the owned pairs are pushed on a stack in LDS, and whenever 256 tasks are there the 256 threads take one each:
+// key again, table lines, candidates, verification -- exactly the steps of k_realign_reads -- with every lane of the wave at work.  What is
+// left when the workgroup's singletons are through is done by as many threads as there are tasks.  A lane pushes its pairs in a row and
+// the lanes of a singleton are neighbours, so the tasks of one singleton -- one row, mostly one contig window -- stay side by side.
+#define RO_PAIRS 4
+template <int W, int G, bool TUP>
+__global__ __launch_bounds__(256) void k_realign_owned(CixGeom g, const unsigned long long *__restrict__ keys,
+                                                       const uint64_t *__restrict__ sgbits, const uint8_t *__restrict__ sgflag,
+                                                       const uint32_t *__restrict__ elig, size_t n_sg, uint32_t sg_per_wg,
+                                                       const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff,
+                                                       const uint64_t *__restrict__ woff, int thr, unsigned long long *__restrict__ claim,
+                                                       unsigned long long *__restrict__ stats, const uint8_t *__restrict__ mark,
+                                                       ulonglong2 *__restrict__ tuples, unsigned long long tup_cap,
+                                                       unsigned long long *__restrict__ tup_count)
+{
+	constexpr int GL = G / RO_PAIRS;                                                     // lanes per singleton while the keys are made
+	constexpr uint32_t SGB = 256 / GL;                                                   // singletons per batch
+	__shared__ uint32_t stack[256 * RO_PAIRS + 256];                                     // tasks: (singleton - the workgroup's first) << 5 | pair
+	__shared__ uint32_t s_top;
+	__shared__ unsigned long long wg_sum[3];
+	const int L = g.L;
+	const size_t sg_first = (size_t)blockIdx.x * sg_per_wg;
+	const size_t sg_end = sg_first + sg_per_wg < n_sg ? sg_first + sg_per_wg : n_sg;
+	const uint64_t kmask = (1ull << (2 * g.klen)) - 1;
+	uint32_t n_look = 0, n_cand = 0, n_pass = 0;
+	if (threadIdx.x == 0) { s_top = 0; wg_sum[0] = wg_sum[1] = wg_sum[2] = 0; }
+	__syncthreads();
+
+	// one task: the body of k_realign_reads for a pair whose key is this share's
+	auto task = [&](uint32_t tk, bool valid) {
+		const size_t sg = sg_first + (tk >> 5);
+		const int q = (int)(tk & 31u);
+		const int dir = q / g.nd, l = q - dir * g.nd;
+		const uint32_t el = (valid && elig) ? elig[sg] : 0xFFFFFFFFu;
+		const bool marked = TUP && valid && mark[sg];
+		const int off = dir ? L - g.ds[l] - g.klen : g.ds[l];
+		uint64_t row[W];
+		const uint64_t *rb = sgbits + sg * (size_t)W;
+#pragma unroll
+		for (int w = 0; w < W; ++w) row[w] = valid ? rb[w] : 0ull;
+		auto verify = [&](uint64_t v) {
+			const uint32_t c = (uint32_t)((v & ((1ull << CIX_TAG_SHIFT) - 1)) >> g.pbits);
+			const int64_t jj = (int64_t)(v & ((1ull << g.pbits) - 1)) - off;
+			if (jj < 0 || (uint64_t)jj >= woff[c + 1] - woff[c]) return;
+			++n_cand;
+			uint64_t win[W], x[W];
+			contig_window<W>(cbits + coff[c], (uint64_t)jj, L, dir != 0, win);
+			int dist = 0;
+#pragma unroll
+			for (int w = 0; w < W; ++w) { x[w] = win[w] ^ row[w]; dist += __popcll(x[w]); }
+			if (dist > thr || bits_key(x, g.ds[l], g.klen) != 0) return;
+			if (!marked)
+				for (int l2 = 0; l2 < l; ++l2)
+					if (((el >> l2) & 1u) && (!dir || g.ds[l2] > 0) && bits_key(x, g.ds[l2], g.klen) == 0) return;
+			uint64_t mm[W];
+#pragma unroll
+			for (int w = 0; w < W; ++w) mm[w] = (x[w] | (x[w] >> 1)) & 0x5555555555555555ull;
+			if (!dir) { if (!encode_ok_sparse<W>(mm, L, false)) return; }                      // kthread_hash_realign.c:393
+			else if (thr > 24 && !encode_ok_sparse<W>(mm, L, true)) return;                   // :461
+			++n_pass;
+			const unsigned long long ck = ((unsigned long long)c << 33) | ((unsigned long long)jj << 5) | ((unsigned long long)dir << 4) | (unsigned long long)l;
+			if (marked) {
+				const unsigned long long at = atomicAdd(tup_count, 1ull);
+				if (at < tup_cap) tuples[at] = make_ulonglong2(ck, (unsigned long long)sg);
+			} else atomicMin(&claim[sg], ck);
+		};
+		uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0; int nc = 0;
+		if (valid) {
+			uint64_t key = bits_key(row, g.ds[l], g.klen);
+			if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
+			uint32_t own, part, h16;
+			cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
+			const uint32_t nl = g.n_lines;
+			const unsigned long long *lines = keys + CIX_HEAD_WORDS;
+			const unsigned long long *L0 = lines + (size_t)part * nl * 8;
+			uint32_t line = cix_home(h16, nl);
+			const unsigned long long tag = cix_tag(key);
+			++n_look;
+			unsigned long long heavy = 0;
+			for (bool more = true, home = true; more; home = false) {
+				const unsigned long long *kl = L0 + (size_t)line * 8;
+				unsigned long long ks[8];
+#pragma unroll
+				for (int s = 0; s < 8; ++s) ks[s] = kl[s];
+				const unsigned long long filled = ks[0] & 0xFFull;
+				more = (ks[0] & CIX_MORE) != 0;
+				if (home && (ks[0] & CIX_HEAVY)) heavy = ks[0];
+#pragma unroll
+				for (int s = 1; s < 8; ++s) {
+					if ((unsigned long long)s > filled) break;
+					if ((ks[s] >> CIX_TAG_SHIFT) != tag) continue;
+					const uint64_t v = ks[s];
+					if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
+					else verify(v);                                                            // a repeat: more copies than registers
+					++nc;
+				}
+				line = line + 1 == nl ? 0 : line + 1;
+			}
+			if (heavy) {
+				const unsigned long long *X = lines + ((size_t)g.n_parts * nl + (heavy >> 32)) * 8;
+				const uint32_t rl = (uint32_t)(heavy >> 10) & 0x3FFFFFu;
+#pragma unroll 1
+				for (uint32_t j = 0; j < rl; ++j) {
+					const uint32_t cn = (uint32_t)X[(size_t)j * 8] & 0xFFu;
+#pragma unroll 1
+					for (uint32_t s = 1; s <= cn; ++s) {
+						const unsigned long long v = X[(size_t)j * 8 + s];
+						if ((v >> CIX_TAG_SHIFT) != tag) continue;
+						if (nc == 0) c0 = v; else if (nc == 1) c1 = v; else if (nc == 2) c2 = v; else if (nc == 3) c3 = v;
+						else verify(v);
+						++nc;
+					}
+				}
+			}
+		}
+#pragma unroll 1
+		for (int i = 0; i < RR_CAND; ++i) {                                                   // the lanes of a wave verify their i-th candidate together
+			if (!__any(nc > i)) break;
+			if (nc > i) verify(i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3);
+		}
+	};
+
+#pragma unroll 1
+	for (size_t base = sg_first; base < sg_end; base += SGB) {                               // (bounds are the workgroup's: every thread takes every turn)
+		const size_t sg = base + threadIdx.x / GL;
+		const int q0 = (int)(threadIdx.x % GL);
+		uint32_t mine = 0;                                                                    // bit it: pair q0 + it * GL is this share's
+		if (sg < sg_end && !sgflag[sg]) {
+			const uint32_t el = elig ? elig[sg] : 0xFFFFFFFFu;
+			uint64_t row[W];
+			const uint64_t *rb = sgbits + sg * (size_t)W;
+#pragma unroll
+			for (int w = 0; w < W; ++w) row[w] = rb[w];
+#pragma unroll
+			for (int it = 0; it < RO_PAIRS; ++it) {
+				const int q = q0 + it * GL;
+				const int dir = q / g.nd, l = q - dir * g.nd;
+				if (q >= 2 * g.nd || (dir && g.ds[l] <= 0) || !((el >> l) & 1u)) continue;      // kthread_hash_realign.c:440
+				uint64_t key = bits_key(row, g.ds[l], g.klen);
+				if (dir) key = (~(rev_groups(key) >> (64 - 2 * g.klen))) & kmask;
+				uint32_t own, part, h16;
+				cix_hash(key, g.n_owners, g.n_parts, own, part, h16);
+				if (own == g.owner) mine |= 1u << it;
+			}
+		}
+		// room on the stack: a prefix sum inside the wave, one LDS atomic per wave
+		const uint32_t cnt = (uint32_t)__popc(mine);
+		uint32_t incl = cnt;
+		const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+		uint32_t wbase = 0;
+		if (lane == 63 && incl) wbase = atomicAdd(&s_top, incl);
+		wbase = __shfl(wbase, 63);
+		uint32_t at = wbase + incl - cnt;
+		const uint32_t rel = (uint32_t)(sg - sg_first) << 5;
+#pragma unroll
+		for (int it = 0; it < RO_PAIRS; ++it)
+			if ((mine >> it) & 1u) stack[at++] = rel | (uint32_t)(q0 + it * GL);
+		__syncthreads();
+		uint32_t top = s_top;
+		while (top >= 256u) {                                                                 // (top is the same in every thread)
+			const uint32_t tk = stack[top - 256u + threadIdx.x];
+			top -= 256u;
+			__syncthreads();                                                                  // every task read before the next push lands on its place
+			if (threadIdx.x == 0) s_top = top;
+			task(tk, true);
+		}
+		__syncthreads();
+	}
+	{
+		const uint32_t top = s_top;                                                          // (< 256; every thread goes in: the verification is a wave's)
+		const bool valid = threadIdx.x < top;
+		task(valid ? stack[threadIdx.x] : 0u, valid);
+	}
+	if (stats) {
+		// a thread has gone through the tasks of many singletons: its counts are whole words here, three reductions per workgroup in all
+		unsigned long long a = n_look, b = n_cand, c = n_pass;
+		for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&wg_sum[0], a); atomicAdd(&wg_sum[1], b); atomicAdd(&wg_sum[2], c); }
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			unsigned long long *st = stats + 4 * (blockIdx.x & 1023);
+			atomicAdd(&st[0], wg_sum[0]); if (wg_sum[1]) atomicAdd(&st[1], wg_sum[1]); if (wg_sum[2]) atomicAdd(&st[2], wg_sum[2]);
+		}
+	}
+}
+
 __global__ void k_stats_fold(const unsigned long long *__restrict__ sets, unsigned long long *__restrict__ out)
 {
 	const int c = threadIdx.x;                                                       // 3 threads
@@ -651,8 +843,19 @@ static int realign_reads_launch(mcom_ctx *ctx, const uint64_t *d_keys, uint64_t 
 	const uint64_t blocks = (n_sg * (uint64_t)G + 255) / 256;
 	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many singletons for one launch");
 #define MCOM_ARGS g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count
+	// a share of the keys: workgroups of a few thousand singletons each (the tasks a workgroup is left with at its end fill part of one turn)
+	uint32_t sg_per_wg = 64;
+	if (g.n_owners > 1) {
+		const uint64_t want_wgs = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 20;
+		uint64_t per = (n_sg + want_wgs - 1) / want_wgs;
+		per = (per + 63) & ~63ull;                                                         // whole batches (64 or 32 singletons)
+		sg_per_wg = (uint32_t)(per < 512 ? 512 : per > 65536 ? 65536 : per);
+	}
+	const uint64_t owned_blocks = (n_sg + sg_per_wg - 1) / sg_per_wg;
 #define MCOM_RA_LAUNCH(WW, GG, TT) do { \
-	if (g.n_owners >= 8) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 8>), dim3((unsigned)((n_sg * (uint64_t)(GG / 8) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
+	if (g.n_owners > 1 && ctx->lookup_route == 0) MCOM_LAUNCH((k_realign_owned<WW, GG, TT>), dim3((unsigned)owned_blocks), dim3(256), 0, ctx->stream, \
+		g, (const unsigned long long*)d_keys, d_sgbits, d_sgflag, d_elig, n_sg, sg_per_wg, d_cbits, d_coff, d_woff, thr, (unsigned long long*)d_claim, sets, d_mark, d_tuples, (unsigned long long)cap, d_count); \
+	else if (g.n_owners >= 8) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 8>), dim3((unsigned)((n_sg * (uint64_t)(GG / 8) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
 	else if (g.n_owners >= 3) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 4>), dim3((unsigned)((n_sg * (uint64_t)(GG / 4) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
 	else if (g.n_owners > 1) MCOM_LAUNCH((k_realign_reads<WW, GG, TT, true, 2>), dim3((unsigned)((n_sg * (uint64_t)(GG / 2) + 255) / 256)), dim3(256), 0, ctx->stream, MCOM_ARGS); \
 	else MCOM_LAUNCH((k_realign_reads<WW, GG, TT, false, 1>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, MCOM_ARGS); } while (0)

@@ -471,6 +471,53 @@ class Context:
         self._check(rc)
         return keys, parts.value
 
+    def cindex_build_shares(self, cbits, coff, woff, n_windows: int, L: int, ranks: int, ininumdict: int = 0):
+        """The ONE index over all contigs cut by key into `ranks` shares, all of them built on this GPU: mcom_cindex_plan_shared,
+        mcom_cindex_entries over the whole set (grouped by owning share) and mcom_cindex_place per share -- what R ranks do with an
+        all-to-all of the entries in between (host/mcom_pipeline.cpp).  Returns [(index words int64, geom)] by share."""
+        torch = _torch()
+        u64 = C.c_uint64
+        self.lib.mcom_cindex_plan_shared.restype = C.c_int
+        self.lib.mcom_cindex_plan_shared.argtypes = [u64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(u64)] * 4
+        self.lib.mcom_cindex_entries.restype = C.c_int
+        self.lib.mcom_cindex_entries.argtypes = [C.c_void_p] * 4 + [C.c_uint32] * 3 + [C.c_int, C.c_int, u64, C.c_void_p, C.c_void_p, u64, C.POINTER(u64)]
+        self.lib.mcom_cindex_place.restype = C.c_int
+        self.lib.mcom_cindex_place.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, u64, C.c_void_p, u64]
+        n_contigs = int(coff.shape[0])
+        ne, share, geom0, nw = u64(), u64(), u64(), u64()
+        self._check(self.lib.mcom_cindex_plan_shared(int(n_windows), n_contigs, L, ininumdict, ranks, 0, C.byref(ne), C.byref(share), C.byref(geom0), C.byref(nw)))
+        cap = int(ne.value) + 1
+        key = torch.empty(cap, dtype=torch.int32, device=self.device)
+        slot = torch.empty(cap, dtype=torch.int64, device=self.device)
+        counts = (u64 * ranks)()
+        self._check(self.lib.mcom_cindex_entries(self._h, self._p(cbits, torch.int64), self._p(coff, torch.int64), self._p(woff, torch.int64), n_contigs, 0, n_contigs,
+                                                 L, ininumdict, geom0.value, self._p(key), self._p(slot), cap, counts))
+        out, at = [], 0
+        for q in range(ranks):
+            g, nwq = u64(), u64()
+            self._check(self.lib.mcom_cindex_plan_shared(int(n_windows), n_contigs, L, ininumdict, ranks, q, C.byref(ne), C.byref(share), C.byref(g), C.byref(nwq)))
+            n = int(counts[q])
+            words = int(nwq.value)
+            for attempt in range(5):                                        # MCOM_E_OVERFLOW: a larger extension area (place overwrites its input: copies)
+                k, sl = key[at:at + n].clone(), slot[at:at + n].clone()
+                kt, st = torch.empty(n + 1, dtype=torch.int32, device=self.device), torch.empty(n + 1, dtype=torch.int64, device=self.device)
+                keys = torch.empty(words, dtype=torch.int64, device=self.device)
+                rc = self.lib.mcom_cindex_place(self._h, self._p(k), self._p(sl), n, 0, self._p(kt), self._p(st), L, ininumdict, g.value, self._p(keys), words)
+                if rc != -4:
+                    break
+                words += max(words, 8 * (int(ne.value) // 7 + 1024))
+            self._check(rc)
+            self.sync()
+            out.append((keys, g.value))
+            at += n
+        return out
+
+    def set_lookup_route(self, route: int):
+        """Test hook of the Stage-2 lookups over a share of the keys: 0 = default (a thread per owned task, k_realign_owned), 1 = several
+        (direction, dictionary) pairs per lane of the whole-index kernel."""
+        self.lib.mcom_set_lookup_route.restype = C.c_int; self.lib.mcom_set_lookup_route.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.lib.mcom_set_lookup_route(self._h, route))
+
     def dicts_eligible(self, dicts, sgbits, maxsearch: int):
         torch = _torch()
         el = torch.zeros(max(int(sgbits.shape[0]), 1), dtype=torch.int32, device=self.device)

@@ -300,6 +300,81 @@ def test_index_keeps_heavy_repeats_in_runs_of_their_own(ctx):
     dicts.close()
 
 
+@pytest.mark.parametrize("L,ranks,heavy", [(150, 2, False), (150, 3, False), (150, 8, False), (100, 8, True), (100, 5, True), (64, 16, False), (200, 8, False)])
+def test_lookups_over_shares_of_the_keys_min_reduced_equal_the_whole_index(ctx, L, ranks, heavy):
+    """Several GPUs share the ONE contig index out BY KEY (mcom_cindex_plan_shared; host/mcom_pipeline.cpp "Stage 2"): rank q places the
+    entries whose keys hash into share q and looks up, for every singleton, only the keys it owns; the claim keys are MIN-reduced
+    (kthread_hash_realign.c:316-508 takes the first dictionary / position that passes: a minimum).  Here all shares are built
+    on the one card: the minimum over the shares must be the whole index's claim of every singleton, pass by pass, for both kernels of
+    the shared lookups (include/mcom_test.h, mcom_set_lookup_route: a thread per owned task / pairs per lane), with pile-ups behind
+    mcom_dicts_eligible and with heavy repeats in the extension area; and the statistics of the shares add up to the whole index's."""
+    import torch
+    from minicom_amd.hip import pack_nt4, pack_contigs
+    rng = np.random.default_rng(L * 100 + ranks)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8); comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    refs = [acgt[rng.integers(0, 4, int(n))] for n in rng.integers(L, 6 * L, 300)]
+    if heavy:
+        seg = acgt[rng.integers(0, 4, 800)]
+        refs += [np.concatenate([acgt[rng.integers(0, 4, int(rng.integers(50, 300)))], seg, acgt[rng.integers(0, 4, int(rng.integers(50, 300)))]]) for _ in range(100)]
+        refs.append(np.full(600, ord("A"), dtype=np.uint8))
+    reads = []
+    for _ in range(21_000):                                                # (more than one workgroup's singletons, and not a multiple of a batch)
+        c = int(rng.integers(0, len(refs)))
+        if rng.random() < 0.2:
+            c %= 8                                                         # pile-ups: bins of more than maxsearch reads at the heads of eight contigs
+            j = int(rng.integers(0, 4))
+        else:
+            j = int(rng.integers(0, len(refs[c]) - L + 1))
+        r = refs[c][j:j + L].copy()
+        for q in rng.integers(0, L, int(rng.integers(0, 7))):
+            r[q] = acgt[rng.integers(0, 4)]
+        reads.append(comp[r][::-1] if rng.random() < 0.5 else r)
+    reads = np.stack(reads)[:20_987]
+    sgbits = torch.from_numpy(pack_nt4(reads).view(np.int64)).cuda()
+    flag = torch.from_numpy((rng.random(len(reads)) < 0.1).astype(np.uint8)).cuda()
+    cbits, coff, clen = pack_contigs([r.tobytes() for r in refs])
+    nwin = np.maximum(clen.astype(np.int64) - L + 1, 0)
+    woff = np.concatenate([[0], np.cumsum(nwin)]).astype(np.uint64)
+    d_cbits, d_coff, d_woff = (torch.from_numpy(a.view(np.int64)).cuda() for a in (cbits, coff, woff))
+    maxsearch = 40
+    dicts = ctx.dicts_build(sgbits, L)
+    elig = ctx.dicts_eligible(dicts, sgbits, maxsearch) if max(dicts.maxbin) > maxsearch else None
+    assert elig is not None
+    whole = ctx.cindex_build(d_cbits, d_coff, d_woff, int(nwin.sum()), L)
+    shares = ctx.cindex_build_shares(d_cbits, d_coff, d_woff, int(nwin.sum()), L, ranks)
+    assert len(shares) == ranks
+    if heavy:
+        assert sum(int(k[0]) for k, _ in shares) > 50                      # extension lines in use on the shares too
+    big = torch.iinfo(torch.int64).max
+    try:
+        for thr in (4, 12, 28):
+            want, st_want = ctx.realign_pass_reads(whole, sgbits, flag, d_cbits, d_coff, d_woff, L, thr, elig=elig, stats=True)
+            ctx.sync()
+            by_route = []
+            for route in (0, 1):
+                ctx.set_lookup_route(route)
+                low = torch.full_like(want, big)
+                sts = []
+                for index in shares:
+                    got, st = ctx.realign_pass_reads(index, sgbits, flag, d_cbits, d_coff, d_woff, L, thr, elig=elig, stats=True)
+                    ctx.sync()
+                    low = torch.minimum(low, torch.where(got < 0, torch.full_like(got, big), got))   # (UINT64_MAX = unclaimed)
+                    sts.append(st.tolist())
+                low = torch.where(low == big, torch.full_like(low, -1), low)
+                assert torch.equal(want, low), (thr, route, int((want != low).sum()))
+                # lookups and passing candidates add up to the whole index's (the verified ones in between count tag collisions, which are the
+                # layout's: equal between the two kernels over the same share, not between a share and the whole index)
+                tot = np.sum(np.array(sts, dtype=np.int64), axis=0)
+                assert (int(tot[0]), int(tot[2])) == (int(st_want[0]), int(st_want[2])), (thr, route, st_want.tolist(), tot.tolist())
+                by_route.append(sts)
+            assert by_route[0] == by_route[1], (thr, by_route)
+            assert int((want != -1).sum()) > 5000
+    finally:
+        ctx.set_lookup_route(0)
+    dicts.close()
+
+
 def test_realign_empty_inputs(ctx):
     import torch
     z64 = torch.zeros((0, 5), dtype=torch.int64, device="cuda")
