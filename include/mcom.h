@@ -170,6 +170,12 @@ int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
  * share of the words -- shares need not end where contigs do -- and the shares are all-gathered (round 5; before, every rank packed all). */
 int mcom_pack_contigs_words(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                             uint64_t total_words, uint64_t *d_cbits, uint64_t w_lo, uint64_t w_hi);
+/* The way back: the strings of n contigs (upper-case ACGT: what the consensus kernels write) from their packed words.  d_coff[c] = first
+ * word of contig c in d_cbits (n entries), d_off[c] = its first character in d_seq (n + 1 entries; d_seq 8-byte aligned); byte_lo / byte_hi
+ * = d_off[0] / d_off[n] on the host.  Bytes of d_seq outside [byte_lo, byte_hi) are not touched.  Several GPUs send a new contig once, as
+ * packed words, and every rank makes the strings it did not build itself (no counterpart in the reference, a shared-memory program). */
+int mcom_unpack_contigs(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_off, uint32_t n,
+                        uint64_t byte_lo, uint64_t byte_hi, uint8_t *d_seq);
 /* The same for the set after a merge round (cp_cluster, kthread_cb.c:397-434: the merged contigs first, then the untouched ones
  * in their order): contigs [0, n_first) are packed from their strings, contig n_first + u takes the packed words of contig
  * d_keepidx[u] of the set before the round (d_cbits_old / d_coff_old).  Same words as mcom_pack_contigs; d_cbits has room for

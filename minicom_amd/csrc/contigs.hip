@@ -565,6 +565,81 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 	return mcom_pack_contigs_words(ctx, d_seq, d_off, d_coff, n, total_words, d_cbits, 0, total_words);
 }
 
+// ------------------------------------------------------------------------------------------------
+// unpack: the strings of n contigs from their packed words -- the inverse of k_pack_contigs for strings of upper-case ACGT, which is
+// what every consensus kernel writes.  Several GPUs send a new contig ONCE, as packed words (a quarter of a byte per base instead of
+// the string AND the words: host/mcom_pipeline.cpp, "merged contigs"), and every rank makes the strings it did not build itself.
+// A block writes 2048 consecutive bytes of the concatenation, a thread one aligned 8-byte word of them; the offsets of the contigs
+// under the block's bytes are staged in LDS (a contig shorter than 16 characters may fall outside: its thread reads global memory).
+// Bytes outside [off[0], off[n]) are not touched.
+// ------------------------------------------------------------------------------------------------
+#define UP_T 256
+#define UP_NC 132
+__global__ __launch_bounds__(UP_T) void k_unpack_contigs(const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ off,
+                                                         uint32_t n, uint8_t *__restrict__ seq)
+{
+	__shared__ uint64_t OF[UP_NC], CO[UP_NC];
+	__shared__ uint32_t srch[16];
+	const uint64_t lo = off[0], hi = off[n];
+	const uint64_t b0 = (lo & ~7ull) + (uint64_t)blockIdx.x * (UP_T * 8);
+	if (b0 >= hi) return;                                                    // (the whole block: nobody is left at a barrier)
+	const uint64_t first = b0 > lo ? b0 : lo;
+	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return off[c] <= first; }, srch);
+	for (int t = threadIdx.x; t < UP_NC; t += UP_T) {
+		const uint64_t c = (uint64_t)c0 + t;
+		OF[t] = c <= n ? off[c] : ~0ull;
+		CO[t] = c < n ? coff[c] : 0;
+	}
+	__syncthreads();
+	const uint64_t gb = b0 + (uint64_t)threadIdx.x * 8;
+	if (gb >= hi || gb + 8 <= lo) return;
+	auto off_at = [&](uint64_t c) { return c - c0 < UP_NC ? OF[c - c0] : (c <= n ? off[c] : ~0ull); };
+	auto coff_at = [&](uint64_t c) { return c - c0 < UP_NC ? CO[c - c0] : (c < n ? coff[c] : 0ull); };
+	// the contig of this thread's first byte: the last staged one that starts at or before it, or a search through the rest
+	const uint64_t fb = gb > lo ? gb : lo;
+	uint64_t c;
+	if (OF[UP_NC - 1] <= fb) {
+		uint64_t a = (uint64_t)c0 + UP_NC - 1, b = n;                          // off[a] <= fb < off[b]
+		while (b - a > 1) { const uint64_t m = (a + b) >> 1; if (off[m] <= fb) a = m; else b = m; }
+		c = a;
+	} else {
+		int a = 0, b = UP_NC - 1;
+		while (b - a > 1) { const int m = (a + b) >> 1; if (OF[m] <= fb) a = m; else b = m; }
+		c = (uint64_t)c0 + a;
+	}
+	uint64_t cstart = off_at(c), cend = off_at(c + 1), cw = coff_at(c);
+	uint64_t word = 0, word_at = ~0ull, out = 0;
+	int b_lo = 8, b_hi = 0;                                                   // the bytes of this word that belong to the n contigs
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const uint64_t b = gb + i;
+		if (b < lo || b >= hi) continue;
+		while (b >= cend) { ++c; cstart = cend; cend = off_at(c + 1); cw = coff_at(c); }   // (contigs without characters are stepped over)
+		const uint64_t idx = b - cstart, wa = cw + (idx >> 5);
+		if (wa != word_at) { word = cbits[wa]; word_at = wa; }
+		const uint32_t code = (uint32_t)(word >> (2 * (idx & 31))) & 3u;
+		out |= (uint64_t)((0x54474341u >> (8 * code)) & 0xFFu) << (8 * i);     // A C G T
+		if (i < b_lo) b_lo = i;
+		b_hi = i + 1;
+	}
+	if (b_lo == 0 && b_hi == 8) *(uint64_t*)(seq + gb) = out;
+	else for (int i = b_lo; i < b_hi; ++i) seq[gb + i] = (uint8_t)(out >> (8 * i));
+}
+
+extern "C" int mcom_unpack_contigs(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_off, uint32_t n,
+                                   uint64_t byte_lo, uint64_t byte_hi, uint8_t *d_seq)
+{
+	if (!ctx) return MCOM_E_ARG;
+	if (n == 0 || byte_hi <= byte_lo) return MCOM_OK;
+	if (!d_cbits || !d_coff || !d_off || !d_seq) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
+	if (((uintptr_t)d_seq & 7) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at an 8-byte boundary");
+	const uint64_t blocks = (byte_hi - (byte_lo & ~7ull) + UP_T * 8 - 1) / (UP_T * 8);
+	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many characters");
+	MCOM_LAUNCH(k_unpack_contigs, dim3((unsigned)blocks), dim3(UP_T), 0, ctx->stream, d_cbits, d_coff, d_off, n, d_seq);
+	MCOM_LAUNCH_CHECK(ctx);
+	return MCOM_OK;
+}
+
 // A merge round changes the merged contigs only: they (the first n_first of the new set) are packed, the packed words of the
 // untouched ones (contig nj + u of the new set = contig keepidx[u] of the old one) are copied -- a quarter of a byte per base
 // instead of a byte.

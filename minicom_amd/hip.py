@@ -346,6 +346,12 @@ class Context:
         self._check(self.lib.mcom_pack_contigs(self._h, self._p(seq), self._p(d_off), self._p(d_coff), len(refs), total, self._p(cbits)))
         return {"seq": seq, "off": d_off, "coff": d_coff, "clen": d_clen, "cbits": cbits, "n": len(refs), "lens": lens}
 
+    def unpack_contigs(self, cbits, coff, off, n: int, byte_lo: int, byte_hi: int, seq):
+        """mcom_unpack_contigs: the strings of n contigs from their packed words, into seq (uint8, 8-byte aligned) at off[c]."""
+        self.lib.mcom_unpack_contigs.restype = C.c_int
+        self.lib.mcom_unpack_contigs.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+        self._check(self.lib.mcom_unpack_contigs(self._h, self._p(cbits), self._p(coff), self._p(off), n, byte_lo, byte_hi, self._p(seq)))
+
     def sketch_contigs(self, seq, off, n: int, w: int, k: int, max_per_contig: int = 0, ids=None):
         """mcom_sketch_contigs.  Returns (moff int32 [n+1], records int64 [total,2])."""
         torch = _torch()

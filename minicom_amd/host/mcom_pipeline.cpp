@@ -1277,7 +1277,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 	// unmerged contigs (kthread_cb.c:397-434) are gone: a round appends what it merged and makes the next list (include/mcom.h,
 	// "Merge rounds without cp_cluster's copies"); when the rounds are over the list is gathered into an ordinary set, once.
 	DevSet S, Tm;                                                            // Tm: a rank's share of a round's merged contigs (multi-GPU)
-	DevBuf<uint32_t> ord, ord2, moff_m, d_jobs, roff_t, d_ids; DevBuf<uint64_t> jmoff_t, jroff_t, cw_t;
+	DevBuf<uint32_t> ord, ord2, moff_m, d_jobs, roff_t, d_ids, clen_l; DevBuf<uint64_t> jmoff_t, jroff_t, cw_t, cw_l, bits_l;
 	DevBuf<mcom_mm128> rec_m, d_pairs, d_pairs_loc; DevBuf<uint8_t> d_flag;
 	PinVec<mcom_mm128> pairs; PinVec<uint8_t> flag;
 	struct Job { uint32_t ci, cj, pos_ori, pos; };
@@ -1452,6 +1452,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);
 			uint64_t tot[3] = {0, 0, 0};
 			uint64_t tn = 0;                                                             // minimizer records of the merged contigs
+			uint64_t words_gathered = 0; bool words_in_place = false;                    // (several GPUs: the round's packed words arrive with the gather)
 			const bool rs = p->resketch && (p->k & 1);
 			if (!p->comm) {
 				for (int attempt = 0;; ++attempt) {
@@ -1505,7 +1506,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				const int R = p->world, me = p->rank;
 				const size_t j0 = nj * (size_t)me / R, j1 = nj * (size_t)(me + 1) / R, njl = j1 - j0;
 				DevSet &T = Tm;
-				uint64_t tl3[3] = {0, 0, 0}, tnl = 0, sk = 0;
+				uint64_t tl3[3] = {0, 0, 0}, tnl = 0, sk = 0, twl = 0;
 				if (njl) {
 					if (!T.mem.reserve(members0 + 1) || !T.moff.reserve(njl + 2) || !T.soff.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
 					if ((rc = p->gpu(mcom_merge_members(p->ctx, S.mem.p, S.moff.p, d_jobs.p + 4 * j0, njl, L, kb, T.mem.p, T.moff.p, T.soff.p, tl3)))) return rc;
@@ -1536,16 +1537,27 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 						sk = tl3[1];
 					}
 					p->stat["sketch_bases"] += (double)sk; p->stat["sketch_records"] += (double)tnl;
+					// The strings of the share do not travel: their PACKED WORDS do (a quarter of a byte per base -- and the packed form is
+					// needed on every rank anyway, so the strings went on top of it: 2.4 of 11.5 GB per rank and step at 64 M reads over eight
+					// ranks), and every rank unpacks the strings the others built (mcom_unpack_contigs, below).  A contig owns whole words, so the
+					// layouts of the shares, one behind the other, are the layout of the round's contigs.
+					if (!cw_l.reserve(njl + 2) || !clen_l.reserve(njl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_contig_layout(p->ctx, T.soff.p, njl, cw_l.p, clen_l.p, &twl)))) return rc;
+					if (!bits_l.reserve(twl + 2)) return p->fail(MCOM_E_NOMEM, "merge buffers");
+					if ((rc = p->gpu(mcom_pack_contigs(p->ctx, T.seq.p, T.soff.p, cw_l.p, (uint32_t)njl, twl, bits_l.p)))) return rc;
 				}
 				lap("t_merge_local");
-				const uint64_t mine[4] = {tl3[0], tl3[1], tl3[2], tnl};
-				std::vector<uint64_t> all, fj(R), cj(R), fm(R), cm(R), fc(R), cc(R), fr(R), cr(R);
-				if ((rc = gather_host(p, mine, 4, all))) return rc;
+				const uint64_t mine[5] = {tl3[0], tl3[1], tl3[2], tnl, twl};
+				std::vector<uint64_t> all, fj(R), cj(R), fm(R), cm(R), fc(R), cc(R), fr(R), cr(R), fw(R), cwq(R);
+				if ((rc = gather_host(p, mine, 5, all))) return rc;
 				for (int q = 0; q < R; ++q) {
 					fj[q] = n_store + nj * (size_t)q / R; cj[q] = nj * (size_t)(q + 1) / R - nj * (size_t)q / R;
-					fm[q] = S.members + tot[0]; cm[q] = all[4 * q]; tot[0] += cm[q]; fc[q] = S.chars + tot[1]; cc[q] = all[4 * q + 1]; tot[1] += cc[q];
-					tot[2] = std::max(tot[2], all[4 * q + 2]); fr[q] = S.nrec + tn; cr[q] = all[4 * q + 3]; tn += cr[q];
+					fm[q] = S.members + tot[0]; cm[q] = all[5 * q]; tot[0] += cm[q]; fc[q] = S.chars + tot[1]; cc[q] = all[5 * q + 1]; tot[1] += cc[q];
+					tot[2] = std::max(tot[2], all[5 * q + 2]); fr[q] = S.nrec + tn; cr[q] = all[5 * q + 3]; tn += cr[q];
+					fw[q] = p->total_words + words_gathered; cwq[q] = all[5 * q + 4]; words_gathered += cwq[q];
 				}
+				if (p->d_cbits.cap < p->total_words + words_gathered + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + words_gathered + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
+				words_in_place = true;
 				maxlen = std::max(maxlen, tot[2]);
 				if (S.nrec + tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records in the store");
 				// offsets of the share move to their places in the store, then everything travels
@@ -1555,7 +1567,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 					return p->fail(MCOM_E_NOMEM, "contig store");
 				const double tx = now_ms(), bx0 = xbytes(p);
 				const uint64_t em = S.members + tot[0], ec = S.chars + tot[1]; const uint32_t er = (uint32_t)(S.nrec + tn);
-				if ((rc = gatherv(p, S.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, S.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, S.seq.p, fc, cc, T.seq.p, false)) || (rc = gatherv(p, S.soff.p, fj, cj, T.soff.p, false)) ||
+				if ((rc = gatherv(p, S.mem.p, fm, cm, T.mem.p)) || (rc = gatherv(p, S.moff.p, fj, cj, T.moff.p, false)) || (rc = gatherv(p, p->d_cbits.p, fw, cwq, bits_l.p, false)) || (rc = gatherv(p, S.soff.p, fj, cj, T.soff.p, false)) ||
 				    (rc = gatherv(p, S.rec.p, fr, cr, T.rec.p, false)) || (rc = gatherv(p, S.roff.p, fj, cj, T.roff.p, false))) return rc;
 				if ((rc = p->h2d(S.moff.p + n_store + nj, &em, 1, "upload")) || (rc = p->h2d(S.soff.p + n_store + nj, &ec, 1, "upload")) || (rc = p->h2d(S.roff.p + n_store + nj, &er, 1, "upload"))) return rc;
 				if ((rc = p->sync("merged contigs"))) return rc;                             // (em / ec / er live on this stack frame)
@@ -1566,8 +1578,11 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			{
 				uint64_t tw2 = 0;
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p + n_store, nj, cw_t.p, p->d_clen.p + n_store, &tw2)))) return rc;
+				if (words_in_place && tw2 != words_gathered) return p->fail(MCOM_E_ARG, "merged contigs: %llu packed words gathered, the layout has %llu", (unsigned long long)words_gathered, (unsigned long long)tw2);
 				if (p->d_cbits.cap < p->total_words + tw2 + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + tw2 + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
-				if ((rc = pack_words(S.soff.p + n_store, cw_t.p, nj, tw2, p->d_cbits.p + p->total_words)) ||
+				// (several GPUs: the words are there -- they are what travelled -- and the strings are made from them)
+				if ((rc = words_in_place ? p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->total_words, cw_t.p, S.soff.p + n_store, (uint32_t)nj, S.chars, S.chars + tot[1], S.seq.p))
+				                         : pack_words(S.soff.p + n_store, cw_t.p, nj, tw2, p->d_cbits.p + p->total_words)) ||
 				    (rc = p->hipc(hipMemsetAsync(p->d_cbits.p + p->total_words + tw2, 0, 16, p->stream), "clear")) ||
 				    (rc = p->gpu(mcom_offsets_append(p->ctx, cw_t.p, nj, p->total_words, p->d_coff_words.p + n_store)))) return rc;
 				p->total_words += tw2;

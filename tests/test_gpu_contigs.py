@@ -84,6 +84,53 @@ def test_pack_contigs_layout(ctx):
     assert np.array_equal(cg["cbits"].cpu().numpy().view(np.uint64)[: len(cbits)], cbits)
 
 
+@pytest.mark.parametrize("lens_kind,first,start", [("reads", 0, 0), ("reads", 700, 13), ("tiny", 3, 5), ("mixed", 1000, 4099), ("long", 2, 1)])
+def test_unpack_contigs_is_the_inverse_of_pack_contigs(ctx, lens_kind, first, start):
+    """mcom_unpack_contigs (several GPUs send a new contig once, as packed words, and every rank makes the strings it did not build): the
+    strings of contigs [first, n) of a set come back from the packed words of mcom_pack_contigs byte for byte, into a buffer whose other
+    bytes are left alone -- contigs of a read's length and more, of a few characters (more of them under one block than its staged
+    offsets hold), some of no characters at all, and of tens of thousands of characters; strings that start at any byte."""
+    import torch
+    rng = np.random.default_rng(len(lens_kind) * 1000 + first)
+    if lens_kind == "reads": lens = rng.integers(100, 900, 3000)
+    elif lens_kind == "tiny": lens = rng.integers(0, 9, 5000)
+    elif lens_kind == "mixed": lens = np.concatenate([rng.integers(0, 12, 1500), rng.integers(150, 3000, 400), rng.integers(1, 5, 900)])
+    else: lens = np.array([70_000, 3, 0, 41_234, 150, 20_001])
+    if lens_kind == "mixed": rng.shuffle(lens)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    refs = [acgt[rng.integers(0, 4, int(n))].tobytes() for n in lens]
+    n = len(refs)
+    # the packed words, restated here (include/mcom.h, mcom_pack_contigs: base i of a contig in bits 2 i of its words, A C G T = 0 1 2 3,
+    # one padding word behind every contig) -- mcom_pack_contigs itself wants contigs of at least one character
+    code = np.zeros(256, dtype=np.uint64); code[[65, 67, 71, 84]] = [0, 1, 2, 3]
+    words = (2 * np.asarray(lens, dtype=np.int64) + 63) // 64 + 1
+    coff_h = np.concatenate([[0], np.cumsum(words)])
+    cb = np.zeros(int(coff_h[-1]) + 1, dtype=np.uint64)
+    for c, r in enumerate(refs):
+        v = code[np.frombuffer(r, dtype=np.uint8)]
+        for w in range(0, len(v), 32):
+            part = v[w:w + 32]
+            cb[coff_h[c] + w // 32] = np.bitwise_or.reduce(part << (2 * np.arange(len(part), dtype=np.uint64))) if len(part) else 0
+    if min(lens) > 0:
+        up = ctx.upload_contigs(refs)
+        assert np.array_equal(up["cbits"].cpu().numpy().view(np.uint64)[:int(coff_h[-1])], cb[:-1])
+    lens_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    set_ = {"off": torch.from_numpy(lens_off).cuda(), "coff": torch.from_numpy(coff_h[:-1].astype(np.int64)).cuda(), "cbits": torch.from_numpy(cb.view(np.int64)).cuda()}
+    # the strings of contigs [first, n) go to out[start + (their offsets - the first one's)]; everything else keeps its 0xEE
+    off = set_["off"].cpu().numpy()
+    rel = off[first:] - off[first] + start
+    total = int(rel[-1])
+    out = torch.full((total + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    d_rel = torch.from_numpy(rel.astype(np.int64)).cuda()
+    coff = set_["coff"][first:].contiguous()
+    ctx.unpack_contigs(set_["cbits"], coff, d_rel, n - first, start, total, out)
+    ctx.sync()
+    got = out.cpu().numpy()
+    want = np.full(total + 64, 0xEE, dtype=np.uint8)
+    want[start:total] = np.frombuffer(b"".join(refs[first:]), dtype=np.uint8)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 def test_match_pro_equals_reference_vectors(ctx, kat):
     import torch
     refs, a, pa, b, pb, want = [], [], [], [], [], []
