@@ -171,7 +171,7 @@ int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off
 int mcom_pack_contigs_words(mcom_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_off, const uint64_t *d_coff, uint32_t n,
                             uint64_t total_words, uint64_t *d_cbits, uint64_t w_lo, uint64_t w_hi);
 /* The way back: the strings of n contigs (upper-case ACGT: what the consensus kernels write) from their packed words.  d_coff[c] = first
- * word of contig c in d_cbits (n entries), d_off[c] = its first character in d_seq (n + 1 entries; d_seq 8-byte aligned); byte_lo / byte_hi
+ * word of contig c in d_cbits (n entries), d_off[c] = its first character in d_seq (n + 1 entries; d_seq 16-byte aligned); byte_lo / byte_hi
  * = d_off[0] / d_off[n] on the host.  Bytes of d_seq outside [byte_lo, byte_hi) are not touched.  Several GPUs send a new contig once, as
  * packed words, and every rank makes the strings it did not build itself (no counterpart in the reference, a shared-memory program). */
 int mcom_unpack_contigs(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_off, uint32_t n,

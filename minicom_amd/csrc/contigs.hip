@@ -569,61 +569,50 @@ extern "C" int mcom_pack_contigs(mcom_ctx *ctx, const uint8_t *d_seq, const uint
 // unpack: the strings of n contigs from their packed words -- the inverse of k_pack_contigs for strings of upper-case ACGT, which is
 // what every consensus kernel writes.  Several GPUs send a new contig ONCE, as packed words (a quarter of a byte per base instead of
 // the string AND the words: host/mcom_pipeline.cpp, "merged contigs"), and every rank makes the strings it did not build itself.
-// A block writes 2048 consecutive bytes of the concatenation, a thread one aligned 8-byte word of them; the offsets of the contigs
-// under the block's bytes are staged in LDS (a contig shorter than 16 characters may fall outside: its thread reads global memory).
-// Bytes outside [off[0], off[n]) are not touched.
+// Sixteen lanes per contig, a lane writes aligned 16-byte pieces of the concatenation (one store; the sixteen lanes 256 bytes in a row):
+// no search for "whose byte is this" -- a first form, one block per 4 KB of the concatenation with a block-wide search through the offsets
+// in front, took 22 - 35 ms over the eight ranks of a 64 M-read job whatever its block size, and this form with the end pieces read and written
+// byte by byte 28; 15 as it stands (1.9 ms per rank for 2.5 GB of strings).  The piece at either end of a contig, shared with its neighbour, is
+// made in registers like any other and stored byte by byte, each contig its own bytes.  Bytes outside [off[0], off[n]) are not touched.
 // ------------------------------------------------------------------------------------------------
-#define UP_T 256
-#define UP_NC 132
-__global__ __launch_bounds__(UP_T) void k_unpack_contigs(const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ off,
-                                                         uint32_t n, uint8_t *__restrict__ seq)
+// eight 2-bit codes (the low 16 bits of x) as eight characters, code i in byte i
+__device__ __forceinline__ uint64_t up_chars8(uint64_t x)
 {
-	__shared__ uint64_t OF[UP_NC], CO[UP_NC];
-	__shared__ uint32_t srch[16];
-	const uint64_t lo = off[0], hi = off[n];
-	const uint64_t b0 = (lo & ~7ull) + (uint64_t)blockIdx.x * (UP_T * 8);
-	if (b0 >= hi) return;                                                    // (the whole block: nobody is left at a barrier)
-	const uint64_t first = b0 > lo ? b0 : lo;
-	const uint32_t c0 = mcom_block_search(n, [&](uint32_t c) { return off[c] <= first; }, srch);
-	for (int t = threadIdx.x; t < UP_NC; t += UP_T) {
-		const uint64_t c = (uint64_t)c0 + t;
-		OF[t] = c <= n ? off[c] : ~0ull;
-		CO[t] = c < n ? coff[c] : 0;
-	}
-	__syncthreads();
-	const uint64_t gb = b0 + (uint64_t)threadIdx.x * 8;
-	if (gb >= hi || gb + 8 <= lo) return;
-	auto off_at = [&](uint64_t c) { return c - c0 < UP_NC ? OF[c - c0] : (c <= n ? off[c] : ~0ull); };
-	auto coff_at = [&](uint64_t c) { return c - c0 < UP_NC ? CO[c - c0] : (c < n ? coff[c] : 0ull); };
-	// the contig of this thread's first byte: the last staged one that starts at or before it, or a search through the rest
-	const uint64_t fb = gb > lo ? gb : lo;
-	uint64_t c;
-	if (OF[UP_NC - 1] <= fb) {
-		uint64_t a = (uint64_t)c0 + UP_NC - 1, b = n;                          // off[a] <= fb < off[b]
-		while (b - a > 1) { const uint64_t m = (a + b) >> 1; if (off[m] <= fb) a = m; else b = m; }
-		c = a;
-	} else {
-		int a = 0, b = UP_NC - 1;
-		while (b - a > 1) { const int m = (a + b) >> 1; if (OF[m] <= fb) a = m; else b = m; }
-		c = (uint64_t)c0 + a;
-	}
-	uint64_t cstart = off_at(c), cend = off_at(c + 1), cw = coff_at(c);
-	uint64_t word = 0, word_at = ~0ull, out = 0;
-	int b_lo = 8, b_hi = 0;                                                   // the bytes of this word that belong to the n contigs
+	uint64_t v = x & 0xFFFFull;
+	v = (v | (v << 24)) & 0x000000FF000000FFull;
+	v = (v | (v << 12)) & 0x000F000F000F000Full;
+	v = (v | (v << 6)) & 0x0303030303030303ull;
+	const uint64_t b0 = v & 0x0101010101010101ull, b1 = (v >> 1) & 0x0101010101010101ull, bb = b0 & b1;
+	// A 0x41, C 0x43 (+2), G 0x47 (+6), T 0x54 (+2 +6 +11): no byte carries into its neighbour
+	return 0x4141414141414141ull + (b0 << 1) + (b1 << 1) + (b1 << 2) + bb + (bb << 1) + (bb << 3);
+}
+__global__ __launch_bounds__(256) void k_unpack_contigs(const uint64_t *__restrict__ cbits, const uint64_t *__restrict__ coff, const uint64_t *__restrict__ off,
+                                                        uint32_t n, uint8_t *__restrict__ seq)
+{
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t c = t >> 4;
+	if (c >= n) return;
+	const uint64_t s = off[c], e = off[c + 1];
+	const uint64_t *w = cbits + coff[c];
+	for (uint64_t gb = (s & ~15ull) + 16 * (t & 15); gb < e; gb += 256) {
+		// the sixteen characters of this piece in two registers, whether the contig covers all of it or not: the piece at a contig's head
+		// starts d bytes in front of the contig (its codes moved up to their bytes' places), the one at its tail reads into the padding word
+		uint64_t codes;
+		if (gb >= s) {
+			const uint64_t idx = gb - s;
+			const int sh = (int)(idx & 31) * 2;
+			const uint64_t w0 = w[idx >> 5];
+			codes = sh > 32 ? (w0 >> sh) | (w[(idx >> 5) + 1] << (64 - sh)) : w0 >> sh;
+		} else codes = w[0] << (2 * (int)(s - gb));
+		const uint64_t c_lo = up_chars8(codes), c_hi = up_chars8(codes >> 16);
+		if (gb >= s && gb + 16 <= e) *(ulonglong2*)(seq + gb) = make_ulonglong2(c_lo, c_hi);
+		else {
+			const int i_lo = gb >= s ? 0 : (int)(s - gb), i_hi = gb + 16 <= e ? 16 : (int)(e - gb);
 #pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		const uint64_t b = gb + i;
-		if (b < lo || b >= hi) continue;
-		while (b >= cend) { ++c; cstart = cend; cend = off_at(c + 1); cw = coff_at(c); }   // (contigs without characters are stepped over)
-		const uint64_t idx = b - cstart, wa = cw + (idx >> 5);
-		if (wa != word_at) { word = cbits[wa]; word_at = wa; }
-		const uint32_t code = (uint32_t)(word >> (2 * (idx & 31))) & 3u;
-		out |= (uint64_t)((0x54474341u >> (8 * code)) & 0xFFu) << (8 * i);     // A C G T
-		if (i < b_lo) b_lo = i;
-		b_hi = i + 1;
+			for (int i = 0; i < 16; ++i)
+				if (i >= i_lo && i < i_hi) seq[gb + i] = (uint8_t)((i < 8 ? c_lo : c_hi) >> (8 * (i & 7)));
+		}
 	}
-	if (b_lo == 0 && b_hi == 8) *(uint64_t*)(seq + gb) = out;
-	else for (int i = b_lo; i < b_hi; ++i) seq[gb + i] = (uint8_t)(out >> (8 * i));
 }
 
 extern "C" int mcom_unpack_contigs(mcom_ctx *ctx, const uint64_t *d_cbits, const uint64_t *d_coff, const uint64_t *d_off, uint32_t n,
@@ -632,10 +621,9 @@ extern "C" int mcom_unpack_contigs(mcom_ctx *ctx, const uint64_t *d_cbits, const
 	if (!ctx) return MCOM_E_ARG;
 	if (n == 0 || byte_hi <= byte_lo) return MCOM_OK;
 	if (!d_cbits || !d_coff || !d_off || !d_seq) return mcom_fail(ctx, MCOM_E_ARG, "null device pointer");
-	if (((uintptr_t)d_seq & 7) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at an 8-byte boundary");
-	const uint64_t blocks = (byte_hi - (byte_lo & ~7ull) + UP_T * 8 - 1) / (UP_T * 8);
-	if (blocks >= (1ull << 31)) return mcom_fail(ctx, MCOM_E_ARG, "too many characters");
-	MCOM_LAUNCH(k_unpack_contigs, dim3((unsigned)blocks), dim3(UP_T), 0, ctx->stream, d_cbits, d_coff, d_off, n, d_seq);
+	if (((uintptr_t)d_seq & 15) != 0) return mcom_fail(ctx, MCOM_E_ARG, "contig strings must start at a 16-byte boundary");
+	const uint64_t blocks = ((uint64_t)n * 16 + 255) / 256;
+	MCOM_LAUNCH(k_unpack_contigs, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_cbits, d_coff, d_off, n, d_seq);
 	MCOM_LAUNCH_CHECK(ctx);
 	return MCOM_OK;
 }

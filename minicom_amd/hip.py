@@ -347,7 +347,7 @@ class Context:
         return {"seq": seq, "off": d_off, "coff": d_coff, "clen": d_clen, "cbits": cbits, "n": len(refs), "lens": lens}
 
     def unpack_contigs(self, cbits, coff, off, n: int, byte_lo: int, byte_hi: int, seq):
-        """mcom_unpack_contigs: the strings of n contigs from their packed words, into seq (uint8, 8-byte aligned) at off[c]."""
+        """mcom_unpack_contigs: the strings of n contigs from their packed words, into seq (uint8, 16-byte aligned) at off[c]."""
         self.lib.mcom_unpack_contigs.restype = C.c_int
         self.lib.mcom_unpack_contigs.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         self._check(self.lib.mcom_unpack_contigs(self._h, self._p(cbits), self._p(coff), self._p(off), n, byte_lo, byte_hi, self._p(seq)))

@@ -292,6 +292,8 @@ struct mcomh_pipeline {
 	// the second set of buffers, and whether d_cbits / d_coff_words / d_clen describe the set in dC
 	DevBuf<uint64_t> d_coff_words_alt, d_cbits_alt; DevBuf<uint32_t> d_clen_alt;
 	bool cbits_for_dC = false;
+	// several GPUs: the bucket stage's contigs travel as packed words, straight into d_cbits (kt_for_bucket); combine_cluster finds them there
+	bool prepacked = false; uint64_t prepacked_words = 0;
 	std::vector<uint64_t> h_coff_words;
 	uint64_t total_words = 0, n_windows = 0;
 	DevBuf<uint64_t> d_cix_keys; uint64_t cix_geom = 0;    // klen-mer index of the Stage-2 contigs (mcom_cindex_build): this rank's share
@@ -886,6 +888,8 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 	p->C.clear();
 	p->dC.n = 0; p->dC.chars = 0; p->dC.members = 0; p->dC.nrec = 0;
 	p->dC_valid = true; p->hostC_valid = false; p->host_off_valid = false; p->cbits_for_dC = false;
+	p->prepacked = p->comm != nullptr; p->prepacked_words = 0;
+	DevBuf<uint64_t> cw_l, bits_l, cw_all; DevBuf<uint32_t> clen_l, clen_all;
 	DevSet &D = p->dC;
 	int rc;
 	if (dist) {                                              // offset entry 0 of the replicated set: nobody's contig writes it
@@ -986,9 +990,34 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 				                                        D.seq.p, D.seq.cap, D.soff.p, D.mem.p, D.mem.cap, D.moff.p, std::min(D.soff.cap, D.moff.cap), d_rej.p, d_rejg.p, d_rej.cap, gc2)))) return rc;
 				if (gc2[0] != gc[0] || gc2[1] != gc[1] || gc2[2] != gc[2] || gc2[3] != gc[3]) return p->fail(MCOM_E_ARG, "contig counts changed between the two calls");
 			}
+			// The strings do not travel: the PACKED WORDS of this rank's new contigs do (a quarter of a byte per base), straight to their place in
+			// d_cbits -- a contig owns whole words, so the rounds' shares one behind the other are the layout combine_cluster makes of the set --
+			// and every rank unpacks the strings the others built (mcom_unpack_contigs).
+			uint64_t twl = 0;
+			if (cn[me]) {
+				const uint64_t start = fc[me];
+				if ((rc = p->h2d(D.soff.p + fn[me] - 1, &start, 1, "upload"))) return rc;   // (the end of the rank below: it arrives with the gather, the layout needs it now; mcom_contig_layout waits for the stream)
+				if (!cw_l.reserve(cn[me] + 2) || !clen_l.reserve(cn[me] + 2)) return p->fail(MCOM_E_NOMEM, "contig set");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, D.soff.p + fn[me] - 1, cn[me], cw_l.p, clen_l.p, &twl)))) return rc;
+				if (!bits_l.reserve(twl + 2)) return p->fail(MCOM_E_NOMEM, "contig set");
+				if ((rc = p->gpu(mcom_pack_contigs(p->ctx, D.seq.p, D.soff.p + fn[me] - 1, cw_l.p, (uint32_t)cn[me], twl, bits_l.p)))) return rc;
+			}
+			std::vector<uint64_t> allw, fw(R), cwq(R);
+			if ((rc = gather_host(p, &twl, 1, allw))) return rc;
+			uint64_t tw_all = 0;
+			for (int q = 0; q < R; ++q) { fw[q] = p->prepacked_words + tw_all; cwq[q] = allw[q]; tw_all += cwq[q]; }
+			if (!p->d_cbits.grow((size_t)(p->prepacked_words + tw_all + 2), (size_t)p->prepacked_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed contigs");
 			const double tx = now_ms(), bx0 = xbytes(p);
-			if ((rc = gatherv(p, D.seq.p, fc, cc)) || (rc = gatherv(p, D.soff.p, fn, cn, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.mem.p, fm, cm, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.moff.p, fn, cn, (const uint64_t*)nullptr, false))) return rc;
+			if ((rc = gatherv(p, p->d_cbits.p, fw, cwq, (const uint64_t*)bits_l.p)) || (rc = gatherv(p, D.soff.p, fn, cn, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.mem.p, fm, cm, (const uint64_t*)nullptr, false)) || (rc = gatherv(p, D.moff.p, fn, cn, (const uint64_t*)nullptr, false))) return rc;
 			p->stat["t_x_contigs"] += now_ms() - tx; p->stat["b_x_contigs"] += xbytes(p) - bx0;
+			if (tn) {
+				uint64_t tw2 = 0;
+				if (!cw_all.reserve(tn + 2) || !clen_all.reserve(tn + 2)) return p->fail(MCOM_E_NOMEM, "contig set");
+				if ((rc = p->gpu(mcom_contig_layout(p->ctx, D.soff.p + D.n, tn, cw_all.p, clen_all.p, &tw2)))) return rc;
+				if (tw2 != tw_all) return p->fail(MCOM_E_ARG, "new contigs: %llu packed words gathered, the layout has %llu", (unsigned long long)tw_all, (unsigned long long)tw2);
+				if ((rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->prepacked_words, cw_all.p, D.soff.p + D.n, (uint32_t)tn, D.chars, D.chars + tc, D.seq.p)))) return rc;
+				p->prepacked_words += tw_all;
+			}
 			D.n += tn; D.chars += tc; D.members += tm;
 			nrej = gc[3];
 		}
@@ -1345,9 +1374,16 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				if (!p->d_coff_words.reserve(std::max(n_store + 1, S.soff.cap)) || !p->d_clen.reserve(std::max(n_store + 1, S.soff.cap))) return p->fail(MCOM_E_NOMEM, "contig layout");   // (with the room the store's offset arrays have)
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, S.soff.p, n_store, p->d_coff_words.p, p->d_clen.p, &tw)))) return rc;
 				p->total_words = tw;
-				if (!p->d_cbits.reserve(tw * 24 / 10 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
-				if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
-				if ((rc = pack_words(S.soff.p, p->d_coff_words.p, n_store, tw, p->d_cbits.p))) return rc;
+				if (p->comm && p->prepacked && p->prepacked_words == tw && p->d_cbits.cap >= tw + 2) {
+					// several GPUs: the bucket stage's contigs travelled as packed words and are in their places (kt_for_bucket)
+					if (!p->d_cbits.grow((size_t)(tw * 24 / 10 + 2), (size_t)tw, p->stream)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+					if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p + tw, 0, 16, p->stream), "clear"))) return rc;
+				} else {
+					if (!p->d_cbits.reserve(tw * 24 / 10 + 2)) return p->fail(MCOM_E_NOMEM, "packed contigs");
+					if ((rc = p->hipc(hipMemsetAsync(p->d_cbits.p, 0, (tw + 2) * 8, p->stream), "clear"))) return rc;
+					if ((rc = pack_words(S.soff.p, p->d_coff_words.p, n_store, tw, p->d_cbits.p))) return rc;
+				}
+				p->prepacked = false;
 				packed_ready = true;
 			}
 			// the first m minimizers are what the contig builders pushed into mi[index] (kthread_bucket.c:463, :370-380, :423-432)
