@@ -230,7 +230,17 @@ def main():
         box = [Comm.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
-        comm = Comm.rccl(rank, world, box[0], local_rank)
+        # RCCL announces itself on STDOUT when its first communicator is made (version, host, library path): this process's stdout is
+        # the ONE JSON line, so file descriptor 1 points at stderr while that happens
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = Comm.rccl(rank, world, box[0], local_rank)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     L = a.read_len
     threads = a.host_threads or max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
     ctx = minicom_amd.Context(local_rank)
