@@ -224,8 +224,9 @@ extern "C" void mcomh_device_free(void *d_ptr) { if (d_ptr) (void)hipFree(d_ptr)
 // sum of the counts before it -- copies its sequence lines into two page-locked blocks of its own that alternate between the
 // thread and the copy engine (pass 2), straight to the rows' place in HBM.  A record boundary inside a piece is found by its
 // shape: a line that starts with '@', followed by a line of L bases, a line that starts with '+' and a line of L characters (a
-// quality line may start with '@' too, but then the line two further on is a sequence, not a '+' line).  Anything else --
-// gzip, FASTA, sequences over several lines, carriage returns, a read of another length -- is left to the sequential reader
+// quality line may start with '@' too, but then the line two further on is a sequence, not a '+' line).  The one-pass form below also
+// takes FASTA, with sequences over one or more lines (fasta_record_at).  Anything else -- gzip of one member, FASTQ with sequences over
+// several lines, carriage returns, a read of another length -- is left to the sequential reader
 // above, which also words the error messages.  Returns 1 = done, 0 = not this layout (nothing touched), < 0 = error.
 namespace {
 struct Piece { size_t begin = 0, end = 0, records = 0, first_row = 0; bool ok = true; };
@@ -242,6 +243,30 @@ inline const char *record_at(const char *p, const char *e, int L)
 	if (q + L > e) return nullptr;
 	if (q + L == e) return e;                                                  // the last line of the file may lack its newline
 	return q[L] == '\n' ? q + L + 1 : nullptr;
+}
+// FASTA (round 5): a record of the expected shape at p -- a line that starts with '>', then the sequence over ONE OR MORE lines, L characters in
+// all, up to a line that starts with '>' or the end of the file (kseq.h reads a sequence line by line until a line starts with '>', '+' or '@';
+// a '+' or '@' line, a blank line or a sequence of another length is "not this shape": the sequential reader takes the file and words the
+// message).  Returns the record's end, or nullptr; *more = the text ends before the record's end can be seen and it is not the file's end.
+inline const char *fasta_record_at(const char *p, const char *e, int L, bool at_eof, bool *more)
+{
+	*more = false;
+	if (p >= e || *p != '>') return nullptr;
+	const char *s = (const char*)memchr(p, '\n', (size_t)(e - p));
+	if (!s) { *more = !at_eof; return nullptr; }
+	++s;
+	int got = 0;
+	for (;;) {
+		if (s >= e) { if (!at_eof) { *more = true; return nullptr; } return got == L ? e : nullptr; }
+		if (*s == '>') return got == L ? s : nullptr;
+		if (*s == '+' || *s == '@' || *s == '\n') return nullptr;
+		const char *nl = (const char*)memchr(s, '\n', (size_t)(e - s));
+		const size_t ll = (size_t)((nl ? nl : e) - s);
+		if (got + ll > (size_t)L) return nullptr;
+		got += (int)ll;
+		if (!nl) { if (!at_eof) { *more = true; return nullptr; } return got == L ? e : nullptr; }
+		s = nl + 1;
+	}
 }
 }
 // ---- pass 1: the file mapped and cut into pieces at record boundaries, every piece validated and counted ---------------------
@@ -474,7 +499,26 @@ size_t mcom_fastq_stream_cap(const char *path, int *L)
 	size_t cap = 0;
 	if (fstat(fd, &stt) == 0 && S_ISREG(stt.st_mode) && stt.st_size >= 64) {
 		const ssize_t got = pread(fd, head, sizeof head, 0);
-		if (got > 8 && head[0] == '@' && !((unsigned char)head[0] == 0x1f && (unsigned char)head[1] == 0x8b)) {
+		if (got > 8 && head[0] == '>') {
+			// FASTA: the first record's sequence lines up to the next '>' line (or the end of a file this short) give the read length
+			const char *e = head + got;
+			const bool whole = (size_t)got == (size_t)stt.st_size;
+			const char *s0 = next_line(head, e);
+			int len = 0; bool closed = false;
+			for (const char *c = s0; c < e; ) {
+				if (*c == '>') { closed = true; break; }
+				const char *nl = (const char*)memchr(c, '\n', (size_t)(e - c));
+				if (!nl) { if (whole) len += (int)(e - c); else len = -1000000; break; }
+				len += (int)(nl - c); c = nl + 1;
+				if (c >= e && whole) closed = true;
+			}
+			if (whole) closed = true;
+			bool more = false;
+			if (closed && len >= 1 && len <= 256 && (!*L || *L == len) && fasta_record_at(head, e, len, whole, &more) != nullptr) {
+				*L = len;
+				cap = (size_t)stt.st_size / (size_t)(len + 3) + 64 + 1;
+			}
+		} else if (got > 8 && head[0] == '@' && !((unsigned char)head[0] == 0x1f && (unsigned char)head[1] == 0x8b)) {
 			const char *e = head + got;
 			const char *s0 = next_line(head, e);
 			const char *s1 = (const char*)memchr(s0, '\n', (size_t)(e - s0));
@@ -501,7 +545,10 @@ int mcom_fastq_stream_packed(const char *path, int L, int device, void *copy_str
 	struct CloseFd { int f; ~CloseFd() { close(f); } } close_fd{fd};
 	const size_t size = (size_t)stt.st_size;
 	const int len = L, W = (2 * len + 63) / 64, NW = (len + 63) / 64;
-	const size_t minrec = (size_t)(2 * len + 6);
+	char first_byte = 0;
+	if (pread(fd, &first_byte, 1, 0) != 1) return 0;
+	const bool fasta = first_byte == '>';                                         // (mcom_fastq_stream_cap has looked at the first record)
+	const size_t minrec = fasta ? (size_t)(len + 3) : (size_t)(2 * len + 6);
 	const size_t nt = (size_t)parser_threads(size);
 	const size_t row_bytes = (size_t)8 * (W + NW);
 	const size_t CH = std::max<size_t>(1024, ((size_t)1 << 20) / row_bytes);      // rows per staging block: about 1 MB
@@ -568,7 +615,8 @@ int mcom_fastq_stream_packed(const char *path, int L, int device, void *copy_str
 			const char *e = buf.data() + have;
 			const char *p = next_line(buf.data(), e);
 			bool found = false;
-			for (int tries = 0; tries < 8 && p < e; ++tries) { if (record_at(p, e, len)) { found = true; break; } p = next_line(p, e); }
+			bool more = false;
+			for (int tries = 0; tries < (fasta ? len + 8 : 8) && p < e; ++tries) { if (fasta ? fasta_record_at(p, e, len, at_eof, &more) != nullptr : record_at(p, e, len) != nullptr) { found = true; break; } p = next_line(p, e); }
 			if (!found) { if (p < e || !at_eof) { shape = 1; return; } pos = have; }   // no record starts here: only the tail of the one before (or nothing at all) is left
 			else pos = (size_t)(p - buf.data());
 		}
@@ -599,9 +647,10 @@ int mcom_fastq_stream_packed(const char *path, int L, int device, void *copy_str
 			const char *p = buf.data() + pos;
 			if (p >= e) { if (at_eof) break; if (!refill(pos)) { err = MCOM_E_ARG; return; } pos = 0; continue; }
 			if ((size_t)(e - p) < (size_t)(2 * len + SLACK / 2) && !at_eof) { if (!refill(pos)) { err = MCOM_E_ARG; return; } pos = 0; continue; }
-			const char *q = record_at(p, e, len);
-			if (!q) { shape = 1; return; }
-			if (q == e && !at_eof) { if (!refill(pos)) { err = MCOM_E_ARG; return; } pos = 0; continue; }   // (the buffer's end is not the file's: the newline may follow)
+			bool more = false;
+			const char *q = fasta ? fasta_record_at(p, e, len, at_eof, &more) : record_at(p, e, len);
+			if (!q) { shape = 1; return; }                                          // (FASTA with `more`: a name line of kilobytes -- the sequential reader's)
+			if (!fasta && q == e && !at_eof) { if (!refill(pos)) { err = MCOM_E_ARG; return; } pos = 0; continue; }   // (the buffer's end is not the file's: the newline may follow)
 			if (in_blk == 0) {
 				const double t_w = fq_now();
 				tm[3 * t + 1] += t_w - t_p;
@@ -611,6 +660,21 @@ int mcom_fastq_stream_packed(const char *path, int L, int device, void *copy_str
 				ow = (uint64_t*)(arena + (2 * t + cur) * blk_bytes); on = ow + CH * (size_t)W;
 			}
 			const unsigned char *sq = (const unsigned char*)next_line(p, e);
+			unsigned char joined[264];
+			if (fasta) {                                                            // a sequence over several lines: its L characters in a row first
+				const char *c = (const char*)sq;
+				const char *nl = (const char*)memchr(c, '\n', (size_t)(q - c));
+				if ((nl ? nl : q) - c < len) {
+					int got = 0;
+					while (got < len) {
+						nl = (const char*)memchr(c, '\n', (size_t)(q - c));
+						const size_t ll = (size_t)((nl ? nl : q) - c);
+						memcpy(joined + got, c, ll); got += (int)ll;
+						c = nl ? nl + 1 : q;
+					}
+					sq = joined;
+				}
+			}
 			for (int w = 0; w < NW; ++w) on[w] = 0;
 			for (int w = 0; w < W; ++w) ow[w] = 0;
 			for (int i0 = 0; i0 < len; i0 += 8) {                                   // (codes by bit tricks on the ASCII ((c >> 1 ^ c >> 2) & 3: A0 C1 G2 T3, N gives 0), N flags by an exact byte-equals-'N', and the bases spelled back from their codes to refuse anything else)

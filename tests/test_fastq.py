@@ -384,3 +384,46 @@ def test_parallel_parser_of_four_line_fastq_equals_the_sequential_reader(tmp_pat
     p = Pipeline.from_fastq(fq)
     assert p.n == reads.shape[0]
     p.close()
+
+
+def _write_fasta(path, reads, width, last_newline=True):
+    """FASTA with names >r0, >r1 ... and the sequence in lines of `width` characters (0: one line)."""
+    n, L = reads.shape
+    w = width or L
+    parts = []
+    for i in range(n):
+        row = reads[i].tobytes()
+        parts.append(b">r%d some text\n" % i + b"\n".join(row[a:a + w] for a in range(0, L, w)) + b"\n")
+    data = b"".join(parts)
+    with open(path, "wb") as f:
+        f.write(data if last_newline else data[:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,width,last_newline", [(150, 0, True), (150, 60, True), (150, 70, False), (100, 7, True), (40, 1, True), (256, 80, True)])
+def test_parallel_parser_takes_fasta_with_sequences_over_several_lines(tmp_path, L, width, last_newline):
+    """bseq.c:38-66 reads FASTA through kseq.h as it reads FASTQ: a '>' line, then the sequence over any number of lines.  The one-pass packing
+    parser (host/mcom_fastq.cpp) takes that shape too -- every core parses a piece, a sequence over several lines is put in a row first -- and
+    gives the rows of the array the file was written from (the digest of the whole pipeline, and the statistics say that it was the parallel
+    route: the sequential reader does not set t_fastq_upload); the sequential reader reads the same reads.  A '+' line in the file is not FASTA:
+    that file goes to the sequential reader."""
+    from minicom_amd import synth
+    from minicom_amd.pipeline import Pipeline, read_fastq
+    n = 120_000 if width != 1 else 30_000
+    reads = np.concatenate([synth.synth_reads(81, n - 500, L), synth.synth_reads(82, 500, L, plumbing=True)])
+    fa = str(tmp_path / "reads.fa")
+    _write_fasta(fa, reads, width, last_newline)
+    p = Pipeline.from_fastq(fa)
+    assert (p.n, p.L) == reads.shape
+    assert p.stat("t_fastq_upload") > 0                                     # the packing parser, not the sequential reader
+    p.pre_process()
+    q = Pipeline(reads); q.pre_process()
+    assert p.result_digest() == q.result_digest()
+    p.close(); q.close()
+    assert np.array_equal(read_fastq(fa)[::97], reads[::97])
+    if width == 60:
+        data = open(fa, "rb").read()
+        cut = data.index(b"\n>r60000 ") + 1
+        open(fa, "wb").write(data[:cut] + b"@x\nACGT\n+\nIIII\n" + data[cut:])
+        with pytest.raises(Exception):
+            Pipeline.from_fastq(fa)                                        # (a read of another length: the sequential reader's message)
