@@ -1016,7 +1016,10 @@ static int kt_for_bucket_impl(mcomh_pipeline *p)
 				if (!cw_all.reserve(tn + 2) || !clen_all.reserve(tn + 2)) return p->fail(MCOM_E_NOMEM, "contig set");
 				if ((rc = p->gpu(mcom_contig_layout(p->ctx, D.soff.p + D.n, tn, cw_all.p, clen_all.p, &tw2)))) return rc;
 				if (tw2 != tw_all) return p->fail(MCOM_E_ARG, "new contigs: %llu packed words gathered, the layout has %llu", (unsigned long long)tw_all, (unsigned long long)tw2);
-				if ((rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->prepacked_words, cw_all.p, D.soff.p + D.n, (uint32_t)tn, D.chars, D.chars + tc, D.seq.p)))) return rc;
+				// (this rank's own strings are where mcom_groups_to_contigs wrote them: the contigs in front of them and behind them are unpacked)
+				const uint64_t i0 = fn[me] - 1 - D.n, i1 = i0 + cn[me];
+				if (i0 && (rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->prepacked_words, cw_all.p, D.soff.p + D.n, (uint32_t)i0, D.chars, fc[me], D.seq.p)))) return rc;
+				if (tn > i1 && (rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->prepacked_words, cw_all.p + i1, D.soff.p + D.n + i1, (uint32_t)(tn - i1), fc[me] + cc[me], D.chars + tc, D.seq.p)))) return rc;
 				p->prepacked_words += tw_all;
 			}
 			D.n += tn; D.chars += tc; D.members += tm;
@@ -1489,7 +1492,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 			if (kb > 29) return p->fail(MCOM_E_ARG, "contig of %llu bases: member offsets need more than 28 bits", (unsigned long long)maxlen);
 			uint64_t tot[3] = {0, 0, 0};
 			uint64_t tn = 0;                                                             // minimizer records of the merged contigs
-			uint64_t words_gathered = 0; bool words_in_place = false;                    // (several GPUs: the round's packed words arrive with the gather)
+			uint64_t words_gathered = 0, own_chars_at = 0, own_chars = 0; bool words_in_place = false;   // (several GPUs: the round's packed words arrive with the gather)
 			const bool rs = p->resketch && (p->k & 1);
 			if (!p->comm) {
 				for (int attempt = 0;; ++attempt) {
@@ -1594,7 +1597,7 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 					fw[q] = p->total_words + words_gathered; cwq[q] = all[5 * q + 4]; words_gathered += cwq[q];
 				}
 				if (p->d_cbits.cap < p->total_words + words_gathered + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + words_gathered + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
-				words_in_place = true;
+				words_in_place = true; own_chars_at = fc[me]; own_chars = cc[me];
 				maxlen = std::max(maxlen, tot[2]);
 				if (S.nrec + tn >= (1ull << 32)) return p->fail(MCOM_E_ARG, "more than 2^32-1 minimizer records in the store");
 				// offsets of the share move to their places in the store, then everything travels
@@ -1618,8 +1621,14 @@ static int combine_cluster_impl(mcomh_pipeline *p)
 				if (words_in_place && tw2 != words_gathered) return p->fail(MCOM_E_ARG, "merged contigs: %llu packed words gathered, the layout has %llu", (unsigned long long)words_gathered, (unsigned long long)tw2);
 				if (p->d_cbits.cap < p->total_words + tw2 + 2) { if (!p->d_cbits.grow((size_t)(p->total_words + tw2 + 2), (size_t)p->total_words, p->stream)) return p->fail(MCOM_E_NOMEM, "packed store"); p->stat["store_grows"] += 1; }
 				// (several GPUs: the words are there -- they are what travelled -- and the strings are made from them)
-				if ((rc = words_in_place ? p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->total_words, cw_t.p, S.soff.p + n_store, (uint32_t)nj, S.chars, S.chars + tot[1], S.seq.p))
-				                         : pack_words(S.soff.p + n_store, cw_t.p, nj, tw2, p->d_cbits.p + p->total_words)) ||
+				if (words_in_place) {
+					// this rank's own strings are copied from where it built them, the others' are unpacked
+					const size_t j0 = nj * (size_t)p->rank / (size_t)p->world, j1 = nj * (size_t)(p->rank + 1) / (size_t)p->world;
+					if (j1 > j0 && (rc = p->hipc(hipMemcpyAsync(S.seq.p + own_chars_at, Tm.seq.p, own_chars, hipMemcpyDeviceToDevice, p->stream), "copy merged strings"))) return rc;
+					if (j0 && (rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->total_words, cw_t.p, S.soff.p + n_store, (uint32_t)j0, S.chars, own_chars_at, S.seq.p)))) return rc;
+					if (nj > j1 && (rc = p->gpu(mcom_unpack_contigs(p->ctx, p->d_cbits.p + p->total_words, cw_t.p + j1, S.soff.p + n_store + j1, (uint32_t)(nj - j1), own_chars_at + own_chars, S.chars + tot[1], S.seq.p)))) return rc;
+				}
+				if ((rc = words_in_place ? MCOM_OK : pack_words(S.soff.p + n_store, cw_t.p, nj, tw2, p->d_cbits.p + p->total_words)) ||
 				    (rc = p->hipc(hipMemsetAsync(p->d_cbits.p + p->total_words + tw2, 0, 16, p->stream), "clear")) ||
 				    (rc = p->gpu(mcom_offsets_append(p->ctx, cw_t.p, nj, p->total_words, p->d_coff_words.p + n_store)))) return rc;
 				p->total_words += tw2;
